@@ -1,0 +1,394 @@
+// oracle/ref_dump.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Dump / timing driver that LINKS the real reference (paullric/tempestmodel, compiled from
+// /root/reference by oracle/Makefile into oracle/_ref/libtempestref.a) and only *calls* its
+// public classes.  No reference source is copied: the Jablonowski-Williamson test-case class is
+// pulled in by #include of the reference's own translation unit where it lies
+// (test/nonhydro_sphere/BaroclinicWaveJWTest.cpp, its main() renamed away).
+//
+// What it produces (TMXD container, see tests/tmxd.py for the reader):
+//   --mode percall : geometry + operators + the inputs/outputs of each hot-path call
+//                    (H.StepExplicit, V.StepExplicit, ApplyDSS, V.StepImplicit,
+//                     H.StepAfterSubCycle) made one at a time on the reference objects.
+//   --mode steps   : instance-0 state after each of N real TimestepScheme::Step calls
+//                    (+ area-weighted checksums), optionally with geometry.
+//   --mode time    : wall time per step of the real reference (CPU baseline "reference").
+//
+// Call sites mirrored (not copied): Model::Go init sequence (src/atm/Model.cpp:316-356),
+// _TempestSetupCubedSphereModel (src/atm/TempestInitialize.h:476-586).
+
+#define main tmx_unused_jw_main
+#include "BaroclinicWaveJWTest.cpp"
+#undef main
+
+#include "GridPatchGLL.h"
+#include "GridPatchCSGLL.h"
+#include "CubedSphereTrans.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+
+///////////////////////////////////////////////////////////////////////////////
+// TMXD writer
+
+struct TmxdWriter {
+	FILE * fp;
+	TmxdWriter() : fp(NULL) {}
+	void open(const std::string & path) {
+		fp = fopen(path.c_str(), "wb");
+		if (!fp) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+		fwrite("TMXD0001", 1, 8, fp);
+	}
+	void close() { if (fp) fclose(fp); fp = NULL; }
+	void rec(const std::string & name, int dtype, const std::vector<size_t> & dims, const void * data) {
+		if (!fp) return;
+		unsigned int nl = name.size();
+		fwrite(&nl, 4, 1, fp);
+		fwrite(name.data(), 1, nl, fp);
+		unsigned int dt = dtype, nd = dims.size();
+		fwrite(&dt, 4, 1, fp);
+		fwrite(&nd, 4, 1, fp);
+		size_t tot = 1;
+		for (size_t d = 0; d < dims.size(); d++) {
+			unsigned long long v = dims[d];
+			fwrite(&v, 8, 1, fp);
+			tot *= dims[d];
+		}
+		fwrite(data, (dtype == 0) ? 8 : 4, tot, fp);
+	}
+	void f64(const std::string & name, const std::vector<size_t> & dims, const double * p) { rec(name, 0, dims, p); }
+	void i32(const std::string & name, const std::vector<size_t> & dims, const int * p) { rec(name, 1, dims, p); }
+	void scalar(const std::string & name, double v) { std::vector<size_t> d; d.push_back(1); f64(name, d, &v); }
+	void iscalar(const std::string & name, int v) { std::vector<size_t> d; d.push_back(1); i32(name, d, &v); }
+};
+
+static std::vector<size_t> D1(size_t a) { std::vector<size_t> d; d.push_back(a); return d; }
+static std::vector<size_t> D2(size_t a, size_t b) { std::vector<size_t> d = D1(a); d.push_back(b); return d; }
+static std::vector<size_t> D3(size_t a, size_t b, size_t c) { std::vector<size_t> d = D2(a,b); d.push_back(c); return d; }
+static std::vector<size_t> D4(size_t a, size_t b, size_t c, size_t e) { std::vector<size_t> d = D3(a,b,c); d.push_back(e); return d; }
+
+static void dump2(TmxdWriter & w, const std::string & n, const DataArray2D<double> & a) {
+	w.f64(n, D2(a.GetRows(), a.GetColumns()), &(a[0][0]));
+}
+static void dump3(TmxdWriter & w, const std::string & n, const DataArray3D<double> & a) {
+	w.f64(n, D3(a.GetSize(0), a.GetSize(1), a.GetSize(2)), &(a[0][0][0]));
+}
+static void dump4(TmxdWriter & w, const std::string & n, const DataArray4D<double> & a) {
+	w.f64(n, D4(a.GetSize(0), a.GetSize(1), a.GetSize(2), a.GetSize(3)), &(a[0][0][0][0]));
+}
+
+static void dumpOp(TmxdWriter & w, const std::string & n, const LinearColumnOperator & op) {
+	const DataArray2D<double> & c = op.GetCoeffs();
+	dump2(w, "op/" + n + "/coeff", c);
+	std::vector<int> b(c.GetRows()), e(c.GetRows());
+	for (size_t k = 0; k < c.GetRows(); k++) { b[k] = op.GetIxBegin()[k]; e[k] = op.GetIxEnd()[k]; }
+	w.i32("op/" + n + "/begin", D1(b.size()), &b[0]);
+	w.i32("op/" + n + "/end", D1(e.size()), &e[0]);
+}
+
+static std::string pname(int p) { char b[32]; snprintf(b, 32, "p%d/", p); return std::string(b); }
+
+///////////////////////////////////////////////////////////////////////////////
+
+static void dumpState(TmxdWriter & w, GridGLL * pGrid, const std::string & tag, int ix) {
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		GridPatch * pPatch = pGrid->GetActivePatch(n);
+		int p = pPatch->GetPatchIndex();
+		dump4(w, "state/" + tag + "/" + pname(p) + "node", pPatch->GetDataState(ix, DataLocation_Node));
+		dump4(w, "state/" + tag + "/" + pname(p) + "redge", pPatch->GetDataState(ix, DataLocation_REdge));
+	}
+}
+
+static void dumpGeometry(TmxdWriter & w, Model & model, GridGLL * pGrid) {
+	const PhysicalConstants & phys = model.GetPhysicalConstants();
+	w.scalar("phys/earth_radius", phys.GetEarthRadius());
+	w.scalar("phys/g", phys.GetG());
+	w.scalar("phys/omega", phys.GetOmega());
+	w.scalar("phys/alpha", phys.GetAlpha());
+	w.scalar("phys/Rd", phys.GetR());
+	w.scalar("phys/cp", phys.GetCp());
+	w.scalar("phys/cv", phys.GetCv());
+	w.scalar("phys/p0", phys.GetP0());
+	w.scalar("grid/ztop", pGrid->GetZtop());
+	w.scalar("grid/reference_length", pGrid->GetReferenceLength());
+	w.iscalar("grid/has_rayleigh", pGrid->HasRayleighFriction() ? 1 : 0);
+	w.iscalar("grid/has_uniform_diffusion", pGrid->HasUniformDiffusion() ? 1 : 0);
+
+	int L = pGrid->GetRElements();
+	w.f64("grid/reta_levels", D1(L), &(pGrid->GetREtaLevels()[0]));
+	w.f64("grid/reta_interfaces", D1(L+1), &(pGrid->GetREtaInterfaces()[0]));
+	w.f64("grid/reta_levels_normarea", D1(L), &(pGrid->GetREtaLevelsNormArea()[0]));
+	w.f64("grid/reta_interfaces_normarea", D1(L+1), &(pGrid->GetREtaInterfacesNormArea()[0]));
+
+	dump2(w, "op/dx_basis_1d", pGrid->GetDxBasis1D());
+	dump2(w, "op/stiffness_1d", pGrid->GetStiffness1D());
+	w.f64("op/gll_weights_1d", D1(pGrid->GetGLLWeights1D().GetRows()), &(pGrid->GetGLLWeights1D()[0]));
+
+	dumpOp(w, "interp_node_to_redge", pGrid->GetOpInterpNodeToREdge());
+	dumpOp(w, "interp_redge_to_node", pGrid->GetOpInterpREdgeToNode());
+	dumpOp(w, "diff_node_to_node", pGrid->GetOpDiffNodeToNode());
+	dumpOp(w, "diff_node_to_redge", pGrid->GetOpDiffNodeToREdge());
+	dumpOp(w, "diff_redge_to_node", pGrid->GetOpDiffREdgeToNode());
+	dumpOp(w, "diff_redge_to_redge", pGrid->GetOpDiffREdgeToREdge());
+	dumpOp(w, "diffdiff_node_to_node", pGrid->GetOpDiffDiffNodeToNode());
+	dumpOp(w, "diffdiff_redge_to_redge", pGrid->GetOpDiffDiffREdgeToREdge());
+	dumpOp(w, "penalty_left", pGrid->GetOpPenaltyNodeToNode().GetLeftOp());
+	dumpOp(w, "penalty_right", pGrid->GetOpPenaltyNodeToNode().GetRightOp());
+
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		GridPatchGLL * pPatch = dynamic_cast<GridPatchGLL*>(pGrid->GetActivePatch(n));
+		const PatchBox & box = pPatch->GetPatchBox();
+		int p = pPatch->GetPatchIndex();
+		std::string pn = pname(p);
+		int ibox[8] = {
+			box.GetPanel(), box.GetHaloElements(),
+			box.GetAGlobalInteriorBegin(), box.GetAGlobalInteriorEnd(),
+			box.GetBGlobalInteriorBegin(), box.GetBGlobalInteriorEnd(),
+			box.GetATotalWidth(), box.GetBTotalWidth()};
+		w.i32(pn + "box", D1(8), ibox);
+		int inb[8];
+		for (int d = 0; d < 8; d++) inb[d] = pPatch->GetNeighborPanel((Direction)d);
+		w.i32(pn + "neighbor_panels", D1(8), inb);
+		w.scalar(pn + "element_delta_a", pPatch->GetElementDeltaA());
+		w.f64(pn + "a_nodes", D1(pPatch->GetANodes().GetRows()), &(pPatch->GetANodes()[0]));
+		w.f64(pn + "b_nodes", D1(pPatch->GetBNodes().GetRows()), &(pPatch->GetBNodes()[0]));
+		dump2(w, pn + "lon", pPatch->GetLongitude());
+		dump2(w, pn + "lat", pPatch->GetLatitude());
+		dump2(w, pn + "jacobian2d", pPatch->GetJacobian2D());
+		dump3(w, pn + "contra_metric_2d_a", pPatch->GetContraMetric2DA());
+		dump3(w, pn + "contra_metric_2d_b", pPatch->GetContraMetric2DB());
+		dump3(w, pn + "jacobian", pPatch->GetJacobian());
+		dump3(w, pn + "jacobian_redge", pPatch->GetJacobianREdge());
+		dump4(w, pn + "contra_metric_a", pPatch->GetContraMetricA());
+		dump4(w, pn + "contra_metric_b", pPatch->GetContraMetricB());
+		dump4(w, pn + "contra_metric_xi", pPatch->GetContraMetricXi());
+		dump4(w, pn + "contra_metric_a_redge", pPatch->GetContraMetricAREdge());
+		dump4(w, pn + "contra_metric_b_redge", pPatch->GetContraMetricBREdge());
+		dump4(w, pn + "contra_metric_xi_redge", pPatch->GetContraMetricXiREdge());
+		dump4(w, pn + "deriv_r_node", pPatch->GetDerivRNode());
+		dump4(w, pn + "deriv_r_redge", pPatch->GetDerivRREdge());
+		dump3(w, pn + "element_area_node", pPatch->GetElementAreaNode());
+		dump3(w, pn + "element_area_redge", pPatch->GetElementAreaREdge());
+		dump2(w, pn + "topography", pPatch->GetTopography());
+		dump3(w, pn + "topography_deriv", pPatch->GetTopographyDeriv());
+		dump2(w, pn + "coriolis_f", pPatch->GetCoriolisF());
+		dump3(w, pn + "z_levels", pPatch->GetZLevels());
+		dump3(w, pn + "z_interfaces", pPatch->GetZInterfaces());
+		dump4(w, pn + "ref_node", pPatch->GetReferenceState(DataLocation_Node));
+		dump4(w, pn + "ref_redge", pPatch->GetReferenceState(DataLocation_REdge));
+	}
+}
+
+// Probe the reference's covector panel transform with unit vectors at every halo node of every
+// patch edge that borders a different panel (same call TransformHaloVelocities makes,
+// GridPatchCSGLL.cpp:1783-1924) and record the 2x2 matrices.
+static void dumpHaloTransforms(TmxdWriter & w, GridGLL * pGrid) {
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		GridPatchGLL * pPatch = dynamic_cast<GridPatchGLL*>(pGrid->GetActivePatch(n));
+		const PatchBox & box = pPatch->GetPatchBox();
+		int p = pPatch->GetPatchIndex();
+		const DataArray1D<double> & dA = pPatch->GetANodes();
+		const DataArray1D<double> & dB = pPatch->GetBNodes();
+		// edges: 0=right,1=top,2=left,3=bottom (Direction enum order)
+		for (int e = 0; e < 4; e++) {
+			int ixPanel = pPatch->GetNeighborPanel((Direction)e);
+			if (ixPanel == box.GetPanel()) continue;
+			bool alongB = (e == 0) || (e == 2);
+			int nAlong = alongB ? box.GetBTotalWidth() : box.GetATotalWidth();
+			int fixed;
+			if (e == 0) fixed = box.GetAInteriorEnd();
+			else if (e == 1) fixed = box.GetBInteriorEnd();
+			else if (e == 2) fixed = box.GetAInteriorBegin() - 1;
+			else fixed = box.GetBInteriorBegin() - 1;
+			std::vector<double> m(nAlong * 4);
+			for (int s = 0; s < nAlong; s++) {
+				int i = alongB ? fixed : s;
+				int j = alongB ? s : fixed;
+				double X = tan(dA[i]), Y = tan(dB[j]);
+				double a0 = 1.0, b0 = 0.0, a1 = 0.0, b1 = 1.0;
+				CubedSphereTrans::CoVecPanelTrans(ixPanel, box.GetPanel(), a0, b0, X, Y);
+				CubedSphereTrans::CoVecPanelTrans(ixPanel, box.GetPanel(), a1, b1, X, Y);
+				// out = M * in, column 0 = image of (1,0), column 1 = image of (0,1)
+				m[4*s+0] = a0; m[4*s+1] = a1; m[4*s+2] = b0; m[4*s+3] = b1;
+			}
+			char nm[64]; snprintf(nm, 64, "halo_trans/p%d/e%d", p, e);
+			w.f64(nm, D3(nAlong, 2, 2), &m[0]);
+			snprintf(nm, 64, "halo_trans/p%d/e%d_srcpanel", p, e);
+			w.iscalar(nm, ixPanel);
+		}
+	}
+}
+
+static void printChecksums(Grid * pGrid, const char * tag, TmxdWriter * w) {
+	DataArray1D<double> dSums;
+	pGrid->Checksum(DataType_State, dSums, 0, ChecksumType_Sum);
+	printf("checksum %s", tag);
+	for (size_t c = 0; c < dSums.GetRows(); c++) printf(" %.15e", dSums[c]);
+	printf("\n");
+	if (w && w->fp) w->f64(std::string("checksum/") + tag, D1(dSums.GetRows()), &dSums[0]);
+}
+
+///////////////////////////////////////////////////////////////////////////////
+
+int main(int argc, char ** argv) {
+	TempestInitialize(&argc, &argv);
+
+	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp";
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1;
+	double dt = 200.0, ztop = 30000.0;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		const char * v = (i + 1 < argc) ? argv[i+1] : "";
+		if (a == "--mode") { mode = v; i++; }
+		else if (a == "--out") { out = v; i++; }
+		else if (a == "--scheme") { scheme = v; i++; }
+		else if (a == "--pert") { pert = v; i++; }
+		else if (a == "--ne") { ne = atoi(v); i++; }
+		else if (a == "--levels") { levels = atoi(v); i++; }
+		else if (a == "--steps") { nsteps = atoi(v); i++; }
+		else if (a == "--warm") { nwarm = atoi(v); i++; }
+		else if (a == "--patches") { npatch = atoi(v); i++; }
+		else if (a == "--geom") { geom = atoi(v); i++; }
+		else if (a == "--every") { every = atoi(v); i++; }
+		else if (a == "--dt") { dt = atof(v); i++; }
+		else if (a == "--ztop") { ztop = atof(v); i++; }
+		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
+	}
+
+try {
+	AnnounceSetVerbosityLevel(0);
+
+	Model model(EquationSet::PrimitiveNonhydrostaticEquations);
+
+	int isec = (int)dt;
+	int iusec = (int)((dt - isec) * 1.0e6 + 0.5);
+	Time timeDeltaT(0, 0, 0, isec, iusec, Time::CalendarNoLeap, Time::TypeDelta);
+	// End time == start time: Model::Go() then performs exactly its initialisation sequence
+	// (Model.cpp:343-366) and returns before the time loop; steps are driven from here.
+	model.SetDeltaT(timeDeltaT);
+	model.SetEndTime(model.GetStartTime());
+
+	// Method of lines (defaults of TempestInitialize.h:112-144)
+	if (scheme == "ars343") model.SetTimestepScheme(new TimestepSchemeARS343(model));
+	else if (scheme == "ars232") model.SetTimestepScheme(new TimestepSchemeARS232(model));
+	else if (scheme == "ark232") model.SetTimestepScheme(new TimestepSchemeARK232(model));
+	else if (scheme == "ars222") model.SetTimestepScheme(new TimestepSchemeARS222(model));
+	else if (scheme == "ars443") model.SetTimestepScheme(new TimestepSchemeARS443(model));
+	else if (scheme == "strang") model.SetTimestepScheme(new TimestepSchemeStrang(model));
+	else { fprintf(stderr, "bad scheme\n"); return 2; }
+
+	HorizontalDynamicsFEM * pH = new HorizontalDynamicsFEM(model, 4, 4, 1.0e15, 1.0e15, 1.0e15, 0.0);
+	model.SetHorizontalDynamics(pH);
+	VerticalDynamicsFEM * pV = new VerticalDynamicsFEM(model, 4, 1, 0, false, true, false);
+	model.SetVerticalDynamics(pV);
+
+	GridCSGLL * pGrid = new GridCSGLL(model);
+	pGrid->DefineParameters();
+	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, 1,
+		Grid::VerticalDiscretization_FiniteElement, Grid::VerticalStaggering_Lorenz);
+	pGrid->InitializeDataLocal();
+	model.SetGrid(pGrid, npatch);
+
+	BaroclinicWaveJWTest::PerturbationType ePert =
+		(pert == "exp") ? BaroclinicWaveJWTest::PerturbationType_Exp
+		                : BaroclinicWaveJWTest::PerturbationType_None;
+	model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, ePert));
+
+	// Model::Go init sequence (EvaluateGeometricTerms, component Initialize)
+	model.Go();
+
+	TmxdWriter w;
+	if (out != "") w.open(out);
+	w.iscalar("cfg/ne", ne);
+	w.iscalar("cfg/np", 4);
+	w.iscalar("cfg/levels", levels);
+	w.iscalar("cfg/npatch", pGrid->GetActivePatchCount());
+	w.iscalar("cfg/ninstances", model.GetComponentDataInstances());
+	w.scalar("cfg/dt", dt);
+	if (geom && w.fp) {
+		dumpGeometry(w, model, pGrid);
+		dumpHaloTransforms(w, pGrid);
+	}
+
+	Time time = model.GetStartTime();
+	TimestepScheme * pTS = model.GetTimestepScheme();
+
+	printChecksums(pGrid, "initial", &w);
+	dumpState(w, pGrid, "initial", 0);
+
+	// optional real warm-up steps (gives W != 0)
+	for (int s = 0; s < nwarm; s++) {
+		pTS->Step(s == 0, false, time, dt);
+		time += timeDeltaT;
+	}
+	if (nwarm > 0) {
+		printChecksums(pGrid, "warm", &w);
+		dumpState(w, pGrid, "warm", 0);
+	}
+
+	if (mode == "percall") {
+		const double sdt = dt * 0.4358665215084590;
+		// H explicit
+		pGrid->CopyData(0, 1, DataType_State);
+		pH->StepExplicit(0, 1, time, sdt);
+		dumpState(w, pGrid, "h_explicit_in_after", 0);   // input instance after the prologue mutation
+		dumpState(w, pGrid, "h_explicit", 1);
+		// V explicit (continues on the same update instance, as the stepper does)
+		pV->StepExplicit(0, 1, time, sdt);
+		dumpState(w, pGrid, "v_explicit", 1);
+		// DSS
+		pGrid->PostProcessSubstage(1, DataType_State);
+		dumpState(w, pGrid, "dss", 1);
+		// V implicit
+		pGrid->CopyData(1, 2, DataType_State);
+		pV->StepImplicit(2, 2, time, sdt);
+		dumpState(w, pGrid, "v_implicit", 2);
+		// hyperviscosity (init 2 -> update 3, work 4)
+		pH->StepAfterSubCycle(2, 3, 4, time, dt);
+		dumpState(w, pGrid, "hypervis_work", 4);
+		dumpState(w, pGrid, "hypervis", 3);
+		// stage algebra: X5 <- 0.3*X5(=0) ... use explicit combo on instances 0..3
+		DataArray1D<double> dCombo(7);
+		dCombo[0] = 0.25; dCombo[1] = -0.5; dCombo[2] = 1.75; dCombo[3] = 0.5;
+		pGrid->LinearCombineData(dCombo, 3, DataType_State);
+		dumpState(w, pGrid, "lincomb", 3);
+
+	} else if (mode == "steps") {
+		for (int s = 0; s < nsteps; s++) {
+			pTS->Step((s == 0) && (nwarm == 0), false, time, dt);
+			time += timeDeltaT;
+			if (((s + 1) % every == 0) || (s == nsteps - 1)) {
+				char tag[32]; snprintf(tag, 32, "step%d", s + 1);
+				printChecksums(pGrid, tag, &w);
+				dumpState(w, pGrid, tag, 0);
+			}
+		}
+
+	} else if (mode == "time") {
+		std::vector<double> t;
+		for (int s = 0; s < nsteps; s++) {
+			auto t0 = std::chrono::steady_clock::now();
+			pTS->Step((s == 0) && (nwarm == 0), false, time, dt);
+			auto t1 = std::chrono::steady_clock::now();
+			time += timeDeltaT;
+			t.push_back(std::chrono::duration<double>(t1 - t0).count());
+		}
+		double tmin = 1e30, tsum = 0;
+		for (size_t i = 0; i < t.size(); i++) { tsum += t[i]; if (t[i] < tmin) tmin = t[i]; }
+		printf("timing steps=%d mean_s=%.6f min_s=%.6f\n", nsteps, tsum / t.size(), tmin);
+		printChecksums(pGrid, "final", &w);
+	}
+
+	w.close();
+
+} catch (Exception & e) {
+	std::cout << e.ToString() << std::endl;
+	TempestDeinitialize();
+	return 1;
+}
+	TempestDeinitialize();
+	return 0;
+}
