@@ -1,0 +1,939 @@
+/* oracle/tmx_oracle.c -- TEST INFRASTRUCTURE ONLY (see tmx_oracle.h).
+ *
+ * CPU restatement, in plain C and in the reference's own data layout, of the hot path of
+ * paullric/tempestmodel for its default configuration (FORMULATION_RHOTHETA_PI,
+ * USE_DIRECTSOLVE + USE_JACOBIAN_DIAGONAL, Lorenz staggering, FE vertical order 1, upwinding on
+ * all variables, Clark-form implicit W advection, 4th-order hyperviscosity; src/atm/Defines.h:23-80,
+ * src/atm/VerticalDynamicsFEM.cpp:33-47).  Each function cites the reference lines it follows.
+ * No reference source text is reproduced; loops are restated over flat arrays.
+ */
+#include "tmx_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { UIx = 0, VIx = 1, PIx = 2, WIx = 3, RIx = 4 };
+
+#define NP 4
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers                                                                                    */
+
+static size_t node_size(const orc_grid * g, const orc_patch * p) { return (size_t)5 * p->na * p->nb * g->L; }
+static size_t redge_size(const orc_grid * g, const orc_patch * p) { return (size_t)5 * p->na * p->nb * (g->L + 1); }
+
+/* banded mat-vec row: out[k] = sum_{l in [b,e)} C[k][l] in[l]  (LinearColumnOperator.h:82-101) */
+static double op_row(const orc_grid * g, int op, const double * in, int k) {
+	const int nin = g->opnin[op];
+	const double * c = g->opc[op] + (size_t)k * nin;
+	double out = 0.0;
+	for (int l = g->opb[op][k]; l < g->ope[op][k]; l++) out += c[l] * in[l];
+	return out;
+}
+
+static void op_apply(const orc_grid * g, int op, const double * in, double * out) {
+	for (int k = 0; k < g->opnout[op]; k++) out[k] = op_row(g, op, in, k);
+}
+
+/* Exner pressure from rho*theta (PhysicalConstants.h:397-399) */
+static double exner_from_rhotheta(const orc_grid * g, double rt) {
+	return g->cp * exp(g->Rd / (g->cp - g->Rd) * log(g->Rd / g->p0 * rt));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* stage algebra: Grid::CopyData / ZeroData / LinearCombineData  (GridPatch.cpp:1402-1553)    */
+
+void orc_copy(const orc_grid * g, orc_state * s, int src, int dst) {
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		memcpy(s->node[dst * g->npatch + p], s->node[src * g->npatch + p], node_size(g, P) * sizeof(double));
+		memcpy(s->redge[dst * g->npatch + p], s->redge[src * g->npatch + p], redge_size(g, P) * sizeof(double));
+	}
+}
+
+void orc_zero(const orc_grid * g, orc_state * s, int ix) {
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		memset(s->node[ix * g->npatch + p], 0, node_size(g, P) * sizeof(double));
+		memset(s->redge[ix * g->npatch + p], 0, redge_size(g, P) * sizeof(double));
+	}
+}
+
+void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff, int ncoeff, int dst) {
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		for (int loc = 0; loc < 2; loc++) {
+			size_t n = loc ? redge_size(g, P) : node_size(g, P);
+			double * d = loc ? s->redge[dst * g->npatch + p] : s->node[dst * g->npatch + p];
+			/* premultiply the destination by its own coefficient (GridPatch.cpp:1461-1468) */
+			if (coeff[dst] == 0.0) memset(d, 0, n * sizeof(double));
+			else for (size_t i = 0; i < n; i++) d[i] *= coeff[dst];
+			for (int m = 0; m < ncoeff; m++) {
+				if (m == dst || coeff[m] == 0.0) continue;
+				const double * a = loc ? s->redge[m * g->npatch + p] : s->node[m * g->npatch + p];
+				const double c = coeff[m];
+				for (size_t i = 0; i < n; i++) d[i] += c * a[i];
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* H explicit: HorizontalDynamicsFEM::StepNonhydrostaticPrimitive                              */
+/* (HorizontalDynamicsFEM.cpp:701-1783)                                                        */
+
+void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = g->L;
+	const double inv_da = 1.0 / g->delta_a;
+	const double * D = g->dx;      /* D[s*4+i]  = dDxBasis1D(s,i)   */
+	const double * S = g->stiff;   /* S[i*4+s]  = dStiffness1D(i,s) */
+
+	double * aux = (double *)malloc(sizeof(double) * 9 * NP * NP * L);
+	double * fa_r = (double *)malloc(sizeof(double) * 4 * NP * NP * L);
+	double * colbuf = (double *)malloc(sizeof(double) * (L + 1));
+#define AUX(c,i,j,k) aux[(((size_t)(c) * NP + (i)) * NP + (j)) * L + (k)]
+#define FLX(c,i,j,k) fa_r[(((size_t)(c) * NP + (i)) * NP + (j)) * L + (k)]
+	enum { ConUa = 0, ConUb, ConUx, CovUx, KE, UCZA, UCZB, UCZX, EXN };
+	enum { FAR = 0, FBR, FAP, FBP };
+
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * nin = s->node[iinit * g->npatch + p];
+		double * ein = s->redge[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		double * eup = s->redge[iupd * g->npatch + p];
+#define NI(c,i,j,k) nin[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+#define EI(c,i,j,k) ein[(((size_t)(c) * na + (i)) * nb + (j)) * (L + 1) + (k)]
+#define NU(c,i,j,k) nup[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+#define EU(c,i,j,k) eup[(((size_t)(c) * na + (i)) * nb + (j)) * (L + 1) + (k)]
+		const double * J2 = P->g[ORC_G_JAC2D];
+		const double * Jn = P->g[ORC_G_JAC];
+		const double * CA = P->g[ORC_G_CMA];
+		const double * CB = P->g[ORC_G_CMB];
+		const double * CX = P->g[ORC_G_CMXI];
+		const double * CXe = P->g[ORC_G_CMXI_E];
+		const double * DR = P->g[ORC_G_DR_N];
+		const double * F = P->g[ORC_G_CORIOLIS];
+#define M3(A,i,j,k) A[((size_t)(i) * nb + (j)) * L + (k)]
+#define M4(A,i,j,k,c) A[(((size_t)(i) * nb + (j)) * L + (k)) * 3 + (c)]
+#define M4E(A,i,j,k,c) A[(((size_t)(i) * nb + (j)) * (L + 1) + (k)) * 3 + (c)]
+
+		/* prologue: W edge->node, U,V node->edge on the INPUT instance, interior nodes only
+		 * (HorizontalDynamicsFEM.cpp:817-831, GridPatchGLL.cpp:80-143) */
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++) {
+			op_apply(g, ORC_OP_INTERP_E2N, &EI(WIx, i, j, 0), &NI(WIx, i, j, 0));
+			op_apply(g, ORC_OP_INTERP_N2E, &NI(UIx, i, j, 0), &EI(UIx, i, j, 0));
+			op_apply(g, ORC_OP_INTERP_N2E, &NI(VIx, i, j, 0), &EI(VIx, i, j, 0));
+		}
+
+		for (int a = 0; a < P->nea; a++)
+		for (int b = 0; b < P->neb; b++) {
+			const int eA = a * NP + 1, eB = b * NP + 1;
+
+			/* (i) contravariant velocities, kinetic energy, Exner pressure (:876-963) */
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++)
+			for (int k = 0; k < L; k++) {
+				const int iA = eA + i, iB = eB + j;
+				const double ua = NI(UIx, iA, iB, k), ub = NI(VIx, iA, iB, k), ux = NI(WIx, iA, iB, k);
+				const double m0 = M4(CA, iA, iB, k, 0), m1 = M4(CA, iA, iB, k, 1), m2 = M4(CA, iA, iB, k, 2);
+				const double m3 = M4(CB, iA, iB, k, 1), m4 = M4(CB, iA, iB, k, 2), m5 = M4(CX, iA, iB, k, 2);
+				AUX(CovUx, i, j, k) = ux;
+				AUX(ConUa, i, j, k) = m0 * ua + m1 * ub + m2 * ux;
+				AUX(ConUb, i, j, k) = m1 * ua + m3 * ub + m4 * ux;
+				AUX(ConUx, i, j, k) = m2 * ua + m4 * ub + m5 * ux;
+				AUX(KE, i, j, k) = 0.5 * (AUX(ConUa, i, j, k) * ua + AUX(ConUb, i, j, k) * ub + AUX(ConUx, i, j, k) * ux);
+				AUX(EXN, i, j, k) = exner_from_rhotheta(g, NI(PIx, iA, iB, k));
+			}
+
+			/* (ii) u x zeta (:966-1039) */
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++)
+			for (int k = 0; k < L; k++) {
+				const int iA = eA + i, iB = eB + j;
+				const double dxua = op_row(g, ORC_OP_DIFF_N2N, &NI(UIx, iA, iB, 0), k);
+				const double dxub = op_row(g, ORC_OP_DIFF_N2N, &NI(VIx, iA, iB, 0), k);
+				double daub = 0.0, daux = 0.0, dbua = 0.0, dbux = 0.0;
+				for (int q = 0; q < NP; q++) {
+					daub += NI(VIx, eA + q, iB, k) * D[q * NP + i];
+					daux += AUX(CovUx, q, j, k) * D[q * NP + i];
+					dbua += NI(UIx, iA, eB + q, k) * D[q * NP + j];
+					dbux += AUX(CovUx, i, q, k) * D[q * NP + j];
+				}
+				daub *= inv_da; daux *= inv_da; dbua *= inv_da; dbux *= inv_da;
+				const double cua = AUX(ConUa, i, j, k), cub = AUX(ConUb, i, j, k), cux = AUX(ConUx, i, j, k);
+				const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
+				AUX(UCZA, i, j, k) = cub * jzx - cux * jzb;
+				AUX(UCZB, i, j, k) = cux * jza - cua * jzx;
+				AUX(UCZX, i, j, k) = -cua * daux - cub * dbux;
+			}
+
+			/* (iii) fluxes (:1042-1100) */
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++)
+			for (int k = 0; k < L; k++) {
+				const int iA = eA + i, iB = eB + j;
+				const double fa = M3(Jn, iA, iB, k) * AUX(ConUa, i, j, k);
+				const double fb = M3(Jn, iA, iB, k) * AUX(ConUb, i, j, k);
+				FLX(FAR, i, j, k) = fa * NI(RIx, iA, iB, k);
+				FLX(FBR, i, j, k) = fb * NI(RIx, iA, iB, k);
+				FLX(FAP, i, j, k) = fa * NI(PIx, iA, iB, k);
+				FLX(FBP, i, j, k) = fb * NI(PIx, iA, iB, k);
+			}
+
+			/* (iv) pointwise update on levels (:1183-1421) */
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++)
+			for (int k = 0; k < L; k++) {
+				const int iA = eA + i, iB = eB + j;
+				const double invJ = 1.0 / M3(Jn, iA, iB, k);
+				const double cua = AUX(ConUa, i, j, k), cub = AUX(ConUb, i, j, k);
+				double dake = 0, dbke = 0, dap = 0, dbp = 0, darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+				for (int q = 0; q < NP; q++) {
+					darf -= FLX(FAR, q, j, k) * S[i * NP + q];
+					dapf -= FLX(FAP, q, j, k) * S[i * NP + q];
+					dap += AUX(EXN, q, j, k) * D[q * NP + i];
+					dake += AUX(KE, q, j, k) * D[q * NP + i];
+				}
+				for (int q = 0; q < NP; q++) {
+					dbrf -= FLX(FBR, i, q, k) * S[j * NP + q];
+					dbpf -= FLX(FBP, i, q, k) * S[j * NP + q];
+					dbp += AUX(EXN, i, q, k) * D[q * NP + j];
+					dbke += AUX(KE, i, q, k) * D[q * NP + j];
+				}
+				darf *= inv_da; dbrf *= inv_da; dapf *= inv_da; dbpf *= inv_da;
+				dap *= inv_da; dbp *= inv_da; dake *= inv_da; dbke *= inv_da;
+				double upa = 0.0, upb = 0.0;
+				upa += AUX(UCZA, i, j, k);
+				upb += AUX(UCZB, i, j, k);
+				upa += F[iA * nb + iB] * J2[iA * nb + iB] * cub;
+				upb -= F[iA * nb + iB] * J2[iA * nb + iB] * cua;
+				const double pgfa = dap * NI(PIx, iA, iB, k) / NI(RIx, iA, iB, k);
+				const double pgfb = dbp * NI(PIx, iA, iB, k) / NI(RIx, iA, iB, k);
+				const double daphi = g->grav * M4(DR, iA, iB, k, 0);
+				const double dbphi = g->grav * M4(DR, iA, iB, k, 1);
+				upa -= (pgfa + dake + daphi);
+				upb -= (pgfb + dbke + dbphi);
+				NU(UIx, iA, iB, k) += dt * upa;
+				NU(VIx, iA, iB, k) += dt * upb;
+				NU(RIx, iA, iB, k) -= dt * invJ * (darf + dbrf);
+				NU(PIx, iA, iB, k) -= dt * invJ * (dapf + dbpf);
+			}
+
+			/* (v) W on interfaces (:1612-1659) */
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				const double u0 = op_row(g, ORC_OP_INTERP_N2E, &NU(UIx, iA, iB, 0), 0);
+				const double v0 = op_row(g, ORC_OP_INTERP_N2E, &NU(VIx, iA, iB, 0), 0);
+				EU(WIx, iA, iB, 0) = -(M4E(CXe, iA, iB, 0, 0) * u0 + M4E(CXe, iA, iB, 0, 1) * v0) / M4E(CXe, iA, iB, 0, 2);
+				for (int k = 0; k < L; k++) colbuf[k] = AUX(UCZX, i, j, k);
+				for (int k = 1; k < L; k++) {
+					EU(WIx, iA, iB, k) += dt * op_row(g, ORC_OP_INTERP_N2E, colbuf, k);
+				}
+			}
+		}
+	}
+	free(aux); free(fa_r); free(colbuf);
+#undef AUX
+#undef FLX
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* V explicit (implicit mode): VerticalDynamicsFEM::StepExplicit                               */
+/* (VerticalDynamicsFEM.cpp:616-1159; active parts :816-828, :984-1023)                        */
+
+static void penalty_apply(const orc_grid * g, const double * w, const double * in, double * out, double * buf) {
+	/* LinearColumnDiscPenaltyFEM::Apply at vertical order 1 (LinearColumnOperatorFEM.cpp:1863-1888) */
+	const int L = g->L;
+	op_apply(g, ORC_OP_PENALTY_L, in, buf);
+	for (int a = 0; a < L - 1; a++) out[a] += buf[a] * w[a];
+	op_apply(g, ORC_OP_PENALTY_R, in, buf);
+	for (int a = 1; a < L; a++) out[a] += buf[a] * w[a - 1];
+}
+
+void orc_v_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = g->L;
+	double * xidot = (double *)malloc(sizeof(double) * (L + 1));
+	double * w = (double *)malloc(sizeof(double) * (L + 1));
+	double * buf = (double *)malloc(sizeof(double) * (L + 1));
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * nin = s->node[iinit * g->npatch + p];
+		double * ein = s->redge[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		const double * CXe = P->g[ORC_G_CMXI_E];
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++) {
+			for (int k = 0; k <= L; k++) {
+				xidot[k] = M4E(CXe, i, j, k, 0) * EI(UIx, i, j, k)
+				         + M4E(CXe, i, j, k, 1) * EI(VIx, i, j, k)
+				         + M4E(CXe, i, j, k, 2) * EI(WIx, i, j, k);
+			}
+			xidot[0] = 0.0; xidot[L] = 0.0;
+			for (int a = 0; a < L - 1; a++) w[a] = dt * fabs(xidot[a + 1]);
+			penalty_apply(g, w, &NI(UIx, i, j, 0), &NU(UIx, i, j, 0), buf);
+			penalty_apply(g, w, &NI(VIx, i, j, 0), &NU(VIx, i, j, 0), buf);
+		}
+	}
+	free(xidot); free(w); free(buf);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DSS: Grid::Exchange + TransformHaloVelocities + GridCSGLL::ApplyDSS (State)                 */
+/* (Grid.cpp:627-685, GridPatchCSGLL.cpp:1783-1924, GridCSGLL.cpp:435-781)                    */
+
+static void avg_a(double * x, int nb, int Lk, int iA, int jb, int je) {
+	for (int j = jb; j < je; j++)
+	for (int k = 0; k < Lk; k++) {
+		double * hi = &x[((size_t)iA * nb + j) * Lk + k];
+		double * lo = &x[((size_t)(iA - 1) * nb + j) * Lk + k];
+		*hi = 0.5 * (*hi + *lo);
+		*lo = *hi;
+	}
+}
+static void avg_b(double * x, int nb, int Lk, int iB, int ib, int ie) {
+	for (int i = ib; i < ie; i++)
+	for (int k = 0; k < Lk; k++) {
+		double * hi = &x[((size_t)i * nb + iB) * Lk + k];
+		double * lo = &x[((size_t)i * nb + iB - 1) * Lk + k];
+		*hi = 0.5 * (*hi + *lo);
+		*lo = *hi;
+	}
+}
+
+void orc_apply_dss(const orc_grid * g, orc_state * s, int ix) {
+	const int L = g->L;
+	/* 1. exchange: pack all strips first (sources are interior nodes, never modified by unpacking) */
+	size_t tot = 0;
+	for (int p = 0; p < g->npatch; p++) tot += (size_t)g->patches[p].nhalo * (5 * L + 1);
+	double * buf = (double *)malloc(sizeof(double) * tot);
+	size_t off = 0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		for (int m = 0; m < P->nhalo; m++, off += 5 * L + 1) {
+			const int q = P->hsp[m];
+			if (q < 0) continue;
+			const orc_patch * Q = &g->patches[q];
+			const double * qn = s->node[ix * g->npatch + q];
+			const double * qe = s->redge[ix * g->npatch + q];
+			const int si = P->hsi[m], sj = P->hsj[m];
+			double * b = buf + off;
+			/* Node array carries U,V,rhotheta,rho; REdge array carries W (Connectivity.cpp:422-457) */
+			const int cn[4] = { UIx, VIx, PIx, RIx };
+			for (int c = 0; c < 4; c++)
+				for (int k = 0; k < L; k++)
+					b[c * L + k] = qn[(((size_t)cn[c] * Q->na + si) * Q->nb + sj) * L + k];
+			for (int k = 0; k <= L; k++)
+				b[4 * L + k] = qe[(((size_t)WIx * Q->na + si) * Q->nb + sj) * (L + 1) + k];
+			/* covector rotation of halo velocities from another panel */
+			if (P->hspanel[m] != P->panel) {
+				const double * T = P->htrans + 4 * (size_t)m;
+				for (int k = 0; k < L; k++) {
+					const double ua = b[k], ub = b[L + k];
+					b[k] = T[0] * ua + T[1] * ub;
+					b[L + k] = T[2] * ua + T[3] * ub;
+				}
+			}
+		}
+	}
+	off = 0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * pn = s->node[ix * g->npatch + p];
+		double * pe = s->redge[ix * g->npatch + p];
+		for (int m = 0; m < P->nhalo; m++, off += 5 * L + 1) {
+			if (P->hsp[m] < 0) continue;
+			const double * b = buf + off;
+			const int i = P->hi[m], j = P->hj[m];
+			const int cn[4] = { UIx, VIx, PIx, RIx };
+			for (int c = 0; c < 4; c++)
+				for (int k = 0; k < L; k++)
+					pn[(((size_t)cn[c] * na + i) * nb + j) * L + k] = b[c * L + k];
+			for (int k = 0; k <= L; k++)
+				pe[(((size_t)WIx * na + i) * nb + j) * (L + 1) + k] = b[4 * L + k];
+		}
+	}
+	free(buf);
+
+	/* 2. pairwise averaging, alpha then beta, 1/3 rule at cube corners (GridCSGLL.cpp:560-777) */
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const int TR = P->neighbor_panels[4], TL = P->neighbor_panels[5];
+		const int BL = P->neighbor_panels[6], BR = P->neighbor_panels[7];
+		for (int c = 0; c < 5; c++) {
+			const int Lk = (c == WIx) ? L + 1 : L;
+			double * x = (c == WIx)
+				? s->redge[ix * g->npatch + p] + (size_t)c * na * nb * Lk
+				: s->node[ix * g->npatch + p] + (size_t)c * na * nb * Lk;
+			int jb, je, ib, ie;
+			for (int a = 1; a < P->nea; a++) avg_a(x, nb, Lk, a * NP + 1, 0, nb);
+			jb = 0; je = nb; if (TL < 0) je -= 2; if (BL < 0) jb += 2;
+			avg_a(x, nb, Lk, 1, jb, je);
+			jb = 0; je = nb; if (TR < 0) je -= 2; if (BR < 0) jb += 2;
+			avg_a(x, nb, Lk, P->nea * NP + 1, jb, je);
+			for (int b = 1; b < P->neb; b++) avg_b(x, nb, Lk, b * NP + 1, 0, na);
+			ib = 0; ie = na; if (BL < 0) ib += 2; if (BR < 0) ie -= 2;
+			avg_b(x, nb, Lk, 1, ib, ie);
+			ib = 0; ie = na; if (TL < 0) ib += 2; if (TR < 0) ie -= 2;
+			avg_b(x, nb, Lk, P->neb * NP + 1, ib, ie);
+#define X3(i,j,k) x[((size_t)(i) * nb + (j)) * Lk + (k)]
+			const double third = 1.0 / 3.0;
+			if (TR < 0) { int iA = na - 2, iB = nb - 2;
+				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB + 1, k)); }
+			if (TL < 0) { int iA = 1, iB = nb - 2;
+				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB + 1, k)); }
+			if (BL < 0) { int iA = 1, iB = 1;
+				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB - 1, k)); }
+			if (BR < 0) { int iA = na - 2, iB = 1;
+				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB - 1, k)); }
+#undef X3
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* banded LU with partial pivoting: LAPACK dgbsv = dgbtrf(unblocked dgbtf2) + dgbtrs            */
+/* (third-party; call site src/base/LinearAlgebra.cpp:156-202 <- VerticalDynamicsFEM.cpp:1457)  */
+
+int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double * b) {
+	const int kv = ku + kl;
+#define AB(i,j) ab[(size_t)(j) * ldab + (kv + (i) - (j))]   /* full-matrix (i,j), 0-based */
+	int info = 0;
+	/* zero the fill-in super-diagonals of the first columns */
+	for (int j = ku + 1; j < (kv < n ? kv : n); j++)
+		for (int i = kv - j; i < kl; i++) ab[(size_t)j * ldab + i] = 0.0;
+	int ju = 0;
+	for (int j = 0; j < n; j++) {
+		if (j + kv < n) for (int i = 0; i < kl; i++) ab[(size_t)(j + kv) * ldab + i] = 0.0;
+		const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+		int jp = 0; double amax = fabs(AB(j, j));
+		for (int i = 1; i <= km; i++) { double v = fabs(AB(j + i, j)); if (v > amax) { amax = v; jp = i; } }
+		ipiv[j] = j + jp;
+		if (AB(j + jp, j) != 0.0) {
+			int t = j + ku + jp; if (t > n - 1) t = n - 1;
+			if (t > ju) ju = t;
+			if (jp != 0) for (int c = j; c <= ju; c++) { double tmp = AB(j + jp, c); AB(j + jp, c) = AB(j, c); AB(j, c) = tmp; }
+			if (km > 0) {
+				const double r = 1.0 / AB(j, j);
+				for (int i = 1; i <= km; i++) AB(j + i, j) *= r;
+				for (int c = j + 1; c <= ju; c++) {
+					const double u = AB(j, c);
+					if (u != 0.0) for (int i = 1; i <= km; i++) AB(j + i, c) -= AB(j + i, j) * u;
+				}
+			}
+		} else if (info == 0) info = j + 1;
+	}
+	if (info != 0) return info;
+	/* forward: apply L and the interchanges */
+	for (int j = 0; j < n - 1; j++) {
+		const int lm = (kl < n - 1 - j) ? kl : n - 1 - j;
+		const int l = ipiv[j];
+		if (l != j) { double tmp = b[l]; b[l] = b[j]; b[j] = tmp; }
+		for (int i = 1; i <= lm; i++) b[j + i] -= b[j] * AB(j + i, j);
+	}
+	/* backward: U x = y, U has kl+ku super-diagonals (column-oriented, as dtbsv) */
+	for (int j = n - 1; j >= 0; j--) {
+		if (b[j] != 0.0) {
+			b[j] /= AB(j, j);
+			const double t = b[j];
+			int lo = j - kv; if (lo < 0) lo = 0;
+			for (int i = j - 1; i >= lo; i--) b[i] -= t * AB(i, j);
+		}
+	}
+#undef AB
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* V implicit: SetupReferenceColumn + PrepareColumn + BuildF + BuildJacobianF + DGBSV          */
+/* (VerticalDynamicsFEM.cpp:1643-1835, 1839-2179, 2183-2780, 2784-3187, 1438-1485)             */
+
+enum { FP = 0, FW = 1, FR = 2, FTOT = 3, OFFD = 4, LDAB = 13 };
+#define VECF(c,k) (FTOT * (k) + (c))
+/* band index of d(row (c1,k1)) / d(col (c0,k0))  (VerticalDynamicsFEM.h:110-122) */
+#define MATF(c0,k0,c1,k1) ((2 * OFFD + (FTOT * (k1) + (c1)) - (FTOT * (k0) + (c0))) + LDAB * (FTOT * (k0) + (c0)))
+
+typedef struct {
+	double *un, *vn, *ue, *ve, *dua, *dub;             /* U,V on nodes/edges, d/dxi on edges   */
+	double *pn, *wn, *rn, *pe, *we, *re;               /* rhotheta, W, rho on nodes / edges     */
+	double *exn, *dpe, *xdn, *xde, *ddw, *mf, *pf, *dmf, *dpf, *ke, *dke, *uw, *aux;
+} colwork;
+
+static double * dalloc(int n) { return (double *)calloc((size_t)n, sizeof(double)); }
+
+static void colwork_init(colwork * w, int L) {
+	double ** f = (double **)w;
+	for (size_t i = 0; i < sizeof(colwork) / sizeof(double *); i++) f[i] = dalloc(L + 2);
+}
+static void colwork_free(colwork * w) {
+	double ** f = (double **)w;
+	for (size_t i = 0; i < sizeof(colwork) / sizeof(double *); i++) free(f[i]);
+}
+
+static void column_f_jacobian(const orc_grid * g, const orc_patch * P, const double * nin, const double * ein,
+	int iA, int iB, double dt, double * x0, double * F, double * AB, colwork * w) {
+	const int L = g->L, na = P->na, nb = P->nb;
+	const int n = FTOT * (L + 1);
+	const double * Jn = P->g[ORC_G_JAC], * Je = P->g[ORC_G_JAC_E];
+	const double * CA = P->g[ORC_G_CMA], * CB = P->g[ORC_G_CMB], * CX = P->g[ORC_G_CMXI];
+	const double * CAe = P->g[ORC_G_CMA_E], * CBe = P->g[ORC_G_CMB_E], * CXe = P->g[ORC_G_CMXI_E];
+	const double * DRe = P->g[ORC_G_DR_E];
+	(void)na;
+
+	/* SetupReferenceColumn (:1643-1835) */
+	for (int k = 0; k < L; k++) { w->un[k] = NI(UIx, iA, iB, k); w->vn[k] = NI(VIx, iA, iB, k); }
+	op_apply(g, ORC_OP_INTERP_N2E, w->un, w->ue);
+	op_apply(g, ORC_OP_INTERP_N2E, w->vn, w->ve);
+	op_apply(g, ORC_OP_DIFF_N2E, w->un, w->dua);
+	op_apply(g, ORC_OP_DIFF_N2E, w->vn, w->dub);
+	memset(x0, 0, sizeof(double) * n);
+	for (int k = 0; k < L; k++) { x0[VECF(FP, k)] = NI(PIx, iA, iB, k); x0[VECF(FR, k)] = NI(RIx, iA, iB, k); }
+	for (int k = 0; k <= L; k++) x0[VECF(FW, k)] = EI(WIx, iA, iB, k);
+
+	/* PrepareColumn (:1839-2179) */
+	for (int k = 0; k < L; k++) { w->pn[k] = x0[VECF(FP, k)]; w->rn[k] = x0[VECF(FR, k)]; }
+	for (int k = 0; k <= L; k++) w->we[k] = x0[VECF(FW, k)];
+	op_apply(g, ORC_OP_INTERP_E2N, w->we, w->wn);
+	op_apply(g, ORC_OP_INTERP_N2E, w->rn, w->re);
+	op_apply(g, ORC_OP_INTERP_N2E, w->pn, w->pe);
+	for (int k = 0; k < L; k++) w->exn[k] = exner_from_rhotheta(g, w->pn[k]);
+	op_apply(g, ORC_OP_DIFF_N2E, w->exn, w->dpe);
+	for (int k = 0; k < L; k++)
+		w->xdn[k] = M4(CX, iA, iB, k, 0) * w->un[k] + M4(CX, iA, iB, k, 1) * w->vn[k] + M4(CX, iA, iB, k, 2) * w->wn[k];
+	for (int k = 1; k < L; k++)
+		w->xde[k] = M4E(CXe, iA, iB, k, 0) * w->ue[k] + M4E(CXe, iA, iB, k, 1) * w->ve[k] + M4E(CXe, iA, iB, k, 2) * w->we[k];
+	w->xde[0] = 0.0; w->xde[L] = 0.0;
+	op_apply(g, ORC_OP_DIFFDIFF_E2E, w->we, w->ddw);
+
+	/* BuildF (:2183-2780) */
+	memset(F, 0, sizeof(double) * n);
+	w->mf[0] = 0.0; w->mf[L] = 0.0; w->pf[0] = 0.0; w->pf[L] = 0.0;
+	for (int k = 1; k < L; k++) {
+		w->mf[k] = Je[((size_t)iA * nb + iB) * (L + 1) + k] * w->re[k] * w->xde[k];
+		w->pf[k] = Je[((size_t)iA * nb + iB) * (L + 1) + k] * w->pe[k] * w->xde[k];
+	}
+	op_apply(g, ORC_OP_DIFF_E2N, w->mf, w->dmf);
+	op_apply(g, ORC_OP_DIFF_E2N, w->pf, w->dpf);
+	for (int k = 0; k < L; k++) {
+		const double invJ = 1.0 / M3(Jn, iA, iB, k);
+		F[VECF(FR, k)] = w->dmf[k] * invJ;
+		F[VECF(FP, k)] += w->dpf[k] * invJ;
+	}
+	for (int k = 0; k < L; k++) {
+		const double ua = w->un[k], ub = w->vn[k], ux = w->wn[k];
+		const double ca = M4(CA, iA, iB, k, 0) * ua + M4(CA, iA, iB, k, 1) * ub + M4(CA, iA, iB, k, 2) * ux;
+		const double cb = M4(CB, iA, iB, k, 0) * ua + M4(CB, iA, iB, k, 1) * ub + M4(CB, iA, iB, k, 2) * ux;
+		const double cx = M4(CX, iA, iB, k, 0) * ua + M4(CX, iA, iB, k, 1) * ub + M4(CX, iA, iB, k, 2) * ux;
+		w->ke[k] = 0.5 * (ca * ua + cb * ub + cx * ux);
+	}
+	op_apply(g, ORC_OP_DIFF_N2E, w->ke, w->dke);
+	for (int k = 1; k < L; k++) {
+		const double pgf = w->dpe[k] * w->pe[k] / w->re[k];
+		F[VECF(FW, k)] = pgf;
+		F[VECF(FW, k)] += g->grav * M4E(DRe, iA, iB, k, 2);
+		const double ua = w->ue[k], ub = w->ve[k], ux = w->we[k];
+		const double ca = M4E(CAe, iA, iB, k, 0) * ua + M4E(CAe, iA, iB, k, 1) * ub + M4E(CAe, iA, iB, k, 2) * ux;
+		const double cb = M4E(CBe, iA, iB, k, 0) * ua + M4E(CBe, iA, iB, k, 1) * ub + M4E(CBe, iA, iB, k, 2) * ux;
+		const double curl = -ca * w->dua[k] - cb * w->dub[k];
+		F[VECF(FW, k)] += (w->dke[k] + curl);
+	}
+	/* upwinding (:2640-2712): weights |xidot| at interfaces 1..L-1 */
+	const double upc = 0.5 * (1.0 / (double)L);            /* m_dUpwindCoeff (:394-395) */
+	for (int a = 0; a < L - 1; a++) w->uw[a] = fabs(w->xde[a + 1]);
+	{	/* rhotheta (c=2) on levels */
+		memset(w->aux, 0, sizeof(double) * (L + 1));
+		double * buf = w->mf;   /* mf no longer needed */
+		penalty_apply(g, w->uw, w->pn, w->aux, buf);
+		for (int k = 0; k < L; k++) F[VECF(FP, k)] -= w->aux[k];
+	}
+	{	/* W (c=3) on interfaces */
+		w->ddw[0] = 0.0; w->ddw[L] = 0.0;
+		for (int k = 0; k <= L; k++) F[VECF(FW, k)] -= upc * fabs(w->xde[k]) * w->ddw[k];
+	}
+	{	/* rho (c=4) on levels */
+		memset(w->aux, 0, sizeof(double) * (L + 1));
+		double * buf = w->mf;
+		penalty_apply(g, w->uw, w->rn, w->aux, buf);
+		for (int k = 0; k < L; k++) F[VECF(FR, k)] -= w->aux[k];
+	}
+	F[VECF(FW, 0)] = 0.0;
+	F[VECF(FW, L)] = 0.0;
+	/* (x - x0)/dt vanishes: the Newton iterate is the initial column (:2776-2779) */
+
+	/* BuildJacobianF_LOR_RhoTheta_Pi (:2977-3187) */
+	memset(AB, 0, sizeof(double) * n * LDAB);
+	const double * cDe2n = g->opc[ORC_OP_DIFF_E2N]; const int * bDe2n = g->opb[ORC_OP_DIFF_E2N], * eDe2n = g->ope[ORC_OP_DIFF_E2N];
+	const double * cIn2e = g->opc[ORC_OP_INTERP_N2E]; const int * bIn2e = g->opb[ORC_OP_INTERP_N2E], * eIn2e = g->ope[ORC_OP_INTERP_N2E];
+	const double * cDn2e = g->opc[ORC_OP_DIFF_N2E]; const int * bDn2e = g->opb[ORC_OP_DIFF_N2E], * eDn2e = g->ope[ORC_OP_DIFF_N2E];
+	const double * cIe2n = g->opc[ORC_OP_INTERP_E2N]; const int * bIe2n = g->opb[ORC_OP_INTERP_E2N], * eIe2n = g->ope[ORC_OP_INTERP_E2N];
+	const double cv = g->cp - g->Rd;
+#define JE(k) Je[((size_t)iA * nb + iB) * (L + 1) + (k)]
+	for (int k = 0; k < L; k++) {
+		const double invJ = 1.0 / M3(Jn, iA, iB, k);
+		for (int m = bDe2n[k]; m < eDe2n[k]; m++) {
+			if (m != 0 && m != L) {
+				const double c = cDe2n[k * (L + 1) + m] * JE(m) * invJ * M4E(CXe, iA, iB, m, 2);
+				AB[MATF(FW, m, FP, k)] += c * w->pe[m];
+				AB[MATF(FW, m, FR, k)] += c * w->re[m];
+			}
+			for (int q = bIn2e[m]; q < eIn2e[m]; q++) {
+				const double c = cDe2n[k * (L + 1) + m] * JE(m) * invJ * cIn2e[m * L + q] * w->xde[m];
+				AB[MATF(FR, q, FR, k)] += c;
+				AB[MATF(FP, q, FP, k)] += c;
+			}
+		}
+	}
+	for (int k = 1; k < L; k++) {
+		const double cA = w->pe[k] * g->Rd / (w->re[k] * cv);
+		for (int m = bDn2e[k]; m < eDn2e[k]; m++)
+			AB[MATF(FP, m, FW, k)] += cA * cDn2e[k * L + m] * w->exn[m] / w->pn[m];
+		const double cB = 1.0 / (w->re[k] * w->re[k]) * w->dpe[k];
+		for (int q = bIn2e[k]; q < eIn2e[k]; q++) {
+			const double cC = cB * cIn2e[k * L + q];
+			AB[MATF(FP, q, FW, k)] += cC * w->re[k];
+			AB[MATF(FR, q, FW, k)] += -cC * w->pe[k];
+		}
+	}
+	for (int k = 1; k < L; k++)
+		for (int l = bDn2e[k]; l < eDn2e[k]; l++)
+			for (int m = bIe2n[l]; m < eIe2n[l]; m++)
+				AB[MATF(FW, m, FW, k)] += cIe2n[l * (L + 1) + m] * cDn2e[k * L + l] * w->xdn[l];
+
+	/* BuildJacobianF_Diffusion (:2784-2973): upwinding terms */
+	const double * cDDe = g->opc[ORC_OP_DIFFDIFF_E2E]; const int * bDDe = g->opb[ORC_OP_DIFFDIFF_E2E], * eDDe = g->ope[ORC_OP_DIFFDIFF_E2E];
+	const double * cPL = g->opc[ORC_OP_PENALTY_L]; const int * bPL = g->opb[ORC_OP_PENALTY_L], * ePL = g->ope[ORC_OP_PENALTY_L];
+	const double * cPR = g->opc[ORC_OP_PENALTY_R]; const int * bPR = g->opb[ORC_OP_PENALTY_R], * ePR = g->ope[ORC_OP_PENALTY_R];
+	for (int c = 2; c < 5; c++) {
+		const int fc = c - 2;
+		if (c == WIx) {
+			for (int k = 0; k <= L; k++) {
+				double sw;
+				if (w->xde[k] > 0.0) sw = M4E(CXe, iA, iB, k, 2);
+				else if (w->xde[k] < 0.0) sw = -M4E(CXe, iA, iB, k, 2);
+				else sw = 0.0;
+				AB[MATF(FW, k, fc, k)] -= upc * sw * w->ddw[k];
+			}
+			for (int k = 0; k <= L; k++)
+				for (int q = bDDe[k]; q < eDDe[k]; q++)
+					AB[MATF(fc, q, fc, k)] -= upc * fabs(w->xde[k]) * cDDe[k * (L + 1) + q];
+		} else {
+			const double * xs = (c == PIx) ? w->pn : w->rn;
+			for (int a = 1; a < L; a++) {
+				const double wt = fabs(w->xde[a]);
+				double sw;
+				if (w->xde[a] > 0.0) sw = M4E(CXe, iA, iB, a, 2);
+				else if (w->xde[a] < 0.0) sw = -M4E(CXe, iA, iB, a, 2);
+				else sw = 0.0;
+				const int kl = a - 1, kr = a;    /* left element = level a-1, right element = level a */
+				for (int q = bPL[kl]; q < ePL[kl]; q++) AB[MATF(FW, a, fc, kl)] -= sw * cPL[kl * L + q] * xs[q];
+				for (int q = bPR[kr]; q < ePR[kr]; q++) AB[MATF(FW, a, fc, kr)] -= sw * cPR[kr * L + q] * xs[q];
+				for (int q = bPL[kl]; q < ePL[kl]; q++) AB[MATF(fc, q, fc, kl)] -= wt * cPL[kl * L + q];
+				for (int q = bPR[kr]; q < ePR[kr]; q++) AB[MATF(fc, q, fc, kr)] -= wt * cPR[kr * L + q];
+			}
+		}
+	}
+	for (int k = 0; k <= L; k++) {
+		AB[MATF(FP, k, FP, k)] += 1.0 / dt;
+		AB[MATF(FW, k, FW, k)] += 1.0 / dt;
+		AB[MATF(FR, k, FR, k)] += 1.0 / dt;
+	}
+#undef JE
+}
+
+void orc_column_f_jacobian(const orc_grid * g, const orc_patch * p, const double * node, const double * redge,
+	int iA, int iB, double dt, double * x0, double * F, double * AB) {
+	colwork w; colwork_init(&w, g->L);
+	column_f_jacobian(g, p, node, redge, iA, iB, dt, x0, F, AB, &w);
+	colwork_free(&w);
+}
+
+int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = g->L;
+	const int n = FTOT * (L + 1);
+	double * x0 = dalloc(n), * F = dalloc(n), * AB = dalloc(n * LDAB);
+	int * ipiv = (int *)malloc(sizeof(int) * n);
+	colwork w; colwork_init(&w, L);
+	int info = 0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * nin = s->node[iinit * g->npatch + p];
+		const double * ein = s->redge[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		double * eup = s->redge[iupd * g->npatch + p];
+		/* unique columns only (:1315-1337) */
+		for (int a = 0; a < P->nea; a++)
+		for (int b = 0; b < P->neb; b++) {
+			const int iend = (a == P->nea - 1) ? NP : NP - 1;
+			const int jend = (b == P->neb - 1) ? NP : NP - 1;
+			for (int i = 0; i < iend; i++)
+			for (int j = 0; j < jend; j++) {
+				const int iA = 1 + a * NP + i, iB = 1 + b * NP + j;
+				column_f_jacobian(g, P, nin, ein, iA, iB, dt, x0, F, AB, &w);
+				int r = orc_dgbsv(n, OFFD, OFFD, AB, LDAB, ipiv, F);
+				if (r != 0 && info == 0) info = r;
+				/* one Newton step x = x0 - J^{-1} F (:1483-1485) and scatter (:1488-1529) */
+				for (int k = 0; k < L; k++) {
+					NU(PIx, iA, iB, k) = x0[VECF(FP, k)] - F[VECF(FP, k)];
+					NU(RIx, iA, iB, k) = x0[VECF(FR, k)] - F[VECF(FR, k)];
+				}
+				for (int k = 0; k <= L; k++) EU(WIx, iA, iB, k) = x0[VECF(FW, k)] - F[VECF(FW, k)];
+			}
+		}
+		/* duplicate element-seam nodes inside the patch receive P, W, Rho (not U,V) (:1543-1633) */
+		for (int a = 1; a < P->nea; a++) {
+			const int iA = a * NP;     /* = interior begin + a*np - 1 */
+			for (int b = 0; b < P->neb; b++) {
+				const int jend = (b == P->neb - 1) ? NP : NP - 1;
+				for (int j = 0; j < jend; j++) {
+					const int iB = 1 + b * NP + j;
+					for (int k = 0; k < L; k++) {
+						NU(PIx, iA, iB, k) = NU(PIx, iA + 1, iB, k);
+						NU(WIx, iA, iB, k) = NU(WIx, iA + 1, iB, k);
+						NU(RIx, iA, iB, k) = NU(RIx, iA + 1, iB, k);
+					}
+					for (int k = 0; k <= L; k++) {
+						EU(PIx, iA, iB, k) = EU(PIx, iA + 1, iB, k);
+						EU(WIx, iA, iB, k) = EU(WIx, iA + 1, iB, k);
+						EU(RIx, iA, iB, k) = EU(RIx, iA + 1, iB, k);
+					}
+				}
+			}
+		}
+		for (int b = 1; b < P->neb; b++)
+		for (int i = 1; i < na - 1; i++) {
+			const int iB = b * NP;
+			for (int k = 0; k < L; k++) {
+				NU(PIx, i, iB, k) = NU(PIx, i, iB + 1, k);
+				NU(WIx, i, iB, k) = NU(WIx, i, iB + 1, k);
+				NU(RIx, i, iB, k) = NU(RIx, i, iB + 1, k);
+			}
+			for (int k = 0; k <= L; k++) {
+				EU(PIx, i, iB, k) = EU(PIx, i, iB + 1, k);
+				EU(WIx, i, iB, k) = EU(WIx, i, iB + 1, k);
+				EU(RIx, i, iB, k) = EU(RIx, i, iB + 1, k);
+			}
+		}
+	}
+	colwork_free(&w);
+	free(x0); free(F); free(AB); free(ipiv);
+	return info;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* hyperviscosity: ApplyScalarHyperdiffusion, ApplyVectorHyperdiffusion (+ComputeCurlAndDiv),   */
+/* StepAfterSubCycle (HorizontalDynamicsFEM.cpp:1867-2203, 2207-2414, 2637-2726;                */
+/* GridPatchCSGLL.cpp:1132-1305)                                                               */
+
+static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally) {
+	const int L = g->L;
+	const double inv_da = 1.0 / g->delta_a;
+	const double * D = g->dx, * S = g->stiff;
+	double local_nu = nu;
+	if (scale_locally && g->ref_length != 0.0) local_nu *= pow(g->delta_a / g->ref_length, 3.2);
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
+		for (int c = 2; c < 5; c++) {
+			const int Lk = (c == WIx) ? L + 1 : L;
+			const double * Jc = (c == WIx) ? P->g[ORC_G_JAC_E] : P->g[ORC_G_JAC];
+			const double * xin = ((c == WIx) ? s->redge[iinit * g->npatch + p] : s->node[iinit * g->npatch + p]) + (size_t)c * na * nb * Lk;
+			double * xup = ((c == WIx) ? s->redge[iupd * g->npatch + p] : s->node[iupd * g->npatch + p]) + (size_t)c * na * nb * Lk;
+#define XI(i,j,k) xin[((size_t)(i) * nb + (j)) * Lk + (k)]
+#define XU(i,j,k) xup[((size_t)(i) * nb + (j)) * Lk + (k)]
+#define JC(i,j,k) Jc[((size_t)(i) * nb + (j)) * Lk + (k)]
+			for (int a = 0; a < P->nea; a++)
+			for (int b = 0; b < P->neb; b++)
+			for (int k = 0; k < Lk; k++) {
+				const int eA = a * NP + 1, eB = b * NP + 1;
+				double ga[NP][NP], gb[NP][NP];
+				for (int i = 0; i < NP; i++)
+				for (int j = 0; j < NP; j++) {
+					const int iA = eA + i, iB = eB + j;
+					double da = 0.0, db = 0.0;
+					for (int q = 0; q < NP; q++) {
+						da += XI(eA + q, iB, k) * D[q * NP + i];
+						db += XI(iA, eB + q, k) * D[q * NP + j];
+					}
+					da *= inv_da; db *= inv_da;
+					ga[i][j] = JC(iA, iB, k) * (C2A[(iA * nb + iB) * 2 + 0] * da + C2A[(iA * nb + iB) * 2 + 1] * db);
+					gb[i][j] = JC(iA, iB, k) * (C2B[(iA * nb + iB) * 2 + 0] * da + C2B[(iA * nb + iB) * 2 + 1] * db);
+				}
+				for (int i = 0; i < NP; i++)
+				for (int j = 0; j < NP; j++) {
+					const int iA = eA + i, iB = eB + j;
+					const double invJ = 1.0 / JC(iA, iB, k);
+					double ua = 0.0, ub = 0.0;
+					for (int q = 0; q < NP; q++) {
+						ua += ga[q][j] * S[i * NP + q];
+						ub += gb[i][q] * S[j * NP + q];
+					}
+					ua *= inv_da; ub *= inv_da;
+					XU(iA, iB, k) -= dt * invJ * local_nu * (ua + ub);
+				}
+			}
+#undef XI
+#undef XU
+#undef JC
+		}
+	}
+}
+
+static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally) {
+	const int L = g->L;
+	const double inv_da = 1.0 / g->delta_a;
+	const double * D = g->dx, * S = g->stiff;
+	double lnd = nud, lnv = nuv;
+	if (scale_locally && g->ref_length != 0.0) {
+		lnd = lnd * pow(g->delta_a / g->ref_length, 3.2);
+		lnv = lnv * pow(g->delta_a / g->ref_length, 3.2);
+	}
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * J2 = P->g[ORC_G_JAC2D];
+		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
+		const double * nin = s->node[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		for (int a = 0; a < P->nea; a++)
+		for (int b = 0; b < P->neb; b++)
+		for (int k = 0; k < L; k++) {
+			const int eA = a * NP + 1, eB = b * NP + 1;
+			double cua[NP][NP], cub[NP][NP], dv[NP][NP], cl[NP][NP];
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				cua[i][j] = C2A[(iA * nb + iB) * 2 + 0] * NI(UIx, iA, iB, k) + C2A[(iA * nb + iB) * 2 + 1] * NI(VIx, iA, iB, k);
+				cub[i][j] = C2B[(iA * nb + iB) * 2 + 0] * NI(UIx, iA, iB, k) + C2B[(iA * nb + iB) * 2 + 1] * NI(VIx, iA, iB, k);
+			}
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				double daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+				for (int q = 0; q < NP; q++) {
+					daub += NI(VIx, eA + q, iB, k) * D[q * NP + i];
+					dbua += NI(UIx, iA, eB + q, k) * D[q * NP + j];
+					dajua += J2[(eA + q) * nb + iB] * cua[q][j] * D[q * NP + i];
+					dbjub += J2[iA * nb + eB + q] * cub[i][q] * D[q * NP + j];
+				}
+				daub *= inv_da; dbua *= inv_da; dajua *= inv_da; dbjub *= inv_da;
+				const double invJ2 = 1.0 / J2[iA * nb + iB];
+				dv[i][j] = (dajua + dbjub) * invJ2;
+				cl[i][j] = (daub - dbua) * invJ2;
+			}
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				double dad = 0, dbd = 0, dac = 0, dbc = 0;
+				for (int q = 0; q < NP; q++) {
+					dad -= S[i * NP + q] * dv[q][j];
+					dbd -= S[j * NP + q] * dv[i][q];
+					dac -= S[i * NP + q] * cl[q][j];
+					dbc -= S[j * NP + q] * cl[i][q];
+				}
+				dad *= inv_da; dbd *= inv_da; dac *= inv_da; dbc *= inv_da;
+				const double upa = lnd * dad - lnv * J2[iA * nb + iB] * (C2B[(iA * nb + iB) * 2 + 0] * dac + C2B[(iA * nb + iB) * 2 + 1] * dbc);
+				const double upb = lnd * dbd + lnv * J2[iA * nb + iB] * (C2A[(iA * nb + iB) * 2 + 0] * dac + C2A[(iA * nb + iB) * 2 + 1] * dbc);
+				NU(UIx, iA, iB, k) -= dt * upa;
+				NU(VIx, iA, iB, k) -= dt * upb;
+			}
+		}
+	}
+}
+
+void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt) {
+	orc_copy(g, s, iinit, iupd);
+	if (g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0) return;
+	orc_zero(g, s, iwork);
+	scalar_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
+	vector_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 1.0, 0);
+	orc_apply_dss(g, s, iwork);
+	scalar_hyperdiff(g, s, iwork, iupd, -dt, g->nu_scalar, 1);
+	vector_hyperdiff(g, s, iwork, iupd, -dt, g->nu_div, g->nu_vort, 1);
+	orc_apply_dss(g, s, iupd);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ARS(3,4,3) IMEX step in U-form: TimestepSchemeARS343 (TimestepSchemeARS343.cpp:25-236)      */
+
+static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp, double * dimp) {
+	const double gm = 0.4358665215084590;
+	const double b1 = -1.5 * gm * gm + 4.0 * gm - 0.25;
+	const double b2 = 1.5 * gm * gm - 5.0 * gm + 1.25;
+	const double a42 = 0.5529291480359398, a43 = 0.5529291480359398;
+	const double a31 = (1.0 - 4.5 * gm + 1.5 * gm * gm) * a42 + (2.75 - 10.5 * gm + 3.75 * gm * gm) * a43
+		- 3.5 + 13 * gm - 4.5 * gm * gm;
+	const double a32 = (-1.0 + 4.5 * gm - 1.5 * gm * gm) * a42 + (-2.75 + 10.5 * gm - 3.75 * gm * gm) * a43
+		+ 4.0 - 12.5 * gm + 4.5 * gm * gm;
+	const double a41 = 1.0 - a42 - a43;
+	const double I[4][4] = { { gm, 0, 0, 0 }, { 0.5 * (1.0 - gm), gm, 0, 0 }, { b1, b2, gm, 0 }, { b1, b2, gm, 0 } };
+	const double E[4][4] = { { gm, 0, 0, 0 }, { a31, a32, 0, 0 }, { a41, a42, a43, 0 }, { 0, b1, b2, gm } };
+	for (int i = 0; i < 4; i++) { dexp[i] = E[i][i]; dimp[i] = I[i][i]; }
+	for (int i = 0; i < 7; i++) u2[i] = u3[i] = u4[i] = 0.0;
+	u2[0] = 1.0 - E[1][0] / E[0][0];
+	u2[1] = E[1][0] / E[0][0] - I[1][0] / I[0][0];
+	u2[2] = I[1][0] / I[0][0];
+	u3[0] = 1.0 - E[2][0] / E[0][0];
+	u3[1] = E[2][0] / E[0][0] - I[2][0] / I[0][0];
+	u3[2] = I[2][0] / I[0][0];
+	u3[3] = E[2][1] / E[1][1] - I[2][1] / I[1][1];
+	u3[4] = I[2][1] / I[1][1];
+	const double u37 = -E[2][1] / E[1][1];
+	u4[0] = 1.0 - E[3][0] / E[0][0];
+	u4[1] = E[3][0] / E[0][0] - I[3][0] / I[0][0];
+	u4[2] = I[3][0] / I[0][0];
+	u4[3] = E[3][1] / E[1][1] - I[3][1] / I[1][1];
+	u4[4] = I[3][1] / I[1][1];
+	u4[5] = E[3][2] / E[2][2] - I[3][2] / I[2][2];
+	u4[6] = I[3][2] / I[2][2];
+	const double u47 = -E[3][1] / E[1][1];
+	const double u48 = -E[3][2] / E[2][2];
+	u3[0] += u37 * u2[0]; u3[1] += u37 * u2[1]; u3[2] += u37 * u2[2];
+	u4[0] += u47 * u2[0] + u48 * u3[0];
+	u4[1] += u47 * u2[1] + u48 * u3[1];
+	u4[2] += u47 * u2[2] + u48 * u3[2];
+	u4[3] += u48 * u3[3];
+	u4[4] += u48 * u3[4];
+}
+
+int orc_step_ars343(const orc_grid * g, orc_state * s, double dt) {
+	double u2[7], u3[7], u4[7], de[4], di[4];
+	int info = 0, r;
+	ars343_tableau(u2, u3, u4, de, di);
+	orc_copy(g, s, 0, 1);
+	orc_h_step_explicit(g, s, 0, 1, de[0] * dt);
+	orc_v_step_explicit(g, s, 0, 1, de[0] * dt);
+	orc_apply_dss(g, s, 1);
+	orc_copy(g, s, 1, 2);
+	r = orc_v_step_implicit(g, s, 2, 2, di[0] * dt); if (r && !info) info = r;
+
+	orc_linear_combine(g, s, u2, 7, 3);
+	orc_h_step_explicit(g, s, 2, 3, de[1] * dt);
+	orc_v_step_explicit(g, s, 2, 3, de[1] * dt);
+	orc_apply_dss(g, s, 3);
+	orc_copy(g, s, 3, 4);
+	r = orc_v_step_implicit(g, s, 4, 4, di[1] * dt); if (r && !info) info = r;
+
+	orc_linear_combine(g, s, u3, 7, 5);
+	orc_h_step_explicit(g, s, 4, 5, de[2] * dt);
+	orc_v_step_explicit(g, s, 4, 5, de[2] * dt);
+	orc_apply_dss(g, s, 5);
+	orc_copy(g, s, 5, 6);
+	r = orc_v_step_implicit(g, s, 6, 6, di[2] * dt); if (r && !info) info = r;
+
+	orc_linear_combine(g, s, u4, 7, 1);
+	orc_h_step_explicit(g, s, 6, 1, de[3] * dt);
+	orc_v_step_explicit(g, s, 6, 1, de[3] * dt);
+	orc_apply_dss(g, s, 1);
+
+	orc_copy(g, s, 1, 0);
+	orc_h_step_after_subcycle(g, s, 1, 0, 2, dt);
+	return info;
+}

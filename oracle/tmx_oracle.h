@@ -1,0 +1,109 @@
+/* oracle/tmx_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference hot path (paullric/tempestmodel), used as the
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  It is never
+ * linked into, imported by, or called from the product library.
+ *
+ * Parity status: PINNED -- every routine is checked against dumps of the real reference
+ * (oracle/_ref, built by oracle/Makefile from /root/reference) in tests/test_oracle_vs_reference.py
+ * via the committed fixtures under tests/golden/.
+ *
+ * Data layout is the reference's own: per patch, per instance,
+ *   node [5][na][nb][L]   and  redge [5][na][nb][L+1]      (k fastest, one-node halo ring,
+ * duplicated element-edge nodes; src/atm/GridPatch.cpp:341-356, src/base/DataArray4D.h:123-231).
+ */
+#ifndef TMX_ORACLE_H
+#define TMX_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	ORC_G_JAC2D = 0,   /* [na][nb]        */
+	ORC_G_CM2A,        /* [na][nb][2]     */
+	ORC_G_CM2B,        /* [na][nb][2]     */
+	ORC_G_JAC,         /* [na][nb][L]     */
+	ORC_G_JAC_E,       /* [na][nb][L+1]   */
+	ORC_G_CMA,         /* [na][nb][L][3]  */
+	ORC_G_CMB,
+	ORC_G_CMXI,
+	ORC_G_CMA_E,       /* [na][nb][L+1][3] */
+	ORC_G_CMB_E,
+	ORC_G_CMXI_E,
+	ORC_G_DR_N,        /* [na][nb][L][3]  */
+	ORC_G_DR_E,        /* [na][nb][L+1][3] */
+	ORC_G_CORIOLIS,    /* [na][nb]        */
+	ORC_G_COUNT
+};
+
+enum {
+	ORC_OP_INTERP_N2E = 0,
+	ORC_OP_INTERP_E2N,
+	ORC_OP_DIFF_N2N,
+	ORC_OP_DIFF_N2E,
+	ORC_OP_DIFF_E2N,
+	ORC_OP_DIFF_E2E,
+	ORC_OP_DIFFDIFF_N2N,
+	ORC_OP_DIFFDIFF_E2E,
+	ORC_OP_PENALTY_L,
+	ORC_OP_PENALTY_R,
+	ORC_OP_COUNT
+};
+
+typedef struct {
+	int panel, na, nb, nea, neb;
+	int neighbor_panels[8];            /* Right, Top, Left, Bottom, TR, TL, BL, BR; -1 = none */
+	const double * g[ORC_G_COUNT];
+	int nhalo;
+	const int * hi; const int * hj;    /* ring node local indices                    */
+	const int * hsp;                   /* source patch (-1 = none)                   */
+	const int * hsi; const int * hsj;  /* source local indices                       */
+	const int * hspanel;               /* source panel                               */
+	const double * htrans;             /* [nhalo][2][2] covector transform           */
+} orc_patch;
+
+typedef struct {
+	int np, L, npatch;
+	double delta_a, ref_length;
+	double grav, Rd, cp, p0;
+	double dx[16], stiff[16];          /* [s][i] row-major, np = 4                   */
+	const double * opc[ORC_OP_COUNT];  /* dense [nout][nin]                          */
+	const int * opb[ORC_OP_COUNT];
+	const int * ope[ORC_OP_COUNT];
+	int opnin[ORC_OP_COUNT];
+	int opnout[ORC_OP_COUNT];
+	double nu_scalar, nu_div, nu_vort;
+	const orc_patch * patches;
+} orc_grid;
+
+/* state: node[inst*npatch + p], redge[inst*npatch + p] */
+typedef struct {
+	int ninst;
+	double ** node;
+	double ** redge;
+} orc_state;
+
+void orc_copy(const orc_grid * g, orc_state * s, int src, int dst);
+void orc_zero(const orc_grid * g, orc_state * s, int ix);
+void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff, int ncoeff, int dst);
+
+void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+void orc_v_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+int  orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+void orc_apply_dss(const orc_grid * g, orc_state * s, int ix);
+void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt);
+int  orc_step_ars343(const orc_grid * g, orc_state * s, double dt);
+
+/* banded LU with partial pivoting, LAPACK dgbsv semantics (1 rhs); ab is [n][ldab] column-major band
+ * storage with ldab = 2*kl+ku+1, entry (i,j) at ab[j*ldab + kl+ku+i-j].  Returns info. */
+int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double * b);
+
+/* single-column implicit pieces, exposed for unit tests: builds F and the band Jacobian of one column */
+void orc_column_f_jacobian(const orc_grid * g, const orc_patch * p, const double * node, const double * redge,
+	int iA, int iB, double dt, double * x0, double * F, double * AB);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

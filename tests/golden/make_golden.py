@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Regenerate the golden fixtures from the REAL reference (oracle/_ref/tmx_ref_dump, built by
+`make -C oracle ref` from /root/reference -- only possible in the build container).
+
+The fixtures are data only: inputs and outputs of the reference's hot-path calls.
+
+  percall_ne3_L5_p6.npz   geometry, operators, halo transforms and the state after each single
+                          hot-path call (H explicit, V explicit, DSS, V implicit, hyperviscosity,
+                          linear combination), starting from the state after 2 real ARS343 steps
+  steps_ne4_L6_p24.npz    24-patch layout: prognostic interior state after 0..3 ARS343 steps
+  steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
+  known_answers.json      area-weighted checksums printed by the reference
+"""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tmxd  # noqa: E402
+
+DUMP = os.path.join(ROOT, "oracle", "_ref", "tmx_ref_dump")
+ENV = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+
+
+def run(args, out):
+    txt = subprocess.run([DUMP] + args + ["--out", out], env=ENV, check=True,
+                         stdout=subprocess.PIPE, universal_newlines=True).stdout
+    sums = {}
+    for line in txt.splitlines():
+        if line.startswith("checksum "):
+            f = line.split()
+            sums[f[1]] = [float(v) for v in f[2:]]
+    return tmxd.read(out), sums
+
+
+def compact_states(d, npatch):
+    """Keep only prognostic slots on interior nodes: node comps (U,V,rhotheta,rho), redge comp W."""
+    out = {}
+    for k, v in d.items():
+        if not k.startswith("state/"):
+            continue
+        if k.endswith("/node"):
+            out[k] = v[[0, 1, 2, 4], 1:-1, 1:-1]
+        else:
+            out[k] = v[3, 1:-1, 1:-1]
+    return out
+
+
+def save(name, rec):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k.replace("/", "__"): v for k, v in rec.items()})
+    print(name, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+def main():
+    tmp = "/tmp/tmx_golden.tmxd"
+    drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge",
+            "ref_node", "ref_redge", "a_nodes", "b_nodes")
+    d, _ = run(["--mode", "percall", "--ne", "3", "--levels", "5", "--dt", "300", "--warm", "2"], tmp)
+    d = {k: v for k, v in d.items() if k.split("/")[-1] not in drop and not k.startswith("state/initial")}
+    save("percall_ne3_L5_p6.npz", d)
+
+    d, sums = run(["--mode", "steps", "--ne", "4", "--levels", "6", "--dt", "200", "--steps", "3",
+                   "--patches", "24", "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    rec.update(compact_states(d, 24))
+    save("steps_ne4_L6_p24.npz", rec)
+
+    d, sums2 = run(["--mode", "steps", "--ne", "3", "--levels", "5", "--dt", "300", "--steps", "10",
+                    "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    cs = compact_states(d, 6)
+    keep = ("initial", "step1", "step2", "step5", "step10")
+    rec.update({k: v for k, v in cs.items() if k.split("/")[1] in keep})
+    save("steps_ne3_L5_p6.npz", rec)
+
+    # reference stdout known answers (same command as SURVEY.md section 8c)
+    _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",
+                 "--geom", "0"], tmp)
+    with open(os.path.join(HERE, "known_answers.json"), "w") as f:
+        json.dump({"jw_ne4_L10_dt200_ars343": ka,
+                   "jw_ne4_L6_p24_dt200_ars343": sums,
+                   "jw_ne3_L5_dt300_ars343": sums2}, f, indent=1)
+    os.remove(tmp)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""The C oracle (oracle/tmx_oracle.c) against golden vectors dumped from the real reference.
+
+Tolerances are relative to the max abs value of each variable.  H/V explicit reproduce the reference
+bit for bit on identical inputs; the implicit solve differs from MKL's dgbsv by rounding only."""
+import json
+import os
+import numpy as np
+import pytest
+import golden_util as gu
+from oracle_lib import Oracle, dgbsv
+
+
+@pytest.fixture(scope="module")
+def percall():
+    d = gu.load("percall_ne3_L5_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True)
+    return d, g
+
+
+def test_percall_chain(percall):
+    d, g = percall
+    npatch = len(g.patches)
+    dt = float(d["cfg/dt"][0]); sdt = dt * gu.ARS343_GAMMA
+    o = Oracle(g)
+    o.set_state(0, gu.full_states(d, "warm", npatch))
+    o.copy_data(0, 1)
+    o.h_step_explicit(0, 1, sdt)
+    # the prologue mutates the input instance (W->levels, U,V->interfaces)
+    for (gn, ge), (rn, re_) in zip(o.get_state(0), gu.full_states(d, "h_explicit_in_after", npatch)):
+        assert np.array_equal(gn[:, 1:-1, 1:-1], rn[:, 1:-1, 1:-1])
+        assert np.array_equal(ge[:, 1:-1, 1:-1], re_[:, 1:-1, 1:-1])
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "h_explicit", npatch))) < 1e-15
+    o.v_step_explicit(0, 1, sdt)
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "v_explicit", npatch))) < 1e-15
+    o.apply_dss(1)
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "dss", npatch))) < 1e-15
+    o.copy_data(1, 2)
+    assert o.v_step_implicit(2, 2, sdt) == 0
+    assert max(gu.prognostic_errors(o.get_state(2), gu.full_states(d, "v_implicit", npatch))) < 1e-12
+    o.h_step_after_subcycle(2, 3, 4, dt)
+    assert max(gu.prognostic_errors(o.get_state(4), gu.full_states(d, "hypervis_work", npatch))) < 1e-12
+    assert max(gu.prognostic_errors(o.get_state(3), gu.full_states(d, "hypervis", npatch))) < 1e-12
+    o.linear_combine_data([0.25, -0.5, 1.75, 0.5, 0, 0, 0], 3)
+    assert max(gu.prognostic_errors(o.get_state(3), gu.full_states(d, "lincomb", npatch))) < 1e-12
+
+
+def test_dss_fills_halo_like_exchange(percall):
+    d, g = percall
+    npatch = len(g.patches)
+    o = Oracle(g)
+    o.set_state(1, gu.full_states(d, "v_explicit", npatch))
+    o.apply_dss(1)
+    ref = gu.full_states(d, "dss", npatch)
+    for P, (gn, ge), (rn, re_) in zip(g.patches, o.get_state(1), ref):
+        mask = np.ones((P.na, P.nb), dtype=bool)
+        for (i, j) in ((0, 0), (0, P.nb - 1), (P.na - 1, 0), (P.na - 1, P.nb - 1)):
+            mask[i, j] = False        # cube-corner halo nodes carry no data in the reference
+        for c in (0, 1, 2, 4):
+            s = np.max(np.abs(rn[c]))
+            assert np.max(np.abs(gn[c] - rn[c])[mask]) < 1e-14 * s
+        s = np.max(np.abs(re_[3]))
+        assert np.max(np.abs(ge[3] - re_[3])[mask]) <= 1e-14 * s
+
+
+@pytest.mark.parametrize("fixture,ne,L,npatch,dt,tags", [
+    ("steps_ne4_L6_p24.npz", 4, 6, 24, 200.0, ["step1", "step2", "step3"]),
+    ("steps_ne3_L5_p6.npz", 3, 5, 6, 300.0, ["step1", "step2", "step5", "step10"]),
+])
+def test_ars343_steps_from_developed_state(fixture, ne, L, npatch, dt, tags):
+    """Full IMEX steps.  Started from the reference's state after step 1: the very first step from the
+    analytically balanced initial state is excluded because sign(xi_dot ~ rounding noise) makes the
+    reference itself discontinuous there ('first-step sensitivity')."""
+    d = gu.load(fixture)
+    g, _ = gu.make_grid(ne, L, npatch)
+    o = Oracle(g)
+    o.set_state(0, gu.expand_compact(d, tags[0], g))
+    step = int(tags[0][4:])
+    for tag in tags[1:]:
+        while step < int(tag[4:]):
+            assert o.step_ars343(dt) == 0
+            step += 1
+        errs = gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, tag, g))
+        assert max(errs) < 1e-10, (tag, errs)
+    cs = g.checksum(o.get_state(0))
+    ref = d["checksum/" + tags[-1]]
+    assert abs(cs[0] - ref[0]) < 1e-11 * abs(ref[0])
+    assert abs(cs[4] - ref[4]) < 1e-12 * abs(ref[4])
+
+
+def test_known_answers_are_the_survey_values():
+    ka = json.load(open(os.path.join(gu.GOLDEN, "known_answers.json")))["jw_ne4_L10_dt200_ars343"]
+    # reference stdout, ne4 L10 ARS343 dt=200s
+    assert ka["initial"][0] == 7.536453292760709e+26
+    assert ka["step3"][0] == 7.536840678700595e+26
+    assert ka["step3"][1] == -2.629408997242810e+20
+    assert ka["step3"][3] == 3.205179299367944e+22
+
+
+def test_dgbsv_against_lapack():
+    """orc_dgbsv restates LAPACK dgbsv (partial pivoting); pinned against scipy's LAPACK."""
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(7)
+    for n, kl, ku in ((18, 4, 4), (93, 4, 4), (12, 1, 1), (33, 4, 4)):
+        ldab = 2 * kl + ku + 1
+        A = np.zeros((n, n))
+        for i in range(n):
+            for j in range(max(0, i - kl), min(n, i + ku + 1)):
+                A[i, j] = rng.standard_normal() * (1e3 if (i + j) % 3 == 0 else 1.0)
+        A[np.arange(n), np.arange(n)] *= 1e-2       # weak diagonal: forces row interchanges
+        b = rng.standard_normal(n)
+        ab = np.zeros((n, ldab))                     # ab[j][kl+ku+i-j]
+        for j in range(n):
+            for i in range(max(0, j - ku), min(n, j + kl + 1)):
+                ab[j, kl + ku + i - j] = A[i, j]
+        info, x, ipiv = dgbsv(ab, b, kl, ku)
+        assert info == 0
+        lub, piv, xr, info2 = lapack.dgbsv(kl, ku, np.asfortranarray(ab.T), b)
+        assert info2 == 0
+        assert np.array_equal(ipiv, piv)
+        assert np.max(np.abs(x - xr)) <= 1e-12 * np.max(np.abs(xr))
+        assert np.sum(ipiv != np.arange(n)) > 0
