@@ -1,0 +1,216 @@
+/* tempest_mi355x.h -- C ABI of the MI355X-native spectral-element dynamics engine.
+ *
+ * Drop-in boundary for ONE path of paullric/tempestmodel: the per-GridPatch RHS evaluation
+ * (HorizontalDynamicsFEM / VerticalDynamicsFEM), the ARS343 IMEX stage loop and the DSS / halo
+ * exchange.  Every entry point names the reference interface it stands in for (file:line under
+ * the reference tree).  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * All functions return 0 on success and a negative TMX_ERR_* code on failure;
+ * tmx_last_error() then returns a message (the reference convention is `throw Exception(...)`,
+ * src/base/Exception.h:25-49 -- the host adapter turns a non-zero return into _EXCEPTIONT).
+ * The library is not re-entrant: one engine <-> one host thread <-> one GPU, exactly as one
+ * reference MPI rank is one thread.
+ *
+ * Interchange layout = the reference's own patch layout (src/atm/GridPatch.cpp:341-356,
+ * src/base/DataArray4D.h:123-231): per patch, row-major
+ *     node  [5][na][nb][L]      redge [5][na][nb][L+1]     na = 4*elems_a + 2, nb = 4*elems_b + 2
+ * with a one-node halo ring and duplicated element-edge nodes; variable order U,V,rho*theta,W,rho
+ * (src/atm/EquationSet.cpp:51-84).  The engine keeps its own element-major layout in HBM
+ *  and converts on upload / download.
+ *
+ * Supported configuration (anything else -> TMX_ERR_UNSUPPORTED): horizontal order np = 4,
+ * FE vertical order 1, Lorenz staggering (W on interfaces), FORMULATION_RHOTHETA_PI,
+ * USE_DIRECTSOLVE + USE_JACOBIAN_DIAGONAL, upwinding on all variables, Clark-form implicit W
+ * advection, hyperviscosity order 4, no tracers (src/atm/Defines.h:23-80,
+ * src/atm/VerticalDynamicsFEM.cpp:33-47).
+ */
+#ifndef TEMPEST_MI355X_H
+#define TEMPEST_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMX_ABI_VERSION 1
+
+#define TMX_OK                 0
+#define TMX_ERR_INVALID       -1   /* bad argument / call order                      */
+#define TMX_ERR_UNSUPPORTED   -2   /* configuration outside the supported path      */
+#define TMX_ERR_DEVICE        -3   /* HIP runtime error                             */
+#define TMX_ERR_SINGULAR      -4   /* column solve hit an exactly zero pivot        */
+#define TMX_ERR_COMM          -5   /* RCCL error                                    */
+
+typedef struct tmx_engine tmx_engine;
+
+/* column operators, in the order of GridGLL::GetOp* (src/atm/GridGLL.h:299-355) */
+enum {
+	TMX_OP_INTERP_NODE_TO_REDGE = 0,
+	TMX_OP_INTERP_REDGE_TO_NODE,
+	TMX_OP_DIFF_NODE_TO_NODE,
+	TMX_OP_DIFF_NODE_TO_REDGE,
+	TMX_OP_DIFF_REDGE_TO_NODE,
+	TMX_OP_DIFF_REDGE_TO_REDGE,
+	TMX_OP_DIFFDIFF_NODE_TO_NODE,
+	TMX_OP_DIFFDIFF_REDGE_TO_REDGE,
+	TMX_OP_PENALTY_LEFT,
+	TMX_OP_PENALTY_RIGHT,
+	TMX_OP_COUNT
+};
+
+/* Scalar configuration.  Sources in the reference: Grid parameters (src/atm/Grid.h:626-816),
+ * PhysicalConstants (src/atm/PhysicalConstants.h:120-135, read AFTER Model::SetTestCase),
+ * HorizontalDynamicsFEM constructor arguments (src/atm/HorizontalDynamicsFEM.h:42-50),
+ * TimestepScheme::GetComponentDataInstances (src/atm/TimestepScheme.h:54-60). */
+typedef struct {
+	int    abi_version;        /* TMX_ABI_VERSION                                              */
+	int    horizontal_order;   /* np; must be 4                                                */
+	int    vertical_order;     /* must be 1                                                    */
+	int    levels;             /* Grid::GetRElements()                                         */
+	int    n_patches;          /* total number of patches of the grid (all ranks)              */
+	int    n_instances;        /* state instances per patch (ARS343: 7)                        */
+	int    n_tracers;          /* must be 0                                                    */
+	int    hypervis_order;     /* 0 or 4                                                       */
+	double element_delta_a;    /* GridPatchGLL::GetElementDeltaA()                             */
+	double reference_length;   /* Grid::GetReferenceLength()                                   */
+	double grav, Rd, cp, p0;   /* PhysicalConstants::GetG/GetR/GetCp/GetP0                     */
+	double nu_scalar, nu_div, nu_vort;
+	int    rank, n_ranks;      /* this process / number of processes sharing the grid          */
+	int    device;             /* HIP device ordinal, -1 = current                             */
+} tmx_config;
+
+/* Geometry of one patch, reference-layout pointers (accessors src/atm/GridPatch.h:482-740).
+ * Arrays are read during the call only. */
+typedef struct {
+	const double * jacobian2d;             /* [na][nb]          GetJacobian2D           */
+	const double * contra_metric_2d_a;     /* [na][nb][2]       GetContraMetric2DA      */
+	const double * contra_metric_2d_b;     /* [na][nb][2]       GetContraMetric2DB      */
+	const double * jacobian;               /* [na][nb][L]       GetJacobian             */
+	const double * jacobian_redge;         /* [na][nb][L+1]     GetJacobianREdge        */
+	const double * contra_metric_a;        /* [na][nb][L][3]    GetContraMetricA        */
+	const double * contra_metric_b;        /* [na][nb][L][3]    GetContraMetricB        */
+	const double * contra_metric_xi;       /* [na][nb][L][3]    GetContraMetricXi       */
+	const double * contra_metric_a_redge;  /* [na][nb][L+1][3]  GetContraMetricAREdge   */
+	const double * contra_metric_b_redge;  /* [na][nb][L+1][3]  GetContraMetricBREdge   */
+	const double * contra_metric_xi_redge; /* [na][nb][L+1][3]  GetContraMetricXiREdge  */
+	const double * deriv_r_node;           /* [na][nb][L][3]    GetDerivRNode           */
+	const double * deriv_r_redge;          /* [na][nb][L+1][3]  GetDerivRREdge          */
+	const double * coriolis_f;             /* [na][nb]          GetCoriolisF            */
+} tmx_patch_geometry;
+
+/* ---- life cycle ---------------------------------------------------------------------------- */
+
+/* Replaces the constructors + Initialize() of HorizontalDynamicsFEM / VerticalDynamicsFEM /
+ * TimestepSchemeARS343 (src/atm/HorizontalDynamicsFEM.cpp:61-209,
+ * src/atm/VerticalDynamicsFEM.cpp:95-435, src/atm/TimestepSchemeARS343.cpp:25-146). */
+int tmx_create(const tmx_config * cfg, tmx_engine ** out);
+void tmx_destroy(tmx_engine * e);
+const char * tmx_last_error(void);
+
+/* GridGLL::GetDxBasis1D / GetStiffness1D (src/atm/GridGLL.h:268-290) and the ten column operators
+ * (LinearColumnOperator::GetCoeffs/GetIxBegin/GetIxEnd, src/atm/LinearColumnOperator.h).
+ * dx_basis[s*4+i] = dDxBasis1D(s,i); stiffness[i*4+s] = dStiffness1D(i,s);
+ * coeff[op] is dense [n_out][n_in] row-major. */
+int tmx_set_operators(tmx_engine * e, const double * dx_basis, const double * stiffness,
+	const double * const * coeff, const int * const * ix_begin, const int * const * ix_end,
+	const int * n_out, const int * n_in);
+
+/* One call per patch of the WHOLE grid, on every rank (PatchBox, src/atm/PatchBox.h; owner =
+ * Grid::DistributePatches, src/atm/Grid.cpp:1038-1062; neighbor_panels = GridPatch::GetNeighborPanel
+ * in Direction order Right,Top,Left,Bottom,TopRight,TopLeft,BottomLeft,BottomRight, -1 = none). */
+int tmx_define_patch(tmx_engine * e, int patch, int panel, int elems_a, int elems_b, int owner_rank,
+	const int * neighbor_panels);
+
+/* Halo ring of one patch (every patch, every rank): ring node (halo_i, halo_j) mirrors interior node
+ * (src_i, src_j) of patch src_patch (-1: no source, cube corner); trans[n][2][2] is the covector
+ * panel transform applied to (U,V) arriving there.  Stands in for the ExchangeBuffer registry and
+ * GridPatchCSGLL::TransformHaloVelocities (src/atm/Connectivity.cpp:797-924,
+ * src/atm/GridPatchCSGLL.cpp:1783-1924, src/atm/CubedSphereTrans.h:1751-1823). */
+int tmx_set_patch_halo(tmx_engine * e, int patch, int n, const int * halo_i, const int * halo_j,
+	const int * src_patch, const int * src_i, const int * src_j, const int * src_panel,
+	const double * trans);
+
+/* Geometry of a patch owned by this rank (GridPatchCSGLL::EvaluateGeometricTerms output,
+ * src/atm/GridPatchCSGLL.cpp:295-574). */
+int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch_geometry * g);
+
+/* Builds the HBM layout, DSS groups, unique-column lists and exchange plan. */
+int tmx_finalize(tmx_engine * e);
+
+/* ---- state transfer (GridPatch::GetDataState, src/atm/GridPatch.h:806-870) ------------------ */
+
+/* Reads the prognostic slots of interior nodes (U,V,rho*theta,rho from node; W from redge). */
+int tmx_upload_state(tmx_engine * e, int patch, int instance, const double * node, const double * redge);
+/* Writes interior nodes: prognostic slots, plus the derived slots the reference keeps beside them
+ * (W on levels, U,V on interfaces: HorizontalDynamicsFEM.cpp:817-831).  Halo ring untouched. */
+int tmx_download_state(tmx_engine * e, int patch, int instance, double * node, double * redge);
+
+/* ---- stage algebra (Grid::CopyData / ZeroData / LinearCombineData, src/atm/Grid.cpp:1585-1621) */
+int tmx_copy_data(tmx_engine * e, int src, int dst);
+int tmx_zero_data(tmx_engine * e, int ix);
+int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int n_coeff, int dst);
+
+/* ---- dynamics ------------------------------------------------------------------------------ */
+
+/* HorizontalDynamicsFEM::StepExplicit -> StepNonhydrostaticPrimitive
+ * (src/atm/HorizontalDynamicsFEM.cpp:1787-1863, 701-1783). */
+int tmx_h_step_explicit(tmx_engine * e, int i_initial, int i_update, double dt);
+/* VerticalDynamicsFEM::StepExplicit, implicit mode (src/atm/VerticalDynamicsFEM.cpp:616-1159). */
+int tmx_v_step_explicit(tmx_engine * e, int i_initial, int i_update, double dt);
+/* VerticalDynamicsFEM::StepImplicit (src/atm/VerticalDynamicsFEM.cpp:1230-1638): one Newton step
+ * per unique column with the analytic band Jacobian and a dgbsv-equivalent pivoted band LU. */
+int tmx_v_step_implicit(tmx_engine * e, int i_initial, int i_update, double dt);
+/* GridGLL::PostProcessSubstage(State) = GridCSGLL::ApplyDSS incl. Grid::Exchange
+ * (src/atm/GridGLL.cpp:571-583, src/atm/GridCSGLL.cpp:435-781, src/atm/Grid.cpp:627-685). */
+int tmx_apply_dss(tmx_engine * e, int instance);
+/* HorizontalDynamicsFEM::StepAfterSubCycle (src/atm/HorizontalDynamicsFEM.cpp:2637-2726). */
+int tmx_h_step_after_subcycle(tmx_engine * e, int i_initial, int i_update, int i_working, double dt);
+
+/* TimestepSchemeARS343::Step (src/atm/TimestepSchemeARS343.cpp:150-236): the whole IMEX step,
+ * resident on the device, asynchronous on the engine's stream. */
+int tmx_step_ars343(tmx_engine * e, double dt);
+
+/* Wait for the engine's stream; reports a deferred TMX_ERR_SINGULAR from column solves. */
+int tmx_sync(tmx_engine * e);
+
+/* ---- multi-GPU (one engine per rank) -------------------------------------------------------- */
+
+/* 128-byte RCCL unique id, created on rank 0 and broadcast by the host (the reference's
+ * MPI_COMM_WORLD, src/atm/TempestInitialize.h:715-727). */
+int tmx_comm_unique_id(unsigned char id[128]);
+int tmx_comm_init(tmx_engine * e, const unsigned char id[128]);
+
+/* ---- introspection for tests / bench --------------------------------------------------------- */
+
+enum {
+	TMX_INFO_LOCAL_COLUMNS = 0,   /* stored columns (16 per element) on this rank        */
+	TMX_INFO_UNIQUE_COLUMNS,      /* columns solved by the implicit step                */
+	TMX_INFO_DSS_GROUPS,          /* co-located node groups touching this rank          */
+	TMX_INFO_LOCAL_ELEMENTS,
+	TMX_INFO_GHOST_COLUMNS,       /* remote copies received per exchange                */
+	TMX_INFO_HBM_BYTES            /* device bytes allocated (low 31 bits of MiB)        */
+};
+long long tmx_info(tmx_engine * e, int what);
+
+/* Host-side DSS / exchange plan, for tests of the multi-rank logic (works on an engine created with
+ * cfg.device = -2, "plan only": no HIP call is made and no kernel can be launched).
+ * what = 0: send list, quadruples (patch, i, j, dest_rank) in wire order
+ * what = 1: receive list, quadruples (patch, i, j, src_rank) in ghost-buffer order
+ * what = 2: DSS groups, (n, col0..col3) with col >= NS meaning ghost NS + index
+ * what = 3: (NS, ncol, n_unique, n_groups, n_cross_panel_groups)
+ * Returns the number of ints written (needed, when out == NULL), -1 on error. */
+int tmx_plan_get(tmx_engine * e, int what, int * out, int cap);
+
+/* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.
+ * kernel ids: TMX_K_* below.  Profiling is off by default (no events recorded). */
+enum {
+	TMX_K_H_EXPLICIT = 0, TMX_K_V_EXPLICIT, TMX_K_VI_ASSEMBLE, TMX_K_VI_SOLVE, TMX_K_DSS,
+	TMX_K_HYPERVIS, TMX_K_LINCOMB, TMX_K_EXCHANGE, TMX_K_COUNT
+};
+int tmx_profile_enable(tmx_engine * e, int on);
+int tmx_profile_get(tmx_engine * e, int kernel, double * total_ms, long long * launches);
+int tmx_profile_reset(tmx_engine * e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEMPEST_MI355X_H */

@@ -1,0 +1,923 @@
+// tmx_host.hip -- host side of the engine: C ABI, HBM layout, DSS groups, exchange plan, step drivers.
+#include "tmx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <numeric>
+
+// ---------------------------------------------------------------------------------------------
+// errors
+
+static thread_local std::string g_err;
+
+void tmx_set_error(const char * fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_err = buf;
+}
+
+extern "C" const char * tmx_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+	tmx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); return TMX_ERR_DEVICE; } } while (0)
+
+#define REQUIRE(cond, code, ...) do { if (!(cond)) { tmx_set_error(__VA_ARGS__); return (code); } } while (0)
+
+static bool plan_only(const tmx_engine * e) { return e->cfg.device == -2; }
+
+// ---------------------------------------------------------------------------------------------
+// RCCL, resolved at run time so the library loads without it (single-GPU use, CPU symbol checks)
+
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_ncclGetUniqueId)(nccl_uid *);
+typedef int (*fn_ncclCommInitRank)(void **, int, nccl_uid, int);
+typedef int (*fn_ncclCommDestroy)(void *);
+typedef int (*fn_ncclGroupStart)(void);
+typedef int (*fn_ncclGroupEnd)(void);
+typedef int (*fn_ncclSend)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_ncclRecv)(void *, size_t, int, int, void *, hipStream_t);
+typedef const char * (*fn_ncclGetErrorString)(int);
+
+static struct {
+	void * lib = nullptr;
+	fn_ncclGetUniqueId GetUniqueId = nullptr;
+	fn_ncclCommInitRank CommInitRank = nullptr;
+	fn_ncclCommDestroy CommDestroy = nullptr;
+	fn_ncclGroupStart GroupStart = nullptr;
+	fn_ncclGroupEnd GroupEnd = nullptr;
+	fn_ncclSend Send = nullptr;
+	fn_ncclRecv Recv = nullptr;
+	fn_ncclGetErrorString GetErrorString = nullptr;
+} g_nccl;
+
+static int load_rccl() {
+	if (g_nccl.Send) return TMX_OK;
+	// prefer an RCCL already in the process (torch ships its own); otherwise the ROCm one
+	void * h = dlopen(nullptr, RTLD_NOW | RTLD_GLOBAL);
+	if (!h || !dlsym(h, "ncclSend")) {
+		const char * names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", nullptr };
+		h = nullptr;
+		for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+	}
+	REQUIRE(h != nullptr, TMX_ERR_COMM, "RCCL not found (librccl.so)");
+	g_nccl.lib = h;
+	g_nccl.GetUniqueId = (fn_ncclGetUniqueId)dlsym(h, "ncclGetUniqueId");
+	g_nccl.CommInitRank = (fn_ncclCommInitRank)dlsym(h, "ncclCommInitRank");
+	g_nccl.CommDestroy = (fn_ncclCommDestroy)dlsym(h, "ncclCommDestroy");
+	g_nccl.GroupStart = (fn_ncclGroupStart)dlsym(h, "ncclGroupStart");
+	g_nccl.GroupEnd = (fn_ncclGroupEnd)dlsym(h, "ncclGroupEnd");
+	g_nccl.Send = (fn_ncclSend)dlsym(h, "ncclSend");
+	g_nccl.Recv = (fn_ncclRecv)dlsym(h, "ncclRecv");
+	g_nccl.GetErrorString = (fn_ncclGetErrorString)dlsym(h, "ncclGetErrorString");
+	REQUIRE(g_nccl.GetUniqueId && g_nccl.CommInitRank && g_nccl.Send && g_nccl.Recv && g_nccl.GroupStart && g_nccl.GroupEnd,
+		TMX_ERR_COMM, "RCCL symbols missing");
+	return TMX_OK;
+}
+
+#define NCCLCHK(call) do { int _r = (call); if (_r != 0) { \
+	tmx_set_error("%s failed: %s", #call, g_nccl.GetErrorString ? g_nccl.GetErrorString(_r) : "?"); return TMX_ERR_COMM; } } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// profiling helper: bracket a launch sequence with events on the engine's stream
+
+struct ProfScope {
+	tmx_engine * e; int id; hipEvent_t a = nullptr, b = nullptr;
+	ProfScope(tmx_engine * e_, int id_) : e(e_), id(id_) {
+		if (e->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+	}
+	~ProfScope() {
+		if (e->prof) { hipEventRecord(b, e->stream); e->prof_pending.push_back({ id, { a, b } }); }
+	}
+};
+
+static void prof_collect(tmx_engine * e) {
+	for (auto & pe : e->prof_pending) {
+		float ms = 0.f;
+		hipEventSynchronize(pe.second.second);
+		hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+		e->prof_slots[pe.first].ms += ms;
+		e->prof_slots[pe.first].n += 1;
+		hipEventDestroy(pe.second.first);
+		hipEventDestroy(pe.second.second);
+	}
+	e->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// life cycle
+
+extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
+	REQUIRE(cfg && out, TMX_ERR_INVALID, "tmx_create: null argument");
+	REQUIRE(cfg->abi_version == TMX_ABI_VERSION, TMX_ERR_INVALID, "tmx_create: ABI version %d, library is %d", cfg->abi_version, TMX_ABI_VERSION);
+	REQUIRE(cfg->horizontal_order == TMX_NP, TMX_ERR_UNSUPPORTED, "horizontal order %d unsupported (np = 4 only)", cfg->horizontal_order);
+	REQUIRE(cfg->vertical_order == 1, TMX_ERR_UNSUPPORTED, "vertical order %d unsupported (1 only)", cfg->vertical_order);
+	REQUIRE(cfg->n_tracers == 0, TMX_ERR_UNSUPPORTED, "tracers unsupported");
+	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0 or 4)", cfg->hypervis_order);
+	REQUIRE(cfg->levels >= 3, TMX_ERR_INVALID, "levels must be >= 3");
+	REQUIRE(cfg->n_patches >= 1 && cfg->n_instances >= 1, TMX_ERR_INVALID, "bad patch / instance count");
+	REQUIRE(cfg->n_ranks >= 1 && cfg->rank >= 0 && cfg->rank < cfg->n_ranks, TMX_ERR_INVALID, "bad rank %d of %d", cfg->rank, cfg->n_ranks);
+	tmx_engine * e = new tmx_engine();
+	e->cfg = *cfg;
+	e->L = cfg->levels;
+	e->patches.resize(cfg->n_patches);
+	e->nslab = 5 * e->L + 1;
+	if (!plan_only(e)) {
+		int ndev = 0;
+		hipError_t r = hipGetDeviceCount(&ndev);
+		if (r != hipSuccess || ndev == 0) {
+			delete e;
+			tmx_set_error("tmx_create: no HIP device available (%s); this engine has no CPU path", hipGetErrorString(r));
+			return TMX_ERR_DEVICE;
+		}
+		if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); }
+		HIPCHK(hipGetDevice(&e->device));
+		HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+	}
+	*out = e;
+	return TMX_OK;
+}
+
+static void free_dev(void * p) { if (p) hipFree(p); }
+static void g_plans_erase(tmx_engine * e);
+
+extern "C" void tmx_destroy(tmx_engine * e) {
+	if (!e) return;
+	if (!plan_only(e)) {
+		if (e->stream) hipStreamSynchronize(e->stream);
+		prof_collect(e);
+		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
+		free_dev(e->d_state); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
+		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_ucol); free_dev(e->d_udep);
+		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
+		if (e->stream) hipStreamDestroy(e->stream);
+	}
+	g_plans_erase(e);
+	delete e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operators
+
+extern "C" int tmx_set_operators(tmx_engine * e, const double * dx_basis, const double * stiffness,
+	const double * const * coeff, const int * const * ix_begin, const int * const * ix_end,
+	const int * n_out, const int * n_in)
+{
+	REQUIRE(e && dx_basis && stiffness && coeff && ix_begin && ix_end && n_out && n_in, TMX_ERR_INVALID, "tmx_set_operators: null argument");
+	const int L = e->L;
+	memcpy(e->h_dx, dx_basis, sizeof(double) * 16);
+	memcpy(e->h_stiff, stiffness, sizeof(double) * 16);
+	// expected shapes (GridGLL.cpp:278-362)
+	const int exp_out[TMX_OP_COUNT] = { L + 1, L, L, L + 1, L, L + 1, L, L + 1, L, L };
+	const int exp_in[TMX_OP_COUNT]  = { L, L + 1, L, L, L + 1, L + 1, L, L + 1, L, L };
+	// offsets each kernel is written for (vertical order 1 stencils)
+	const int lo[TMX_OP_COUNT] = { -2, 0, -1, -1, 0, -1, -1, -1, 0, -1 };
+	const int hi[TMX_OP_COUNT] = { 1, 1, 1, 0, 1, 1, 1, 1, 1, 0 };
+	e->h_ops.assign((size_t)TMX_OP_COUNT * (L + 1) * TMX_OPW, 0.0);
+	for (int op = 0; op < TMX_OP_COUNT; op++) {
+		REQUIRE(n_out[op] == exp_out[op] && n_in[op] == exp_in[op], TMX_ERR_INVALID,
+			"operator %d has shape %dx%d, expected %dx%d", op, n_out[op], n_in[op], exp_out[op], exp_in[op]);
+		for (int k = 0; k < n_out[op]; k++) {
+			for (int l = ix_begin[op][k]; l < ix_end[op][k]; l++) {
+				const double c = coeff[op][(size_t)k * n_in[op] + l];
+				if (c == 0.0) continue;
+				const int off = l - k;
+				REQUIRE(off >= lo[op] && off <= hi[op], TMX_ERR_UNSUPPORTED,
+					"operator %d row %d has a coefficient at offset %d outside the vertical-order-1 stencil", op, k, off);
+				e->h_ops[((size_t)op * (L + 1) + k) * TMX_OPW + (off + 2)] = c;
+			}
+		}
+	}
+	e->ops_set = true;
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// patches, halos, layout
+
+extern "C" int tmx_define_patch(tmx_engine * e, int patch, int panel, int elems_a, int elems_b, int owner_rank,
+	const int * neighbor_panels)
+{
+	REQUIRE(e && neighbor_panels, TMX_ERR_INVALID, "tmx_define_patch: null argument");
+	REQUIRE(!e->finalized && e->ne_local == 0, TMX_ERR_INVALID, "tmx_define_patch after layout was fixed");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index %d out of range", patch);
+	REQUIRE(elems_a > 0 && elems_b > 0 && panel >= 0 && panel < 6, TMX_ERR_INVALID, "bad patch box");
+	REQUIRE(owner_rank >= 0 && owner_rank < e->cfg.n_ranks, TMX_ERR_INVALID, "owner rank %d out of range", owner_rank);
+	PatchInfo & P = e->patches[patch];
+	P.defined = true; P.panel = panel; P.nea = elems_a; P.neb = elems_b;
+	P.na = TMX_NP * elems_a + 2; P.nb = TMX_NP * elems_b + 2; P.owner = owner_rank;
+	memcpy(P.nbp, neighbor_panels, sizeof(int) * 8);
+	return TMX_OK;
+}
+
+extern "C" int tmx_set_patch_halo(tmx_engine * e, int patch, int n, const int * halo_i, const int * halo_j,
+	const int * src_patch, const int * src_i, const int * src_j, const int * src_panel, const double * trans)
+{
+	REQUIRE(e && halo_i && halo_j && src_patch && src_i && src_j && src_panel && trans, TMX_ERR_INVALID, "tmx_set_patch_halo: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].defined, TMX_ERR_INVALID, "patch %d not defined", patch);
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_patch_halo after tmx_finalize");
+	PatchInfo & P = e->patches[patch];
+	P.hi.assign(halo_i, halo_i + n); P.hj.assign(halo_j, halo_j + n);
+	P.hsp.assign(src_patch, src_patch + n); P.hsi.assign(src_i, src_i + n); P.hsj.assign(src_j, src_j + n);
+	P.hspanel.assign(src_panel, src_panel + n);
+	P.htrans.assign(trans, trans + (size_t)4 * n);
+	for (int m = 0; m < n; m++) {
+		REQUIRE(P.hi[m] >= 0 && P.hi[m] < P.na && P.hj[m] >= 0 && P.hj[m] < P.nb, TMX_ERR_INVALID, "halo node out of range");
+		REQUIRE(P.hsp[m] < e->cfg.n_patches, TMX_ERR_INVALID, "halo source patch out of range");
+	}
+	P.halo_set = true;
+	return TMX_OK;
+}
+
+static int ensure_layout(tmx_engine * e) {
+	if (e->ne_local > 0) return TMX_OK;
+	int ne = 0;
+	e->local_patches.clear();
+	for (int p = 0; p < e->cfg.n_patches; p++) {
+		PatchInfo & P = e->patches[p];
+		REQUIRE(P.defined, TMX_ERR_INVALID, "patch %d was never defined", p);
+		if (P.owner == e->cfg.rank) { P.elem_base = ne; ne += P.nea * P.neb; e->local_patches.push_back(p); }
+	}
+	REQUIRE(ne > 0, TMX_ERR_INVALID, "rank %d owns no patch", e->cfg.rank);
+	e->ne_local = ne;
+	e->ncol = ne * TMX_NQ;
+	e->NS = ((e->ncol + TMX_TILE - 1) / TMX_TILE) * TMX_TILE;
+	e->inst_stride = (size_t)e->nslab * e->NS;
+	const size_t NS = e->NS; const int L = e->L;
+	e->h_g2d.assign((size_t)G2_COUNT * NS, 0.0);
+	e->h_g3n.assign((size_t)G3N_COUNT * L * NS, 0.0);
+	e->h_g3e.assign((size_t)G3E_COUNT * (L + 1) * NS, 0.0);
+	// benign values in the padding columns
+	for (size_t c = e->ncol; c < NS; c++) { e->h_g2d[G2_J2D * NS + c] = 1.0; e->h_g2d[G2_JN * NS + c] = 1.0; e->h_g2d[G2_JE * NS + c] = 1.0; }
+	return TMX_OK;
+}
+
+// column index of local node (i,j) (reference patch-local indices, 1-based interior) of a local patch
+static inline int col_of(const PatchInfo & P, int i, int j) {
+	const int a = (i - 1) / TMX_NP, ii = (i - 1) % TMX_NP, b = (j - 1) / TMX_NP, jj = (j - 1) % TMX_NP;
+	return (P.elem_base + a * P.neb + b) * TMX_NQ + ii * TMX_NP + jj;
+}
+
+extern "C" int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch_geometry * g) {
+	REQUIRE(e && g, TMX_ERR_INVALID, "tmx_set_patch_geometry: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_patch_geometry after tmx_finalize");
+	int r = ensure_layout(e);
+	if (r) return r;
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
+	const int L = e->L, nb = P.nb;
+	const size_t NS = e->NS;
+	for (int i = 1; i < P.na - 1; i++)
+	for (int j = 1; j < P.nb - 1; j++) {
+		const int c = col_of(P, i, j);
+		const size_t ij = (size_t)i * nb + j;
+		e->h_g2d[G2_J2D * NS + c] = g->jacobian2d[ij];
+		e->h_g2d[G2_F * NS + c] = g->coriolis_f[ij];
+		e->h_g2d[G2_C2A0 * NS + c] = g->contra_metric_2d_a[ij * 2 + 0];
+		e->h_g2d[G2_C2A1 * NS + c] = g->contra_metric_2d_a[ij * 2 + 1];
+		e->h_g2d[G2_C2B1 * NS + c] = g->contra_metric_2d_b[ij * 2 + 1];
+		REQUIRE(g->contra_metric_2d_b[ij * 2 + 0] == g->contra_metric_2d_a[ij * 2 + 1], TMX_ERR_UNSUPPORTED, "2-D contravariant metric is not symmetric");
+		e->h_g2d[G2_JN * NS + c] = g->jacobian[ij * L];
+		e->h_g2d[G2_JE * NS + c] = g->jacobian_redge[ij * (L + 1)];
+		e->h_g2d[G2_DRX * NS + c] = g->deriv_r_node[(ij * L) * 3 + 2];
+		for (int k = 0; k < L; k++) {
+			const size_t o = (ij * L + k) * 3;
+			// structure of the reference metric (GridPatchCSGLL.cpp:444-494): level-independent
+			// Jacobian / d_xi R, horizontal block equal to the 2-D metric, symmetric cross terms
+			REQUIRE(g->jacobian[ij * L + k] == g->jacobian[ij * L] &&
+			        g->deriv_r_node[o + 2] == g->deriv_r_node[(ij * L) * 3 + 2] &&
+			        g->contra_metric_a[o + 0] == g->contra_metric_2d_a[ij * 2 + 0] &&
+			        g->contra_metric_a[o + 1] == g->contra_metric_2d_a[ij * 2 + 1] &&
+			        g->contra_metric_b[o + 0] == g->contra_metric_2d_b[ij * 2 + 0] &&
+			        g->contra_metric_b[o + 1] == g->contra_metric_2d_b[ij * 2 + 1] &&
+			        g->contra_metric_xi[o + 0] == g->contra_metric_a[o + 2] &&
+			        g->contra_metric_xi[o + 1] == g->contra_metric_b[o + 2],
+			        TMX_ERR_UNSUPPORTED, "node metric of patch %d does not have the Gal-Chen structure the engine stores", patch);
+			const size_t d = (size_t)k * NS + c, s3 = (size_t)L * NS;
+			e->h_g3n[G3N_CA2 * s3 + d] = g->contra_metric_a[o + 2];
+			e->h_g3n[G3N_CB2 * s3 + d] = g->contra_metric_b[o + 2];
+			e->h_g3n[G3N_CX2 * s3 + d] = g->contra_metric_xi[o + 2];
+			e->h_g3n[G3N_DRA * s3 + d] = g->deriv_r_node[o + 0];
+			e->h_g3n[G3N_DRB * s3 + d] = g->deriv_r_node[o + 1];
+		}
+		for (int k = 0; k <= L; k++) {
+			const size_t o = (ij * (L + 1) + k) * 3;
+			REQUIRE(g->jacobian_redge[ij * (L + 1) + k] == g->jacobian_redge[ij * (L + 1)] &&
+			        g->deriv_r_redge[o + 2] == g->deriv_r_node[(ij * L) * 3 + 2] &&
+			        g->contra_metric_a_redge[o + 0] == g->contra_metric_2d_a[ij * 2 + 0] &&
+			        g->contra_metric_a_redge[o + 1] == g->contra_metric_2d_a[ij * 2 + 1] &&
+			        g->contra_metric_b_redge[o + 0] == g->contra_metric_2d_b[ij * 2 + 0] &&
+			        g->contra_metric_b_redge[o + 1] == g->contra_metric_2d_b[ij * 2 + 1] &&
+			        g->contra_metric_xi_redge[o + 0] == g->contra_metric_a_redge[o + 2] &&
+			        g->contra_metric_xi_redge[o + 1] == g->contra_metric_b_redge[o + 2],
+			        TMX_ERR_UNSUPPORTED, "interface metric of patch %d does not have the Gal-Chen structure the engine stores", patch);
+			const size_t d = (size_t)k * NS + c, s3 = (size_t)(L + 1) * NS;
+			e->h_g3e[G3E_CX0 * s3 + d] = g->contra_metric_xi_redge[o + 0];
+			e->h_g3e[G3E_CX1 * s3 + d] = g->contra_metric_xi_redge[o + 1];
+			e->h_g3e[G3E_CX2 * s3 + d] = g->contra_metric_xi_redge[o + 2];
+		}
+	}
+	P.geom_set = true;
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: DSS groups, unique columns, exchange plan, device buffers
+
+struct NodeRef { int patch, i, j; };
+
+static int uf_find(std::vector<int> & par, int x) {
+	while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; }
+	return x;
+}
+
+template <class T> static int dev_upload(T ** d, const std::vector<T> & h, size_t * bytes) {
+	const size_t n = h.size() ? h.size() : 1;
+	HIPCHK(hipMalloc((void **)d, n * sizeof(T)));
+	if (h.size()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+	*bytes += n * sizeof(T);
+	return TMX_OK;
+}
+
+// plan data kept on the host for introspection (tests of the N>1 logic)
+struct PlanHost {
+	std::vector<int> grp_cols, grp_n, grp_x;
+	std::vector<double> xmat;
+	std::vector<int> send_nodes;   // triples (patch,i,j) in send order
+	std::vector<int> recv_nodes;   // triples (patch,i,j) in ghost order
+	std::vector<int> send_cols;
+	std::vector<int> ucol, udep;
+};
+static std::map<tmx_engine *, PlanHost> g_plans;
+static void g_plans_erase(tmx_engine * e) { g_plans.erase(e); }
+
+extern "C" int tmx_finalize(tmx_engine * e) {
+	REQUIRE(e, TMX_ERR_INVALID, "tmx_finalize: null engine");
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_finalize called twice");
+	REQUIRE(e->ops_set, TMX_ERR_INVALID, "tmx_set_operators must precede tmx_finalize");
+	int r = ensure_layout(e);
+	if (r) return r;
+	const int np = e->cfg.n_patches, me = e->cfg.rank, NR = e->cfg.n_ranks;
+	for (int p = 0; p < np; p++) {
+		REQUIRE(e->patches[p].halo_set, TMX_ERR_INVALID, "halo of patch %d not set", p);
+		if (e->patches[p].owner == me && !plan_only(e))
+			REQUIRE(e->patches[p].geom_set, TMX_ERR_INVALID, "geometry of local patch %d not set", p);
+	}
+	PlanHost & plan = g_plans[e];
+
+	// ---- union-find over all interior nodes of all patches
+	std::vector<size_t> poff(np + 1, 0);
+	for (int p = 0; p < np; p++) poff[p + 1] = poff[p] + (size_t)e->patches[p].na * e->patches[p].nb;
+	std::vector<int> par(poff[np]);
+	std::iota(par.begin(), par.end(), 0);
+	auto nid = [&](int p, int i, int j) { return (int)(poff[p] + (size_t)i * e->patches[p].nb + j); };
+	auto unite = [&](int a, int b) { a = uf_find(par, a); b = uf_find(par, b); if (a != b) par[std::max(a, b)] = std::min(a, b); };
+	for (int p = 0; p < np; p++) {
+		const PatchInfo & P = e->patches[p];
+		for (int a = 1; a < P.nea; a++) for (int j = 1; j < P.nb - 1; j++) unite(nid(p, a * TMX_NP, j), nid(p, a * TMX_NP + 1, j));
+		for (int b = 1; b < P.neb; b++) for (int i = 1; i < P.na - 1; i++) unite(nid(p, i, b * TMX_NP), nid(p, i, b * TMX_NP + 1));
+		for (size_t m = 0; m < P.hi.size(); m++) {
+			if (P.hsp[m] < 0) continue;
+			const int xi = std::min(std::max(P.hi[m], 1), P.na - 2), xj = std::min(std::max(P.hj[m], 1), P.nb - 2);
+			const PatchInfo & Q = e->patches[P.hsp[m]];
+			REQUIRE(P.hsi[m] >= 1 && P.hsi[m] < Q.na - 1 && P.hsj[m] >= 1 && P.hsj[m] < Q.nb - 1, TMX_ERR_INVALID, "halo source is not an interior node");
+			unite(nid(p, xi, xj), nid(P.hsp[m], P.hsi[m], P.hsj[m]));
+		}
+	}
+	// members per root
+	std::map<int, std::vector<int>> comps;
+	for (int p = 0; p < np; p++) {
+		const PatchInfo & P = e->patches[p];
+		for (int i = 1; i < P.na - 1; i++) for (int j = 1; j < P.nb - 1; j++) {
+			const bool edge = ((i - 1) % TMX_NP == 0) || ((i - 1) % TMX_NP == TMX_NP - 1) || ((j - 1) % TMX_NP == 0) || ((j - 1) % TMX_NP == TMX_NP - 1);
+			if (!edge) continue;
+			comps[uf_find(par, nid(p, i, j))].push_back(nid(p, i, j));
+		}
+	}
+	auto node_of = [&](int id) {
+		int p = (int)(std::upper_bound(poff.begin(), poff.end(), (size_t)id) - poff.begin()) - 1;
+		const int loc = id - (int)poff[p];
+		return NodeRef{ p, loc / e->patches[p].nb, loc % e->patches[p].nb };
+	};
+	// panel transform lookup: (dst patch node adjacent to a ring entry whose source panel is sp) -> matrix
+	auto find_trans = [&](const NodeRef & dst, int src_panel, double * M) -> bool {
+		const PatchInfo & P = e->patches[dst.patch];
+		for (size_t m = 0; m < P.hi.size(); m++) {
+			if (P.hsp[m] < 0 || P.hspanel[m] != src_panel) continue;
+			const int xi = std::min(std::max(P.hi[m], 1), P.na - 2), xj = std::min(std::max(P.hj[m], 1), P.nb - 2);
+			if (xi == dst.i && xj == dst.j) { memcpy(M, &P.htrans[4 * m], 4 * sizeof(double)); return true; }
+		}
+		return false;
+	};
+
+	// ---- exchange lists: (owner s -> needer r) node ids
+	std::vector<std::vector<int>> send_to(NR), recv_from(NR);
+	struct Grp { std::vector<int> ids; };
+	std::vector<Grp> groups;
+	for (auto & kv : comps) {
+		std::vector<int> & ids = kv.second;
+		if (ids.size() < 2) continue;
+		REQUIRE(ids.size() <= 4, TMX_ERR_INVALID, "DSS group with %d members (connectivity is inconsistent)", (int)ids.size());
+		std::sort(ids.begin(), ids.end());
+		bool local = false;
+		for (int id : ids) if (e->patches[node_of(id).patch].owner == me) local = true;
+		if (!local) continue;
+		groups.push_back(Grp{ ids });
+		for (int a : ids) for (int b : ids) {
+			const int oa = e->patches[node_of(a).patch].owner, ob = e->patches[node_of(b).patch].owner;
+			if (oa == me && ob != me) send_to[ob].push_back(a);
+			if (oa != me && ob == me) recv_from[oa].push_back(a);
+		}
+	}
+	e->send_rank_off.assign(NR + 1, 0); e->recv_rank_off.assign(NR + 1, 0);
+	std::map<int, int> ghost_index;
+	for (int rk = 0; rk < NR; rk++) {
+		auto uniq = [](std::vector<int> & v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+		uniq(send_to[rk]); uniq(recv_from[rk]);
+		e->send_rank_off[rk + 1] = e->send_rank_off[rk] + (int)send_to[rk].size();
+		e->recv_rank_off[rk + 1] = e->recv_rank_off[rk] + (int)recv_from[rk].size();
+		for (size_t t = 0; t < recv_from[rk].size(); t++) {
+			ghost_index[recv_from[rk][t]] = e->recv_rank_off[rk] + (int)t;
+			NodeRef nr = node_of(recv_from[rk][t]);
+			plan.recv_nodes.insert(plan.recv_nodes.end(), { nr.patch, nr.i, nr.j });
+		}
+		for (int id : send_to[rk]) {
+			NodeRef nr = node_of(id);
+			plan.send_nodes.insert(plan.send_nodes.end(), { nr.patch, nr.i, nr.j });
+			plan.send_cols.push_back(col_of(e->patches[nr.patch], nr.i, nr.j));
+		}
+	}
+	e->nsend = e->send_rank_off[NR];
+	e->nghost = e->recv_rank_off[NR];
+	e->nghost_pad = std::max(e->nghost, 1);
+
+	// ---- device group tables
+	e->ngroups = (int)groups.size();
+	plan.grp_cols.assign((size_t)e->ngroups * 4, -1);
+	plan.grp_n.assign(e->ngroups, 0);
+	plan.grp_x.assign(e->ngroups, -1);
+	for (int g = 0; g < e->ngroups; g++) {
+		const std::vector<int> & ids = groups[g].ids;
+		plan.grp_n[g] = (int)ids.size();
+		bool cross = false;
+		for (size_t m = 0; m < ids.size(); m++) {
+			NodeRef nr = node_of(ids[m]);
+			const PatchInfo & P = e->patches[nr.patch];
+			plan.grp_cols[(size_t)g * 4 + m] = (P.owner == me) ? col_of(P, nr.i, nr.j) : e->NS + ghost_index[ids[m]];
+			if (P.panel != e->patches[node_of(ids[0]).patch].panel) cross = true;
+		}
+		if (cross) {
+			plan.grp_x[g] = (int)(plan.xmat.size() / 32);
+			const NodeRef f = node_of(ids[0]);
+			const int fpanel = e->patches[f.patch].panel;
+			double M[32];
+			for (int m = 0; m < 4; m++) { double * A = M + m * 8; A[0] = 1; A[1] = 0; A[2] = 0; A[3] = 1; A[4] = 1; A[5] = 0; A[6] = 0; A[7] = 1; }
+			for (size_t m = 0; m < ids.size(); m++) {
+				NodeRef nr = node_of(ids[m]);
+				const int mp = e->patches[nr.patch].panel;
+				if (mp == fpanel) continue;
+				// A: member panel -> frame panel (looked up at a frame-panel member); B: frame -> member panel
+				bool okA = false, okB = find_trans(nr, fpanel, M + m * 8 + 4);
+				for (size_t t = 0; t < ids.size() && !okA; t++) {
+					NodeRef nt = node_of(ids[t]);
+					if (e->patches[nt.patch].panel == fpanel) okA = find_trans(nt, mp, M + m * 8);
+				}
+				REQUIRE(okA && okB, TMX_ERR_INVALID, "missing covector transform between panels %d and %d", mp, fpanel);
+			}
+			plan.xmat.insert(plan.xmat.end(), M, M + 32);
+		}
+	}
+	e->nxgroups = (int)(plan.xmat.size() / 32);
+
+	// ---- unique columns of the implicit solve and their in-patch duplicates (VerticalDynamicsFEM.cpp:1315-1337, 1543-1633)
+	for (int p : e->local_patches) {
+		const PatchInfo & P = e->patches[p];
+		for (int a = 0; a < P.nea; a++) for (int b = 0; b < P.neb; b++)
+		for (int ii = 0; ii < TMX_NP; ii++) for (int jj = 0; jj < TMX_NP; jj++) {
+			const bool ua = (ii < TMX_NP - 1) || (a == P.nea - 1), ub = (jj < TMX_NP - 1) || (b == P.neb - 1);
+			if (!ua || !ub) continue;
+			const int i = 1 + a * TMX_NP + ii, j = 1 + b * TMX_NP + jj;
+			plan.ucol.push_back(col_of(P, i, j));
+			const bool da = (ii == 0 && a > 0), db = (jj == 0 && b > 0);
+			plan.udep.push_back(da ? col_of(P, i - 1, j) : -1);
+			plan.udep.push_back(db ? col_of(P, i, j - 1) : -1);
+			plan.udep.push_back((da && db) ? col_of(P, i - 1, j - 1) : -1);
+		}
+	}
+	e->nunique = (int)plan.ucol.size();
+	e->NUS = ((e->nunique + 63) / 64) * 64;
+	e->finalized = true;
+	if (plan_only(e)) return TMX_OK;
+
+	// ---- device allocation + upload
+	HIPCHK(hipSetDevice(e->device));
+	size_t bytes = 0;
+	const size_t NS = e->NS; const int L = e->L;
+	const size_t state_bytes = (size_t)e->cfg.n_instances * e->inst_stride * sizeof(double);
+	HIPCHK(hipMalloc((void **)&e->d_state, state_bytes)); bytes += state_bytes;
+	HIPCHK(hipMemset(e->d_state, 0, state_bytes));
+	if ((r = dev_upload(&e->d_g2d, e->h_g2d, &bytes))) return r;
+	if ((r = dev_upload(&e->d_g3n, e->h_g3n, &bytes))) return r;
+	if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
+	if ((r = dev_upload(&e->d_ops, e->h_ops, &bytes))) return r;
+	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)L * NS * sizeof(double))); bytes += (size_t)L * NS * sizeof(double);
+	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)L * NS * sizeof(double)));
+	if ((r = dev_upload(&e->d_grp_cols, plan.grp_cols, &bytes))) return r;
+	if ((r = dev_upload(&e->d_grp_n, plan.grp_n, &bytes))) return r;
+	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
+	if ((r = dev_upload(&e->d_xmat, plan.xmat, &bytes))) return r;
+	if ((r = dev_upload(&e->d_send_cols, plan.send_cols, &bytes))) return r;
+	if ((r = dev_upload(&e->d_ucol, plan.ucol, &bytes))) return r;
+	if ((r = dev_upload(&e->d_udep, plan.udep, &bytes))) return r;
+	const size_t gb = (size_t)e->nslab * e->nghost_pad * sizeof(double), sb = (size_t)e->nslab * std::max(e->nsend, 1) * sizeof(double);
+	HIPCHK(hipMalloc((void **)&e->d_ghost, gb)); HIPCHK(hipMemset(e->d_ghost, 0, gb)); bytes += gb;
+	HIPCHK(hipMalloc((void **)&e->d_sendbuf, sb)); bytes += sb;
+	const int n = TMX_FTOT * (L + 1);
+	const size_t abb = (size_t)n * TMX_BW * e->NUS * sizeof(double), rb = (size_t)n * e->NUS * sizeof(double);
+	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); bytes += abb;
+	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
+	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	e->hbm_bytes = bytes;
+	// host staging no longer needed
+	std::vector<double>().swap(e->h_g2d); std::vector<double>().swap(e->h_g3n); std::vector<double>().swap(e->h_g3e);
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// state transfer
+
+static int check_state_args(tmx_engine * e, int patch, int instance) {
+	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not local", patch);
+	REQUIRE(instance >= 0 && instance < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range", instance);
+	return TMX_OK;
+}
+
+extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const double * node, const double * redge) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(node && redge, TMX_ERR_INVALID, "tmx_upload_state: null array");
+	const PatchInfo & P = e->patches[patch];
+	const int L = e->L, na = P.na, nb = P.nb;
+	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
+	std::vector<double> buf((size_t)e->nslab * ncp);
+	const int nodevar[4] = { 0, 1, 2, 4 };
+	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j) - c0;
+		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
+			buf[(size_t)(v * L + k) * ncp + c] = node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k];
+		for (int k = 0; k <= L; k++)
+			buf[(size_t)(4 * L + k) * ncp + c] = redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k];
+	}
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + c0, (size_t)e->NS * sizeof(double),
+		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), e->nslab, hipMemcpyHostToDevice));
+	return TMX_OK;
+}
+
+extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, double * node, double * redge) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(node && redge, TMX_ERR_INVALID, "tmx_download_state: null array");
+	const PatchInfo & P = e->patches[patch];
+	const int L = e->L, na = P.na, nb = P.nb;
+	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
+	std::vector<double> buf((size_t)e->nslab * ncp);
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy2D(buf.data(), (size_t)ncp * sizeof(double), e->d_state + (size_t)instance * e->inst_stride + c0,
+		(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), e->nslab, hipMemcpyDeviceToHost));
+	const int nodevar[4] = { 0, 1, 2, 4 };
+	const double * ops = e->h_ops.data();
+	auto opc = [&](int op, int k, int off) { return ops[((size_t)op * (L + 1) + k) * TMX_OPW + (off + 2)]; };
+	std::vector<double> colU(L), colV(L), colW(L + 1);
+	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j) - c0;
+		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
+			node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k] = buf[(size_t)(v * L + k) * ncp + c];
+		for (int k = 0; k <= L; k++)
+			redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k] = buf[(size_t)(4 * L + k) * ncp + c];
+		// derived slots the reference keeps beside the prognostic ones (HorizontalDynamicsFEM.cpp:817-831)
+		for (int k = 0; k < L; k++) { colU[k] = buf[(size_t)(0 * L + k) * ncp + c]; colV[k] = buf[(size_t)(1 * L + k) * ncp + c]; }
+		for (int k = 0; k <= L; k++) colW[k] = buf[(size_t)(4 * L + k) * ncp + c];
+		for (int k = 0; k < L; k++) {
+			double w = 0.0;
+			w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * colW[k];
+			w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * colW[k + 1];
+			node[(((size_t)3 * na + i) * nb + j) * L + k] = w;
+		}
+		for (int k = 0; k <= L; k++) {
+			double ue = 0.0, ve = 0.0;
+			for (int off = -2; off <= 1; off++) {
+				const int l = k + off;
+				if (l < 0 || l >= L) continue;
+				const double cc = opc(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
+				if (cc == 0.0) continue;
+				ue += cc * colU[l]; ve += cc * colV[l];
+			}
+			redge[(((size_t)0 * na + i) * nb + j) * (L + 1) + k] = ue;
+			redge[(((size_t)1 * na + i) * nb + j) * (L + 1) + k] = ve;
+		}
+	}
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel parameter block
+
+static KParams make_params(const tmx_engine * e) {
+	KParams p;
+	p.L = e->L; p.ncol = e->ncol; p.NS = e->NS;
+	p.g2d = e->d_g2d; p.g3n = e->d_g3n; p.g3e = e->d_g3e; p.ops = e->d_ops;
+	p.inv_da = 1.0 / e->cfg.element_delta_a;
+	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
+	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
+	return p;
+}
+
+static int check_ready(tmx_engine * e) {
+	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
+	return TMX_OK;
+}
+static int check_inst(tmx_engine * e, int ix) {
+	REQUIRE(ix >= 0 && ix < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range [0,%d)", ix, e->cfg.n_instances);
+	return TMX_OK;
+}
+static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)ix * e->inst_stride; }
+
+static int launch_check(const char * what) {
+	hipError_t r = hipGetLastError();
+	if (r != hipSuccess) { tmx_set_error("%s: %s", what, hipGetErrorString(r)); return TMX_ERR_DEVICE; }
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage algebra
+
+extern "C" int tmx_copy_data(tmx_engine * e, int src, int dst) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, src)) || (r = check_inst(e, dst))) return r;
+	if (src == dst) return TMX_OK;
+	ProfScope ps(e, TMX_K_LINCOMB);
+	HIPCHK(hipMemcpyAsync(inst(e, dst), inst(e, src), e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	return TMX_OK;
+}
+
+extern "C" int tmx_zero_data(tmx_engine * e, int ix) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
+	HIPCHK(hipMemsetAsync(inst(e, ix), 0, e->inst_stride * sizeof(double), e->stream));
+	return TMX_OK;
+}
+
+extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int n_coeff, int dst) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, dst))) return r;
+	REQUIRE(coeff && n_coeff > dst && n_coeff <= e->cfg.n_instances, TMX_ERR_INVALID,
+		"linear_combine_data: %d coefficients for destination %d and %d instances", n_coeff, dst, e->cfg.n_instances);
+	const double * src[8]; double cf[8];
+	int n = 1;
+	src[0] = inst(e, dst); cf[0] = coeff[dst];
+	for (int m = 0; m < n_coeff; m++) {
+		if (m == dst || coeff[m] == 0.0) continue;
+		REQUIRE(n < 8, TMX_ERR_UNSUPPORTED, "linear_combine_data: more than 7 source terms");
+		src[n] = inst(e, m); cf[n] = coeff[m]; n++;
+	}
+	ProfScope ps(e, TMX_K_LINCOMB);
+	tmxk_lincomb(e, e->inst_stride, inst(e, dst), n, src, cf, coeff[dst] != 0.0 ? 1 : 0);
+	return launch_check("lincomb");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dynamics
+
+extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
+	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
+	ProfScope ps(e, TMX_K_H_EXPLICIT);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	return launch_check("h_step_explicit");
+}
+
+extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "V StepExplicit: initial and update data instance must be distinct");
+	ProfScope ps(e, TMX_K_V_EXPLICIT);
+	tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	return launch_check("v_step_explicit");
+}
+
+extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
+	KParams p = make_params(e);
+	{ ProfScope ps(e, TMX_K_VI_ASSEMBLE); tmxk_vi_assemble(e, p, inst(e, iinit), dt); }
+	{ ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_solve(e, p, inst(e, iinit), inst(e, iupd)); }
+	return launch_check("v_step_implicit");
+}
+
+static int exchange(tmx_engine * e, const KParams & p, double * x) {
+	if (e->cfg.n_ranks == 1 || (e->nsend == 0 && e->nghost == 0)) return TMX_OK;
+	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
+	ProfScope ps(e, TMX_K_EXCHANGE);
+	// sendbuf / ghost are laid out [slab][n]; one send/recv per (peer, slab run) would be many small
+	// messages, so the per-peer segments are sent slab by slab inside ONE group call.
+	tmxk_pack(e, p, x);
+	NCCLCHK(g_nccl.GroupStart());
+	for (int rk = 0; rk < e->cfg.n_ranks; rk++) {
+		const int ns = e->send_rank_off[rk + 1] - e->send_rank_off[rk], nr = e->recv_rank_off[rk + 1] - e->recv_rank_off[rk];
+		for (int sl = 0; sl < e->nslab; sl++) {
+			if (ns) NCCLCHK(g_nccl.Send(e->d_sendbuf + (size_t)sl * e->nsend + e->send_rank_off[rk], (size_t)ns, 8 /* ncclFloat64 */, rk, e->comm, e->stream));
+			if (nr) NCCLCHK(g_nccl.Recv(e->d_ghost + (size_t)sl * e->nghost_pad + e->recv_rank_off[rk], (size_t)nr, 8, rk, e->comm, e->stream));
+		}
+	}
+	NCCLCHK(g_nccl.GroupEnd());
+	return TMX_OK;
+}
+
+extern "C" int tmx_apply_dss(tmx_engine * e, int ix) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
+	KParams p = make_params(e);
+	if ((r = exchange(e, p, inst(e, ix)))) return r;
+	ProfScope ps(e, TMX_K_DSS);
+	tmxk_dss(e, p, inst(e, ix));
+	return launch_check("apply_dss");
+}
+
+extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd)) || (r = check_inst(e, iwork))) return r;
+	// preconditions of the reference (HorizontalDynamicsFEM.cpp:2648-2655)
+	REQUIRE(iinit != iwork, TMX_ERR_INVALID, "StepAfterSubCycle: initial and working data must be distinct");
+	REQUIRE(iupd != iwork, TMX_ERR_INVALID, "StepAfterSubCycle: working and update data must be distinct");
+	const tmx_config & c = e->cfg;
+	if ((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0) return tmx_copy_data(e, iinit, iupd);
+	KParams p = make_params(e);
+	double scale = 1.0;
+	if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
+	{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0); }
+	if ((r = launch_check("hypervis pass 1"))) return r;
+	if ((r = tmx_apply_dss(e, iwork))) return r;
+	{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale); }
+	if ((r = launch_check("hypervis pass 2"))) return r;
+	return tmx_apply_dss(e, iupd);
+}
+
+// ARS(3,4,3) tableau in U-form (TimestepSchemeARS343.cpp:25-146)
+static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp, double * dimp) {
+	const double gm = 0.4358665215084590;
+	const double b1 = -1.5 * gm * gm + 4.0 * gm - 0.25;
+	const double b2 = 1.5 * gm * gm - 5.0 * gm + 1.25;
+	const double a42 = 0.5529291480359398, a43 = 0.5529291480359398;
+	const double a31 = (1.0 - 4.5 * gm + 1.5 * gm * gm) * a42 + (2.75 - 10.5 * gm + 3.75 * gm * gm) * a43 - 3.5 + 13 * gm - 4.5 * gm * gm;
+	const double a32 = (-1.0 + 4.5 * gm - 1.5 * gm * gm) * a42 + (-2.75 + 10.5 * gm - 3.75 * gm * gm) * a43 + 4.0 - 12.5 * gm + 4.5 * gm * gm;
+	const double a41 = 1.0 - a42 - a43;
+	const double I[4][4] = { { gm, 0, 0, 0 }, { 0.5 * (1.0 - gm), gm, 0, 0 }, { b1, b2, gm, 0 }, { b1, b2, gm, 0 } };
+	const double E[4][4] = { { gm, 0, 0, 0 }, { a31, a32, 0, 0 }, { a41, a42, a43, 0 }, { 0, b1, b2, gm } };
+	for (int i = 0; i < 4; i++) { dexp[i] = E[i][i]; dimp[i] = I[i][i]; }
+	for (int i = 0; i < 7; i++) u2[i] = u3[i] = u4[i] = 0.0;
+	u2[0] = 1.0 - E[1][0] / E[0][0]; u2[1] = E[1][0] / E[0][0] - I[1][0] / I[0][0]; u2[2] = I[1][0] / I[0][0];
+	u3[0] = 1.0 - E[2][0] / E[0][0]; u3[1] = E[2][0] / E[0][0] - I[2][0] / I[0][0]; u3[2] = I[2][0] / I[0][0];
+	u3[3] = E[2][1] / E[1][1] - I[2][1] / I[1][1]; u3[4] = I[2][1] / I[1][1];
+	const double u37 = -E[2][1] / E[1][1];
+	u4[0] = 1.0 - E[3][0] / E[0][0]; u4[1] = E[3][0] / E[0][0] - I[3][0] / I[0][0]; u4[2] = I[3][0] / I[0][0];
+	u4[3] = E[3][1] / E[1][1] - I[3][1] / I[1][1]; u4[4] = I[3][1] / I[1][1];
+	u4[5] = E[3][2] / E[2][2] - I[3][2] / I[2][2]; u4[6] = I[3][2] / I[2][2];
+	const double u47 = -E[3][1] / E[1][1], u48 = -E[3][2] / E[2][2];
+	u3[0] += u37 * u2[0]; u3[1] += u37 * u2[1]; u3[2] += u37 * u2[2];
+	u4[0] += u47 * u2[0] + u48 * u3[0]; u4[1] += u47 * u2[1] + u48 * u3[1]; u4[2] += u47 * u2[2] + u48 * u3[2];
+	u4[3] += u48 * u3[3]; u4[4] += u48 * u3[4];
+}
+
+extern "C" int tmx_step_ars343(tmx_engine * e, double dt) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(e->cfg.n_instances >= 7, TMX_ERR_INVALID, "ARS343 needs 7 data instances (TimestepSchemeARS343.h:48-56), engine has %d", e->cfg.n_instances);
+	double u2[7], u3[7], u4[7], de[4], di[4];
+	ars343_tableau(u2, u3, u4, de, di);
+#define STEP(call) do { if ((r = (call))) return r; } while (0)
+	STEP(tmx_copy_data(e, 0, 1));
+	STEP(tmx_h_step_explicit(e, 0, 1, de[0] * dt));
+	STEP(tmx_v_step_explicit(e, 0, 1, de[0] * dt));
+	STEP(tmx_apply_dss(e, 1));
+	STEP(tmx_copy_data(e, 1, 2));
+	STEP(tmx_v_step_implicit(e, 2, 2, di[0] * dt));
+	STEP(tmx_linear_combine_data(e, u2, 7, 3));
+	STEP(tmx_h_step_explicit(e, 2, 3, de[1] * dt));
+	STEP(tmx_v_step_explicit(e, 2, 3, de[1] * dt));
+	STEP(tmx_apply_dss(e, 3));
+	STEP(tmx_copy_data(e, 3, 4));
+	STEP(tmx_v_step_implicit(e, 4, 4, di[1] * dt));
+	STEP(tmx_linear_combine_data(e, u3, 7, 5));
+	STEP(tmx_h_step_explicit(e, 4, 5, de[2] * dt));
+	STEP(tmx_v_step_explicit(e, 4, 5, de[2] * dt));
+	STEP(tmx_apply_dss(e, 5));
+	STEP(tmx_copy_data(e, 5, 6));
+	STEP(tmx_v_step_implicit(e, 6, 6, di[2] * dt));
+	STEP(tmx_linear_combine_data(e, u4, 7, 1));
+	STEP(tmx_h_step_explicit(e, 6, 1, de[3] * dt));
+	STEP(tmx_v_step_explicit(e, 6, 1, de[3] * dt));
+	STEP(tmx_apply_dss(e, 1));
+	STEP(tmx_copy_data(e, 1, 0));
+	STEP(tmx_h_step_after_subcycle(e, 1, 0, 2, dt));
+#undef STEP
+	return TMX_OK;
+}
+
+extern "C" int tmx_sync(tmx_engine * e) {
+	int r; if ((r = check_ready(e))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));
+	prof_collect(e);
+	int flag = 0;
+	HIPCHK(hipMemcpy(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+	if (flag) {
+		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+		tmx_set_error("column solve failed: exactly singular band matrix (LAPACK dgbsv info > 0)");
+		return TMX_ERR_SINGULAR;
+	}
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU
+
+extern "C" int tmx_comm_unique_id(unsigned char id[128]) {
+	int r = load_rccl();
+	if (r) return r;
+	nccl_uid u;
+	NCCLCHK(g_nccl.GetUniqueId(&u));
+	memcpy(id, u.internal, 128);
+	return TMX_OK;
+}
+
+extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
+	REQUIRE(e && id && !plan_only(e), TMX_ERR_INVALID, "tmx_comm_init: bad argument");
+	int r = load_rccl();
+	if (r) return r;
+	HIPCHK(hipSetDevice(e->device));
+	nccl_uid u;
+	memcpy(u.internal, id, 128);
+	NCCLCHK(g_nccl.CommInitRank(&e->comm, e->cfg.n_ranks, u, e->cfg.rank));
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// introspection
+
+extern "C" long long tmx_info(tmx_engine * e, int what) {
+	if (!e) return -1;
+	switch (what) {
+		case TMX_INFO_LOCAL_COLUMNS: return e->ncol;
+		case TMX_INFO_UNIQUE_COLUMNS: return e->nunique;
+		case TMX_INFO_DSS_GROUPS: return e->ngroups;
+		case TMX_INFO_LOCAL_ELEMENTS: return e->ne_local;
+		case TMX_INFO_GHOST_COLUMNS: return e->nghost;
+		case TMX_INFO_HBM_BYTES: return (long long)e->hbm_bytes;
+	}
+	return -1;
+}
+
+// exchange / DSS plan for host-side tests: what = 0 send nodes (patch,i,j,dest_rank), 1 recv nodes
+// (patch,i,j,src_rank), 2 groups (n, then 4 x column-or-NS+ghost).  Returns the number of ints written
+// (or needed when out == nullptr).
+extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
+	if (!e || !e->finalized) return -1;
+	PlanHost & plan = g_plans[e];
+	std::vector<int> v;
+	if (what == 0 || what == 1) {
+		const std::vector<int> & nodes = what ? plan.recv_nodes : plan.send_nodes;
+		const std::vector<int> & off = what ? e->recv_rank_off : e->send_rank_off;
+		for (int rk = 0; rk < e->cfg.n_ranks; rk++)
+			for (int t = off[rk]; t < off[rk + 1]; t++) { v.push_back(nodes[3 * t]); v.push_back(nodes[3 * t + 1]); v.push_back(nodes[3 * t + 2]); v.push_back(rk); }
+	} else if (what == 2) {
+		for (int g = 0; g < e->ngroups; g++) { v.push_back(plan.grp_n[g]); for (int m = 0; m < 4; m++) v.push_back(plan.grp_cols[(size_t)g * 4 + m]); }
+	} else if (what == 3) {
+		v.push_back(e->NS); v.push_back(e->ncol); v.push_back(e->nunique); v.push_back(e->ngroups); v.push_back(e->nxgroups);
+	} else return -1;
+	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
+	return (int)v.size();
+}
+
+extern "C" int tmx_profile_enable(tmx_engine * e, int on) {
+	REQUIRE(e, TMX_ERR_INVALID, "null engine");
+	e->prof = (on != 0);
+	return TMX_OK;
+}
+
+extern "C" int tmx_profile_get(tmx_engine * e, int kernel, double * total_ms, long long * launches) {
+	REQUIRE(e && kernel >= 0 && kernel < TMX_K_COUNT, TMX_ERR_INVALID, "bad kernel id");
+	if (!plan_only(e) && e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); }
+	if (total_ms) *total_ms = e->prof_slots[kernel].ms;
+	if (launches) *launches = e->prof_slots[kernel].n;
+	return TMX_OK;
+}
+
+extern "C" int tmx_profile_reset(tmx_engine * e) {
+	REQUIRE(e, TMX_ERR_INVALID, "null engine");
+	if (!plan_only(e) && e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); }
+	for (int i = 0; i < TMX_K_COUNT; i++) e->prof_slots[i] = ProfSlot();
+	return TMX_OK;
+}

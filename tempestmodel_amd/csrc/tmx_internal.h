@@ -1,0 +1,119 @@
+// tmx_internal.h -- engine internals shared by the host side (tmx_host.hip) and the kernels
+// (tmx_kernels.hip).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/tempest_mi355x.h"
+
+#define TMX_NP 4            // GLL nodes per element side (horizontal order 4)
+#define TMX_NQ 16           // nodes per element
+#define TMX_TILE 64         // columns per workgroup row = 4 elements = one wavefront
+#define TMX_FTOT 3          // unknowns per level of the implicit column system (rho*theta, W, rho)
+#define TMX_BW 9            // band entries per row of the column Jacobian (kl = ku = 4)
+
+// variable slabs inside one state instance: var v, level k -> slab index; every slab is NS doubles
+// U: [0,L)  V: [L,2L)  T(rho*theta): [2L,3L)  R(rho): [3L,4L)  W: [4L,5L]   (5L+1 slabs)
+#define TMX_SLAB_U(L,k) (k)
+#define TMX_SLAB_V(L,k) ((L) + (k))
+#define TMX_SLAB_T(L,k) (2 * (L) + (k))
+#define TMX_SLAB_R(L,k) (3 * (L) + (k))
+#define TMX_SLAB_W(L,k) (4 * (L) + (k))
+
+// 2-D (per column) geometry slabs
+enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_COUNT };
+// 3-D node geometry [field][L][NS]
+enum { G3N_CA2 = 0, G3N_CB2, G3N_CX2, G3N_DRA, G3N_DRB, G3N_COUNT };
+// 3-D interface geometry [field][L+1][NS]
+enum { G3E_CX0 = 0, G3E_CX1, G3E_CX2, G3E_COUNT };
+
+// column operators in relative-offset form: coefficient of in[k+off], off = -2..+2
+#define TMX_OPW 5
+
+struct KParams {
+	int L, ncol, NS;
+	const double * g2d;     // [G2_COUNT][NS]
+	const double * g3n;     // [G3N_COUNT][L][NS]
+	const double * g3e;     // [G3E_COUNT][L+1][NS]
+	const double * ops;     // [TMX_OP_COUNT][L+1][TMX_OPW]
+	double inv_da;
+	double grav, Rd, cp, p0;
+	double dx[16];          // dx[s*4+i]    = dDxBasis1D(s,i)
+	double stiff[16];       // stiff[i*4+s] = dStiffness1D(i,s)
+};
+
+struct PatchInfo {
+	bool defined = false, halo_set = false, geom_set = false;
+	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
+	int nbp[8];
+	int elem_base = -1;                      // first local element, -1 if not owned
+	std::vector<int> hi, hj, hsp, hsi, hsj, hspanel;
+	std::vector<double> htrans;
+};
+
+struct ProfSlot { double ms = 0.0; long long n = 0; };
+
+struct tmx_engine {
+	tmx_config cfg;
+	int L = 0;
+	bool ops_set = false, finalized = false;
+	std::vector<PatchInfo> patches;
+	std::vector<int> local_patches;
+
+	// layout
+	int ne_local = 0, ncol = 0, NS = 0, nslab = 0;
+	size_t inst_stride = 0;
+
+	// host staging of geometry in device layout (filled by tmx_set_patch_geometry)
+	std::vector<double> h_g2d, h_g3n, h_g3e;
+	std::vector<double> h_ops;
+	double h_dx[16], h_stiff[16];
+
+	// device
+	int device = 0;
+	hipStream_t stream = nullptr;
+	double * d_state = nullptr;
+	double * d_g2d = nullptr, * d_g3n = nullptr, * d_g3e = nullptr, * d_ops = nullptr;
+	double * d_scratch = nullptr;            // [L][NS] (u x zeta)_xi hand-off between the two H kernels
+	// DSS
+	int ngroups = 0, nxgroups = 0, nghost = 0;
+	int * d_grp_cols = nullptr;              // [ngroups][4] column index (>= NS: ghost NS+idx), -1 = none
+	int * d_grp_n = nullptr;                 // [ngroups] member count (2..4); high bit 8 = cross-panel, index in bits 16+
+	int * d_grp_x = nullptr;                 // [ngroups] index into the cross-panel matrices or -1
+	double * d_xmat = nullptr;               // [nxgroups][4][2][4]: per member A (to frame) and B (from frame)
+	double * d_ghost = nullptr;              // [nslab][nghost_pad] received remote copies
+	double * d_sendbuf = nullptr;
+	int * d_send_cols = nullptr;
+	int nsend = 0, nghost_pad = 0;
+	std::vector<int> send_rank_off, recv_rank_off;   // per-rank offsets (size n_ranks+1)
+	// implicit solve
+	int nunique = 0, NUS = 0;
+	int * d_ucol = nullptr;                  // [nunique]
+	int * d_udep = nullptr;                  // [nunique][3] dependents (-1 = none)
+	double * d_ab = nullptr;                 // [3(L+1)*9][NUS] band rows, overwritten by U rows
+	double * d_rhs = nullptr;                // [3(L+1)][NUS]
+	int * d_flag = nullptr;                  // singular-pivot flag
+	size_t hbm_bytes = 0;
+
+	// comm
+	void * comm = nullptr;                   // ncclComm_t
+	void * nccl_lib = nullptr;
+
+	// profiling
+	bool prof = false;
+	ProfSlot prof_slots[TMX_K_COUNT];
+	std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+};
+
+void tmx_set_error(const char * fmt, ...);
+
+// kernel launchers (tmx_kernels.hip)
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);
+void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);
+void tmxk_dss(tmx_engine * e, const KParams & p, double * x);
+void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v);
+void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
+void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);

@@ -1,0 +1,803 @@
+// tmx_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the spectral-element hot path.
+//
+// HBM layout: every field is a stack of "slabs" of NS doubles, one slab per
+// (variable, level); inside a slab the index is the column  col = element*16 + i*4 + j
+// (i = alpha node, j = beta node of the 4x4 GLL element).  One wavefront = 64 consecutive
+// columns = 4 whole elements at one level, so every global access of a wavefront is one
+// contiguous 512-byte segment and the np x np contractions stay inside a 16-lane group.
+//
+// All kernels are HBM-bound fp64 stencil work: one thread per (column, level),
+// horizontal contractions through LDS, vertical stencils through neighbouring slabs (served by
+// L2 / Infinity Cache).  Compiled with -ffp-contract=off so the arithmetic follows the operation
+// order of the reference (which is built without FMA contraction).
+//
+// Reference behaviour restated (file:line under the reference tree) is cited per kernel.
+#include "tmx_internal.h"
+
+#define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads)
+
+#define OPC(op, k, off) p.ops[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+
+__device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double rt) {
+	// PhysicalConstants::ExnerPressureFromRhoTheta (src/atm/PhysicalConstants.h:397-399)
+	return p.cp * exp(p.Rd / (p.cp - p.Rd) * log(p.Rd / p.p0 * rt));
+}
+
+// ---------------------------------------------------------------------------------------------
+// H explicit, part 1: HorizontalDynamicsFEM::StepNonhydrostaticPrimitive, updates on levels
+// (src/atm/HorizontalDynamicsFEM.cpp:848-1421).  The prologue interpolations (:817-831) are
+// recomputed on the fly instead of being stored.  (u x zeta)_xi is handed to part 2 via `ucz`.
+
+__global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
+	double * __restrict__ xup, double * __restrict__ ucz, double dt)
+{
+	__shared__ double s[KT_H][9][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = threadIdx.y;
+	const int tid = ty * 64 + lane;
+	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const int k = blockIdx.y * KT_H + ty;
+	const bool act = (k < L) && (col < p.ncol);
+
+	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
+	double conUa = 0, conUb = 0, conUx = 0, dxua = 0, dxub = 0;
+	if (act) {
+		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
+		ua = xin[TMX_SLAB_U(L, k) * NS + col];
+		ub = xin[TMX_SLAB_V(L, k) * NS + col];
+		rt = xin[TMX_SLAB_T(L, k) * NS + col];
+		rh = xin[TMX_SLAB_R(L, k) * NS + col];
+		const double we0 = xin[TMX_SLAB_W(L, k) * NS + col];
+		const double we1 = xin[TMX_SLAB_W(L, k + 1) * NS + col];
+		const double uam = xin[TMX_SLAB_U(L, km) * NS + col], uap = xin[TMX_SLAB_U(L, kp) * NS + col];
+		const double ubm = xin[TMX_SLAB_V(L, km) * NS + col], ubp = xin[TMX_SLAB_V(L, kp) * NS + col];
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		jn = p.g2d[G2_JN * NS + col]; j2d = p.g2d[G2_J2D * NS + col]; fcor = p.g2d[G2_F * NS + col];
+		const size_t o3 = (size_t)k * NS + col, s3 = (size_t)L * NS;
+		ca2 = p.g3n[G3N_CA2 * s3 + o3]; cb2 = p.g3n[G3N_CB2 * s3 + o3]; cx2 = p.g3n[G3N_CX2 * s3 + o3];
+		dra = p.g3n[G3N_DRA * s3 + o3]; drb = p.g3n[G3N_DRB * s3 + o3];
+		// W on levels (InterpolateREdgeToNode, GridPatchGLL.cpp:111-143)
+		ux = 0.0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * we1;
+		// contravariant velocities, kinetic energy (:884-930)
+		conUa = c2a0 * ua + c2a1 * ub + ca2 * ux;
+		conUb = c2a1 * ua + c2b1 * ub + cb2 * ux;
+		conUx = ca2 * ua + cb2 * ub + cx2 * ux;
+		// vertical derivatives of the covariant velocities (DifferentiateNodeToNode, :975-982)
+		const double dm = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, -1), d0 = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 0), dp = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 1);
+		dxua = 0.0; dxua += dm * uam; dxua += d0 * ua; dxua += dp * uap;
+		dxub = 0.0; dxub += dm * ubm; dxub += d0 * ub; dxub += dp * ubp;
+	}
+	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
+	const double exn = act ? exner_from_rhotheta(p, rt) : 0.0;
+	const double fa = jn * conUa, fb = jn * conUb;
+	s[ty][0][lane] = ua;  s[ty][1][lane] = ub;  s[ty][2][lane] = ux;
+	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
+	s[ty][5][lane] = fa * rh; s[ty][6][lane] = fa * rt;
+	s[ty][7][lane] = fb * rh; s[ty][8][lane] = fb * rt;
+	__syncthreads();
+	if (!act) return;
+
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
+	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j;        // node (t, j)
+		const double D = sD[t * 4 + i], S = sS[i * 4 + t];
+		daub += s[ty][1][la] * D;
+		daux += s[ty][2][la] * D;
+		dap  += s[ty][3][la] * D;
+		dake += s[ty][4][la] * D;
+		darf -= s[ty][5][la] * S;
+		dapf -= s[ty][6][la] * S;
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int lb = eb + 4 * i + t;        // node (i, t)
+		const double D = sD[t * 4 + j], S = sS[j * 4 + t];
+		dbua += s[ty][0][lb] * D;
+		dbux += s[ty][2][lb] * D;
+		dbp  += s[ty][3][lb] * D;
+		dbke += s[ty][4][lb] * D;
+		dbrf -= s[ty][7][lb] * S;
+		dbpf -= s[ty][8][lb] * S;
+	}
+	const double ida = p.inv_da;
+	daub *= ida; daux *= ida; dbua *= ida; dbux *= ida;
+	darf *= ida; dbrf *= ida; dapf *= ida; dbpf *= ida;
+	dap *= ida; dbp *= ida; dake *= ida; dbke *= ida;
+
+	// u x zeta (:1011-1037)
+	const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
+	const double ucza = conUb * jzx - conUx * jzb;
+	const double uczb = conUx * jza - conUa * jzx;
+	const double uczx = -conUa * daux - conUb * dbux;
+
+	// pointwise updates (:1321-1421)
+	const double invJ = 1.0 / jn;
+	double upa = 0.0, upb = 0.0;
+	upa += ucza; upb += uczb;
+	upa += fcor * j2d * conUb;
+	upb -= fcor * j2d * conUa;
+	const double pgfa = dap * rt / rh, pgfb = dbp * rt / rh;
+	const double daphi = p.grav * dra, dbphi = p.grav * drb;
+	upa -= (pgfa + dake + daphi);
+	upb -= (pgfb + dbke + dbphi);
+	const size_t oU = TMX_SLAB_U(L, k) * NS + col, oV = TMX_SLAB_V(L, k) * NS + col;
+	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
+	xup[oU] += dt * upa;
+	xup[oV] += dt * upb;
+	xup[oR] -= dt * invJ * (darf + dbrf);
+	xup[oT] -= dt * invJ * (dapf + dbpf);
+	ucz[(size_t)k * NS + col] = uczx;
+}
+
+// H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
+// boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
+__global__ __launch_bounds__(256) void k_h_w_update(KParams p, double * __restrict__ xup,
+	const double * __restrict__ ucz, double dt)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + threadIdx.y;
+	if (k >= L || col >= p.ncol) return;
+	if (k == 0) {
+		double u0 = 0.0, v0 = 0.0;
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * xup[TMX_SLAB_U(L, 0) * NS + col];
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * xup[TMX_SLAB_U(L, 1) * NS + col];
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * xup[TMX_SLAB_V(L, 0) * NS + col];
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * xup[TMX_SLAB_V(L, 1) * NS + col];
+		const size_t s3 = (size_t)(L + 1) * NS;
+		const double cx0 = p.g3e[G3E_CX0 * s3 + col], cx1 = p.g3e[G3E_CX1 * s3 + col], cx2 = p.g3e[G3E_CX2 * s3 + col];
+		xup[TMX_SLAB_W(L, 0) * NS + col] = -(cx0 * u0 + cx1 * v0) / cx2;
+	} else {
+		double v = 0.0;
+		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
+		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
+		xup[TMX_SLAB_W(L, k) * NS + col] += dt * v;
+	}
+}
+
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
+	hipLaunchKernelGGL(k_h_explicit, grd, blk, 0, e->stream, p, xin, xup, e->d_scratch, dt);
+	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xup, (const double *)e->d_scratch, dt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// V explicit (implicit mode): xi_dot on interfaces and first-order upwind penalty on U,V
+// (src/atm/VerticalDynamicsFEM.cpp:816-828, 984-1023; LinearColumnOperatorFEM.cpp:1863-1888).
+
+__device__ __forceinline__ double xidot_edge(const KParams & p, const double * __restrict__ xin, int kk, int col) {
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	if (kk <= 0 || kk >= L) return 0.0;
+	// U,V on interfaces = InterpolateNodeToREdge of the node values (H prologue, :817-831)
+	double ue = 0.0, ve = 0.0;
+#pragma unroll
+	for (int off = -2; off <= 1; off++) {
+		const int l = kk + off;
+		if (l < 0 || l >= L) continue;
+		const double c = OPC(TMX_OP_INTERP_NODE_TO_REDGE, kk, off);
+		ue += c * xin[TMX_SLAB_U(L, l) * NS + col];
+		ve += c * xin[TMX_SLAB_V(L, l) * NS + col];
+	}
+	const double we = xin[TMX_SLAB_W(L, kk) * NS + col];
+	const size_t s3 = (size_t)(L + 1) * NS, o3 = (size_t)kk * NS + col;
+	return p.g3e[G3E_CX0 * s3 + o3] * ue + p.g3e[G3E_CX1 * s3 + o3] * ve + p.g3e[G3E_CX2 * s3 + o3] * we;
+}
+
+__global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __restrict__ xin,
+	double * __restrict__ xup, double dt)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + threadIdx.y;
+	if (k >= L || col >= p.ncol) return;
+	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
+	const double w_lo = dt * fabs(xidot_edge(p, xin, k, col));       // weight of interface k
+	const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
+#pragma unroll
+	for (int v = 0; v < 2; v++) {
+		const int sb = v * L;
+		const double x0 = xin[(size_t)(sb + k) * NS + col];
+		const double xm = xin[(size_t)(sb + km) * NS + col], xp = xin[(size_t)(sb + kp) * NS + col];
+		double out = xup[(size_t)(sb + k) * NS + col];
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * x0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * xp;
+			out += b * w_hi;
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * xm;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * x0;
+			out += b * w_lo;
+		}
+		xup[(size_t)(sb + k) * NS + col] = out;
+	}
+}
+
+void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_v_explicit, grd, blk, 0, e->stream, p, xin, xup, dt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DSS: average co-located copies (GridCSGLL::ApplyDSS, src/atm/GridCSGLL.cpp:435-781) expressed
+// per group of co-located nodes instead of per patch edge: 2 copies -> 1/2 sum, 4 -> pairwise
+// halves, 3 (cube corner) -> 1/3 sum.  (U,V) of copies on other panels are rotated with the
+// covector panel transform first (GridPatchCSGLL.cpp:1783-1924).  Copies owned by other ranks are
+// read from the ghost buffer filled by the exchange.
+
+__global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
+	int nghost_pad, int ngroups, const int * __restrict__ gcols, const int * __restrict__ gn,
+	const int * __restrict__ gx, const double * __restrict__ xmat)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int g = blockIdx.x * 64 + threadIdx.x;
+	const int kk = blockIdx.y * 4 + threadIdx.y;
+	if (g >= ngroups || kk > L) return;
+	const int n = gn[g];
+	int c[4];
+#pragma unroll
+	for (int m = 0; m < 4; m++) c[m] = gcols[g * 4 + m];
+	const int xi = gx[g];
+
+	auto ld = [&](int slab, int m) -> double {
+		const int cc = c[m];
+		return (cc < (int)NS) ? x[(size_t)slab * NS + cc] : ghost[(size_t)slab * nghost_pad + (cc - (int)NS)];
+	};
+	auto avg = [&](const double * v) -> double {
+		if (n == 2) return 0.5 * (v[0] + v[1]);
+		if (n == 4) return 0.5 * (0.5 * (v[0] + v[1]) + 0.5 * (v[2] + v[3]));
+		return (1.0 / 3.0) * (v[0] + v[1] + v[2]);
+	};
+	// scalar slabs
+	const int nsc = (kk < L) ? ((xi < 0) ? 5 : 3) : 1;
+	int slabs[5];
+	slabs[0] = TMX_SLAB_W(L, kk);
+	slabs[1] = TMX_SLAB_T(L, kk); slabs[2] = TMX_SLAB_R(L, kk);
+	slabs[3] = TMX_SLAB_U(L, kk); slabs[4] = TMX_SLAB_V(L, kk);
+	for (int t = 0; t < nsc; t++) {
+		double v[4] = { 0, 0, 0, 0 };
+		for (int m = 0; m < n; m++) v[m] = ld(slabs[t], m);
+		const double a = avg(v);
+		for (int m = 0; m < n; m++) if (c[m] < (int)NS) x[(size_t)slabs[t] * NS + c[m]] = a;
+	}
+	// covector (U,V) across panels: rotate every copy into the frame of member 0, average, rotate back
+	if (xi >= 0 && kk < L) {
+		const double * M = xmat + (size_t)xi * 32;
+		double va[4] = { 0, 0, 0, 0 }, vb[4] = { 0, 0, 0, 0 };
+		for (int m = 0; m < n; m++) {
+			const double ua = ld(TMX_SLAB_U(L, kk), m), ub = ld(TMX_SLAB_V(L, kk), m);
+			const double * A = M + m * 8;
+			va[m] = A[0] * ua + A[1] * ub;
+			vb[m] = A[2] * ua + A[3] * ub;
+		}
+		const double aa = avg(va), ab = avg(vb);
+		for (int m = 0; m < n; m++) {
+			if (c[m] >= (int)NS) continue;
+			const double * B = M + m * 8 + 4;
+			x[(size_t)TMX_SLAB_U(L, kk) * NS + c[m]] = B[0] * aa + B[1] * ab;
+			x[(size_t)TMX_SLAB_V(L, kk) * NS + c[m]] = B[2] * aa + B[3] * ab;
+		}
+	}
+}
+
+void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
+	if (e->ngroups == 0) return;
+	dim3 blk(64, 4), grd((e->ngroups + 63) / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, e->nghost_pad, e->ngroups,
+		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat);
+}
+
+// gather the copies other ranks need into the send buffer: sendbuf[slab][i] = x[slab][send_cols[i]]
+__global__ __launch_bounds__(256) void k_pack(int nslab, size_t NS, int nsend, int nsend_pad,
+	const double * __restrict__ x, const int * __restrict__ cols, double * __restrict__ buf)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int sl = blockIdx.y;
+	if (i >= nsend) return;
+	buf[(size_t)sl * nsend_pad + i] = x[(size_t)sl * NS + cols[i]];
+}
+
+void tmxk_pack(tmx_engine * e, const KParams & p, const double * x) {
+	if (e->nsend == 0) return;
+	dim3 blk(256), grd((e->nsend + 255) / 256, e->nslab);
+	hipLaunchKernelGGL(k_pack, grd, blk, 0, e->stream, e->nslab, (size_t)p.NS, e->nsend, e->nsend,
+		x, (const int *)e->d_send_cols, e->d_sendbuf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hyperviscosity pass: scalar Laplacian of rho*theta, W, rho and vector Laplacian of (U,V)
+// (ApplyScalarHyperdiffusion / ApplyVectorHyperdiffusion / ComputeCurlAndDiv,
+//  src/atm/HorizontalDynamicsFEM.cpp:1867-2203, 2207-2414; src/atm/GridPatchCSGLL.cpp:1132-1305).
+// out = base - dt * (...)(src); base = 0 when xbase == nullptr (first pass into the zeroed work
+// instance), otherwise the instance that StepAfterSubCycle copied into the update instance.
+
+__global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s, double nu_d, double nu_v)
+{
+	__shared__ double s[4][8][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = threadIdx.y;
+	const int tid = ty * 64 + lane;
+	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const int kk = blockIdx.y * 4 + ty;
+	const bool actw = (kk <= L) && (col < p.ncol);     // interface level (W)
+	const bool actn = (kk < L) && (col < p.ncol);      // model level (U,V,rho*theta,rho)
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+
+	double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
+	if (actw) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+	}
+	if (actn) {
+		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+		psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
+		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
+		ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+	}
+	const double cua = c2a0 * ua + c2a1 * ub;
+	const double cub = c2a1 * ua + c2b1 * ub;
+	s[ty][0][lane] = psiT; s[ty][1][lane] = psiR; s[ty][2][lane] = psiW;
+	s[ty][3][lane] = ua;   s[ty][4][lane] = ub;
+	s[ty][5][lane] = j2d * cua; s[ty][6][lane] = j2d * cub;
+	__syncthreads();
+
+	double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+		daT += s[ty][0][la] * Da; dbT += s[ty][0][lb] * Db;
+		daR += s[ty][1][la] * Da; dbR += s[ty][1][lb] * Db;
+		daW += s[ty][2][la] * Da; dbW += s[ty][2][lb] * Db;
+		daub += s[ty][4][la] * Da; dbua += s[ty][3][lb] * Db;
+		dajua += s[ty][5][la] * Da; dbjub += s[ty][6][lb] * Db;
+	}
+	const double ida = p.inv_da;
+	daT *= ida; dbT *= ida; daR *= ida; dbR *= ida; daW *= ida; dbW *= ida;
+	daub *= ida; dbua *= ida; dajua *= ida; dbjub *= ida;
+	const double invJ2 = 1.0 / j2d;
+	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+	__syncthreads();
+	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
+	s[ty][2][lane] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lane] = jn * (c2a1 * daR + c2b1 * dbR);
+	s[ty][4][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lane] = je * (c2a1 * daW + c2b1 * dbW);
+	s[ty][6][lane] = dv; s[ty][7][lane] = cl;
+	__syncthreads();
+	if (!actw) return;
+
+	double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+		uaT += s[ty][0][la] * Sa; ubT += s[ty][1][lb] * Sb;
+		uaR += s[ty][2][la] * Sa; ubR += s[ty][3][lb] * Sb;
+		uaW += s[ty][4][la] * Sa; ubW += s[ty][5][lb] * Sb;
+		dad -= Sa * s[ty][6][la]; dbd -= Sb * s[ty][6][lb];
+		dac -= Sa * s[ty][7][la]; dbc -= Sb * s[ty][7][lb];
+	}
+	uaT *= ida; ubT *= ida; uaR *= ida; ubR *= ida; uaW *= ida; ubW *= ida;
+	dad *= ida; dbd *= ida; dac *= ida; dbc *= ida;
+
+	{
+		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
+		const double b = xbase ? xbase[o] : 0.0;
+		xout[o] = b - dt * (1.0 / je) * nu_s * (uaW + ubW);
+	}
+	if (actn) {
+		const double invJ = 1.0 / jn;
+		size_t o = TMX_SLAB_T(L, kk) * NS + col;
+		double b = xbase ? xbase[o] : 0.0;
+		xout[o] = b - dt * invJ * nu_s * (uaT + ubT);
+		o = TMX_SLAB_R(L, kk) * NS + col;
+		b = xbase ? xbase[o] : 0.0;
+		xout[o] = b - dt * invJ * nu_s * (uaR + ubR);
+		const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
+		const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
+		o = TMX_SLAB_U(L, kk) * NS + col;
+		b = xbase ? xbase[o] : 0.0;
+		xout[o] = b - dt * upa;
+		o = TMX_SLAB_V(L, kk) * NS + col;
+		b = xbase ? xbase[o] : 0.0;
+		xout[o] = b - dt * upb;
+	}
+}
+
+void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage algebra: X_d <- c_d X_d + sum_m c_m X_m, accumulated in the reference's order
+// (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508)
+
+struct LinTerms { const double * src[8]; double coef[8]; int n; int premul; };
+
+__global__ __launch_bounds__(256) void k_lincomb(size_t n, double * __restrict__ dst, LinTerms t) {
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * 256;
+	for (; i < n; i += stride) {
+		double v = t.premul ? dst[i] * t.coef[0] : 0.0;
+		for (int m = 1; m < t.n; m++) v += t.coef[m] * t.src[m][i];
+		dst[i] = v;
+	}
+}
+
+void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int premul) {
+	LinTerms t;
+	t.n = nterms; t.premul = premul;
+	for (int m = 0; m < nterms; m++) { t.src[m] = src[m]; t.coef[m] = coef[m]; }
+	const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+	hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(256), 0, e->stream, n, dst, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// V implicit, part 1: residual F and analytic band Jacobian of one block row (level) of one column
+// (VerticalDynamicsFEM::SetupReferenceColumn / PrepareColumn / BuildF / BuildJacobianF_LOR_RhoTheta_Pi /
+//  BuildJacobianF_Diffusion, src/atm/VerticalDynamicsFEM.cpp:1643-1835, 1839-2179, 2183-2780,
+//  2977-3187, 2784-2973).  Unknown ordering (rho*theta_k, W_k, rho_k) interleaved per level
+// (VerticalDynamicsFEM.h:97-104).  Row r keeps its 9 band entries AB[r][d], d = col - r + 4.
+
+__global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * __restrict__ xin, double dt,
+	int nunique, int NUS, const int * __restrict__ ucol, double * __restrict__ AB, double * __restrict__ RHS)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int u = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + threadIdx.y;
+	if (u >= nunique || k > L) return;
+	const int col = ucol[u];
+	const double invdt = 1.0 / dt;
+	const double upc = 0.5 * (1.0 / (double)L);             // m_dUpwindCoeff (:394-395)
+	const double cv = p.cp - p.Rd;
+
+	double rowP[TMX_BW], rowW[TMX_BW], rowR[TMX_BW];
+#pragma unroll
+	for (int d = 0; d < TMX_BW; d++) { rowP[d] = 0.0; rowW[d] = 0.0; rowR[d] = 0.0; }
+	double fP = 0.0, fW = 0.0, fR = 0.0;
+	// band offset of column (c', k') seen from row (c, k): d = 3(k'-k) + (c'-c) + 4
+#define DOFF(cr, cc, dk) (3 * (dk) + ((cc) - (cr)) + 4)
+
+	auto ldn = [&](int slabbase, int l) -> double {      // node slab, clamped level
+		const int lc = l < 0 ? 0 : (l > L - 1 ? L - 1 : l);
+		return xin[(size_t)(slabbase + lc) * NS + col];
+	};
+	auto ldw = [&](int l) -> double {
+		const int lc = l < 0 ? 0 : (l > L ? L : l);
+		return xin[(size_t)TMX_SLAB_W(L, lc) * NS + col];
+	};
+	const size_t s3e = (size_t)(L + 1) * NS, s3n = (size_t)L * NS;
+	auto cxe = [&](int f, int m) -> double { return p.g3e[f * s3e + (size_t)m * NS + col]; };
+	const double c2a0 = p.g2d[G2_C2A0 * NS + col], c2a1 = p.g2d[G2_C2A1 * NS + col], c2b1 = p.g2d[G2_C2B1 * NS + col];
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col], drx = p.g2d[G2_DRX * NS + col];
+
+	// interface quantities at interface m: interpolated state and xi_dot (PrepareColumn :2056-2069)
+	auto interp_n2e = [&](int slabbase, int m) -> double {
+		double v = 0.0;
+#pragma unroll
+		for (int off = -2; off <= 1; off++) {
+			const int l = m + off;
+			if (l < 0 || l >= L) continue;
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * xin[(size_t)(slabbase + l) * NS + col];
+		}
+		return v;
+	};
+	auto xidot_e = [&](int m) -> double {
+		if (m <= 0 || m >= L) return 0.0;
+		const double ue = interp_n2e(TMX_SLAB_U(L, 0), m), ve = interp_n2e(TMX_SLAB_V(L, 0), m);
+		return cxe(G3E_CX0, m) * ue + cxe(G3E_CX1, m) * ve + cxe(G3E_CX2, m) * ldw(m);
+	};
+
+	if (k < L) {
+		// ---------------- rows (rho*theta_k) and (rho_k) ----------------
+		const double invJ = 1.0 / jn;
+		const double pm = ldn(TMX_SLAB_T(L, 0), k - 1), p0 = ldn(TMX_SLAB_T(L, 0), k), pp = ldn(TMX_SLAB_T(L, 0), k + 1);
+		const double rm = ldn(TMX_SLAB_R(L, 0), k - 1), r0 = ldn(TMX_SLAB_R(L, 0), k), rp = ldn(TMX_SLAB_R(L, 0), k + 1);
+		const double xd0 = xidot_e(k), xd1 = xidot_e(k + 1);
+		const double pe0 = interp_n2e(TMX_SLAB_T(L, 0), k), pe1 = interp_n2e(TMX_SLAB_T(L, 0), k + 1);
+		const double re0 = interp_n2e(TMX_SLAB_R(L, 0), k), re1 = interp_n2e(TMX_SLAB_R(L, 0), k + 1);
+		// fluxes on interfaces, zero at the boundaries (BuildF :2215-2226, :2295-2306)
+		const double mf0 = (k >= 1) ? je * re0 * xd0 : 0.0, mf1 = (k + 1 <= L - 1) ? je * re1 * xd1 : 0.0;
+		const double pf0 = (k >= 1) ? je * pe0 * xd0 : 0.0, pf1 = (k + 1 <= L - 1) ? je * pe1 * xd1 : 0.0;
+		const double de0 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
+		double dmf = 0.0; dmf += de0 * mf0; dmf += de1 * mf1;
+		double dpf = 0.0; dpf += de0 * pf0; dpf += de1 * pf1;
+		fR = dmf * invJ;
+		fP += dpf * invJ;
+		// upwind penalty on levels (BuildF :2640-2712)
+		const double wlo = fabs(xd0), whi = fabs(xd1);      // weights of interfaces k and k+1
+		const double pl0 = OPC(TMX_OP_PENALTY_LEFT, k, 0), pl1 = OPC(TMX_OP_PENALTY_LEFT, k, 1);
+		const double pr0 = OPC(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPC(TMX_OP_PENALTY_RIGHT, k, 0);
+		{
+			double a = 0.0;
+			if (k < L - 1) { double b = 0.0; b += pl0 * p0; b += pl1 * pp; a += b * whi; }
+			if (k > 0) { double b = 0.0; b += pr0 * pm; b += pr1 * p0; a += b * wlo; }
+			fP -= a;
+			a = 0.0;
+			if (k < L - 1) { double b = 0.0; b += pl0 * r0; b += pl1 * rp; a += b * whi; }
+			if (k > 0) { double b = 0.0; b += pr0 * rm; b += pr1 * r0; a += b * wlo; }
+			fR -= a;
+		}
+		// Jacobian: conservative flux terms (:3069-3103)
+#pragma unroll
+		for (int mm = 0; mm < 2; mm++) {
+			const int m = k + mm;
+			const double dcoef = mm ? de1 : de0;
+			const double xd = mm ? xd1 : xd0;
+			if (m != 0 && m != L) {
+				const double c = dcoef * je * invJ * cxe(G3E_CX2, m);
+				rowP[DOFF(0, 1, mm)] += c * (mm ? pe1 : pe0);
+				rowR[DOFF(2, 1, mm)] += c * (mm ? re1 : re0);
+			}
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int qn = m + off;
+				if (qn < 0 || qn >= L) continue;
+				const double ci = OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+				if (ci == 0.0) continue;
+				const int dk = qn - k;
+				if (dk < -1 || dk > 1) continue;
+				const double c = dcoef * je * invJ * ci * xd;
+				rowR[DOFF(2, 2, dk)] += c;
+				rowP[DOFF(0, 0, dk)] += c;
+			}
+		}
+		// Jacobian: upwinding on levels (BuildJacobianF_Diffusion :2905-2970); interface a = k acts
+		// through the right operator, a = k+1 through the left operator
+		if (k >= 1) {
+			const double sw = (xd0 > 0.0) ? cxe(G3E_CX2, k) : ((xd0 < 0.0) ? -cxe(G3E_CX2, k) : 0.0);
+			rowP[DOFF(0, 1, 0)] -= sw * pr0 * pm; rowP[DOFF(0, 1, 0)] -= sw * pr1 * p0;
+			rowP[DOFF(0, 0, -1)] -= wlo * pr0;    rowP[DOFF(0, 0, 0)] -= wlo * pr1;
+			rowR[DOFF(2, 1, 0)] -= sw * pr0 * rm; rowR[DOFF(2, 1, 0)] -= sw * pr1 * r0;
+			rowR[DOFF(2, 2, -1)] -= wlo * pr0;    rowR[DOFF(2, 2, 0)] -= wlo * pr1;
+		}
+		if (k + 1 <= L - 1) {
+			const double sw = (xd1 > 0.0) ? cxe(G3E_CX2, k + 1) : ((xd1 < 0.0) ? -cxe(G3E_CX2, k + 1) : 0.0);
+			rowP[DOFF(0, 1, 1)] -= sw * pl0 * p0; rowP[DOFF(0, 1, 1)] -= sw * pl1 * pp;
+			rowP[DOFF(0, 0, 0)] -= whi * pl0;     rowP[DOFF(0, 0, 1)] -= whi * pl1;
+			rowR[DOFF(2, 1, 1)] -= sw * pl0 * r0; rowR[DOFF(2, 1, 1)] -= sw * pl1 * rp;
+			rowR[DOFF(2, 2, 0)] -= whi * pl0;     rowR[DOFF(2, 2, 1)] -= whi * pl1;
+		}
+	}
+	if (k >= 1 && k <= L - 1) {
+		// ---------------- row (W_k), interior interfaces ----------------
+		const double pm = ldn(TMX_SLAB_T(L, 0), k - 1), p0 = ldn(TMX_SLAB_T(L, 0), k);
+		const double exm = exner_from_rhotheta(p, pm), ex0 = exner_from_rhotheta(p, p0);
+		const double pe = interp_n2e(TMX_SLAB_T(L, 0), k), re = interp_n2e(TMX_SLAB_R(L, 0), k);
+		const double dnm = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, -1), dn0 = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, 0);
+		double dpe = 0.0; dpe += dnm * exm; dpe += dn0 * ex0;
+		const double unm = ldn(TMX_SLAB_U(L, 0), k - 1), un0 = ldn(TMX_SLAB_U(L, 0), k);
+		const double vnm = ldn(TMX_SLAB_V(L, 0), k - 1), vn0 = ldn(TMX_SLAB_V(L, 0), k);
+		const double wem = ldw(k - 1), we0 = ldw(k), wep = ldw(k + 1);
+		// W on levels k-1, k (InterpolateREdgeToNode)
+		double wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * wem; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * we0;
+		double wn0 = 0.0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * wep;
+		// node metric at k-1, k
+		const size_t om = (size_t)(k - 1) * NS + col, o0 = (size_t)k * NS + col;
+		const double ca2m = p.g3n[G3N_CA2 * s3n + om], cb2m = p.g3n[G3N_CB2 * s3n + om], cx2m = p.g3n[G3N_CX2 * s3n + om];
+		const double ca20 = p.g3n[G3N_CA2 * s3n + o0], cb20 = p.g3n[G3N_CB2 * s3n + o0], cx20 = p.g3n[G3N_CX2 * s3n + o0];
+		// xi_dot on levels (:2049-2054) and kinetic energy on levels (BuildF :2455-2478)
+		const double xdnm = ca2m * unm + cb2m * vnm + cx2m * wnm;
+		const double xdn0 = ca20 * un0 + cb20 * vn0 + cx20 * wn0;
+		double kem, ke0;
+		{
+			const double ca = c2a0 * unm + c2a1 * vnm + ca2m * wnm, cb = c2a1 * unm + c2b1 * vnm + cb2m * wnm;
+			kem = 0.5 * (ca * unm + cb * vnm + xdnm * wnm);
+		}
+		{
+			const double ca = c2a0 * un0 + c2a1 * vn0 + ca20 * wn0, cb = c2a1 * un0 + c2b1 * vn0 + cb20 * wn0;
+			ke0 = 0.5 * (ca * un0 + cb * vn0 + xdn0 * wn0);
+		}
+		double dke = 0.0; dke += dnm * kem; dke += dn0 * ke0;
+		double dua = 0.0; dua += dnm * unm; dua += dn0 * un0;
+		double dub = 0.0; dub += dnm * vnm; dub += dn0 * vn0;
+		// interface values
+		const double ue = interp_n2e(TMX_SLAB_U(L, 0), k), ve = interp_n2e(TMX_SLAB_V(L, 0), k);
+		const double cx0e = cxe(G3E_CX0, k), cx1e = cxe(G3E_CX1, k), cx2e = cxe(G3E_CX2, k);
+		const double xde = cx0e * ue + cx1e * ve + cx2e * we0;
+		// F_W (BuildF :2527-2572)
+		fW = dpe * pe / re;
+		fW += p.grav * drx;
+		{
+			const double ca = c2a0 * ue + c2a1 * ve + cx0e * we0;
+			const double cb = c2a1 * ue + c2b1 * ve + cx1e * we0;
+			const double curl = -ca * dua - cb * dub;
+			fW += (dke + curl);
+		}
+		// second derivative of W for the upwind term (PrepareColumn :2091-2102, BuildF :2680-2691)
+		const double ddm = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, -1), dd0 = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 0), ddp = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 1);
+		double ddw = 0.0; ddw += ddm * wem; ddw += dd0 * we0; ddw += ddp * wep;
+		fW -= upc * fabs(xde) * ddw;
+		// Jacobian of the W row (:3106-3152)
+		const double cA = pe * p.Rd / (re * cv);
+		rowW[DOFF(1, 0, -1)] += cA * dnm * exm / pm;
+		rowW[DOFF(1, 0, 0)] += cA * dn0 * ex0 / p0;
+		const double cB = 1.0 / (re * re) * dpe;
+		const double im = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1), i0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0);
+		{
+			const double cC = cB * im;
+			rowW[DOFF(1, 0, -1)] += cC * re;
+			rowW[DOFF(1, 2, -1)] += -cC * pe;
+		}
+		{
+			const double cC = cB * i0;
+			rowW[DOFF(1, 0, 0)] += cC * re;
+			rowW[DOFF(1, 2, 0)] += -cC * pe;
+		}
+		// Clark-form dW_k/dW_m (:3140-3152): l = k-1 -> m in {k-1,k}; l = k -> m in {k,k+1}
+		rowW[DOFF(1, 1, -1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * dn0 * xdn0;
+		rowW[DOFF(1, 1, 1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * dn0 * xdn0;
+		// upwinding on interfaces (BuildJacobianF_Diffusion :2873-2902)
+		const double sw = (xde > 0.0) ? cx2e : ((xde < 0.0) ? -cx2e : 0.0);
+		rowW[DOFF(1, 1, 0)] -= upc * sw * ddw;
+		rowW[DOFF(1, 1, -1)] -= upc * fabs(xde) * ddm;
+		rowW[DOFF(1, 1, 0)] -= upc * fabs(xde) * dd0;
+		rowW[DOFF(1, 1, 1)] -= upc * fabs(xde) * ddp;
+	}
+	// identity / dt on the whole diagonal (:3172-3176); rows W_0, W_L and the unused level-L slots
+	// of rho*theta and rho are pure identity rows with F = 0
+	rowP[4] += invdt; rowW[4] += invdt; rowR[4] += invdt;
+
+	const int r0 = TMX_FTOT * k;
+#pragma unroll
+	for (int d = 0; d < TMX_BW; d++) {
+		AB[((size_t)(r0 + 0) * TMX_BW + d) * NUS + u] = rowP[d];
+		AB[((size_t)(r0 + 1) * TMX_BW + d) * NUS + u] = rowW[d];
+		AB[((size_t)(r0 + 2) * TMX_BW + d) * NUS + u] = rowR[d];
+	}
+	RHS[(size_t)(r0 + 0) * NUS + u] = fP;
+	RHS[(size_t)(r0 + 1) * NUS + u] = fW;
+	RHS[(size_t)(r0 + 2) * NUS + u] = fR;
+#undef DOFF
+}
+
+void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt) {
+	if (e->nunique == 0) return;
+	dim3 blk(64, 4), grd((e->nunique + 63) / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_vi_assemble, grd, blk, 0, e->stream, p, xin, dt, e->nunique, e->NUS,
+		(const int *)e->d_ucol, e->d_ab, e->d_rhs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// V implicit, part 2: banded LU with partial pivoting + solve, one column per lane, the active
+// window (5 rows x 9 columns) in registers.  Same elimination order, pivot choice (first maximum)
+// and substitution order as LAPACK dgbtf2 / dgbtrs / dtbsv, which the reference calls through
+// LAPACK::DGBSV (src/base/LinearAlgebra.cpp:156-202 <- src/atm/VerticalDynamicsFEM.cpp:1457-1459).
+// Then x = x0 - delta (:1483-1485) is scattered to the column and to the duplicate element-seam
+// nodes of the same patch (:1488-1633; rho*theta, W, rho only -- U,V are not touched).
+
+__global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, double * xup,
+	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int u = blockIdx.x * 64 + threadIdx.x;
+	if (u >= nunique) return;
+	const int n = TMX_FTOT * (L + 1);
+
+	double R[5][TMX_BW], b[5];
+#pragma unroll
+	for (int r = 0; r < 5; r++) {
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) {
+			const int d = c - r + 4;           // window column c = matrix column c (j = 0)
+			R[r][c] = (d >= 0 && d < TMX_BW && r < n) ? AB[((size_t)r * TMX_BW + d) * NUS + u] : 0.0;
+		}
+		b[r] = (r < n) ? RHS[(size_t)r * NUS + u] : 0.0;
+	}
+	bool singular = false;
+	for (int jcol = 0; jcol < n; jcol++) {
+		// pivot: first row of maximum |entry| in the leading window column (idamax)
+		int pv = 0;
+		double amax = fabs(R[0][0]);
+#pragma unroll
+		for (int r = 1; r < 5; r++) {
+			const double v = fabs(R[r][0]);
+			if (v > amax) { amax = v; pv = r; }
+		}
+#pragma unroll
+		for (int r = 1; r < 5; r++) {
+			const bool sw = (pv == r);
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				const double a0 = R[0][c], ar = R[r][c];
+				R[0][c] = sw ? ar : a0;
+				R[r][c] = sw ? a0 : ar;
+			}
+			const double b0 = b[0], br = b[r];
+			b[0] = sw ? br : b0;
+			b[r] = sw ? b0 : br;
+		}
+		if (R[0][0] == 0.0) singular = true;
+		// row jcol of U and of the forward-substituted right-hand side
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
+		RHS[(size_t)jcol * NUS + u] = b[0];
+		const double rcp = 1.0 / R[0][0];
+#pragma unroll
+		for (int r = 1; r < 5; r++) {
+			const double l = R[r][0] * rcp;
+#pragma unroll
+			for (int c = 1; c < TMX_BW; c++) R[r][c] -= l * R[0][c];
+			b[r] -= b[0] * l;
+		}
+		// slide the window: drop the pivot row and the pivot column, take in matrix row jcol + 5
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+#pragma unroll
+			for (int c = 0; c < TMX_BW - 1; c++) R[r][c] = R[r + 1][c + 1];
+			R[r][TMX_BW - 1] = 0.0;
+			b[r] = b[r + 1];
+		}
+		const int rn = jcol + 5;
+		if (rn < n) {
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) R[4][c] = AB[((size_t)rn * TMX_BW + c) * NUS + u];
+			b[4] = RHS[(size_t)rn * NUS + u];
+		} else {
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) R[4][c] = 0.0;
+			b[4] = 0.0;
+		}
+	}
+	if (singular) atomicExch(flag, 1);
+
+	// back substitution in dtbsv order, scatter x0 - delta
+	const int col = ucol[u];
+	int dep[3];
+#pragma unroll
+	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	double xw[TMX_BW - 1];
+#pragma unroll
+	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
+	for (int r = n - 1; r >= 0; r--) {
+		double acc = RHS[(size_t)r * NUS + u];
+		double ur[TMX_BW];
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) ur[c] = AB[((size_t)r * TMX_BW + c) * NUS + u];
+#pragma unroll
+		for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c];
+		const double xr = acc / ur[0];
+#pragma unroll
+		for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];
+		xw[0] = xr;
+		const int k = r / TMX_FTOT, cc = r - k * TMX_FTOT;
+		if (cc != 1 && k == L) continue;       // unused level-L slots of rho*theta / rho
+		const int slab = (cc == 0) ? TMX_SLAB_T(L, k) : ((cc == 1) ? TMX_SLAB_W(L, k) : TMX_SLAB_R(L, k));
+		const double val = xin[(size_t)slab * NS + col] - xr;
+		xup[(size_t)slab * NS + col] = val;
+#pragma unroll
+		for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val;
+	}
+}
+
+void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup) {
+	if (e->nunique == 0) return;
+	hipLaunchKernelGGL(k_vi_solve, dim3((e->nunique + 63) / 64), dim3(64), 0, e->stream, p, xin, xup,
+		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+}

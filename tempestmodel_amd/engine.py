@@ -1,0 +1,355 @@
+"""ctypes binding of the C ABI (include/tempest_mi355x.h) and thin host-side mirrors of the
+reference plugin classes for this path (same method names, argument meaning and error behaviour
+as src/atm/HorizontalDynamics.h:54-175, VerticalDynamics.h:46-129, TimestepScheme.h:54-121,
+Grid.cpp:1585-1621), so parity tests read like calls on the reference objects.
+
+There is NO CPU path here: every compute call goes to libtempest_mi355x.so (hand-written HIP,
+gfx950).  If the library is missing, import fails loudly; if no GPU is present, creating an
+engine raises :class:`TempestError`.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtempest_mi355x.so")
+
+TMX_ABI_VERSION = 1
+OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
+            "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
+            "penalty_left", "penalty_right"]
+GEOM_FIELDS = ["jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "jacobian", "jacobian_redge",
+               "contra_metric_a", "contra_metric_b", "contra_metric_xi",
+               "contra_metric_a_redge", "contra_metric_b_redge", "contra_metric_xi_redge",
+               "deriv_r_node", "deriv_r_redge", "coriolis_f"]
+KERNEL_NAMES = ["h_explicit", "v_explicit", "vi_assemble", "vi_solve", "dss", "hypervis", "lincomb", "exchange"]
+
+PD = C.POINTER(C.c_double)
+PI = C.POINTER(C.c_int)
+
+
+class TempestError(RuntimeError):
+    """Mirrors the reference's Exception (src/base/Exception.h:25-49): raised on a non-zero return."""
+
+    def __init__(self, code, msg):
+        super().__init__("tempest_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+class TmxConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int), ("horizontal_order", C.c_int), ("vertical_order", C.c_int),
+                ("levels", C.c_int), ("n_patches", C.c_int), ("n_instances", C.c_int), ("n_tracers", C.c_int),
+                ("hypervis_order", C.c_int),
+                ("element_delta_a", C.c_double), ("reference_length", C.c_double),
+                ("grav", C.c_double), ("Rd", C.c_double), ("cp", C.c_double), ("p0", C.c_double),
+                ("nu_scalar", C.c_double), ("nu_div", C.c_double), ("nu_vort", C.c_double),
+                ("rank", C.c_int), ("n_ranks", C.c_int), ("device", C.c_int)]
+
+
+class TmxPatchGeometry(C.Structure):
+    _fields_ = [(n, PD) for n in GEOM_FIELDS]
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library.  Fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libtempest_mi355x.so is missing at %s -- build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
+                          "this package has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.tmx_last_error.restype = C.c_char_p
+    lib.tmx_info.restype = C.c_longlong
+    lib.tmx_destroy.restype = None
+    for name in ("tmx_h_step_explicit", "tmx_v_step_explicit", "tmx_v_step_implicit"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    lib.tmx_h_step_after_subcycle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.tmx_step_ars343.argtypes = [C.c_void_p, C.c_double]
+    lib.tmx_apply_dss.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_copy_data.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.tmx_zero_data.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_linear_combine_data.argtypes = [C.c_void_p, PD, C.c_int, C.c_int]
+    lib.tmx_sync.argtypes = [C.c_void_p]
+    lib.tmx_destroy.argtypes = [C.c_void_p]
+    lib.tmx_finalize.argtypes = [C.c_void_p]
+    lib.tmx_info.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_plan_get.argtypes = [C.c_void_p, C.c_int, PI, C.c_int]
+    lib.tmx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_profile_reset.argtypes = [C.c_void_p]
+    lib.tmx_profile_get.argtypes = [C.c_void_p, C.c_int, PD, C.POINTER(C.c_longlong)]
+    lib.tmx_upload_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
+    lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
+    lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
+    _lib = lib
+    return lib
+
+
+def _pd(a):
+    return a.ctypes.data_as(PD)
+
+
+def _pi(a):
+    return a.ctypes.data_as(PI)
+
+
+def default_owner(npatch, n_ranks):
+    """Panel-major block map of patches to ranks (results do not depend on the map)."""
+    per = (npatch + n_ranks - 1) // n_ranks
+    return [min(p // per, n_ranks - 1) for p in range(npatch)]
+
+
+class Engine:
+    """One engine per process / GPU, built from a :class:`tempestmodel_amd.cubed_sphere.CubedSphereGrid`
+    (or anything exposing the same reference-layout arrays)."""
+
+    def __init__(self, grid, n_instances=7, nu=(1.0e15, 1.0e15, 1.0e15), hypervis_order=4,
+                 rank=0, n_ranks=1, owner=None, device=-1):
+        self.lib = load_library()
+        self.grid = grid
+        self.L = grid.L
+        self.npatch = len(grid.patches)
+        self.rank, self.n_ranks = rank, n_ranks
+        self.owner = list(owner) if owner is not None else default_owner(self.npatch, n_ranks)
+        cfg = TmxConfig()
+        cfg.abi_version = TMX_ABI_VERSION
+        cfg.horizontal_order, cfg.vertical_order = grid.np, 1
+        cfg.levels, cfg.n_patches, cfg.n_instances, cfg.n_tracers = grid.L, self.npatch, n_instances, 0
+        cfg.hypervis_order = hypervis_order
+        cfg.element_delta_a, cfg.reference_length = grid.delta_a, grid.reference_length
+        ph = grid.phys
+        cfg.grav, cfg.Rd, cfg.cp, cfg.p0 = ph.g, ph.Rd, ph.cp, ph.p0
+        cfg.nu_scalar, cfg.nu_div, cfg.nu_vort = nu
+        cfg.rank, cfg.n_ranks, cfg.device = rank, n_ranks, device
+        self.cfg = cfg
+        self.plan_only = (device == -2)
+        h = C.c_void_p()
+        self._chk(self.lib.tmx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        try:
+            self._setup()
+        except Exception:
+            self.close()
+            raise
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _chk(self, code):
+        if code != 0:
+            raise TempestError(code, self.lib.tmx_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tmx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _setup(self):
+        g = self.grid
+        keep = []
+        n = len(OP_NAMES)
+        cs = (PD * n)(); bs = (PI * n)(); es = (PI * n)()
+        nout = (C.c_int * n)(); nin = (C.c_int * n)()
+        for i, nm in enumerate(OP_NAMES):
+            c, b, e = g.ops[nm]
+            c = np.ascontiguousarray(c, dtype=np.float64)
+            b = np.ascontiguousarray(b, dtype=np.int32); e = np.ascontiguousarray(e, dtype=np.int32)
+            keep += [c, b, e]
+            cs[i], bs[i], es[i] = _pd(c), _pi(b), _pi(e)
+            nout[i], nin[i] = c.shape
+        dx = np.ascontiguousarray(g.dx, dtype=np.float64)
+        st = np.ascontiguousarray(g.stiff, dtype=np.float64)
+        self._chk(self.lib.tmx_set_operators(self.h, _pd(dx), _pd(st), cs, bs, es, nout, nin))
+        for P in g.patches:
+            nbp = (C.c_int * 8)(*[int(v) for v in P.neighbor_panels])
+            self._chk(self.lib.tmx_define_patch(self.h, P.index, P.panel, (P.ga1 - P.ga0) // g.np,
+                                                (P.gb1 - P.gb0) // g.np, self.owner[P.index], nbp))
+        for P in g.patches:
+            hh = P.halo
+            arrs = [np.ascontiguousarray(hh[k], dtype=np.int32) for k in
+                    ("i", "j", "src_patch", "src_i", "src_j", "src_panel")]
+            tr = np.ascontiguousarray(hh["trans"], dtype=np.float64)
+            self._chk(self.lib.tmx_set_patch_halo(self.h, P.index, len(arrs[0]), *[_pi(a) for a in arrs], _pd(tr)))
+        if not self.plan_only:
+            for P in g.patches:
+                if self.owner[P.index] != self.rank:
+                    continue
+                pg = TmxPatchGeometry()
+                for nm in GEOM_FIELDS:
+                    a = np.ascontiguousarray(P.geom[nm], dtype=np.float64)
+                    keep.append(a)
+                    setattr(pg, nm, _pd(a))
+                self._chk(self.lib.tmx_set_patch_geometry(self.h, P.index, C.byref(pg)))
+        self._chk(self.lib.tmx_finalize(self.h))
+
+    @property
+    def local_patches(self):
+        return [p for p in range(self.npatch) if self.owner[p] == self.rank]
+
+    # -- state (GridPatch::GetDataState) ----------------------------------------------------------
+    def upload_state(self, instance, states):
+        """``states[p] = (node[5][na][nb][L], redge[5][na][nb][L+1])`` for every patch (remote ones ignored)."""
+        for p in self.local_patches:
+            n = np.ascontiguousarray(states[p][0], dtype=np.float64)
+            e = np.ascontiguousarray(states[p][1], dtype=np.float64)
+            self._chk(self.lib.tmx_upload_state(self.h, p, instance, _pd(n), _pd(e)))
+
+    def download_state(self, instance):
+        out = [None] * self.npatch
+        for p in self.local_patches:
+            P = self.grid.patches[p]
+            n = np.zeros((5, P.na, P.nb, self.L)); e = np.zeros((5, P.na, P.nb, self.L + 1))
+            self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n), _pd(e)))
+            out[p] = (n, e)
+        return out
+
+    # -- C ABI, one method per entry point -----------------------------------------------------------
+    def copy_data(self, src, dst):
+        self._chk(self.lib.tmx_copy_data(self.h, src, dst))
+
+    def zero_data(self, ix):
+        self._chk(self.lib.tmx_zero_data(self.h, ix))
+
+    def linear_combine_data(self, coeff, dst):
+        c = np.ascontiguousarray(coeff, dtype=np.float64)
+        self._chk(self.lib.tmx_linear_combine_data(self.h, _pd(c), len(c), dst))
+
+    def h_step_explicit(self, iinit, iupd, dt):
+        self._chk(self.lib.tmx_h_step_explicit(self.h, iinit, iupd, dt))
+
+    def v_step_explicit(self, iinit, iupd, dt):
+        self._chk(self.lib.tmx_v_step_explicit(self.h, iinit, iupd, dt))
+
+    def v_step_implicit(self, iinit, iupd, dt):
+        self._chk(self.lib.tmx_v_step_implicit(self.h, iinit, iupd, dt))
+
+    def apply_dss(self, ix):
+        self._chk(self.lib.tmx_apply_dss(self.h, ix))
+
+    def h_step_after_subcycle(self, iinit, iupd, iwork, dt):
+        self._chk(self.lib.tmx_h_step_after_subcycle(self.h, iinit, iupd, iwork, dt))
+
+    def step_ars343(self, dt):
+        self._chk(self.lib.tmx_step_ars343(self.h, dt))
+
+    def sync(self):
+        self._chk(self.lib.tmx_sync(self.h))
+
+    def info(self, what):
+        return int(self.lib.tmx_info(self.h, what))
+
+    def plan(self, what):
+        n = self.lib.tmx_plan_get(self.h, what, None, 0)
+        if n < 0:
+            raise TempestError(-1, "tmx_plan_get failed")
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        self.lib.tmx_plan_get(self.h, what, _pi(a), n)
+        return a[:n]
+
+    def comm_init(self, unique_id):
+        self._chk(self.lib.tmx_comm_init(self.h, unique_id))
+
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        code = lib.tmx_comm_unique_id(buf)
+        if code != 0:
+            raise TempestError(code, lib.tmx_last_error().decode())
+        return buf.raw
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.tmx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.tmx_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for i, nm in enumerate(KERNEL_NAMES):
+            ms = C.c_double(); n = C.c_longlong()
+            self._chk(self.lib.tmx_profile_get(self.h, i, C.byref(ms), C.byref(n)))
+            out[nm] = (ms.value, n.value)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Mirrors of the reference plugin classes for this path.
+
+
+class Grid:
+    """Stage algebra + DSS entry points of the reference Grid (Grid.cpp:1585-1621, GridGLL.cpp:571-583)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def CopyData(self, ixSource, ixDest):
+        self.engine.copy_data(ixSource, ixDest)
+
+    def ZeroData(self, ixData):
+        self.engine.zero_data(ixData)
+
+    def LinearCombineData(self, dCoeff, ixDest):
+        self.engine.linear_combine_data(dCoeff, ixDest)
+
+    def PostProcessSubstage(self, iDataUpdate):
+        self.engine.apply_dss(iDataUpdate)
+
+    ApplyDSS = PostProcessSubstage
+
+
+class HorizontalDynamicsFEM:
+    """HorizontalDynamicsFEM (HorizontalDynamicsFEM.h:36-316) for the nonhydrostatic equation set."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def GetHaloElements(self):
+        return 1
+
+    def StepExplicit(self, iDataInitial, iDataUpdate, time, dDeltaT):
+        self.engine.h_step_explicit(iDataInitial, iDataUpdate, dDeltaT)
+
+    def StepImplicit(self, iDataInitial, iDataUpdate, time, dDeltaT):
+        pass    # no-op in the reference as well (HorizontalDynamics.h:119-126)
+
+    def StepAfterSubCycle(self, iDataInitial, iDataUpdate, iDataWorking, time, dDeltaT):
+        self.engine.h_step_after_subcycle(iDataInitial, iDataUpdate, iDataWorking, dDeltaT)
+
+
+class VerticalDynamicsFEM:
+    """VerticalDynamicsFEM (VerticalDynamicsFEM.h) in implicit mode."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def StepExplicit(self, iDataInitial, iDataUpdate, time, dDeltaT):
+        self.engine.v_step_explicit(iDataInitial, iDataUpdate, dDeltaT)
+
+    def StepImplicit(self, iDataInitial, iDataUpdate, time, dDeltaT):
+        self.engine.v_step_implicit(iDataInitial, iDataUpdate, dDeltaT)
+
+
+class TimestepSchemeARS343:
+    """TimestepSchemeARS343 (TimestepSchemeARS343.h:48-56, .cpp:150-236)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def GetComponentDataInstances(self):
+        return 7
+
+    def GetTracerDataInstances(self):
+        return 7
+
+    def Step(self, fFirstStep, fLastStep, time, dDeltaT):
+        self.engine.step_ars343(dDeltaT)
