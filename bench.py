@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: whole ARS343 IMEX steps of the Jablonowski-Williamson
+baroclinic wave on the cubed sphere (BASELINE.json metric: element-DOF-updates/s and SYPD).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one full TimestepSchemeARS343::Step (4 H-explicit, 4 V-explicit, 3 V-implicit column
+solves, 6 DSS incl. exchange, stage algebra, two-pass hyperviscosity) on synthetic input of the
+reference's own closed-form initial state, resident in HBM.  Rank 0 prints ONE JSON line.
+
+  value       element-DOF-updates/s = N_el * 16 * L * 5 * K / wall      (whole job, all ranks)
+  roofline    dominant operation: algorithmic bytes / measured device time (HIP events)
+  cpu_baseline  the real reference (oracle/_ref, "reference") when its binary travelled with the
+              snapshot, else the C oracle ("port"), timed on 1 host core on a bounded sample
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# algorithmic bytes per point (stored node x level) per call, SURVEY.md section 8(d)
+ALG_BYTES = {
+    "h_explicit": 200.0,     # 5 R state + 5 R/W update + 10 metric
+    "v_explicit": 80.0,
+    "v_implicit": 272.0,     # vi_assemble + vi_solve together
+    "dss": 60.0,
+    "hypervis": 216.0,       # per pass (432 per step, two passes)
+    "lincomb": 600.0 / 10,   # 600 B/point/step over the copy/combine launches of one step
+}
+OP_KERNELS = {
+    "h_explicit": ["h_explicit"], "v_explicit": ["v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
+    "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"],
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
+    """Host-CPU baseline on rank 0: the real reference if its binary is present, else the C oracle."""
+    dof_per_step = 6 * ne * ne * 16 * L * 5
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "tmx_ref_dump")
+    if os.path.exists(ref_bin):
+        try:
+            env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+            out = subprocess.run([ref_bin, "--mode", "time", "--ne", str(ne), "--levels", str(L), "--dt", str(dt),
+                                  "--steps", str(nsteps_ref), "--warm", "1", "--patches", "6"],
+                                 env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 universal_newlines=True, timeout=900).stdout
+            for line in out.splitlines():
+                if line.startswith("timing"):
+                    f = dict(kv.split("=") for kv in line.split()[1:])
+                    tmin = float(f["min_s"])
+                    return {"value": dof_per_step / tmin, "unit": "element-DOF-updates/s", "cores": 1,
+                            "kind": "reference",
+                            "sample": "real reference binary (oracle/_ref), ne%d L%d ARS343 dt=%gs, 1 MPI rank, "
+                                      "min of %d steps after 1 warm-up step; %.3f s/step" % (ne, L, dt, nsteps_ref, tmin),
+                            "sypd": dt / tmin / 365.0}
+        except Exception as ex:  # fall through to the port
+            sys.stderr.write("reference baseline failed (%s), using the C oracle\n" % ex)
+    import golden_util as gu
+    from oracle_lib import Oracle
+    g, states = gu.make_grid(ne, L, 6)
+    o = Oracle(g)
+    o.set_state(0, states)
+    o.step_ars343(dt)
+    ts = []
+    for _ in range(nsteps_port):
+        t0 = time.time(); o.step_ars343(dt); ts.append(time.time() - t0)
+    tmin = min(ts)
+    return {"value": dof_per_step / tmin, "unit": "element-DOF-updates/s", "cores": 1, "kind": "port",
+            "sample": "C oracle (oracle/tmx_oracle.c), ne%d L%d ARS343 dt=%gs, 1 thread, min of %d steps; %.3f s/step"
+                      % (ne, L, dt, nsteps_port, tmin),
+            "sypd": dt / tmin / 365.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ne", type=int, default=30)
+    ap.add_argument("--levels", type=int, default=30)
+    ap.add_argument("--dt", type=float, default=150.0)
+    ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import golden_util as gu
+    from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
+    from tempestmodel_amd.engine import Engine
+
+    ne, L, dt = args.ne, args.levels, args.dt
+    grid = CubedSphereGrid(ne, L, 30000.0, ppd=args.ppd)
+    states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
+    eng = Engine(grid, rank=rank, n_ranks=world, device=local_rank)
+    if world > 1:
+        if rank == 0:
+            uid = torch.tensor(list(Engine.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        eng.comm_init(bytes(uid.cpu().tolist()))
+    eng.upload_state(0, states)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        eng.step_ars343(dt)
+    barrier()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_ars343(dt)
+    barrier()
+    wall = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    # sanity: the state must still be finite
+    chk = eng.download_state(0)
+    import numpy as np
+    for p in eng.local_patches:
+        if not (np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all()):
+            sys.exit("bench.py: state became non-finite")
+
+    if rank == 0:
+        n_el = 6 * ne * ne
+        dof_per_step = n_el * 16 * L * 5
+        points = 6 * (ne * 4) ** 2 * L
+        ms_per_step = 1e3 * wall / args.steps
+        value = dof_per_step * args.steps / wall
+        # dominant operation of the step on this rank
+        op_time = {op: sum(prof[k][0] for k in ks) for op, ks in OP_KERNELS.items()}
+        dom = max(op_time, key=op_time.get)
+        launches = max(prof[OP_KERNELS[dom][0]][1], 1)
+        avg_ms = op_time[dom] / launches
+        local_points = points / world
+        achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
+            "value": value, "unit": "element-DOF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "sypd": dt / (wall / args.steps) / 365.0,
+            "config": {"workload": "Jablonowski-Williamson baroclinic wave, cubed sphere ne%d np4 L%d, ztop 30 km, "
+                                   "ARS343 dt=%gs, hyperviscosity order 4, %d patches" % (ne, L, dt, len(grid.patches)),
+                       "elements": n_el, "dof_per_step": dof_per_step, "dt_s": dt,
+                       "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world)},
+            "roofline": {"bound": "hbm", "kernel": "+".join("k_" + k for k in OP_KERNELS[dom]), "operation": dom,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ne, L, dt, 3, 3)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

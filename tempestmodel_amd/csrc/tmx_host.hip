@@ -62,7 +62,7 @@ static int load_rccl() {
 	// prefer an RCCL already in the process (torch ships its own); otherwise the ROCm one
 	void * h = dlopen(nullptr, RTLD_NOW | RTLD_GLOBAL);
 	if (!h || !dlsym(h, "ncclSend")) {
-		const char * names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", nullptr };
+		const char * names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr };   // soname first: reuses an RCCL already loaded (torch bundles one)
 		h = nullptr;
 		for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
 	}
