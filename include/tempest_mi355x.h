@@ -197,8 +197,11 @@ long long tmx_info(tmx_engine * e, int what);
  * what = 1: receive list, quadruples (patch, i, j, src_rank) in ghost-buffer order
  * what = 2: DSS groups, (n, col0..col3) with col >= NS meaning ghost NS + index
  * what = 3: (NS, ncol, n_unique, n_groups, n_cross_panel_groups)
+ * what = 4: per group, index into the cross-panel matrices or -1
  * Returns the number of ints written (needed, when out == NULL), -1 on error. */
 int tmx_plan_get(tmx_engine * e, int what, int * out, int cap);
+/* [n_cross][4][8] doubles: per member the 2x2 matrix into the frame of member 0 and the 2x2 back. */
+int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
 
 /* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.
  * kernel ids: TMX_K_* below.  Profiling is off by default (no events recorded). */

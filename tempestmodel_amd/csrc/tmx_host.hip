@@ -896,9 +896,19 @@ extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 		for (int g = 0; g < e->ngroups; g++) { v.push_back(plan.grp_n[g]); for (int m = 0; m < 4; m++) v.push_back(plan.grp_cols[(size_t)g * 4 + m]); }
 	} else if (what == 3) {
 		v.push_back(e->NS); v.push_back(e->ncol); v.push_back(e->nunique); v.push_back(e->ngroups); v.push_back(e->nxgroups);
+	} else if (what == 4) {
+		v = plan.grp_x;
 	} else return -1;
 	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
 	return (int)v.size();
+}
+
+// cross-panel covector matrices of the DSS groups: [n_cross][4 members][A(2x2) to frame, B(2x2) from frame]
+extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
+	if (!e || !e->finalized) return -1;
+	PlanHost & plan = g_plans[e];
+	if (out) { if ((int)plan.xmat.size() > cap) return -1; memcpy(out, plan.xmat.data(), plan.xmat.size() * sizeof(double)); }
+	return (int)plan.xmat.size();
 }
 
 extern "C" int tmx_profile_enable(tmx_engine * e, int on) {

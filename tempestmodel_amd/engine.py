@@ -79,6 +79,7 @@ def load_library():
     lib.tmx_finalize.argtypes = [C.c_void_p]
     lib.tmx_info.argtypes = [C.c_void_p, C.c_int]
     lib.tmx_plan_get.argtypes = [C.c_void_p, C.c_int, PI, C.c_int]
+    lib.tmx_plan_get_matrices.argtypes = [C.c_void_p, PD, C.c_int]
     lib.tmx_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.tmx_profile_reset.argtypes = [C.c_void_p]
     lib.tmx_profile_get.argtypes = [C.c_void_p, C.c_int, PD, C.POINTER(C.c_longlong)]
@@ -254,6 +255,12 @@ class Engine:
         a = np.zeros(max(n, 1), dtype=np.int32)
         self.lib.tmx_plan_get(self.h, what, _pi(a), n)
         return a[:n]
+
+    def plan_matrices(self):
+        n = self.lib.tmx_plan_get_matrices(self.h, None, 0)
+        a = np.zeros(max(n, 1), dtype=np.float64)
+        self.lib.tmx_plan_get_matrices(self.h, _pd(a), n)
+        return a[:n].reshape(-1, 4, 2, 2, 2)
 
     def comm_init(self, unique_id):
         self._chk(self.lib.tmx_comm_init(self.h, unique_id))
