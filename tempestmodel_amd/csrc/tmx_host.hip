@@ -128,6 +128,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->L = cfg->levels;
 	e->patches.resize(cfg->n_patches);
 	e->nslab = 5 * e->L + 1;
+	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
 	if (!plan_only(e)) {
 		int ndev = 0;
 		hipError_t r = hipGetDeviceCount(&ndev);
@@ -191,6 +192,8 @@ extern "C" int tmx_set_operators(tmx_engine * e, const double * dx_basis, const 
 				const int off = l - k;
 				REQUIRE(off >= lo[op] && off <= hi[op], TMX_ERR_UNSUPPORTED,
 					"operator %d row %d has a coefficient at offset %d outside the vertical-order-1 stencil", op, k, off);
+				if (op == TMX_OP_INTERP_NODE_TO_REDGE && k >= 1 && k <= L - 1)
+					REQUIRE(off == -1 || off == 0, TMX_ERR_UNSUPPORTED, "interior row %d of InterpNodeToREdge is not a two-point stencil", k);
 				e->h_ops[((size_t)op * (L + 1) + k) * TMX_OPW + (off + 2)] = c;
 			}
 		}
@@ -436,6 +439,24 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 			if (oa == me && ob != me) send_to[ob].push_back(a);
 			if (oa != me && ob == me) recv_from[oa].push_back(a);
 		}
+	}
+	// order the groups by the device column of their first local member: consecutive lanes of the
+	// DSS kernel then touch the same 128-byte element rows (element-major locality)
+	{
+		std::vector<std::pair<int, int>> key(groups.size());
+		for (size_t g = 0; g < groups.size(); g++) {
+			int best = 0x7fffffff;
+			for (int id : groups[g].ids) {
+				NodeRef nr = node_of(id);
+				const PatchInfo & P = e->patches[nr.patch];
+				if (P.owner == me) best = std::min(best, col_of(P, nr.i, nr.j));
+			}
+			key[g] = { best, (int)g };
+		}
+		std::sort(key.begin(), key.end());
+		std::vector<Grp> sorted(groups.size());
+		for (size_t g = 0; g < groups.size(); g++) sorted[g] = groups[key[g].second];
+		groups.swap(sorted);
 	}
 	e->send_rank_off.assign(NR + 1, 0); e->recv_rank_off.assign(NR + 1, 0);
 	std::map<int, int> ghost_index;
@@ -700,8 +721,23 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	return launch_check("h_step_explicit");
+}
+
+// CopyData(initial -> update) followed by StepExplicit(initial, update) in one pass:
+// update = initial + dt * rhs(initial), bit-identical to the two reference calls
+static int h_step_explicit_from_copy(tmx_engine * e, int iinit, int iupd, double dt) {
+	ProfScope ps(e, TMX_K_H_EXPLICIT);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iinit), inst(e, iupd), dt);
+	return launch_check("h_step_explicit(fused copy)");
+}
+
+// CopyData restricted to the U,V slabs: the implicit step overwrites rho*theta, W, rho of every column
+static int copy_uv(tmx_engine * e, int src, int dst) {
+	ProfScope ps(e, TMX_K_LINCOMB);
+	HIPCHK(hipMemcpyAsync(inst(e, dst), inst(e, src), (size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	return TMX_OK;
 }
 
 extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
@@ -716,8 +752,12 @@ extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double d
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
 	KParams p = make_params(e);
-	{ ProfScope ps(e, TMX_K_VI_ASSEMBLE); tmxk_vi_assemble(e, p, inst(e, iinit), dt); }
-	{ ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_solve(e, p, inst(e, iinit), inst(e, iupd)); }
+	if (e->vi_mode == 1) {
+		{ ProfScope ps(e, TMX_K_VI_ASSEMBLE); tmxk_vi_assemble(e, p, inst(e, iinit), dt); }
+		{ ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_solve(e, p, inst(e, iinit), inst(e, iupd)); }
+	} else {
+		ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_fused(e, p, inst(e, iinit), inst(e, iupd), dt);
+	}
 	return launch_check("v_step_implicit");
 }
 
@@ -799,29 +839,31 @@ extern "C" int tmx_step_ars343(tmx_engine * e, double dt) {
 	double u2[7], u3[7], u4[7], de[4], di[4];
 	ars343_tableau(u2, u3, u4, de, di);
 #define STEP(call) do { if ((r = (call))) return r; } while (0)
-	STEP(tmx_copy_data(e, 0, 1));
-	STEP(tmx_h_step_explicit(e, 0, 1, de[0] * dt));
+	// The reference's CopyData calls are folded into their consumers where the result is bit-identical:
+	// Copy(0->1)+H(0,1) = one pass; Copy(s->t)+V.StepImplicit(t,t) = copy of U,V + StepImplicit(s,t)
+	// (the implicit step rewrites rho*theta, W, rho of every stored column); Copy(1->0) before
+	// StepAfterSubCycle(1,0,2) is dropped because the second hyperviscosity pass writes every slab of 0.
+	STEP(h_step_explicit_from_copy(e, 0, 1, de[0] * dt));
 	STEP(tmx_v_step_explicit(e, 0, 1, de[0] * dt));
 	STEP(tmx_apply_dss(e, 1));
-	STEP(tmx_copy_data(e, 1, 2));
-	STEP(tmx_v_step_implicit(e, 2, 2, di[0] * dt));
+	STEP(copy_uv(e, 1, 2));
+	STEP(tmx_v_step_implicit(e, 1, 2, di[0] * dt));
 	STEP(tmx_linear_combine_data(e, u2, 7, 3));
 	STEP(tmx_h_step_explicit(e, 2, 3, de[1] * dt));
 	STEP(tmx_v_step_explicit(e, 2, 3, de[1] * dt));
 	STEP(tmx_apply_dss(e, 3));
-	STEP(tmx_copy_data(e, 3, 4));
-	STEP(tmx_v_step_implicit(e, 4, 4, di[1] * dt));
+	STEP(copy_uv(e, 3, 4));
+	STEP(tmx_v_step_implicit(e, 3, 4, di[1] * dt));
 	STEP(tmx_linear_combine_data(e, u3, 7, 5));
 	STEP(tmx_h_step_explicit(e, 4, 5, de[2] * dt));
 	STEP(tmx_v_step_explicit(e, 4, 5, de[2] * dt));
 	STEP(tmx_apply_dss(e, 5));
-	STEP(tmx_copy_data(e, 5, 6));
-	STEP(tmx_v_step_implicit(e, 6, 6, di[2] * dt));
+	STEP(copy_uv(e, 5, 6));
+	STEP(tmx_v_step_implicit(e, 5, 6, di[2] * dt));
 	STEP(tmx_linear_combine_data(e, u4, 7, 1));
 	STEP(tmx_h_step_explicit(e, 6, 1, de[3] * dt));
 	STEP(tmx_v_step_explicit(e, 6, 1, de[3] * dt));
 	STEP(tmx_apply_dss(e, 1));
-	STEP(tmx_copy_data(e, 1, 0));
 	STEP(tmx_h_step_after_subcycle(e, 1, 0, 2, dt));
 #undef STEP
 	return TMX_OK;

@@ -29,7 +29,7 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 // recomputed on the fly instead of being stored.  (u x zeta)_xi is handed to part 2 via `ucz`.
 
 __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double * __restrict__ ucz, double dt)
+	const double * xbase, double * xup, double * __restrict__ ucz, double dt)
 {
 	__shared__ double s[KT_H][9][64];
 	__shared__ double sD[16], sS[16];
@@ -129,23 +129,29 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	upb -= (pgfb + dbke + dbphi);
 	const size_t oU = TMX_SLAB_U(L, k) * NS + col, oV = TMX_SLAB_V(L, k) * NS + col;
 	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
-	xup[oU] += dt * upa;
-	xup[oV] += dt * upb;
-	xup[oR] -= dt * invJ * (darf + dbrf);
-	xup[oT] -= dt * invJ * (dapf + dbpf);
+	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
+	// instance when the preceding CopyData(initial -> update) is fused away
+	xup[oU] = xbase[oU] + dt * upa;
+	xup[oV] = xbase[oV] + dt * upb;
+	xup[oR] = xbase[oR] - dt * invJ * (darf + dbrf);
+	xup[oT] = xbase[oT] - dt * invJ * (dapf + dbpf);
 	ucz[(size_t)k * NS + col] = uczx;
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
-__global__ __launch_bounds__(256) void k_h_w_update(KParams p, double * __restrict__ xup,
+__global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xbase, double * xup,
 	const double * __restrict__ ucz, double dt)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + threadIdx.y;
-	if (k >= L || col >= p.ncol) return;
+	if (k > L || col >= p.ncol) return;
+	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
+		if (xbase != xup) xup[TMX_SLAB_W(L, L) * NS + col] = xbase[TMX_SLAB_W(L, L) * NS + col];
+		return;
+	}
 	if (k == 0) {
 		double u0 = 0.0, v0 = 0.0;
 		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * xup[TMX_SLAB_U(L, 0) * NS + col];
@@ -159,15 +165,15 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, double * __restri
 		double v = 0.0;
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
-		xup[TMX_SLAB_W(L, k) * NS + col] += dt * v;
+		xup[TMX_SLAB_W(L, k) * NS + col] = xbase[TMX_SLAB_W(L, k) * NS + col] + dt * v;
 	}
 }
 
-void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
 	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
-	hipLaunchKernelGGL(k_h_explicit, grd, blk, 0, e->stream, p, xin, xup, e->d_scratch, dt);
-	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xup, (const double *)e->d_scratch, dt);
+	hipLaunchKernelGGL(k_h_explicit, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, dt);
+	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, dt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,5 +805,336 @@ __global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, 
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup) {
 	if (e->nunique == 0) return;
 	hipLaunchKernelGGL(k_vi_solve, dim3((e->nunique + 63) / 64), dim3(64), 0, e->stream, p, xin, xup,
+		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// V implicit, fused: the same residual / Jacobian / pivoted band LU as k_vi_assemble + k_vi_solve,
+// but each block row (level) is assembled in registers right before it enters the LU window, so the
+// band matrix never goes to HBM (only the U rows needed by the back substitution do).  The state of
+// the three levels a block row touches lives in a sliding register window; the loads of the next
+// level are issued one block (three pivot steps) ahead of their first use.
+// Arithmetic is statement-for-statement that of the split kernels: results are bit-identical.
+
+struct NodeLev { double un, vn, pn, rn, ca2, cb2, cx2; };
+struct EdgeLev { double we, ce0, ce1, ce2; };
+
+__device__ __forceinline__ NodeLev load_node(const KParams & p, const double * xin, int l, int col) {
+	NodeLev n = { 0, 0, 1, 1, 0, 0, 0 };
+	const int L = p.L;
+	if (l < 0 || l >= L) return n;
+	const size_t NS = (size_t)p.NS, s3 = (size_t)L * NS, o = (size_t)l * NS + col;
+	n.un = xin[TMX_SLAB_U(L, l) * NS + col]; n.vn = xin[TMX_SLAB_V(L, l) * NS + col];
+	n.pn = xin[TMX_SLAB_T(L, l) * NS + col]; n.rn = xin[TMX_SLAB_R(L, l) * NS + col];
+	n.ca2 = p.g3n[G3N_CA2 * s3 + o]; n.cb2 = p.g3n[G3N_CB2 * s3 + o]; n.cx2 = p.g3n[G3N_CX2 * s3 + o];
+	return n;
+}
+__device__ __forceinline__ EdgeLev load_edge(const KParams & p, const double * xin, int l, int col) {
+	EdgeLev e = { 0, 0, 0, 0 };
+	const int L = p.L;
+	if (l < 0 || l > L) return e;
+	const size_t NS = (size_t)p.NS, s3 = (size_t)(L + 1) * NS, o = (size_t)l * NS + col;
+	e.we = xin[TMX_SLAB_W(L, l) * NS + col];
+	e.ce0 = p.g3e[G3E_CX0 * s3 + o]; e.ce1 = p.g3e[G3E_CX1 * s3 + o]; e.ce2 = p.g3e[G3E_CX2 * s3 + o];
+	return e;
+}
+
+struct ColConst { double c2a0, c2a1, c2b1, jn, je, drx, invdt, upc, cv; };
+
+// block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
+__device__ __forceinline__ void compute_block(const KParams & p, const ColConst & cc, int k,
+	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
+	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR)
+{
+	const int L = p.L;
+#pragma unroll
+	for (int d = 0; d < TMX_BW; d++) { rowP[d] = 0.0; rowW[d] = 0.0; rowR[d] = 0.0; }
+	fP = 0.0; fW = 0.0; fR = 0.0;
+#define DOFF(cr, cc_, dk) (3 * (dk) + ((cc_) - (cr)) + 4)
+	// interior interpolation stencils (offsets -1, 0), verified by tmx_set_operators
+	const double ib_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, -1), ib_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, 0);
+	if (k < L) {
+		const double ic_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1), ic_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
+		const double invJ = 1.0 / cc.jn;
+		const double pm = A.pn, p0 = B.pn, pp = C.pn, rm = A.rn, r0 = B.rn, rp = C.rn;
+		double xd0 = 0.0, xd1 = 0.0, pe0 = 0.0, pe1 = 0.0, re0 = 0.0, re1 = 0.0;
+		if (k >= 1) {
+			double ue = 0.0, ve = 0.0;
+			ue += ib_m * A.un; ue += ib_0 * B.un; ve += ib_m * A.vn; ve += ib_0 * B.vn;
+			xd0 = eb.ce0 * ue + eb.ce1 * ve + eb.ce2 * eb.we;
+			pe0 += ib_m * pm; pe0 += ib_0 * p0; re0 += ib_m * rm; re0 += ib_0 * r0;
+		}
+		if (k + 1 <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+			ue += ic_m * B.un; ue += ic_0 * C.un; ve += ic_m * B.vn; ve += ic_0 * C.vn;
+			xd1 = ec.ce0 * ue + ec.ce1 * ve + ec.ce2 * ec.we;
+			pe1 += ic_m * p0; pe1 += ic_0 * pp; re1 += ic_m * r0; re1 += ic_0 * rp;
+		}
+		const double mf0 = (k >= 1) ? cc.je * re0 * xd0 : 0.0, mf1 = (k + 1 <= L - 1) ? cc.je * re1 * xd1 : 0.0;
+		const double pf0 = (k >= 1) ? cc.je * pe0 * xd0 : 0.0, pf1 = (k + 1 <= L - 1) ? cc.je * pe1 * xd1 : 0.0;
+		const double de0 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
+		double dmf = 0.0; dmf += de0 * mf0; dmf += de1 * mf1;
+		double dpf = 0.0; dpf += de0 * pf0; dpf += de1 * pf1;
+		fR = dmf * invJ;
+		fP += dpf * invJ;
+		const double wlo = fabs(xd0), whi = fabs(xd1);
+		const double pl0 = OPC(TMX_OP_PENALTY_LEFT, k, 0), pl1 = OPC(TMX_OP_PENALTY_LEFT, k, 1);
+		const double pr0 = OPC(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPC(TMX_OP_PENALTY_RIGHT, k, 0);
+		{
+			double a = 0.0;
+			if (k < L - 1) { double b = 0.0; b += pl0 * p0; b += pl1 * pp; a += b * whi; }
+			if (k > 0) { double b = 0.0; b += pr0 * pm; b += pr1 * p0; a += b * wlo; }
+			fP -= a;
+			a = 0.0;
+			if (k < L - 1) { double b = 0.0; b += pl0 * r0; b += pl1 * rp; a += b * whi; }
+			if (k > 0) { double b = 0.0; b += pr0 * rm; b += pr1 * r0; a += b * wlo; }
+			fR -= a;
+		}
+		// conservative flux terms: m = k (interface b), m = k+1 (interface c)
+		if (k >= 1) {       // m = k, neither 0 nor L
+			const double c = de0 * cc.je * invJ * eb.ce2;
+			rowP[DOFF(0, 1, 0)] += c * pe0;
+			rowR[DOFF(2, 1, 0)] += c * re0;
+			const double cm = de0 * cc.je * invJ * ib_m * xd0, c0 = de0 * cc.je * invJ * ib_0 * xd0;
+			rowR[DOFF(2, 2, -1)] += cm; rowP[DOFF(0, 0, -1)] += cm;
+			rowR[DOFF(2, 2, 0)] += c0;  rowP[DOFF(0, 0, 0)] += c0;
+		}
+		if (k + 1 <= L - 1) {   // m = k+1
+			const double c = de1 * cc.je * invJ * ec.ce2;
+			rowP[DOFF(0, 1, 1)] += c * pe1;
+			rowR[DOFF(2, 1, 1)] += c * re1;
+			const double cm = de1 * cc.je * invJ * ic_m * xd1, c0 = de1 * cc.je * invJ * ic_0 * xd1;
+			rowR[DOFF(2, 2, 0)] += cm; rowP[DOFF(0, 0, 0)] += cm;
+			rowR[DOFF(2, 2, 1)] += c0; rowP[DOFF(0, 0, 1)] += c0;
+		}
+		if (k >= 1) {
+			const double sw = (xd0 > 0.0) ? eb.ce2 : ((xd0 < 0.0) ? -eb.ce2 : 0.0);
+			rowP[DOFF(0, 1, 0)] -= sw * pr0 * pm; rowP[DOFF(0, 1, 0)] -= sw * pr1 * p0;
+			rowP[DOFF(0, 0, -1)] -= wlo * pr0;    rowP[DOFF(0, 0, 0)] -= wlo * pr1;
+			rowR[DOFF(2, 1, 0)] -= sw * pr0 * rm; rowR[DOFF(2, 1, 0)] -= sw * pr1 * r0;
+			rowR[DOFF(2, 2, -1)] -= wlo * pr0;    rowR[DOFF(2, 2, 0)] -= wlo * pr1;
+		}
+		if (k + 1 <= L - 1) {
+			const double sw = (xd1 > 0.0) ? ec.ce2 : ((xd1 < 0.0) ? -ec.ce2 : 0.0);
+			rowP[DOFF(0, 1, 1)] -= sw * pl0 * p0; rowP[DOFF(0, 1, 1)] -= sw * pl1 * pp;
+			rowP[DOFF(0, 0, 0)] -= whi * pl0;     rowP[DOFF(0, 0, 1)] -= whi * pl1;
+			rowR[DOFF(2, 1, 1)] -= sw * pl0 * r0; rowR[DOFF(2, 1, 1)] -= sw * pl1 * rp;
+			rowR[DOFF(2, 2, 0)] -= whi * pl0;     rowR[DOFF(2, 2, 1)] -= whi * pl1;
+		}
+	}
+	if (k >= 1 && k <= L - 1) {
+		const double pm = A.pn, p0 = B.pn;
+		const double exm = exner_from_rhotheta(p, pm), ex0 = exner_from_rhotheta(p, p0);
+		double pe = 0.0, re = 0.0;
+		pe += ib_m * pm; pe += ib_0 * p0; re += ib_m * A.rn; re += ib_0 * B.rn;
+		const double dnm = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, -1), dn0 = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, 0);
+		double dpe = 0.0; dpe += dnm * exm; dpe += dn0 * ex0;
+		const double unm = A.un, un0 = B.un, vnm = A.vn, vn0 = B.vn;
+		const double wem = ea.we, we0 = eb.we, wep = ec.we;
+		double wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * wem; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * we0;
+		double wn0 = 0.0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * wep;
+		const double xdnm = A.ca2 * unm + A.cb2 * vnm + A.cx2 * wnm;
+		const double xdn0 = B.ca2 * un0 + B.cb2 * vn0 + B.cx2 * wn0;
+		double kem, ke0;
+		{
+			const double ca = cc.c2a0 * unm + cc.c2a1 * vnm + A.ca2 * wnm, cb = cc.c2a1 * unm + cc.c2b1 * vnm + A.cb2 * wnm;
+			kem = 0.5 * (ca * unm + cb * vnm + xdnm * wnm);
+		}
+		{
+			const double ca = cc.c2a0 * un0 + cc.c2a1 * vn0 + B.ca2 * wn0, cb = cc.c2a1 * un0 + cc.c2b1 * vn0 + B.cb2 * wn0;
+			ke0 = 0.5 * (ca * un0 + cb * vn0 + xdn0 * wn0);
+		}
+		double dke = 0.0; dke += dnm * kem; dke += dn0 * ke0;
+		double dua = 0.0; dua += dnm * unm; dua += dn0 * un0;
+		double dub = 0.0; dub += dnm * vnm; dub += dn0 * vn0;
+		double ue = 0.0, ve = 0.0;
+		ue += ib_m * unm; ue += ib_0 * un0; ve += ib_m * vnm; ve += ib_0 * vn0;
+		const double cx0e = eb.ce0, cx1e = eb.ce1, cx2e = eb.ce2;
+		const double xde = cx0e * ue + cx1e * ve + cx2e * we0;
+		fW = dpe * pe / re;
+		fW += p.grav * cc.drx;
+		{
+			const double ca = cc.c2a0 * ue + cc.c2a1 * ve + cx0e * we0;
+			const double cb = cc.c2a1 * ue + cc.c2b1 * ve + cx1e * we0;
+			const double curl = -ca * dua - cb * dub;
+			fW += (dke + curl);
+		}
+		const double ddm = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, -1), dd0 = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 0), ddp = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 1);
+		double ddw = 0.0; ddw += ddm * wem; ddw += dd0 * we0; ddw += ddp * wep;
+		fW -= cc.upc * fabs(xde) * ddw;
+		const double cA = pe * p.Rd / (re * cc.cv);
+		rowW[DOFF(1, 0, -1)] += cA * dnm * exm / pm;
+		rowW[DOFF(1, 0, 0)] += cA * dn0 * ex0 / p0;
+		const double cB = 1.0 / (re * re) * dpe;
+		{
+			const double cC = cB * ib_m;
+			rowW[DOFF(1, 0, -1)] += cC * re;
+			rowW[DOFF(1, 2, -1)] += -cC * pe;
+		}
+		{
+			const double cC = cB * ib_0;
+			rowW[DOFF(1, 0, 0)] += cC * re;
+			rowW[DOFF(1, 2, 0)] += -cC * pe;
+		}
+		rowW[DOFF(1, 1, -1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * dn0 * xdn0;
+		rowW[DOFF(1, 1, 1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * dn0 * xdn0;
+		const double sw = (xde > 0.0) ? cx2e : ((xde < 0.0) ? -cx2e : 0.0);
+		rowW[DOFF(1, 1, 0)] -= cc.upc * sw * ddw;
+		rowW[DOFF(1, 1, -1)] -= cc.upc * fabs(xde) * ddm;
+		rowW[DOFF(1, 1, 0)] -= cc.upc * fabs(xde) * dd0;
+		rowW[DOFF(1, 1, 1)] -= cc.upc * fabs(xde) * ddp;
+	}
+	rowP[4] += cc.invdt; rowW[4] += cc.invdt; rowR[4] += cc.invdt;
+#undef DOFF
+}
+
+// one elimination step on the register window (dgbtf2 + forward substitution of dgbtrs), then slide
+__device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
+	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
+	const double * inrow, double inb)
+{
+	int pv = 0;
+	double amax = fabs(R[0][0]);
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		const double v = fabs(R[r][0]);
+		if (v > amax) { amax = v; pv = r; }
+	}
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		const bool sw = (pv == r);
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) {
+			const double a0 = R[0][c], ar = R[r][c];
+			R[0][c] = sw ? ar : a0;
+			R[r][c] = sw ? a0 : ar;
+		}
+		const double b0 = b[0], br = b[r];
+		b[0] = sw ? br : b0;
+		b[r] = sw ? b0 : br;
+	}
+	if (R[0][0] == 0.0) singular = true;
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
+	RHS[(size_t)jcol * NUS + u] = b[0];
+	const double rcp = 1.0 / R[0][0];
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		const double l = R[r][0] * rcp;
+#pragma unroll
+		for (int c = 1; c < TMX_BW; c++) R[r][c] -= l * R[0][c];
+		b[r] -= b[0] * l;
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+#pragma unroll
+		for (int c = 0; c < TMX_BW - 1; c++) R[r][c] = R[r + 1][c + 1];
+		R[r][TMX_BW - 1] = 0.0;
+		b[r] = b[r + 1];
+	}
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c];
+	b[4] = inb;
+}
+
+__global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, double * xup, double dt,
+	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int u = blockIdx.x * 64 + threadIdx.x;
+	if (u >= nunique) return;
+	const int n = TMX_FTOT * (L + 1);
+	const int col = ucol[u];
+	ColConst cc;
+	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+
+	// level window for block k: nodes k-1,k,k+1 and interfaces k-1,k,k+1
+	NodeLev nA = load_node(p, xin, -1, col), nB = load_node(p, xin, 0, col), nC = load_node(p, xin, 1, col);
+	EdgeLev eA = load_edge(p, xin, -1, col), eB = load_edge(p, xin, 0, col), eC = load_edge(p, xin, 1, col);
+	NodeLev nN = load_node(p, xin, 2, col);
+	EdgeLev eN = load_edge(p, xin, 2, col);
+
+	double R[5][TMX_BW], b[5];
+	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+	double sP[TMX_BW], sW[TMX_BW], sR[TMX_BW], gP, gW, gR;
+	// blocks 0 and 1 -> matrix rows 0..5
+	compute_block(p, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+	nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
+	nN = load_node(p, xin, 3, col); eN = load_edge(p, xin, 3, col);
+	compute_block(p, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR);
+	// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) {
+		R[0][c] = (c + 4 < TMX_BW) ? rP[c + 4] : 0.0;         // row 0: d = c + 4
+		R[1][c] = (c + 3 < TMX_BW) ? rW[c + 3] : 0.0;         // row 1: d = c + 3
+		R[2][c] = (c + 2 < TMX_BW) ? rR[c + 2] : 0.0;
+		R[3][c] = (c + 1 < TMX_BW) ? sP[c + 1] : 0.0;
+		R[4][c] = sW[c];
+	}
+	b[0] = fP; b[1] = fW; b[2] = fR; b[3] = gP; b[4] = gW;
+	bool singular = false;
+	lu_pivot_step(R, b, singular, AB, RHS, 0, NUS, u, sR, gR);      // pivot 0 takes in row 5
+	for (int m = 2; m <= L; m++) {
+		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
+		nN = load_node(p, xin, m + 2, col); eN = load_edge(p, xin, m + 2, col);   // used two blocks from now
+		compute_block(p, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP);
+		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW);
+		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR);
+	}
+	{
+		double z[TMX_BW];
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
+		for (int j = n - 5; j < n; j++) lu_pivot_step(R, b, singular, AB, RHS, j, NUS, u, z, 0.0);
+	}
+	if (singular) atomicExch(flag, 1);
+
+	// back substitution (dtbsv order) with the U rows prefetched two steps ahead
+	int dep[3];
+#pragma unroll
+	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	double xw[TMX_BW - 1];
+#pragma unroll
+	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
+	double u0[TMX_BW], u1[TMX_BW], y0, y1;
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) { u0[c] = AB[((size_t)(n - 1) * TMX_BW + c) * NUS + u]; u1[c] = AB[((size_t)(n - 2) * TMX_BW + c) * NUS + u]; }
+	y0 = RHS[(size_t)(n - 1) * NUS + u]; y1 = RHS[(size_t)(n - 2) * NUS + u];
+	for (int r = n - 1; r >= 0; r--) {
+		double u2[TMX_BW], y2 = 0.0;
+		const int rn = (r >= 2) ? r - 2 : 0;
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) u2[c] = AB[((size_t)rn * TMX_BW + c) * NUS + u];
+		y2 = RHS[(size_t)rn * NUS + u];
+		double acc = y0;
+#pragma unroll
+		for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * u0[c];
+		const double xr = acc / u0[0];
+#pragma unroll
+		for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];
+		xw[0] = xr;
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) { u0[c] = u1[c]; u1[c] = u2[c]; }
+		y0 = y1; y1 = y2;
+		const int k = r / TMX_FTOT, cc2 = r - k * TMX_FTOT;
+		if (cc2 != 1 && k == L) continue;
+		const int slab = (cc2 == 0) ? TMX_SLAB_T(L, k) : ((cc2 == 1) ? TMX_SLAB_W(L, k) : TMX_SLAB_R(L, k));
+		const double val = xin[(size_t)slab * NS + col] - xr;
+		xup[(size_t)slab * NS + col] = val;
+#pragma unroll
+		for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val;
+	}
+}
+
+void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	if (e->nunique == 0) return;
+	hipLaunchKernelGGL(k_vi_fused, dim3((e->nunique + 63) / 64), dim3(64), 0, e->stream, p, xin, xup, dt,
 		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
 }

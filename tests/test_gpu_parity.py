@@ -134,3 +134,28 @@ def test_hundred_steps_ne4_L10():
         assert max(errs) < TOL_STEPS, errs
     finally:
         e.close()
+
+
+def test_fused_column_kernel_is_bit_identical_to_split_kernels():
+    """k_vi_fused (production) vs k_vi_assemble + k_vi_solve (TMX_VI_MODE=split): same arithmetic."""
+    import os
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step2", g)
+    out = []
+    for mode in ("fused", "split"):
+        os.environ["TMX_VI_MODE"] = mode
+        try:
+            e = Engine(g)
+        finally:
+            os.environ.pop("TMX_VI_MODE", None)
+        e.upload_state(1, start)
+        e.copy_data(1, 2)
+        e.v_step_implicit(1, 2, 87.0)
+        e.sync()
+        out.append(e.download_state(2))
+        e.close()
+    for (an, ae), (bn, be) in zip(*out):
+        assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
+        assert np.array_equal(ae[3], be[3])
