@@ -549,8 +549,8 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	if ((r = dev_upload(&e->d_g3n, e->h_g3n, &bytes))) return r;
 	if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
 	if ((r = dev_upload(&e->d_ops, e->h_ops, &bytes))) return r;
-	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)L * NS * sizeof(double))); bytes += (size_t)L * NS * sizeof(double);
-	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)L * NS * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)(L + 4) * NS * sizeof(double))); bytes += (size_t)(L + 4) * NS * sizeof(double);
+	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)(L + 4) * NS * sizeof(double)));
 	if ((r = dev_upload(&e->d_grp_cols, plan.grp_cols, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_n, plan.grp_n, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
@@ -721,16 +721,19 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
 	return launch_check("h_step_explicit");
 }
 
 // CopyData(initial -> update) followed by StepExplicit(initial, update) in one pass:
 // update = initial + dt * rhs(initial), bit-identical to the two reference calls
-static int h_step_explicit_from_copy(tmx_engine * e, int iinit, int iupd, double dt) {
+// H.StepExplicit + V.StepExplicit of one stage in one pass over the state; `ibase` is the instance the
+// update starts from (== iupd for the reference's in-place accumulation, == iinit when the preceding
+// CopyData(initial -> update) is folded in).  Bit-identical to the separate calls.
+static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iinit), inst(e, iupd), dt);
-	return launch_check("h_step_explicit(fused copy)");
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 1);
+	return launch_check("hv_step_explicit");
 }
 
 // CopyData restricted to the U,V slabs: the implicit step overwrites rho*theta, W, rho of every column
@@ -843,26 +846,22 @@ extern "C" int tmx_step_ars343(tmx_engine * e, double dt) {
 	// Copy(0->1)+H(0,1) = one pass; Copy(s->t)+V.StepImplicit(t,t) = copy of U,V + StepImplicit(s,t)
 	// (the implicit step rewrites rho*theta, W, rho of every stored column); Copy(1->0) before
 	// StepAfterSubCycle(1,0,2) is dropped because the second hyperviscosity pass writes every slab of 0.
-	STEP(h_step_explicit_from_copy(e, 0, 1, de[0] * dt));
-	STEP(tmx_v_step_explicit(e, 0, 1, de[0] * dt));
+	STEP(hv_step_explicit(e, 0, 0, 1, de[0] * dt));
 	STEP(tmx_apply_dss(e, 1));
 	STEP(copy_uv(e, 1, 2));
 	STEP(tmx_v_step_implicit(e, 1, 2, di[0] * dt));
 	STEP(tmx_linear_combine_data(e, u2, 7, 3));
-	STEP(tmx_h_step_explicit(e, 2, 3, de[1] * dt));
-	STEP(tmx_v_step_explicit(e, 2, 3, de[1] * dt));
+	STEP(hv_step_explicit(e, 2, 3, 3, de[1] * dt));
 	STEP(tmx_apply_dss(e, 3));
 	STEP(copy_uv(e, 3, 4));
 	STEP(tmx_v_step_implicit(e, 3, 4, di[1] * dt));
 	STEP(tmx_linear_combine_data(e, u3, 7, 5));
-	STEP(tmx_h_step_explicit(e, 4, 5, de[2] * dt));
-	STEP(tmx_v_step_explicit(e, 4, 5, de[2] * dt));
+	STEP(hv_step_explicit(e, 4, 5, 5, de[2] * dt));
 	STEP(tmx_apply_dss(e, 5));
 	STEP(copy_uv(e, 5, 6));
 	STEP(tmx_v_step_implicit(e, 5, 6, di[2] * dt));
 	STEP(tmx_linear_combine_data(e, u4, 7, 1));
-	STEP(tmx_h_step_explicit(e, 6, 1, de[3] * dt));
-	STEP(tmx_v_step_explicit(e, 6, 1, de[3] * dt));
+	STEP(hv_step_explicit(e, 6, 1, 1, de[3] * dt));
 	STEP(tmx_apply_dss(e, 1));
 	STEP(tmx_h_step_after_subcycle(e, 1, 0, 2, dt));
 #undef STEP

@@ -28,8 +28,13 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 // (src/atm/HorizontalDynamicsFEM.cpp:848-1421).  The prologue interpolations (:817-831) are
 // recomputed on the fly instead of being stored.  (u x zeta)_xi is handed to part 2 via `ucz`.
 
+// FUSE_V: also apply VerticalDynamicsFEM::StepExplicit (k_v_explicit) to the freshly updated U,V in
+// registers -- same statements in the same order, so the result is bit-identical to the two calls.
+// The H-only values of levels 0,1 are kept in `uv01` for the bottom boundary condition of W, which the
+// reference evaluates before V.StepExplicit runs (HorizontalDynamicsFEM.cpp:1615-1638).
+template <bool FUSE_V>
 __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
-	const double * xbase, double * xup, double * __restrict__ ucz, double dt)
+	const double * xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
 {
 	__shared__ double s[KT_H][9][64];
 	__shared__ double sD[16], sS[16];
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
 	double conUa = 0, conUb = 0, conUx = 0, dxua = 0, dxub = 0;
+	double v_uam = 0, v_uap = 0, v_ubm = 0, v_ubp = 0, w_hi = 0, w_lo = 0;
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
 		ua = xin[TMX_SLAB_U(L, k) * NS + col];
@@ -70,6 +76,27 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		const double dm = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, -1), d0 = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 0), dp = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 1);
 		dxua = 0.0; dxua += dm * uam; dxua += d0 * ua; dxua += dp * uap;
 		dxub = 0.0; dxub += dm * ubm; dxub += d0 * ub; dxub += dp * ubp;
+		if (FUSE_V) {
+			// xi_dot on the interfaces k and k+1 (VerticalDynamicsFEM.cpp:816-828), zero at the boundaries
+			v_uam = uam; v_uap = uap; v_ubm = ubm; v_ubp = ubp;
+			const size_t s3e = (size_t)(L + 1) * NS;
+			double xlo = 0.0, xhi = 0.0;
+			if (k >= 1) {
+				double ue = 0.0, ve = 0.0;
+				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * uam; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ua;
+				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ubm; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ub;
+				const size_t o = (size_t)k * NS + col;
+				xlo = p.g3e[G3E_CX0 * s3e + o] * ue + p.g3e[G3E_CX1 * s3e + o] * ve + p.g3e[G3E_CX2 * s3e + o] * we0;
+			}
+			if (k + 1 <= L - 1) {
+				double ue = 0.0, ve = 0.0;
+				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ua; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * uap;
+				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ub; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * ubp;
+				const size_t o = (size_t)(k + 1) * NS + col;
+				xhi = p.g3e[G3E_CX0 * s3e + o] * ue + p.g3e[G3E_CX1 * s3e + o] * ve + p.g3e[G3E_CX2 * s3e + o] * we1;
+			}
+			w_hi = dt * fabs(xhi); w_lo = dt * fabs(xlo);
+		}
 	}
 	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
 	const double exn = act ? exner_from_rhotheta(p, rt) : 0.0;
@@ -131,8 +158,30 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
 	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
 	// instance when the preceding CopyData(initial -> update) is fused away
-	xup[oU] = xbase[oU] + dt * upa;
-	xup[oV] = xbase[oV] + dt * upb;
+	double outU = xbase[oU] + dt * upa;
+	double outV = xbase[oV] + dt * upb;
+	if (FUSE_V) {
+		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
+		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ua; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_uap;
+			outU += b * w_hi;
+			b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ub; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_ubp;
+			outV += b * w_hi;
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_uam; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ua;
+			outU += b * w_lo;
+			b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_ubm; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ub;
+			outV += b * w_lo;
+		}
+	}
+	xup[oU] = outU;
+	xup[oV] = outV;
 	xup[oR] = xbase[oR] - dt * invJ * (darf + dbrf);
 	xup[oT] = xbase[oT] - dt * invJ * (dapf + dbpf);
 	ucz[(size_t)k * NS + col] = uczx;
@@ -141,7 +190,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xbase, double * xup,
-	const double * __restrict__ ucz, double dt)
+	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -154,10 +203,15 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xb
 	}
 	if (k == 0) {
 		double u0 = 0.0, v0 = 0.0;
-		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * xup[TMX_SLAB_U(L, 0) * NS + col];
-		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * xup[TMX_SLAB_U(L, 1) * NS + col];
-		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * xup[TMX_SLAB_V(L, 0) * NS + col];
-		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * xup[TMX_SLAB_V(L, 1) * NS + col];
+		// updated U,V of levels 0,1 as the H step left them (uv01 when V.StepExplicit was fused in)
+		const double * pu0 = uv01 ? uv01 + col : xup + TMX_SLAB_U(L, 0) * NS + col;
+		const double * pu1 = uv01 ? uv01 + NS + col : xup + TMX_SLAB_U(L, 1) * NS + col;
+		const double * pv0 = uv01 ? uv01 + 2 * NS + col : xup + TMX_SLAB_V(L, 0) * NS + col;
+		const double * pv1 = uv01 ? uv01 + 3 * NS + col : xup + TMX_SLAB_V(L, 1) * NS + col;
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * (*pu0);
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pu1);
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * (*pv0);
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pv1);
 		const size_t s3 = (size_t)(L + 1) * NS;
 		const double cx0 = p.g3e[G3E_CX0 * s3 + col], cx1 = p.g3e[G3E_CX1 * s3 + col], cx2 = p.g3e[G3E_CX2 * s3 + col];
 		xup[TMX_SLAB_W(L, 0) * NS + col] = -(cx0 * u0 + cx1 * v0) / cx2;
@@ -169,11 +223,14 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xb
 	}
 }
 
-void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v) {
 	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
-	hipLaunchKernelGGL(k_h_explicit, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, dt);
+	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
+	if (fuse_v) hipLaunchKernelGGL(k_h_explicit<true>, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt);
+	else hipLaunchKernelGGL(k_h_explicit<false>, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt);
 	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, dt);
+	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch,
+		fuse_v ? (const double *)uv01 : (const double *)nullptr, dt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1096,41 +1153,44 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	}
 	if (singular) atomicExch(flag, 1);
 
-	// back substitution (dtbsv order) with the U rows prefetched two steps ahead
+	// back substitution (dtbsv order).  Rows are consumed three per loop trip from three register
+	// sets; the loads that refill a set are issued right after it is consumed, i.e. three rows
+	// (one trip) ahead of their use, without register-to-register rotation (which would force the
+	// wait into the same trip).  n = 3(L+1) is a multiple of 3.
 	int dep[3];
 #pragma unroll
 	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
-	double u0[TMX_BW], u1[TMX_BW], y0, y1;
-#pragma unroll
-	for (int c = 0; c < TMX_BW; c++) { u0[c] = AB[((size_t)(n - 1) * TMX_BW + c) * NUS + u]; u1[c] = AB[((size_t)(n - 2) * TMX_BW + c) * NUS + u]; }
-	y0 = RHS[(size_t)(n - 1) * NUS + u]; y1 = RHS[(size_t)(n - 2) * NUS + u];
-	for (int r = n - 1; r >= 0; r--) {
-		double u2[TMX_BW], y2 = 0.0;
-		const int rn = (r >= 2) ? r - 2 : 0;
-#pragma unroll
-		for (int c = 0; c < TMX_BW; c++) u2[c] = AB[((size_t)rn * TMX_BW + c) * NUS + u];
-		y2 = RHS[(size_t)rn * NUS + u];
-		double acc = y0;
-#pragma unroll
-		for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * u0[c];
-		const double xr = acc / u0[0];
-#pragma unroll
-		for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];
-		xw[0] = xr;
-#pragma unroll
-		for (int c = 0; c < TMX_BW; c++) { u0[c] = u1[c]; u1[c] = u2[c]; }
-		y0 = y1; y1 = y2;
-		const int k = r / TMX_FTOT, cc2 = r - k * TMX_FTOT;
-		if (cc2 != 1 && k == L) continue;
-		const int slab = (cc2 == 0) ? TMX_SLAB_T(L, k) : ((cc2 == 1) ? TMX_SLAB_W(L, k) : TMX_SLAB_R(L, k));
-		const double val = xin[(size_t)slab * NS + col] - xr;
-		xup[(size_t)slab * NS + col] = val;
-#pragma unroll
-		for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val;
+	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc;
+#define LOAD_UROW(dst, ydst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
+		_Pragma("unroll") for (int c = 0; c < TMX_BW; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
+		ydst = RHS[(size_t)rr_ * NUS + u]; } while (0)
+#define BACK_ROW(ur, yr, row) do { \
+		double acc = yr; \
+		_Pragma("unroll") for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c]; \
+		const double xr = acc / ur[0]; \
+		_Pragma("unroll") for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1]; \
+		xw[0] = xr; \
+		const int k_ = (row) / TMX_FTOT, c_ = (row) - k_ * TMX_FTOT; \
+		if (!(c_ != 1 && k_ == L)) { \
+			const int slab = (c_ == 0) ? TMX_SLAB_T(L, k_) : ((c_ == 1) ? TMX_SLAB_W(L, k_) : TMX_SLAB_R(L, k_)); \
+			const double val = xin[(size_t)slab * NS + col] - xr; \
+			xup[(size_t)slab * NS + col] = val; \
+			_Pragma("unroll") for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val; \
+		} } while (0)
+	LOAD_UROW(ua, ya, n - 1); LOAD_UROW(ub, yb, n - 2); LOAD_UROW(uc, yc, n - 3);
+	for (int r = n - 1; r >= 2; r -= 3) {
+		BACK_ROW(ua, ya, r);
+		LOAD_UROW(ua, ya, r - 3);
+		BACK_ROW(ub, yb, r - 1);
+		LOAD_UROW(ub, yb, r - 4);
+		BACK_ROW(uc, yc, r - 2);
+		LOAD_UROW(uc, yc, r - 5);
 	}
+#undef LOAD_UROW
+#undef BACK_ROW
 }
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {

@@ -159,3 +159,68 @@ def test_fused_column_kernel_is_bit_identical_to_split_kernels():
     for (an, ae), (bn, be) in zip(*out):
         assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
         assert np.array_equal(ae[3], be[3])
+
+
+def _reference_call_sequence(e, dt):
+    """TimestepSchemeARS343::Step spelled out with one ABI call per reference call
+    (TimestepSchemeARS343.cpp:150-236); the tableau is taken from the oracle's restatement."""
+    import ctypes as C
+    from oracle_lib import lib as olib
+    # tableau via the C oracle is not exported; restate the U-form combos numerically from the ABI-independent formulae
+    gm = 0.4358665215084590
+    b1 = -1.5 * gm * gm + 4.0 * gm - 0.25; b2 = 1.5 * gm * gm - 5.0 * gm + 1.25
+    a42 = a43 = 0.5529291480359398
+    a31 = (1.0 - 4.5 * gm + 1.5 * gm * gm) * a42 + (2.75 - 10.5 * gm + 3.75 * gm * gm) * a43 - 3.5 + 13 * gm - 4.5 * gm * gm
+    a32 = (-1.0 + 4.5 * gm - 1.5 * gm * gm) * a42 + (-2.75 + 10.5 * gm - 3.75 * gm * gm) * a43 + 4.0 - 12.5 * gm + 4.5 * gm * gm
+    a41 = 1.0 - a42 - a43
+    I = [[gm, 0, 0, 0], [0.5 * (1.0 - gm), gm, 0, 0], [b1, b2, gm, 0], [b1, b2, gm, 0]]
+    E = [[gm, 0, 0, 0], [a31, a32, 0, 0], [a41, a42, a43, 0], [0, b1, b2, gm]]
+    u2 = [0.0] * 7; u3 = [0.0] * 7; u4 = [0.0] * 7
+    u2[0] = 1.0 - E[1][0] / E[0][0]; u2[1] = E[1][0] / E[0][0] - I[1][0] / I[0][0]; u2[2] = I[1][0] / I[0][0]
+    u3[0] = 1.0 - E[2][0] / E[0][0]; u3[1] = E[2][0] / E[0][0] - I[2][0] / I[0][0]; u3[2] = I[2][0] / I[0][0]
+    u3[3] = E[2][1] / E[1][1] - I[2][1] / I[1][1]; u3[4] = I[2][1] / I[1][1]
+    u37 = -E[2][1] / E[1][1]
+    u4[0] = 1.0 - E[3][0] / E[0][0]; u4[1] = E[3][0] / E[0][0] - I[3][0] / I[0][0]; u4[2] = I[3][0] / I[0][0]
+    u4[3] = E[3][1] / E[1][1] - I[3][1] / I[1][1]; u4[4] = I[3][1] / I[1][1]
+    u4[5] = E[3][2] / E[2][2] - I[3][2] / I[2][2]; u4[6] = I[3][2] / I[2][2]
+    u47 = -E[3][1] / E[1][1]; u48 = -E[3][2] / E[2][2]
+    for i in range(3):
+        u3[i] += u37 * u2[i]
+    for i in range(3):
+        u4[i] += u47 * u2[i] + u48 * u3[i]
+    u4[3] += u48 * u3[3]; u4[4] += u48 * u3[4]
+    de = [E[i][i] for i in range(4)]
+    e.copy_data(0, 1)
+    e.h_step_explicit(0, 1, de[0] * dt); e.v_step_explicit(0, 1, de[0] * dt); e.apply_dss(1)
+    e.copy_data(1, 2); e.v_step_implicit(2, 2, gm * dt)
+    e.linear_combine_data(u2, 3)
+    e.h_step_explicit(2, 3, de[1] * dt); e.v_step_explicit(2, 3, de[1] * dt); e.apply_dss(3)
+    e.copy_data(3, 4); e.v_step_implicit(4, 4, gm * dt)
+    e.linear_combine_data(u3, 5)
+    e.h_step_explicit(4, 5, de[2] * dt); e.v_step_explicit(4, 5, de[2] * dt); e.apply_dss(5)
+    e.copy_data(5, 6); e.v_step_implicit(6, 6, gm * dt)
+    e.linear_combine_data(u4, 1)
+    e.h_step_explicit(6, 1, de[3] * dt); e.v_step_explicit(6, 1, de[3] * dt); e.apply_dss(1)
+    e.copy_data(1, 0)
+    e.h_step_after_subcycle(1, 0, 2, dt)
+
+
+def test_production_step_is_bit_identical_to_the_reference_call_sequence():
+    """tmx_step_ars343 folds copies and V.StepExplicit into neighbouring kernels; the state it produces must
+    equal, bit for bit, the one produced by issuing every reference call separately through the ABI."""
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step1", g)
+    a = Engine(g); b = Engine(g)
+    try:
+        a.upload_state(0, start); b.upload_state(0, start)
+        for _ in range(2):
+            a.step_ars343(200.0)
+            _reference_call_sequence(b, 200.0)
+        a.sync(); b.sync()
+        for (an, ae), (bn, be) in zip(a.download_state(0), b.download_state(0)):
+            assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
+            assert np.array_equal(ae[3], be[3])
+    finally:
+        a.close(); b.close()
