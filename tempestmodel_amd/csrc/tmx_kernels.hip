@@ -899,7 +899,10 @@ __device__ __forceinline__ EdgeLev load_edge(const KParams & p, const double * x
 struct ColConst { double c2a0, c2a1, c2b1, jn, je, drx, invdt, upc, cv; };
 
 // block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
-__device__ __forceinline__ void compute_block(const KParams & p, const ColConst & cc, int k,
+#undef OPC
+#define OPC(op, k, off) opsl[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+
+__device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
 	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR)
 {
@@ -1100,7 +1103,13 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
 {
+	// column-operator coefficients in LDS: read with ds_read (lgkmcnt), so that they neither need
+	// vector-memory round trips nor force vmcnt(0) waits that would drain the prefetches and stores
+	extern __shared__ double opsl_mem[];
+	double * opsl = opsl_mem;
 	const int L = p.L;
+	for (int t = threadIdx.x; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 64) opsl[t] = p.ops[t];
+	__syncthreads();
 	const size_t NS = (size_t)p.NS;
 	const int u = blockIdx.x * 64 + threadIdx.x;
 	if (u >= nunique) return;
@@ -1121,10 +1130,10 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
 	double sP[TMX_BW], sW[TMX_BW], sR[TMX_BW], gP, gW, gR;
 	// blocks 0 and 1 -> matrix rows 0..5
-	compute_block(p, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+	compute_block(p, opsl, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
 	nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 	nN = load_node(p, xin, 3, col); eN = load_edge(p, xin, 3, col);
-	compute_block(p, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR);
+	compute_block(p, opsl, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR);
 	// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
 #pragma unroll
 	for (int c = 0; c < TMX_BW; c++) {
@@ -1140,7 +1149,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	for (int m = 2; m <= L; m++) {
 		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 		nN = load_node(p, xin, m + 2, col); eN = load_edge(p, xin, m + 2, col);   // used two blocks from now
-		compute_block(p, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+		compute_block(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR);
@@ -1163,38 +1172,43 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
-	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc;
-#define LOAD_UROW(dst, ydst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
+	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc, xa, xb, xc;
+	// slab of matrix row `row` (level k, component c); the unused level-L slots of rho*theta / rho map to -1
+#define ROW_SLAB(row) (((row) % TMX_FTOT) == 1 ? TMX_SLAB_W(L, (row) / TMX_FTOT) : \
+		(((row) / TMX_FTOT) == L ? -1 : (((row) % TMX_FTOT) == 0 ? TMX_SLAB_T(L, (row) / TMX_FTOT) : TMX_SLAB_R(L, (row) / TMX_FTOT))))
+#define LOAD_UROW(dst, ydst, xdst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
 		_Pragma("unroll") for (int c = 0; c < TMX_BW; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
-		ydst = RHS[(size_t)rr_ * NUS + u]; } while (0)
-#define BACK_ROW(ur, yr, row) do { \
+		ydst = RHS[(size_t)rr_ * NUS + u]; \
+		const int sl_ = ROW_SLAB(rr_); xdst = (sl_ >= 0) ? xin[(size_t)sl_ * NS + col] : 0.0; } while (0)
+#define BACK_ROW(ur, yr, x0r, row) do { \
 		double acc = yr; \
 		_Pragma("unroll") for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c]; \
 		const double xr = acc / ur[0]; \
 		_Pragma("unroll") for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1]; \
 		xw[0] = xr; \
-		const int k_ = (row) / TMX_FTOT, c_ = (row) - k_ * TMX_FTOT; \
-		if (!(c_ != 1 && k_ == L)) { \
-			const int slab = (c_ == 0) ? TMX_SLAB_T(L, k_) : ((c_ == 1) ? TMX_SLAB_W(L, k_) : TMX_SLAB_R(L, k_)); \
-			const double val = xin[(size_t)slab * NS + col] - xr; \
+		const int slab = ROW_SLAB(row); \
+		if (slab >= 0) { \
+			const double val = x0r - xr; \
 			xup[(size_t)slab * NS + col] = val; \
 			_Pragma("unroll") for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val; \
 		} } while (0)
-	LOAD_UROW(ua, ya, n - 1); LOAD_UROW(ub, yb, n - 2); LOAD_UROW(uc, yc, n - 3);
+	LOAD_UROW(ua, ya, xa, n - 1); LOAD_UROW(ub, yb, xb, n - 2); LOAD_UROW(uc, yc, xc, n - 3);
 	for (int r = n - 1; r >= 2; r -= 3) {
-		BACK_ROW(ua, ya, r);
-		LOAD_UROW(ua, ya, r - 3);
-		BACK_ROW(ub, yb, r - 1);
-		LOAD_UROW(ub, yb, r - 4);
-		BACK_ROW(uc, yc, r - 2);
-		LOAD_UROW(uc, yc, r - 5);
+		BACK_ROW(ua, ya, xa, r);
+		LOAD_UROW(ua, ya, xa, r - 3);
+		BACK_ROW(ub, yb, xb, r - 1);
+		LOAD_UROW(ub, yb, xb, r - 4);
+		BACK_ROW(uc, yc, xc, r - 2);
+		LOAD_UROW(uc, yc, xc, r - 5);
 	}
+#undef ROW_SLAB
 #undef LOAD_UROW
 #undef BACK_ROW
 }
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nunique == 0) return;
-	hipLaunchKernelGGL(k_vi_fused, dim3((e->nunique + 63) / 64), dim3(64), 0, e->stream, p, xin, xup, dt,
+	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double);
+	hipLaunchKernelGGL(k_vi_fused, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
 		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
 }
