@@ -131,13 +131,20 @@ def main():
     for _ in range(args.warmup):
         eng.step_ars343(dt)
     barrier()
-    eng.profile_enable(True)
-    eng.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step_ars343(dt)
     barrier()
     wall = time.perf_counter() - t0
+    # per-kernel device time: the same K steps again with HIP events around every launch on the
+    # engine's stream (kept out of the timed region: the event markers cost a few % of wall time)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_ars343(dt)
+    barrier()
+    wall_prof = time.perf_counter() - t1
     prof = eng.profile()
     eng.profile_enable(False)
     if world > 1:
@@ -181,6 +188,7 @@ def main():
                          "traffic": None, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 3, 3)

@@ -203,6 +203,13 @@ int tmx_plan_get(tmx_engine * e, int what, int * out, int cap);
 /* [n_cross][4][8] doubles: per member the 2x2 matrix into the frame of member 0 and the 2x2 back. */
 int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
 
+/* Test hooks (tests/ only): n engines = ranks 0..n-1 of one grid inside ONE process on one device; the
+ * RCCL transport is replaced by device-to-device copies in wire order, everything else (packing, ghost
+ * indexing, DSS with remote members) is the production path. */
+int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int instance);
+/* Grouped ncclSend/ncclRecv to self through the engine's communicator and stream. */
+int tmx_debug_comm_selftest(tmx_engine * e);
+
 /* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.
  * kernel ids: TMX_K_* below.  Profiling is off by default (no events recorded). */
 enum {

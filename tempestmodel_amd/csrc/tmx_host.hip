@@ -783,6 +783,63 @@ static int exchange(tmx_engine * e, const KParams & p, double * x) {
 	return TMX_OK;
 }
 
+// ---- test hooks for the multi-rank device path on a single GPU ------------------------------------
+// Several engines (ranks 0..n-1 of the same n-rank grid) live in ONE process on one device; the
+// transport is replaced by device-to-device copies that follow exactly the wire order of the RCCL
+// path (segment [send_rank_off[r], send_rank_off[r+1]) of each slab of the sender -> segment
+// [recv_rank_off[s], ...) of the receiver's ghost buffer).  Packing, ghost indexing and the DSS
+// kernel with remote members are the production code.
+extern "C" int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int ix) {
+	REQUIRE(engines && n >= 1, TMX_ERR_INVALID, "tmx_debug_dss_loopback: bad argument");
+	int r;
+	for (int a = 0; a < n; a++) {
+		tmx_engine * e = engines[a];
+		if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
+		REQUIRE(e->cfg.n_ranks == n && e->cfg.rank == a, TMX_ERR_INVALID, "engine %d is rank %d of %d", a, e->cfg.rank, e->cfg.n_ranks);
+		tmxk_pack(e, make_params(e), inst(e, ix));
+		HIPCHK(hipStreamSynchronize(e->stream));
+	}
+	for (int s_ = 0; s_ < n; s_++) for (int d_ = 0; d_ < n; d_++) {
+		if (s_ == d_) continue;
+		tmx_engine * S = engines[s_], * D = engines[d_];
+		const int ns = S->send_rank_off[d_ + 1] - S->send_rank_off[d_], nr = D->recv_rank_off[s_ + 1] - D->recv_rank_off[s_];
+		REQUIRE(ns == nr, TMX_ERR_INVALID, "rank %d sends %d columns to rank %d which expects %d", s_, ns, d_, nr);
+		if (ns == 0) continue;
+		HIPCHK(hipMemcpy2D(D->d_ghost + D->recv_rank_off[s_], (size_t)D->nghost_pad * sizeof(double),
+			S->d_sendbuf + S->send_rank_off[d_], (size_t)S->nsend * sizeof(double),
+			(size_t)ns * sizeof(double), S->nslab, hipMemcpyDeviceToDevice));
+	}
+	for (int a = 0; a < n; a++) {
+		tmx_engine * e = engines[a];
+		tmxk_dss(e, make_params(e), inst(e, ix));
+		if ((r = launch_check("dss (loopback)"))) return r;
+	}
+	return TMX_OK;
+}
+
+// RCCL transport self-test on one rank: a grouped send/recv to self of the send buffer into the ghost
+// buffer region (library resolution, communicator, stream ordering).  Returns TMX_OK if the bytes arrive.
+extern "C" int tmx_debug_comm_selftest(tmx_engine * e) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init first");
+	const int n = 4096;
+	double * a = nullptr, * b = nullptr;
+	HIPCHK(hipMalloc((void **)&a, n * sizeof(double))); HIPCHK(hipMalloc((void **)&b, n * sizeof(double)));
+	std::vector<double> h(n), g(n, 0.0);
+	for (int i = 0; i < n; i++) h[i] = 0.5 * i + 1.0;
+	HIPCHK(hipMemcpy(a, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(b, 0, n * sizeof(double)));
+	NCCLCHK(g_nccl.GroupStart());
+	NCCLCHK(g_nccl.Send(a, (size_t)n, 8, e->cfg.rank, e->comm, e->stream));
+	NCCLCHK(g_nccl.Recv(b, (size_t)n, 8, e->cfg.rank, e->comm, e->stream));
+	NCCLCHK(g_nccl.GroupEnd());
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy(g.data(), b, n * sizeof(double), hipMemcpyDeviceToHost));
+	hipFree(a); hipFree(b);
+	for (int i = 0; i < n; i++) REQUIRE(g[i] == h[i], TMX_ERR_COMM, "RCCL self send/recv returned wrong data at %d", i);
+	return TMX_OK;
+}
+
 extern "C" int tmx_apply_dss(tmx_engine * e, int ix) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
 	KParams p = make_params(e);

@@ -274,6 +274,18 @@ class Engine:
             raise TempestError(code, lib.tmx_last_error().decode())
         return buf.raw
 
+    def comm_selftest(self):
+        self._chk(self.lib.tmx_debug_comm_selftest(self.h))
+
+    @staticmethod
+    def dss_loopback(engines, instance):
+        """Test hook: DSS across several single-process 'rank' engines (see tmx_debug_dss_loopback)."""
+        lib = load_library()
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        code = lib.tmx_debug_dss_loopback(arr, len(engines), instance)
+        if code != 0:
+            raise TempestError(code, lib.tmx_last_error().decode())
+
     def profile_enable(self, on=True):
         self._chk(self.lib.tmx_profile_enable(self.h, 1 if on else 0))
 
