@@ -156,7 +156,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
-		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_ucol); free_dev(e->d_udep);
+		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
 	}
@@ -556,6 +556,21 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
 	if ((r = dev_upload(&e->d_xmat, plan.xmat, &bytes))) return r;
 	if ((r = dev_upload(&e->d_send_cols, plan.send_cols, &bytes))) return r;
+	{
+		// wire layout [peer][slab][count_peer]: element t of a peer's segment at nslab*off + slab*count + (t - off)
+		std::vector<int> sb(e->nsend), ss(e->nsend), gb(e->nghost), gs(e->nghost);
+		for (int rk = 0; rk < NR; rk++) {
+			const int so = e->send_rank_off[rk], sc = e->send_rank_off[rk + 1] - so;
+			for (int t = 0; t < sc; t++) { sb[so + t] = e->nslab * so + t; ss[so + t] = sc; }
+			const int ro = e->recv_rank_off[rk], rc = e->recv_rank_off[rk + 1] - ro;
+			for (int t = 0; t < rc; t++) { gb[ro + t] = e->nslab * ro + t; gs[ro + t] = rc; }
+		}
+		REQUIRE((long long)e->nslab * std::max(e->nsend, e->nghost) < 0x7fffffffLL, TMX_ERR_UNSUPPORTED, "exchange buffer exceeds 2^31 doubles");
+		if ((r = dev_upload(&e->d_send_base, sb, &bytes))) return r;
+		if ((r = dev_upload(&e->d_send_stride, ss, &bytes))) return r;
+		if ((r = dev_upload(&e->d_ghost_base, gb, &bytes))) return r;
+		if ((r = dev_upload(&e->d_ghost_stride, gs, &bytes))) return r;
+	}
 	if ((r = dev_upload(&e->d_ucol, plan.ucol, &bytes))) return r;
 	if ((r = dev_upload(&e->d_udep, plan.udep, &bytes))) return r;
 	const size_t gb = (size_t)e->nslab * e->nghost_pad * sizeof(double), sb = (size_t)e->nslab * std::max(e->nsend, 1) * sizeof(double);
@@ -768,16 +783,14 @@ static int exchange(tmx_engine * e, const KParams & p, double * x) {
 	if (e->cfg.n_ranks == 1 || (e->nsend == 0 && e->nghost == 0)) return TMX_OK;
 	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
-	// sendbuf / ghost are laid out [slab][n]; one send/recv per (peer, slab run) would be many small
-	// messages, so the per-peer segments are sent slab by slab inside ONE group call.
+	// ONE message per neighbour rank per exchange (the reference aggregates its ExchangeBuffers the same
+	// way, Connectivity.cpp:928-993): buffers are [peer][slab][count_peer], contiguous per peer.
 	tmxk_pack(e, p, x);
 	NCCLCHK(g_nccl.GroupStart());
 	for (int rk = 0; rk < e->cfg.n_ranks; rk++) {
 		const int ns = e->send_rank_off[rk + 1] - e->send_rank_off[rk], nr = e->recv_rank_off[rk + 1] - e->recv_rank_off[rk];
-		for (int sl = 0; sl < e->nslab; sl++) {
-			if (ns) NCCLCHK(g_nccl.Send(e->d_sendbuf + (size_t)sl * e->nsend + e->send_rank_off[rk], (size_t)ns, 8 /* ncclFloat64 */, rk, e->comm, e->stream));
-			if (nr) NCCLCHK(g_nccl.Recv(e->d_ghost + (size_t)sl * e->nghost_pad + e->recv_rank_off[rk], (size_t)nr, 8, rk, e->comm, e->stream));
-		}
+		if (ns) NCCLCHK(g_nccl.Send(e->d_sendbuf + (size_t)e->nslab * e->send_rank_off[rk], (size_t)ns * e->nslab, 8 /* ncclFloat64 */, rk, e->comm, e->stream));
+		if (nr) NCCLCHK(g_nccl.Recv(e->d_ghost + (size_t)e->nslab * e->recv_rank_off[rk], (size_t)nr * e->nslab, 8, rk, e->comm, e->stream));
 	}
 	NCCLCHK(g_nccl.GroupEnd());
 	return TMX_OK;
@@ -805,10 +818,10 @@ extern "C" int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int ix) {
 		const int ns = S->send_rank_off[d_ + 1] - S->send_rank_off[d_], nr = D->recv_rank_off[s_ + 1] - D->recv_rank_off[s_];
 		REQUIRE(ns == nr, TMX_ERR_INVALID, "rank %d sends %d columns to rank %d which expects %d", s_, ns, d_, nr);
 		if (ns == 0) continue;
-		HIPCHK(hipMemcpy2D(D->d_ghost + D->recv_rank_off[s_], (size_t)D->nghost_pad * sizeof(double),
-			S->d_sendbuf + S->send_rank_off[d_], (size_t)S->nsend * sizeof(double),
-			(size_t)ns * sizeof(double), S->nslab, hipMemcpyDeviceToDevice));
+		HIPCHK(hipMemcpy(D->d_ghost + (size_t)D->nslab * D->recv_rank_off[s_], S->d_sendbuf + (size_t)S->nslab * S->send_rank_off[d_],
+			(size_t)ns * S->nslab * sizeof(double), hipMemcpyDeviceToDevice));
 	}
+	HIPCHK(hipDeviceSynchronize());     // device-to-device copies may still be in flight on the null stream
 	for (int a = 0; a < n; a++) {
 		tmx_engine * e = engines[a];
 		tmxk_dss(e, make_params(e), inst(e, ix));

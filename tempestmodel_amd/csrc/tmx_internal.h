@@ -83,7 +83,8 @@ struct tmx_engine {
 	double * d_xmat = nullptr;               // [nxgroups][4][2][4]: per member A (to frame) and B (from frame)
 	double * d_ghost = nullptr;              // [nslab][nghost_pad] received remote copies
 	double * d_sendbuf = nullptr;
-	int * d_send_cols = nullptr;
+	int * d_send_cols = nullptr, * d_send_base = nullptr, * d_send_stride = nullptr;
+	int * d_ghost_base = nullptr, * d_ghost_stride = nullptr;
 	int nsend = 0, nghost_pad = 0;
 	std::vector<int> send_rank_off, recv_rank_off;   // per-rank offsets (size n_ranks+1)
 	// implicit solve

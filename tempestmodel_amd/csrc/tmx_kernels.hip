@@ -302,8 +302,8 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 // read from the ghost buffer filled by the exchange.
 
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
-	int nghost_pad, int ngroups, const int * __restrict__ gcols, const int * __restrict__ gn,
-	const int * __restrict__ gx, const double * __restrict__ xmat)
+	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
+	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -316,9 +316,17 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	for (int m = 0; m < 4; m++) c[m] = gcols[g * 4 + m];
 	const int xi = gx[g];
 
+	// remote copies sit in the receive buffer exactly as they came off the wire: [peer][slab][count_peer]
+	int gb[4], gs[4];
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+		const bool gh = (c[m] >= (int)NS);
+		gb[m] = gh ? gbase[c[m] - (int)NS] : 0;
+		gs[m] = gh ? gstride[c[m] - (int)NS] : 0;
+	}
 	auto ld = [&](int slab, int m) -> double {
 		const int cc = c[m];
-		return (cc < (int)NS) ? x[(size_t)slab * NS + cc] : ghost[(size_t)slab * nghost_pad + (cc - (int)NS)];
+		return (cc < (int)NS) ? x[(size_t)slab * NS + cc] : ghost[(size_t)gb[m] + (size_t)slab * gs[m]];
 	};
 	auto avg = [&](const double * v) -> double {
 		if (n == 2) return 0.5 * (v[0] + v[1]);
@@ -360,25 +368,28 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
 	if (e->ngroups == 0) return;
 	dim3 blk(64, 4), grd((e->ngroups + 63) / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, e->nghost_pad, e->ngroups,
+	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, (const int *)e->d_ghost_base,
+		(const int *)e->d_ghost_stride, e->ngroups,
 		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat);
 }
 
-// gather the copies other ranks need into the send buffer: sendbuf[slab][i] = x[slab][send_cols[i]]
-__global__ __launch_bounds__(256) void k_pack(int nslab, size_t NS, int nsend, int nsend_pad,
-	const double * __restrict__ x, const int * __restrict__ cols, double * __restrict__ buf)
+// gather the copies other ranks need into the send buffer, one contiguous message per peer:
+// sendbuf = [peer][slab][count_peer]; entry i of the plan lives at base[i] + slab * stride[i]
+__global__ __launch_bounds__(256) void k_pack(int nslab, size_t NS, int nsend,
+	const double * __restrict__ x, const int * __restrict__ cols, const int * __restrict__ base,
+	const int * __restrict__ stride, double * __restrict__ buf)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	const int sl = blockIdx.y;
 	if (i >= nsend) return;
-	buf[(size_t)sl * nsend_pad + i] = x[(size_t)sl * NS + cols[i]];
+	buf[(size_t)base[i] + (size_t)sl * stride[i]] = x[(size_t)sl * NS + cols[i]];
 }
 
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x) {
 	if (e->nsend == 0) return;
 	dim3 blk(256), grd((e->nsend + 255) / 256, e->nslab);
-	hipLaunchKernelGGL(k_pack, grd, blk, 0, e->stream, e->nslab, (size_t)p.NS, e->nsend, e->nsend,
-		x, (const int *)e->d_send_cols, e->d_sendbuf);
+	hipLaunchKernelGGL(k_pack, grd, blk, 0, e->stream, e->nslab, (size_t)p.NS, e->nsend,
+		x, (const int *)e->d_send_cols, (const int *)e->d_send_base, (const int *)e->d_send_stride, e->d_sendbuf);
 }
 
 // ---------------------------------------------------------------------------------------------
