@@ -1,0 +1,390 @@
+// adapter/TempestMI355X.h -- the reference-side binding of the MI355X engine.
+//
+// Three thin subclasses of Tempest's own plugin interfaces that forward to the C ABI
+// (include/tempest_mi355x.h).  Compiles against the reference headers (src/atm, src/base) and
+// contains no reference code; this is the file a Tempest maintainer adds.
+//
+//   TimestepSchemeARS343_MI355X  production mode: the whole IMEX step runs on the GPU, the host
+//                                arrays are refreshed (instance 0) at the end of every Step.
+//   HorizontalDynamicsMI355X /   parity mode: the reference's own TimestepScheme, Grid::CopyData,
+//   VerticalDynamicsMI355X       LinearCombineData and ApplyDSS keep running on the host arrays; every
+//                                call uploads the instances it reads and downloads the one it writes.
+//
+// Interfaces honoured: HorizontalDynamics (src/atm/HorizontalDynamics.h:34-175), VerticalDynamics
+// (src/atm/VerticalDynamics.h:29-135), TimestepScheme (src/atm/TimestepScheme.h:32-125).
+#ifndef TEMPEST_MI355X_ADAPTER_H
+#define TEMPEST_MI355X_ADAPTER_H
+
+#include "Model.h"
+#include "GridGLL.h"
+#include "GridCSGLL.h"
+#include "GridPatchGLL.h"
+#include "GridSpacing.h"
+#include "CubedSphereTrans.h"
+#include "HorizontalDynamics.h"
+#include "VerticalDynamics.h"
+#include "TimestepScheme.h"
+#include "Exception.h"
+
+#include "tempest_mi355x.h"
+
+#include <cmath>
+#include <map>
+#include <vector>
+
+///////////////////////////////////////////////////////////////////////////////
+
+class MI355XEngine {
+public:
+	static MI355XEngine & For(Model & model) {
+		static std::map<Model *, MI355XEngine *> s_map;
+		std::map<Model *, MI355XEngine *>::iterator it = s_map.find(&model);
+		if (it == s_map.end()) {
+			it = s_map.insert(std::make_pair(&model, new MI355XEngine(model))).first;
+		}
+		return *(it->second);
+	}
+
+	void SetViscosity(double dNuScalar, double dNuDiv, double dNuVort, int nOrder) {
+		m_dNuScalar = dNuScalar; m_dNuDiv = dNuDiv; m_dNuVort = dNuVort; m_nHypervisOrder = nOrder;
+	}
+
+	static void Check(int iRet) {
+		if (iRet != TMX_OK) {
+			_EXCEPTION1("tempest_mi355x: %s", tmx_last_error());
+		}
+	}
+
+	tmx_engine * Handle() { Initialize(); return m_pEngine; }
+
+	// GridPatch::GetDataState arrays -> device
+	void Upload(int ixData) {
+		Initialize();
+		GridGLL * pGrid = Grid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			Check(tmx_upload_state(m_pEngine, pPatch->GetPatchIndex(), ixData,
+				&(pPatch->GetDataState(ixData, DataLocation_Node)[0][0][0][0]),
+				&(pPatch->GetDataState(ixData, DataLocation_REdge)[0][0][0][0])));
+		}
+	}
+
+	// device -> GridPatch::GetDataState arrays (interior nodes; halo untouched)
+	void Download(int ixData) {
+		Initialize();
+		GridGLL * pGrid = Grid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			Check(tmx_download_state(m_pEngine, pPatch->GetPatchIndex(), ixData,
+				&(pPatch->GetDataState(ixData, DataLocation_Node)[0][0][0][0]),
+				&(pPatch->GetDataState(ixData, DataLocation_REdge)[0][0][0][0])));
+		}
+	}
+
+	~MI355XEngine() {
+		if (m_pEngine != NULL) {
+			tmx_destroy(m_pEngine);
+		}
+	}
+
+private:
+	MI355XEngine(Model & model) :
+		m_model(model), m_pEngine(NULL),
+		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4)
+	{ }
+
+	GridGLL * Grid() {
+		GridGLL * pGrid = dynamic_cast<GridGLL *>(m_model.GetGrid());
+		if (pGrid == NULL) {
+			_EXCEPTIONT("tempest_mi355x requires a GridGLL");
+		}
+		return pGrid;
+	}
+
+	// Called on first use, i.e. after Model::Go has evaluated the geometric terms.
+	void Initialize() {
+		if (m_pEngine != NULL) {
+			return;
+		}
+		GridGLL * pGrid = Grid();
+		if (pGrid->GetActivePatchCount() == 0) {
+			_EXCEPTIONT("tempest_mi355x: no active patch on this rank");
+		}
+		const PhysicalConstants & phys = m_model.GetPhysicalConstants();
+		const int nOrder = pGrid->GetHorizontalOrder();
+		const int nRElements = pGrid->GetRElements();
+		const int nPatches = pGrid->GetPatchCount();
+
+		int nRank = 0;
+		int nRanks = 1;
+#ifdef TEMPEST_MPIOMP
+		MPI_Comm_rank(MPI_COMM_WORLD, &nRank);
+		MPI_Comm_size(MPI_COMM_WORLD, &nRanks);
+#endif
+
+		tmx_config cfg;
+		cfg.abi_version = TMX_ABI_VERSION;
+		cfg.horizontal_order = nOrder;
+		cfg.vertical_order = pGrid->GetVerticalOrder();
+		cfg.levels = nRElements;
+		cfg.n_patches = nPatches;
+		cfg.n_instances = m_model.GetComponentDataInstances();
+		cfg.n_tracers = m_model.GetEquationSet().GetTracers();
+		cfg.hypervis_order = m_nHypervisOrder;
+		cfg.element_delta_a =
+			dynamic_cast<GridPatchGLL *>(pGrid->GetActivePatch(0))->GetElementDeltaA();
+		cfg.reference_length = pGrid->GetReferenceLength();
+		cfg.grav = phys.GetG();
+		cfg.Rd = phys.GetR();
+		cfg.cp = phys.GetCp();
+		cfg.p0 = phys.GetP0();
+		cfg.nu_scalar = m_dNuScalar;
+		cfg.nu_div = m_dNuDiv;
+		cfg.nu_vort = m_dNuVort;
+		cfg.rank = nRank;
+		cfg.n_ranks = nRanks;
+		cfg.device = -1;
+		Check(tmx_create(&cfg, &m_pEngine));
+
+		// 1-D spectral-element matrices and the ten column operators
+		{
+			const LinearColumnOperator * ops[TMX_OP_COUNT] = {
+				&(pGrid->GetOpInterpNodeToREdge()), &(pGrid->GetOpInterpREdgeToNode()),
+				&(pGrid->GetOpDiffNodeToNode()), &(pGrid->GetOpDiffNodeToREdge()),
+				&(pGrid->GetOpDiffREdgeToNode()), &(pGrid->GetOpDiffREdgeToREdge()),
+				&(pGrid->GetOpDiffDiffNodeToNode()), &(pGrid->GetOpDiffDiffREdgeToREdge()),
+				&(pGrid->GetOpPenaltyNodeToNode().GetLeftOp()), &(pGrid->GetOpPenaltyNodeToNode().GetRightOp())};
+			const double * coeff[TMX_OP_COUNT];
+			const int * ixb[TMX_OP_COUNT];
+			const int * ixe[TMX_OP_COUNT];
+			int nOut[TMX_OP_COUNT];
+			int nIn[TMX_OP_COUNT];
+			std::vector< std::vector<int> > vecB(TMX_OP_COUNT), vecE(TMX_OP_COUNT);
+			for (int o = 0; o < TMX_OP_COUNT; o++) {
+				const DataArray2D<double> & dC = ops[o]->GetCoeffs();
+				nOut[o] = dC.GetRows();
+				nIn[o] = dC.GetColumns();
+				coeff[o] = &(dC[0][0]);
+				for (int k = 0; k < nOut[o]; k++) {
+					vecB[o].push_back(ops[o]->GetIxBegin()[k]);
+					vecE[o].push_back(ops[o]->GetIxEnd()[k]);
+				}
+				ixb[o] = &(vecB[o][0]);
+				ixe[o] = &(vecE[o][0]);
+			}
+			// dStiffness1D is stored (m,i) with S[m][i] used as dStiffness1D(i,s): same row-major layout
+			Check(tmx_set_operators(m_pEngine,
+				&(pGrid->GetDxBasis1D()[0][0]), &(pGrid->GetStiffness1D()[0][0]),
+				coeff, ixb, ixe, nOut, nIn));
+		}
+
+		// Patches of the whole grid and their halo rings
+		const int nGlobalNodes = nOrder * pGrid->GetABaseResolution();
+		GridSpacingGaussLobattoRepeated glspacing(
+			0.5 * M_PI / pGrid->GetABaseResolution(), -0.25 * M_PI, nOrder);
+
+		for (int n = 0; n < nPatches; n++) {
+			const PatchBox & box = pGrid->GetPatchBox(n);
+			int ixNeighbor[8];
+			const int iProbeA[8] = {
+				box.GetAGlobalInteriorEnd(), box.GetAGlobalInteriorBegin(),
+				box.GetAGlobalInteriorBegin()-1, box.GetAGlobalInteriorBegin(),
+				box.GetAGlobalInteriorEnd(), box.GetAGlobalInteriorBegin()-1,
+				box.GetAGlobalInteriorBegin()-1, box.GetAGlobalInteriorEnd()};
+			const int iProbeB[8] = {
+				box.GetBGlobalInteriorBegin(), box.GetBGlobalInteriorEnd(),
+				box.GetBGlobalInteriorBegin(), box.GetBGlobalInteriorBegin()-1,
+				box.GetBGlobalInteriorEnd(), box.GetBGlobalInteriorEnd(),
+				box.GetBGlobalInteriorBegin()-1, box.GetBGlobalInteriorBegin()-1};
+			for (int d = 0; d < 8; d++) {
+				int ixA, ixB; bool f1, f2, f3;
+				CubedSphereTrans::RelativeCoord(
+					nGlobalNodes, box.GetPanel(), iProbeA[d], iProbeB[d],
+					ixNeighbor[d], ixA, ixB, f1, f2, f3);
+				if ((ixA == (-1)) && (ixB == (-1))) {
+					ixNeighbor[d] = -1;
+				}
+			}
+			Check(tmx_define_patch(m_pEngine, n, box.GetPanel(),
+				box.GetAInteriorWidth() / nOrder, box.GetBInteriorWidth() / nOrder,
+				pGrid->GetPatchProcessor(n), ixNeighbor));
+		}
+
+		for (int n = 0; n < nPatches; n++) {
+			const PatchBox & box = pGrid->GetPatchBox(n);
+			const int nA = box.GetATotalWidth();
+			const int nB = box.GetBTotalWidth();
+			std::vector<int> hi, hj, sp, si, sj, spanel;
+			std::vector<double> trans;
+			for (int i = 0; i < nA; i++) {
+			for (int j = 0; j < nB; j++) {
+				if ((i != 0) && (j != 0) && (i != nA-1) && (j != nB-1)) {
+					continue;
+				}
+				const int gA = box.GetAGlobalBegin() + i;
+				const int gB = box.GetBGlobalBegin() + j;
+				int ixPanel, ixA, ixB; bool f1, f2, f3;
+				CubedSphereTrans::RelativeCoord(
+					nGlobalNodes, box.GetPanel(), gA, gB, ixPanel, ixA, ixB, f1, f2, f3);
+				hi.push_back(i);
+				hj.push_back(j);
+				double dT[4] = {1.0, 0.0, 0.0, 1.0};
+				int ixSrcPatch = -1;
+				if (!((ixA == (-1)) && (ixB == (-1)))) {
+					for (int m = 0; m < nPatches; m++) {
+						if (pGrid->GetPatchBox(m).ContainsGlobalPoint(ixPanel, ixA, ixB)) {
+							ixSrcPatch = m;
+							break;
+						}
+					}
+				}
+				if (ixSrcPatch < 0) {
+					sp.push_back(-1); si.push_back(0); sj.push_back(0); spanel.push_back(-1);
+				} else {
+					const PatchBox & boxSrc = pGrid->GetPatchBox(ixSrcPatch);
+					sp.push_back(ixSrcPatch);
+					si.push_back(ixA - boxSrc.GetAGlobalBegin());
+					sj.push_back(ixB - boxSrc.GetBGlobalBegin());
+					spanel.push_back(ixPanel);
+					if (ixPanel != box.GetPanel()) {
+						// the call GridPatchCSGLL::TransformHaloVelocities makes, probed with unit vectors
+						const double dX = tan(glspacing.GetNode(gA));
+						const double dY = tan(glspacing.GetNode(gB));
+						double dA0 = 1.0, dB0 = 0.0, dA1 = 0.0, dB1 = 1.0;
+						CubedSphereTrans::CoVecPanelTrans(ixPanel, box.GetPanel(), dA0, dB0, dX, dY);
+						CubedSphereTrans::CoVecPanelTrans(ixPanel, box.GetPanel(), dA1, dB1, dX, dY);
+						dT[0] = dA0; dT[1] = dA1; dT[2] = dB0; dT[3] = dB1;
+					}
+				}
+				trans.insert(trans.end(), dT, dT + 4);
+			}
+			}
+			Check(tmx_set_patch_halo(m_pEngine, n, (int)hi.size(),
+				&hi[0], &hj[0], &sp[0], &si[0], &sj[0], &spanel[0], &trans[0]));
+		}
+
+		// Geometry of the patches this rank owns
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			tmx_patch_geometry g;
+			g.jacobian2d = &(pPatch->GetJacobian2D()[0][0]);
+			g.contra_metric_2d_a = &(pPatch->GetContraMetric2DA()[0][0][0]);
+			g.contra_metric_2d_b = &(pPatch->GetContraMetric2DB()[0][0][0]);
+			g.jacobian = &(pPatch->GetJacobian()[0][0][0]);
+			g.jacobian_redge = &(pPatch->GetJacobianREdge()[0][0][0]);
+			g.contra_metric_a = &(pPatch->GetContraMetricA()[0][0][0][0]);
+			g.contra_metric_b = &(pPatch->GetContraMetricB()[0][0][0][0]);
+			g.contra_metric_xi = &(pPatch->GetContraMetricXi()[0][0][0][0]);
+			g.contra_metric_a_redge = &(pPatch->GetContraMetricAREdge()[0][0][0][0]);
+			g.contra_metric_b_redge = &(pPatch->GetContraMetricBREdge()[0][0][0][0]);
+			g.contra_metric_xi_redge = &(pPatch->GetContraMetricXiREdge()[0][0][0][0]);
+			g.deriv_r_node = &(pPatch->GetDerivRNode()[0][0][0][0]);
+			g.deriv_r_redge = &(pPatch->GetDerivRREdge()[0][0][0][0]);
+			g.coriolis_f = &(pPatch->GetCoriolisF()[0][0]);
+			Check(tmx_set_patch_geometry(m_pEngine, pPatch->GetPatchIndex(), &g));
+		}
+		Check(tmx_finalize(m_pEngine));
+
+#ifdef TEMPEST_MPIOMP
+		if (nRanks > 1) {
+			unsigned char id[128];
+			if (nRank == 0) {
+				Check(tmx_comm_unique_id(id));
+			}
+			MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+			Check(tmx_comm_init(m_pEngine, id));
+		}
+#endif
+	}
+
+private:
+	Model & m_model;
+	tmx_engine * m_pEngine;
+	double m_dNuScalar, m_dNuDiv, m_dNuVort;
+	int m_nHypervisOrder;
+};
+
+///////////////////////////////////////////////////////////////////////////////
+
+///	<summary>
+///		Drop-in for HorizontalDynamicsFEM (nonhydrostatic primitive equations).
+///	</summary>
+class HorizontalDynamicsMI355X : public HorizontalDynamics {
+public:
+	HorizontalDynamicsMI355X(
+		Model & model, int nHorizontalOrder, int nHyperviscosityOrder,
+		double dNuScalar, double dNuDiv, double dNuVort
+	) : HorizontalDynamics(model) {
+		MI355XEngine::For(model).SetViscosity(dNuScalar, dNuDiv, dNuVort, nHyperviscosityOrder);
+	}
+
+	virtual void StepExplicit(int iDataInitial, int iDataUpdate, const Time & time, double dDeltaT) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		eng.Upload(iDataUpdate);
+		MI355XEngine::Check(tmx_h_step_explicit(eng.Handle(), iDataInitial, iDataUpdate, dDeltaT));
+		eng.Download(iDataInitial);   // derived slots written by the reference's prologue
+		eng.Download(iDataUpdate);
+	}
+
+	virtual void StepAfterSubCycle(
+		int iDataInitial, int iDataUpdate, int iDataWorking, const Time & time, double dDeltaT
+	) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		MI355XEngine::Check(tmx_h_step_after_subcycle(
+			eng.Handle(), iDataInitial, iDataUpdate, iDataWorking, dDeltaT));
+		eng.Download(iDataUpdate);
+		eng.Download(iDataWorking);
+	}
+};
+
+///	<summary>
+///		Drop-in for VerticalDynamicsFEM (implicit mode).
+///	</summary>
+class VerticalDynamicsMI355X : public VerticalDynamics {
+public:
+	VerticalDynamicsMI355X(Model & model, int nHorizontalOrder, int nVerticalOrder) :
+		VerticalDynamics(model)
+	{ }
+
+	virtual void StepExplicit(int iDataInitial, int iDataUpdate, const Time & time, double dDeltaT) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		eng.Upload(iDataUpdate);
+		MI355XEngine::Check(tmx_v_step_explicit(eng.Handle(), iDataInitial, iDataUpdate, dDeltaT));
+		eng.Download(iDataUpdate);
+	}
+
+	virtual void StepImplicit(int iDataInitial, int iDataUpdate, const Time & time, double dDeltaT) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		if (iDataUpdate != iDataInitial) {
+			eng.Upload(iDataUpdate);
+		}
+		MI355XEngine::Check(tmx_v_step_implicit(eng.Handle(), iDataInitial, iDataUpdate, dDeltaT));
+		MI355XEngine::Check(tmx_sync(eng.Handle()));
+		eng.Download(iDataUpdate);
+	}
+};
+
+///	<summary>
+///		Drop-in for TimestepSchemeARS343: the whole step on the device.
+///	</summary>
+class TimestepSchemeARS343_MI355X : public TimestepScheme {
+public:
+	TimestepSchemeARS343_MI355X(Model & model) : TimestepScheme(model) { }
+
+	virtual int GetComponentDataInstances() const { return 7; }   // TimestepSchemeARS343.h:48-56
+	virtual int GetTracerDataInstances() const { return 7; }
+
+	virtual void Step(bool fFirstStep, bool fLastStep, const Time & time, double dDeltaT) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(0);
+		MI355XEngine::Check(tmx_step_ars343(eng.Handle(), dDeltaT));
+		MI355XEngine::Check(tmx_sync(eng.Handle()));
+		eng.Download(0);
+	}
+};
+
+#endif

@@ -1,0 +1,197 @@
+// adapter/mi355x_driver.cpp -- end-to-end drop-in check (test infrastructure).
+//
+// Runs the reference's own Model / Grid / BaroclinicWaveJWTest with the adapter plugins of
+// TempestMI355X.h installed, and compares against the pure reference inside the same process:
+//
+//   1. build the model exactly as the reference test driver does (TempestInitialize.h:476-586);
+//   2. `--warm` steps with the reference classes (leaves the balanced initial state);
+//   3. K steps with the reference classes                      -> state R
+//   4. restore, K steps through the adapter (--mode production: TimestepSchemeARS343_MI355X;
+//      --mode parity: HorizontalDynamicsMI355X + VerticalDynamicsMI355X under the reference's own
+//      TimestepSchemeARS343)                                   -> state G
+//   5. print max |G - R| / max |R| per variable; exit status 0 iff below --tol.
+//
+// The reference test case is pulled in by #include of its own translation unit where it lies.
+
+#define main tmx_unused_jw_main
+#include "BaroclinicWaveJWTest.cpp"
+#undef main
+
+#include "TempestMI355X.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// Plugins that forward either to the reference implementation or to the adapter.
+class HSwitch : public HorizontalDynamics {
+public:
+	HorizontalDynamicsFEM m_ref;
+	HorizontalDynamicsMI355X m_dev;
+	bool m_fDevice;
+	HSwitch(Model & model) :
+		HorizontalDynamics(model),
+		m_ref(model, 4, 4, 1.0e15, 1.0e15, 1.0e15, 0.0),
+		m_dev(model, 4, 4, 1.0e15, 1.0e15, 1.0e15),
+		m_fDevice(false) { }
+	virtual void Initialize() { static_cast<HorizontalDynamics &>(m_ref).Initialize(); }
+	virtual void StepExplicit(int a, int b, const Time & t, double dt) {
+		if (m_fDevice) m_dev.StepExplicit(a, b, t, dt); else static_cast<HorizontalDynamics &>(m_ref).StepExplicit(a, b, t, dt);
+	}
+	virtual void StepAfterSubCycle(int a, int b, int c, const Time & t, double dt) {
+		if (m_fDevice) m_dev.StepAfterSubCycle(a, b, c, t, dt); else static_cast<HorizontalDynamics &>(m_ref).StepAfterSubCycle(a, b, c, t, dt);
+	}
+};
+
+class VSwitch : public VerticalDynamics {
+public:
+	VerticalDynamicsFEM m_ref;
+	VerticalDynamicsMI355X m_dev;
+	bool m_fDevice;
+	VSwitch(Model & model) :
+		VerticalDynamics(model),
+		m_ref(model, 4, 1, 0, false, true, false),
+		m_dev(model, 4, 1),
+		m_fDevice(false) { }
+	virtual void Initialize() { static_cast<VerticalDynamics &>(m_ref).Initialize(); }
+	virtual void StepExplicit(int a, int b, const Time & t, double dt) {
+		if (m_fDevice) m_dev.StepExplicit(a, b, t, dt); else static_cast<VerticalDynamics &>(m_ref).StepExplicit(a, b, t, dt);
+	}
+	virtual void StepImplicit(int a, int b, const Time & t, double dt) {
+		if (m_fDevice) m_dev.StepImplicit(a, b, t, dt); else static_cast<VerticalDynamics &>(m_ref).StepImplicit(a, b, t, dt);
+	}
+};
+
+class TSwitch : public TimestepScheme {
+public:
+	TimestepSchemeARS343 m_ref;
+	TimestepSchemeARS343_MI355X m_dev;
+	bool m_fDevice;
+	TSwitch(Model & model) : TimestepScheme(model), m_ref(model), m_dev(model), m_fDevice(false) { }
+	virtual int GetComponentDataInstances() const { return static_cast<const TimestepScheme &>(m_ref).GetComponentDataInstances(); }
+	virtual int GetTracerDataInstances() const { return static_cast<const TimestepScheme &>(m_ref).GetTracerDataInstances(); }
+	virtual void Initialize() { static_cast<TimestepScheme &>(m_ref).Initialize(); }
+	virtual void Step(bool f, bool l, const Time & t, double dt) {
+		if (m_fDevice) m_dev.Step(f, l, t, dt); else static_cast<TimestepScheme &>(m_ref).Step(f, l, t, dt);
+	}
+};
+
+typedef std::vector< std::vector<double> > Snapshot;
+
+static void save(GridGLL * pGrid, Snapshot & s) {
+	s.clear();
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		GridPatch * p = pGrid->GetActivePatch(n);
+		for (int loc = 0; loc < 2; loc++) {
+			DataArray4D<double> & d = p->GetDataState(0, loc ? DataLocation_REdge : DataLocation_Node);
+			s.push_back(std::vector<double>(&d[0][0][0][0], &d[0][0][0][0] + d.GetTotalSize()));
+		}
+	}
+}
+
+static void restore(GridGLL * pGrid, const Snapshot & s) {
+	int q = 0;
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		GridPatch * p = pGrid->GetActivePatch(n);
+		for (int loc = 0; loc < 2; loc++) {
+			DataArray4D<double> & d = p->GetDataState(0, loc ? DataLocation_REdge : DataLocation_Node);
+			memcpy(&d[0][0][0][0], &s[q][0], s[q].size() * sizeof(double));
+			q++;
+		}
+	}
+}
+
+int main(int argc, char ** argv) {
+	TempestInitialize(&argc, &argv);
+	std::string mode = "production";
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1;
+	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		const char * v = (i + 1 < argc) ? argv[i+1] : "";
+		if (a == "--mode") { mode = v; i++; }
+		else if (a == "--ne") { ne = atoi(v); i++; }
+		else if (a == "--levels") { levels = atoi(v); i++; }
+		else if (a == "--steps") { nsteps = atoi(v); i++; }
+		else if (a == "--warm") { nwarm = atoi(v); i++; }
+		else if (a == "--patches") { npatch = atoi(v); i++; }
+		else if (a == "--dt") { dt = atof(v); i++; }
+		else if (a == "--tol") { tol = atof(v); i++; }
+		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
+	}
+	int status = 1;
+try {
+	AnnounceSetVerbosityLevel(0);
+	Model model(EquationSet::PrimitiveNonhydrostaticEquations);
+	Time timeDeltaT(0, 0, 0, (int)dt, 0, Time::CalendarNoLeap, Time::TypeDelta);
+	model.SetDeltaT(timeDeltaT);
+	model.SetEndTime(model.GetStartTime());
+
+	TSwitch * pT = new TSwitch(model);
+	HSwitch * pH = new HSwitch(model);
+	VSwitch * pV = new VSwitch(model);
+	model.SetTimestepScheme(pT);
+	model.SetHorizontalDynamics(pH);
+	model.SetVerticalDynamics(pV);
+
+	GridCSGLL * pGrid = new GridCSGLL(model);
+	pGrid->DefineParameters();
+	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, 1,
+		Grid::VerticalDiscretization_FiniteElement, Grid::VerticalStaggering_Lorenz);
+	pGrid->InitializeDataLocal();
+	model.SetGrid(pGrid, npatch);
+	model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, BaroclinicWaveJWTest::PerturbationType_Exp));
+	model.Go();     // initialisation only (end time == start time)
+
+	Time time = model.GetStartTime();
+	for (int s = 0; s < nwarm; s++) { pT->Step(s == 0, false, time, dt); time += timeDeltaT; }
+	Snapshot start, ref, got;
+	save(pGrid, start);
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); }
+	save(pGrid, ref);
+
+	restore(pGrid, start);
+	if (mode == "production") { pT->m_fDevice = true; }
+	else if (mode == "parity") { pH->m_fDevice = true; pV->m_fDevice = true; }
+	else { fprintf(stderr, "bad mode\n"); return 2; }
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); }
+	save(pGrid, got);
+
+	// compare prognostic slots on interior nodes
+	const int L = levels;
+	double dmax[5] = {0, 0, 0, 0, 0}, smax[5] = {0, 0, 0, 0, 0};
+	int q = 0;
+	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+		const PatchBox & box = pGrid->GetActivePatch(n)->GetPatchBox();
+		const int nA = box.GetATotalWidth(), nB = box.GetBTotalWidth();
+		for (int loc = 0; loc < 2; loc++, q++) {
+			const int Lk = loc ? L + 1 : L;
+			for (int c = 0; c < 5; c++) {
+				if ((c == 3) != (loc == 1)) continue;
+				for (int i = 1; i < nA - 1; i++) for (int j = 1; j < nB - 1; j++) for (int k = 0; k < Lk; k++) {
+					const size_t o = (((size_t)c * nA + i) * nB + j) * Lk + k;
+					const double d = fabs(got[q][o] - ref[q][o]), sv = fabs(ref[q][o]);
+					if (d > dmax[c]) dmax[c] = d;
+					if (sv > smax[c]) smax[c] = sv;
+				}
+			}
+		}
+	}
+	double worst = 0.0;
+	printf("adapter %s ne%d L%d patches=%d steps=%d: max rel diff vs reference (U V rhotheta W rho):", mode.c_str(), ne, levels, npatch, nsteps);
+	for (int c = 0; c < 5; c++) {
+		const double r = (smax[c] > 0) ? dmax[c] / smax[c] : dmax[c];
+		printf(" %.3e", r);
+		if (r > worst) worst = r;
+	}
+	printf("\n");
+	status = (worst < tol) ? 0 : 1;
+	printf("%s\n", status == 0 ? "ADAPTER_OK" : "ADAPTER_MISMATCH");
+} catch (Exception & e) {
+	std::cout << e.ToString() << std::endl;
+	status = 3;
+}
+	TempestDeinitialize();
+	return status;
+}

@@ -1,0 +1,30 @@
+"""End-to-end drop-in check on the GPU: the REAL reference (Model, Grid, BaroclinicWaveJWTest,
+TimestepSchemeARS343, ApplyDSS ... compiled from /root/reference into oracle/_ref) running with the
+adapter plugins of adapter/TempestMI355X.h, compared inside one process with the pure reference.
+
+The binary is built in the build container (`make -C oracle ref`) and travels with the snapshot;
+the test is skipped where it is absent."""
+import os
+import subprocess
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
+
+
+@pytest.mark.parametrize("mode,args", [
+    ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6"]),
+    ("production", ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
+    ("parity", ["--ne", "4", "--levels", "10", "--steps", "3", "--patches", "6"]),
+])
+def test_reference_driver_with_adapter_plugins(mode, args):
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/tmx_adapter_run not built (needs /root/reference)")
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([BIN, "--mode", mode, "--dt", "200", "--warm", "1", "--tol", "1e-10"] + args,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-6:])
+    print(tail)
+    assert r.returncode == 0 and "ADAPTER_OK" in r.stdout, tail
