@@ -165,9 +165,22 @@ int tmx_apply_dss(tmx_engine * e, int instance);
 /* HorizontalDynamicsFEM::StepAfterSubCycle (src/atm/HorizontalDynamicsFEM.cpp:2637-2726). */
 int tmx_h_step_after_subcycle(tmx_engine * e, int i_initial, int i_update, int i_working, double dt);
 
-/* TimestepSchemeARS343::Step (src/atm/TimestepSchemeARS343.cpp:150-236): the whole IMEX step,
- * resident on the device, asynchronous on the engine's stream. */
-int tmx_step_ars343(tmx_engine * e, double dt);
+/* TimestepScheme::Step of the reference's IMEX / split steppers, the whole step resident on the device and
+ * asynchronous on the engine's stream.  Each is the reference's own call sequence:
+ *   ARS343  src/atm/TimestepSchemeARS343.cpp:150-236     ARS232  src/atm/TimestepSchemeARS232.cpp:52-150
+ *   ARS222  src/atm/TimestepSchemeARS222.cpp:51-119      ARK232  src/atm/TimestepSchemeARK232.cpp:53-225
+ *   STRANG  src/atm/TimestepSchemeStrang.cpp:450-674 (KinnmarkGrayUllrich35, off-centering 0: the default
+ *           --timescheme of every reference test, TempestInitialize.h:142)
+ * first_step / last_step have the meaning of TimestepScheme::Step's fFirstStep / fLastStep. */
+enum { TMX_SCHEME_ARS343 = 0, TMX_SCHEME_ARS232, TMX_SCHEME_ARS222, TMX_SCHEME_ARS443, TMX_SCHEME_ARK232, TMX_SCHEME_STRANG };
+int tmx_step(tmx_engine * e, int scheme, int first_step, int last_step, double dt);
+/* TimestepScheme::GetComponentDataInstances of that scheme (-1: unknown). */
+int tmx_scheme_instances(int scheme);
+int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_ARS343, 0, 0, dt) */
+
+/* VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612): update -= dt F(initial)
+ * on every column (used by ARK232). */
+int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int i_initial, int i_update, double dt);
 
 /* Wait for the engine's stream; reports a deferred TMX_ERR_SINGULAR from column solves. */
 int tmx_sync(tmx_engine * e);

@@ -364,6 +364,10 @@ try {
 				char tag[32]; snprintf(tag, 32, "step%d", s + 1);
 				printChecksums(pGrid, tag, &w);
 				dumpState(w, pGrid, tag, 0);
+				if (scheme == "strang") {
+					// the Strang stepper carries instance 1 over to the next step (TimestepSchemeStrang.cpp:639-657)
+					dumpState(w, pGrid, std::string(tag) + "_carry", 1);
+				}
 			}
 		}
 

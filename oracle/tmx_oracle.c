@@ -937,3 +937,140 @@ int orc_step_ars343(const orc_grid * g, orc_state * s, double dt) {
 	orc_h_step_after_subcycle(g, s, 1, 0, 2, dt);
 	return info;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* VerticalDynamicsFEM::StepImplicitTermsExplicitly (VerticalDynamicsFEM.cpp:439-612):         */
+/* update -= dt * F(initial) on every interior column                                          */
+
+void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = g->L;
+	const int n = FTOT * (L + 1);
+	double * x0 = dalloc(n), * F = dalloc(n), * AB = dalloc(n * LDAB);
+	colwork w; colwork_init(&w, L);
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * nin = s->node[iinit * g->npatch + p];
+		const double * ein = s->redge[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		double * eup = s->redge[iupd * g->npatch + p];
+		for (int iA = 1; iA < na - 1; iA++)
+		for (int iB = 1; iB < nb - 1; iB++) {
+			column_f_jacobian(g, P, nin, ein, iA, iB, dt, x0, F, AB, &w);
+			for (int k = 0; k < L; k++) {
+				NU(PIx, iA, iB, k) -= dt * F[VECF(FP, k)];
+				NU(RIx, iA, iB, k) -= dt * F[VECF(FR, k)];
+			}
+			for (int k = 0; k <= L; k++) EU(WIx, iA, iB, k) -= dt * F[VECF(FW, k)];
+		}
+	}
+	colwork_free(&w);
+	free(x0); free(F); free(AB);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the other steppers of the path, call for call as the reference issues them                   */
+
+static void hvd(const orc_grid * g, orc_state * s, int i, int u, double c) {
+	orc_h_step_explicit(g, s, i, u, c);
+	orc_v_step_explicit(g, s, i, u, c);
+	orc_apply_dss(g, s, u);
+}
+
+/* scheme: 1 ARS232 (TimestepSchemeARS232.cpp:52-150), 2 ARS222 (TimestepSchemeARS222.cpp:51-119),
+ * 3 ARS443 (TimestepSchemeARS443.cpp), 4 ARK232 (TimestepSchemeARK232.cpp:53-225),
+ * 5 Strang/KGU35 (TimestepSchemeStrang.cpp:450-674), 0 ARS343 */
+int orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last, double dt) {
+	int info = 0, r;
+#define VI(i, u, c) do { r = orc_v_step_implicit(g, s, i, u, c); if (r && !info) info = r; } while (0)
+	if (scheme == 0) return orc_step_ars343(g, s, dt);
+	if (scheme == 1) {
+		const double gm = 1.0 - 1.0 / sqrt(2.0), dl = -(2.0 * sqrt(2.0)) / 3.0;
+		const double I[3][3] = { { gm, 0, 0 }, { 1.0 - gm, gm, 0 }, { 1.0 - gm, gm, 0 } };
+		const double E[3][3] = { { gm, 0, 0 }, { dl, 1.0 - dl, 0 }, { 0, 1.0 - gm, gm } };
+		double u2[6] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0], I[1][0] / I[0][0], 0, 0, 0 };
+		double u3[7] = { 1.0 - E[2][0] / E[0][0], E[2][0] / E[0][0] - I[2][0] / I[0][0], I[2][0] / I[0][0],
+			E[2][1] / E[1][1] - I[2][1] / I[1][1], I[2][1] / I[1][1], -E[2][1] / E[1][1], 0 };
+		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, E[0][0] * dt);
+		orc_copy(g, s, 1, 2); VI(2, 2, I[0][0] * dt);
+		orc_linear_combine(g, s, u2, 6, 5); orc_copy(g, s, 5, 3); hvd(g, s, 2, 3, E[1][1] * dt);
+		orc_copy(g, s, 3, 4); VI(4, 4, I[1][1] * dt);
+		orc_linear_combine(g, s, u3, 7, 6); hvd(g, s, 4, 6, E[2][2] * dt);
+		orc_copy(g, s, 6, 2); orc_h_step_after_subcycle(g, s, 2, 1, 6, dt); orc_copy(g, s, 1, 0);
+		return info;
+	}
+	if (scheme == 2) {
+		const double gm = 1.0 - 0.5 * sqrt(2.0), dl = 1.0 - 1.0 / (2.0 * gm);
+		const double I[2][2] = { { gm, 0 }, { 1.0 - gm, gm } };
+		const double E[2][2] = { { gm, 0 }, { dl, 1.0 - dl } };
+		double u2[4] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0], I[1][0] / I[0][0], 0 };
+		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, E[0][0] * dt);
+		orc_copy(g, s, 1, 2); VI(2, 2, I[0][0] * dt); orc_apply_dss(g, s, 2);
+		orc_linear_combine(g, s, u2, 4, 3); hvd(g, s, 2, 3, E[1][1] * dt);
+		VI(3, 3, I[1][1] * dt); orc_apply_dss(g, s, 3);
+		orc_copy(g, s, 3, 2); orc_h_step_after_subcycle(g, s, 2, 1, 3, dt); orc_copy(g, s, 1, 0);
+		return info;
+	}
+	if (scheme == 3) {
+		const double I[4][4] = { { 1./2., 0, 0, 0 }, { 1./6., 1./2., 0, 0 }, { -1./2., 1./2., 1./2., 0 }, { 3./2., -3./2., 1./2., 1./2. } };
+		const double E[4][4] = { { 1./2., 0, 0, 0 }, { 11./18., 1./18., 0, 0 }, { 5./6., -5./6., 1./2., 0 }, { 1./4., 7./4., 3./4., -7./4. } };
+		double u2[8] = { 0 }, u3[9] = { 0 }, u4[10] = { 0 };
+		u2[0] = 1.0 - E[1][0] / E[0][0]; u2[1] = E[1][0] / E[0][0] - I[1][0] / I[0][0]; u2[2] = I[1][0] / I[0][0];
+		u3[0] = 1.0 - E[2][0] / E[0][0]; u3[1] = E[2][0] / E[0][0] - I[2][0] / I[0][0]; u3[2] = I[2][0] / I[0][0];
+		u3[3] = E[2][1] / E[1][1] - I[2][1] / I[1][1]; u3[4] = I[2][1] / I[1][1]; u3[7] = -E[2][1] / E[1][1];
+		u4[0] = 1.0 - E[3][0] / E[0][0]; u4[1] = E[3][0] / E[0][0] - I[3][0] / I[0][0]; u4[2] = I[3][0] / I[0][0];
+		u4[3] = E[3][1] / E[1][1] - I[3][1] / I[1][1]; u4[4] = I[3][1] / I[1][1];
+		u4[5] = E[3][2] / E[2][2] - I[3][2] / I[2][2]; u4[6] = I[3][2] / I[2][2];
+		u4[7] = -E[3][1] / E[1][1]; u4[8] = -E[3][2] / E[2][2];
+		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, E[0][0] * dt);
+		orc_copy(g, s, 1, 2); VI(2, 2, I[0][0] * dt); orc_apply_dss(g, s, 2);
+		orc_linear_combine(g, s, u2, 8, 7); orc_copy(g, s, 7, 3); hvd(g, s, 2, 3, E[1][1] * dt);
+		orc_copy(g, s, 3, 4); VI(4, 4, I[1][1] * dt); orc_apply_dss(g, s, 4);
+		orc_linear_combine(g, s, u3, 9, 8); orc_copy(g, s, 8, 5); hvd(g, s, 4, 5, E[2][2] * dt);
+		orc_copy(g, s, 5, 6); VI(6, 6, I[2][2] * dt); orc_apply_dss(g, s, 6);
+		orc_linear_combine(g, s, u4, 10, 9); hvd(g, s, 6, 9, E[3][3] * dt);
+		VI(9, 9, I[3][3] * dt); orc_apply_dss(g, s, 9);
+		orc_copy(g, s, 9, 2); orc_h_step_after_subcycle(g, s, 2, 1, 9, dt); orc_copy(g, s, 1, 0);
+		return info;
+	}
+	if (scheme == 4) {
+		const double gm = 1.0 - 1.0 / sqrt(2.0), dl = 1.0 / (2.0 * sqrt(2.0));
+		const double al = 1.0 / 6.0 * (3.0 + 2.0 * sqrt(2.0));
+		const double I[3][3] = { { gm, gm, 0 }, { dl, dl, gm }, { dl, dl, gm } };
+		const double E[3][3] = { { 2.0 * gm, 0, 0 }, { 1.0 - al, al, 0 }, { dl, dl, gm } };
+		double u2[7] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0],
+			I[1][0] / I[0][0] - I[1][1] / I[0][1], I[1][1] / I[0][1], 0, 0, 0 };
+		double u3[8] = { 1.0 - E[2][0] / E[0][0], E[2][0] / E[0][0] - I[2][0] / I[0][0],
+			I[2][0] / I[0][0] - I[2][1] / I[0][1], I[2][1] / I[0][1],
+			E[2][1] / E[1][1] - I[2][2] / I[1][2], I[2][2] / I[1][2], -E[2][1] / E[1][1], 0 };
+		for (int n = 0; n < 2; n++) {
+			orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, E[0][0] * dt / 2);
+			if (n < 1) orc_copy(g, s, 1, 0);
+		}
+		orc_copy(g, s, 1, 2); orc_v_step_implicit_terms_explicitly(g, s, 1, 2, I[0][0] * dt); orc_apply_dss(g, s, 2);
+		orc_copy(g, s, 2, 3); VI(3, 3, I[0][1] * dt); orc_apply_dss(g, s, 3);
+		orc_linear_combine(g, s, u2, 7, 6); orc_copy(g, s, 6, 4); hvd(g, s, 3, 4, E[1][1] * dt);
+		orc_copy(g, s, 4, 5); VI(5, 5, I[1][2] * dt); orc_apply_dss(g, s, 5);
+		orc_linear_combine(g, s, u3, 8, 7); hvd(g, s, 5, 7, E[2][2] * dt);
+		orc_copy(g, s, 7, 2); orc_h_step_after_subcycle(g, s, 7, 1, 3, dt); orc_copy(g, s, 1, 0);
+		return info;
+	}
+	if (scheme == 5) {
+		const double half = 0.5 * dt;
+		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
+		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+		if (first) VI(0, 0, half); else orc_linear_combine(g, s, carry, 2, 0);
+		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, dt / 5.0);
+		orc_copy(g, s, 0, 2); hvd(g, s, 1, 2, dt / 5.0);
+		orc_copy(g, s, 0, 3); hvd(g, s, 2, 3, dt / 3.0);
+		orc_copy(g, s, 0, 2); hvd(g, s, 3, 2, 2.0 * dt / 3.0);
+		orc_linear_combine(g, s, kgu, 5, 4); hvd(g, s, 2, 4, 3.0 * dt / 4.0);
+		orc_copy(g, s, 4, 1); orc_h_step_after_subcycle(g, s, 4, 1, 2, dt);
+		orc_copy(g, s, 1, 0); VI(0, 0, 0.5 * (1.0 + 0.0) * dt);
+		orc_linear_combine(g, s, offc, 2, 0);
+		if (!last) orc_linear_combine(g, s, fin, 2, 1);
+		return info;
+	}
+#undef VI
+	return -1;
+}

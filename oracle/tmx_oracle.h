@@ -94,6 +94,9 @@ int  orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 void orc_apply_dss(const orc_grid * g, orc_state * s, int ix);
 void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt);
 int  orc_step_ars343(const orc_grid * g, orc_state * s, double dt);
+void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+/* scheme: 0 ARS343, 1 ARS232, 2 ARS222, 3 ARS443, 4 ARK232, 5 Strang (KGU35) */
+int  orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last, double dt);
 
 /* banded LU with partial pivoting, LAPACK dgbsv semantics (1 rhs); ab is [n][ldab] column-major band
  * storage with ldab = 2*kl+ku+1, entry (i,j) at ab[j*ldab + kl+ku+i-j].  Returns info. */

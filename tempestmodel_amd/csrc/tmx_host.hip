@@ -715,12 +715,12 @@ extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, dst))) return r;
 	REQUIRE(coeff && n_coeff > dst && n_coeff <= e->cfg.n_instances, TMX_ERR_INVALID,
 		"linear_combine_data: %d coefficients for destination %d and %d instances", n_coeff, dst, e->cfg.n_instances);
-	const double * src[8]; double cf[8];
+	const double * src[12]; double cf[12];
 	int n = 1;
 	src[0] = inst(e, dst); cf[0] = coeff[dst];
 	for (int m = 0; m < n_coeff; m++) {
 		if (m == dst || coeff[m] == 0.0) continue;
-		REQUIRE(n < 8, TMX_ERR_UNSUPPORTED, "linear_combine_data: more than 7 source terms");
+		REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear_combine_data: more than 11 source terms");
 		src[n] = inst(e, m); cf[n] = coeff[m]; n++;
 	}
 	ProfScope ps(e, TMX_K_LINCOMB);
@@ -880,6 +880,11 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	return tmx_apply_dss(e, iupd);
 }
 
+static bool hypervis_active(const tmx_engine * e) {
+	const tmx_config & c = e->cfg;
+	return !((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0);
+}
+
 // ARS(3,4,3) tableau in U-form (TimestepSchemeARS343.cpp:25-146)
 static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp, double * dimp) {
 	const double gm = 0.4358665215084590;
@@ -906,37 +911,245 @@ static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp,
 	u4[3] += u48 * u3[3]; u4[4] += u48 * u3[4];
 }
 
-extern "C" int tmx_step_ars343(tmx_engine * e, double dt) {
-	int r; if ((r = check_ready(e))) return r;
-	REQUIRE(e->cfg.n_instances >= 7, TMX_ERR_INVALID, "ARS343 needs 7 data instances (TimestepSchemeARS343.h:48-56), engine has %d", e->cfg.n_instances);
-	double u2[7], u3[7], u4[7], de[4], di[4];
-	ars343_tableau(u2, u3, u4, de, di);
-#define STEP(call) do { if ((r = (call))) return r; } while (0)
-	// The reference's CopyData calls are folded into their consumers where the result is bit-identical:
-	// Copy(0->1)+H(0,1) = one pass; Copy(s->t)+V.StepImplicit(t,t) = copy of U,V + StepImplicit(s,t)
-	// (the implicit step rewrites rho*theta, W, rho of every stored column); Copy(1->0) before
-	// StepAfterSubCycle(1,0,2) is dropped because the second hyperviscosity pass writes every slab of 0.
-	STEP(hv_step_explicit(e, 0, 0, 1, de[0] * dt));
-	STEP(tmx_apply_dss(e, 1));
-	STEP(copy_uv(e, 1, 2));
-	STEP(tmx_v_step_implicit(e, 1, 2, di[0] * dt));
-	STEP(tmx_linear_combine_data(e, u2, 7, 3));
-	STEP(hv_step_explicit(e, 2, 3, 3, de[1] * dt));
-	STEP(tmx_apply_dss(e, 3));
-	STEP(copy_uv(e, 3, 4));
-	STEP(tmx_v_step_implicit(e, 3, 4, di[1] * dt));
-	STEP(tmx_linear_combine_data(e, u3, 7, 5));
-	STEP(hv_step_explicit(e, 4, 5, 5, de[2] * dt));
-	STEP(tmx_apply_dss(e, 5));
-	STEP(copy_uv(e, 5, 6));
-	STEP(tmx_v_step_implicit(e, 5, 6, di[2] * dt));
-	STEP(tmx_linear_combine_data(e, u4, 7, 1));
-	STEP(hv_step_explicit(e, 6, 1, 1, de[3] * dt));
-	STEP(tmx_apply_dss(e, 1));
-	STEP(tmx_h_step_after_subcycle(e, 1, 0, 2, dt));
-#undef STEP
+// ---------------------------------------------------------------------------------------------
+// Time steppers.  Every reference TimestepScheme::Step on this path is a fixed sequence of the same
+// few Grid / HorizontalDynamics / VerticalDynamics calls; it is written down here call for call as a
+// small program, and run_program folds neighbouring calls into one kernel pass where the result is
+// bit-identical (see the rules there).
+
+enum OpKind { OP_COPY, OP_LINCOMB, OP_HEXP, OP_VEXP, OP_DSS, OP_VIMP, OP_VITE, OP_HVIS };
+struct Op {
+	int kind, a, b, c;
+	double coef;
+	double lc[12];
+	int nlc;
+};
+typedef std::vector<Op> Program;
+
+static void P_copy(Program & p, int a, int b) { Op o = { OP_COPY, a, b, 0, 0.0, { 0 }, 0 }; p.push_back(o); }
+static void P_h(Program & p, int i, int u, double c) { Op o = { OP_HEXP, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
+static void P_v(Program & p, int i, int u, double c) { Op o = { OP_VEXP, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
+static void P_hv(Program & p, int i, int u, double c) { P_h(p, i, u, c); P_v(p, i, u, c); }
+static void P_dss(Program & p, int i) { Op o = { OP_DSS, i, 0, 0, 0.0, { 0 }, 0 }; p.push_back(o); }
+static void P_vimp(Program & p, int i, int u, double c) { Op o = { OP_VIMP, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
+static void P_vite(Program & p, int i, int u, double c) { Op o = { OP_VITE, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
+static void P_hvis(Program & p, int i, int u, int w, double c) { Op o = { OP_HVIS, i, u, w, c, { 0 }, 0 }; p.push_back(o); }
+static void P_lc(Program & p, const double * cf, int n, int dst) {
+	Op o = { OP_LINCOMB, dst, 0, 0, 0.0, { 0 }, n };
+	for (int i = 0; i < n; i++) o.lc[i] = cf[i];
+	p.push_back(o);
+}
+
+static int scheme_instances(int scheme) {
+	switch (scheme) {
+		case TMX_SCHEME_ARS343: return 7;    // TimestepSchemeARS343.h:48-56
+		case TMX_SCHEME_ARS232: return 7;    // TimestepSchemeARS232.h
+		case TMX_SCHEME_ARS222: return 4;
+		case TMX_SCHEME_ARS443: return 10;
+		case TMX_SCHEME_ARK232: return 8;
+		case TMX_SCHEME_STRANG: return 5;
+	}
+	return -1;
+}
+
+// U-form combination coefficients shared by the ARS schemes: u_f(stage) from explicit/implicit tableaux
+static int build_program(int scheme, int first, int last, double dt, Program & p) {
+	p.clear();
+	if (scheme == TMX_SCHEME_ARS343) {
+		// TimestepSchemeARS343::Step (TimestepSchemeARS343.cpp:150-236)
+		double u2[7], u3[7], u4[7], de[4], di[4];
+		ars343_tableau(u2, u3, u4, de, di);
+		P_copy(p, 0, 1); P_hv(p, 0, 1, de[0] * dt); P_dss(p, 1);
+		P_copy(p, 1, 2); P_vimp(p, 2, 2, di[0] * dt);
+		P_lc(p, u2, 7, 3); P_hv(p, 2, 3, de[1] * dt); P_dss(p, 3);
+		P_copy(p, 3, 4); P_vimp(p, 4, 4, di[1] * dt);
+		P_lc(p, u3, 7, 5); P_hv(p, 4, 5, de[2] * dt); P_dss(p, 5);
+		P_copy(p, 5, 6); P_vimp(p, 6, 6, di[2] * dt);
+		P_lc(p, u4, 7, 1); P_hv(p, 6, 1, de[3] * dt); P_dss(p, 1);
+		P_copy(p, 1, 0); P_hvis(p, 1, 0, 2, dt);
+		return TMX_OK;
+	}
+	if (scheme == TMX_SCHEME_ARS232) {
+		// TimestepSchemeARS232::Step (TimestepSchemeARS232.cpp:25-150)
+		const double g = 1.0 - 1.0 / std::sqrt(2.0), d = -(2.0 * std::sqrt(2.0)) / 3.0;
+		const double I[3][3] = { { g, 0, 0 }, { 1.0 - g, g, 0 }, { 1.0 - g, g, 0 } };
+		const double E[3][3] = { { g, 0, 0 }, { d, 1.0 - d, 0 }, { 0, 1.0 - g, g } };
+		double u2[6] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0], I[1][0] / I[0][0], 0, 0, 0 };
+		double u3[7] = { 1.0 - E[2][0] / E[0][0], E[2][0] / E[0][0] - I[2][0] / I[0][0], I[2][0] / I[0][0],
+			E[2][1] / E[1][1] - I[2][1] / I[1][1], I[2][1] / I[1][1], -E[2][1] / E[1][1], 0 };
+		P_copy(p, 0, 1); P_hv(p, 0, 1, E[0][0] * dt); P_dss(p, 1);
+		P_copy(p, 1, 2); P_vimp(p, 2, 2, I[0][0] * dt);
+		P_lc(p, u2, 6, 5); P_copy(p, 5, 3); P_hv(p, 2, 3, E[1][1] * dt); P_dss(p, 3);
+		P_copy(p, 3, 4); P_vimp(p, 4, 4, I[1][1] * dt);
+		P_lc(p, u3, 7, 6); P_hv(p, 4, 6, E[2][2] * dt); P_dss(p, 6);
+		P_copy(p, 6, 2); P_hvis(p, 2, 1, 6, dt); P_copy(p, 1, 0);
+		return TMX_OK;
+	}
+	if (scheme == TMX_SCHEME_ARS222) {
+		// TimestepSchemeARS222::Step (TimestepSchemeARS222.cpp:25-119)
+		const double g = 1.0 - 0.5 * std::sqrt(2.0), d = 1.0 - 1.0 / (2.0 * g);
+		const double I[2][2] = { { g, 0 }, { 1.0 - g, g } };
+		const double E[2][2] = { { g, 0 }, { d, 1.0 - d } };
+		double u2[4] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0], I[1][0] / I[0][0], 0 };
+		P_copy(p, 0, 1); P_hv(p, 0, 1, E[0][0] * dt); P_dss(p, 1);
+		P_copy(p, 1, 2); P_vimp(p, 2, 2, I[0][0] * dt); P_dss(p, 2);
+		P_lc(p, u2, 4, 3); P_hv(p, 2, 3, E[1][1] * dt); P_dss(p, 3);
+		P_vimp(p, 3, 3, I[1][1] * dt); P_dss(p, 3);
+		P_copy(p, 3, 2); P_hvis(p, 2, 1, 3, dt); P_copy(p, 1, 0);
+		return TMX_OK;
+	}
+	if (scheme == TMX_SCHEME_STRANG) {
+		// TimestepSchemeStrang::Step, KinnmarkGrayUllrich35, off-centering 0 (TimestepSchemeStrang.cpp:450-674)
+		const double half = 0.5 * dt;
+		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
+		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+		if (first) P_vimp(p, 0, 0, half); else P_lc(p, carry, 2, 0);
+		P_copy(p, 0, 1); P_hv(p, 0, 1, dt / 5.0); P_dss(p, 1);
+		P_copy(p, 0, 2); P_hv(p, 1, 2, dt / 5.0); P_dss(p, 2);
+		P_copy(p, 0, 3); P_hv(p, 2, 3, dt / 3.0); P_dss(p, 3);
+		P_copy(p, 0, 2); P_hv(p, 3, 2, 2.0 * dt / 3.0); P_dss(p, 2);
+		P_lc(p, kgu, 5, 4); P_hv(p, 2, 4, 3.0 * dt / 4.0); P_dss(p, 4);
+		P_copy(p, 4, 1); P_hvis(p, 4, 1, 2, dt);
+		P_copy(p, 1, 0); P_vimp(p, 0, 0, 0.5 * (1.0 + 0.0) * dt);
+		P_lc(p, offc, 2, 0);
+		if (!last) P_lc(p, fin, 2, 1);
+		return TMX_OK;
+	}
+	if (scheme == TMX_SCHEME_ARK232) {
+		// TimestepSchemeARK232::Step with its two sub-cycled stages (TimestepSchemeARK232.cpp:25-225)
+		const double g = 1.0 - 1.0 / std::sqrt(2.0), d = 1.0 / (2.0 * std::sqrt(2.0));
+		const double al = 1.0 / 6.0 * (3.0 + 2.0 * std::sqrt(2.0));
+		const double I[3][3] = { { g, g, 0 }, { d, d, g }, { d, d, g } };
+		const double E[3][3] = { { 2.0 * g, 0, 0 }, { 1.0 - al, al, 0 }, { d, d, g } };
+		double u2[7] = { 1.0 - E[1][0] / E[0][0], E[1][0] / E[0][0] - I[1][0] / I[0][0],
+			I[1][0] / I[0][0] - I[1][1] / I[0][1], I[1][1] / I[0][1], 0, 0, 0 };
+		double u3[8] = { 1.0 - E[2][0] / E[0][0], E[2][0] / E[0][0] - I[2][0] / I[0][0],
+			I[2][0] / I[0][0] - I[2][1] / I[0][1], I[2][1] / I[0][1],
+			E[2][1] / E[1][1] - I[2][2] / I[1][2], I[2][2] / I[1][2], -E[2][1] / E[1][1], 0 };
+		// SubcycleStageExplicit(coeff E00, 2 sub-steps, 0 -> 1)
+		for (int n = 0; n < 2; n++) {
+			P_copy(p, 0, 1); P_hv(p, 0, 1, E[0][0] * dt / 2); P_dss(p, 1);
+			if (n < 1) P_copy(p, 1, 0);
+		}
+		// SubcycleStageImplicitExplicitly(coeff I00, 1 sub-step, 1 -> 2)
+		P_copy(p, 1, 2); P_vite(p, 1, 2, I[0][0] * dt); P_dss(p, 2);
+		P_copy(p, 2, 3); P_vimp(p, 3, 3, I[0][1] * dt); P_dss(p, 3);
+		P_lc(p, u2, 7, 6); P_copy(p, 6, 4); P_hv(p, 3, 4, E[1][1] * dt); P_dss(p, 4);
+		P_copy(p, 4, 5); P_vimp(p, 5, 5, I[1][2] * dt); P_dss(p, 5);
+		P_lc(p, u3, 8, 7); P_hv(p, 5, 7, E[2][2] * dt); P_dss(p, 7);
+		P_copy(p, 7, 2); P_hvis(p, 7, 1, 3, dt); P_copy(p, 1, 0);
+		return TMX_OK;
+	}
+	if (scheme == TMX_SCHEME_ARS443) {
+		// TimestepSchemeARS443::Step (TimestepSchemeARS443.cpp)
+		const double I[4][4] = { { 0.5, 0, 0, 0 }, { 1.0 / 6.0, 0.5, 0, 0 }, { -0.5, 0.5, 0.5, 0 }, { 1.5, -1.5, 0.5, 0.5 } };
+		const double E[4][4] = { { 0.5, 0, 0, 0 }, { 11.0 / 18.0, 1.0 / 18.0, 0, 0 }, { 5.0 / 6.0, -5.0 / 6.0, 0.5, 0 }, { 0.25, 1.75, 0.75, -1.75 } };
+		double u2[8], u3[9], u4[10];
+		for (int i = 0; i < 8; i++) u2[i] = 0; for (int i = 0; i < 9; i++) u3[i] = 0; for (int i = 0; i < 10; i++) u4[i] = 0;
+		u2[0] = 1.0 - E[1][0] / E[0][0]; u2[1] = E[1][0] / E[0][0] - I[1][0] / I[0][0]; u2[2] = I[1][0] / I[0][0];
+		u3[0] = 1.0 - E[2][0] / E[0][0]; u3[1] = E[2][0] / E[0][0] - I[2][0] / I[0][0]; u3[2] = I[2][0] / I[0][0];
+		u3[3] = E[2][1] / E[1][1] - I[2][1] / I[1][1]; u3[4] = I[2][1] / I[1][1]; u3[7] = -E[2][1] / E[1][1];
+		u4[0] = 1.0 - E[3][0] / E[0][0]; u4[1] = E[3][0] / E[0][0] - I[3][0] / I[0][0]; u4[2] = I[3][0] / I[0][0];
+		u4[3] = E[3][1] / E[1][1] - I[3][1] / I[1][1]; u4[4] = I[3][1] / I[1][1];
+		u4[5] = E[3][2] / E[2][2] - I[3][2] / I[2][2]; u4[6] = I[3][2] / I[2][2];
+		u4[7] = -E[3][1] / E[1][1]; u4[8] = -E[3][2] / E[2][2];
+		P_copy(p, 0, 1); P_hv(p, 0, 1, E[0][0] * dt); P_dss(p, 1);
+		P_copy(p, 1, 2); P_vimp(p, 2, 2, I[0][0] * dt); P_dss(p, 2);
+		P_lc(p, u2, 8, 7); P_copy(p, 7, 3); P_hv(p, 2, 3, E[1][1] * dt); P_dss(p, 3);
+		P_copy(p, 3, 4); P_vimp(p, 4, 4, I[1][1] * dt); P_dss(p, 4);
+		P_lc(p, u3, 9, 8); P_copy(p, 8, 5); P_hv(p, 4, 5, E[2][2] * dt); P_dss(p, 5);
+		P_copy(p, 5, 6); P_vimp(p, 6, 6, I[2][2] * dt); P_dss(p, 6);
+		P_lc(p, u4, 10, 9); P_hv(p, 6, 9, E[3][3] * dt); P_dss(p, 9);
+		P_vimp(p, 9, 9, I[3][3] * dt); P_dss(p, 9);
+		P_copy(p, 9, 2); P_hvis(p, 2, 1, 9, dt); P_copy(p, 1, 0);
+		return TMX_OK;
+	}
+	tmx_set_error("unknown time scheme %d", scheme);
+	return TMX_ERR_INVALID;
+}
+
+extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, int iupd, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	REQUIRE(iinit != iupd && dt != 0.0, TMX_ERR_INVALID, "StepImplicitTermsExplicitly: distinct instances and non-zero dt required");
+	ProfScope ps(e, TMX_K_VI_ASSEMBLE);
+	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	return launch_check("v_step_implicit_terms_explicitly");
+}
+static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { return tmx_v_step_implicit_terms_explicitly(e, iinit, iupd, dt); }
+
+static int run_program(tmx_engine * e, const Program & p) {
+	int r;
+	const size_t n = p.size();
+	for (size_t i = 0; i < n; i++) {
+		const Op & o = p[i];
+		const Op * n1 = (i + 1 < n) ? &p[i + 1] : nullptr;
+		const Op * n2 = (i + 2 < n) ? &p[i + 2] : nullptr;
+		switch (o.kind) {
+		case OP_COPY:
+			// Copy(a->b) + H(a,b,c) + V(a,b,c)  ==  one pass  b = a + c * rhs(a)
+			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->a == o.a && n1->b == o.b &&
+			    n2->a == o.a && n2->b == o.b && n1->coef == n2->coef) {
+				if ((r = hv_step_explicit(e, o.a, o.a, o.b, n1->coef))) return r;
+				i += 2; break;
+			}
+			// Copy(s->t) [twice in some schemes] + V.StepImplicit(t,t,c): the solve rewrites rho*theta, W, rho
+			// of every stored column, so only U,V need copying and the solve reads s directly
+			{
+				size_t j = i + 1;
+				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
+				if (!e->sw && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
+					if ((r = copy_uv(e, o.a, o.b))) return r;
+					if ((r = tmx_v_step_implicit(e, o.a, o.b, p[j].coef))) return r;
+					i = j; break;
+				}
+			}
+			// Copy(a->b) + StepAfterSubCycle(a,b,w): the second hyperviscosity pass writes every slab of b
+			if (n1 && n1->kind == OP_HVIS && n1->a == o.a && n1->b == o.b && hypervis_active(e)) break;
+			if ((r = tmx_copy_data(e, o.a, o.b))) return r;
+			break;
+		case OP_HEXP:
+			if (!e->sw && n1 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n1->coef == o.coef) {
+				if ((r = hv_step_explicit(e, o.a, o.b, o.b, o.coef))) return r;
+				i += 1; break;
+			}
+			if ((r = tmx_h_step_explicit(e, o.a, o.b, o.coef))) return r;
+			break;
+		case OP_VEXP:
+			if ((r = tmx_v_step_explicit(e, o.a, o.b, o.coef))) return r;
+			break;
+		case OP_DSS:
+			if ((r = tmx_apply_dss(e, o.a))) return r;
+			break;
+		case OP_VIMP:
+			if ((r = tmx_v_step_implicit(e, o.a, o.b, o.coef))) return r;
+			break;
+		case OP_VITE:
+			if ((r = vi_terms_explicit(e, o.a, o.b, o.coef))) return r;
+			break;
+		case OP_HVIS:
+			if ((r = tmx_h_step_after_subcycle(e, o.a, o.b, o.c, o.coef))) return r;
+			break;
+		case OP_LINCOMB:
+			if ((r = tmx_linear_combine_data(e, o.lc, o.nlc, o.a))) return r;
+			break;
+		}
+	}
 	return TMX_OK;
 }
+
+extern "C" int tmx_scheme_instances(int scheme) { return scheme_instances(scheme); }
+
+extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_step, double dt) {
+	int r; if ((r = check_ready(e))) return r;
+	const int need = scheme_instances(scheme);
+	REQUIRE(need > 0, TMX_ERR_INVALID, "unknown time scheme %d", scheme);
+	REQUIRE(e->cfg.n_instances >= need, TMX_ERR_INVALID, "time scheme %d needs %d data instances, engine has %d", scheme, need, e->cfg.n_instances);
+	Program p;
+	if ((r = build_program(scheme, first_step, last_step, dt, p))) return r;
+	return run_program(e, p);
+}
+
+extern "C" int tmx_step_ars343(tmx_engine * e, double dt) { return tmx_step(e, TMX_SCHEME_ARS343, 0, 0, dt); }
 
 extern "C" int tmx_sync(tmx_engine * e) {
 	int r; if ((r = check_ready(e))) return r;

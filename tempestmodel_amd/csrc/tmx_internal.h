@@ -101,6 +101,7 @@ struct tmx_engine {
 	void * nccl_lib = nullptr;
 
 	// profiling
+	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
 	bool prof = false;
 	ProfSlot prof_slots[TMX_K_COUNT];
@@ -115,6 +116,7 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x);
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v);

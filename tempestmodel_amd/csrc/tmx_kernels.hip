@@ -507,7 +507,7 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 // stage algebra: X_d <- c_d X_d + sum_m c_m X_m, accumulated in the reference's order
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508)
 
-struct LinTerms { const double * src[8]; double coef[8]; int n; int premul; };
+struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 
 __global__ __launch_bounds__(256) void k_lincomb(size_t n, double * __restrict__ dst, LinTerms t) {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1222,4 +1222,37 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double);
 	hipLaunchKernelGGL(k_vi_fused, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
 		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612):
+// update -= dt * F(initial) for rho*theta, W, rho on EVERY column (F = BuildF of the initial column).
+
+__global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const double * __restrict__ xin,
+	double * __restrict__ xup, double dt)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + threadIdx.y;
+	if (col >= p.ncol || k > L) return;
+	ColConst cc;
+	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+	const NodeLev nA = load_node(p, xin, k - 1, col), nB = load_node(p, xin, k, col), nC = load_node(p, xin, k + 1, col);
+	const EdgeLev eA = load_edge(p, xin, k - 1, col), eB = load_edge(p, xin, k, col), eC = load_edge(p, xin, k + 1, col);
+	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+	compute_block(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+	if (k < L) {
+		xup[TMX_SLAB_T(L, k) * NS + col] -= dt * fP;
+		xup[TMX_SLAB_R(L, k) * NS + col] -= dt * fR;
+	}
+	xup[TMX_SLAB_W(L, k) * NS + col] -= dt * fW;
+}
+
+void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_vi_terms_explicit, grd, blk, 0, e->stream, p, xin, xup, dt);
 }

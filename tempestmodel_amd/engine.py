@@ -70,6 +70,8 @@ def load_library():
         getattr(lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     lib.tmx_h_step_after_subcycle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
     lib.tmx_step_ars343.argtypes = [C.c_void_p, C.c_double]
+    lib.tmx_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.tmx_v_step_implicit_terms_explicitly.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     lib.tmx_apply_dss.argtypes = [C.c_void_p, C.c_int]
     lib.tmx_copy_data.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.tmx_zero_data.argtypes = [C.c_void_p, C.c_int]
@@ -241,6 +243,19 @@ class Engine:
 
     def step_ars343(self, dt):
         self._chk(self.lib.tmx_step_ars343(self.h, dt))
+
+    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5}
+
+    def step(self, scheme, dt, first=False, last=False):
+        """TimestepScheme::Step of the named reference scheme (tmx_step)."""
+        self._chk(self.lib.tmx_step(self.h, self.SCHEMES[scheme], int(first), int(last), dt))
+
+    @classmethod
+    def scheme_instances(cls, scheme):
+        return int(load_library().tmx_scheme_instances(cls.SCHEMES[scheme]))
+
+    def v_step_implicit_terms_explicitly(self, iinit, iupd, dt):
+        self._chk(self.lib.tmx_v_step_implicit_terms_explicitly(self.h, iinit, iupd, dt))
 
     def sync(self):
         self._chk(self.lib.tmx_sync(self.h))

@@ -9,6 +9,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
                           linear combination), starting from the state after 2 real ARS343 steps
   steps_ne4_L6_p24.npz    24-patch layout: prognostic interior state after 0..3 ARS343 steps
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
+  schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
   known_answers.json      area-weighted checksums printed by the reference
 """
 import json
@@ -77,6 +78,19 @@ def main():
     keep = ("initial", "step1", "step2", "step5", "step10")
     rec.update({k: v for k, v in cs.items() if k.split("/")[1] in keep})
     save("steps_ne3_L5_p6.npz", rec)
+
+    # the other steppers of the path: state after steps 1 and 3, tiny grid
+    rec = {}
+    for scheme in ("ars232", "ars222", "ars443", "ark232", "strang"):
+        d, _ = run(["--mode", "steps", "--ne", "2", "--levels", "4", "--dt", "400", "--steps", "3",
+                    "--scheme", scheme, "--geom", "0"], tmp)
+        cs = compact_states(d, 6)
+        for k, v in cs.items():
+            tag = k.split("/")[1]
+            if tag.split("_")[0] in ("step1", "step3"):
+                rec[k.replace("state/", "state/%s_" % scheme, 1)] = v
+        rec["cfg/dt"] = d["cfg/dt"]
+    save("schemes_ne2_L4_p6.npz", rec)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

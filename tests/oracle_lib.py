@@ -58,6 +58,7 @@ def lib():
         _lib.orc_dgbsv.restype = C.c_int
         _lib.orc_v_step_implicit.restype = C.c_int
         _lib.orc_step_ars343.restype = C.c_int
+        _lib.orc_step.restype = C.c_int
     return _lib
 
 
@@ -169,6 +170,15 @@ class Oracle:
 
     def step_ars343(self, dt):
         return lib().orc_step_ars343(C.byref(self.cgrid), C.byref(self.cstate), C.c_double(dt))
+
+    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5}
+
+    def step(self, scheme, dt, first=False, last=False):
+        return lib().orc_step(C.byref(self.cgrid), C.byref(self.cstate), self.SCHEMES[scheme],
+                              int(first), int(last), C.c_double(dt))
+
+    def v_step_implicit_terms_explicitly(self, iinit, iupd, dt):
+        lib().orc_v_step_implicit_terms_explicitly(C.byref(self.cgrid), C.byref(self.cstate), iinit, iupd, C.c_double(dt))
 
 
 def dgbsv(ab, b, kl, ku):

@@ -287,3 +287,30 @@ def test_rccl_transport_selftest():
         e.comm_selftest()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("scheme", ["ars232", "ars222", "ars443", "ark232", "strang"])
+def test_other_time_schemes(scheme):
+    """SURVEY 8a rows T2/T3 on the GPU: tmx_step for every stepper of the path vs the reference golden state
+    and the oracle (two steps from the reference's state after step 1)."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("schemes_ne2_L4_p6.npz")
+    g, _ = gu.make_grid(2, 4, 6)
+    o = Oracle(g, ninst=10)
+    e = Engine(g, n_instances=10)
+    try:
+        for setter in (o.set_state, e.upload_state):
+            setter(0, gu.expand_compact(d, "%s_step1" % scheme, g))
+            if scheme == "strang":
+                setter(1, gu.expand_compact(d, "strang_step1_carry", g))
+        assert Engine.scheme_instances(scheme) <= 10
+        for _ in range(2):
+            assert o.step(scheme, 400.0) == 0
+            e.step(scheme, 400.0)
+        e.sync()
+        got = e.download_state(0)
+        assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_STEPS
+        assert max(gu.prognostic_errors(got, gu.expand_compact(d, "%s_step3" % scheme, g))) < TOL_STEPS
+    finally:
+        e.close()

@@ -119,3 +119,25 @@ def test_dgbsv_against_lapack():
         assert np.array_equal(ipiv, piv)
         assert np.max(np.abs(x - xr)) <= 1e-12 * np.max(np.abs(xr))
         assert np.sum(ipiv != np.arange(n)) > 0
+
+
+def _scheme_start(d, scheme, g, o_or_e, setter):
+    start = gu.expand_compact(d, "%s_step1" % scheme, g)
+    setter(0, start)
+    if scheme == "strang":
+        setter(1, gu.expand_compact(d, "strang_step1_carry", g))
+    return start
+
+
+@pytest.mark.parametrize("scheme", ["ars232", "ars222", "ars443", "ark232", "strang"])
+def test_other_time_schemes_vs_reference(scheme):
+    """the remaining steppers of the path, two steps from the reference's state after
+    its first step (ne2, L4, dt 400 s) against the reference's state after step 3."""
+    d = gu.load("schemes_ne2_L4_p6.npz")
+    g, _ = gu.make_grid(2, 4, 6)
+    o = Oracle(g, ninst=10)
+    _scheme_start(d, scheme, g, o, o.set_state)
+    for _ in range(2):
+        assert o.step(scheme, 400.0) == 0
+    errs = gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "%s_step3" % scheme, g))
+    assert max(errs) < 1e-10, (scheme, errs)
