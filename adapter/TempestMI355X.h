@@ -144,10 +144,17 @@ private:
 		cfg.rank = nRank;
 		cfg.n_ranks = nRanks;
 		cfg.device = -1;
+		cfg.equation_set =
+			(m_model.GetEquationSet().GetType() == EquationSet::ShallowWaterEquations)
+				? TMX_EQN_SHALLOW_WATER : TMX_EQN_PRIMITIVE_NONHYDROSTATIC;
 		Check(tmx_create(&cfg, &m_pEngine));
 
 		// 1-D spectral-element matrices and the ten column operators
-		{
+		if (cfg.equation_set == TMX_EQN_SHALLOW_WATER) {
+			Check(tmx_set_operators(m_pEngine,
+				&(pGrid->GetDxBasis1D()[0][0]), &(pGrid->GetStiffness1D()[0][0]),
+				NULL, NULL, NULL, NULL, NULL));
+		} else {
 			const LinearColumnOperator * ops[TMX_OP_COUNT] = {
 				&(pGrid->GetOpInterpNodeToREdge()), &(pGrid->GetOpInterpREdgeToNode()),
 				&(pGrid->GetOpDiffNodeToNode()), &(pGrid->GetOpDiffNodeToREdge()),
@@ -281,6 +288,7 @@ private:
 			g.deriv_r_node = &(pPatch->GetDerivRNode()[0][0][0][0]);
 			g.deriv_r_redge = &(pPatch->GetDerivRREdge()[0][0][0][0]);
 			g.coriolis_f = &(pPatch->GetCoriolisF()[0][0]);
+			g.topography = &(pPatch->GetTopography()[0][0]);
 			Check(tmx_set_patch_geometry(m_pEngine, pPatch->GetPatchIndex(), &g));
 		}
 		Check(tmx_finalize(m_pEngine));

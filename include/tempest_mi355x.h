@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 1
+#define TMX_ABI_VERSION 2
 
 #define TMX_OK                 0
 #define TMX_ERR_INVALID       -1   /* bad argument / call order                      */
@@ -75,8 +75,14 @@ typedef struct {
 	double grav, Rd, cp, p0;   /* PhysicalConstants::GetG/GetR/GetCp/GetP0                     */
 	double nu_scalar, nu_div, nu_vort;
 	int    rank, n_ranks;      /* this process / number of processes sharing the grid          */
-	int    device;             /* HIP device ordinal, -1 = current                             */
+	int    device;             /* HIP device ordinal, -1 = current, -2 = plan only (no GPU)    */
+	int    equation_set;       /* EquationSet::Type (src/atm/EquationSet.h): TMX_EQN_*          */
 } tmx_config;
+
+#define TMX_EQN_PRIMITIVE_NONHYDROSTATIC 0   /* 5 components U,V,rho*theta,W,rho                        */
+#define TMX_EQN_SHALLOW_WATER            1   /* 3 components U,V,H on one level; node is [3][na][nb][1],
+                                                redge is ignored; vertical dynamics are the reference's
+                                                VerticalDynamicsStub (levels == 1, TempestInitialize.h:362) */
 
 /* Geometry of one patch, reference-layout pointers (accessors src/atm/GridPatch.h:482-740).
  * Arrays are read during the call only. */
@@ -95,6 +101,7 @@ typedef struct {
 	const double * deriv_r_node;           /* [na][nb][L][3]    GetDerivRNode           */
 	const double * deriv_r_redge;          /* [na][nb][L+1][3]  GetDerivRREdge          */
 	const double * coriolis_f;             /* [na][nb]          GetCoriolisF            */
+	const double * topography;             /* [na][nb]          GetTopography (shallow water only; may be NULL) */
 } tmx_patch_geometry;
 
 /* ---- life cycle ---------------------------------------------------------------------------- */
@@ -151,8 +158,8 @@ int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int n_coeff, i
 
 /* ---- dynamics ------------------------------------------------------------------------------ */
 
-/* HorizontalDynamicsFEM::StepExplicit -> StepNonhydrostaticPrimitive
- * (src/atm/HorizontalDynamicsFEM.cpp:1787-1863, 701-1783). */
+/* HorizontalDynamicsFEM::StepExplicit -> StepNonhydrostaticPrimitive or StepShallowWater
+ * (src/atm/HorizontalDynamicsFEM.cpp:1787-1863, 701-1783, 321-647). */
 int tmx_h_step_explicit(tmx_engine * e, int i_initial, int i_update, double dt);
 /* VerticalDynamicsFEM::StepExplicit, implicit mode (src/atm/VerticalDynamicsFEM.cpp:616-1159). */
 int tmx_v_step_explicit(tmx_engine * e, int i_initial, int i_update, double dt);

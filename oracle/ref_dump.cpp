@@ -20,6 +20,9 @@
 #define main tmx_unused_jw_main
 #include "BaroclinicWaveJWTest.cpp"
 #undef main
+#define main tmx_unused_sw2_main
+#include "SWTest2.cpp"
+#undef main
 
 #include "GridPatchGLL.h"
 #include "GridPatchCSGLL.h"
@@ -236,7 +239,7 @@ static void printChecksums(Grid * pGrid, const char * tag, TmxdWriter * w) {
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 
-	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp";
+	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp", tcase = "jw";
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1;
 	double dt = 200.0, ztop = 30000.0;
 	for (int i = 1; i < argc; i++) {
@@ -246,6 +249,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--out") { out = v; i++; }
 		else if (a == "--scheme") { scheme = v; i++; }
 		else if (a == "--pert") { pert = v; i++; }
+		else if (a == "--case") { tcase = v; i++; }
 		else if (a == "--ne") { ne = atoi(v); i++; }
 		else if (a == "--levels") { levels = atoi(v); i++; }
 		else if (a == "--steps") { nsteps = atoi(v); i++; }
@@ -261,7 +265,9 @@ int main(int argc, char ** argv) {
 try {
 	AnnounceSetVerbosityLevel(0);
 
-	Model model(EquationSet::PrimitiveNonhydrostaticEquations);
+	const bool fSW = (tcase == "sw2");
+	if (fSW) { levels = 1; }
+	Model model(fSW ? EquationSet::ShallowWaterEquations : EquationSet::PrimitiveNonhydrostaticEquations);
 
 	int isec = (int)dt;
 	int iusec = (int)((dt - isec) * 1.0e6 + 0.5);
@@ -282,7 +288,9 @@ try {
 
 	HorizontalDynamicsFEM * pH = new HorizontalDynamicsFEM(model, 4, 4, 1.0e15, 1.0e15, 1.0e15, 0.0);
 	model.SetHorizontalDynamics(pH);
-	VerticalDynamicsFEM * pV = new VerticalDynamicsFEM(model, 4, 1, 0, false, true, false);
+	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
+	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
+	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, false, true, false));
 	model.SetVerticalDynamics(pV);
 
 	GridCSGLL * pGrid = new GridCSGLL(model);
@@ -295,7 +303,11 @@ try {
 	BaroclinicWaveJWTest::PerturbationType ePert =
 		(pert == "exp") ? BaroclinicWaveJWTest::PerturbationType_Exp
 		                : BaroclinicWaveJWTest::PerturbationType_None;
-	model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, ePert));
+	if (fSW) {
+		model.SetTestCase(new ShallowWaterTestCase2(2998.104995, 38.61068277, 0.0));   // SWTest2.cpp defaults
+	} else {
+		model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, ePert));
+	}
 
 	// Model::Go init sequence (EvaluateGeometricTerms, component Initialize)
 	model.Go();

@@ -82,7 +82,10 @@ void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff,
 /* H explicit: HorizontalDynamicsFEM::StepNonhydrostaticPrimitive                              */
 /* (HorizontalDynamicsFEM.cpp:701-1783)                                                        */
 
+static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+
 void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	if (g->shallow_water) { sw_step_explicit(g, s, iinit, iupd, dt); return; }
 	const int L = g->L;
 	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx;      /* D[s*4+i]  = dDxBasis1D(s,i)   */
@@ -255,6 +258,7 @@ static void penalty_apply(const orc_grid * g, const double * w, const double * i
 }
 
 void orc_v_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	if (g->shallow_water) return;      /* VerticalDynamicsStub (TempestInitialize.h:362-365) */
 	const int L = g->L;
 	double * xidot = (double *)malloc(sizeof(double) * (L + 1));
 	double * w = (double *)malloc(sizeof(double) * (L + 1));
@@ -654,6 +658,7 @@ void orc_column_f_jacobian(const orc_grid * g, const orc_patch * p, const double
 }
 
 int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	if (g->shallow_water) return 0;    /* VerticalDynamicsStub */
 	const int L = g->L;
 	const int n = FTOT * (L + 1);
 	double * x0 = dalloc(n), * F = dalloc(n), * AB = dalloc(n * LDAB);
@@ -1073,4 +1078,71 @@ int orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last,
 	}
 #undef VI
 	return -1;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* HorizontalDynamicsFEM::StepShallowWater (HorizontalDynamicsFEM.cpp:321-647); H lives in slot 2 */
+
+static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = 1;
+	const double inv_da = 1.0 / g->delta_a;
+	const double * D = g->dx, * S = g->stiff;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * nin = s->node[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		const double * J2 = P->g[ORC_G_JAC2D], * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
+		const double * F = P->g[ORC_G_CORIOLIS], * ZS = P->g[ORC_G_TOPO];
+		for (int a = 0; a < P->nea; a++)
+		for (int b = 0; b < P->neb; b++) {
+			const int eA = a * NP + 1, eB = b * NP + 1, k = 0;
+			double cua[NP][NP], cub[NP][NP], ke[NP][NP], fa[NP][NP], fb[NP][NP];
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				const double ua = NI(UIx, iA, iB, k), ub = NI(VIx, iA, iB, k);
+				cua[i][j] = C2A[(iA * nb + iB) * 2 + 0] * ua + C2A[(iA * nb + iB) * 2 + 1] * ub;
+				cub[i][j] = C2B[(iA * nb + iB) * 2 + 0] * ua + C2B[(iA * nb + iB) * 2 + 1] * ub;
+				ke[i][j] = 0.5 * (cua[i][j] * ua + cub[i][j] * ub);
+				ke[i][j] += g->grav * NI(PIx, iA, iB, k);
+			}
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				const double ba = J2[iA * nb + iB] * cua[i][j], bb = J2[iA * nb + iB] * cub[i][j];
+				fa[i][j] = ba * (NI(PIx, iA, iB, k) - ZS[iA * nb + iB]);
+				fb[i][j] = bb * (NI(PIx, iA, iB, k) - ZS[iA * nb + iB]);
+			}
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = eA + i, iB = eB + j;
+				const double invJ2 = 1.0 / J2[iA * nb + iB];
+				double daub = 0, dbua = 0, dake = 0, dbke = 0, dafa = 0, dbfb = 0;
+				for (int q = 0; q < NP; q++) {
+					dafa -= fa[q][j] * S[i * NP + q];
+					daub += NI(VIx, eA + q, iB, k) * D[q * NP + i];
+					dake += ke[q][j] * D[q * NP + i];
+				}
+				for (int q = 0; q < NP; q++) {
+					dbfb -= fb[i][q] * S[j * NP + q];
+					dbua += NI(UIx, iA, eB + q, k) * D[q * NP + j];
+					dbke += ke[i][q] * D[q * NP + j];
+				}
+				dafa *= inv_da; daub *= inv_da; dake *= inv_da;
+				dbfb *= inv_da; dbua *= inv_da; dbke *= inv_da;
+				double upa = 0.0, upb = 0.0;
+				const double zeta = (daub - dbua);
+				const double ucza = cub[i][j] * zeta, uczb = -cua[i][j] * zeta;
+				upa += F[iA * nb + iB] * J2[iA * nb + iB] * cub[i][j];
+				upb -= F[iA * nb + iB] * J2[iA * nb + iB] * cua[i][j];
+				upa += -dake + ucza;
+				upb += -dbke + uczb;
+				NU(UIx, iA, iB, k) += dt * upa;
+				NU(VIx, iA, iB, k) += dt * upb;
+				NU(PIx, iA, iB, k) -= dt * invJ2 * (dafa + dbfb);
+			}
+		}
+	}
 }

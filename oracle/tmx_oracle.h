@@ -34,6 +34,7 @@ enum {
 	ORC_G_DR_N,        /* [na][nb][L][3]  */
 	ORC_G_DR_E,        /* [na][nb][L+1][3] */
 	ORC_G_CORIOLIS,    /* [na][nb]        */
+	ORC_G_TOPO,        /* [na][nb]  (shallow water only) */
 	ORC_G_COUNT
 };
 
@@ -75,6 +76,7 @@ typedef struct {
 	int opnout[ORC_OP_COUNT];
 	double nu_scalar, nu_div, nu_vort;
 	const orc_patch * patches;
+	int shallow_water;                 /* 1: ShallowWaterEquations (U,V,H; H kept in slot 2, one level)  */
 } orc_grid;
 
 /* state: node[inst*npatch + p], redge[inst*npatch + p] */

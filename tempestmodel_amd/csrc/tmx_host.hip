@@ -120,7 +120,10 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg->vertical_order == 1, TMX_ERR_UNSUPPORTED, "vertical order %d unsupported (1 only)", cfg->vertical_order);
 	REQUIRE(cfg->n_tracers == 0, TMX_ERR_UNSUPPORTED, "tracers unsupported");
 	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0 or 4)", cfg->hypervis_order);
-	REQUIRE(cfg->levels >= 3, TMX_ERR_INVALID, "levels must be >= 3");
+	REQUIRE(cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC || cfg->equation_set == TMX_EQN_SHALLOW_WATER,
+		TMX_ERR_UNSUPPORTED, "equation set %d unsupported", cfg->equation_set);
+	if (cfg->equation_set == TMX_EQN_SHALLOW_WATER) REQUIRE(cfg->levels == 1, TMX_ERR_INVALID, "shallow water needs levels == 1");
+	else REQUIRE(cfg->levels >= 3, TMX_ERR_INVALID, "levels must be >= 3");
 	REQUIRE(cfg->n_patches >= 1 && cfg->n_instances >= 1, TMX_ERR_INVALID, "bad patch / instance count");
 	REQUIRE(cfg->n_ranks >= 1 && cfg->rank >= 0 && cfg->rank < cfg->n_ranks, TMX_ERR_INVALID, "bad rank %d of %d", cfg->rank, cfg->n_ranks);
 	tmx_engine * e = new tmx_engine();
@@ -128,6 +131,9 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->L = cfg->levels;
 	e->patches.resize(cfg->n_patches);
 	e->nslab = 5 * e->L + 1;
+	e->sw = (cfg->equation_set == TMX_EQN_SHALLOW_WATER);
+	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
+		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
 	if (!plan_only(e)) {
 		int ndev = 0;
@@ -171,10 +177,12 @@ extern "C" int tmx_set_operators(tmx_engine * e, const double * dx_basis, const 
 	const double * const * coeff, const int * const * ix_begin, const int * const * ix_end,
 	const int * n_out, const int * n_in)
 {
-	REQUIRE(e && dx_basis && stiffness && coeff && ix_begin && ix_end && n_out && n_in, TMX_ERR_INVALID, "tmx_set_operators: null argument");
+	REQUIRE(e && dx_basis && stiffness, TMX_ERR_INVALID, "tmx_set_operators: null argument");
+	REQUIRE(e->sw || (coeff && ix_begin && ix_end && n_out && n_in), TMX_ERR_INVALID, "tmx_set_operators: null argument");
 	const int L = e->L;
 	memcpy(e->h_dx, dx_basis, sizeof(double) * 16);
 	memcpy(e->h_stiff, stiffness, sizeof(double) * 16);
+	if (e->sw) { e->ops_set = true; return TMX_OK; }      // no column operators on one level
 	// expected shapes (GridGLL.cpp:278-362)
 	const int exp_out[TMX_OP_COUNT] = { L + 1, L, L, L + 1, L, L + 1, L, L + 1, L, L };
 	const int exp_in[TMX_OP_COUNT]  = { L, L + 1, L, L, L + 1, L + 1, L, L + 1, L, L };
@@ -289,6 +297,13 @@ extern "C" int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch
 		e->h_g2d[G2_C2B1 * NS + c] = g->contra_metric_2d_b[ij * 2 + 1];
 		REQUIRE(g->contra_metric_2d_b[ij * 2 + 0] == g->contra_metric_2d_a[ij * 2 + 1], TMX_ERR_UNSUPPORTED, "2-D contravariant metric is not symmetric");
 		e->h_g2d[G2_JN * NS + c] = g->jacobian[ij * L];
+		if (e->sw) {
+			// 2-D equation set: only the 2-D metric, the (single-level) Jacobian and the topography are used
+			e->h_g2d[G2_JE * NS + c] = g->jacobian[ij * L];
+			e->h_g2d[G2_DRX * NS + c] = 1.0;
+			e->h_g2d[G2_ZS * NS + c] = g->topography ? g->topography[ij] : 0.0;
+			continue;
+		}
 		e->h_g2d[G2_JE * NS + c] = g->jacobian_redge[ij * (L + 1)];
 		e->h_g2d[G2_DRX * NS + c] = g->deriv_r_node[(ij * L) * 3 + 2];
 		for (int k = 0; k < L; k++) {
@@ -600,7 +615,7 @@ static int check_state_args(tmx_engine * e, int patch, int instance) {
 extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const double * node, const double * redge) {
 	int r = check_state_args(e, patch, instance);
 	if (r) return r;
-	REQUIRE(node && redge, TMX_ERR_INVALID, "tmx_upload_state: null array");
+	REQUIRE(node && (redge || e->sw), TMX_ERR_INVALID, "tmx_upload_state: null array");
 	const PatchInfo & P = e->patches[patch];
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
@@ -608,6 +623,10 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 	const int nodevar[4] = { 0, 1, 2, 4 };
 	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
 		const int c = col_of(P, i, j) - c0;
+		if (e->sw) {        // node is [3][na][nb][1]: U, V, H -> slabs U, V, "rho*theta"
+			for (int v = 0; v < 3; v++) buf[(size_t)v * ncp + c] = node[((size_t)v * na + i) * nb + j];
+			continue;
+		}
 		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
 			buf[(size_t)(v * L + k) * ncp + c] = node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k];
 		for (int k = 0; k <= L; k++)
@@ -622,7 +641,7 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, double * node, double * redge) {
 	int r = check_state_args(e, patch, instance);
 	if (r) return r;
-	REQUIRE(node && redge, TMX_ERR_INVALID, "tmx_download_state: null array");
+	REQUIRE(node && (redge || e->sw), TMX_ERR_INVALID, "tmx_download_state: null array");
 	const PatchInfo & P = e->patches[patch];
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
@@ -636,6 +655,10 @@ extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, doubl
 	std::vector<double> colU(L), colV(L), colW(L + 1);
 	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
 		const int c = col_of(P, i, j) - c0;
+		if (e->sw) {
+			for (int v = 0; v < 3; v++) node[((size_t)v * na + i) * nb + j] = buf[(size_t)v * ncp + c];
+			continue;
+		}
 		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
 			node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k] = buf[(size_t)(v * L + k) * ncp + c];
 		for (int k = 0; k <= L; k++)
@@ -736,7 +759,8 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
+	if (e->sw) tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
 	return launch_check("h_step_explicit");
 }
 
@@ -760,6 +784,7 @@ static int copy_uv(tmx_engine * e, int src, int dst) {
 
 extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	if (e->sw) return TMX_OK;      // VerticalDynamicsStub
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "V StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_V_EXPLICIT);
 	tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
@@ -768,6 +793,7 @@ extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 
 extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double dt) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+	if (e->sw) return TMX_OK;      // VerticalDynamicsStub
 	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
 	KParams p = make_params(e);
 	if (e->vi_mode == 1) {

@@ -21,7 +21,7 @@
 #define TMX_SLAB_W(L,k) (4 * (L) + (k))
 
 // 2-D (per column) geometry slabs
-enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_COUNT };
+enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS, G2_COUNT };
 // 3-D node geometry [field][L][NS]
 enum { G3N_CA2 = 0, G3N_CB2, G3N_CX2, G3N_DRA, G3N_DRB, G3N_COUNT };
 // 3-D interface geometry [field][L+1][NS]
@@ -112,6 +112,7 @@ void tmx_set_error(const char * fmt, ...);
 
 // kernel launchers (tmx_kernels.hip)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v);
+void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);

@@ -1256,3 +1256,68 @@ void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xi
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
 	hipLaunchKernelGGL(k_vi_terms_explicit, grd, blk, 0, e->stream, p, xin, xup, dt);
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Shallow water: HorizontalDynamicsFEM::StepShallowWater (src/atm/HorizontalDynamicsFEM.cpp:321-647).
+// One level; H is kept in the rho*theta slab.  out = base + dt * rhs(in).
+
+__global__ __launch_bounds__(64) void k_sw_explicit(KParams p, const double * __restrict__ xin,
+	const double * xbase, double * xup, double dt)
+{
+	__shared__ double s[5][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x;
+	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const bool act = col < p.ncol;
+	double ua = 0, ub = 0, h = 0, c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, fcor = 0, zs = 0;
+	if (act) {
+		ua = xin[0 * NS + col]; ub = xin[1 * NS + col]; h = xin[2 * NS + col];
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; fcor = p.g2d[G2_F * NS + col]; zs = p.g2d[G2_ZS * NS + col];
+	}
+	const double cua = c2a0 * ua + c2a1 * ub;
+	const double cub = c2a1 * ua + c2b1 * ub;
+	double ke = 0.5 * (cua * ua + cub * ub);
+	ke += p.grav * h;
+	const double ba = j2d * cua, bb = j2d * cub;
+	s[0][lane] = ua; s[1][lane] = ub; s[2][lane] = ke;
+	s[3][lane] = ba * (h - zs); s[4][lane] = bb * (h - zs);
+	__syncthreads();
+	if (!act) return;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	double daub = 0, dbua = 0, dake = 0, dbke = 0, dafa = 0, dbfb = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j;
+		dafa -= s[3][la] * sS[i * 4 + t];
+		daub += s[1][la] * sD[t * 4 + i];
+		dake += s[2][la] * sD[t * 4 + i];
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int lb = eb + 4 * i + t;
+		dbfb -= s[4][lb] * sS[j * 4 + t];
+		dbua += s[0][lb] * sD[t * 4 + j];
+		dbke += s[2][lb] * sD[t * 4 + j];
+	}
+	const double ida = p.inv_da;
+	dafa *= ida; daub *= ida; dake *= ida; dbfb *= ida; dbua *= ida; dbke *= ida;
+	double upa = 0.0, upb = 0.0;
+	const double zeta = (daub - dbua);
+	const double ucza = cub * zeta, uczb = -cua * zeta;
+	upa += fcor * j2d * cub;
+	upb -= fcor * j2d * cua;
+	upa += -dake + ucza;
+	upb += -dbke + uczb;
+	const double invJ2 = 1.0 / j2d;
+	xup[0 * NS + col] = xbase[0 * NS + col] + dt * upa;
+	xup[1 * NS + col] = xbase[1 * NS + col] + dt * upb;
+	xup[2 * NS + col] = xbase[2 * NS + col] - dt * invJ2 * (dafa + dbfb);
+}
+
+void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
+	hipLaunchKernelGGL(k_sw_explicit, dim3(p.NS / 64), dim3(64), 0, e->stream, p, xin, xbase, xup, dt);
+}

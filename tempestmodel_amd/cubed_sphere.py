@@ -353,7 +353,10 @@ class CubedSphereGrid:
     ``ppd`` = patches per panel direction (``6*ppd**2`` patches, GridCSGLL.cpp:101-145).
     """
 
-    def __init__(self, ne, levels, ztop, ppd=1, npts=4, phys=None):
+    def __init__(self, ne, levels, ztop, ppd=1, npts=4, phys=None, shallow_water=False):
+        self.shallow_water = shallow_water     # 2-D equation set: one level, ztop = 1, no topography in the metric
+        if shallow_water:
+            levels, ztop = 1, 1.0
         if ne % ppd != 0:
             raise ValueError("elements must divide equally among patches (GridCSGLL.cpp:115-118)")
         self.ne, self.L, self.ztop, self.ppd, self.np = ne, levels, float(ztop), ppd, npts
@@ -370,7 +373,7 @@ class CubedSphereGrid:
         wi = np.full(L + 1, 0.5 / L)
         wi[1:L] *= 2.0
         self.reta_interfaces_normarea = wi
-        self.ops = column_operators_vo1(L)
+        self.ops = None if shallow_water else column_operators_vo1(L)
 
         self.patches = []
         epp = ne // ppd
@@ -646,6 +649,8 @@ class CubedSphereGrid:
             zs = g["topography"]
             dazs = g["topography_deriv"][..., 0]
             dbzs = g["topography_deriv"][..., 1]
+            if self.shallow_water:     # fIs2DEquationSet (GridPatchCSGLL.cpp:388-393)
+                zs = np.zeros_like(zs); dazs = np.zeros_like(dazs); dbzs = np.zeros_like(dbzs)
             g["coriolis_f"] = 2.0 * self.phys.omega * np.sin(P.lat)
             J2 = (1.0 + X * X) * (1.0 + Y * Y) / (d * d * d)
             J2 = J2 * a * a
@@ -702,6 +707,8 @@ class CubedSphereGrid:
         self.set_topography(test.evaluate_topography)
         self.evaluate_geometric_terms()
         a = self.phys.earth_radius
+        if self.shallow_water:
+            return self._evaluate_shallow_water(test)
         states = []
         for P in self.patches:
             g = P.geom
@@ -720,6 +727,20 @@ class CubedSphereGrid:
             g["ref_node"] = out["ref_node"]
             g["ref_redge"] = out["ref_redge"]
             states.append((out["state_node"], out["state_redge"]))
+        return states
+
+    def _evaluate_shallow_water(self, test):
+        """Shallow-water state (U, V, H) on one level; stored in the 5-slot containers of this package with
+        H in slot 2 and slots 3,4 zero (GridPatchCSGLL.cpp:578-920 with a 3-component equation set)."""
+        a = self.phys.earth_radius
+        states = []
+        for P in self.patches:
+            u, v, h = test.evaluate_pointwise(self.phys, P.lon, P.lat)
+            ua, ub = covec_abp_from_rll(P.X[:, None], P.Y[None, :], P.panel, u * a, v * a)
+            node = np.zeros((5, P.na, P.nb, 1)); redge = np.zeros((5, P.na, P.nb, 2))
+            node[UIX, ..., 0] = ua; node[VIX, ..., 0] = ub; node[PIX, ..., 0] = h
+            P.geom["ref_node"] = np.zeros_like(node); P.geom["ref_redge"] = np.zeros_like(redge)
+            states.append((node, redge))
         return states
 
     # -- diagnostics ------------------------------------------------------------------------------
@@ -833,3 +854,26 @@ class BaroclinicWaveJW:
             ulon = ulon + np.where(gc < 1.0, self.Up * np.exp(-gc * gc), 0.0)
         zero = np.zeros_like(ulon)
         return [ulon, zero, theta, zero.copy(), rho]
+
+
+class ShallowWaterTest2:
+    """Williamson et al. (1992) test 2, steady geostrophic flow, as evaluated by
+    test/shallowwater_sphere/SWTest2.cpp:59-118 (defaults of its command line: h0, u0, alpha = 0)."""
+
+    def __init__(self, h0=2998.104995, u0=38.61068277, alpha_deg=0.0):
+        self.h0, self.u0, self.alpha = h0, u0, alpha_deg * math.pi / 180.0
+
+    def evaluate_physical_constants(self, phys):
+        phys.alpha = self.alpha
+
+    def evaluate_topography(self, phys, lon, lat):
+        return np.zeros_like(lon)
+
+    def evaluate_pointwise(self, phys, lon, lat):
+        lat = np.where(np.abs(lat - 0.5 * math.pi) < 1.0e-12, lat - 1.0e-12, lat)
+        lat = np.where(np.abs(lat + 0.5 * math.pi) < 1.0e-12, lat + 1.0e-12, lat)
+        u = self.u0 * np.cos(lat) * (math.cos(self.alpha) + np.cos(lon) * np.tan(lat) * math.sin(self.alpha))
+        v = -self.u0 * np.sin(lon) * math.sin(self.alpha)
+        htrig = -np.cos(lon) * np.cos(lat) * math.sin(self.alpha) + np.sin(lat) * math.cos(self.alpha)
+        h = self.h0 - (phys.earth_radius * phys.omega + 0.5 * self.u0) * self.u0 * htrig * htrig / phys.g
+        return u, v, h

@@ -14,14 +14,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtempest_mi355x.so")
 
-TMX_ABI_VERSION = 1
+TMX_ABI_VERSION = 2
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
             "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
             "penalty_left", "penalty_right"]
 GEOM_FIELDS = ["jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "jacobian", "jacobian_redge",
                "contra_metric_a", "contra_metric_b", "contra_metric_xi",
                "contra_metric_a_redge", "contra_metric_b_redge", "contra_metric_xi_redge",
-               "deriv_r_node", "deriv_r_redge", "coriolis_f"]
+               "deriv_r_node", "deriv_r_redge", "coriolis_f", "topography"]
 KERNEL_NAMES = ["h_explicit", "v_explicit", "vi_assemble", "vi_solve", "dss", "hypervis", "lincomb", "exchange"]
 
 PD = C.POINTER(C.c_double)
@@ -43,7 +43,7 @@ class TmxConfig(C.Structure):
                 ("element_delta_a", C.c_double), ("reference_length", C.c_double),
                 ("grav", C.c_double), ("Rd", C.c_double), ("cp", C.c_double), ("p0", C.c_double),
                 ("nu_scalar", C.c_double), ("nu_div", C.c_double), ("nu_vort", C.c_double),
-                ("rank", C.c_int), ("n_ranks", C.c_int), ("device", C.c_int)]
+                ("rank", C.c_int), ("n_ranks", C.c_int), ("device", C.c_int), ("equation_set", C.c_int)]
 
 
 class TmxPatchGeometry(C.Structure):
@@ -129,6 +129,8 @@ class Engine:
         cfg.grav, cfg.Rd, cfg.cp, cfg.p0 = ph.g, ph.Rd, ph.cp, ph.p0
         cfg.nu_scalar, cfg.nu_div, cfg.nu_vort = nu
         cfg.rank, cfg.n_ranks, cfg.device = rank, n_ranks, device
+        self.shallow_water = bool(getattr(grid, "shallow_water", False))
+        cfg.equation_set = 1 if self.shallow_water else 0
         self.cfg = cfg
         self.plan_only = (device == -2)
         h = C.c_void_p()
@@ -163,6 +165,8 @@ class Engine:
         cs = (PD * n)(); bs = (PI * n)(); es = (PI * n)()
         nout = (C.c_int * n)(); nin = (C.c_int * n)()
         for i, nm in enumerate(OP_NAMES):
+            if g.ops is None:
+                break
             c, b, e = g.ops[nm]
             c = np.ascontiguousarray(c, dtype=np.float64)
             b = np.ascontiguousarray(b, dtype=np.int32); e = np.ascontiguousarray(e, dtype=np.int32)
@@ -202,6 +206,10 @@ class Engine:
     def upload_state(self, instance, states):
         """``states[p] = (node[5][na][nb][L], redge[5][na][nb][L+1])`` for every patch (remote ones ignored)."""
         for p in self.local_patches:
+            if self.shallow_water:      # reference layout of the 3-component set: node [3][na][nb][1]
+                n = np.ascontiguousarray(states[p][0][[0, 1, 2]], dtype=np.float64)
+                self._chk(self.lib.tmx_upload_state(self.h, p, instance, _pd(n), None))
+                continue
             n = np.ascontiguousarray(states[p][0], dtype=np.float64)
             e = np.ascontiguousarray(states[p][1], dtype=np.float64)
             self._chk(self.lib.tmx_upload_state(self.h, p, instance, _pd(n), _pd(e)))
@@ -211,7 +219,12 @@ class Engine:
         for p in self.local_patches:
             P = self.grid.patches[p]
             n = np.zeros((5, P.na, P.nb, self.L)); e = np.zeros((5, P.na, P.nb, self.L + 1))
-            self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n), _pd(e)))
+            if self.shallow_water:
+                n3 = np.zeros((3, P.na, P.nb, 1))
+                self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n3), None))
+                n[[0, 1, 2]] = n3
+            else:
+                self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n), _pd(e)))
             out[p] = (n, e)
         return out
 

@@ -10,6 +10,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   steps_ne4_L6_p24.npz    24-patch layout: prognostic interior state after 0..3 ARS343 steps
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
+  sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
   known_answers.json      area-weighted checksums printed by the reference
 """
 import json
@@ -92,13 +93,25 @@ def main():
         rec["cfg/dt"] = d["cfg/dt"]
     save("schemes_ne2_L4_p6.npz", rec)
 
+    # configuration 1 of BASELINE.json: Williamson shallow-water test 2, ne8, default Strang/KGU35 stepper
+    d, sw_sums = run(["--case", "sw2", "--mode", "steps", "--ne", "8", "--dt", "200", "--steps", "10",
+                      "--scheme", "strang", "--geom", "1"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    for k, v in d.items():
+        if k.startswith("state/") and k.endswith("/node") and k.split("/")[1] in ("initial", "step1", "step10"):
+            rec[k] = v[:, 1:-1, 1:-1]
+        if k in ("p0/jacobian2d", "p4/jacobian2d", "p0/coriolis_f", "p4/contra_metric_2d_a", "p0/jacobian", "p0/topography"):
+            rec[k] = v
+    save("sw2_ne8_strang.npz", rec)
+
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",
                  "--geom", "0"], tmp)
     with open(os.path.join(HERE, "known_answers.json"), "w") as f:
         json.dump({"jw_ne4_L10_dt200_ars343": ka,
                    "jw_ne4_L6_p24_dt200_ars343": sums,
-                   "jw_ne3_L5_dt300_ars343": sums2}, f, indent=1)
+                   "jw_ne3_L5_dt300_ars343": sums2,
+                   "sw2_ne8_dt200_strang": sw_sums}, f, indent=1)
     os.remove(tmp)
 
 

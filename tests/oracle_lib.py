@@ -11,7 +11,7 @@ ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 G_NAMES = ["jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "jacobian", "jacobian_redge",
            "contra_metric_a", "contra_metric_b", "contra_metric_xi",
            "contra_metric_a_redge", "contra_metric_b_redge", "contra_metric_xi_redge",
-           "deriv_r_node", "deriv_r_redge", "coriolis_f"]
+           "deriv_r_node", "deriv_r_redge", "coriolis_f", "topography"]
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
             "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
             "penalty_left", "penalty_right"]
@@ -37,7 +37,7 @@ class OrcGrid(C.Structure):
                 ("opc", PD * 10), ("opb", PI * 10), ("ope", PI * 10),
                 ("opnin", C.c_int * 10), ("opnout", C.c_int * 10),
                 ("nu_scalar", C.c_double), ("nu_div", C.c_double), ("nu_vort", C.c_double),
-                ("patches", C.POINTER(OrcPatch))]
+                ("patches", C.POINTER(OrcPatch)), ("shallow_water", C.c_int)]
 
 
 class OrcState(C.Structure):
@@ -86,7 +86,10 @@ class Oracle:
         g.grav, g.Rd, g.cp, g.p0 = ph.g, ph.Rd, ph.cp, ph.p0
         g.dx = (C.c_double * 16)(*np.ascontiguousarray(grid.dx).ravel())
         g.stiff = (C.c_double * 16)(*np.ascontiguousarray(grid.stiff).ravel())
+        self.shallow_water = bool(getattr(grid, "shallow_water", False))
         for i, nm in enumerate(OP_NAMES):
+            if grid.ops is None:
+                break
             c, b, e = grid.ops[nm]
             c = np.ascontiguousarray(c, dtype=np.float64)
             b = np.ascontiguousarray(b, dtype=np.int32)
@@ -117,6 +120,7 @@ class Oracle:
             self._keep.append(t)
             cp.htrans = _pd(t)
         g.patches = self.cpatches
+        g.shallow_water = 1 if self.shallow_water else 0
         self.cgrid = g
         # state storage
         self.node = [[np.zeros((5, P.na, P.nb, self.L)) for P in grid.patches] for _ in range(ninst)]

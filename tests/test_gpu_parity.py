@@ -314,3 +314,26 @@ def test_other_time_schemes(scheme):
         assert max(gu.prognostic_errors(got, gu.expand_compact(d, "%s_step3" % scheme, g))) < TOL_STEPS
     finally:
         e.close()
+
+
+def test_shallow_water_test2_strang():
+    """BASELINE config 1 on the GPU: Williamson test 2 (ne8, Strang/KGU35, dt 200 s), 10 steps from the
+    analytic initial state vs the reference's dumped state and the oracle."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    from test_oracle_vs_reference import _sw_setup, _sw_ref
+    d = gu.load("sw2_ne8_strang.npz")
+    g, states = _sw_setup()
+    o = Oracle(g, ninst=5); o.set_state(0, states)
+    e = Engine(g, n_instances=5)
+    try:
+        e.upload_state(0, states)
+        for n in range(10):
+            assert o.step("strang", 200.0, first=(n == 0)) == 0
+            e.step("strang", 200.0, first=(n == 0))
+        e.sync()
+        got = e.download_state(0)
+        assert max(gu.prognostic_errors(got, o.get_state(0))[:3]) < 1e-12
+        assert max(gu.prognostic_errors(got, _sw_ref(d, "step10", g))[:3]) < 1e-12
+    finally:
+        e.close()
