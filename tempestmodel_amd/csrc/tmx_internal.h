@@ -103,6 +103,7 @@ struct tmx_engine {
 	// profiling
 	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
+	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
 	bool prof = false;
 	ProfSlot prof_slots[TMX_K_COUNT];
 	std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;

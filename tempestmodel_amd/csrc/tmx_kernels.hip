@@ -926,13 +926,19 @@ __device__ __forceinline__ EdgeLev load_edge(const KParams & p, const double * x
 
 struct ColConst { double c2a0, c2a1, c2b1, jn, je, drx, invdt, upc, cv; };
 
-// block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
-#undef OPC
-#define OPC(op, k, off) opsl[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+// Values one block row shares with the next (level k quantities become level k-1 quantities, interface
+// k+1 quantities become interface k quantities).  Carrying them over instead of recomputing is the same
+// arithmetic on the same operands, so results stay bit-identical to the stand-alone evaluation.
+struct BlkCarry {
+	double ex, wn, xdn, ke;            // node k: Exner pressure, W on the level, xi_dot, kinetic energy
+	double ue, ve, xd, pe, re;         // interface k+1: U,V, xi_dot, rho*theta, rho interpolated
+};
 
+// block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
+template <bool CARRY>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
-	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR)
+	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy)
 {
 	const int L = p.L;
 #pragma unroll
@@ -941,23 +947,30 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 #define DOFF(cr, cc_, dk) (3 * (dk) + ((cc_) - (cr)) + 4)
 	// interior interpolation stencils (offsets -1, 0), verified by tmx_set_operators
 	const double ib_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, -1), ib_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, 0);
+
+	// ---- interface k: interpolated U,V,rho*theta,rho and xi_dot (PrepareColumn :2056-2069) ----
+	double ue_b = 0.0, ve_b = 0.0, xd0 = 0.0, pe0 = 0.0, re0 = 0.0;
+	if (k >= 1 && k <= L - 1) {
+		if (CARRY) { ue_b = cy.ue; ve_b = cy.ve; xd0 = cy.xd; pe0 = cy.pe; re0 = cy.re; }
+		else {
+			ue_b += ib_m * A.un; ue_b += ib_0 * B.un; ve_b += ib_m * A.vn; ve_b += ib_0 * B.vn;
+			xd0 = eb.ce0 * ue_b + eb.ce1 * ve_b + eb.ce2 * eb.we;
+			pe0 += ib_m * A.pn; pe0 += ib_0 * B.pn; re0 += ib_m * A.rn; re0 += ib_0 * B.rn;
+		}
+	}
+	// ---- interface k+1 ----
+	double ue_c = 0.0, ve_c = 0.0, xd1 = 0.0, pe1 = 0.0, re1 = 0.0;
+	double ic_m = 0.0, ic_0 = 0.0;
+	if (k + 1 <= L - 1) {
+		ic_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1); ic_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
+		ue_c += ic_m * B.un; ue_c += ic_0 * C.un; ve_c += ic_m * B.vn; ve_c += ic_0 * C.vn;
+		xd1 = ec.ce0 * ue_c + ec.ce1 * ve_c + ec.ce2 * ec.we;
+		pe1 += ic_m * B.pn; pe1 += ic_0 * C.pn; re1 += ic_m * B.rn; re1 += ic_0 * C.rn;
+	}
+
 	if (k < L) {
-		const double ic_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1), ic_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
 		const double invJ = 1.0 / cc.jn;
 		const double pm = A.pn, p0 = B.pn, pp = C.pn, rm = A.rn, r0 = B.rn, rp = C.rn;
-		double xd0 = 0.0, xd1 = 0.0, pe0 = 0.0, pe1 = 0.0, re0 = 0.0, re1 = 0.0;
-		if (k >= 1) {
-			double ue = 0.0, ve = 0.0;
-			ue += ib_m * A.un; ue += ib_0 * B.un; ve += ib_m * A.vn; ve += ib_0 * B.vn;
-			xd0 = eb.ce0 * ue + eb.ce1 * ve + eb.ce2 * eb.we;
-			pe0 += ib_m * pm; pe0 += ib_0 * p0; re0 += ib_m * rm; re0 += ib_0 * r0;
-		}
-		if (k + 1 <= L - 1) {
-			double ue = 0.0, ve = 0.0;
-			ue += ic_m * B.un; ue += ic_0 * C.un; ve += ic_m * B.vn; ve += ic_0 * C.vn;
-			xd1 = ec.ce0 * ue + ec.ce1 * ve + ec.ce2 * ec.we;
-			pe1 += ic_m * p0; pe1 += ic_0 * pp; re1 += ic_m * r0; re1 += ic_0 * rp;
-		}
 		const double mf0 = (k >= 1) ? cc.je * re0 * xd0 : 0.0, mf1 = (k + 1 <= L - 1) ? cc.je * re1 * xd1 : 0.0;
 		const double pf0 = (k >= 1) ? cc.je * pe0 * xd0 : 0.0, pf1 = (k + 1 <= L - 1) ? cc.je * pe1 * xd1 : 0.0;
 		const double de0 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
@@ -1010,35 +1023,39 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			rowR[DOFF(2, 2, 0)] -= whi * pl0;     rowR[DOFF(2, 2, 1)] -= whi * pl1;
 		}
 	}
+
+	// ---- node k quantities the W rows of this block and of the next one use ----
+	double ex0 = 0.0, wn0 = 0.0, xdn0 = 0.0, ke0 = 0.0;
+	if (k <= L - 1 && (CARRY || k >= 1)) {
+		ex0 = exner_from_rhotheta(p, B.pn);
+		wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * eb.we; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * ec.we;
+		xdn0 = B.ca2 * B.un + B.cb2 * B.vn + B.cx2 * wn0;
+		const double ca = cc.c2a0 * B.un + cc.c2a1 * B.vn + B.ca2 * wn0, cb = cc.c2a1 * B.un + cc.c2b1 * B.vn + B.cb2 * wn0;
+		ke0 = 0.5 * (ca * B.un + cb * B.vn + xdn0 * wn0);
+	}
 	if (k >= 1 && k <= L - 1) {
 		const double pm = A.pn, p0 = B.pn;
-		const double exm = exner_from_rhotheta(p, pm), ex0 = exner_from_rhotheta(p, p0);
-		double pe = 0.0, re = 0.0;
-		pe += ib_m * pm; pe += ib_0 * p0; re += ib_m * A.rn; re += ib_0 * B.rn;
+		double exm, wnm, xdnm, kem;
+		if (CARRY) { exm = cy.ex; wnm = cy.wn; xdnm = cy.xdn; kem = cy.ke; }
+		else {
+			exm = exner_from_rhotheta(p, pm);
+			wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * ea.we; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * eb.we;
+			xdnm = A.ca2 * A.un + A.cb2 * A.vn + A.cx2 * wnm;
+			const double ca = cc.c2a0 * A.un + cc.c2a1 * A.vn + A.ca2 * wnm, cb = cc.c2a1 * A.un + cc.c2b1 * A.vn + A.cb2 * wnm;
+			kem = 0.5 * (ca * A.un + cb * A.vn + xdnm * wnm);
+		}
+		(void)wnm;
+		const double pe = pe0, re = re0;
 		const double dnm = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, -1), dn0 = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, 0);
 		double dpe = 0.0; dpe += dnm * exm; dpe += dn0 * ex0;
 		const double unm = A.un, un0 = B.un, vnm = A.vn, vn0 = B.vn;
 		const double wem = ea.we, we0 = eb.we, wep = ec.we;
-		double wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * wem; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * we0;
-		double wn0 = 0.0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * wep;
-		const double xdnm = A.ca2 * unm + A.cb2 * vnm + A.cx2 * wnm;
-		const double xdn0 = B.ca2 * un0 + B.cb2 * vn0 + B.cx2 * wn0;
-		double kem, ke0;
-		{
-			const double ca = cc.c2a0 * unm + cc.c2a1 * vnm + A.ca2 * wnm, cb = cc.c2a1 * unm + cc.c2b1 * vnm + A.cb2 * wnm;
-			kem = 0.5 * (ca * unm + cb * vnm + xdnm * wnm);
-		}
-		{
-			const double ca = cc.c2a0 * un0 + cc.c2a1 * vn0 + B.ca2 * wn0, cb = cc.c2a1 * un0 + cc.c2b1 * vn0 + B.cb2 * wn0;
-			ke0 = 0.5 * (ca * un0 + cb * vn0 + xdn0 * wn0);
-		}
 		double dke = 0.0; dke += dnm * kem; dke += dn0 * ke0;
 		double dua = 0.0; dua += dnm * unm; dua += dn0 * un0;
 		double dub = 0.0; dub += dnm * vnm; dub += dn0 * vn0;
-		double ue = 0.0, ve = 0.0;
-		ue += ib_m * unm; ue += ib_0 * un0; ve += ib_m * vnm; ve += ib_0 * vn0;
+		const double ue = ue_b, ve = ve_b;
 		const double cx0e = eb.ce0, cx1e = eb.ce1, cx2e = eb.ce2;
-		const double xde = cx0e * ue + cx1e * ve + cx2e * we0;
+		const double xde = xd0;
 		fW = dpe * pe / re;
 		fW += p.grav * cc.drx;
 		{
@@ -1075,6 +1092,10 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		rowW[DOFF(1, 1, 1)] -= cc.upc * fabs(xde) * ddp;
 	}
 	rowP[4] += cc.invdt; rowW[4] += cc.invdt; rowR[4] += cc.invdt;
+	if (CARRY) {
+		cy.ex = ex0; cy.wn = wn0; cy.xdn = xdn0; cy.ke = ke0;
+		cy.ue = ue_c; cy.ve = ve_c; cy.xd = xd1; cy.pe = pe1; cy.re = re1;
+	}
 #undef DOFF
 }
 
@@ -1127,6 +1148,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	b[4] = inb;
 }
 
+template <bool CARRY>
 __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
@@ -1158,10 +1180,11 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
 	double sP[TMX_BW], sW[TMX_BW], sR[TMX_BW], gP, gW, gR;
 	// blocks 0 and 1 -> matrix rows 0..5
-	compute_block(p, opsl, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+	BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	compute_block<CARRY>(p, opsl, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 	nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 	nN = load_node(p, xin, 3, col); eN = load_edge(p, xin, 3, col);
-	compute_block(p, opsl, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR);
+	compute_block<CARRY>(p, opsl, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR, cy);
 	// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
 #pragma unroll
 	for (int c = 0; c < TMX_BW; c++) {
@@ -1177,7 +1200,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	for (int m = 2; m <= L; m++) {
 		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 		nN = load_node(p, xin, m + 2, col); eN = load_edge(p, xin, m + 2, col);   // used two blocks from now
-		compute_block(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR);
@@ -1237,8 +1260,12 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nunique == 0) return;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double);
-	hipLaunchKernelGGL(k_vi_fused, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
-		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+	if (e->vi_carry)
+		hipLaunchKernelGGL(k_vi_fused<true>, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
+			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+	else
+		hipLaunchKernelGGL(k_vi_fused<false>, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
+			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
 }
 
 
@@ -1261,7 +1288,8 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 	const NodeLev nA = load_node(p, xin, k - 1, col), nB = load_node(p, xin, k, col), nC = load_node(p, xin, k + 1, col);
 	const EdgeLev eA = load_edge(p, xin, k - 1, col), eB = load_edge(p, xin, k, col), eC = load_edge(p, xin, k + 1, col);
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
-	compute_block(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR);
+	BlkCarry cy;
+	compute_block<false>(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 	if (k < L) {
 		xup[TMX_SLAB_T(L, k) * NS + col] -= dt * fP;
 		xup[TMX_SLAB_R(L, k) * NS + col] -= dt * fR;
