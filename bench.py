@@ -39,6 +39,23 @@ OP_KERNELS = {
     "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"],
 }
 HBM_PEAK_GBS = 8000.0
+# rocprof kernel names per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
+OP_ROCPROF = {"h_explicit": ["k_h_explicit<true>", "k_h_w_update"], "v_implicit": ["k_vi_fused<true>"], "dss": ["k_dss"],
+              "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"], "v_explicit": ["k_v_explicit"]}
+
+
+def measured_traffic(op, ne, L, world):
+    """HBM bytes per launch of the operation's kernels from the committed PMC pass (FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes).  The table was
+    taken at ne30 L30 on one GPU; for any other workload the traffic is not known -> None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not (ne == 30 and L == 30 and world == 1 and os.path.exists(path)):
+        return None
+    try:
+        tab = json.load(open(path))["kernels"]
+        return sum(tab[k]["hbm_bytes_per_launch"] for k in OP_ROCPROF[op])
+    except Exception:
+        return None
 
 
 def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
@@ -185,7 +202,7 @@ def main():
                        "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world)},
             "roofline": {"bound": "hbm", "kernel": "+".join("k_" + k for k in OP_KERNELS[dom]), "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": avg_ms,
+                         "traffic": measured_traffic(dom, ne, L, world), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,

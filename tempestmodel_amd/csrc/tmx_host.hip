@@ -767,6 +767,29 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 
 // CopyData(initial -> update) followed by StepExplicit(initial, update) in one pass:
 // update = initial + dt * rhs(initial), bit-identical to the two reference calls
+static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int dst, const double ** src, double * cf, int * premul) {
+	int n = 1;
+	src[0] = inst(e, dst); cf[0] = coeff[dst];
+	for (int m = 0; m < n_coeff; m++) {
+		if (m == dst || coeff[m] == 0.0) continue;
+		if (n >= 12) return -1;
+		src[n] = inst(e, m); cf[n] = coeff[m]; n++;
+	}
+	*premul = (coeff[dst] != 0.0) ? 1 : 0;
+	return n;
+}
+
+// LinearCombineData(coeff -> d) + H.StepExplicit(i, d) + V.StepExplicit(i, d) in one pass: the combination is
+// evaluated inside the kernels (same accumulation order), the combined state is never written and re-read.
+static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double dt, const double * coeff, int n_coeff) {
+	const double * src[12]; double cf[12]; int premul = 0;
+	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul);
+	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
+	ProfScope ps(e, TMX_K_H_EXPLICIT);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 1, n, src, cf, premul);
+	return launch_check("hv_step_explicit(lincomb)");
+}
+
 // H.StepExplicit + V.StepExplicit of one stage in one pass over the state; `ibase` is the instance the
 // update starts from (== iupd for the reference's in-place accumulation, == iinit when the preceding
 // CopyData(initial -> update) is folded in).  Bit-identical to the separate calls.
@@ -1114,9 +1137,9 @@ static int run_program(tmx_engine * e, const Program & p) {
 		switch (o.kind) {
 		case OP_COPY:
 			// Copy(a->b) + H(a,b,c) + V(a,b,c)  ==  one pass  b = a + c * rhs(a)
-			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->a == o.a && n1->b == o.b &&
-			    n2->a == o.a && n2->b == o.b && n1->coef == n2->coef) {
-				if ((r = hv_step_explicit(e, o.a, o.a, o.b, n1->coef))) return r;
+			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.b && n2->a == n1->a &&
+			    n2->b == o.b && n1->coef == n2->coef && n1->a != o.b) {
+				if ((r = hv_step_explicit(e, n1->a, o.a, o.b, n1->coef))) return r;
 				i += 2; break;
 			}
 			// Copy(s->t) [twice in some schemes] + V.StepImplicit(t,t,c): the solve rewrites rho*theta, W, rho
@@ -1157,6 +1180,12 @@ static int run_program(tmx_engine * e, const Program & p) {
 			if ((r = tmx_h_step_after_subcycle(e, o.a, o.b, o.c, o.coef))) return r;
 			break;
 		case OP_LINCOMB:
+			// LinearCombine(-> d) + H(i,d,c) + V(i,d,c): combination evaluated inside the explicit kernels
+			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.a && n2->b == o.a &&
+			    n1->a == n2->a && n1->coef == n2->coef && n1->a != o.a) {
+				if ((r = hv_step_explicit_lincomb(e, n1->a, o.a, n1->coef, o.lc, o.nlc))) return r;
+				i += 2; break;
+			}
 			if ((r = tmx_linear_combine_data(e, o.lc, o.nlc, o.a))) return r;
 			break;
 		}

@@ -112,7 +112,8 @@ struct tmx_engine {
 void tmx_set_error(const char * fmt, ...);
 
 // kernel launchers (tmx_kernels.hip)
-void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v);
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
+	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);

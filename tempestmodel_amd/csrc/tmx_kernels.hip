@@ -18,6 +18,20 @@
 
 #define OPC(op, k, off) p.ops[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
 
+// Linear combination of state instances in the reference's accumulation order
+// (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508): v = c_d * X_d (or 0), then += c_m * X_m.
+struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
+
+// base value of the update instance at flat offset o: either a plain instance (n == 0: src[0] is the base
+// pointer) or the linear combination evaluated on the fly, so that LinearCombineData + StepExplicit is one
+// pass instead of write + re-read of the combined state.  Same operations in the same order.
+__device__ __forceinline__ double base_value(const LinTerms & t, size_t o) {
+	if (t.n == 0) return t.src[0][o];
+	double v = t.premul ? t.src[0][o] * t.coef[0] : 0.0;
+	for (int m = 1; m < t.n; m++) v += t.coef[m] * t.src[m][o];
+	return v;
+}
+
 // XCD-aware tile order for the gather-heavy DSS kernel.  Workgroups are dealt round-robin over the 8 XCDs
 // (b and b+8 share one, each XCD has its own L2), so a 1-D launch is unfolded such that every XCD sweeps a
 // contiguous range of group tiles: the 128-byte element rows a tile touches are shared with its
@@ -48,7 +62,7 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 // reference evaluates before V.StepExplicit runs (HorizontalDynamicsFEM.cpp:1615-1638).
 template <bool FUSE_V>
 __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
-	const double * xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
+	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
 {
 	__shared__ double s[KT_H][9][64];
 	__shared__ double sD[16], sS[16];
@@ -172,8 +186,8 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
 	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
 	// instance when the preceding CopyData(initial -> update) is fused away
-	double outU = xbase[oU] + dt * upa;
-	double outV = xbase[oV] + dt * upb;
+	double outU = base_value(xbase, oU) + dt * upa;
+	double outV = base_value(xbase, oV) + dt * upb;
 	if (FUSE_V) {
 		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
 		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
@@ -196,14 +210,14 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	}
 	xup[oU] = outU;
 	xup[oV] = outV;
-	xup[oR] = xbase[oR] - dt * invJ * (darf + dbrf);
-	xup[oT] = xbase[oT] - dt * invJ * (dapf + dbpf);
+	xup[oR] = base_value(xbase, oR) - dt * invJ * (darf + dbrf);
+	xup[oT] = base_value(xbase, oT) - dt * invJ * (dapf + dbpf);
 	ucz[(size_t)k * NS + col] = uczx;
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
-__global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xbase, double * xup,
+__global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
 	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt)
 {
 	const int L = p.L;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xb
 	const int k = blockIdx.y * 4 + threadIdx.y;
 	if (k > L || col >= p.ncol) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
-		if (xbase != xup) xup[TMX_SLAB_W(L, L) * NS + col] = xbase[TMX_SLAB_W(L, L) * NS + col];
+		if (xbase.n != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value(xbase, TMX_SLAB_W(L, L) * NS + col);
 		return;
 	}
 	if (k == 0) {
@@ -233,11 +247,17 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, const double * xb
 		double v = 0.0;
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
-		xup[TMX_SLAB_W(L, k) * NS + col] = xbase[TMX_SLAB_W(L, k) * NS + col] + dt * v;
+		xup[TMX_SLAB_W(L, k) * NS + col] = base_value(xbase, TMX_SLAB_W(L, k) * NS + col) + dt * v;
 	}
 }
 
-void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v) {
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
+	int nterms, const double * const * src, const double * coef, int premul) {
+	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
+	LinTerms xbase;
+	xbase.n = nterms; xbase.premul = premul;
+	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
 	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
 	if (fuse_v) hipLaunchKernelGGL(k_h_explicit<true>, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt);
@@ -524,7 +544,6 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 // stage algebra: X_d <- c_d X_d + sum_m c_m X_m, accumulated in the reference's order
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508)
 
-struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 
 __global__ __launch_bounds__(256) void k_lincomb(size_t n, double * __restrict__ dst, LinTerms t) {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
