@@ -25,10 +25,17 @@ struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 // base value of the update instance at flat offset o: either a plain instance (n == 0: src[0] is the base
 // pointer) or the linear combination evaluated on the fly, so that LinearCombineData + StepExplicit is one
 // pass instead of write + re-read of the combined state.  Same operations in the same order.
+// NT = number of entries (compile time, so that every load of the combination is issued at once; a
+// run-time loop over the kernel-argument arrays serialises one memory round trip per term).
+template <int NT>
 __device__ __forceinline__ double base_value(const LinTerms & t, size_t o) {
-	if (t.n == 0) return t.src[0][o];
-	double v = t.premul ? t.src[0][o] * t.coef[0] : 0.0;
-	for (int m = 1; m < t.n; m++) v += t.coef[m] * t.src[m][o];
+	if (NT == 0) return t.src[0][o];
+	double x[NT > 0 ? NT : 1];
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? t.src[m][o] : 0.0;
+	double v = t.premul ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
 	return v;
 }
 
@@ -60,7 +67,7 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 // registers -- same statements in the same order, so the result is bit-identical to the two calls.
 // The H-only values of levels 0,1 are kept in `uv01` for the bottom boundary condition of W, which the
 // reference evaluates before V.StepExplicit runs (HorizontalDynamicsFEM.cpp:1615-1638).
-template <bool FUSE_V>
+template <bool FUSE_V, int NT>
 __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
 {
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
 	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
 	// instance when the preceding CopyData(initial -> update) is fused away
-	double outU = base_value(xbase, oU) + dt * upa;
-	double outV = base_value(xbase, oV) + dt * upb;
+	double outU = base_value<NT>(xbase, oU) + dt * upa;
+	double outV = base_value<NT>(xbase, oV) + dt * upb;
 	if (FUSE_V) {
 		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
 		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
@@ -210,13 +217,14 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	}
 	xup[oU] = outU;
 	xup[oV] = outV;
-	xup[oR] = base_value(xbase, oR) - dt * invJ * (darf + dbrf);
-	xup[oT] = base_value(xbase, oT) - dt * invJ * (dapf + dbpf);
+	xup[oR] = base_value<NT>(xbase, oR) - dt * invJ * (darf + dbrf);
+	xup[oT] = base_value<NT>(xbase, oT) - dt * invJ * (dapf + dbpf);
 	ucz[(size_t)k * NS + col] = uczx;
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
+template <int NT>
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
 	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt)
 {
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	const int k = blockIdx.y * 4 + threadIdx.y;
 	if (k > L || col >= p.ncol) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
-		if (xbase.n != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value(xbase, TMX_SLAB_W(L, L) * NS + col);
+		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * NS + col);
 		return;
 	}
 	if (k == 0) {
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 		double v = 0.0;
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
-		xup[TMX_SLAB_W(L, k) * NS + col] = base_value(xbase, TMX_SLAB_W(L, k) * NS + col) + dt * v;
+		xup[TMX_SLAB_W(L, k) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, k) * NS + col) + dt * v;
 	}
 }
 
@@ -258,13 +266,27 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	xbase.n = nterms; xbase.premul = premul;
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
 	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
-	if (fuse_v) hipLaunchKernelGGL(k_h_explicit<true>, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt);
-	else hipLaunchKernelGGL(k_h_explicit<false>, grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt);
 	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_h_w_update, grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch,
-		fuse_v ? (const double *)uv01 : (const double *)nullptr, dt);
+	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
+#define LAUNCH_HV(NT_) do { \
+		if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt); } while (0)
+	switch (nterms) {
+		case 0: LAUNCH_HV(0); break;
+		case 2: LAUNCH_HV(2); break;
+		case 3: LAUNCH_HV(3); break;
+		case 4: LAUNCH_HV(4); break;
+		case 5: LAUNCH_HV(5); break;
+		case 6: LAUNCH_HV(6); break;
+		case 7: LAUNCH_HV(7); break;
+		case 8: LAUNCH_HV(8); break;
+		default: LAUNCH_HV(12); break;      // entries beyond n carry coefficient 0 and a valid pointer (see below)
+	}
+#undef LAUNCH_HV
 }
 
 // ---------------------------------------------------------------------------------------------
