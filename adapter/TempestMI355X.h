@@ -290,6 +290,18 @@ private:
 			g.coriolis_f = &(pPatch->GetCoriolisF()[0][0]);
 			g.topography = &(pPatch->GetTopography()[0][0]);
 			Check(tmx_set_patch_geometry(m_pEngine, pPatch->GetPatchIndex(), &g));
+
+			// Factors of the closed-form 3-D metric (GridPatchCSGLL.cpp:370-568; m_dXNode = tan(m_dANode),
+			// :212-219).  The engine verifies them against the arrays above bit for bit before using them.
+			if (m_model.GetEquationSet().GetType() != EquationSet::ShallowWaterEquations) {
+				const PatchBox & box = pPatch->GetPatchBox();
+				std::vector<double> dXNode(box.GetATotalWidth()), dYNode(box.GetBTotalWidth());
+				for (int i = 0; i < box.GetATotalWidth(); i++) dXNode[i] = tan(pPatch->GetANode(i));
+				for (int j = 0; j < box.GetBTotalWidth(); j++) dYNode[j] = tan(pPatch->GetBNode(j));
+				Check(tmx_set_patch_metric_factors(m_pEngine, pPatch->GetPatchIndex(), &dXNode[0], &dYNode[0],
+					&(pPatch->GetTopographyDeriv()[0][0][0]), phys.GetEarthRadius(),
+					&(pGrid->GetREtaLevels()[0]), &(pGrid->GetREtaInterfaces()[0])));
+			}
 		}
 		Check(tmx_finalize(m_pEngine));
 

@@ -187,6 +187,8 @@ try {
 	}
 	printf("\n");
 	status = (worst < tol) ? 0 : 1;
+	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",
+		tmx_info(MI355XEngine::For(model).Handle(), TMX_INFO_METRIC_CLOSED_FORM) == 1 ? "active" : "refused, arrays streamed");
 	printf("%s\n", status == 0 ? "ADAPTER_OK" : "ADAPTER_MISMATCH");
 } catch (Exception & e) {
 	std::cout << e.ToString() << std::endl;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 2
+#define TMX_ABI_VERSION 3
 
 #define TMX_OK                 0
 #define TMX_ERR_INVALID       -1   /* bad argument / call order                      */
@@ -140,6 +140,21 @@ int tmx_set_patch_halo(tmx_engine * e, int patch, int n, const int * halo_i, con
  * src/atm/GridPatchCSGLL.cpp:295-574). */
 int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch_geometry * g);
 
+/* OPTIONAL, per owned patch, after tmx_set_patch_geometry: the factors of the closed form behind the 3-D
+ * terrain-following metric (Gal-Chen coordinate, src/atm/GridPatchCSGLL.cpp:370-568):
+ *   x_node[i] = tan(alpha_i), y_node[j] = tan(beta_j)  (GridPatchCSGLL::m_dXNode / m_dYNode = tan of GetANode / GetBNode),
+ *   topography_deriv[i][j][2]                           (GridPatch::GetTopographyDeriv, after its start-up DSS),
+ *   earth_radius                                        (PhysicalConstants::GetEarthRadius),
+ *   reta_levels[L], reta_interfaces[L+1]                (Grid::GetREtaLevels / GetREtaInterfaces).
+ * The engine re-evaluates contra_metric_{a,b,xi}[..][2], contra_metric_xi_redge and deriv_r_node[..][0..1] from
+ * these with the reference's own expressions and compares them with the arrays of tmx_set_patch_geometry BIT FOR
+ * BIT.  Only if every value of every owned patch agrees do the kernels evaluate the metric in registers instead of
+ * streaming the 3-D arrays from HBM (and the arrays are then not kept on the device); otherwise the stored arrays
+ * stay in use.  Results are identical either way; tmx_info(TMX_INFO_METRIC_CLOSED_FORM) tells which is active.
+ * Returns TMX_OK also when the comparison fails (it is not an error). */
+int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const double * x_node, const double * y_node,
+	const double * topography_deriv, double earth_radius, const double * reta_levels, const double * reta_interfaces);
+
 /* Builds the HBM layout, DSS groups, unique-column lists and exchange plan. */
 int tmx_finalize(tmx_engine * e);
 
@@ -207,7 +222,8 @@ enum {
 	TMX_INFO_DSS_GROUPS,          /* co-located node groups touching this rank          */
 	TMX_INFO_LOCAL_ELEMENTS,
 	TMX_INFO_GHOST_COLUMNS,       /* remote copies received per exchange                */
-	TMX_INFO_HBM_BYTES            /* device bytes allocated (low 31 bits of MiB)        */
+	TMX_INFO_HBM_BYTES,           /* device bytes allocated (low 31 bits of MiB)        */
+	TMX_INFO_METRIC_CLOSED_FORM   /* 1: 3-D metric evaluated in registers, 0: streamed  */
 };
 long long tmx_info(tmx_engine * e, int what);
 

@@ -161,7 +161,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->stream) hipStreamSynchronize(e->stream);
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
-		free_dev(e->d_state); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_state); free_dev(e->d_eta); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
@@ -345,6 +345,62 @@ extern "C" int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch
 		}
 	}
 	P.geom_set = true;
+	return TMX_OK;
+}
+
+// Closed form of the 3-D metric (GridPatchCSGLL.cpp:370-568).  The factors are accepted only if they
+// reproduce every stored value bit for bit, so the kernels' in-register evaluation cannot change results.
+extern "C" int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const double * x_node, const double * y_node,
+	const double * topography_deriv, double earth_radius, const double * reta_levels, const double * reta_interfaces)
+{
+	REQUIRE(e && x_node && y_node && topography_deriv && reta_levels && reta_interfaces, TMX_ERR_INVALID, "tmx_set_patch_metric_factors: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_patch_metric_factors after tmx_finalize");
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.geom_set, TMX_ERR_INVALID, "tmx_set_patch_metric_factors before tmx_set_patch_geometry (patch %d)", patch);
+	P.metric_ok = false;
+	if (e->sw) return TMX_OK;                 // 2-D equation set: there is no 3-D metric
+	const int L = e->L, nb = P.nb;
+	const size_t NS = e->NS;
+	std::vector<double> eta(2 * L + 1);
+	for (int k = 0; k < L; k++) eta[k] = 1.0 - reta_levels[k];
+	for (int k = 0; k <= L; k++) eta[L + k] = 1.0 - reta_interfaces[k];
+	if (e->h_eta.empty()) e->h_eta = eta;
+	else if (memcmp(e->h_eta.data(), eta.data(), eta.size() * sizeof(double)) != 0) return TMX_OK;   // patches disagree
+	const size_t s3n = (size_t)L * NS, s3e = (size_t)(L + 1) * NS;
+	bool ok = true;
+	for (int i = 1; i < P.na - 1 && ok; i++)
+	for (int j = 1; j < P.nb - 1 && ok; j++) {
+		const int c = col_of(P, i, j);
+		const size_t ij = (size_t)i * nb + j;
+		const double dX = x_node[i], dY = y_node[j];
+		const double dDelta2 = (1.0 + dX * dX + dY * dY);
+		const double sc = dDelta2 / (1.0 + dX * dX) / (1.0 + dY * dY) / (earth_radius * earth_radius);
+		const double dxr = e->h_g2d[G2_DRX * NS + c];
+		const double mp = -sc / dxr, ma = (1.0 + dY * dY), mb = dX * dY, mc = (1.0 + dX * dX);
+		const double daz = topography_deriv[ij * 2 + 0], dbz = topography_deriv[ij * 2 + 1];
+		const double idx = 1.0 / dxr, idx2 = 1.0 / (dxr * dxr);
+		// the 2-D metric must come from the same factors
+		ok = ok && e->h_g2d[G2_C2A0 * NS + c] == sc * ma && e->h_g2d[G2_C2A1 * NS + c] == sc * dX * dY &&
+		     e->h_g2d[G2_C2B1 * NS + c] == sc * mc;
+		for (int k = 0; k < 2 * L + 1 && ok; k++) {
+			const double dar = eta[k] * daz, dbr = eta[k] * dbz;
+			const double c0 = mp * (ma * dar + mb * dbr);
+			const double c1 = mp * (mb * dar + mc * dbr);
+			const double c2 = idx2 - idx * (c0 * dar + c1 * dbr);
+			if (k < L) {
+				const size_t d = (size_t)k * NS + c;
+				ok = e->h_g3n[G3N_CA2 * s3n + d] == c0 && e->h_g3n[G3N_CB2 * s3n + d] == c1 && e->h_g3n[G3N_CX2 * s3n + d] == c2 &&
+				     e->h_g3n[G3N_DRA * s3n + d] == dar && e->h_g3n[G3N_DRB * s3n + d] == dbr;
+			} else {
+				const size_t d = (size_t)(k - L) * NS + c;
+				ok = e->h_g3e[G3E_CX0 * s3e + d] == c0 && e->h_g3e[G3E_CX1 * s3e + d] == c1 && e->h_g3e[G3E_CX2 * s3e + d] == c2;
+			}
+		}
+		e->h_g2d[G2_MP * NS + c] = mp; e->h_g2d[G2_MA * NS + c] = ma; e->h_g2d[G2_MB * NS + c] = mb; e->h_g2d[G2_MC * NS + c] = mc;
+		e->h_g2d[G2_DAZ * NS + c] = daz; e->h_g2d[G2_DBZ * NS + c] = dbz; e->h_g2d[G2_IDX * NS + c] = idx; e->h_g2d[G2_IDX2 * NS + c] = idx2;
+	}
+	P.metric_ok = ok;
 	return TMX_OK;
 }
 
@@ -561,9 +617,17 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	const size_t state_bytes = (size_t)e->cfg.n_instances * e->inst_stride * sizeof(double);
 	HIPCHK(hipMalloc((void **)&e->d_state, state_bytes)); bytes += state_bytes;
 	HIPCHK(hipMemset(e->d_state, 0, state_bytes));
+	// closed-form 3-D metric only if every owned patch delivered factors that reproduce its arrays exactly
+	e->metric_closed = !e->sw && !e->h_eta.empty();
+	for (int lp : e->local_patches) e->metric_closed = e->metric_closed && e->patches[lp].metric_ok;
+	if (const char * m = getenv("TMX_METRIC")) if (strcmp(m, "stored") == 0) e->metric_closed = false;
 	if ((r = dev_upload(&e->d_g2d, e->h_g2d, &bytes))) return r;
-	if ((r = dev_upload(&e->d_g3n, e->h_g3n, &bytes))) return r;
-	if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
+	if (e->metric_closed) {
+		if ((r = dev_upload(&e->d_eta, e->h_eta, &bytes))) return r;
+	} else {
+		if ((r = dev_upload(&e->d_g3n, e->h_g3n, &bytes))) return r;
+		if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
+	}
 	if ((r = dev_upload(&e->d_ops, e->h_ops, &bytes))) return r;
 	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)(L + 4) * NS * sizeof(double))); bytes += (size_t)(L + 4) * NS * sizeof(double);
 	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)(L + 4) * NS * sizeof(double)));
@@ -696,6 +760,7 @@ static KParams make_params(const tmx_engine * e) {
 	KParams p;
 	p.L = e->L; p.ncol = e->ncol; p.NS = e->NS;
 	p.g2d = e->d_g2d; p.g3n = e->d_g3n; p.g3e = e->d_g3e; p.ops = e->d_ops;
+	p.eta = e->d_eta; p.closed = e->metric_closed ? 1 : 0;
 	p.inv_da = 1.0 / e->cfg.element_delta_a;
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
@@ -1256,6 +1321,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_LOCAL_ELEMENTS: return e->ne_local;
 		case TMX_INFO_GHOST_COLUMNS: return e->nghost;
 		case TMX_INFO_HBM_BYTES: return (long long)e->hbm_bytes;
+		case TMX_INFO_METRIC_CLOSED_FORM: return e->metric_closed ? 1 : 0;
 	}
 	return -1;
 }

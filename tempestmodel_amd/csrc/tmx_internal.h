@@ -21,7 +21,10 @@
 #define TMX_SLAB_W(L,k) (4 * (L) + (k))
 
 // 2-D (per column) geometry slabs
-enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS, G2_COUNT };
+enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS,
+	// factors of the closed-form 3-D metric (tmx_set_patch_metric_factors): -s/d_xi R, 1+Y^2, XY, 1+X^2,
+	// d_alpha zs, d_beta zs, 1/d_xi R, 1/(d_xi R)^2
+	G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2, G2_COUNT };
 // 3-D node geometry [field][L][NS]
 enum { G3N_CA2 = 0, G3N_CB2, G3N_CX2, G3N_DRA, G3N_DRB, G3N_COUNT };
 // 3-D interface geometry [field][L+1][NS]
@@ -36,6 +39,8 @@ struct KParams {
 	const double * g3n;     // [G3N_COUNT][L][NS]
 	const double * g3e;     // [G3E_COUNT][L+1][NS]
 	const double * ops;     // [TMX_OP_COUNT][L+1][TMX_OPW]
+	const double * eta;     // closed-form metric: 1 - eta of the levels [0,L) and of the interfaces [L, 2L+1)
+	int closed;             // 1: evaluate the 3-D metric from the G2_M* factors (g3n / g3e are null)
 	double inv_da;
 	double grav, Rd, cp, p0;
 	double dx[16];          // dx[s*4+i]    = dDxBasis1D(s,i)
@@ -43,7 +48,7 @@ struct KParams {
 };
 
 struct PatchInfo {
-	bool defined = false, halo_set = false, geom_set = false;
+	bool defined = false, halo_set = false, geom_set = false, metric_ok = false;
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
@@ -67,6 +72,9 @@ struct tmx_engine {
 	// host staging of geometry in device layout (filled by tmx_set_patch_geometry)
 	std::vector<double> h_g2d, h_g3n, h_g3e;
 	std::vector<double> h_ops;
+	std::vector<double> h_eta;               // [2L+1] 1 - eta (levels, then interfaces); empty until metric factors are set
+	bool metric_closed = false;              // kernels evaluate the 3-D metric in registers
+	double * d_eta = nullptr;
 	double h_dx[16], h_stiff[16];
 
 	// device

@@ -27,6 +27,11 @@ struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 // pass instead of write + re-read of the combined state.  Same operations in the same order.
 // NT = number of entries (compile time, so that every load of the combination is issued at once; a
 // run-time loop over the kernel-argument arrays serialises one memory round trip per term).
+// Every kernel here is launched with blockDim.x == 64: one wavefront per threadIdx.y.  Telling the compiler
+// that the level index is wave-uniform moves the operator coefficients, the 1 - eta table and all slab
+// offsets to scalar loads / SALU and frees the vector registers they occupied.
+#define WAVE_UNIFORM(v) __builtin_amdgcn_readfirstlane((int)(v))
+
 template <int NT>
 __device__ __forceinline__ double base_value(const LinTerms & t, size_t o) {
 	if (NT == 0) return t.src[0][o];
@@ -48,9 +53,49 @@ __device__ __forceinline__ bool xcd_tile(int nx, int ny, int & x, int & y) {
 	const int b = blockIdx.x;
 	const int xcd = b & 7, r = b >> 3;
 	const int per = (nx + 7) >> 3;            // column tiles per XCD
-	y = r % ny;
-	x = xcd * per + r / ny;
-	return (r / ny) < per && x < nx;
+	y = r / per;                              // level-major inside the XCD
+	x = xcd * per + r % per;
+	return y < ny && x < nx;
+}
+
+// 3-D terrain-following metric (GridPatchCSGLL.cpp:441-566).  Stored mode streams the reference's arrays;
+// closed mode evaluates the same expressions, operation for operation, from eight per-column factors and the
+// 1 - eta table (accepted by tmx_set_patch_metric_factors only after a bit-for-bit comparison), which removes
+// 8 doubles per point from the explicit kernels' HBM traffic and 6 from the column solve's.
+struct MetCol { double mp, ma, mb, mc, daz, dbz, idx, idx2; };
+__device__ __forceinline__ MetCol met_col(const KParams & p, int col) {
+	MetCol m = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	if (p.closed) {
+		const size_t NS = (size_t)p.NS;
+		m.mp = p.g2d[G2_MP * NS + col]; m.ma = p.g2d[G2_MA * NS + col]; m.mb = p.g2d[G2_MB * NS + col]; m.mc = p.g2d[G2_MC * NS + col];
+		m.daz = p.g2d[G2_DAZ * NS + col]; m.dbz = p.g2d[G2_DBZ * NS + col]; m.idx = p.g2d[G2_IDX * NS + col]; m.idx2 = p.g2d[G2_IDX2 * NS + col];
+	}
+	return m;
+}
+__device__ __forceinline__ void met_eval(const MetCol & m, double e, double & c0, double & c1, double & c2, double & dra, double & drb) {
+	dra = e * m.daz; drb = e * m.dbz;
+	c0 = m.mp * (m.ma * dra + m.mb * drb);
+	c1 = m.mp * (m.mb * dra + m.mc * drb);
+	c2 = m.idx2 - m.idx * (c0 * dra + c1 * drb);
+}
+// node level k: g^{alpha xi}, g^{beta xi}, g^{xi xi}, d_alpha R, d_beta R
+__device__ __forceinline__ void metric_node(const KParams & p, const MetCol & m, int k, int col,
+	double & ca2, double & cb2, double & cx2, double & dra, double & drb) {
+	if (p.closed) { met_eval(m, p.eta[k], ca2, cb2, cx2, dra, drb); return; }
+	const size_t s3 = (size_t)p.L * p.NS, o = (size_t)k * p.NS + col;
+	ca2 = p.g3n[G3N_CA2 * s3 + o]; cb2 = p.g3n[G3N_CB2 * s3 + o]; cx2 = p.g3n[G3N_CX2 * s3 + o];
+	dra = p.g3n[G3N_DRA * s3 + o]; drb = p.g3n[G3N_DRB * s3 + o];
+}
+__device__ __forceinline__ void metric_node3(const KParams & p, const MetCol & m, int k, int col, double & ca2, double & cb2, double & cx2) {
+	if (p.closed) { double a, b; met_eval(m, p.eta[k], ca2, cb2, cx2, a, b); return; }
+	const size_t s3 = (size_t)p.L * p.NS, o = (size_t)k * p.NS + col;
+	ca2 = p.g3n[G3N_CA2 * s3 + o]; cb2 = p.g3n[G3N_CB2 * s3 + o]; cx2 = p.g3n[G3N_CX2 * s3 + o];
+}
+// interface k: g^{xi alpha}, g^{xi beta}, g^{xi xi}
+__device__ __forceinline__ void metric_edge(const KParams & p, const MetCol & m, int k, int col, double & cx0, double & cx1, double & cx2) {
+	if (p.closed) { double a, b; met_eval(m, p.eta[p.L + k], cx0, cx1, cx2, a, b); return; }
+	const size_t s3 = (size_t)(p.L + 1) * p.NS, o = (size_t)k * p.NS + col;
+	cx0 = p.g3e[G3E_CX0 * s3 + o]; cx1 = p.g3e[G3E_CX1 * s3 + o]; cx2 = p.g3e[G3E_CX2 * s3 + o];
 }
 
 __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double rt) {
@@ -73,7 +118,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 {
 	__shared__ double s[KT_H][9][64];
 	__shared__ double sD[16], sS[16];
-	const int lane = threadIdx.x, ty = threadIdx.y;
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
@@ -98,9 +143,8 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		const double ubm = xin[TMX_SLAB_V(L, km) * NS + col], ubp = xin[TMX_SLAB_V(L, kp) * NS + col];
 		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
 		jn = p.g2d[G2_JN * NS + col]; j2d = p.g2d[G2_J2D * NS + col]; fcor = p.g2d[G2_F * NS + col];
-		const size_t o3 = (size_t)k * NS + col, s3 = (size_t)L * NS;
-		ca2 = p.g3n[G3N_CA2 * s3 + o3]; cb2 = p.g3n[G3N_CB2 * s3 + o3]; cx2 = p.g3n[G3N_CX2 * s3 + o3];
-		dra = p.g3n[G3N_DRA * s3 + o3]; drb = p.g3n[G3N_DRB * s3 + o3];
+		const MetCol mc = met_col(p, col);
+		metric_node(p, mc, k, col, ca2, cb2, cx2, dra, drb);
 		// W on levels (InterpolateREdgeToNode, GridPatchGLL.cpp:111-143)
 		ux = 0.0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * we1;
 		// contravariant velocities, kinetic energy (:884-930)
@@ -114,21 +158,22 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		if (FUSE_V) {
 			// xi_dot on the interfaces k and k+1 (VerticalDynamicsFEM.cpp:816-828), zero at the boundaries
 			v_uam = uam; v_uap = uap; v_ubm = ubm; v_ubp = ubp;
-			const size_t s3e = (size_t)(L + 1) * NS;
 			double xlo = 0.0, xhi = 0.0;
 			if (k >= 1) {
 				double ue = 0.0, ve = 0.0;
 				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * uam; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ua;
 				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ubm; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ub;
-				const size_t o = (size_t)k * NS + col;
-				xlo = p.g3e[G3E_CX0 * s3e + o] * ue + p.g3e[G3E_CX1 * s3e + o] * ve + p.g3e[G3E_CX2 * s3e + o] * we0;
+				double e0, e1, e2;
+				metric_edge(p, mc, k, col, e0, e1, e2);
+				xlo = e0 * ue + e1 * ve + e2 * we0;
 			}
 			if (k + 1 <= L - 1) {
 				double ue = 0.0, ve = 0.0;
 				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ua; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * uap;
 				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ub; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * ubp;
-				const size_t o = (size_t)(k + 1) * NS + col;
-				xhi = p.g3e[G3E_CX0 * s3e + o] * ue + p.g3e[G3E_CX1 * s3e + o] * ve + p.g3e[G3E_CX2 * s3e + o] * we1;
+				double e0, e1, e2;
+				metric_edge(p, mc, k + 1, col, e0, e1, e2);
+				xhi = e0 * ue + e1 * ve + e2 * we1;
 			}
 			w_hi = dt * fabs(xhi); w_lo = dt * fabs(xlo);
 		}
@@ -231,7 +276,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + threadIdx.y;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k > L || col >= p.ncol) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
 		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * NS + col);
@@ -248,8 +293,8 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pu1);
 		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * (*pv0);
 		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pv1);
-		const size_t s3 = (size_t)(L + 1) * NS;
-		const double cx0 = p.g3e[G3E_CX0 * s3 + col], cx1 = p.g3e[G3E_CX1 * s3 + col], cx2 = p.g3e[G3E_CX2 * s3 + col];
+		double cx0, cx1, cx2;
+		metric_edge(p, met_col(p, col), 0, col, cx0, cx1, cx2);
 		xup[TMX_SLAB_W(L, 0) * NS + col] = -(cx0 * u0 + cx1 * v0) / cx2;
 	} else {
 		double v = 0.0;
@@ -308,8 +353,9 @@ __device__ __forceinline__ double xidot_edge(const KParams & p, const double * _
 		ve += c * xin[TMX_SLAB_V(L, l) * NS + col];
 	}
 	const double we = xin[TMX_SLAB_W(L, kk) * NS + col];
-	const size_t s3 = (size_t)(L + 1) * NS, o3 = (size_t)kk * NS + col;
-	return p.g3e[G3E_CX0 * s3 + o3] * ue + p.g3e[G3E_CX1 * s3 + o3] * ve + p.g3e[G3E_CX2 * s3 + o3] * we;
+	double e0, e1, e2;
+	metric_edge(p, met_col(p, col), kk, col, e0, e1, e2);
+	return e0 * ue + e1 * ve + e2 * we;
 }
 
 __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __restrict__ xin,
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + threadIdx.y;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k >= L || col >= p.ncol) return;
 	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
 	const double w_lo = dt * fabs(xidot_edge(p, xin, k, col));       // weight of interface k
@@ -357,6 +403,10 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 // covector panel transform first (GridPatchCSGLL.cpp:1783-1924).  Copies owned by other ranks are
 // read from the ghost buffer filled by the exchange.
 
+// Every load of the group (5 slabs x up to 4 copies) is issued before the first use, so a wave keeps up to
+// 20 gathers in flight (measured 90 -> 74 us per call at ne30 L30 against loading slab by slab), and the tiles
+// of one XCD run level-major, so that the partially used 128-byte element rows of a 4-level tile are completed
+// by the neighbouring group tiles while they still sit in that XCD's L2 (74 -> 68 us).
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
 	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat)
@@ -366,61 +416,69 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	int bx, by;
 	if (!xcd_tile((ngroups + 63) / 64, (L + 1 + 3) / 4, bx, by)) return;
 	const int g = bx * 64 + threadIdx.x;
-	const int kk = by * 4 + threadIdx.y;
+	const int kk = by * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (g >= ngroups || kk > L) return;
 	const int n = gn[g];
-	int c[4];
-#pragma unroll
-	for (int m = 0; m < 4; m++) c[m] = gcols[g * 4 + m];
+	const int4 c4 = *(const int4 *)(gcols + g * 4);
+	const int c[4] = { c4.x, c4.y, c4.z, c4.w };
 	const int xi = gx[g];
-
-	// remote copies sit in the receive buffer exactly as they came off the wire: [peer][slab][count_peer]
-	int gb[4], gs[4];
+	const double * ptr[4]; size_t str[4]; bool loc[4];
 #pragma unroll
 	for (int m = 0; m < 4; m++) {
-		const bool gh = (c[m] >= (int)NS);
-		gb[m] = gh ? gbase[c[m] - (int)NS] : 0;
-		gs[m] = gh ? gstride[c[m] - (int)NS] : 0;
+		loc[m] = (c[m] < (int)NS);
+		const bool on = (m < n);
+		if (!on) { ptr[m] = x; str[m] = 0; loc[m] = false; }
+		else if (loc[m]) { ptr[m] = x + c[m]; str[m] = NS; }
+		else { ptr[m] = ghost + gbase[c[m] - (int)NS]; str[m] = (size_t)gstride[c[m] - (int)NS]; }
 	}
-	auto ld = [&](int slab, int m) -> double {
-		const int cc = c[m];
-		return (cc < (int)NS) ? x[(size_t)slab * NS + cc] : ghost[(size_t)gb[m] + (size_t)slab * gs[m]];
-	};
-	auto avg = [&](const double * v) -> double {
-		if (n == 2) return 0.5 * (v[0] + v[1]);
-		if (n == 4) return 0.5 * (0.5 * (v[0] + v[1]) + 0.5 * (v[2] + v[3]));
-		return (1.0 / 3.0) * (v[0] + v[1] + v[2]);
-	};
-	// scalar slabs
-	const int nsc = (kk < L) ? ((xi < 0) ? 5 : 3) : 1;
+	const bool lev = (kk < L);
 	int slabs[5];
 	slabs[0] = TMX_SLAB_W(L, kk);
-	slabs[1] = TMX_SLAB_T(L, kk); slabs[2] = TMX_SLAB_R(L, kk);
-	slabs[3] = TMX_SLAB_U(L, kk); slabs[4] = TMX_SLAB_V(L, kk);
-	for (int t = 0; t < nsc; t++) {
-		double v[4] = { 0, 0, 0, 0 };
-		for (int m = 0; m < n; m++) v[m] = ld(slabs[t], m);
-		const double a = avg(v);
-		for (int m = 0; m < n; m++) if (c[m] < (int)NS) x[(size_t)slabs[t] * NS + c[m]] = a;
+	slabs[1] = lev ? TMX_SLAB_T(L, kk) : slabs[0]; slabs[2] = lev ? TMX_SLAB_R(L, kk) : slabs[0];
+	slabs[3] = lev ? TMX_SLAB_U(L, kk) : slabs[0]; slabs[4] = lev ? TMX_SLAB_V(L, kk) : slabs[0];
+	double v[5][4];
+#pragma unroll
+	for (int t = 0; t < 5; t++)
+#pragma unroll
+		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
+	auto avg = [&](const double * w) -> double {
+		if (n == 2) return 0.5 * (w[0] + w[1]);
+		if (n == 4) return 0.5 * (0.5 * (w[0] + w[1]) + 0.5 * (w[2] + w[3]));
+		return (1.0 / 3.0) * (w[0] + w[1] + w[2]);
+	};
+	double out[5][4];
+#pragma unroll
+	for (int t = 0; t < 3; t++) {
+		const double a = avg(v[t]);
+#pragma unroll
+		for (int m = 0; m < 4; m++) out[t][m] = a;
 	}
-	// covector (U,V) across panels: rotate every copy into the frame of member 0, average, rotate back
-	if (xi >= 0 && kk < L) {
+	if (xi < 0) {
+		const double a3 = avg(v[3]), a4 = avg(v[4]);
+#pragma unroll
+		for (int m = 0; m < 4; m++) { out[3][m] = a3; out[4][m] = a4; }
+	} else {
 		const double * M = xmat + (size_t)xi * 32;
 		double va[4] = { 0, 0, 0, 0 }, vb[4] = { 0, 0, 0, 0 };
-		for (int m = 0; m < n; m++) {
-			const double ua = ld(TMX_SLAB_U(L, kk), m), ub = ld(TMX_SLAB_V(L, kk), m);
+#pragma unroll
+		for (int m = 0; m < 4; m++) if (m < n) {
 			const double * A = M + m * 8;
-			va[m] = A[0] * ua + A[1] * ub;
-			vb[m] = A[2] * ua + A[3] * ub;
+			va[m] = A[0] * v[3][m] + A[1] * v[4][m];
+			vb[m] = A[2] * v[3][m] + A[3] * v[4][m];
 		}
 		const double aa = avg(va), ab = avg(vb);
-		for (int m = 0; m < n; m++) {
-			if (c[m] >= (int)NS) continue;
+#pragma unroll
+		for (int m = 0; m < 4; m++) if (m < n) {
 			const double * B = M + m * 8 + 4;
-			x[(size_t)TMX_SLAB_U(L, kk) * NS + c[m]] = B[0] * aa + B[1] * ab;
-			x[(size_t)TMX_SLAB_V(L, kk) * NS + c[m]] = B[2] * aa + B[3] * ab;
+			out[3][m] = B[0] * aa + B[1] * ab;
+			out[4][m] = B[2] * aa + B[3] * ab;
 		}
 	}
+#pragma unroll
+	for (int t = 0; t < 5; t++)
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (loc[m] && (t == 0 || lev)) x[(size_t)slabs[t] * NS + c[m]] = out[t][m];
 }
 
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
@@ -463,7 +521,7 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 {
 	__shared__ double s[4][8][64];
 	__shared__ double sD[16], sS[16];
-	const int lane = threadIdx.x, ty = threadIdx.y;
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
@@ -598,7 +656,7 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int u = blockIdx.x * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + threadIdx.y;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (u >= nunique || k > L) return;
 	const int col = ucol[u];
 	const double invdt = 1.0 / dt;
@@ -621,7 +679,12 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 		return xin[(size_t)TMX_SLAB_W(L, lc) * NS + col];
 	};
 	const size_t s3e = (size_t)(L + 1) * NS, s3n = (size_t)L * NS;
-	auto cxe = [&](int f, int m) -> double { return p.g3e[f * s3e + (size_t)m * NS + col]; };
+	const MetCol mcol = met_col(p, col);
+	auto cxe = [&](int f, int m) -> double {
+		double e0, e1, e2;
+		metric_edge(p, mcol, m, col, e0, e1, e2);
+		return f == G3E_CX0 ? e0 : (f == G3E_CX1 ? e1 : e2);
+	};
 	const double c2a0 = p.g2d[G2_C2A0 * NS + col], c2a1 = p.g2d[G2_C2A1 * NS + col], c2b1 = p.g2d[G2_C2B1 * NS + col];
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col], drx = p.g2d[G2_DRX * NS + col];
 
@@ -728,8 +791,9 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 		double wn0 = 0.0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * wep;
 		// node metric at k-1, k
 		const size_t om = (size_t)(k - 1) * NS + col, o0 = (size_t)k * NS + col;
-		const double ca2m = p.g3n[G3N_CA2 * s3n + om], cb2m = p.g3n[G3N_CB2 * s3n + om], cx2m = p.g3n[G3N_CX2 * s3n + om];
-		const double ca20 = p.g3n[G3N_CA2 * s3n + o0], cb20 = p.g3n[G3N_CB2 * s3n + o0], cx20 = p.g3n[G3N_CX2 * s3n + o0];
+		double ca2m, cb2m, cx2m, ca20, cb20, cx20;
+		metric_node3(p, mcol, k - 1, col, ca2m, cb2m, cx2m);
+		metric_node3(p, mcol, k, col, ca20, cb20, cx20);
 		// xi_dot on levels (:2049-2054) and kinetic energy on levels (BuildF :2455-2478)
 		const double xdnm = ca2m * unm + cb2m * vnm + cx2m * wnm;
 		const double xdn0 = ca20 * un0 + cb20 * vn0 + cx20 * wn0;
@@ -945,23 +1009,23 @@ void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double
 struct NodeLev { double un, vn, pn, rn, ca2, cb2, cx2; };
 struct EdgeLev { double we, ce0, ce1, ce2; };
 
-__device__ __forceinline__ NodeLev load_node(const KParams & p, const double * xin, int l, int col) {
+__device__ __forceinline__ NodeLev load_node(const KParams & p, const MetCol & mc, const double * xin, int l, int col) {
 	NodeLev n = { 0, 0, 1, 1, 0, 0, 0 };
 	const int L = p.L;
 	if (l < 0 || l >= L) return n;
-	const size_t NS = (size_t)p.NS, s3 = (size_t)L * NS, o = (size_t)l * NS + col;
+	const size_t NS = (size_t)p.NS;
 	n.un = xin[TMX_SLAB_U(L, l) * NS + col]; n.vn = xin[TMX_SLAB_V(L, l) * NS + col];
 	n.pn = xin[TMX_SLAB_T(L, l) * NS + col]; n.rn = xin[TMX_SLAB_R(L, l) * NS + col];
-	n.ca2 = p.g3n[G3N_CA2 * s3 + o]; n.cb2 = p.g3n[G3N_CB2 * s3 + o]; n.cx2 = p.g3n[G3N_CX2 * s3 + o];
+	metric_node3(p, mc, l, col, n.ca2, n.cb2, n.cx2);
 	return n;
 }
-__device__ __forceinline__ EdgeLev load_edge(const KParams & p, const double * xin, int l, int col) {
+__device__ __forceinline__ EdgeLev load_edge(const KParams & p, const MetCol & mc, const double * xin, int l, int col) {
 	EdgeLev e = { 0, 0, 0, 0 };
 	const int L = p.L;
 	if (l < 0 || l > L) return e;
-	const size_t NS = (size_t)p.NS, s3 = (size_t)(L + 1) * NS, o = (size_t)l * NS + col;
+	const size_t NS = (size_t)p.NS;
 	e.we = xin[TMX_SLAB_W(L, l) * NS + col];
-	e.ce0 = p.g3e[G3E_CX0 * s3 + o]; e.ce1 = p.g3e[G3E_CX1 * s3 + o]; e.ce2 = p.g3e[G3E_CX2 * s3 + o];
+	metric_edge(p, mc, l, col, e.ce0, e.ce1, e.ce2);
 	return e;
 }
 
@@ -1210,12 +1274,13 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
 	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
 	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+	const MetCol mcol = met_col(p, col);
 
 	// level window for block k: nodes k-1,k,k+1 and interfaces k-1,k,k+1
-	NodeLev nA = load_node(p, xin, -1, col), nB = load_node(p, xin, 0, col), nC = load_node(p, xin, 1, col);
-	EdgeLev eA = load_edge(p, xin, -1, col), eB = load_edge(p, xin, 0, col), eC = load_edge(p, xin, 1, col);
-	NodeLev nN = load_node(p, xin, 2, col);
-	EdgeLev eN = load_edge(p, xin, 2, col);
+	NodeLev nA = load_node(p, mcol, xin, -1, col), nB = load_node(p, mcol, xin, 0, col), nC = load_node(p, mcol, xin, 1, col);
+	EdgeLev eA = load_edge(p, mcol, xin, -1, col), eB = load_edge(p, mcol, xin, 0, col), eC = load_edge(p, mcol, xin, 1, col);
+	NodeLev nN = load_node(p, mcol, xin, 2, col);
+	EdgeLev eN = load_edge(p, mcol, xin, 2, col);
 
 	double R[5][TMX_BW], b[5];
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
@@ -1224,7 +1289,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	compute_block<CARRY>(p, opsl, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 	nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
-	nN = load_node(p, xin, 3, col); eN = load_edge(p, xin, 3, col);
+	nN = load_node(p, mcol, xin, 3, col); eN = load_edge(p, mcol, xin, 3, col);
 	compute_block<CARRY>(p, opsl, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR, cy);
 	// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
 #pragma unroll
@@ -1240,7 +1305,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	lu_pivot_step(R, b, singular, AB, RHS, 0, NUS, u, sR, gR);      // pivot 0 takes in row 5
 	for (int m = 2; m <= L; m++) {
 		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
-		nN = load_node(p, xin, m + 2, col); eN = load_edge(p, xin, m + 2, col);   // used two blocks from now
+		nN = load_node(p, mcol, xin, m + 2, col); eN = load_edge(p, mcol, xin, m + 2, col);   // used two blocks from now
 		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP);
 		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW);
@@ -1320,14 +1385,15 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + threadIdx.y;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (col >= p.ncol || k > L) return;
 	ColConst cc;
 	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
 	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
 	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
-	const NodeLev nA = load_node(p, xin, k - 1, col), nB = load_node(p, xin, k, col), nC = load_node(p, xin, k + 1, col);
-	const EdgeLev eA = load_edge(p, xin, k - 1, col), eB = load_edge(p, xin, k, col), eC = load_edge(p, xin, k + 1, col);
+	const MetCol mcol = met_col(p, col);
+	const NodeLev nA = load_node(p, mcol, xin, k - 1, col), nB = load_node(p, mcol, xin, k, col), nC = load_node(p, mcol, xin, k + 1, col);
+	const EdgeLev eA = load_edge(p, mcol, xin, k - 1, col), eB = load_edge(p, mcol, xin, k, col), eC = load_edge(p, mcol, xin, k + 1, col);
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
 	BlkCarry cy;
 	compute_block<false>(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);

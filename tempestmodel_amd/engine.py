@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtempest_mi355x.so")
 
-TMX_ABI_VERSION = 2
+TMX_ABI_VERSION = 3
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
             "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
             "penalty_left", "penalty_right"]
@@ -87,6 +87,7 @@ def load_library():
     lib.tmx_profile_get.argtypes = [C.c_void_p, C.c_int, PD, C.POINTER(C.c_longlong)]
     lib.tmx_upload_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
+    lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     _lib = lib
@@ -196,6 +197,16 @@ class Engine:
                     keep.append(a)
                     setattr(pg, nm, _pd(a))
                 self._chk(self.lib.tmx_set_patch_geometry(self.h, P.index, C.byref(pg)))
+                # closed form of the 3-D metric, where the grid knows its factors (reference:
+                # GridPatchCSGLL::m_dXNode/m_dYNode, GetTopographyDeriv, Grid::GetREtaLevels/Interfaces)
+                if (not self.shallow_water and getattr(P, "X", None) is not None
+                        and "topography_deriv" in P.geom and getattr(g, "reta_levels", None) is not None):
+                    fx = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                          (P.X, P.Y, P.geom["topography_deriv"], g.reta_levels, g.reta_interfaces)]
+                    keep += fx
+                    self._chk(self.lib.tmx_set_patch_metric_factors(
+                        self.h, P.index, _pd(fx[0]), _pd(fx[1]), _pd(fx[2]), float(g.phys.earth_radius),
+                        _pd(fx[3]), _pd(fx[4])))
         self._chk(self.lib.tmx_finalize(self.h))
 
     @property

@@ -28,3 +28,5 @@ def test_reference_driver_with_adapter_plugins(mode, args):
     tail = "\n".join(r.stdout.splitlines()[-6:])
     print(tail)
     assert r.returncode == 0 and "ADAPTER_OK" in r.stdout, tail
+    # the metric factors read from the reference's own grid objects reproduce its arrays bit for bit
+    assert "verified bit for bit): active" in r.stdout, tail

@@ -163,6 +163,51 @@ def test_fused_column_kernel_is_bit_identical_to_split_kernels():
             assert np.array_equal(ae[3], be[3])
 
 
+def test_closed_form_metric_is_bit_identical_to_stored_arrays():
+    """tmx_set_patch_metric_factors: the kernels' in-register evaluation of the terrain-following metric
+    (GridPatchCSGLL.cpp:441-566) is accepted only after a bit-for-bit comparison with the stored arrays, so
+    whole steps and the per-call kernels agree bit for bit with the engine streaming the arrays; factors that
+    do not reproduce the arrays are refused (stored arrays stay in use)."""
+    import os
+    from tempestmodel_amd.engine import Engine
+    INFO_CLOSED = 6
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step2", g)
+    out = []
+    for mode in ("closed", "stored"):
+        os.environ["TMX_METRIC"] = mode
+        try:
+            e = Engine(g)
+        finally:
+            os.environ.pop("TMX_METRIC", None)
+        assert e.info(INFO_CLOSED) == (1 if mode == "closed" else 0)
+        e.upload_state(0, start)
+        res = []
+        e.copy_data(0, 1); e.h_step_explicit(0, 1, 40.0); e.sync(); res.append(e.download_state(1))
+        e.v_step_explicit(0, 1, 40.0); e.sync(); res.append(e.download_state(1))
+        e.copy_data(0, 2); e.v_step_implicit(0, 2, 87.0); e.sync(); res.append(e.download_state(2))
+        e.copy_data(0, 3); e.v_step_implicit_terms_explicitly(0, 3, 40.0); e.sync(); res.append(e.download_state(3))
+        for _ in range(3):
+            e.step_ars343(200.0)
+        e.sync(); res.append(e.download_state(0))
+        out.append(res)
+        e.close()
+    for ra, rb in zip(*out):
+        for (an, ae), (bn, be) in zip(ra, rb):
+            assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
+            assert np.array_equal(ae[3], be[3])
+    # perturbed factors must be refused
+    keep = g.patches[0].X.copy()
+    try:
+        g.patches[0].X = keep * (1.0 + 1e-15)
+        e = Engine(g)
+        assert e.info(INFO_CLOSED) == 0
+        e.close()
+    finally:
+        g.patches[0].X = keep
+
+
 def _reference_call_sequence(e, dt):
     """TimestepSchemeARS343::Step spelled out with one ABI call per reference call
     (TimestepSchemeARS343.cpp:150-236); the tableau is taken from the oracle's restatement."""
