@@ -25,35 +25,41 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# algorithmic bytes per point (stored node x level) per call, SURVEY.md section 8(d)
-ALG_BYTES = {
-    "h_explicit": 200.0,     # 5 R state + 5 R/W update + 10 metric
-    "v_explicit": 80.0,
-    "v_implicit": 272.0,     # vi_assemble + vi_solve together
-    "dss": 60.0,
-    "hypervis": 216.0,       # per pass (432 per step, two passes)
-    "lincomb": 600.0 / 10,   # 600 B/point/step over the copy/combine launches of one step
-}
-OP_KERNELS = {
-    "h_explicit": ["h_explicit"], "v_explicit": ["v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
-    "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"],
-}
+# Algorithmic bytes per point (stored node x level) per LAUNCH of each operation, from SURVEY.md section 8(d)
+# (DESIGN.md "Roofline accounting" derives them).  One ARS343 step = 4 h_explicit + 3 v_implicit + 6 dss +
+# 2 hypervis launches; the stage combinations and VerticalDynamicsFEM::StepExplicit are fused into h_explicit.
+#   h_explicit : H row 200 B (5 R state + 5 R + 5 W update + 10 metric) minus the 5 R of the update instance that
+#                the fused combination replaces (40 B) plus the stage-combination row, 600 B/step over 4 launches
+#                (150 B); the V-explicit row (80 B) is NOT counted: fusion removes its traffic altogether
+#   v_implicit : 272 B (5 R + 3 W + 26 metric)
+#   dss        : 60 B,  hypervis: 216 B per pass (the fused pass kernel moves less than that)
+#   lincomb    : the copies left un-fused (device copies of whole / partial instances); no SURVEY row of its own
+ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 216.0, "lincomb": 0.0}
+ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
+# engine profile slots (HIP events) that make up each operation
+OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
+              "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
-# rocprof kernel names per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
-OP_ROCPROF = {"h_explicit": ["k_h_explicit<true>", "k_h_w_update"], "v_implicit": ["k_vi_fused<true>"], "dss": ["k_dss"],
-              "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"], "v_explicit": ["k_v_explicit"]}
+# rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
+OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused"], "dss": ["k_dss"],
+              "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
 
 
-def measured_traffic(op, ne, L, world):
-    """HBM bytes per launch of the operation's kernels from the committed PMC pass (FETCH_SIZE / WRITE_SIZE
-    collected in separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes).  The table was
+def measured_traffic(op, ne, L, world, launches_per_step):
+    """HBM bytes per launch of the operation from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  The table was
     taken at ne30 L30 on one GPU; for any other workload the traffic is not known -> None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not (ne == 30 and L == 30 and world == 1 and os.path.exists(path)):
         return None
     try:
-        tab = json.load(open(path))["kernels"]
-        return sum(tab[k]["hbm_bytes_per_launch"] for k in OP_ROCPROF[op])
+        tab = json.load(open(path))
+        per_step = 0.0
+        for name, row in tab["kernels"].items():
+            base = name.replace("void ", "").split("<")[0].split("(")[0]
+            if base in OP_ROCPROF[op]:
+                per_step += row["hbm_bytes_per_launch"] * row["launches"] / tab["steps"]
+        return per_step / launches_per_step if per_step > 0 and launches_per_step > 0 else None
     except Exception:
         return None
 
@@ -182,13 +188,15 @@ def main():
         points = 6 * (ne * 4) ** 2 * L
         ms_per_step = 1e3 * wall / args.steps
         value = dof_per_step * args.steps / wall
-        # dominant operation of the step on this rank
+        # dominant operation of the step on this rank; a launch = one call of the operation (its kernels together)
         op_time = {op: sum(prof[k][0] for k in ks) for op, ks in OP_KERNELS.items()}
-        dom = max(op_time, key=op_time.get)
-        launches = max(prof[OP_KERNELS[dom][0]][1], 1)
-        avg_ms = op_time[dom] / launches
+        dom = max((op for op in op_time if ALG_BYTES[op] > 0), key=op_time.get)
+        op_launches = {op: max(sum(prof[k][1] for k in ks), 1) for op, ks in OP_KERNELS.items()}
+        avg_ms = op_time[dom] / op_launches[dom]
         local_points = points / world
         achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
+        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_fused",
+                       "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
         out = {
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
             "value": value, "unit": "element-DOF-updates/s",
@@ -200,10 +208,17 @@ def main():
                                    "ARS343 dt=%gs, hyperviscosity order 4, %d patches" % (ne, L, dt, len(grid.patches)),
                        "elements": n_el, "dof_per_step": dof_per_step, "dt_s": dt,
                        "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world)},
-            "roofline": {"bound": "hbm", "kernel": "+".join("k_" + k for k in OP_KERNELS[dom]), "operation": dom,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom, ne, L, world), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points},
+                         "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
+                         "per_operation": {op: {"launches_per_step": op_launches[op] / args.steps,
+                                                "ms_per_launch": op_time[op] / op_launches[op],
+                                                "achieved_GBs": ALG_BYTES[op] * local_points
+                                                / max(op_time[op] / op_launches[op] * 1e-3, 1e-12) / 1e9,
+                                                "traffic": measured_traffic(op, ne, L, world, op_launches[op] / args.steps)}
+                                           for op in OP_KERNELS},
+                         "whole_step_algorithmic_GBs": ALG_BYTES_PER_STEP * points * args.steps / wall / 1e9},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
         }

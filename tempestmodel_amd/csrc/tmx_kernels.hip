@@ -86,14 +86,22 @@ __device__ __forceinline__ void metric_node(const KParams & p, const MetCol & m,
 	ca2 = p.g3n[G3N_CA2 * s3 + o]; cb2 = p.g3n[G3N_CB2 * s3 + o]; cx2 = p.g3n[G3N_CX2 * s3 + o];
 	dra = p.g3n[G3N_DRA * s3 + o]; drb = p.g3n[G3N_DRB * s3 + o];
 }
-__device__ __forceinline__ void metric_node3(const KParams & p, const MetCol & m, int k, int col, double & ca2, double & cb2, double & cx2) {
-	if (p.closed) { double a, b; met_eval(m, p.eta[k], ca2, cb2, cx2, a, b); return; }
+// MM: 0 = metric mode read from p.closed at run time, 1 - eta table in global memory (the explicit kernels);
+//     1 = closed form, table in LDS (`etal`); 2 = stored arrays.  1 and 2 are k_vi_fused's compile-time variants:
+//     a fixed number of loads per block row lets the compiler count vmcnt exactly, and a pointer that may be LDS
+//     or global would become a flat load, which also counts on vmcnt.
+template <int MM = 0>
+__device__ __forceinline__ void metric_node3(const KParams & p, const MetCol & m, int k, int col, double & ca2, double & cb2, double & cx2,
+	const double * etal = nullptr) {
+	if (MM == 1 || (MM == 0 && p.closed)) { double a, b; met_eval(m, MM == 1 ? etal[k] : p.eta[k], ca2, cb2, cx2, a, b); return; }
 	const size_t s3 = (size_t)p.L * p.NS, o = (size_t)k * p.NS + col;
 	ca2 = p.g3n[G3N_CA2 * s3 + o]; cb2 = p.g3n[G3N_CB2 * s3 + o]; cx2 = p.g3n[G3N_CX2 * s3 + o];
 }
 // interface k: g^{xi alpha}, g^{xi beta}, g^{xi xi}
-__device__ __forceinline__ void metric_edge(const KParams & p, const MetCol & m, int k, int col, double & cx0, double & cx1, double & cx2) {
-	if (p.closed) { double a, b; met_eval(m, p.eta[p.L + k], cx0, cx1, cx2, a, b); return; }
+template <int MM = 0>
+__device__ __forceinline__ void metric_edge(const KParams & p, const MetCol & m, int k, int col, double & cx0, double & cx1, double & cx2,
+	const double * etal = nullptr) {
+	if (MM == 1 || (MM == 0 && p.closed)) { double a, b; met_eval(m, MM == 1 ? etal[p.L + k] : p.eta[p.L + k], cx0, cx1, cx2, a, b); return; }
 	const size_t s3 = (size_t)(p.L + 1) * p.NS, o = (size_t)k * p.NS + col;
 	cx0 = p.g3e[G3E_CX0 * s3 + o]; cx1 = p.g3e[G3E_CX1 * s3 + o]; cx2 = p.g3e[G3E_CX2 * s3 + o];
 }
@@ -1009,23 +1017,30 @@ void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double
 struct NodeLev { double un, vn, pn, rn, ca2, cb2, cx2; };
 struct EdgeLev { double we, ce0, ce1, ce2; };
 
-__device__ __forceinline__ NodeLev load_node(const KParams & p, const MetCol & mc, const double * xin, int l, int col) {
-	NodeLev n = { 0, 0, 1, 1, 0, 0, 0 };
+// Loads are unconditional with the level clamped into range: a fixed number of loads per block row keeps the
+// compiler's vmcnt bookkeeping exact, so a wait for the previous block row's prefetch does not also wait for
+// the loads just issued.  Out-of-range levels (-1 below block row 0, L and L+1 past the top) therefore carry
+// the values of the nearest level; compute_block only touches them under its k >= 1 / k + 1 <= L - 1 guards or
+// with zero operator coefficients, so results do not depend on them (checked bitwise against the split kernels).
+template <int MM = 0>
+__device__ __forceinline__ NodeLev load_node(const KParams & p, const MetCol & mc, const double * xin, int l, int col, const double * etal = nullptr) {
+	NodeLev n;
 	const int L = p.L;
-	if (l < 0 || l >= L) return n;
+	const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
 	const size_t NS = (size_t)p.NS;
-	n.un = xin[TMX_SLAB_U(L, l) * NS + col]; n.vn = xin[TMX_SLAB_V(L, l) * NS + col];
-	n.pn = xin[TMX_SLAB_T(L, l) * NS + col]; n.rn = xin[TMX_SLAB_R(L, l) * NS + col];
-	metric_node3(p, mc, l, col, n.ca2, n.cb2, n.cx2);
+	n.un = xin[TMX_SLAB_U(L, lc) * NS + col]; n.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
+	n.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; n.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
+	metric_node3<MM>(p, mc, lc, col, n.ca2, n.cb2, n.cx2, etal);
 	return n;
 }
-__device__ __forceinline__ EdgeLev load_edge(const KParams & p, const MetCol & mc, const double * xin, int l, int col) {
-	EdgeLev e = { 0, 0, 0, 0 };
+template <int MM = 0>
+__device__ __forceinline__ EdgeLev load_edge(const KParams & p, const MetCol & mc, const double * xin, int l, int col, const double * etal = nullptr) {
+	EdgeLev e;
 	const int L = p.L;
-	if (l < 0 || l > L) return e;
+	const int lc = l < 0 ? 0 : (l > L ? L : l);
 	const size_t NS = (size_t)p.NS;
-	e.we = xin[TMX_SLAB_W(L, l) * NS + col];
-	metric_edge(p, mc, l, col, e.ce0, e.ce1, e.ce2);
+	e.we = xin[TMX_SLAB_W(L, lc) * NS + col];
+	metric_edge<MM>(p, mc, lc, col, e.ce0, e.ce1, e.ce2, etal);
 	return e;
 }
 
@@ -1040,6 +1055,8 @@ struct BlkCarry {
 };
 
 // block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
+// column-operator coefficients from the LDS copy (ds_read: no vector-memory round trip, no vmcnt wait behind the U-row stores)
+#define OPCL(op, k, off) opsl[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
 template <bool CARRY>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
@@ -1051,7 +1068,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	fP = 0.0; fW = 0.0; fR = 0.0;
 #define DOFF(cr, cc_, dk) (3 * (dk) + ((cc_) - (cr)) + 4)
 	// interior interpolation stencils (offsets -1, 0), verified by tmx_set_operators
-	const double ib_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, -1), ib_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, 0);
+	const double ib_m = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, -1), ib_0 = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, 0);
 
 	// ---- interface k: interpolated U,V,rho*theta,rho and xi_dot (PrepareColumn :2056-2069) ----
 	double ue_b = 0.0, ve_b = 0.0, xd0 = 0.0, pe0 = 0.0, re0 = 0.0;
@@ -1067,7 +1084,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	double ue_c = 0.0, ve_c = 0.0, xd1 = 0.0, pe1 = 0.0, re1 = 0.0;
 	double ic_m = 0.0, ic_0 = 0.0;
 	if (k + 1 <= L - 1) {
-		ic_m = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1); ic_0 = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
+		ic_m = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1); ic_0 = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
 		ue_c += ic_m * B.un; ue_c += ic_0 * C.un; ve_c += ic_m * B.vn; ve_c += ic_0 * C.vn;
 		xd1 = ec.ce0 * ue_c + ec.ce1 * ve_c + ec.ce2 * ec.we;
 		pe1 += ic_m * B.pn; pe1 += ic_0 * C.pn; re1 += ic_m * B.rn; re1 += ic_0 * C.rn;
@@ -1078,14 +1095,14 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		const double pm = A.pn, p0 = B.pn, pp = C.pn, rm = A.rn, r0 = B.rn, rp = C.rn;
 		const double mf0 = (k >= 1) ? cc.je * re0 * xd0 : 0.0, mf1 = (k + 1 <= L - 1) ? cc.je * re1 * xd1 : 0.0;
 		const double pf0 = (k >= 1) ? cc.je * pe0 * xd0 : 0.0, pf1 = (k + 1 <= L - 1) ? cc.je * pe1 * xd1 : 0.0;
-		const double de0 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
+		const double de0 = OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
 		double dmf = 0.0; dmf += de0 * mf0; dmf += de1 * mf1;
 		double dpf = 0.0; dpf += de0 * pf0; dpf += de1 * pf1;
 		fR = dmf * invJ;
 		fP += dpf * invJ;
 		const double wlo = fabs(xd0), whi = fabs(xd1);
-		const double pl0 = OPC(TMX_OP_PENALTY_LEFT, k, 0), pl1 = OPC(TMX_OP_PENALTY_LEFT, k, 1);
-		const double pr0 = OPC(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPC(TMX_OP_PENALTY_RIGHT, k, 0);
+		const double pl0 = OPCL(TMX_OP_PENALTY_LEFT, k, 0), pl1 = OPCL(TMX_OP_PENALTY_LEFT, k, 1);
+		const double pr0 = OPCL(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPCL(TMX_OP_PENALTY_RIGHT, k, 0);
 		{
 			double a = 0.0;
 			if (k < L - 1) { double b = 0.0; b += pl0 * p0; b += pl1 * pp; a += b * whi; }
@@ -1133,7 +1150,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	double ex0 = 0.0, wn0 = 0.0, xdn0 = 0.0, ke0 = 0.0;
 	if (k <= L - 1 && (CARRY || k >= 1)) {
 		ex0 = exner_from_rhotheta(p, B.pn);
-		wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * eb.we; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * ec.we;
+		wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * eb.we; wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * ec.we;
 		xdn0 = B.ca2 * B.un + B.cb2 * B.vn + B.cx2 * wn0;
 		const double ca = cc.c2a0 * B.un + cc.c2a1 * B.vn + B.ca2 * wn0, cb = cc.c2a1 * B.un + cc.c2b1 * B.vn + B.cb2 * wn0;
 		ke0 = 0.5 * (ca * B.un + cb * B.vn + xdn0 * wn0);
@@ -1144,14 +1161,14 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		if (CARRY) { exm = cy.ex; wnm = cy.wn; xdnm = cy.xdn; kem = cy.ke; }
 		else {
 			exm = exner_from_rhotheta(p, pm);
-			wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * ea.we; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * eb.we;
+			wnm = 0.0; wnm += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * ea.we; wnm += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * eb.we;
 			xdnm = A.ca2 * A.un + A.cb2 * A.vn + A.cx2 * wnm;
 			const double ca = cc.c2a0 * A.un + cc.c2a1 * A.vn + A.ca2 * wnm, cb = cc.c2a1 * A.un + cc.c2b1 * A.vn + A.cb2 * wnm;
 			kem = 0.5 * (ca * A.un + cb * A.vn + xdnm * wnm);
 		}
 		(void)wnm;
 		const double pe = pe0, re = re0;
-		const double dnm = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, -1), dn0 = OPC(TMX_OP_DIFF_NODE_TO_REDGE, k, 0);
+		const double dnm = OPCL(TMX_OP_DIFF_NODE_TO_REDGE, k, -1), dn0 = OPCL(TMX_OP_DIFF_NODE_TO_REDGE, k, 0);
 		double dpe = 0.0; dpe += dnm * exm; dpe += dn0 * ex0;
 		const double unm = A.un, un0 = B.un, vnm = A.vn, vn0 = B.vn;
 		const double wem = ea.we, we0 = eb.we, wep = ec.we;
@@ -1169,7 +1186,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			const double curl = -ca * dua - cb * dub;
 			fW += (dke + curl);
 		}
-		const double ddm = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, -1), dd0 = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 0), ddp = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 1);
+		const double ddm = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, -1), dd0 = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 0), ddp = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 1);
 		double ddw = 0.0; ddw += ddm * wem; ddw += dd0 * we0; ddw += ddp * wep;
 		fW -= cc.upc * fabs(xde) * ddw;
 		const double cA = pe * p.Rd / (re * cc.cv);
@@ -1186,10 +1203,10 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			rowW[DOFF(1, 0, 0)] += cC * re;
 			rowW[DOFF(1, 2, 0)] += -cC * pe;
 		}
-		rowW[DOFF(1, 1, -1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * dnm * xdnm;
-		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * dnm * xdnm;
-		rowW[DOFF(1, 1, 0)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * dn0 * xdn0;
-		rowW[DOFF(1, 1, 1)] += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * dn0 * xdn0;
+		rowW[DOFF(1, 1, -1)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * dnm * xdnm;
+		rowW[DOFF(1, 1, 0)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * dn0 * xdn0;
+		rowW[DOFF(1, 1, 1)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * dn0 * xdn0;
 		const double sw = (xde > 0.0) ? cx2e : ((xde < 0.0) ? -cx2e : 0.0);
 		rowW[DOFF(1, 1, 0)] -= cc.upc * sw * ddw;
 		rowW[DOFF(1, 1, -1)] -= cc.upc * fabs(xde) * ddm;
@@ -1204,10 +1221,22 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 #undef DOFF
 }
 
-// one elimination step on the register window (dgbtf2 + forward substitution of dgbtrs), then slide
+#undef OPCL
+
+// one elimination step on the register window (dgbtf2 + forward substitution of dgbtrs), then slide.
+// U rows go to the HBM scratch for the back substitution.  Entries 4..8 of a row are fill-in that exists only
+// for some pivot choices (measured on the baroclinic wave: 9 of the 15 such entries per block row are exactly
+// zero in every column, because rho*theta / W / rho rows pivot 4 / 3 / 2 rows down almost everywhere).  With
+// SPARSE an entry that is zero in all 64 lanes is not written, and `umask` (LDS, one word per row) tells the back
+// substitution which ones to read back; skipped entries are exact zeros, so the solve is unchanged.  This cuts
+// the kernel's HBM traffic by about a fifth (measured 286 vs 320 us per call at ne30 L30).
+// (Tried and dropped: detecting a wave-uniform pivot row with a ballot and swapping registers at compile time
+// instead of 160 v_cndmask per step, and skipping the update of all-zero fill-in columns -- neither changed the
+// time, the kernel is bound by HBM traffic at ne30 and by dependent-issue latency on small grids.)
+template <bool SPARSE>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
-	const double * inrow, double inb)
+	const double * inrow, double inb, int * umask)
 {
 	int pv = 0;
 	double amax = fabs(R[0][0]);
@@ -1231,7 +1260,16 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	}
 	if (R[0][0] == 0.0) singular = true;
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
+	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
+	int mask = 0;
+#pragma unroll
+	for (int c = 4; c < TMX_BW; c++) {
+		if (!SPARSE || __builtin_amdgcn_ballot_w64(R[0][c] != 0.0) != 0) {
+			AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
+			mask |= 1 << c;
+		}
+	}
+	if (threadIdx.x == 0) umask[jcol] = mask;
 	RHS[(size_t)jcol * NUS + u] = b[0];
 	const double rcp = 1.0 / R[0][0];
 #pragma unroll
@@ -1253,7 +1291,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	b[4] = inb;
 }
 
-template <bool CARRY>
+template <bool CARRY, bool SPARSE, bool CLOSED>
 __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
@@ -1263,7 +1301,11 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	extern __shared__ double opsl_mem[];
 	double * opsl = opsl_mem;
 	const int L = p.L;
+	constexpr int MM = CLOSED ? 1 : 2;
+	double * etal = opsl_mem + TMX_OP_COUNT * (L + 1) * TMX_OPW;             // [2L+1] 1 - eta (closed-form metric), else unused
+	int * umask = (int *)(etal + 2 * L + 1);                                 // [3(L+1)] which fill-in entries of a U row exist
 	for (int t = threadIdx.x; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 64) opsl[t] = p.ops[t];
+	if (CLOSED) for (int t = threadIdx.x; t < 2 * L + 1; t += 64) etal[t] = p.eta[t];
 	__syncthreads();
 	const size_t NS = (size_t)p.NS;
 	const int u = blockIdx.x * 64 + threadIdx.x;
@@ -1277,10 +1319,10 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	const MetCol mcol = met_col(p, col);
 
 	// level window for block k: nodes k-1,k,k+1 and interfaces k-1,k,k+1
-	NodeLev nA = load_node(p, mcol, xin, -1, col), nB = load_node(p, mcol, xin, 0, col), nC = load_node(p, mcol, xin, 1, col);
-	EdgeLev eA = load_edge(p, mcol, xin, -1, col), eB = load_edge(p, mcol, xin, 0, col), eC = load_edge(p, mcol, xin, 1, col);
-	NodeLev nN = load_node(p, mcol, xin, 2, col);
-	EdgeLev eN = load_edge(p, mcol, xin, 2, col);
+	NodeLev nA = load_node<MM>(p, mcol, xin, -1, col, etal), nB = load_node<MM>(p, mcol, xin, 0, col, etal), nC = load_node<MM>(p, mcol, xin, 1, col, etal);
+	EdgeLev eA = load_edge<MM>(p, mcol, xin, -1, col, etal), eB = load_edge<MM>(p, mcol, xin, 0, col, etal), eC = load_edge<MM>(p, mcol, xin, 1, col, etal);
+	NodeLev nN = load_node<MM>(p, mcol, xin, 2, col, etal);
+	EdgeLev eN = load_edge<MM>(p, mcol, xin, 2, col, etal);
 
 	double R[5][TMX_BW], b[5];
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
@@ -1289,7 +1331,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	compute_block<CARRY>(p, opsl, cc, 0, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 	nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
-	nN = load_node(p, mcol, xin, 3, col); eN = load_edge(p, mcol, xin, 3, col);
+	nN = load_node<MM>(p, mcol, xin, 3, col, etal); eN = load_edge<MM>(p, mcol, xin, 3, col, etal);
 	compute_block<CARRY>(p, opsl, cc, 1, nA, nB, nC, eA, eB, eC, sP, sW, sR, gP, gW, gR, cy);
 	// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
 #pragma unroll
@@ -1302,20 +1344,24 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	}
 	b[0] = fP; b[1] = fW; b[2] = fR; b[3] = gP; b[4] = gW;
 	bool singular = false;
-	lu_pivot_step(R, b, singular, AB, RHS, 0, NUS, u, sR, gR);      // pivot 0 takes in row 5
+	lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 0, NUS, u, sR, gR, umask);      // pivot 0 takes in row 5
+	// Drain the prologue's loads here, once: otherwise the per-column constants loaded before the loop count as
+	// "possibly still in flight" at the loop header and the compiler waits vmcnt(0) -- i.e. for all U-row
+	// stores of the previous block row -- at their first use in EVERY iteration.
+	__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 	for (int m = 2; m <= L; m++) {
 		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
-		nN = load_node(p, mcol, xin, m + 2, col); eN = load_edge(p, mcol, xin, m + 2, col);   // used two blocks from now
+		nN = load_node<MM>(p, mcol, xin, m + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, m + 2, col, etal);   // used two blocks from now
 		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
-		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP);
-		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW);
-		lu_pivot_step(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR);
+		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
+		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
+		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
 	}
 	{
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step(R, b, singular, AB, RHS, j, NUS, u, z, 0.0);
+		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
 	}
 	if (singular) atomicExch(flag, 1);
 
@@ -1334,7 +1380,9 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 #define ROW_SLAB(row) (((row) % TMX_FTOT) == 1 ? TMX_SLAB_W(L, (row) / TMX_FTOT) : \
 		(((row) / TMX_FTOT) == L ? -1 : (((row) % TMX_FTOT) == 0 ? TMX_SLAB_T(L, (row) / TMX_FTOT) : TMX_SLAB_R(L, (row) / TMX_FTOT))))
 #define LOAD_UROW(dst, ydst, xdst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
-		_Pragma("unroll") for (int c = 0; c < TMX_BW; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
+		const int mk_ = __builtin_amdgcn_readfirstlane(umask[rr_]); \
+		_Pragma("unroll") for (int c = 0; c < 4; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
+		_Pragma("unroll") for (int c = 4; c < TMX_BW; c++) dst[c] = (mk_ & (1 << c)) ? AB[((size_t)rr_ * TMX_BW + c) * NUS + u] : 0.0; \
 		ydst = RHS[(size_t)rr_ * NUS + u]; \
 		const int sl_ = ROW_SLAB(rr_); xdst = (sl_ >= 0) ? xin[(size_t)sl_ * NS + col] : 0.0; } while (0)
 #define BACK_ROW(ur, yr, x0r, row) do { \
@@ -1365,13 +1413,18 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nunique == 0) return;
-	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double);
-	if (e->vi_carry)
-		hipLaunchKernelGGL(k_vi_fused<true>, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
-			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
-	else
-		hipLaunchKernelGGL(k_vi_fused<false>, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt,
-			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
+	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
+#define LAUNCH_VI(C_, S_) do { if (p.closed) \
+		hipLaunchKernelGGL((k_vi_fused<C_, S_, true>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
+			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \
+	else \
+		hipLaunchKernelGGL((k_vi_fused<C_, S_, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
+			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); } while (0)
+	if (!e->vi_carry) LAUNCH_VI(false, true);
+	else if (sparse) LAUNCH_VI(true, true);
+	else LAUNCH_VI(true, false);
+#undef LAUNCH_VI
 }
 
 
