@@ -1349,14 +1349,28 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	// "possibly still in flight" at the loop header and the compiler waits vmcnt(0) -- i.e. for all U-row
 	// stores of the previous block row -- at their first use in EVERY iteration.
 	__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#ifdef TMX_VI_TIMING
+	long long t_asm = 0, t_lu = 0, t_all0 = __builtin_readcyclecounter();
+#define TMARK(acc) do { const long long t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define TMARK(acc)
+#endif
 	for (int m = 2; m <= L; m++) {
+#ifdef TMX_VI_TIMING
+		long long t0_ = __builtin_readcyclecounter();
+#endif
 		nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 		nN = load_node<MM>(p, mcol, xin, m + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, m + 2, col, etal);   // used two blocks from now
 		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
+		TMARK(t_asm);
 		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
 		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
 		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+		TMARK(t_lu);
 	}
+#ifdef TMX_VI_TIMING
+	const long long t_fwd = __builtin_readcyclecounter() - t_all0;
+#endif
 	{
 		double z[TMX_BW];
 #pragma unroll
@@ -1409,6 +1423,11 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 #undef ROW_SLAB
 #undef LOAD_UROW
 #undef BACK_ROW
+#ifdef TMX_VI_TIMING
+	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 7))
+		printf("vi timing block %d: forward loop %lld cycles (assembly %lld, LU %lld), total incl. back substitution %lld\n",
+			(int)blockIdx.x, t_fwd, t_asm, t_lu, (long long)(__builtin_readcyclecounter() - t_all0));
+#endif
 }
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {

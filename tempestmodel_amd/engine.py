@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtempest_mi355x.so")
+# TMX_LIBRARY: developer override to A/B an alternative build of the same ABI (e.g. the -DTMX_VI_TIMING variant)
+LIB_PATH = os.environ.get("TMX_LIBRARY") or os.path.join(_HERE, "libtempest_mi355x.so")
 
 TMX_ABI_VERSION = 3
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",

@@ -11,6 +11,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
+  steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
 """
 import json
@@ -103,6 +104,14 @@ def main():
         if k in ("p0/jacobian2d", "p4/jacobian2d", "p0/coriolis_f", "p4/contra_metric_2d_a", "p0/jacobian", "p0/topography"):
             rec[k] = v
     save("sw2_ne8_strang.npz", rec)
+
+    # north-star gate: 100 reference ARS343 steps at ne4 L10 from the developed state after 2 steps
+    d, _ = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--warm", "2", "--steps", "100",
+                "--every", "100", "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    cs = compact_states(d, 6)
+    rec.update({k: v for k, v in cs.items() if k.split("/")[1] in ("warm", "step100")})
+    save("steps100_ne4_L10_p6.npz", rec)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

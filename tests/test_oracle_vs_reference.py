@@ -87,6 +87,20 @@ def test_ars343_steps_from_developed_state(fixture, ne, L, npatch, dt, tags):
     assert abs(cs[4] - ref[4]) < 1e-12 * abs(ref[4])
 
 
+def test_hundred_reference_steps_ne4_L10():
+    """North-star gate on the CPU side: the C oracle stays within 1e-10 of the real reference over 100 ARS343
+    steps (ne4 L10 dt 200 s, from the reference's state after 2 steps)."""
+    d = gu.load("steps100_ne4_L10_p6.npz")
+    g, _ = gu.make_grid(4, 10, 6)
+    o = Oracle(g)
+    o.set_state(0, gu.expand_compact(d, "warm", g))
+    for _ in range(100):
+        assert o.step_ars343(200.0) == 0
+    errs = gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step100", g))
+    print("oracle vs reference after 100 steps:", errs)
+    assert max(errs) < 1e-10, errs
+
+
 def test_known_answers_are_the_survey_values():
     ka = json.load(open(os.path.join(gu.GOLDEN, "known_answers.json")))["jw_ne4_L10_dt200_ars343"]
     # SURVEY.md section 8(c): reference stdout, ne4 L10 ARS343 dt=200s
