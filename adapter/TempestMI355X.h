@@ -291,6 +291,16 @@ private:
 			g.topography = &(pPatch->GetTopography()[0][0]);
 			Check(tmx_set_patch_geometry(m_pEngine, pPatch->GetPatchIndex(), &g));
 
+			// Rayleigh friction (HorizontalDynamicsFEM::ApplyRayleighFriction runs at the end of StepAfterSubCycle)
+			if (pGrid->HasRayleighFriction() &&
+			    m_model.GetEquationSet().GetType() != EquationSet::ShallowWaterEquations) {
+				Check(tmx_set_patch_rayleigh(m_pEngine, pPatch->GetPatchIndex(),
+					&(pPatch->GetRayleighStrength(DataLocation_Node)[0][0][0]),
+					&(pPatch->GetRayleighStrength(DataLocation_REdge)[0][0][0]),
+					&(pPatch->GetReferenceState(DataLocation_Node)[0][0][0][0]),
+					&(pPatch->GetReferenceState(DataLocation_REdge)[0][0][0][0])));
+			}
+
 			// Factors of the closed-form 3-D metric (GridPatchCSGLL.cpp:370-568; m_dXNode = tan(m_dANode),
 			// :212-219).  The engine verifies them against the arrays above bit for bit before using them.
 			if (m_model.GetEquationSet().GetType() != EquationSet::ShallowWaterEquations) {

@@ -155,6 +155,17 @@ int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch_geometry *
 int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const double * x_node, const double * y_node,
 	const double * topography_deriv, double earth_radius, const double * reta_levels, const double * reta_interfaces);
 
+/* OPTIONAL, per owned patch: Rayleigh friction (Grid::HasRayleighFriction(); test cases with a damping layer,
+ * e.g. test/nonhydro_sphere/ScharMountainSphereTest.cpp).  strength_node [na][nb][L] / strength_redge [na][nb][L+1]
+ * = GridPatch::GetRayleighStrength(DataLocation_Node / _REdge), ref_node [5][na][nb][L] / ref_redge [5][na][nb][L+1]
+ * = GridPatch::GetReferenceState (src/atm/GridPatch.h, filled by GridPatchCSGLL::EvaluateTestCase,
+ * src/atm/GridPatchCSGLL.cpp:663-683).  When set (on every owned patch or on none), tmx_h_step_after_subcycle ends
+ * with HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570, called at
+ * :2719-2724 under APPLY_RAYLEIGH_WITH_HYPERVIS): ten sub-cycled backward-Euler relaxations of U, V, rho*theta and
+ * W towards the reference state wherever the strength is non-zero.  Not available for the shallow-water set. */
+int tmx_set_patch_rayleigh(tmx_engine * e, int patch, const double * strength_node, const double * strength_redge,
+	const double * ref_node, const double * ref_redge);
+
 /* Builds the HBM layout, DSS groups, unique-column lists and exchange plan. */
 int tmx_finalize(tmx_engine * e);
 

@@ -23,6 +23,9 @@
 #define main tmx_unused_sw2_main
 #include "SWTest2.cpp"
 #undef main
+#define main tmx_unused_schar_main
+#include "ScharMountainSphereTest.cpp"
+#undef main
 
 #include "GridPatchGLL.h"
 #include "GridPatchCSGLL.h"
@@ -182,6 +185,10 @@ static void dumpGeometry(TmxdWriter & w, Model & model, GridGLL * pGrid) {
 		dump3(w, pn + "z_interfaces", pPatch->GetZInterfaces());
 		dump4(w, pn + "ref_node", pPatch->GetReferenceState(DataLocation_Node));
 		dump4(w, pn + "ref_redge", pPatch->GetReferenceState(DataLocation_REdge));
+		if (pGrid->HasRayleighFriction()) {
+			dump3(w, pn + "rayleigh_node", pPatch->GetRayleighStrength(DataLocation_Node));
+			dump3(w, pn + "rayleigh_redge", pPatch->GetRayleighStrength(DataLocation_REdge));
+		}
 	}
 }
 
@@ -305,6 +312,10 @@ try {
 		                : BaroclinicWaveJWTest::PerturbationType_None;
 	if (fSW) {
 		model.SetTestCase(new ShallowWaterTestCase2(2998.104995, 38.61068277, 0.0));   // SWTest2.cpp defaults
+	} else if (tcase == "schar") {
+		// ScharMountainSphereTest.cpp defaults (:417-441): reduced planet X = 500, no rotation, Rayleigh layer above 20 km
+		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
+		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
 	} else {
 		model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, ePert));
 	}

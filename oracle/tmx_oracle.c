@@ -853,16 +853,59 @@ static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 	}
 }
 
+/* HorizontalDynamicsFEM::ApplyRayleighFriction (HorizontalDynamicsFEM.cpp:2420-2570): where the strength is
+ * non-zero, ten sub-cycled backward-Euler relaxations of U, V, rho*theta (levels) and W (interfaces) towards
+ * the reference state; rho is not touched (nEffectiveC, :2455-2461).  Interior nodes only. */
+static void rayleigh_friction(const orc_grid * g, orc_state * s, int iupd, double dt) {
+	const int L = g->L;
+	const int ncycles = 10;
+	const double factor = 1.0 / ncycles;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		if (!P->ray_node) continue;
+		const int na = P->na, nb = P->nb;
+		double * nup = s->node[iupd * g->npatch + p];
+		double * eup = s->redge[iupd * g->npatch + p];
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++) {
+			for (int k = 0; k < L; k++) {
+				const double nu = P->ray_node[((size_t)i * nb + j) * L + k];
+				if (nu == 0.0) continue;
+				for (int c = 0; c < 4; c++) {
+					if (c == 3) continue;                  /* W lives on interfaces */
+					const size_t o = (((size_t)c * na + i) * nb + j) * L + k;
+					for (int si = 0; si < ncycles; si++) {
+						const double f = 1.0 / (1.0 + factor * dt * nu);
+						nup[o] = f * nup[o] + (1.0 - f) * P->ref_node[o];
+					}
+				}
+			}
+			for (int k = 0; k <= L; k++) {
+				const double nu = P->ray_redge[((size_t)i * nb + j) * (L + 1) + k];
+				if (nu == 0.0) continue;
+				const size_t o = (((size_t)3 * na + i) * nb + j) * (L + 1) + k;
+				for (int si = 0; si < ncycles; si++) {
+					const double f = 1.0 / (1.0 + factor * dt * nu);
+					eup[o] = f * eup[o] + (1.0 - f) * P->ref_redge[o];
+				}
+			}
+		}
+	}
+}
+
 void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt) {
 	orc_copy(g, s, iinit, iupd);
-	if (g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0) return;
-	orc_zero(g, s, iwork);
-	scalar_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
-	vector_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 1.0, 0);
-	orc_apply_dss(g, s, iwork);
-	scalar_hyperdiff(g, s, iwork, iupd, -dt, g->nu_scalar, 1);
-	vector_hyperdiff(g, s, iwork, iupd, -dt, g->nu_div, g->nu_vort, 1);
-	orc_apply_dss(g, s, iupd);
+	if (!(g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0)) {
+		orc_zero(g, s, iwork);
+		scalar_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
+		vector_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 1.0, 0);
+		orc_apply_dss(g, s, iwork);
+		scalar_hyperdiff(g, s, iwork, iupd, -dt, g->nu_scalar, 1);
+		vector_hyperdiff(g, s, iwork, iupd, -dt, g->nu_div, g->nu_vort, 1);
+		orc_apply_dss(g, s, iupd);
+	}
+	/* APPLY_RAYLEIGH_WITH_HYPERVIS (Defines.h:70, HorizontalDynamicsFEM.cpp:2719-2724) */
+	if (!g->shallow_water) rayleigh_friction(g, s, iupd, dt);
 }
 
 /* ------------------------------------------------------------------------------------------ */

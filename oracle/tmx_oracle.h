@@ -62,6 +62,10 @@ typedef struct {
 	const int * hsi; const int * hsj;  /* source local indices                       */
 	const int * hspanel;               /* source panel                               */
 	const double * htrans;             /* [nhalo][2][2] covector transform           */
+	/* Rayleigh friction (all NULL = none): strength [na][nb][L] / [na][nb][L+1] (GridPatch::GetRayleighStrength)
+	 * and the reference state [5][na][nb][L] / [5][na][nb][L+1] (GridPatch::GetReferenceState)                */
+	const double * ray_node; const double * ray_redge;
+	const double * ref_node; const double * ref_redge;
 } orc_patch;
 
 typedef struct {

@@ -161,7 +161,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->stream) hipStreamSynchronize(e->stream);
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
-		free_dev(e->d_state); free_dev(e->d_eta); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_state); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
@@ -404,6 +404,39 @@ extern "C" int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const dou
 	return TMX_OK;
 }
 
+// Rayleigh friction inputs (GridPatch::GetRayleighStrength / GetReferenceState), gathered into the device layout
+extern "C" int tmx_set_patch_rayleigh(tmx_engine * e, int patch, const double * strength_node, const double * strength_redge,
+	const double * ref_node, const double * ref_redge)
+{
+	REQUIRE(e && strength_node && strength_redge && ref_node && ref_redge, TMX_ERR_INVALID, "tmx_set_patch_rayleigh: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_patch_rayleigh after tmx_finalize");
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "Rayleigh friction with the shallow-water equation set is not supported");
+	int r = ensure_layout(e);
+	if (r) return r;
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
+	const int L = e->L, na = P.na, nb = P.nb;
+	const size_t NS = e->NS;
+	if (e->h_ray_nu.empty()) { e->h_ray_nu.assign((size_t)(2 * L + 1) * NS, 0.0); e->h_ray_ref.assign((size_t)(4 * L + 1) * NS, 0.0); }
+	for (int i = 1; i < na - 1; i++)
+	for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j);
+		const size_t ij = (size_t)i * nb + j;
+		for (int k = 0; k < L; k++) {
+			e->h_ray_nu[(size_t)k * NS + c] = strength_node[ij * L + k];
+			for (int v = 0; v < 3; v++)      // U, V, rho*theta
+				e->h_ray_ref[(size_t)(v * L + k) * NS + c] = ref_node[(((size_t)v * na + i) * nb + j) * L + k];
+		}
+		for (int k = 0; k <= L; k++) {
+			e->h_ray_nu[(size_t)(L + k) * NS + c] = strength_redge[ij * (L + 1) + k];
+			e->h_ray_ref[(size_t)(3 * L + k) * NS + c] = ref_redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k];
+		}
+	}
+	P.rayleigh_set = true;
+	return TMX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // finalize: DSS groups, unique columns, exchange plan, device buffers
 
@@ -629,6 +662,17 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
 	}
 	if ((r = dev_upload(&e->d_ops, e->h_ops, &bytes))) return r;
+	{
+		int nset = 0;
+		for (int lp : e->local_patches) nset += e->patches[lp].rayleigh_set ? 1 : 0;
+		REQUIRE(nset == 0 || nset == (int)e->local_patches.size(), TMX_ERR_INVALID, "tmx_set_patch_rayleigh was called for %d of %d owned patches", nset, (int)e->local_patches.size());
+		e->rayleigh = nset > 0;
+		if (e->rayleigh) {
+			if ((r = dev_upload(&e->d_ray_nu, e->h_ray_nu, &bytes))) return r;
+			if ((r = dev_upload(&e->d_ray_ref, e->h_ray_ref, &bytes))) return r;
+		}
+		std::vector<double>().swap(e->h_ray_nu); std::vector<double>().swap(e->h_ray_ref);
+	}
 	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)(L + 4) * NS * sizeof(double))); bytes += (size_t)(L + 4) * NS * sizeof(double);
 	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)(L + 4) * NS * sizeof(double)));
 	if ((r = dev_upload(&e->d_grp_cols, plan.grp_cols, &bytes))) return r;
@@ -983,16 +1027,26 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	REQUIRE(iinit != iwork, TMX_ERR_INVALID, "StepAfterSubCycle: initial and working data must be distinct");
 	REQUIRE(iupd != iwork, TMX_ERR_INVALID, "StepAfterSubCycle: working and update data must be distinct");
 	const tmx_config & c = e->cfg;
-	if ((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0) return tmx_copy_data(e, iinit, iupd);
 	KParams p = make_params(e);
-	double scale = 1.0;
-	if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
-	{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0); }
-	if ((r = launch_check("hypervis pass 1"))) return r;
-	if ((r = tmx_apply_dss(e, iwork))) return r;
-	{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale); }
-	if ((r = launch_check("hypervis pass 2"))) return r;
-	return tmx_apply_dss(e, iupd);
+	if ((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0) {
+		if ((r = tmx_copy_data(e, iinit, iupd))) return r;
+	} else {
+		double scale = 1.0;
+		if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0); }
+		if ((r = launch_check("hypervis pass 1"))) return r;
+		if ((r = tmx_apply_dss(e, iwork))) return r;
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale); }
+		if ((r = launch_check("hypervis pass 2"))) return r;
+		if ((r = tmx_apply_dss(e, iupd))) return r;
+	}
+	// APPLY_RAYLEIGH_WITH_HYPERVIS (Defines.h:70; HorizontalDynamicsFEM.cpp:2719-2724)
+	if (e->rayleigh) {
+		ProfScope ps(e, TMX_K_HYPERVIS);
+		tmxk_rayleigh(e, p, inst(e, iupd), dt);
+		return launch_check("rayleigh friction");
+	}
+	return TMX_OK;
 }
 
 static bool hypervis_active(const tmx_engine * e) {

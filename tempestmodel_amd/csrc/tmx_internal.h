@@ -48,7 +48,7 @@ struct KParams {
 };
 
 struct PatchInfo {
-	bool defined = false, halo_set = false, geom_set = false, metric_ok = false;
+	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false;
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
@@ -75,6 +75,11 @@ struct tmx_engine {
 	std::vector<double> h_eta;               // [2L+1] 1 - eta (levels, then interfaces); empty until metric factors are set
 	bool metric_closed = false;              // kernels evaluate the 3-D metric in registers
 	double * d_eta = nullptr;
+	// Rayleigh friction (tmx_set_patch_rayleigh): strength [2L+1][NS] (levels, then interfaces) and reference
+	// state [4L+1][NS] (U, V, rho*theta on levels, W on interfaces)
+	std::vector<double> h_ray_nu, h_ray_ref;
+	bool rayleigh = false;
+	double * d_ray_nu = nullptr, * d_ray_ref = nullptr;
 	double h_dx[16], h_stiff[16];
 
 	// device
@@ -133,3 +138,4 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	double dt, double nu_s, double nu_d, double nu_v);
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
+void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);

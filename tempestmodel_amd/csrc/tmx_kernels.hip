@@ -498,6 +498,51 @@ void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
 		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat);
 }
 
+// HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
+// is non-zero, ten sub-cycled backward-Euler relaxations x <- f x + (1 - f) x_ref, f = 1 / (1 + dt nu / 10), of
+// U, V, rho*theta (strength on levels) and W (strength on interfaces); rho is left alone (:2455-2461).
+__global__ __launch_bounds__(256) void k_rayleigh(int L, int NS_, int ncol, double * __restrict__ x,
+	const double * __restrict__ nu, const double * __restrict__ ref, double dt)
+{
+	const size_t NS = (size_t)NS_;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k > L || col >= ncol) return;
+	const double factor = 1.0 / 10;
+	if (k < L) {
+		const double dnu = nu[(size_t)k * NS + col];
+		if (dnu != 0.0) {
+#pragma unroll
+			for (int v = 0; v < 3; v++) {
+				const size_t o = (size_t)(v * L + k) * NS + col;        // U, V, rho*theta slabs are [0, 3L)
+				double xv = x[o];
+				const double r = ref[o];
+				for (int si = 0; si < 10; si++) {
+					const double f = 1.0 / (1.0 + factor * dt * dnu);
+					xv = f * xv + (1.0 - f) * r;
+				}
+				x[o] = xv;
+			}
+		}
+	}
+	const double dnu = nu[(size_t)(L + k) * NS + col];
+	if (dnu != 0.0) {
+		const size_t o = (size_t)TMX_SLAB_W(L, k) * NS + col;
+		double xv = x[o];
+		const double r = ref[(size_t)(3 * L + k) * NS + col];
+		for (int si = 0; si < 10; si++) {
+			const double f = 1.0 / (1.0 + factor * dt * dnu);
+			xv = f * xv + (1.0 - f) * r;
+		}
+		x[o] = xv;
+	}
+}
+
+void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_rayleigh, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt);
+}
+
 // gather the copies other ranks need into the send buffer, one contiguous message per peer:
 // sendbuf = [peer][slab][count_peer]; entry i of the plan lives at base[i] + slab * stride[i]
 __global__ __launch_bounds__(256) void k_pack(int nslab, size_t NS, int nsend,

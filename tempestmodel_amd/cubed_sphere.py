@@ -704,6 +704,8 @@ class CubedSphereGrid:
         """Topography, geometry, initial and reference state on every node incl. halo
         (GridPatchCSGLL.cpp:578-920; Model::SetTestCase, Model.cpp:225-258)."""
         test.evaluate_physical_constants(self.phys)
+        if getattr(test, "reference_length", None) is not None:
+            self.reference_length = test.reference_length
         self.set_topography(test.evaluate_topography)
         self.evaluate_geometric_terms()
         a = self.phys.earth_radius
@@ -726,7 +728,12 @@ class CubedSphereGrid:
                     out[kind + "_" + loc] = np.stack([np.broadcast_to(s, z.shape) for s in st], 0).copy()
             g["ref_node"] = out["ref_node"]
             g["ref_redge"] = out["ref_redge"]
+            # Rayleigh friction strength on levels and interfaces, every node incl. halo (GridPatchCSGLL.cpp:663-683)
+            if getattr(test, "has_rayleigh_friction", False):
+                g["rayleigh_node"] = test.evaluate_rayleigh_strength(g["z_levels"])
+                g["rayleigh_redge"] = test.evaluate_rayleigh_strength(g["z_interfaces"])
             states.append((out["state_node"], out["state_redge"]))
+        self.has_rayleigh_friction = bool(getattr(test, "has_rayleigh_friction", False))
         return states
 
     def _evaluate_shallow_water(self, test):
@@ -854,6 +861,51 @@ class BaroclinicWaveJW:
             ulon = ulon + np.where(gc < 1.0, self.Up * np.exp(-gc * gc), 0.0)
         zero = np.zeros_like(ulon)
         return [ulon, zero, theta, zero.copy(), rho]
+
+
+class ScharMountainSphere:
+    """Schar-type mountain on a reduced-radius planet with a Rayleigh damping layer, as evaluated by the
+    reference test driver (test/nonhydro_sphere/ScharMountainSphereTest.cpp:120-250, defaults :417-441).
+    The one stock cubed-sphere test family whose Rayleigh strength is not identically zero."""
+
+    has_rayleigh_friction = True
+
+    def __init__(self, ztop=30000.0, X=500.0, omega=0.0, lonc=45.0, latc=0.0, h0=250.0, d=5000.0, xi=4000.0,
+                 teq=300.0, ueq=20.0, cs=0.0, zh=20000.0, tau0=25.0):
+        self.ztop, self.X, self.omega = ztop, X, omega
+        self.lonc, self.latc = lonc * math.pi / 180.0, latc * math.pi / 180.0
+        self.h0, self.d, self.xi, self.teq, self.ueq, self.cs, self.zh, self.tau0 = h0, d, xi, teq, ueq, cs, zh, tau0
+
+    @property
+    def reference_length(self):
+        """model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * dEarthScaling) (:463)."""
+        return 0.5 * math.pi / 30.0 * self.X
+
+    def evaluate_physical_constants(self, phys):
+        phys.omega = self.omega * self.X
+        phys.earth_radius = phys.earth_radius / self.X
+
+    def evaluate_topography(self, phys, lon, lat):
+        r = phys.earth_radius * np.arccos(math.sin(self.latc) * np.sin(lat)
+                                          + math.cos(self.latc) * np.cos(lat) * np.cos(lon - self.lonc))
+        cos_term = np.cos(math.pi * r / self.xi)
+        exp_term = np.exp(-r * r / (self.d * self.d))
+        return self.h0 * exp_term * cos_term * cos_term
+
+    def evaluate_rayleigh_strength(self, z):
+        nz = (z - self.zh) / (self.ztop - self.zh)
+        depth = np.sin(math.pi / 2.0 * nz)
+        depth = depth * depth
+        return np.where(z > self.zh, depth / self.tau0, 0.0)
+
+    def evaluate_pointwise(self, phys, z, lon, lat, reference=False):
+        s2 = np.sin(lat) * np.sin(lat)
+        T = self.teq * (1.0 - self.cs * self.ueq * self.ueq / phys.g * s2)
+        p = phys.p0 * np.exp(-self.ueq * self.ueq / (2.0 * phys.Rd * self.teq) * s2 - phys.g * z / (phys.Rd * T))
+        rho = p / (phys.Rd * T)
+        u = self.ueq * np.cos(lat) * np.sqrt(2.0 * self.teq / T * self.cs * z + T / self.teq)
+        zero = np.zeros_like(z)
+        return [u, zero.copy(), phys.rhotheta_from_pressure(p) / rho, zero.copy(), rho]
 
 
 class ShallowWaterTest2:

@@ -89,6 +89,7 @@ def load_library():
     lib.tmx_upload_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
+    lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     _lib = lib
@@ -198,6 +199,12 @@ class Engine:
                     keep.append(a)
                     setattr(pg, nm, _pd(a))
                 self._chk(self.lib.tmx_set_patch_geometry(self.h, P.index, C.byref(pg)))
+                # Rayleigh friction (Grid::HasRayleighFriction): strength and reference state
+                if not self.shallow_water and getattr(g, "has_rayleigh_friction", False) and "rayleigh_node" in P.geom:
+                    fr = [np.ascontiguousarray(P.geom[nm], dtype=np.float64) for nm in
+                          ("rayleigh_node", "rayleigh_redge", "ref_node", "ref_redge")]
+                    keep += fr
+                    self._chk(self.lib.tmx_set_patch_rayleigh(self.h, P.index, *[_pd(a) for a in fr]))
                 # closed form of the 3-D metric, where the grid knows its factors (reference:
                 # GridPatchCSGLL::m_dXNode/m_dYNode, GetTopographyDeriv, Grid::GetREtaLevels/Interfaces)
                 if (not self.shallow_water and getattr(P, "X", None) is not None

@@ -11,6 +11,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
+  percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
 """
@@ -62,7 +63,7 @@ def save(name, rec):
 def main():
     tmp = "/tmp/tmx_golden.tmxd"
     drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge",
-            "ref_node", "ref_redge", "a_nodes", "b_nodes")
+            "a_nodes", "b_nodes")
     d, _ = run(["--mode", "percall", "--ne", "3", "--levels", "5", "--dt", "300", "--warm", "2"], tmp)
     d = {k: v for k, v in d.items() if k.split("/")[-1] not in drop and not k.startswith("state/initial")}
     save("percall_ne3_L5_p6.npz", d)
@@ -112,6 +113,17 @@ def main():
     cs = compact_states(d, 6)
     rec.update({k: v for k, v in cs.items() if k.split("/")[1] in ("warm", "step100")})
     save("steps100_ne4_L10_p6.npz", rec)
+
+    # Rayleigh friction.  Schar mountain on the reduced-radius sphere (the stock cubed-sphere test whose
+    # Rayleigh strength is not identically zero), per-call chain (StepAfterSubCycle applies the friction) and 3 steps
+    d, _ = run(["--case", "schar", "--mode", "percall", "--ne", "3", "--levels", "6", "--dt", "0.5", "--warm", "2"], tmp)
+    d = {k: v for k, v in d.items() if k.split("/")[-1] not in drop and not k.startswith("state/initial")}
+    save("percall_schar_ne3_L6_p6.npz", d)
+    d, _ = run(["--case", "schar", "--mode", "steps", "--ne", "3", "--levels", "6", "--dt", "0.5", "--steps", "3",
+                "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    rec.update(compact_states(d, 6))
+    save("steps_schar_ne3_L6_p6.npz", rec)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

@@ -1,7 +1,7 @@
 """Helpers shared by the parity tests: fixture loading and grid construction."""
 import os
 import numpy as np
-from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
+from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW, ScharMountainSphere
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ARS343_GAMMA = 0.4358665215084590
@@ -12,19 +12,22 @@ def load(name):
     return {k.replace("__", "/"): z[k] for k in z.files}
 
 
-def make_grid(ne, L, npatch, ztop=30000.0, pert="exp"):
+def make_grid(ne, L, npatch, ztop=30000.0, pert="exp", case="jw"):
+    """case: "jw" Jablonowski-Williamson baroclinic wave, "schar" Schar mountain on the reduced-radius sphere
+    (Rayleigh layer; ScharMountainSphereTest.cpp defaults)."""
     ppd = int(round((npatch / 6) ** 0.5))
     g = CubedSphereGrid(ne, L, ztop, ppd=ppd)
-    states = g.evaluate_test_case(BaroclinicWaveJW(0.0, ztop, pert))
+    test = BaroclinicWaveJW(0.0, ztop, pert) if case == "jw" else ScharMountainSphere(ztop=ztop)
+    states = g.evaluate_test_case(test)
     return g, states
 
 
-def grid_from_fixture(d, override=True):
+def grid_from_fixture(d, override=True, case="jw"):
     """Grid for a fixture; with ``override`` the geometry / operator arrays are replaced by the
     reference's own (bit-identical inputs for per-call parity)."""
     ne = int(d["cfg/ne"][0]); L = int(d["cfg/levels"][0]); npatch = int(d["cfg/npatch"][0])
     ztop = float(d["grid/ztop"][0]) if "grid/ztop" in d else 30000.0
-    g, states = make_grid(ne, L, npatch, ztop)
+    g, states = make_grid(ne, L, npatch, ztop, case=case)
     if override:
         for P in g.patches:
             for nm in list(P.geom):

@@ -26,7 +26,8 @@ class OrcPatch(C.Structure):
                 ("g", PD * len(G_NAMES)),
                 ("nhalo", C.c_int),
                 ("hi", PI), ("hj", PI), ("hsp", PI), ("hsi", PI), ("hsj", PI), ("hspanel", PI),
-                ("htrans", PD)]
+                ("htrans", PD),
+                ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD)]
 
 
 class OrcGrid(C.Structure):
@@ -119,6 +120,12 @@ class Oracle:
             t = np.ascontiguousarray(h["trans"], dtype=np.float64)
             self._keep.append(t)
             cp.htrans = _pd(t)
+            # Rayleigh friction: strength + reference state, when the grid's test case defines them
+            if getattr(grid, "has_rayleigh_friction", False) and "rayleigh_node" in P.geom:
+                for fld in ("rayleigh_node", "rayleigh_redge", "ref_node", "ref_redge"):
+                    a = np.ascontiguousarray(P.geom[fld], dtype=np.float64)
+                    self._keep.append(a)
+                    setattr(cp, {"rayleigh_node": "ray_node", "rayleigh_redge": "ray_redge"}.get(fld, fld), _pd(a))
         g.patches = self.cpatches
         g.shallow_water = 1 if self.shallow_water else 0
         self.cgrid = g

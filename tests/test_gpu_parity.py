@@ -11,12 +11,17 @@ TOL_STEPS = 1e-10     # north-star tolerance for multi-step state differences
 TOL_W_NE15 = 5e-10    # W after 100 steps at ne15 L30: see test_hundred_steps_ne15_L30
 
 
-@pytest.fixture(scope="module")
-def percall():
+@pytest.fixture(scope="module", params=["jw", "schar"])
+def percall(request):
+    """jw: baroclinic wave; schar: Schar mountain on the reduced-radius sphere with a Rayleigh layer (row H7)."""
     from tempestmodel_amd.engine import Engine
     from oracle_lib import Oracle
-    d = gu.load("percall_ne3_L5_p6.npz")
-    g, _ = gu.grid_from_fixture(d, override=True)
+    if request.param == "jw":
+        d = gu.load("percall_ne3_L5_p6.npz")
+        g, _ = gu.grid_from_fixture(d, override=True)
+    else:
+        d = gu.load("percall_schar_ne3_L6_p6.npz")
+        g, _ = gu.grid_from_fixture(d, override=True, case="schar")
     e = Engine(g)
     o = Oracle(g)
     yield d, g, e, o
@@ -91,12 +96,13 @@ def test_error_behaviour(percall):
 @pytest.mark.parametrize("fixture,ne,L,npatch,dt,tags", [
     ("steps_ne4_L6_p24.npz", 4, 6, 24, 200.0, ["step1", "step2", "step3"]),
     ("steps_ne3_L5_p6.npz", 3, 5, 6, 300.0, ["step1", "step2", "step5", "step10"]),
+    ("steps_schar_ne3_L6_p6.npz", 3, 6, 6, 0.5, ["step1", "step2", "step3"]),
 ])
 def test_ars343_steps_vs_reference_and_oracle(fixture, ne, L, npatch, dt, tags):
     from tempestmodel_amd.engine import Engine
     from oracle_lib import Oracle
     d = gu.load(fixture)
-    g, _ = gu.make_grid(ne, L, npatch)
+    g, _ = gu.make_grid(ne, L, npatch, case="schar" if "schar" in fixture else "jw")
     start = gu.expand_compact(d, tags[0], g)
     o = Oracle(g); o.set_state(0, start)
     e = Engine(g); e.upload_state(0, start)

@@ -10,10 +10,17 @@ import golden_util as gu
 from oracle_lib import Oracle, dgbsv
 
 
-@pytest.fixture(scope="module")
-def percall():
-    d = gu.load("percall_ne3_L5_p6.npz")
-    g, _ = gu.grid_from_fixture(d, override=True)
+@pytest.fixture(scope="module", params=["jw", "schar"])
+def percall(request):
+    """jw: baroclinic wave (ne3 L5); schar: Schar mountain on the reduced-radius sphere with a Rayleigh layer
+    (ne3 L6; SURVEY row H7 -- StepAfterSubCycle ends with ApplyRayleighFriction there)."""
+    if request.param == "jw":
+        d = gu.load("percall_ne3_L5_p6.npz")
+        g, _ = gu.grid_from_fixture(d, override=True)
+    else:
+        d = gu.load("percall_schar_ne3_L6_p6.npz")
+        g, _ = gu.grid_from_fixture(d, override=True, case="schar")
+        assert g.has_rayleigh_friction and float(np.max(g.patches[0].geom["rayleigh_node"])) > 0.0
     return d, g
 
 
@@ -65,13 +72,14 @@ def test_dss_fills_halo_like_exchange(percall):
 @pytest.mark.parametrize("fixture,ne,L,npatch,dt,tags", [
     ("steps_ne4_L6_p24.npz", 4, 6, 24, 200.0, ["step1", "step2", "step3"]),
     ("steps_ne3_L5_p6.npz", 3, 5, 6, 300.0, ["step1", "step2", "step5", "step10"]),
+    ("steps_schar_ne3_L6_p6.npz", 3, 6, 6, 0.5, ["step1", "step2", "step3"]),
 ])
 def test_ars343_steps_from_developed_state(fixture, ne, L, npatch, dt, tags):
     """Full IMEX steps.  Started from the reference's state after step 1: the very first step from the
     analytically balanced initial state is excluded because sign(xi_dot ~ rounding noise) makes the
     reference itself discontinuous there ('first-step sensitivity')."""
     d = gu.load(fixture)
-    g, _ = gu.make_grid(ne, L, npatch)
+    g, _ = gu.make_grid(ne, L, npatch, case="schar" if "schar" in fixture else "jw")
     o = Oracle(g)
     o.set_state(0, gu.expand_compact(d, tags[0], g))
     step = int(tags[0][4:])
