@@ -135,6 +135,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
+	if (const char * m = getenv("TMX_VI_PAIR")) e->vi_pair = (atoi(m) != 0) ? 1 : 0;
 	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
 	if (!plan_only(e)) {
 		int ndev = 0;

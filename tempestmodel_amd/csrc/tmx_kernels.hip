@@ -1336,6 +1336,57 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	b[4] = inb;
 }
 
+// Back substitution (dtbsv order) over the U rows and transformed right-hand side the elimination left in the
+// HBM scratch, result x0 - delta scattered to the column and its in-patch duplicates.  Rows are consumed three per
+// loop trip from three register sets; the loads that refill a set are issued right after it is consumed, i.e.
+// three rows (one trip) ahead of their use, without register-to-register rotation (which would force the wait
+// into the same trip).  n = 3(L+1) is a multiple of 3.
+__device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int u, int col, int NUS,
+	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, double * xup,
+	const int * __restrict__ udep, const int * umask)
+{
+	int dep[3];
+#pragma unroll
+	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	double xw[TMX_BW - 1];
+#pragma unroll
+	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
+	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc, xa, xb, xc;
+	// slab of matrix row `row` (level k, component c); the unused level-L slots of rho*theta / rho map to -1
+#define ROW_SLAB(row) (((row) % TMX_FTOT) == 1 ? TMX_SLAB_W(L, (row) / TMX_FTOT) : \
+		(((row) / TMX_FTOT) == L ? -1 : (((row) % TMX_FTOT) == 0 ? TMX_SLAB_T(L, (row) / TMX_FTOT) : TMX_SLAB_R(L, (row) / TMX_FTOT))))
+#define LOAD_UROW(dst, ydst, xdst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
+		const int mk_ = __builtin_amdgcn_readfirstlane(umask[rr_]); \
+		_Pragma("unroll") for (int c = 0; c < 4; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
+		_Pragma("unroll") for (int c = 4; c < TMX_BW; c++) dst[c] = (mk_ & (1 << c)) ? AB[((size_t)rr_ * TMX_BW + c) * NUS + u] : 0.0; \
+		ydst = RHS[(size_t)rr_ * NUS + u]; \
+		const int sl_ = ROW_SLAB(rr_); xdst = (sl_ >= 0) ? xin[(size_t)sl_ * NS + col] : 0.0; } while (0)
+#define BACK_ROW(ur, yr, x0r, row) do { \
+		double acc = yr; \
+		_Pragma("unroll") for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c]; \
+		const double xr = acc / ur[0]; \
+		_Pragma("unroll") for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1]; \
+		xw[0] = xr; \
+		const int slab = ROW_SLAB(row); \
+		if (slab >= 0) { \
+			const double val = x0r - xr; \
+			xup[(size_t)slab * NS + col] = val; \
+			_Pragma("unroll") for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val; \
+		} } while (0)
+	LOAD_UROW(ua, ya, xa, n - 1); LOAD_UROW(ub, yb, xb, n - 2); LOAD_UROW(uc, yc, xc, n - 3);
+	for (int r = n - 1; r >= 2; r -= 3) {
+		BACK_ROW(ua, ya, xa, r);
+		LOAD_UROW(ua, ya, xa, r - 3);
+		BACK_ROW(ub, yb, xb, r - 1);
+		LOAD_UROW(ub, yb, xb, r - 4);
+		BACK_ROW(uc, yc, xc, r - 2);
+		LOAD_UROW(uc, yc, xc, r - 5);
+	}
+#undef ROW_SLAB
+#undef LOAD_UROW
+#undef BACK_ROW
+}
+
 template <bool CARRY, bool SPARSE, bool CLOSED>
 __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
@@ -1424,50 +1475,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	}
 	if (singular) atomicExch(flag, 1);
 
-	// back substitution (dtbsv order).  Rows are consumed three per loop trip from three register
-	// sets; the loads that refill a set are issued right after it is consumed, i.e. three rows
-	// (one trip) ahead of their use, without register-to-register rotation (which would force the
-	// wait into the same trip).  n = 3(L+1) is a multiple of 3.
-	int dep[3];
-#pragma unroll
-	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
-	double xw[TMX_BW - 1];
-#pragma unroll
-	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
-	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc, xa, xb, xc;
-	// slab of matrix row `row` (level k, component c); the unused level-L slots of rho*theta / rho map to -1
-#define ROW_SLAB(row) (((row) % TMX_FTOT) == 1 ? TMX_SLAB_W(L, (row) / TMX_FTOT) : \
-		(((row) / TMX_FTOT) == L ? -1 : (((row) % TMX_FTOT) == 0 ? TMX_SLAB_T(L, (row) / TMX_FTOT) : TMX_SLAB_R(L, (row) / TMX_FTOT))))
-#define LOAD_UROW(dst, ydst, xdst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
-		const int mk_ = __builtin_amdgcn_readfirstlane(umask[rr_]); \
-		_Pragma("unroll") for (int c = 0; c < 4; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
-		_Pragma("unroll") for (int c = 4; c < TMX_BW; c++) dst[c] = (mk_ & (1 << c)) ? AB[((size_t)rr_ * TMX_BW + c) * NUS + u] : 0.0; \
-		ydst = RHS[(size_t)rr_ * NUS + u]; \
-		const int sl_ = ROW_SLAB(rr_); xdst = (sl_ >= 0) ? xin[(size_t)sl_ * NS + col] : 0.0; } while (0)
-#define BACK_ROW(ur, yr, x0r, row) do { \
-		double acc = yr; \
-		_Pragma("unroll") for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c]; \
-		const double xr = acc / ur[0]; \
-		_Pragma("unroll") for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1]; \
-		xw[0] = xr; \
-		const int slab = ROW_SLAB(row); \
-		if (slab >= 0) { \
-			const double val = x0r - xr; \
-			xup[(size_t)slab * NS + col] = val; \
-			_Pragma("unroll") for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val; \
-		} } while (0)
-	LOAD_UROW(ua, ya, xa, n - 1); LOAD_UROW(ub, yb, xb, n - 2); LOAD_UROW(uc, yc, xc, n - 3);
-	for (int r = n - 1; r >= 2; r -= 3) {
-		BACK_ROW(ua, ya, xa, r);
-		LOAD_UROW(ua, ya, xa, r - 3);
-		BACK_ROW(ub, yb, xb, r - 1);
-		LOAD_UROW(ub, yb, xb, r - 4);
-		BACK_ROW(uc, yc, xc, r - 2);
-		LOAD_UROW(uc, yc, xc, r - 5);
-	}
-#undef ROW_SLAB
-#undef LOAD_UROW
-#undef BACK_ROW
+	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask);
 #ifdef TMX_VI_TIMING
 	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 7))
 		printf("vi timing block %d: forward loop %lld cycles (assembly %lld, LU %lld), total incl. back substitution %lld\n",
@@ -1475,10 +1483,138 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 #endif
 }
 
+// Two-wavefront variant of k_vi_fused: the block rows of a column are independent of one another, only the
+// elimination is sequential.  Wavefront 0 of the workgroup assembles block row t (compute_block, the same code)
+// into a double-buffered LDS ring while wavefront 1 runs the three pivot steps of block row t-1; one barrier
+// per block row.  The dependent chain of a column shrinks from assembly + LU to max(assembly, LU) per level
+// (cycle counts in DESIGN.md), which is what bounds the kernel on small per-GPU grids.  Same statements on the
+// same operands: bit-identical to k_vi_fused.
+template <bool SPARSE, bool CLOSED, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
+	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
+{
+	extern __shared__ double opsl_mem[];
+	double * opsl = opsl_mem;
+	const int L = p.L;
+	constexpr int MM = CLOSED ? 1 : 2;
+	constexpr int NQ = 3 * TMX_BW + 3;                                       // doubles per block row and column
+	double * etal = opsl_mem + TMX_OP_COUNT * (L + 1) * TMX_OPW;             // [2L+1]
+	// PAIRS producer/consumer pairs per workgroup (2 pairs = 4 wavefronts = one per SIMD of a CU)
+	const int lane = threadIdx.x, wv = WAVE_UNIFORM(threadIdx.y), role = wv & 1, pair = wv >> 1;
+	double * ring = etal + 2 * L + 1 + (size_t)pair * 2 * NQ * 64;           // [PAIRS][2][NQ][64]
+	int * umask = (int *)(etal + 2 * L + 1 + (size_t)PAIRS * 2 * NQ * 64) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
+	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128 * PAIRS) opsl[t] = p.ops[t];
+	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += 128 * PAIRS) etal[t] = p.eta[t];
+	__syncthreads();
+	const size_t NS = (size_t)p.NS;
+	const int u = (blockIdx.x * PAIRS + pair) * 64 + lane;
+	if (u >= nunique) return;          // both wavefronts drop the same lanes; each keeps at least one
+	const int n = TMX_FTOT * (L + 1);
+	const int col = ucol[u];
+
+	if (role == 0) {
+		// ---- producer: assemble block rows 0..L ----
+		ColConst cc;
+		cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+		cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+		cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+		const MetCol mcol = met_col(p, col);
+		NodeLev nA, nB = load_node<MM>(p, mcol, xin, -1, col, etal), nC = load_node<MM>(p, mcol, xin, 0, col, etal);
+		EdgeLev eA, eB = load_edge<MM>(p, mcol, xin, -1, col, etal), eC = load_edge<MM>(p, mcol, xin, 0, col, etal);
+		NodeLev nN = load_node<MM>(p, mcol, xin, 1, col, etal);
+		EdgeLev eN = load_edge<MM>(p, mcol, xin, 1, col, etal);
+		BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+		for (int t = 0; t <= L + 1; t++) {
+			if (t <= L) {
+				nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
+				nN = load_node<MM>(p, mcol, xin, t + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 2, col, etal);
+				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
+				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
+#pragma unroll
+				for (int c = 0; c < TMX_BW; c++) { q[c * 64] = rP[c]; q[(TMX_BW + c) * 64] = rW[c]; q[(2 * TMX_BW + c) * 64] = rR[c]; }
+				q[(3 * TMX_BW) * 64] = fP; q[(3 * TMX_BW + 1) * 64] = fW; q[(3 * TMX_BW + 2) * 64] = fR;
+			}
+			__syncthreads();
+		}
+		return;
+	}
+
+	// ---- consumer: pivoted band elimination on the 5x9 register window ----
+	double R[5][TMX_BW], b[5];
+	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP = 0.0, fW = 0.0, fR = 0.0;
+	bool singular = false;
+#pragma unroll
+	for (int r = 0; r < 5; r++) {
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) R[r][c] = 0.0;
+		b[r] = 0.0;
+	}
+	for (int t = 0; t <= L + 1; t++) {
+		if (t >= 1) {
+			const int m = t - 1;
+			const double * q = ring + (size_t)(m & 1) * NQ * 64 + lane;
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) { rP[c] = q[c * 64]; rW[c] = q[(TMX_BW + c) * 64]; rR[c] = q[(2 * TMX_BW + c) * 64]; }
+			fP = q[(3 * TMX_BW) * 64]; fW = q[(3 * TMX_BW + 1) * 64]; fR = q[(3 * TMX_BW + 2) * 64];
+			if (m == 0) {
+				// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
+#pragma unroll
+				for (int c = 0; c < TMX_BW; c++) {
+					R[0][c] = (c + 4 < TMX_BW) ? rP[c + 4] : 0.0;
+					R[1][c] = (c + 3 < TMX_BW) ? rW[c + 3] : 0.0;
+					R[2][c] = (c + 2 < TMX_BW) ? rR[c + 2] : 0.0;
+				}
+				b[0] = fP; b[1] = fW; b[2] = fR;
+			} else if (m == 1) {
+#pragma unroll
+				for (int c = 0; c < TMX_BW; c++) {
+					R[3][c] = (c + 1 < TMX_BW) ? rP[c + 1] : 0.0;
+					R[4][c] = rW[c];
+				}
+				b[3] = fP; b[4] = fW;
+				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 0, NUS, u, rR, fR, umask);      // pivot 0 takes in row 5
+			} else {
+				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
+				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
+				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+			}
+		}
+		__syncthreads();
+	}
+	{
+		double z[TMX_BW];
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
+		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
+	}
+	if (singular) atomicExch(flag, 1);
+	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask);
+}
+
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nunique == 0) return;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
+	// The pair kernel shortens the per-column dependent chain (134 vs 166 us on a small grid) but needs every
+	// wavefront alone on its SIMD: two pairs per workgroup = one workgroup per CU.  Measured: 137-140 us up to 211
+	// workgroups, 273 us from 243 on (the dispatcher then doubles up on some CUs while others idle), where the
+	// one-wavefront kernel takes 186 us.  So it is used below 200 workgroups -- i.e. on the per-GPU share of the
+	// ne30 grid from 2 GPUs up -- and the one-wavefront kernel above.
+	const int ngrp = (e->nunique + 63) / 64;
+	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry && (ngrp + 1) / 2 <= 200);
+	if (use_pair) {
+		const size_t lds2 = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) +
+			2 * ((size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int));
+		if (p.closed)
+			hipLaunchKernelGGL((k_vi_pair<true, true, 2>), dim3((ngrp + 1) / 2), dim3(64, 4), lds2, e->stream, p, xin, xup, dt,
+				e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+		else
+			hipLaunchKernelGGL((k_vi_pair<true, false, 2>), dim3((ngrp + 1) / 2), dim3(64, 4), lds2, e->stream, p, xin, xup, dt,
+				e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+		return;
+	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, true>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
 			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \

@@ -218,27 +218,29 @@ def test_hundred_steps_ne15_L30():
         e.close()
 
 
-def test_fused_column_kernel_is_bit_identical_to_split_kernels():
-    """k_vi_fused (production) and k_vi_assemble + k_vi_solve (TMX_VI_MODE=split) perform the same
-    arithmetic: results are bit-identical."""
+def test_fused_column_kernels_are_bit_identical_to_split_kernels():
+    """k_vi_fused (one wavefront per 64 columns), k_vi_pair (assembly and elimination in two wavefronts; what small
+    per-GPU grids run) and k_vi_assemble + k_vi_solve (TMX_VI_MODE=split) perform the same arithmetic:
+    results are bit-identical."""
     import os
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps_ne4_L6_p24.npz")
     g, _ = gu.make_grid(4, 6, 24)
     start = gu.expand_compact(d, "step2", g)
     out = []
-    for mode in ("fused", "split"):
-        os.environ["TMX_VI_MODE"] = mode
+    for env in ({"TMX_VI_PAIR": "0"}, {"TMX_VI_PAIR": "1"}, {"TMX_VI_MODE": "split"}, {"TMX_VI_PAIR": "0", "TMX_VI_SPARSE": "0"}):
+        os.environ.update(env)
         try:
             e = Engine(g)
+            e.upload_state(1, start)
+            e.copy_data(1, 2)
+            e.v_step_implicit(1, 2, 87.0)
+            e.sync()
+            out.append(e.download_state(2))
+            e.close()
         finally:
-            os.environ.pop("TMX_VI_MODE", None)
-        e.upload_state(1, start)
-        e.copy_data(1, 2)
-        e.v_step_implicit(1, 2, 87.0)
-        e.sync()
-        out.append(e.download_state(2))
-        e.close()
+            for k in env:
+                os.environ.pop(k, None)
     for other in out[1:]:
         for (an, ae), (bn, be) in zip(out[0], other):
             assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
