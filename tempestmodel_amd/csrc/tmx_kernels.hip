@@ -32,6 +32,31 @@ struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 // offsets to scalar loads / SALU and frees the vector registers they occupied.
 #define WAVE_UNIFORM(v) __builtin_amdgcn_readfirstlane((int)(v))
 
+// Addressing: every global access here is  base pointer + (wave-uniform slab offset) + (lane's column).  Written
+// as (uniform 64-bit pointer) + (32-bit per-lane BYTE offset) it maps onto the saddr form of global_load /
+// global_store -- one 32-bit VGPR offset shared by all accesses of a thread instead of a 64-bit VGPR address
+// (2 registers + a v_lshl_add_u64) per access.  An instance is 104 MB at ne30 L30; a slab row (NS columns) must
+// stay below 4 GiB of bytes, checked at finalize.
+__device__ __forceinline__ double ldu(const double * uniform_base, unsigned lane_byte_off) {
+	return *(const double *)((const char *)uniform_base + lane_byte_off);
+}
+__device__ __forceinline__ void stu(double * uniform_base, unsigned lane_byte_off, double v) {
+	*(double *)((char *)uniform_base + lane_byte_off) = v;
+}
+
+// base_value with the slab offset (uniform, in doubles) and the lane's byte offset kept apart
+template <int NT>
+__device__ __forceinline__ double base_value_u(const LinTerms & t, size_t slab_off, unsigned colb) {
+	if (NT == 0) return ldu(t.src[0] + slab_off, colb);
+	double x[NT > 0 ? NT : 1];
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(t.src[m] + slab_off, colb) : 0.0;
+	double v = t.premul ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
+	return v;
+}
+
 template <int NT>
 __device__ __forceinline__ double base_value(const LinTerms & t, size_t o) {
 	if (NT == 0) return t.src[0][o];
@@ -139,18 +164,25 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
 	double conUa = 0, conUb = 0, conUx = 0, dxua = 0, dxub = 0;
 	double v_uam = 0, v_uap = 0, v_ubm = 0, v_ubp = 0, w_hi = 0, w_lo = 0;
+	// base of the update (a plain instance or the fused stage combination): loaded in the same burst as the state
+	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
+	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
+	double bU = 0, bV = 0, bT = 0, bR = 0;
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
-		ua = xin[TMX_SLAB_U(L, k) * NS + col];
-		ub = xin[TMX_SLAB_V(L, k) * NS + col];
-		rt = xin[TMX_SLAB_T(L, k) * NS + col];
-		rh = xin[TMX_SLAB_R(L, k) * NS + col];
-		const double we0 = xin[TMX_SLAB_W(L, k) * NS + col];
-		const double we1 = xin[TMX_SLAB_W(L, k + 1) * NS + col];
-		const double uam = xin[TMX_SLAB_U(L, km) * NS + col], uap = xin[TMX_SLAB_U(L, kp) * NS + col];
-		const double ubm = xin[TMX_SLAB_V(L, km) * NS + col], ubp = xin[TMX_SLAB_V(L, kp) * NS + col];
-		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
-		jn = p.g2d[G2_JN * NS + col]; j2d = p.g2d[G2_J2D * NS + col]; fcor = p.g2d[G2_F * NS + col];
+		const unsigned cb = (unsigned)col * 8u;
+		ua = ldu(xin + TMX_SLAB_U(L, k) * NS, cb);
+		ub = ldu(xin + TMX_SLAB_V(L, k) * NS, cb);
+		rt = ldu(xin + TMX_SLAB_T(L, k) * NS, cb);
+		rh = ldu(xin + TMX_SLAB_R(L, k) * NS, cb);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * NS, cb);
+		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * NS, cb);
+		const double uam = ldu(xin + TMX_SLAB_U(L, km) * NS, cb), uap = ldu(xin + TMX_SLAB_U(L, kp) * NS, cb);
+		const double ubm = ldu(xin + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xin + TMX_SLAB_V(L, kp) * NS, cb);
+		bU = base_value_u<NT>(xbase, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_u<NT>(xbase, TMX_SLAB_V(L, k) * NS, cb);
+		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * NS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * NS, cb);
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		jn = ldu(p.g2d + G2_JN * NS, cb); j2d = ldu(p.g2d + G2_J2D * NS, cb); fcor = ldu(p.g2d + G2_F * NS, cb);
 		const MetCol mc = met_col(p, col);
 		metric_node(p, mc, k, col, ca2, cb2, cx2, dra, drb);
 		// W on levels (InterpolateREdgeToNode, GridPatchGLL.cpp:111-143)
@@ -195,6 +227,9 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	s[ty][7][lane] = fb * rh; s[ty][8][lane] = fb * rt;
 	__syncthreads();
 	if (!act) return;
+#ifdef TMX_H_SCHED_BARRIER
+	__builtin_amdgcn_sched_barrier(0);
+#endif
 
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
 	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
@@ -242,12 +277,12 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	const double daphi = p.grav * dra, dbphi = p.grav * drb;
 	upa -= (pgfa + dake + daphi);
 	upb -= (pgfb + dbke + dbphi);
-	const size_t oU = TMX_SLAB_U(L, k) * NS + col, oV = TMX_SLAB_V(L, k) * NS + col;
-	const size_t oT = TMX_SLAB_T(L, k) * NS + col, oR = TMX_SLAB_R(L, k) * NS + col;
+	const size_t sU = TMX_SLAB_U(L, k) * NS, sV = TMX_SLAB_V(L, k) * NS, sT = TMX_SLAB_T(L, k) * NS, sR = TMX_SLAB_R(L, k) * NS;
+	const unsigned colb = (unsigned)col * 8u;
 	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
 	// instance when the preceding CopyData(initial -> update) is fused away
-	double outU = base_value<NT>(xbase, oU) + dt * upa;
-	double outV = base_value<NT>(xbase, oV) + dt * upb;
+	double outU = bU + dt * upa;
+	double outV = bV + dt * upb;
 	if (FUSE_V) {
 		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
 		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
@@ -268,11 +303,11 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 			outV += b * w_lo;
 		}
 	}
-	xup[oU] = outU;
-	xup[oV] = outV;
-	xup[oR] = base_value<NT>(xbase, oR) - dt * invJ * (darf + dbrf);
-	xup[oT] = base_value<NT>(xbase, oT) - dt * invJ * (dapf + dbpf);
-	ucz[(size_t)k * NS + col] = uczx;
+	stu(xup + sU, colb, outU);
+	stu(xup + sV, colb, outV);
+	stu(xup + sR, colb, bR - dt * invJ * (darf + dbrf));
+	stu(xup + sT, colb, bT - dt * invJ * (dapf + dbpf));
+	stu(ucz + (size_t)k * NS, colb, uczx);
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
