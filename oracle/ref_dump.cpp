@@ -27,6 +27,37 @@
 #include "ScharMountainSphereTest.cpp"
 #undef main
 
+// Test INPUT of our own (not path code): the reference's Jablonowski-Williamson state plus closed-form tracer
+// densities, so that the reference's tracer transport can be driven and dumped -- no stock
+// cubed-sphere test enables tracers without Fortran physics.  tempestmodel_amd/cubed_sphere.py mirrors the formulas.
+class JWWithTracers : public BaroclinicWaveJWTest {
+public:
+	JWWithTracers(double dAlpha, double dZtop, PerturbationType e, int nTracers) :
+		BaroclinicWaveJWTest(dAlpha, dZtop, e), m_nTracers(nTracers) { }
+	virtual int GetTracerCount() const { return m_nTracers; }
+	virtual void EvaluateReferenceState(const PhysicalConstants & phys, double dZ, double dLon, double dLat,
+		double * dState, double * dTracer) const {
+		BaroclinicWaveJWTest::EvaluateReferenceState(phys, dZ, dLon, dLat, dState);
+		for (int c = 0; c < m_nTracers; c++) dTracer[c] = 0.0;
+	}
+	virtual void EvaluatePointwiseState(const PhysicalConstants & phys, const Time & time, double dZ, double dLon,
+		double dLat, double * dState, double * dTracer) const {
+		BaroclinicWaveJWTest::EvaluatePointwiseState(phys, time, dZ, dLon, dLat, dState, dTracer);
+		const double dRho = dState[4];
+		// tracer 0: smooth, strictly positive mixing ratio
+		if (m_nTracers > 0) dTracer[0] = dRho * (0.5 * (1.0 + sin(dLat) * cos(dLon)) * exp(-dZ / 8000.0) + 0.01);
+		// tracer 1: compact cosine bell below 12 km, exactly zero elsewhere (undershoots -> the filters act)
+		if (m_nTracers > 1) {
+			double dR = acos(sin(0.6) * sin(dLat) + cos(0.6) * cos(dLat) * cos(dLon - 0.9)) / 0.5;
+			double dQ = (dR < 1.0 && dZ < 12000.0) ? 0.5 * (1.0 + cos(M_PI * dR)) : 0.0;
+			dTracer[1] = dRho * dQ;
+		}
+		for (int c = 2; c < m_nTracers; c++) dTracer[c] = dRho * 0.001 * (c + 1);
+	}
+private:
+	int m_nTracers;
+};
+
 #include "GridPatchGLL.h"
 #include "GridPatchCSGLL.h"
 #include "CubedSphereTrans.h"
@@ -105,6 +136,8 @@ static void dumpState(TmxdWriter & w, GridGLL * pGrid, const std::string & tag, 
 		int p = pPatch->GetPatchIndex();
 		dump4(w, "state/" + tag + "/" + pname(p) + "node", pPatch->GetDataState(ix, DataLocation_Node));
 		dump4(w, "state/" + tag + "/" + pname(p) + "redge", pPatch->GetDataState(ix, DataLocation_REdge));
+		if (pPatch->GetDataTracers(ix).GetSize(0) > 0)
+			dump4(w, "state/" + tag + "/" + pname(p) + "tracers", pPatch->GetDataTracers(ix));
 	}
 }
 
@@ -247,7 +280,7 @@ int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 
 	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp", tcase = "jw";
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1;
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0;
 	double dt = 200.0, ztop = 30000.0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -264,6 +297,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--patches") { npatch = atoi(v); i++; }
 		else if (a == "--geom") { geom = atoi(v); i++; }
 		else if (a == "--every") { every = atoi(v); i++; }
+		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--ztop") { ztop = atof(v); i++; }
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
@@ -274,7 +308,14 @@ try {
 
 	const bool fSW = (tcase == "sw2");
 	if (fSW) { levels = 1; }
-	Model model(fSW ? EquationSet::ShallowWaterEquations : EquationSet::PrimitiveNonhydrostaticEquations);
+	// tracers are declared on the EquationSet before the Model exists (as test/dcmip2016/SupercellTest.cpp:271-281 does)
+	EquationSet eqn(fSW ? EquationSet::ShallowWaterEquations : EquationSet::PrimitiveNonhydrostaticEquations);
+	for (int c = 0; c < ntracers; c++) {
+		char nm[16]; snprintf(nm, 16, "RhoQ%d", c);
+		eqn.InsertTracer(nm, nm);
+	}
+	UserDataMeta metaUserData;
+	Model model(eqn, metaUserData);
 
 	int isec = (int)dt;
 	int iusec = (int)((dt - isec) * 1.0e6 + 0.5);
@@ -316,6 +357,8 @@ try {
 		// ScharMountainSphereTest.cpp defaults (:417-441): reduced planet X = 500, no rotation, Rayleigh layer above 20 km
 		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
 		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
+	} else if (ntracers > 0) {
+		model.SetTestCase(new JWWithTracers(0.0, ztop, ePert, ntracers));
 	} else {
 		model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, ePert));
 	}
@@ -330,6 +373,7 @@ try {
 	w.iscalar("cfg/levels", levels);
 	w.iscalar("cfg/npatch", pGrid->GetActivePatchCount());
 	w.iscalar("cfg/ninstances", model.GetComponentDataInstances());
+	w.iscalar("cfg/ntracers", ntracers);
 	w.scalar("cfg/dt", dt);
 	if (geom && w.fp) {
 		dumpGeometry(w, model, pGrid);
@@ -356,6 +400,7 @@ try {
 		const double sdt = dt * 0.4358665215084590;
 		// H explicit
 		pGrid->CopyData(0, 1, DataType_State);
+		pGrid->CopyData(0, 1, DataType_Tracers);
 		pH->StepExplicit(0, 1, time, sdt);
 		dumpState(w, pGrid, "h_explicit_in_after", 0);   // input instance after the prologue mutation
 		dumpState(w, pGrid, "h_explicit", 1);
@@ -364,9 +409,11 @@ try {
 		dumpState(w, pGrid, "v_explicit", 1);
 		// DSS
 		pGrid->PostProcessSubstage(1, DataType_State);
+		pGrid->PostProcessSubstage(1, DataType_Tracers);
 		dumpState(w, pGrid, "dss", 1);
 		// V implicit
 		pGrid->CopyData(1, 2, DataType_State);
+		pGrid->CopyData(1, 2, DataType_Tracers);
 		pV->StepImplicit(2, 2, time, sdt);
 		dumpState(w, pGrid, "v_implicit", 2);
 		// hyperviscosity (init 2 -> update 3, work 4)
@@ -377,6 +424,7 @@ try {
 		DataArray1D<double> dCombo(7);
 		dCombo[0] = 0.25; dCombo[1] = -0.5; dCombo[2] = 1.75; dCombo[3] = 0.5;
 		pGrid->LinearCombineData(dCombo, 3, DataType_State);
+		pGrid->LinearCombineData(dCombo, 3, DataType_Tracers);
 		dumpState(w, pGrid, "lincomb", 3);
 
 	} else if (mode == "steps") {

@@ -21,6 +21,8 @@ enum { UIx = 0, VIx = 1, PIx = 2, WIx = 3, RIx = 4 };
 
 static size_t node_size(const orc_grid * g, const orc_patch * p) { return (size_t)5 * p->na * p->nb * g->L; }
 static size_t redge_size(const orc_grid * g, const orc_patch * p) { return (size_t)5 * p->na * p->nb * (g->L + 1); }
+static size_t tracer_size(const orc_grid * g, const orc_patch * p) { return (size_t)g->ntracers * p->na * p->nb * g->L; }
+static int has_tracers(const orc_grid * g, const orc_state * s) { return g->ntracers > 0 && s->tracer != NULL; }
 
 /* banded mat-vec row: out[k] = sum_{l in [b,e)} C[k][l] in[l]  (LinearColumnOperator.h:82-101) */
 static double op_row(const orc_grid * g, int op, const double * in, int k) {
@@ -48,6 +50,7 @@ void orc_copy(const orc_grid * g, orc_state * s, int src, int dst) {
 		const orc_patch * P = &g->patches[p];
 		memcpy(s->node[dst * g->npatch + p], s->node[src * g->npatch + p], node_size(g, P) * sizeof(double));
 		memcpy(s->redge[dst * g->npatch + p], s->redge[src * g->npatch + p], redge_size(g, P) * sizeof(double));
+		if (has_tracers(g, s)) memcpy(s->tracer[dst * g->npatch + p], s->tracer[src * g->npatch + p], tracer_size(g, P) * sizeof(double));
 	}
 }
 
@@ -56,21 +59,22 @@ void orc_zero(const orc_grid * g, orc_state * s, int ix) {
 		const orc_patch * P = &g->patches[p];
 		memset(s->node[ix * g->npatch + p], 0, node_size(g, P) * sizeof(double));
 		memset(s->redge[ix * g->npatch + p], 0, redge_size(g, P) * sizeof(double));
+		if (has_tracers(g, s)) memset(s->tracer[ix * g->npatch + p], 0, tracer_size(g, P) * sizeof(double));
 	}
 }
 
 void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff, int ncoeff, int dst) {
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
-		for (int loc = 0; loc < 2; loc++) {
-			size_t n = loc ? redge_size(g, P) : node_size(g, P);
-			double * d = loc ? s->redge[dst * g->npatch + p] : s->node[dst * g->npatch + p];
+		for (int loc = 0; loc < (has_tracers(g, s) ? 3 : 2); loc++) {
+			size_t n = (loc == 2) ? tracer_size(g, P) : (loc ? redge_size(g, P) : node_size(g, P));
+			double * d = (loc == 2) ? s->tracer[dst * g->npatch + p] : (loc ? s->redge[dst * g->npatch + p] : s->node[dst * g->npatch + p]);
 			/* premultiply the destination by its own coefficient (GridPatch.cpp:1461-1468) */
 			if (coeff[dst] == 0.0) memset(d, 0, n * sizeof(double));
 			else for (size_t i = 0; i < n; i++) d[i] *= coeff[dst];
 			for (int m = 0; m < ncoeff; m++) {
 				if (m == dst || coeff[m] == 0.0) continue;
-				const double * a = loc ? s->redge[m * g->npatch + p] : s->node[m * g->npatch + p];
+				const double * a = (loc == 2) ? s->tracer[m * g->npatch + p] : (loc ? s->redge[m * g->npatch + p] : s->node[m * g->npatch + p]);
 				const double c = coeff[m];
 				for (size_t i = 0; i < n; i++) d[i] += c * a[i];
 			}
@@ -83,6 +87,39 @@ void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff,
 /* (HorizontalDynamicsFEM.cpp:701-1783)                                                        */
 
 static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+
+/* HorizontalDynamicsFEM::FilterNegativeTracers (HorizontalDynamicsFEM.cpp:213-317, POSITIVE_DEFINITE_FILTER_TRACERS,
+ * Defines.h:80): per element, level and tracer clip negatives to zero and rescale the rest to keep the element mass */
+static void filter_negative_tracers_h(const orc_grid * g, orc_state * s, int iupd) {
+	if (!has_tracers(g, s)) return;
+	const int L = g->L;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * t = s->tracer[iupd * g->npatch + p];
+		for (int a = 0; a < P->nea; a++)
+		for (int b = 0; b < P->neb; b++)
+		for (int c = 0; c < g->ntracers; c++)
+		for (int k = 0; k < L; k++) {
+			double total = 0.0, nonneg = 0.0;
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = a * NP + i + 1, iB = b * NP + j + 1;
+				const double q = t[(((size_t)c * na + iA) * nb + iB) * L + k];
+				const double pm = q * P->area_node[((size_t)iA * nb + iB) * L + k];
+				total += pm;
+				if (q >= 0.0) nonneg += pm;
+			}
+			const double r = total / nonneg;
+			for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++) {
+				const int iA = a * NP + i + 1, iB = b * NP + j + 1;
+				double * q = &t[(((size_t)c * na + iA) * nb + iB) * L + k];
+				if (*q > 0.0) *q *= r; else *q = 0.0;
+			}
+		}
+	}
+}
 
 void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	if (g->shallow_water) { sw_step_explicit(g, s, iinit, iupd, dt); return; }
@@ -225,6 +262,35 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 				NU(PIx, iA, iB, k) -= dt * invJ * (dapf + dbpf);
 			}
 
+			/* tracers: flux form with the same mass-flux base J u^a, J u^b (:1090-1100, :1531-1553) */
+			if (has_tracers(g, s)) {
+				const double * tin = s->tracer[iinit * g->npatch + p];
+				double * tup = s->tracer[iupd * g->npatch + p];
+				double taf[NP][NP], tbf[NP][NP];
+				for (int c = 0; c < g->ntracers; c++)
+				for (int k = 0; k < L; k++) {
+					for (int i = 0; i < NP; i++)
+					for (int j = 0; j < NP; j++) {
+						const int iA = eA + i, iB = eB + j;
+						const double q = tin[(((size_t)c * na + iA) * nb + iB) * L + k];
+						taf[i][j] = M3(Jn, iA, iB, k) * AUX(ConUa, i, j, k) * q;
+						tbf[i][j] = M3(Jn, iA, iB, k) * AUX(ConUb, i, j, k) * q;
+					}
+					for (int i = 0; i < NP; i++)
+					for (int j = 0; j < NP; j++) {
+						const int iA = eA + i, iB = eB + j;
+						const double invJ = 1.0 / M3(Jn, iA, iB, k);
+						double da = 0.0, db = 0.0;
+						for (int q = 0; q < NP; q++) {
+							da -= taf[q][j] * S[i * NP + q];
+							db -= tbf[i][q] * S[j * NP + q];
+						}
+						da *= inv_da; db *= inv_da;
+						tup[(((size_t)c * na + iA) * nb + iB) * L + k] -= dt * invJ * (da + db);
+					}
+				}
+			}
+
 			/* (v) W on interfaces (:1612-1659) */
 			for (int i = 0; i < NP; i++)
 			for (int j = 0; j < NP; j++) {
@@ -242,6 +308,7 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 	free(aux); free(fa_r); free(colbuf);
 #undef AUX
 #undef FLX
+	filter_negative_tracers_h(g, s, iupd);      /* HorizontalDynamicsFEM::StepExplicit, :1862 */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -309,6 +376,36 @@ static void avg_b(double * x, int nb, int Lk, int iB, int ib, int ie) {
 	}
 }
 
+static void dss_average_field(const orc_patch * P, double * x, int Lk) {
+	const int na = P->na, nb = P->nb;
+	const int TR = P->neighbor_panels[4], TL = P->neighbor_panels[5];
+	const int BL = P->neighbor_panels[6], BR = P->neighbor_panels[7];
+	int jb, je, ib, ie;
+	for (int a = 1; a < P->nea; a++) avg_a(x, nb, Lk, a * NP + 1, 0, nb);
+	jb = 0; je = nb; if (TL < 0) je -= 2; if (BL < 0) jb += 2;
+	avg_a(x, nb, Lk, 1, jb, je);
+	jb = 0; je = nb; if (TR < 0) je -= 2; if (BR < 0) jb += 2;
+	avg_a(x, nb, Lk, P->nea * NP + 1, jb, je);
+	for (int b = 1; b < P->neb; b++) avg_b(x, nb, Lk, b * NP + 1, 0, na);
+	ib = 0; ie = na; if (BL < 0) ib += 2; if (BR < 0) ie -= 2;
+	avg_b(x, nb, Lk, 1, ib, ie);
+	ib = 0; ie = na; if (TL < 0) ib += 2; if (TR < 0) ie -= 2;
+	avg_b(x, nb, Lk, P->neb * NP + 1, ib, ie);
+#define X3(i,j,k) x[((size_t)(i) * nb + (j)) * Lk + (k)]
+	const double third = 1.0 / 3.0;
+	if (TR < 0) { int iA = na - 2, iB = nb - 2;
+		for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB + 1, k)); }
+	if (TL < 0) { int iA = 1, iB = nb - 2;
+		for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB + 1, k)); }
+	if (BL < 0) { int iA = 1, iB = 1;
+		for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB - 1, k)); }
+	if (BR < 0) { int iA = na - 2, iB = 1;
+		for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB - 1, k)); }
+#undef X3
+}
+
+static void dss_tracers(const orc_grid * g, orc_state * s, int ix);
+
 void orc_apply_dss(const orc_grid * g, orc_state * s, int ix) {
 	const int L = g->L;
 	/* 1. exchange: pack all strips first (sources are interior nodes, never modified by unpacking) */
@@ -368,36 +465,53 @@ void orc_apply_dss(const orc_grid * g, orc_state * s, int ix) {
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
 		const int na = P->na, nb = P->nb;
-		const int TR = P->neighbor_panels[4], TL = P->neighbor_panels[5];
-		const int BL = P->neighbor_panels[6], BR = P->neighbor_panels[7];
 		for (int c = 0; c < 5; c++) {
 			const int Lk = (c == WIx) ? L + 1 : L;
 			double * x = (c == WIx)
 				? s->redge[ix * g->npatch + p] + (size_t)c * na * nb * Lk
 				: s->node[ix * g->npatch + p] + (size_t)c * na * nb * Lk;
-			int jb, je, ib, ie;
-			for (int a = 1; a < P->nea; a++) avg_a(x, nb, Lk, a * NP + 1, 0, nb);
-			jb = 0; je = nb; if (TL < 0) je -= 2; if (BL < 0) jb += 2;
-			avg_a(x, nb, Lk, 1, jb, je);
-			jb = 0; je = nb; if (TR < 0) je -= 2; if (BR < 0) jb += 2;
-			avg_a(x, nb, Lk, P->nea * NP + 1, jb, je);
-			for (int b = 1; b < P->neb; b++) avg_b(x, nb, Lk, b * NP + 1, 0, na);
-			ib = 0; ie = na; if (BL < 0) ib += 2; if (BR < 0) ie -= 2;
-			avg_b(x, nb, Lk, 1, ib, ie);
-			ib = 0; ie = na; if (TL < 0) ib += 2; if (TR < 0) ie -= 2;
-			avg_b(x, nb, Lk, P->neb * NP + 1, ib, ie);
-#define X3(i,j,k) x[((size_t)(i) * nb + (j)) * Lk + (k)]
-			const double third = 1.0 / 3.0;
-			if (TR < 0) { int iA = na - 2, iB = nb - 2;
-				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB + 1, k)); }
-			if (TL < 0) { int iA = 1, iB = nb - 2;
-				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB + 1, k)); }
-			if (BL < 0) { int iA = 1, iB = 1;
-				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA - 1, iB, k) + X3(iA, iB - 1, k)); }
-			if (BR < 0) { int iA = na - 2, iB = 1;
-				for (int k = 0; k < Lk; k++) X3(iA, iB, k) = third * (X3(iA, iB, k) + X3(iA + 1, iB, k) + X3(iA, iB - 1, k)); }
-#undef X3
+			dss_average_field(P, x, Lk);
 		}
+	}
+	dss_tracers(g, s, ix);
+}
+
+/* Grid::Exchange + ApplyDSS for DataType_Tracers: scalars on levels, no covector rotation */
+static void dss_tracers(const orc_grid * g, orc_state * s, int ix) {
+	if (!has_tracers(g, s)) return;
+	const int L = g->L, nt = g->ntracers;
+	size_t tot = 0;
+	for (int p = 0; p < g->npatch; p++) tot += (size_t)g->patches[p].nhalo * nt * L;
+	double * buf = (double *)malloc(sizeof(double) * (tot ? tot : 1));
+	size_t off = 0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		for (int m = 0; m < P->nhalo; m++, off += (size_t)nt * L) {
+			const int q = P->hsp[m];
+			if (q < 0) continue;
+			const orc_patch * Q = &g->patches[q];
+			const double * qt = s->tracer[ix * g->npatch + q];
+			for (int c = 0; c < nt; c++)
+				for (int k = 0; k < L; k++)
+					buf[off + (size_t)c * L + k] = qt[(((size_t)c * Q->na + P->hsi[m]) * Q->nb + P->hsj[m]) * L + k];
+		}
+	}
+	off = 0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		double * pt = s->tracer[ix * g->npatch + p];
+		for (int m = 0; m < P->nhalo; m++, off += (size_t)nt * L) {
+			if (P->hsp[m] < 0) continue;
+			for (int c = 0; c < nt; c++)
+				for (int k = 0; k < L; k++)
+					pt[(((size_t)c * P->na + P->hi[m]) * P->nb + P->hj[m]) * L + k] = buf[off + (size_t)c * L + k];
+		}
+	}
+	free(buf);
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		for (int c = 0; c < nt; c++)
+			dss_average_field(P, s->tracer[ix * g->npatch + p] + (size_t)c * P->na * P->nb * L, L);
 	}
 }
 
@@ -657,6 +771,114 @@ void orc_column_f_jacobian(const orc_grid * g, const orc_patch * p, const double
 	colwork_free(&w);
 }
 
+/* VerticalDynamicsFEM::UpdateColumnTracers (VerticalDynamicsFEM.cpp:3783-4282), implicit mode, vertical order 1,
+ * upwinding on, no uniform diffusion: backward-Euler vertical transport of every tracer density with the xi_dot of
+ * the INITIAL column in the (tridiagonal) matrix and upwind weights, the xi_dot of the UPDATED W in the mass flux.
+ * x0 = initial column state, w->ue / w->ve = initial U,V on interfaces (both left by column_f_jacobian),
+ * eup = updated REdge array of the patch. */
+static void update_column_tracers(const orc_grid * g, const orc_patch * P, int iA, int iB, double dt,
+	const double * x0, const colwork * w, const double * eup, const double * tin, double * tup)
+{
+	const int L = g->L, na = P->na, nb = P->nb, nt = g->ntracers;
+	const double * Jn = P->g[ORC_G_JAC], * Je = P->g[ORC_G_JAC_E], * CXe = P->g[ORC_G_CMXI_E];
+	const int ld = L;                       /* m_matTracersLUDF is [L][L]; band (kl = ku = 1) rows 0..3 of each column */
+	double * A = dalloc(L * ld), * A2 = dalloc(L * ld);
+	double * xd0 = dalloc(L + 1), * xd1 = dalloc(L + 1), * qn = dalloc(L + 1), * qe = dalloc(L + 2);
+	double * mf = dalloc(L + 1), * dmf = dalloc(L + 1), * Fq = dalloc(L + 1), * ww = dalloc(L + 1), * aux = dalloc(L + 1), * buf = dalloc(L + 1);
+	int * ipiv = (int *)malloc(sizeof(int) * L);
+#define TMAT(n_, k_) A[(2 + (k_) - (n_)) + ld * (n_)]      /* TracerMatFIx(n, k): d F_k / d q_n (VerticalDynamicsFEM.h:128-137) */
+	const double * Cdiff = g->opc[ORC_OP_DIFF_E2N], * Cint = g->opc[ORC_OP_INTERP_N2E];
+	const double * Cpl = g->opc[ORC_OP_PENALTY_L], * Cpr = g->opc[ORC_OP_PENALTY_R];
+	const int ndiff = g->opnin[ORC_OP_DIFF_E2N], nint = g->opnin[ORC_OP_INTERP_N2E];
+	const int npl = g->opnin[ORC_OP_PENALTY_L], npr = g->opnin[ORC_OP_PENALTY_R];
+	/* xi_dot of the initial column on interfaces (:3943-3957) */
+	for (int k = 1; k < L; k++)
+		xd0[k] = M4E(CXe, iA, iB, k, 0) * w->ue[k] + M4E(CXe, iA, iB, k, 1) * w->ve[k] + M4E(CXe, iA, iB, k, 2) * x0[VECF(FW, k)];
+	xd0[0] = 0.0; xd0[L] = 0.0;
+	/* dRhoQ_k / dRhoQ_n (:3959-3976) */
+	for (int k = 0; k < L; k++)
+		for (int m = g->opb[ORC_OP_DIFF_E2N][k]; m < g->ope[ORC_OP_DIFF_E2N][k]; m++)
+			for (int n = g->opb[ORC_OP_INTERP_N2E][m]; n < g->ope[ORC_OP_INTERP_N2E][m]; n++)
+				TMAT(n, k) += Cdiff[(size_t)k * ndiff + m] * Je[((size_t)iA * nb + iB) * (L + 1) + m]
+					/ Jn[((size_t)iA * nb + iB) * L + k] * Cint[(size_t)m * nint + n] * xd0[m];
+	/* upwinding in the Jacobian (:3978-4016) */
+	for (int a = 1; a < L; a++) {
+		const double weight = fabs(xd0[a]);
+		for (int k = a - 1; k < a; k++)
+			for (int n = g->opb[ORC_OP_PENALTY_L][k]; n < g->ope[ORC_OP_PENALTY_L][k]; n++)
+				TMAT(n, k) -= weight * Cpl[(size_t)k * npl + n];
+		for (int k = a; k < a + 1; k++)
+			for (int n = g->opb[ORC_OP_PENALTY_R][k]; n < g->ope[ORC_OP_PENALTY_R][k]; n++)
+				TMAT(n, k) -= weight * Cpr[(size_t)k * npr + n];
+	}
+	for (int k = 0; k < L; k++) TMAT(k, k) += 1.0 / dt;
+	/* xi_dot with the UPDATED W (:4059-4086) */
+	for (int k = 1; k < L; k++)
+		xd1[k] = M4E(CXe, iA, iB, k, 0) * w->ue[k] + M4E(CXe, iA, iB, k, 1) * w->ve[k]
+			+ M4E(CXe, iA, iB, k, 2) * eup[(((size_t)WIx * na + iA) * nb + iB) * (L + 1) + k];
+	xd1[0] = 0.0; xd1[L] = 0.0;
+	for (int c = 0; c < nt; c++) {
+		for (int k = 0; k < L; k++) qn[k] = tin[(((size_t)c * na + iA) * nb + iB) * L + k];
+		op_apply(g, ORC_OP_INTERP_N2E, qn, qe);
+		for (int k = 0; k <= L; k++) mf[k] = Je[((size_t)iA * nb + iB) * (L + 1) + k] * qe[k] * xd1[k];
+		mf[0] = 0.0; mf[L] = 0.0;
+		op_apply(g, ORC_OP_DIFF_E2N, mf, dmf);
+		for (int k = 0; k < L; k++) Fq[k] = dmf[k] / Jn[((size_t)iA * nb + iB) * L + k];
+		/* upwinding with the initial xi_dot (:4153-4181) */
+		for (int a = 0; a < L - 1; a++) ww[a] = fabs(xd0[a + 1]);
+		for (int k = 0; k < L; k++) aux[k] = 0.0;
+		penalty_apply(g, ww, qn, aux, buf);
+		for (int k = 0; k < L; k++) Fq[k] -= aux[k];
+		/* implicit velocity correction (:4183-4233) */
+		for (int a = 1; a < L; a++) {
+			double sw;
+			if (xd0[a] > 0.0) sw = 1.0 * M4E(CXe, iA, iB, a, 2);
+			else if (xd0[a] < 0.0) sw = -1.0 * M4E(CXe, iA, iB, a, 2);
+			else sw = 0.0;
+			const double jump = sw * (eup[(((size_t)WIx * na + iA) * nb + iB) * (L + 1) + a] - x0[VECF(FW, a)]);
+			for (int k = a - 1; k < a; k++)
+				for (int n = g->opb[ORC_OP_PENALTY_L][k]; n < g->ope[ORC_OP_PENALTY_L][k]; n++)
+					Fq[k] -= Cpl[(size_t)k * npl + n] * qn[n] * jump;
+			for (int k = a; k < a + 1; k++)
+				for (int n = g->opb[ORC_OP_PENALTY_R][k]; n < g->ope[ORC_OP_PENALTY_R][k]; n++)
+					Fq[k] -= Cpr[(size_t)k * npr + n] * qn[n] * jump;
+		}
+		/* DGBTRF once + DGBTRS per tracer == dgbsv on a fresh copy of the same matrix (:4024-4268) */
+		memcpy(A2, A, sizeof(double) * L * ld);
+		orc_dgbsv(L, 1, 1, A2, ld, ipiv, Fq);
+		for (int k = 0; k < L; k++) tup[(((size_t)c * na + iA) * nb + iB) * L + k] -= Fq[k];
+	}
+#undef TMAT
+	free(A); free(A2); free(xd0); free(xd1); free(qn); free(qe); free(mf); free(dmf); free(Fq); free(ww); free(aux); free(buf); free(ipiv);
+}
+
+/* VerticalDynamicsFEM::FilterNegativeTracers (VerticalDynamicsFEM.cpp:4286-4347): per column */
+static void filter_negative_tracers_v(const orc_grid * g, orc_state * s, int iupd) {
+	if (!has_tracers(g, s)) return;
+	const int L = g->L;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * t = s->tracer[iupd * g->npatch + p];
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++)
+		for (int c = 0; c < g->ntracers; c++) {
+			double total = 0.0, nonneg = 0.0;
+			for (int k = 0; k < L; k++) {
+				const double q = t[(((size_t)c * na + i) * nb + j) * L + k];
+				const double pm = q * P->area_node[((size_t)i * nb + j) * L + k];
+				total += pm;
+				if (q >= 0.0) nonneg += pm;
+			}
+			const double r = total / nonneg;
+			for (int k = 0; k < L; k++) {
+				double * q = &t[(((size_t)c * na + i) * nb + j) * L + k];
+				if (*q > 0.0) *q *= r; else *q = 0.0;
+			}
+		}
+	}
+}
+
 int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	if (g->shallow_water) return 0;    /* VerticalDynamicsStub */
 	const int L = g->L;
@@ -689,6 +911,9 @@ int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, 
 					NU(RIx, iA, iB, k) = x0[VECF(FR, k)] - F[VECF(FR, k)];
 				}
 				for (int k = 0; k <= L; k++) EU(WIx, iA, iB, k) = x0[VECF(FW, k)] - F[VECF(FW, k)];
+				if (has_tracers(g, s))
+					update_column_tracers(g, P, iA, iB, dt, x0, &w, eup,
+						s->tracer[iinit * g->npatch + p], s->tracer[iupd * g->npatch + p]);
 			}
 		}
 		/* duplicate element-seam nodes inside the patch receive P, W, Rho (not U,V) (:1543-1633) */
@@ -708,6 +933,12 @@ int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, 
 						EU(WIx, iA, iB, k) = EU(WIx, iA + 1, iB, k);
 						EU(RIx, iA, iB, k) = EU(RIx, iA + 1, iB, k);
 					}
+					if (has_tracers(g, s)) {
+						double * tup = s->tracer[iupd * g->npatch + p];
+						for (int c = 0; c < g->ntracers; c++)
+							for (int k = 0; k < L; k++)
+								tup[(((size_t)c * na + iA) * nb + iB) * L + k] = tup[(((size_t)c * na + iA + 1) * nb + iB) * L + k];
+					}
 				}
 			}
 		}
@@ -724,10 +955,17 @@ int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, 
 				EU(WIx, i, iB, k) = EU(WIx, i, iB + 1, k);
 				EU(RIx, i, iB, k) = EU(RIx, i, iB + 1, k);
 			}
+			if (has_tracers(g, s)) {
+				double * tup = s->tracer[iupd * g->npatch + p];
+				for (int c = 0; c < g->ntracers; c++)
+					for (int k = 0; k < L; k++)
+						tup[(((size_t)c * na + i) * nb + iB) * L + k] = tup[(((size_t)c * na + i) * nb + iB + 1) * L + k];
+			}
 		}
 	}
 	colwork_free(&w);
 	free(x0); free(F); free(AB); free(ipiv);
+	filter_negative_tracers_v(g, s, iupd);      /* VerticalDynamicsFEM::StepImplicit, :1637 */
 	return info;
 }
 
@@ -751,6 +989,62 @@ static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 			const double * Jc = (c == WIx) ? P->g[ORC_G_JAC_E] : P->g[ORC_G_JAC];
 			const double * xin = ((c == WIx) ? s->redge[iinit * g->npatch + p] : s->node[iinit * g->npatch + p]) + (size_t)c * na * nb * Lk;
 			double * xup = ((c == WIx) ? s->redge[iupd * g->npatch + p] : s->node[iupd * g->npatch + p]) + (size_t)c * na * nb * Lk;
+#define XI(i,j,k) xin[((size_t)(i) * nb + (j)) * Lk + (k)]
+#define XU(i,j,k) xup[((size_t)(i) * nb + (j)) * Lk + (k)]
+#define JC(i,j,k) Jc[((size_t)(i) * nb + (j)) * Lk + (k)]
+			for (int a = 0; a < P->nea; a++)
+			for (int b = 0; b < P->neb; b++)
+			for (int k = 0; k < Lk; k++) {
+				const int eA = a * NP + 1, eB = b * NP + 1;
+				double ga[NP][NP], gb[NP][NP];
+				for (int i = 0; i < NP; i++)
+				for (int j = 0; j < NP; j++) {
+					const int iA = eA + i, iB = eB + j;
+					double da = 0.0, db = 0.0;
+					for (int q = 0; q < NP; q++) {
+						da += XI(eA + q, iB, k) * D[q * NP + i];
+						db += XI(iA, eB + q, k) * D[q * NP + j];
+					}
+					da *= inv_da; db *= inv_da;
+					ga[i][j] = JC(iA, iB, k) * (C2A[(iA * nb + iB) * 2 + 0] * da + C2A[(iA * nb + iB) * 2 + 1] * db);
+					gb[i][j] = JC(iA, iB, k) * (C2B[(iA * nb + iB) * 2 + 0] * da + C2B[(iA * nb + iB) * 2 + 1] * db);
+				}
+				for (int i = 0; i < NP; i++)
+				for (int j = 0; j < NP; j++) {
+					const int iA = eA + i, iB = eB + j;
+					const double invJ = 1.0 / JC(iA, iB, k);
+					double ua = 0.0, ub = 0.0;
+					for (int q = 0; q < NP; q++) {
+						ua += ga[q][j] * S[i * NP + q];
+						ub += gb[i][q] * S[j * NP + q];
+					}
+					ua *= inv_da; ub *= inv_da;
+					XU(iA, iB, k) -= dt * invJ * local_nu * (ua + ub);
+				}
+			}
+#undef XI
+#undef XU
+#undef JC
+		}
+	}
+}
+
+/* ApplyScalarHyperdiffusion, tracer branch (iType == 1, :1999-2035): the same Laplacian on every tracer density */
+static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally) {
+	if (!has_tracers(g, s)) return;
+	const int L = g->L;
+	const double inv_da = 1.0 / g->delta_a;
+	const double * D = g->dx, * S = g->stiff;
+	double local_nu = nu;
+	if (scale_locally && g->ref_length != 0.0) local_nu *= pow(g->delta_a / g->ref_length, 3.2);
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb, Lk = L;
+		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
+		const double * Jc = P->g[ORC_G_JAC];
+		for (int c = 0; c < g->ntracers; c++) {
+			const double * xin = s->tracer[iinit * g->npatch + p] + (size_t)c * na * nb * Lk;
+			double * xup = s->tracer[iupd * g->npatch + p] + (size_t)c * na * nb * Lk;
 #define XI(i,j,k) xin[((size_t)(i) * nb + (j)) * Lk + (k)]
 #define XU(i,j,k) xup[((size_t)(i) * nb + (j)) * Lk + (k)]
 #define JC(i,j,k) Jc[((size_t)(i) * nb + (j)) * Lk + (k)]
@@ -898,10 +1192,13 @@ void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int
 	if (!(g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0)) {
 		orc_zero(g, s, iwork);
 		scalar_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
+		tracer_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
 		vector_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 1.0, 0);
 		orc_apply_dss(g, s, iwork);
 		scalar_hyperdiff(g, s, iwork, iupd, -dt, g->nu_scalar, 1);
+		tracer_hyperdiff(g, s, iwork, iupd, -dt, g->nu_scalar, 1);
 		vector_hyperdiff(g, s, iwork, iupd, -dt, g->nu_div, g->nu_vort, 1);
+		filter_negative_tracers_h(g, s, iupd);       /* HorizontalDynamicsFEM.cpp:2707 */
 		orc_apply_dss(g, s, iupd);
 	}
 	/* APPLY_RAYLEIGH_WITH_HYPERVIS (Defines.h:70, HorizontalDynamicsFEM.cpp:2719-2724) */

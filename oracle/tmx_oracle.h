@@ -66,6 +66,7 @@ typedef struct {
 	 * and the reference state [5][na][nb][L] / [5][na][nb][L+1] (GridPatch::GetReferenceState)                */
 	const double * ray_node; const double * ray_redge;
 	const double * ref_node; const double * ref_redge;
+	const double * area_node;          /* [na][nb][L] GridPatch::GetElementAreaNode (tracer filters; NULL without tracers) */
 } orc_patch;
 
 typedef struct {
@@ -81,6 +82,7 @@ typedef struct {
 	double nu_scalar, nu_div, nu_vort;
 	const orc_patch * patches;
 	int shallow_water;                 /* 1: ShallowWaterEquations (U,V,H; H kept in slot 2, one level)  */
+	int ntracers;                      /* EquationSet::GetTracers(); tracer densities live on levels      */
 } orc_grid;
 
 /* state: node[inst*npatch + p], redge[inst*npatch + p] */
@@ -88,6 +90,7 @@ typedef struct {
 	int ninst;
 	double ** node;
 	double ** redge;
+	double ** tracer;                  /* tracer[inst*npatch + p] = [ntracers][na][nb][L] (GridPatch::GetDataTracers), NULL if none */
 } orc_state;
 
 void orc_copy(const orc_grid * g, orc_state * s, int src, int dst);

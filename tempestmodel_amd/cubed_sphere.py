@@ -728,12 +728,21 @@ class CubedSphereGrid:
                     out[kind + "_" + loc] = np.stack([np.broadcast_to(s, z.shape) for s in st], 0).copy()
             g["ref_node"] = out["ref_node"]
             g["ref_redge"] = out["ref_redge"]
+            # tracer densities on levels (GridPatch::GetDataTracers), every node incl. halo
+            nt = int(getattr(test, "ntracers", 0))
+            if nt > 0:
+                z = g["z_levels"]
+                lon = P.lon[..., None] * np.ones(z.shape[-1]); lat = P.lat[..., None] * np.ones(z.shape[-1])
+                tr = test.evaluate_tracers(self.phys, z, lon, lat, out["state_node"][RIX])
+                self.initial_tracers = getattr(self, "initial_tracers", {})
+                self.initial_tracers[P.index] = np.stack([np.broadcast_to(t, z.shape) for t in tr], 0).copy()
             # Rayleigh friction strength on levels and interfaces, every node incl. halo (GridPatchCSGLL.cpp:663-683)
             if getattr(test, "has_rayleigh_friction", False):
                 g["rayleigh_node"] = test.evaluate_rayleigh_strength(g["z_levels"])
                 g["rayleigh_redge"] = test.evaluate_rayleigh_strength(g["z_interfaces"])
             states.append((out["state_node"], out["state_redge"]))
         self.has_rayleigh_friction = bool(getattr(test, "has_rayleigh_friction", False))
+        self.ntracers = int(getattr(test, "ntracers", 0))
         return states
 
     def _evaluate_shallow_water(self, test):
@@ -782,10 +791,24 @@ class BaroclinicWaveJW:
     pert_lat = 2.0 * math.pi / 9.0
     pert_r = 0.1
 
-    def __init__(self, alpha=0.0, ztop=30000.0, pert="exp"):
+    def __init__(self, alpha=0.0, ztop=30000.0, pert="exp", ntracers=0):
         self.alpha = alpha
         self.ztop = ztop
         self.pert = pert
+        self.ntracers = ntracers      # closed-form tracer densities of oracle/ref_dump.cpp's JWWithTracers (a test input)
+
+    def evaluate_tracers(self, phys, z, lon, lat, rho):
+        """Tracer densities rho*q, same formulas as JWWithTracers in oracle/ref_dump.cpp."""
+        out = []
+        if self.ntracers > 0:
+            out.append(rho * (0.5 * (1.0 + np.sin(lat) * np.cos(lon)) * np.exp(-z / 8000.0) + 0.01))
+        if self.ntracers > 1:
+            r = np.arccos(math.sin(0.6) * np.sin(lat) + math.cos(0.6) * np.cos(lat) * np.cos(lon - 0.9)) / 0.5
+            q = np.where((r < 1.0) & (z < 12000.0), 0.5 * (1.0 + np.cos(math.pi * r)), 0.0)
+            out.append(rho * q)
+        for c in range(2, self.ntracers):
+            out.append(rho * 0.001 * (c + 1))
+        return out
 
     def evaluate_physical_constants(self, phys):
         phys.alpha = self.alpha

@@ -12,6 +12,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
   percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
+  percall_tracers_ne3_L6_p6.npz / steps_tracers_ne3_L6_p6.npz   JW + 2 tracer densities (rows H8, V8)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
 """
@@ -49,6 +50,8 @@ def compact_states(d, npatch):
             continue
         if k.endswith("/node"):
             out[k] = v[[0, 1, 2, 4], 1:-1, 1:-1]
+        elif k.endswith("/tracers"):
+            out[k] = v[:, 1:-1, 1:-1]
         else:
             out[k] = v[3, 1:-1, 1:-1]
     return out
@@ -105,6 +108,17 @@ def main():
         if k in ("p0/jacobian2d", "p4/jacobian2d", "p0/coriolis_f", "p4/contra_metric_2d_a", "p0/jacobian", "p0/topography"):
             rec[k] = v
     save("sw2_ne8_strang.npz", rec)
+
+    # tracer transport.  JW state + two closed-form tracer densities (JWWithTracers in ref_dump.cpp)
+    d, _ = run(["--tracers", "2", "--mode", "percall", "--ne", "3", "--levels", "6", "--dt", "200", "--warm", "2"], tmp)
+    drop_tr = tuple(x for x in drop if x != "element_area_node") + ("ref_node", "ref_redge")   # the filters need the areas
+    d = {k: v for k, v in d.items() if k.split("/")[-1] not in drop_tr and not k.startswith("state/initial")}
+    save("percall_tracers_ne3_L6_p6.npz", d)
+    d, _ = run(["--tracers", "2", "--mode", "steps", "--ne", "3", "--levels", "6", "--dt", "200", "--steps", "4",
+                "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    rec.update(compact_states(d, 6))
+    save("steps_tracers_ne3_L6_p6.npz", rec)
 
     # north-star gate: 100 reference ARS343 steps at ne4 L10 from the developed state after 2 steps
     d, _ = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--warm", "2", "--steps", "100",

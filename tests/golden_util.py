@@ -12,22 +12,22 @@ def load(name):
     return {k.replace("__", "/"): z[k] for k in z.files}
 
 
-def make_grid(ne, L, npatch, ztop=30000.0, pert="exp", case="jw"):
+def make_grid(ne, L, npatch, ztop=30000.0, pert="exp", case="jw", ntracers=0):
     """case: "jw" Jablonowski-Williamson baroclinic wave, "schar" Schar mountain on the reduced-radius sphere
     (Rayleigh layer; ScharMountainSphereTest.cpp defaults)."""
     ppd = int(round((npatch / 6) ** 0.5))
     g = CubedSphereGrid(ne, L, ztop, ppd=ppd)
-    test = BaroclinicWaveJW(0.0, ztop, pert) if case == "jw" else ScharMountainSphere(ztop=ztop)
+    test = BaroclinicWaveJW(0.0, ztop, pert, ntracers=ntracers) if case == "jw" else ScharMountainSphere(ztop=ztop)
     states = g.evaluate_test_case(test)
     return g, states
 
 
-def grid_from_fixture(d, override=True, case="jw"):
+def grid_from_fixture(d, override=True, case="jw", ntracers=0):
     """Grid for a fixture; with ``override`` the geometry / operator arrays are replaced by the
     reference's own (bit-identical inputs for per-call parity)."""
     ne = int(d["cfg/ne"][0]); L = int(d["cfg/levels"][0]); npatch = int(d["cfg/npatch"][0])
     ztop = float(d["grid/ztop"][0]) if "grid/ztop" in d else 30000.0
-    g, states = make_grid(ne, L, npatch, ztop, case=case)
+    g, states = make_grid(ne, L, npatch, ztop, case=case, ntracers=ntracers)
     if override:
         for P in g.patches:
             for nm in list(P.geom):
@@ -43,6 +43,32 @@ def grid_from_fixture(d, override=True, case="jw"):
 
 def full_states(d, tag, npatch):
     return [(d["state/%s/p%d/node" % (tag, p)], d["state/%s/p%d/redge" % (tag, p)]) for p in range(npatch)]
+
+
+def full_tracers(d, tag, npatch):
+    return [d["state/%s/p%d/tracers" % (tag, p)] for p in range(npatch)]
+
+
+def expand_compact_tracers(d, tag, grid):
+    """Compact fixture tracers (interior nodes) -> full [nt][na][nb][L] arrays, halo zero."""
+    out = []
+    for P in grid.patches:
+        c = d["state/%s/p%d/tracers" % (tag, P.index)]
+        t = np.zeros((c.shape[0], P.na, P.nb, grid.L))
+        t[:, 1:-1, 1:-1] = c
+        out.append(t)
+    return out
+
+
+def tracer_errors(got, ref):
+    """Max abs difference per tracer over interior nodes, relative to the max abs value of that tracer in ``ref``."""
+    nt = ref[0].shape[0]
+    errs = []
+    for c in range(nt):
+        num = max(float(np.max(np.abs(a[c, 1:-1, 1:-1] - b[c, 1:-1, 1:-1]))) for a, b in zip(got, ref))
+        den = max(float(np.max(np.abs(b[c, 1:-1, 1:-1]))) for b in ref)
+        errs.append(num / den if den > 0 else num)
+    return errs
 
 
 def expand_compact(d, tag, grid):

@@ -27,7 +27,7 @@ class OrcPatch(C.Structure):
                 ("nhalo", C.c_int),
                 ("hi", PI), ("hj", PI), ("hsp", PI), ("hsi", PI), ("hsj", PI), ("hspanel", PI),
                 ("htrans", PD),
-                ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD)]
+                ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD), ("area_node", PD)]
 
 
 class OrcGrid(C.Structure):
@@ -38,11 +38,11 @@ class OrcGrid(C.Structure):
                 ("opc", PD * 10), ("opb", PI * 10), ("ope", PI * 10),
                 ("opnin", C.c_int * 10), ("opnout", C.c_int * 10),
                 ("nu_scalar", C.c_double), ("nu_div", C.c_double), ("nu_vort", C.c_double),
-                ("patches", C.POINTER(OrcPatch)), ("shallow_water", C.c_int)]
+                ("patches", C.POINTER(OrcPatch)), ("shallow_water", C.c_int), ("ntracers", C.c_int)]
 
 
 class OrcState(C.Structure):
-    _fields_ = [("ninst", C.c_int), ("node", C.POINTER(PD)), ("redge", C.POINTER(PD))]
+    _fields_ = [("ninst", C.c_int), ("node", C.POINTER(PD)), ("redge", C.POINTER(PD)), ("tracer", C.POINTER(PD))]
 
 
 _lib = None
@@ -128,6 +128,13 @@ class Oracle:
                     setattr(cp, {"rayleigh_node": "ray_node", "rayleigh_redge": "ray_redge"}.get(fld, fld), _pd(a))
         g.patches = self.cpatches
         g.shallow_water = 1 if self.shallow_water else 0
+        self.ntracers = int(getattr(grid, "ntracers", 0))
+        g.ntracers = self.ntracers
+        if self.ntracers:
+            for P in grid.patches:
+                a = np.ascontiguousarray(P.geom["element_area_node"], dtype=np.float64)
+                self._keep.append(a)
+                self.cpatches[P.index].area_node = _pd(a)
         self.cgrid = g
         # state storage
         self.node = [[np.zeros((5, P.na, P.nb, self.L)) for P in grid.patches] for _ in range(ninst)]
@@ -142,6 +149,15 @@ class Oracle:
         st.ninst = ninst
         st.node = C.cast(self._np, C.POINTER(PD))
         st.redge = C.cast(self._ep, C.POINTER(PD))
+        # tracer densities [ntracers][na][nb][L] per instance and patch (GridPatch::GetDataTracers)
+        self.tracer = None
+        if self.ntracers:
+            self.tracer = [[np.zeros((self.ntracers, P.na, P.nb, self.L)) for P in grid.patches] for _ in range(ninst)]
+            self._tp = (PD * (ninst * self.npatch))()
+            for i in range(ninst):
+                for p in range(self.npatch):
+                    self._tp[i * self.npatch + p] = _pd(self.tracer[i][p])
+            st.tracer = C.cast(self._tp, C.POINTER(PD))
         self.cstate = st
 
     # -- state access ------------------------------------------------------------------------
@@ -152,6 +168,13 @@ class Oracle:
 
     def get_state(self, inst):
         return [(self.node[inst][p].copy(), self.redge[inst][p].copy()) for p in range(self.npatch)]
+
+    def set_tracers(self, inst, tracers):
+        for p in range(self.npatch):
+            self.tracer[inst][p][...] = tracers[p]
+
+    def get_tracers(self, inst):
+        return [self.tracer[inst][p].copy() for p in range(self.npatch)]
 
     # -- operations (names follow the reference classes) ---------------------------------------
     def copy_data(self, src, dst):

@@ -95,6 +95,48 @@ def test_ars343_steps_from_developed_state(fixture, ne, L, npatch, dt, tags):
     assert abs(cs[4] - ref[4]) < 1e-12 * abs(ref[4])
 
 
+def test_tracer_percall_chain():
+    """tracer flux divergence + element filter in H.StepExplicit, tracer DSS, the implicit column
+    tracer update (tridiagonal dgbtrf/dgbtrs) + column filter in V.StepImplicit, tracer hyperdiffusion + filter in
+    StepAfterSubCycle, tracer stage algebra -- each against the reference's own output on identical inputs."""
+    d = gu.load("percall_tracers_ne3_L6_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, ntracers=2)
+    dt = float(d["cfg/dt"][0]); sdt = dt * gu.ARS343_GAMMA
+    o = Oracle(g)
+    o.set_state(0, gu.full_states(d, "warm", 6)); o.set_tracers(0, gu.full_tracers(d, "warm", 6))
+    o.copy_data(0, 1)
+    o.h_step_explicit(0, 1, sdt)
+    assert max(gu.tracer_errors(o.get_tracers(1), gu.full_tracers(d, "h_explicit", 6))) < 1e-15
+    o.v_step_explicit(0, 1, sdt)
+    assert max(gu.tracer_errors(o.get_tracers(1), gu.full_tracers(d, "v_explicit", 6))) < 1e-15
+    o.apply_dss(1)
+    assert max(gu.tracer_errors(o.get_tracers(1), gu.full_tracers(d, "dss", 6))) < 1e-15
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "dss", 6))) < 1e-15
+    o.copy_data(1, 2)
+    assert o.v_step_implicit(2, 2, sdt) == 0
+    assert max(gu.tracer_errors(o.get_tracers(2), gu.full_tracers(d, "v_implicit", 6))) < 1e-13
+    o.h_step_after_subcycle(2, 3, 4, dt)
+    assert max(gu.tracer_errors(o.get_tracers(4), gu.full_tracers(d, "hypervis_work", 6))) < 1e-12
+    assert max(gu.tracer_errors(o.get_tracers(3), gu.full_tracers(d, "hypervis", 6))) < 1e-12
+    o.linear_combine_data([0.25, -0.5, 1.75, 0.5, 0, 0, 0], 3)
+    assert max(gu.tracer_errors(o.get_tracers(3), gu.full_tracers(d, "lincomb", 6))) < 1e-12
+    # the filters were exercised: the reference's own state has clipped zeros next to positive values
+    t = gu.full_tracers(d, "h_explicit", 6)[0][1, 1:-1, 1:-1]
+    assert (t == 0.0).any() and (t > 0.0).any()
+
+
+def test_tracer_steps_vs_reference():
+    """Whole ARS343 steps with two tracers from the reference's state after step 1."""
+    d = gu.load("steps_tracers_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, ntracers=2)
+    o = Oracle(g)
+    o.set_state(0, gu.expand_compact(d, "step1", g)); o.set_tracers(0, gu.expand_compact_tracers(d, "step1", g))
+    for step in (2, 3, 4):
+        assert o.step_ars343(200.0) == 0
+        assert max(gu.tracer_errors(o.get_tracers(0), gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-12
+        assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-10
+
+
 def test_hundred_reference_steps_ne4_L10():
     """North-star gate on the CPU side: the C oracle stays within 1e-10 of the real reference over 100 ARS343
     steps (ne4 L10 dt 200 s, from the reference's state after 2 steps)."""
