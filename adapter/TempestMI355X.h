@@ -66,6 +66,10 @@ public:
 			Check(tmx_upload_state(m_pEngine, pPatch->GetPatchIndex(), ixData,
 				&(pPatch->GetDataState(ixData, DataLocation_Node)[0][0][0][0]),
 				&(pPatch->GetDataState(ixData, DataLocation_REdge)[0][0][0][0])));
+			if (m_model.GetEquationSet().GetTracers() > 0) {
+				Check(tmx_upload_tracers(m_pEngine, pPatch->GetPatchIndex(), ixData,
+					&(pPatch->GetDataTracers(ixData)[0][0][0][0])));
+			}
 		}
 	}
 
@@ -78,6 +82,10 @@ public:
 			Check(tmx_download_state(m_pEngine, pPatch->GetPatchIndex(), ixData,
 				&(pPatch->GetDataState(ixData, DataLocation_Node)[0][0][0][0]),
 				&(pPatch->GetDataState(ixData, DataLocation_REdge)[0][0][0][0])));
+			if (m_model.GetEquationSet().GetTracers() > 0) {
+				Check(tmx_download_tracers(m_pEngine, pPatch->GetPatchIndex(), ixData,
+					&(pPatch->GetDataTracers(ixData)[0][0][0][0])));
+			}
 		}
 	}
 
@@ -289,6 +297,7 @@ private:
 			g.deriv_r_redge = &(pPatch->GetDerivRREdge()[0][0][0][0]);
 			g.coriolis_f = &(pPatch->GetCoriolisF()[0][0]);
 			g.topography = &(pPatch->GetTopography()[0][0]);
+			g.element_area_node = &(pPatch->GetElementAreaNode()[0][0][0]);
 			Check(tmx_set_patch_geometry(m_pEngine, pPatch->GetPatchIndex(), &g));
 
 			// Rayleigh friction (HorizontalDynamicsFEM::ApplyRayleighFriction runs at the end of StepAfterSubCycle)

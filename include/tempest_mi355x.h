@@ -21,7 +21,7 @@
  * Supported configuration (anything else -> TMX_ERR_UNSUPPORTED): horizontal order np = 4,
  * FE vertical order 1, Lorenz staggering (W on interfaces), FORMULATION_RHOTHETA_PI,
  * USE_DIRECTSOLVE + USE_JACOBIAN_DIAGONAL, upwinding on all variables, Clark-form implicit W
- * advection, hyperviscosity order 4, no tracers (src/atm/Defines.h:23-80,
+ * advection, hyperviscosity order 4, tracers without uniform diffusion (src/atm/Defines.h:23-80,
  * src/atm/VerticalDynamicsFEM.cpp:33-47).
  */
 #ifndef TEMPEST_MI355X_H
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 3
+#define TMX_ABI_VERSION 4
 
 #define TMX_OK                 0
 #define TMX_ERR_INVALID       -1   /* bad argument / call order                      */
@@ -68,7 +68,7 @@ typedef struct {
 	int    levels;             /* Grid::GetRElements()                                         */
 	int    n_patches;          /* total number of patches of the grid (all ranks)              */
 	int    n_instances;        /* state instances per patch (ARS343: 7)                        */
-	int    n_tracers;          /* must be 0                                                    */
+	int    n_tracers;          /* EquationSet::GetTracers(); tracer densities on levels (nonhydrostatic set only) */
 	int    hypervis_order;     /* 0 or 4                                                       */
 	double element_delta_a;    /* GridPatchGLL::GetElementDeltaA()                             */
 	double reference_length;   /* Grid::GetReferenceLength()                                   */
@@ -102,6 +102,7 @@ typedef struct {
 	const double * deriv_r_redge;          /* [na][nb][L+1][3]  GetDerivRREdge          */
 	const double * coriolis_f;             /* [na][nb]          GetCoriolisF            */
 	const double * topography;             /* [na][nb]          GetTopography (shallow water only; may be NULL) */
+	const double * element_area_node;      /* [na][nb][L]       GetElementAreaNode (tracer filters; NULL when n_tracers == 0) */
 } tmx_patch_geometry;
 
 /* ---- life cycle ---------------------------------------------------------------------------- */
@@ -176,6 +177,13 @@ int tmx_upload_state(tmx_engine * e, int patch, int instance, const double * nod
 /* Writes interior nodes: prognostic slots, plus the derived slots the reference keeps beside them
  * (W on levels, U,V on interfaces: HorizontalDynamicsFEM.cpp:817-831).  Halo ring untouched. */
 int tmx_download_state(tmx_engine * e, int patch, int instance, double * node, double * redge);
+
+/* Tracer densities of one instance, GridPatch::GetDataTracers(instance): [n_tracers][na][nb][L] (src/atm/GridPatch.h:885-905).
+ * Every operation of this interface that the reference applies to DataType_Tracers next to DataType_State (CopyData,
+ * LinearCombineData, ZeroData, PostProcessSubstage/ApplyDSS, the tracer parts of StepExplicit / StepImplicit /
+ * StepAfterSubCycle incl. FilterNegativeTracers) acts on them as well. */
+int tmx_upload_tracers(tmx_engine * e, int patch, int instance, const double * tracers);
+int tmx_download_tracers(tmx_engine * e, int patch, int instance, double * tracers);
 
 /* ---- stage algebra (Grid::CopyData / ZeroData / LinearCombineData, src/atm/Grid.cpp:1585-1621) */
 int tmx_copy_data(tmx_engine * e, int src, int dst);

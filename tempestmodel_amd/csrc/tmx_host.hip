@@ -118,7 +118,8 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg->abi_version == TMX_ABI_VERSION, TMX_ERR_INVALID, "tmx_create: ABI version %d, library is %d", cfg->abi_version, TMX_ABI_VERSION);
 	REQUIRE(cfg->horizontal_order == TMX_NP, TMX_ERR_UNSUPPORTED, "horizontal order %d unsupported (np = 4 only)", cfg->horizontal_order);
 	REQUIRE(cfg->vertical_order == 1, TMX_ERR_UNSUPPORTED, "vertical order %d unsupported (1 only)", cfg->vertical_order);
-	REQUIRE(cfg->n_tracers == 0, TMX_ERR_UNSUPPORTED, "tracers unsupported");
+	REQUIRE(cfg->n_tracers >= 0 && cfg->n_tracers <= 16, TMX_ERR_UNSUPPORTED, "0..16 tracers supported, got %d", cfg->n_tracers);
+	REQUIRE(cfg->n_tracers == 0 || cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC, TMX_ERR_UNSUPPORTED, "tracers are supported with the nonhydrostatic equation set only");
 	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0 or 4)", cfg->hypervis_order);
 	REQUIRE(cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC || cfg->equation_set == TMX_EQN_SHALLOW_WATER,
 		TMX_ERR_UNSUPPORTED, "equation set %d unsupported", cfg->equation_set);
@@ -130,7 +131,8 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->cfg = *cfg;
 	e->L = cfg->levels;
 	e->patches.resize(cfg->n_patches);
-	e->nslab = 5 * e->L + 1;
+	e->nt = cfg->n_tracers;
+	e->nslab = 5 * e->L + 1 + e->nt * e->L;
 	e->sw = (cfg->equation_set == TMX_EQN_SHALLOW_WATER);
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
@@ -162,7 +164,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->stream) hipStreamSynchronize(e->stream);
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
-		free_dev(e->d_state); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_state); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
@@ -299,6 +301,11 @@ extern "C" int tmx_set_patch_geometry(tmx_engine * e, int patch, const tmx_patch
 		e->h_g2d[G2_C2B1 * NS + c] = g->contra_metric_2d_b[ij * 2 + 1];
 		REQUIRE(g->contra_metric_2d_b[ij * 2 + 0] == g->contra_metric_2d_a[ij * 2 + 1], TMX_ERR_UNSUPPORTED, "2-D contravariant metric is not symmetric");
 		e->h_g2d[G2_JN * NS + c] = g->jacobian[ij * L];
+		if (e->nt > 0) {
+			REQUIRE(g->element_area_node, TMX_ERR_INVALID, "tracers need tmx_patch_geometry.element_area_node (patch %d)", patch);
+			if (e->h_area.empty()) e->h_area.assign((size_t)L * NS, 0.0);
+			for (int k = 0; k < L; k++) e->h_area[(size_t)k * NS + c] = g->element_area_node[ij * L + k];
+		}
 		if (e->sw) {
 			// 2-D equation set: only the 2-D metric, the (single-level) Jacobian and the topography are used
 			e->h_g2d[G2_JE * NS + c] = g->jacobian[ij * L];
@@ -663,6 +670,11 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		if ((r = dev_upload(&e->d_g3e, e->h_g3e, &bytes))) return r;
 	}
 	if ((r = dev_upload(&e->d_ops, e->h_ops, &bytes))) return r;
+	if (e->nt > 0) {
+		if ((r = dev_upload(&e->d_area, e->h_area, &bytes))) return r;
+		std::vector<double>().swap(e->h_area);
+		HIPCHK(hipMalloc((void **)&e->d_w0, (size_t)(L + 1) * NS * sizeof(double))); bytes += (size_t)(L + 1) * NS * sizeof(double);
+	}
 	{
 		int nset = 0;
 		for (int lp : e->local_patches) nset += e->patches[lp].rayleigh_set ? 1 : 0;
@@ -729,7 +741,8 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 	const PatchInfo & P = e->patches[patch];
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
-	std::vector<double> buf((size_t)e->nslab * ncp);
+	const int nstate = 5 * L + 1;          // state slabs; tracer slabs are moved by tmx_upload_tracers
+	std::vector<double> buf((size_t)nstate * ncp);
 	const int nodevar[4] = { 0, 1, 2, 4 };
 	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
 		const int c = col_of(P, i, j) - c0;
@@ -744,7 +757,46 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 	}
 	HIPCHK(hipStreamSynchronize(e->stream));
 	HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + c0, (size_t)e->NS * sizeof(double),
-		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), e->nslab, hipMemcpyHostToDevice));
+		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), nstate, hipMemcpyHostToDevice));
+	return TMX_OK;
+}
+
+// GridPatch::GetDataTracers(instance) [nt][na][nb][L] <-> tracer slabs
+extern "C" int tmx_upload_tracers(tmx_engine * e, int patch, int instance, const double * tracers) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(e->nt > 0 && tracers, TMX_ERR_INVALID, "tmx_upload_tracers: engine has no tracers / null array");
+	const PatchInfo & P = e->patches[patch];
+	const int L = e->L, na = P.na, nb = P.nb, nq = e->nt * L;
+	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
+	std::vector<double> buf((size_t)nq * ncp);
+	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j) - c0;
+		for (int v = 0; v < e->nt; v++) for (int k = 0; k < L; k++)
+			buf[(size_t)(v * L + k) * ncp + c] = tracers[(((size_t)v * na + i) * nb + j) * L + k];
+	}
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + (size_t)(5 * L + 1) * e->NS + c0, (size_t)e->NS * sizeof(double),
+		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), nq, hipMemcpyHostToDevice));
+	return TMX_OK;
+}
+
+extern "C" int tmx_download_tracers(tmx_engine * e, int patch, int instance, double * tracers) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(e->nt > 0 && tracers, TMX_ERR_INVALID, "tmx_download_tracers: engine has no tracers / null array");
+	const PatchInfo & P = e->patches[patch];
+	const int L = e->L, na = P.na, nb = P.nb, nq = e->nt * L;
+	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
+	std::vector<double> buf((size_t)nq * ncp);
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy2D(buf.data(), (size_t)ncp * sizeof(double), e->d_state + (size_t)instance * e->inst_stride + (size_t)(5 * L + 1) * e->NS + c0,
+		(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), nq, hipMemcpyDeviceToHost));
+	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j) - c0;
+		for (int v = 0; v < e->nt; v++) for (int k = 0; k < L; k++)
+			tracers[(((size_t)v * na + i) * nb + j) * L + k] = buf[(size_t)(v * L + k) * ncp + c];
+	}
 	return TMX_OK;
 }
 
@@ -755,10 +807,11 @@ extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, doubl
 	const PatchInfo & P = e->patches[patch];
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
-	std::vector<double> buf((size_t)e->nslab * ncp);
+	const int nstate = 5 * L + 1;
+	std::vector<double> buf((size_t)nstate * ncp);
 	HIPCHK(hipStreamSynchronize(e->stream));
 	HIPCHK(hipMemcpy2D(buf.data(), (size_t)ncp * sizeof(double), e->d_state + (size_t)instance * e->inst_stride + c0,
-		(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), e->nslab, hipMemcpyDeviceToHost));
+		(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), nstate, hipMemcpyDeviceToHost));
 	const int nodevar[4] = { 0, 1, 2, 4 };
 	const double * ops = e->h_ops.data();
 	auto opc = [&](int op, int k, int off) { return ops[((size_t)op * (L + 1) + k) * TMX_OPW + (off + 2)]; };
@@ -872,6 +925,7 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
 	if (e->sw) tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
+	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	return launch_check("h_step_explicit");
 }
 
@@ -897,6 +951,14 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
 	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 1, n, src, cf, premul);
+	if (e->nt > 0) {
+		// tracers: the combination is formed on the tracer slabs first, the tracer kernel then updates in place
+		const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
+		const double * tsrc[12];
+		for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
+		tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
+		tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+	}
 	return launch_check("hv_step_explicit(lincomb)");
 }
 
@@ -906,6 +968,7 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
 	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 1);
+	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
 	return launch_check("hv_step_explicit");
 }
 
@@ -925,18 +988,37 @@ extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	return launch_check("v_step_explicit");
 }
 
-extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double dt) {
+// itbase: instance whose tracer densities the column update is subtracted from (the update instance in the
+// reference; the initial instance when the CopyData in front of the call was folded away)
+static int v_step_implicit_impl(tmx_engine * e, int iinit, int iupd, double dt, int itbase) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	if (e->sw) return TMX_OK;      // VerticalDynamicsStub
 	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
 	KParams p = make_params(e);
+	const double * w0 = inst(e, iinit) + (size_t)TMX_SLAB_W(e->L, 0) * e->NS;
+	if (e->nt > 0 && iinit == iupd) {
+		// in place: the state kernel overwrites W, the tracer update needs the initial one (m_dColumnState)
+		HIPCHK(hipMemcpyAsync(e->d_w0, w0, (size_t)(e->L + 1) * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		w0 = e->d_w0;
+	}
 	if (e->vi_mode == 1) {
 		{ ProfScope ps(e, TMX_K_VI_ASSEMBLE); tmxk_vi_assemble(e, p, inst(e, iinit), dt); }
 		{ ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_solve(e, p, inst(e, iinit), inst(e, iupd)); }
 	} else {
 		ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_fused(e, p, inst(e, iinit), inst(e, iupd), dt);
 	}
+	if (e->nt > 0) {
+		// UpdateColumnTracers with the updated W, duplicates, then VerticalDynamicsFEM::FilterNegativeTracers
+		ProfScope ps(e, TMX_K_VI_SOLVE);
+		REQUIRE(tmxk_vi_tracers(e, p, inst(e, iinit), w0, inst(e, itbase), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
+			"tracer column update: %d levels do not fit the LDS working set", e->L);
+		tmxk_v_filter_tracers(e, p, inst(e, iupd));
+	}
 	return launch_check("v_step_implicit");
+}
+
+extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double dt) {
+	return v_step_implicit_impl(e, iinit, iupd, dt, iupd);
 }
 
 static int exchange(tmx_engine * e, const KParams & p, double * x) {
@@ -1034,10 +1116,12 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	} else {
 		double scale = 1.0;
 		if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0); }
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0); }
 		if ((r = launch_check("hypervis pass 1"))) return r;
 		if ((r = tmx_apply_dss(e, iwork))) return r;
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale); }
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, 1); }
 		if ((r = launch_check("hypervis pass 2"))) return r;
 		if ((r = tmx_apply_dss(e, iupd))) return r;
 	}
@@ -1241,6 +1325,7 @@ static int build_program(int scheme, int first, int last, double dt, Program & p
 extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, int iupd, double dt) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	REQUIRE(iinit != iupd && dt != 0.0, TMX_ERR_INVALID, "StepImplicitTermsExplicitly: distinct instances and non-zero dt required");
+	REQUIRE(e->nt == 0, TMX_ERR_UNSUPPORTED, "StepImplicitTermsExplicitly (ARK232) with tracers is not supported");
 	ProfScope ps(e, TMX_K_VI_ASSEMBLE);
 	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	return launch_check("v_step_implicit_terms_explicitly");
@@ -1269,7 +1354,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
 				if (!e->sw && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
 					if ((r = copy_uv(e, o.a, o.b))) return r;
-					if ((r = tmx_v_step_implicit(e, o.a, o.b, p[j].coef))) return r;
+					if ((r = v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a))) return r;
 					i = j; break;
 				}
 			}

@@ -19,6 +19,8 @@
 #define TMX_SLAB_T(L,k) (2 * (L) + (k))
 #define TMX_SLAB_R(L,k) (3 * (L) + (k))
 #define TMX_SLAB_W(L,k) (4 * (L) + (k))
+// tracer c, level k (after the 5L+1 state slabs)
+#define TMX_SLAB_Q(L,c,k) (5 * (L) + 1 + (c) * (L) + (k))
 
 // 2-D (per column) geometry slabs
 enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS,
@@ -73,6 +75,10 @@ struct tmx_engine {
 	std::vector<double> h_g2d, h_g3n, h_g3e;
 	std::vector<double> h_ops;
 	std::vector<double> h_eta;               // [2L+1] 1 - eta (levels, then interfaces); empty until metric factors are set
+	int nt = 0;                              // tracers
+	std::vector<double> h_area;              // [L][NS] element_area_node (tracer filters)
+	double * d_area = nullptr;
+	double * d_w0 = nullptr;                 // [L+1][NS] W of the initial column, saved when StepImplicit runs in place
 	bool metric_closed = false;              // kernels evaluate the 3-D metric in registers
 	double * d_eta = nullptr;
 	// Rayleigh friction (tmx_set_patch_rayleigh): strength [2L+1][NS] (levels, then interfaces) and reference
@@ -140,3 +146,8 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
+// tracers (rows H8 / V8)
+void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
+void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);
+int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
+void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);

@@ -452,7 +452,7 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 // by the neighbouring group tiles while they still sit in that XCD's L2 (74 -> 68 us).
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
-	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat)
+	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat, int nt)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -522,6 +522,18 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 			if (loc[m] && (t == 0 || lev)) x[(size_t)slabs[t] * NS + c[m]] = out[t][m];
+	// tracer densities: scalars on levels (ApplyDSS(DataType_Tracers))
+	if (lev) {
+		for (int q = 0; q < nt; q++) {
+			const size_t sl = (size_t)TMX_SLAB_Q(L, q, kk);
+			double w[4];
+#pragma unroll
+			for (int m = 0; m < 4; m++) w[m] = (m < n) ? ptr[m][sl * str[m]] : 0.0;
+			const double a = avg(w);
+#pragma unroll
+			for (int m = 0; m < 4; m++) if (loc[m]) x[sl * NS + c[m]] = a;
+		}
+	}
 }
 
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
@@ -530,7 +542,7 @@ void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
 	dim3 blk(64, 4), grd(8 * ((nx + 7) / 8) * ny);
 	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, (const int *)e->d_ghost_base,
 		(const int *)e->d_ghost_stride, e->ngroups,
-		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat);
+		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat, e->nt);
 }
 
 // HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
@@ -576,6 +588,371 @@ __global__ __launch_bounds__(256) void k_rayleigh(int L, int NS_, int ncol, doub
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
 	hipLaunchKernelGGL(k_rayleigh, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracer transport.  Tracer densities are node scalars stored as extra slabs
+// TMX_SLAB_Q(L, c, k) behind the state slabs, so copies, linear combinations, packing and the exchange treat
+// them like any other slab.  The kernels below are the tracer parts of the reference's state operators.
+
+// H explicit, tracer part (HorizontalDynamicsFEM.cpp:1090-1100, :1531-1553) + FilterNegativeTracers (:213-317):
+// rho q <- base - dt / J * (weak divergence of J u^a rho q, J u^b rho q) with the mass-flux base of the state
+// update (same contravariant velocities, recomputed here), then per element and level: clip negatives, rescale the
+// positive values so that the element mass is unchanged.
+__global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const double * __restrict__ area,
+	const double * __restrict__ xin, const double * xbase, double * xup, double dt)
+{
+	__shared__ double s[4][4][64];
+	__shared__ double sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	if (ty * 64 + lane < 16) sS[ty * 64 + lane] = p.stiff[ty * 64 + lane];
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const int k = blockIdx.y * 4 + ty;
+	const bool act = (k < L) && (col < p.ncol);
+	const int kc = (k < L) ? k : L - 1;
+	const unsigned cb = (unsigned)col * 8u;
+	double fa = 0.0, fb = 0.0, invJ = 0.0, ar = 0.0;
+	if (act) {
+		const double ua = ldu(xin + TMX_SLAB_U(L, kc) * NS, cb), ub = ldu(xin + TMX_SLAB_V(L, kc) * NS, cb);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, kc) * NS, cb), we1 = ldu(xin + TMX_SLAB_W(L, kc + 1) * NS, cb);
+		const double c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb), c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb), c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		const double jn = ldu(p.g2d + G2_JN * NS, cb);
+		double ca2, cb2, cx2;
+		metric_node3(p, met_col(p, col), kc, col, ca2, cb2, cx2);
+		double ux = 0.0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, kc, 0) * we0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, kc, 1) * we1;
+		const double conUa = c2a0 * ua + c2a1 * ub + ca2 * ux;
+		const double conUb = c2a1 * ua + c2b1 * ub + cb2 * ux;
+		fa = jn * conUa; fb = jn * conUb; invJ = 1.0 / jn;
+		ar = ldu(area + (size_t)kc * NS, cb);
+	}
+	s[ty][3][lane] = ar;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	for (int c = 0; c < nt; c++) {
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
+		const double qv = act ? ldu(xin + so, cb) : 0.0;
+		const double bv = act ? ldu(xbase + so, cb) : 0.0;
+		__syncthreads();
+		s[ty][0][lane] = fa * qv; s[ty][1][lane] = fb * qv;
+		__syncthreads();
+		double da = 0.0, db = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			da -= s[ty][0][eb + 4 * t + j] * sS[i * 4 + t];
+			db -= s[ty][1][eb + 4 * i + t] * sS[j * 4 + t];
+		}
+		da *= p.inv_da; db *= p.inv_da;
+		double out = bv - dt * invJ * (da + db);
+		s[ty][2][lane] = out;
+		__syncthreads();
+		double total = 0.0, nonneg = 0.0;
+#pragma unroll
+		for (int n = 0; n < 16; n++) {
+			const double qq = s[ty][2][eb + n];
+			const double pm = qq * s[ty][3][eb + n];
+			total += pm;
+			if (qq >= 0.0) nonneg += pm;
+		}
+		const double r = total / nonneg;
+		out = (out > 0.0) ? out * r : 0.0;
+		if (act) stu(xup + so, cb, out);
+	}
+}
+
+void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_h_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt);
+}
+
+// ApplyScalarHyperdiffusion, tracer branch (HorizontalDynamicsFEM.cpp:1999-2035, :2076-2165) and, after the second
+// pass, FilterNegativeTracers (:2707).  xbase == nullptr: base 0 (the zeroed working instance of the first pass).
+__global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, const double * __restrict__ area,
+	const double * __restrict__ xsrc, const double * xbase, double * xout, double dt, double nu, int filter)
+{
+	__shared__ double s[4][4][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	if (ty * 64 + lane < 16) { sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const int k = blockIdx.y * 4 + ty;
+	const bool act = (k < L) && (col < p.ncol);
+	const int kc = (k < L) ? k : L - 1;
+	const unsigned cb = (unsigned)col * 8u;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, ar = 0;
+	if (act) {
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		jn = ldu(p.g2d + G2_JN * NS, cb);
+		if (filter) ar = ldu(area + (size_t)kc * NS, cb);
+	}
+	s[ty][3][lane] = ar;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	for (int c = 0; c < nt; c++) {
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
+		const double psi = act ? ldu(xsrc + so, cb) : 0.0;
+		const double bv = (act && xbase) ? ldu(xbase + so, cb) : 0.0;
+		__syncthreads();
+		s[ty][0][lane] = psi;
+		__syncthreads();
+		double da = 0.0, db = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			da += s[ty][0][eb + 4 * t + j] * sD[t * 4 + i];
+			db += s[ty][0][eb + 4 * i + t] * sD[t * 4 + j];
+		}
+		da *= p.inv_da; db *= p.inv_da;
+		s[ty][1][lane] = jn * (c2a0 * da + c2a1 * db);
+		s[ty][2][lane] = jn * (c2a1 * da + c2b1 * db);
+		__syncthreads();
+		double ua = 0.0, ub = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			ua += s[ty][1][eb + 4 * t + j] * sS[i * 4 + t];
+			ub += s[ty][2][eb + 4 * i + t] * sS[j * 4 + t];
+		}
+		ua *= p.inv_da; ub *= p.inv_da;
+		double out = bv - dt * (1.0 / jn) * nu * (ua + ub);
+		if (filter) {
+			__syncthreads();
+			s[ty][0][lane] = out;
+			__syncthreads();
+			double total = 0.0, nonneg = 0.0;
+#pragma unroll
+			for (int n = 0; n < 16; n++) {
+				const double qq = s[ty][0][eb + n];
+				const double pm = qq * s[ty][3][eb + n];
+				total += pm;
+				if (qq >= 0.0) nonneg += pm;
+			}
+			const double r = total / nonneg;
+			out = (out > 0.0) ? out * r : 0.0;
+		}
+		if (act) stu(xout + so, cb, out);
+	}
+}
+
+void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_hypervis_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xsrc, xbase, xout, dt, nu, filter);
+}
+
+// VerticalDynamicsFEM::UpdateColumnTracers (VerticalDynamicsFEM.cpp:3783-4282), implicit mode, vertical order 1:
+// one lane per unique column.  The tridiagonal matrix (kl = ku = 1) is kept in LAPACK band storage
+// AB(i, j) = sm[(j * 4 + 2 + i - j)] and factorised / solved with the dgbtf2 / dgbtrs loops (first-maximum
+// pivoting, column-oriented back substitution) -- the restatement oracle/tmx_oracle.c:orc_dgbsv pins against
+// LAPACK -- once per tracer on a fresh copy, which is what dgbtrf + dgbtrs per tracer compute.
+// xin: initial instance (U, V, tracer densities), w0: W of the initial column [L+1][NS] (a saved copy when the step
+// runs in place and the state kernel has already overwritten it), xup: update instance (updated W; receives the tracers),
+// xbase: instance holding the tracer values the update is subtracted from (the update instance itself in the
+// reference; the initial instance when the preceding CopyData was fused away).
+__global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
+	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag)
+{
+	extern __shared__ double smt[];
+	const int L = p.L, lane = threadIdx.x;
+	const size_t NS = (size_t)p.NS;
+	double * A = smt;                        // [L][4][64] band matrix, rebuilt and factorised per tracer
+	double * F = A + (size_t)L * 4 * 64;     // [L][64] right-hand side / solution
+	double * xd0 = F + (size_t)L * 64;       // [L+1][64] xi_dot of the initial column on interfaces
+	double * xd1 = xd0 + (size_t)(L + 1) * 64;   // [L+1][64] xi_dot with the updated W
+	double * qn = xd1 + (size_t)(L + 1) * 64;    // [L][64] tracer density of the column
+	const int u = blockIdx.x * 64 + lane;
+	if (u >= nunique) return;
+	const int col = ucol[u];
+	const MetCol mc = met_col(p, col);
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+#define ABW(i_, j_) A[((size_t)(j_) * 4 + 2 + (i_) - (j_)) * 64 + lane]
+	// U,V on interfaces (InterpolateNodeToREdge of the initial column), xi_dot initial / updated (:3943-3957, :4059-4086)
+	for (int k = 0; k <= L; k++) {
+		double x0v = 0.0, x1v = 0.0;
+		if (k >= 1 && k <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = k + off;
+				if (l < 0 || l >= L) continue;
+				const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
+				ue += cc * xin[(size_t)TMX_SLAB_U(L, l) * NS + col];
+				ve += cc * xin[(size_t)TMX_SLAB_V(L, l) * NS + col];
+			}
+			double e0, e1, e2;
+			metric_edge(p, mc, k, col, e0, e1, e2);
+			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)k * NS + col];
+			x1v = e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
+		}
+		xd0[(size_t)k * 64 + lane] = x0v; xd1[(size_t)k * 64 + lane] = x1v;
+	}
+	// The matrix (the same for every tracer; the reference factorises it once) is cheap to rebuild from xi_dot, which
+	// keeps the LDS footprint at (8L + 2) x 512 bytes.
+	auto assemble = [&]() {
+		for (int t = 0; t < L * 4; t++) A[(size_t)t * 64 + lane] = 0.0;
+		// d F_k / d q_n: DiffREdgeToNode x J_e / J_n x InterpNodeToREdge x xi_dot (:3959-3976); J is level-independent
+		for (int k = 0; k < L; k++)
+			for (int mo = 0; mo <= 1; mo++) {
+				const int m = k + mo;                          // DiffREdgeToNode row k touches interfaces k, k+1
+				const double dc = OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, mo);
+				for (int no = -2; no <= 1; no++) {
+					const int n = m + no;                      // InterpNodeToREdge row m: nodes m-1, m (two-sided at the ends)
+					if (n < 0 || n >= L) continue;
+					if (n - k < -1 || n - k > 1) continue;     // outside the band the coefficient is structurally zero
+					ABW(k, n) += dc * je / jn * OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, no) * xd0[(size_t)m * 64 + lane];
+				}
+			}
+		// upwinding in the Jacobian (:3978-4016): interface a, weight |xi_dot_a|
+		for (int a = 1; a < L; a++) {
+			const double wgt = fabs(xd0[(size_t)a * 64 + lane]);
+			ABW(a - 1, a - 1) -= wgt * OPC(TMX_OP_PENALTY_LEFT, a - 1, 0);
+			ABW(a - 1, a) -= wgt * OPC(TMX_OP_PENALTY_LEFT, a - 1, 1);
+			ABW(a, a - 1) -= wgt * OPC(TMX_OP_PENALTY_RIGHT, a, -1);
+			ABW(a, a) -= wgt * OPC(TMX_OP_PENALTY_RIGHT, a, 0);
+		}
+		for (int k = 0; k < L; k++) ABW(k, k) += 1.0 / dt;
+	};
+
+	int dep[3];
+#pragma unroll
+	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	bool singular = false;
+	for (int c = 0; c < nt; c++) {
+		for (int k = 0; k < L; k++) qn[(size_t)k * 64 + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		// mass flux with the updated xi_dot, its divergence (:4092-4140)
+		for (int k = 0; k < L; k++) {
+			double mf[2];
+			for (int mo = 0; mo <= 1; mo++) {
+				const int m = k + mo;
+				double qe = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn[(size_t)l * 64 + lane];
+				}
+				mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd1[(size_t)m * 64 + lane];
+			}
+			double dmf = 0.0;
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[1];
+			F[(size_t)k * 64 + lane] = dmf / jn;
+		}
+		// upwinding with the initial xi_dot (LinearColumnDiscPenaltyFEM::Apply; :4153-4181)
+		for (int k = 0; k < L; k++) {
+			double aux = 0.0;
+			if (k < L - 1) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn[(size_t)k * 64 + lane];
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn[(size_t)(k + 1) * 64 + lane];
+				aux += b * fabs(xd0[(size_t)(k + 1) * 64 + lane]);
+			}
+			if (k > 0) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn[(size_t)(k - 1) * 64 + lane];
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn[(size_t)k * 64 + lane];
+				aux += b * fabs(xd0[(size_t)k * 64 + lane]);
+			}
+			F[(size_t)k * 64 + lane] -= aux;
+		}
+		// implicit velocity correction (:4183-4233)
+		for (int a = 1; a < L; a++) {
+			const double xa = xd0[(size_t)a * 64 + lane];
+			double e0, e1, e2;
+			metric_edge(p, mc, a, col, e0, e1, e2);
+			const double sw = (xa > 0.0) ? 1.0 * e2 : ((xa < 0.0) ? -1.0 * e2 : 0.0);
+			const double jump = sw * (xup[(size_t)TMX_SLAB_W(L, a) * NS + col] - w0[(size_t)a * NS + col]);
+			double f = F[(size_t)(a - 1) * 64 + lane];
+			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 0) * qn[(size_t)(a - 1) * 64 + lane] * jump;
+			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 1) * qn[(size_t)a * 64 + lane] * jump;
+			F[(size_t)(a - 1) * 64 + lane] = f;
+			f = F[(size_t)a * 64 + lane];
+			f -= OPC(TMX_OP_PENALTY_RIGHT, a, -1) * qn[(size_t)(a - 1) * 64 + lane] * jump;
+			f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * 64 + lane] * jump;
+			F[(size_t)a * 64 + lane] = f;
+		}
+		// dgbtf2 (kl = ku = 1, kv = 2) on a fresh matrix, forward substitution with the interchanges, dtbsv
+		assemble();
+		int ju = 0;
+		for (int jj = 0; jj < L; jj++) {
+			if (jj + 2 < L) ABW(jj + 2 - 2, jj + 2) = 0.0;         // fill-in super-diagonal of column jj + kv
+			const int km = (jj < L - 1) ? 1 : 0;
+			int jp = 0;
+			if (km && fabs(ABW(jj + 1, jj)) > fabs(ABW(jj, jj))) jp = 1;
+			const double piv = ABW(jj + jp, jj);
+			if (piv != 0.0) {
+				int tt = jj + 1 + jp; if (tt > L - 1) tt = L - 1;
+				if (tt > ju) ju = tt;
+				if (jp) for (int cc = jj; cc <= ju; cc++) { const double tmp = ABW(jj + 1, cc); ABW(jj + 1, cc) = ABW(jj, cc); ABW(jj, cc) = tmp; }
+				if (km) {
+					const double r = 1.0 / ABW(jj, jj);
+					ABW(jj + 1, jj) *= r;
+					for (int cc = jj + 1; cc <= ju; cc++) {
+						const double uu = ABW(jj, cc);
+						if (uu != 0.0) ABW(jj + 1, cc) -= ABW(jj + 1, jj) * uu;
+					}
+				}
+				// forward substitution of this column (dgbtrs): interchange, then eliminate
+				if (jj < L - 1) {
+					if (jp) { const double tmp = F[(size_t)(jj + 1) * 64 + lane]; F[(size_t)(jj + 1) * 64 + lane] = F[(size_t)jj * 64 + lane]; F[(size_t)jj * 64 + lane] = tmp; }
+					F[(size_t)(jj + 1) * 64 + lane] -= F[(size_t)jj * 64 + lane] * ABW(jj + 1, jj);
+				}
+			} else singular = true;
+		}
+		for (int jj = L - 1; jj >= 0; jj--) {
+			double bj = F[(size_t)jj * 64 + lane];
+			if (bj != 0.0) {
+				bj /= ABW(jj, jj);
+				F[(size_t)jj * 64 + lane] = bj;
+				const int lo = (jj - 2 < 0) ? 0 : jj - 2;
+				for (int ii = jj - 1; ii >= lo; ii--) F[(size_t)ii * 64 + lane] -= bj * ABW(ii, jj);
+			}
+		}
+		for (int k = 0; k < L; k++) {
+			const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
+			const double val = xbase[so + col] - F[(size_t)k * 64 + lane];
+			xup[so + col] = val;
+#pragma unroll
+			for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[so + dep[t]] = val;
+		}
+	}
+	if (singular) atomicExch(flag, 1);
+#undef ABW
+}
+
+int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
+	if (e->nunique == 0 || e->nt == 0) return 0;
+	const size_t lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 64 * sizeof(double);
+	if (lds > 160 * 1024) return -1;
+	hipFuncSetAttribute((const void *)k_vi_tracers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(k_vi_tracers, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt,
+		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag);
+	return 0;
+}
+
+// VerticalDynamicsFEM::FilterNegativeTracers (VerticalDynamicsFEM.cpp:4286-4347): per stored column and tracer
+__global__ __launch_bounds__(256) void k_v_filter_tracers(KParams p, int nt, const double * __restrict__ area, double * x) {
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	const int c = blockIdx.y;
+	if (col >= p.ncol || c >= nt) return;
+	double total = 0.0, nonneg = 0.0;
+	for (int k = 0; k < L; k++) {
+		const double q = x[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		const double pm = q * area[(size_t)k * NS + col];
+		total += pm;
+		if (q >= 0.0) nonneg += pm;
+	}
+	const double r = total / nonneg;
+	for (int k = 0; k < L; k++) {
+		const size_t o = (size_t)TMX_SLAB_Q(L, c, k) * NS + col;
+		const double q = x[o];
+		x[o] = (q > 0.0) ? q * r : 0.0;
+	}
+}
+
+void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x) {
+	if (e->nt == 0) return;
+	hipLaunchKernelGGL(k_v_filter_tracers, dim3((p.ncol + 255) / 256, e->nt), dim3(256), 0, e->stream, p, e->nt, (const double *)e->d_area, x);
 }
 
 // gather the copies other ranks need into the send buffer, one contiguous message per peer:

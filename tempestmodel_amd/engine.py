@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TMX_LIBRARY: developer override to A/B an alternative build of the same ABI (e.g. the -DTMX_VI_TIMING variant)
 LIB_PATH = os.environ.get("TMX_LIBRARY") or os.path.join(_HERE, "libtempest_mi355x.so")
 
-TMX_ABI_VERSION = 3
+TMX_ABI_VERSION = 4
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
             "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
             "penalty_left", "penalty_right"]
 GEOM_FIELDS = ["jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "jacobian", "jacobian_redge",
                "contra_metric_a", "contra_metric_b", "contra_metric_xi",
                "contra_metric_a_redge", "contra_metric_b_redge", "contra_metric_xi_redge",
-               "deriv_r_node", "deriv_r_redge", "coriolis_f", "topography"]
+               "deriv_r_node", "deriv_r_redge", "coriolis_f", "topography", "element_area_node"]
 KERNEL_NAMES = ["h_explicit", "v_explicit", "vi_assemble", "vi_solve", "dss", "hypervis", "lincomb", "exchange"]
 
 PD = C.POINTER(C.c_double)
@@ -90,6 +90,8 @@ def load_library():
     lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
+    lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
+    lib.tmx_download_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     _lib = lib
@@ -125,7 +127,8 @@ class Engine:
         cfg = TmxConfig()
         cfg.abi_version = TMX_ABI_VERSION
         cfg.horizontal_order, cfg.vertical_order = grid.np, 1
-        cfg.levels, cfg.n_patches, cfg.n_instances, cfg.n_tracers = grid.L, self.npatch, n_instances, 0
+        self.ntracers = int(getattr(grid, "ntracers", 0))
+        cfg.levels, cfg.n_patches, cfg.n_instances, cfg.n_tracers = grid.L, self.npatch, n_instances, self.ntracers
         cfg.hypervis_order = hypervis_order
         cfg.element_delta_a, cfg.reference_length = grid.delta_a, grid.reference_length
         ph = grid.phys
@@ -245,6 +248,21 @@ class Engine:
             else:
                 self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n), _pd(e)))
             out[p] = (n, e)
+        return out
+
+    def upload_tracers(self, instance, tracers):
+        """``tracers[p] = [n_tracers][na][nb][L]`` (GridPatch::GetDataTracers) for every patch (remote ones ignored)."""
+        for p in self.local_patches:
+            t = np.ascontiguousarray(tracers[p], dtype=np.float64)
+            self._chk(self.lib.tmx_upload_tracers(self.h, p, instance, _pd(t)))
+
+    def download_tracers(self, instance):
+        out = [None] * self.npatch
+        for p in self.local_patches:
+            P = self.grid.patches[p]
+            t = np.zeros((self.ntracers, P.na, P.nb, self.L))
+            self._chk(self.lib.tmx_download_tracers(self.h, p, instance, _pd(t)))
+            out[p] = t
         return out
 
     # -- C ABI, one method per entry point -----------------------------------------------------------

@@ -121,6 +121,71 @@ def test_ars343_steps_vs_reference_and_oracle(fixture, ne, L, npatch, dt, tags):
         e.close()
 
 
+def test_tracer_percall_chain():
+    """SURVEY rows H8 / V8 on the device: every tracer operation against the C oracle and the reference's own output
+    (fixture percall_tracers_ne3_L6_p6.npz: JW state + two closed-form tracer densities, one with compact support so
+    that both FilterNegativeTracers variants act)."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("percall_tracers_ne3_L6_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, ntracers=2)
+    dt = float(d["cfg/dt"][0]); sdt = dt * gu.ARS343_GAMMA
+    e = Engine(g); o = Oracle(g)
+    try:
+        st, tr = gu.full_states(d, "warm", 6), gu.full_tracers(d, "warm", 6)
+        o.set_state(0, st); o.set_tracers(0, tr); e.upload_state(0, st); e.upload_tracers(0, tr)
+        assert max(gu.tracer_errors(e.download_tracers(0), tr)) == 0.0
+
+        def cmp(ie, io, tag, tol):
+            e.sync()
+            got = e.download_tracers(ie)
+            assert max(gu.tracer_errors(got, o.get_tracers(io))) < tol, tag
+            assert max(gu.tracer_errors(got, gu.full_tracers(d, tag, 6))) < tol, tag
+            assert max(gu.prognostic_errors(e.download_state(ie), o.get_state(io))) < 1e-11, tag
+
+        o.copy_data(0, 1); e.copy_data(0, 1)
+        o.h_step_explicit(0, 1, sdt); e.h_step_explicit(0, 1, sdt); cmp(1, 1, "h_explicit", TOL_CALL)
+        o.v_step_explicit(0, 1, sdt); e.v_step_explicit(0, 1, sdt); cmp(1, 1, "v_explicit", TOL_CALL)
+        o.apply_dss(1); e.apply_dss(1); cmp(1, 1, "dss", TOL_CALL)
+        o.copy_data(1, 2); e.copy_data(1, 2)
+        assert o.v_step_implicit(2, 2, sdt) == 0
+        e.v_step_implicit(2, 2, sdt); cmp(2, 2, "v_implicit", 1e-11)
+        o.h_step_after_subcycle(2, 3, 4, dt); e.h_step_after_subcycle(2, 3, 4, dt)
+        cmp(4, 4, "hypervis_work", 1e-11); cmp(3, 3, "hypervis", 1e-11)
+        cf = [0.25, -0.5, 1.75, 0.5, 0, 0, 0]
+        o.linear_combine_data(cf, 3); e.linear_combine_data(cf, 3); cmp(3, 3, "lincomb", 1e-11)
+    finally:
+        e.close()
+
+
+def test_tracer_steps_vs_reference_and_oracle():
+    """Whole ARS343 steps with two tracers (production program incl. the fused paths) from the reference's state after
+    step 1; also the other steppers' generic operations through ARS232."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("steps_tracers_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, ntracers=2)
+    st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
+    o = Oracle(g); o.set_state(0, st); o.set_tracers(0, tr)
+    e = Engine(g); e.upload_state(0, st); e.upload_tracers(0, tr)
+    try:
+        for step in (2, 3, 4):
+            assert o.step_ars343(200.0) == 0
+            e.step_ars343(200.0)
+            e.sync()
+            got = e.download_tracers(0)
+            assert max(gu.tracer_errors(got, o.get_tracers(0))) < 1e-11, step
+            assert max(gu.tracer_errors(got, gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-11, step
+            assert max(gu.prognostic_errors(e.download_state(0), gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS, step
+        for _ in range(2):
+            assert o.step("ars232", 200.0) == 0
+            e.step("ars232", 200.0)
+        e.sync()
+        assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) < 1e-11
+    finally:
+        e.close()
+
+
 def test_hundred_steps_ne4_L10():
     """North-star gate: fp64 state difference < 1e-10 after 100 ARS343 steps (vs the oracle, same inputs)."""
     from tempestmodel_amd.engine import Engine
