@@ -16,6 +16,10 @@
 #define main tmx_unused_jw_main
 #include "BaroclinicWaveJWTest.cpp"
 #undef main
+#define main tmx_unused_schar_main
+#include "ScharMountainSphereTest.cpp"
+#undef main
+#include "test_inputs.h"       // JWWithTracers: the JW state plus closed-form tracer densities (a test input of ours)
 
 #include "TempestMI355X.h"
 
@@ -87,6 +91,9 @@ static void save(GridGLL * pGrid, Snapshot & s) {
 			DataArray4D<double> & d = p->GetDataState(0, loc ? DataLocation_REdge : DataLocation_Node);
 			s.push_back(std::vector<double>(&d[0][0][0][0], &d[0][0][0][0] + d.GetTotalSize()));
 		}
+		DataArray4D<double> & t = p->GetDataTracers(0);
+		if (t.GetSize(0) > 0) s.push_back(std::vector<double>(&t[0][0][0][0], &t[0][0][0][0] + t.GetTotalSize()));
+		else s.push_back(std::vector<double>());
 	}
 }
 
@@ -99,13 +106,16 @@ static void restore(GridGLL * pGrid, const Snapshot & s) {
 			memcpy(&d[0][0][0][0], &s[q][0], s[q].size() * sizeof(double));
 			q++;
 		}
+		DataArray4D<double> & t = p->GetDataTracers(0);
+		if (t.GetSize(0) > 0) memcpy(&t[0][0][0][0], &s[q][0], s[q].size() * sizeof(double));
+		q++;
 	}
 }
 
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
-	std::string mode = "production";
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1;
+	std::string mode = "production", tcase = "jw";
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -118,13 +128,19 @@ int main(int argc, char ** argv) {
 		else if (a == "--patches") { npatch = atoi(v); i++; }
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--tol") { tol = atof(v); i++; }
+		else if (a == "--case") { tcase = v; i++; }
+		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	int status = 1;
 try {
 	AnnounceSetVerbosityLevel(0);
-	Model model(EquationSet::PrimitiveNonhydrostaticEquations);
-	Time timeDeltaT(0, 0, 0, (int)dt, 0, Time::CalendarNoLeap, Time::TypeDelta);
+	EquationSet eqn(EquationSet::PrimitiveNonhydrostaticEquations);
+	for (int c = 0; c < ntracers; c++) { char nm[16]; snprintf(nm, 16, "RhoQ%d", c); eqn.InsertTracer(nm, nm); }
+	UserDataMeta metaUserData;
+	Model model(eqn, metaUserData);
+	const int isec = (int)dt, iusec = (int)((dt - isec) * 1.0e6 + 0.5);
+	Time timeDeltaT(0, 0, 0, isec, iusec, Time::CalendarNoLeap, Time::TypeDelta);
 	model.SetDeltaT(timeDeltaT);
 	model.SetEndTime(model.GetStartTime());
 
@@ -141,7 +157,15 @@ try {
 		Grid::VerticalDiscretization_FiniteElement, Grid::VerticalStaggering_Lorenz);
 	pGrid->InitializeDataLocal();
 	model.SetGrid(pGrid, npatch);
-	model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, BaroclinicWaveJWTest::PerturbationType_Exp));
+	if (tcase == "schar") {
+		// ScharMountainSphereTest.cpp defaults: reduced planet X = 500, no rotation, Rayleigh layer above 20 km
+		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
+		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
+	} else if (ntracers > 0) {
+		model.SetTestCase(new JWWithTracers(0.0, ztop, BaroclinicWaveJWTest::PerturbationType_Exp, ntracers));
+	} else {
+		model.SetTestCase(new BaroclinicWaveJWTest(0.0, ztop, BaroclinicWaveJWTest::PerturbationType_Exp));
+	}
 	model.Go();     // initialisation only (end time == start time)
 
 	Time time = model.GetStartTime();
@@ -160,11 +184,23 @@ try {
 
 	// compare prognostic slots on interior nodes
 	const int L = levels;
-	double dmax[5] = {0, 0, 0, 0, 0}, smax[5] = {0, 0, 0, 0, 0};
+	double dmax[5] = {0, 0, 0, 0, 0}, smax[5] = {0, 0, 0, 0, 0}, tdmax = 0.0, tsmax = 0.0;
 	int q = 0;
 	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
 		const PatchBox & box = pGrid->GetActivePatch(n)->GetPatchBox();
 		const int nA = box.GetATotalWidth(), nB = box.GetBTotalWidth();
+		// tracers (third snapshot entry of the patch)
+		{
+			const size_t per = (size_t)nA * nB * L;
+			const std::vector<double> & tg = got[q + 2], & tr = ref[q + 2];
+			for (size_t c = 0; c * per < tr.size(); c++)
+				for (int i = 1; i < nA - 1; i++) for (int j = 1; j < nB - 1; j++) for (int k = 0; k < L; k++) {
+					const size_t o = c * per + ((size_t)i * nB + j) * L + k;
+					const double d = fabs(tg[o] - tr[o]), sv = fabs(tr[o]);
+					if (d > tdmax) tdmax = d;
+					if (sv > tsmax) tsmax = sv;
+				}
+		}
 		for (int loc = 0; loc < 2; loc++, q++) {
 			const int Lk = loc ? L + 1 : L;
 			for (int c = 0; c < 5; c++) {
@@ -177,6 +213,7 @@ try {
 				}
 			}
 		}
+		q++;     // skip the tracer entry
 	}
 	double worst = 0.0;
 	printf("adapter %s ne%d L%d patches=%d steps=%d: max rel diff vs reference (U V rhotheta W rho):", mode.c_str(), ne, levels, npatch, nsteps);
@@ -185,6 +222,12 @@ try {
 		printf(" %.3e", r);
 		if (r > worst) worst = r;
 	}
+	if (ntracers > 0) {
+		const double r = (tsmax > 0) ? tdmax / tsmax : tdmax;
+		printf("  tracers %.3e", r);
+		if (r > worst) worst = r;
+	}
+	if (pGrid->HasRayleighFriction()) printf("  [Rayleigh friction active]");
 	printf("\n");
 	status = (worst < tol) ? 0 : 1;
 	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",

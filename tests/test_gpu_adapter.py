@@ -18,12 +18,17 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6"]),
     ("production", ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
     ("parity", ["--ne", "4", "--levels", "10", "--steps", "3", "--patches", "6"]),
+    # row H7: Schar mountain on the reduced-radius sphere, Rayleigh layer (dt 0.5 s)
+    ("production", ["--case", "schar", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6", "--dt", "0.5"]),
+    # rows H8 / V8: two tracer densities
+    ("production", ["--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
+    ("parity", ["--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6"]),
 ])
 def test_reference_driver_with_adapter_plugins(mode, args):
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/tmx_adapter_run not built (needs /root/reference)")
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
-    r = subprocess.run([BIN, "--mode", mode, "--dt", "200", "--warm", "1", "--tol", "1e-10"] + args,
+    r = subprocess.run([BIN, "--mode", mode, "--dt", "200", "--warm", "1", "--tol", "1e-10"] + args,     # a later --dt overrides
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     tail = "\n".join(r.stdout.splitlines()[-6:])
     print(tail)
