@@ -25,8 +25,10 @@
 #include "VerticalDynamics.h"
 #include "TimestepScheme.h"
 #include "Exception.h"
+#include "WorkflowProcess.h"
 
 #include "tempest_mi355x.h"
+#include "WorkflowProcess.h"
 
 #include <cmath>
 #include <map>
@@ -423,6 +425,42 @@ public:
 		MI355XEngine::Check(tmx_step_ars343(eng.Handle(), dDeltaT));
 		MI355XEngine::Check(tmx_sync(eng.Handle()));
 		eng.Download(0);
+	}
+};
+
+///////////////////////////////////////////////////////////////////////////////
+
+///	<summary>
+///		HeldSuarezPhysics (src/atm/HeldSuarezPhysics.h) on the device: a WorkflowProcess with the same constructor,
+///		attached with Model::AttachWorkflowProcess exactly like the reference class.
+///	</summary>
+class HeldSuarezPhysicsMI355X : public WorkflowProcess {
+public:
+	HeldSuarezPhysicsMI355X(Model & model, const Time & timeFrequency) :
+		WorkflowProcess(model, timeFrequency) { }
+
+	virtual void Perform(const Time & time) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		tmx_engine * pEngine = eng.Handle();
+		Grid * pGrid = m_model.GetGrid();
+		const PhysicalConstants & phys = m_model.GetPhysicalConstants();
+		// the "surface pressure" of HeldSuarezPhysics.cpp:99-101, formed on the reference's own arrays
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			const PatchBox & box = pPatch->GetPatchBox();
+			const DataArray4D<double> & dataREdge = pPatch->GetDataState(0, DataLocation_REdge);
+			DataArray2D<double> dPs(box.GetATotalWidth(), box.GetBTotalWidth());
+			for (int i = 0; i < box.GetATotalWidth(); i++)
+			for (int j = 0; j < box.GetBTotalWidth(); j++)
+				dPs[i][j] = phys.PressureFromRhoTheta(dataREdge[4][i][j][0] * dataREdge[2][i][j][0]);
+			MI355XEngine::Check(tmx_set_patch_physics_inputs(pEngine, pPatch->GetPatchIndex(),
+				&(pPatch->GetLatitude()[0][0]), &(dPs[0][0])));
+		}
+		eng.Upload(0);
+		MI355XEngine::Check(tmx_physics_held_suarez(pEngine, 0, m_timeFrequency.GetSeconds()));
+		MI355XEngine::Check(tmx_sync(pEngine));
+		eng.Download(0);
+		WorkflowProcess::Perform(time);
 	}
 };
 

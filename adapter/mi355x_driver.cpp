@@ -22,6 +22,7 @@
 #include "test_inputs.h"       // JWWithTracers: the JW state plus closed-form tracer densities (a test input of ours)
 
 #include "TempestMI355X.h"
+#include "HeldSuarezPhysics.h"
 
 #include <cstdio>
 #include <cstring>
@@ -115,7 +116,7 @@ static void restore(GridGLL * pGrid, const Snapshot & s) {
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 	std::string mode = "production", tcase = "jw";
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0;
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -130,6 +131,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--tol") { tol = atof(v); i++; }
 		else if (a == "--case") { tcase = v; i++; }
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
+		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing after every step
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	int status = 1;
@@ -172,14 +174,17 @@ try {
 	for (int s = 0; s < nwarm; s++) { pT->Step(s == 0, false, time, dt); time += timeDeltaT; }
 	Snapshot start, ref, got;
 	save(pGrid, start);
-	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); }
+	// column physics as WorkflowProcess (Model::Go calls Perform after every step, Model.cpp:477-481)
+	HeldSuarezPhysics hsRef(model, timeDeltaT);
+	HeldSuarezPhysicsMI355X hsDev(model, timeDeltaT);
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (physics) hsRef.Perform(time); }
 	save(pGrid, ref);
 
 	restore(pGrid, start);
 	if (mode == "production") { pT->m_fDevice = true; }
 	else if (mode == "parity") { pH->m_fDevice = true; pV->m_fDevice = true; }
 	else { fprintf(stderr, "bad mode\n"); return 2; }
-	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); }
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (physics) hsDev.Perform(time); }
 	save(pGrid, got);
 
 	// compare prognostic slots on interior nodes
@@ -228,6 +233,7 @@ try {
 		if (r > worst) worst = r;
 	}
 	if (pGrid->HasRayleighFriction()) printf("  [Rayleigh friction active]");
+	if (physics) printf("  [Held-Suarez physics after every step]");
 	printf("\n");
 	status = (worst < tol) ? 0 : 1;
 	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",

@@ -223,6 +223,20 @@ int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_AR
  * on every column (used by ARK232). */
 int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int i_initial, int i_update, double dt);
 
+/* ---- column physics as a WorkflowProcess on the device ------------------------ */
+
+/* Per owned patch: latitude [na][nb] (GridPatch::GetLatitude) and the "surface pressure" [na][nb] that
+ * HeldSuarezPhysics::Perform forms as PhysicalConstants::PressureFromRhoTheta(REdge[rho][i][j][0] * REdge[rhotheta][i][j][0])
+ * (src/atm/HeldSuarezPhysics.cpp:99-101).  With Lorenz staggering nothing on this path updates those interface
+ * slots after the test case filled them, and the engine does not store them, so the caller evaluates the
+ * expression on its own arrays (the adapter does, with the reference's PhysicalConstants) and hands it over. */
+int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const double * latitude, const double * surface_pressure);
+/* HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301) on `instance` with dDeltaT = dt: backward-Euler
+ * boundary-layer friction on U,V and the relaxation of rho*theta towards the Held-Suarez equilibrium temperature.
+ * Keeping the state on the device across Model::Go's physics call removes the download + upload per step that a
+ * host-side WorkflowProcess forces (src/atm/Model.cpp:477-481). */
+int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt);
+
 /* Wait for the engine's stream; reports a deferred TMX_ERR_SINGULAR from column solves. */
 int tmx_sync(tmx_engine * e);
 

@@ -1206,6 +1206,58 @@ void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Column physics: HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301), Lorenz staggering   */
+/* (rho*theta on levels).  Boundary-layer friction on U,V by backward Euler, Newtonian relaxation of       */
+/* rho*theta towards the Held-Suarez equilibrium temperature with the "Ullrich update" (:239-247).         */
+/* Quirks of the reference kept as they are: the friction's sigma uses PressureFromRhoTheta(rho * rhotheta) */
+/* (:107-110), and the surface pressure comes from the interface slots of rho and rho*theta (:99-101),     */
+/* which nothing updates with this staggering -- it is an input here (orc_patch.surf_p).                   */
+
+void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt) {
+	const int L = g->L;
+	const double gamma = g->cp / (g->cp - g->Rd), kappa = g->Rd / g->cp;
+	const double pscal = g->p0 * pow(g->Rd / g->p0, gamma);
+	const double bsig = 0.7, kf = 1.0 / 86400.0, ka = (1.0 / 40.0) / 86400.0, ks = (1.0 / 4.0) / 86400.0;
+	const double dty = 60.0, dthz = 10.0, tmin = 200.0, tmax = 315.0;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * nn = s->node[ix * g->npatch + p];
+#define NN(c,i,j,k) nn[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++) {
+			const double ps = P->surf_p[(size_t)i * nb + j];
+			for (int k = 0; k < L; k++) {
+				const double pr = pscal * exp(log(NN(RIx, i, j, k) * NN(PIx, i, j, k)) * gamma);
+				const double sigma = pr / ps;
+				double bs = (sigma - bsig) / (1.0 - bsig);
+				if (bs < 0.0) bs = 0.0;
+				NN(UIx, i, j, k) /= (1.0 + kf * bs * dt);
+				NN(VIx, i, j, k) /= (1.0 + kf * bs * dt);
+			}
+			for (int k = 0; k < L; k++) {
+				const double pr = pscal * exp(log(NN(PIx, i, j, k)) * gamma);
+				const double sigma = pr / ps;
+				double bs = (sigma - bsig) / (1.0 - bsig);
+				if (bs < 0.0) bs = 0.0;
+				const double T = pr / (NN(RIx, i, j, k) * g->Rd);
+				const double lat = P->lat[(size_t)i * nb + j];
+				const double sl = sin(lat), cl = cos(lat);
+				const double c4 = cl * cl * cl * cl;
+				const double kt = ka + (ks - ka) * bs * c4;
+				double teq = tmax - dty * sl * sl - dthz * log(pr / g->p0) * cl * cl;
+				teq *= pow(pr / g->p0, kappa);
+				if (teq < tmin) teq = tmin;
+				const double ddh = -kt / gamma * (1.0 + (gamma - 1.0) * teq / T);
+				const double dh = -kt / gamma * (1.0 - teq / T);
+				NN(PIx, i, j, k) *= 1.0 + dt / (1.0 - dt * ddh) * dh;
+			}
+		}
+#undef NN
+	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* ARS(3,4,3) IMEX step in U-form: TimestepSchemeARS343 (TimestepSchemeARS343.cpp:25-236)      */
 
 static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp, double * dimp) {

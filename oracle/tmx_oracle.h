@@ -67,6 +67,8 @@ typedef struct {
 	const double * ray_node; const double * ray_redge;
 	const double * ref_node; const double * ref_redge;
 	const double * area_node;          /* [na][nb][L] GridPatch::GetElementAreaNode (tracer filters; NULL without tracers) */
+	const double * lat;                /* [na][nb] GridPatch::GetLatitude (column physics; may be NULL) */
+	const double * surf_p;             /* [na][nb] the "surface pressure" HeldSuarezPhysics::Perform forms from the interface slots (may be NULL) */
 } orc_patch;
 
 typedef struct {
@@ -106,6 +108,9 @@ int  orc_step_ars343(const orc_grid * g, orc_state * s, double dt);
 void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
 /* scheme: 0 ARS343, 1 ARS232, 2 ARS222, 3 ARS443, 4 ARK232, 5 Strang (KGU35) */
 int  orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last, double dt);
+
+/* HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301) on instance ix */
+void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt);
 
 /* banded LU with partial pivoting, LAPACK dgbsv semantics (1 rhs); ab is [n][ldab] column-major band
  * storage with ldab = 2*kl+ku+1, entry (i,j) at ab[j*ldab + kl+ku+i-j].  Returns info. */

@@ -412,6 +412,34 @@ extern "C" int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const dou
 	return TMX_OK;
 }
 
+// Column physics inputs (latitude, Held-Suarez surface pressure) into two 2-D slabs
+extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const double * latitude, const double * surface_pressure) {
+	REQUIRE(e && latitude && surface_pressure, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "column physics with the shallow-water equation set is not supported");
+	int r = ensure_layout(e);
+	if (r) return r;
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
+	const size_t NS = e->NS;
+	std::vector<double> lat((size_t)P.nea * P.neb * TMX_NQ), ps(lat.size());
+	const int c0 = P.elem_base * TMX_NQ;
+	for (int i = 1; i < P.na - 1; i++)
+	for (int j = 1; j < P.nb - 1; j++) {
+		const int c = col_of(P, i, j);
+		lat[c - c0] = latitude[(size_t)i * P.nb + j];
+		ps[c - c0] = surface_pressure[(size_t)i * P.nb + j];
+		if (!e->finalized) { e->h_g2d[G2_LAT * NS + c] = lat[c - c0]; e->h_g2d[G2_PS * NS + c] = ps[c - c0]; }
+	}
+	if (e->finalized && !plan_only(e)) {       // may be refreshed at any time (the caller owns the source arrays)
+		HIPCHK(hipStreamSynchronize(e->stream));
+		HIPCHK(hipMemcpy(e->d_g2d + G2_LAT * NS + c0, lat.data(), lat.size() * sizeof(double), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(e->d_g2d + G2_PS * NS + c0, ps.data(), ps.size() * sizeof(double), hipMemcpyHostToDevice));
+	}
+	P.physics_set = true;
+	return TMX_OK;
+}
+
 // Rayleigh friction inputs (GridPatch::GetRayleighStrength / GetReferenceState), gathered into the device layout
 extern "C" int tmx_set_patch_rayleigh(tmx_engine * e, int patch, const double * strength_node, const double * strength_redge,
 	const double * ref_node, const double * ref_redge)
@@ -1411,6 +1439,16 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 }
 
 extern "C" int tmx_step_ars343(tmx_engine * e, double dt) { return tmx_step(e, TMX_SCHEME_ARS343, 0, 0, dt); }
+
+extern "C" int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "Held-Suarez physics with the shallow-water equation set is not supported");
+	for (int lp : e->local_patches)
+		REQUIRE(e->patches[lp].physics_set, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs was not called for patch %d", lp);
+	ProfScope ps(e, TMX_K_LINCOMB);
+	tmxk_held_suarez(e, make_params(e), inst(e, instance), dt);
+	return launch_check("physics_held_suarez");
+}
 
 extern "C" int tmx_sync(tmx_engine * e) {
 	int r; if ((r = check_ready(e))) return r;

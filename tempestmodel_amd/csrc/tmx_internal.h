@@ -24,6 +24,7 @@
 
 // 2-D (per column) geometry slabs
 enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS,
+	G2_LAT, G2_PS,      // column physics inputs (tmx_set_patch_physics_inputs): latitude, Held-Suarez surface pressure
 	// factors of the closed-form 3-D metric (tmx_set_patch_metric_factors): -s/d_xi R, 1+Y^2, XY, 1+X^2,
 	// d_alpha zs, d_beta zs, 1/d_xi R, 1/(d_xi R)^2
 	G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2, G2_COUNT };
@@ -50,7 +51,7 @@ struct KParams {
 };
 
 struct PatchInfo {
-	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false;
+	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false, physics_set = false;
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
@@ -146,6 +147,7 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
+void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);

@@ -955,6 +955,55 @@ void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x) {
 	hipLaunchKernelGGL(k_v_filter_tracers, dim3((p.ncol + 255) / 256, e->nt), dim3(256), 0, e->stream, p, e->nt, (const double *)e->d_area, x);
 }
 
+// Column physics: HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301), Lorenz staggering.  Pointwise
+// in (column, level): backward-Euler boundary-layer friction on U,V (sigma from PressureFromRhoTheta(rho * rhotheta),
+// :107-126, as the reference writes it) and relaxation of rho*theta towards the equilibrium temperature with the
+// "Ullrich update" (:186-247).  The surface pressure is an input (tmx_set_patch_physics_inputs).
+__global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restrict__ x, double dt, double gamma, double kappa, double pscal)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k >= L || col >= p.ncol) return;
+	const unsigned cb = (unsigned)col * 8u;
+	const double bsig = 0.7, kf = 1.0 / 86400.0, ka = (1.0 / 40.0) / 86400.0, ks = (1.0 / 4.0) / 86400.0;
+	const double dty = 60.0, dthz = 10.0, tmin = 200.0, tmax = 315.0;
+	const double ps = ldu(p.g2d + G2_PS * NS, cb), lat = ldu(p.g2d + G2_LAT * NS, cb);
+	const double rho = ldu(x + TMX_SLAB_R(L, k) * NS, cb), rt = ldu(x + TMX_SLAB_T(L, k) * NS, cb);
+	{
+		const double pr = pscal * exp(log(rho * rt) * gamma);
+		const double sigma = pr / ps;
+		double bs = (sigma - bsig) / (1.0 - bsig);
+		if (bs < 0.0) bs = 0.0;
+		const double u = ldu(x + TMX_SLAB_U(L, k) * NS, cb), v = ldu(x + TMX_SLAB_V(L, k) * NS, cb);
+		stu(x + TMX_SLAB_U(L, k) * NS, cb, u / (1.0 + kf * bs * dt));
+		stu(x + TMX_SLAB_V(L, k) * NS, cb, v / (1.0 + kf * bs * dt));
+	}
+	const double pr = pscal * exp(log(rt) * gamma);
+	const double sigma = pr / ps;
+	double bs = (sigma - bsig) / (1.0 - bsig);
+	if (bs < 0.0) bs = 0.0;
+	const double T = pr / (rho * p.Rd);
+	const double sl = sin(lat), cl = cos(lat);
+	const double c4 = cl * cl * cl * cl;
+	const double kt = ka + (ks - ka) * bs * c4;
+	double teq = tmax - dty * sl * sl - dthz * log(pr / p.p0) * cl * cl;
+	teq *= pow(pr / p.p0, kappa);
+	if (teq < tmin) teq = tmin;
+	const double ddh = -kt / gamma * (1.0 + (gamma - 1.0) * teq / T);
+	const double dh = -kt / gamma * (1.0 - teq / T);
+	stu(x + TMX_SLAB_T(L, k) * NS, cb, rt * (1.0 + dt / (1.0 - dt * ddh) * dh));
+}
+
+void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt) {
+	// PhysicalConstants::GetGamma / GetKappa / pressure scaling (src/atm/PhysicalConstants.h:355-376), host libm as in the reference
+	const double gamma = p.cp / (p.cp - p.Rd), kappa = p.Rd / p.cp;
+	const double pscal = p.p0 * pow(p.Rd / p.p0, gamma);
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_held_suarez, grd, blk, 0, e->stream, p, x, dt, gamma, kappa, pscal);
+}
+
 // gather the copies other ranks need into the send buffer, one contiguous message per peer:
 // sendbuf = [peer][slab][count_peer]; entry i of the plan lives at base[i] + slab * stride[i]
 __global__ __launch_bounds__(256) void k_pack(int nslab, size_t NS, int nsend,

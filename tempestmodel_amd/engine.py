@@ -90,6 +90,8 @@ def load_library():
     lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
+    lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
+    lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_download_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
@@ -249,6 +251,20 @@ class Engine:
                 self._chk(self.lib.tmx_download_state(self.h, p, instance, _pd(n), _pd(e)))
             out[p] = (n, e)
         return out
+
+    # -- column physics (WorkflowProcess on the device) -----------------------------------------------
+    def set_physics_inputs(self, surface_pressure):
+        """``surface_pressure[p] = [na][nb]``: what HeldSuarezPhysics::Perform computes from the interface slots
+        (HeldSuarezPhysics.cpp:99-101); latitude comes from the grid (GridPatch::GetLatitude)."""
+        for p in self.local_patches:
+            P = self.grid.patches[p]
+            la = np.ascontiguousarray(P.lat, dtype=np.float64)
+            sp = np.ascontiguousarray(surface_pressure[p], dtype=np.float64)
+            self._chk(self.lib.tmx_set_patch_physics_inputs(self.h, p, _pd(la), _pd(sp)))
+
+    def held_suarez(self, instance, dt):
+        """HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301)."""
+        self._chk(self.lib.tmx_physics_held_suarez(self.h, instance, dt))
 
     def upload_tracers(self, instance, tracers):
         """``tracers[p] = [n_tracers][na][nb][L]`` (GridPatch::GetDataTracers) for every patch (remote ones ignored)."""

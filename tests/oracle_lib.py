@@ -27,7 +27,8 @@ class OrcPatch(C.Structure):
                 ("nhalo", C.c_int),
                 ("hi", PI), ("hj", PI), ("hsp", PI), ("hsi", PI), ("hsj", PI), ("hspanel", PI),
                 ("htrans", PD),
-                ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD), ("area_node", PD)]
+                ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD), ("area_node", PD),
+                ("lat", PD), ("surf_p", PD)]
 
 
 class OrcGrid(C.Structure):
@@ -120,6 +121,14 @@ class Oracle:
             t = np.ascontiguousarray(h["trans"], dtype=np.float64)
             self._keep.append(t)
             cp.htrans = _pd(t)
+            # column physics inputs: latitude, and the reference's "surface pressure" when the test supplies it
+            la = np.ascontiguousarray(P.lat, dtype=np.float64)
+            self._keep.append(la)
+            cp.lat = _pd(la)
+            if "hs_surface_pressure" in P.geom:
+                sp = np.ascontiguousarray(P.geom["hs_surface_pressure"], dtype=np.float64)
+                self._keep.append(sp)
+                cp.surf_p = _pd(sp)
             # Rayleigh friction: strength + reference state, when the grid's test case defines them
             if getattr(grid, "has_rayleigh_friction", False) and "rayleigh_node" in P.geom:
                 for fld in ("rayleigh_node", "rayleigh_redge", "ref_node", "ref_redge"):
@@ -210,6 +219,9 @@ class Oracle:
     def step(self, scheme, dt, first=False, last=False):
         return lib().orc_step(C.byref(self.cgrid), C.byref(self.cstate), self.SCHEMES[scheme],
                               int(first), int(last), C.c_double(dt))
+
+    def held_suarez(self, ix, dt):
+        lib().orc_held_suarez(C.byref(self.cgrid), C.byref(self.cstate), ix, C.c_double(dt))
 
     def v_step_implicit_terms_explicitly(self, iinit, iupd, dt):
         lib().orc_v_step_implicit_terms_explicitly(C.byref(self.cgrid), C.byref(self.cstate), iinit, iupd, C.c_double(dt))

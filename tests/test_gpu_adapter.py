@@ -23,6 +23,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     # rows H8 / V8: two tracer densities
     ("production", ["--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("parity", ["--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6"]),
+    # Held-Suarez forcing as a WorkflowProcess after every step (HeldSuarezPhysicsMI355X)
+    ("production", ["--physics", "1", "--ne", "2", "--levels", "30", "--steps", "3", "--patches", "6"]),
 ])
 def test_reference_driver_with_adapter_plugins(mode, args):
     if not os.path.exists(BIN):

@@ -186,6 +186,32 @@ def test_tracer_steps_vs_reference_and_oracle():
         e.close()
 
 
+def test_held_suarez_physics():
+    """the column physics kernel against the C oracle and the reference's own output
+    (HeldSuarezPhysics::Perform on the JW state after 2 steps); only exp/log/pow/sin/cos differ from the CPU."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("physics_hs_ne2_L30_p6.npz")
+    g, _ = gu.make_grid(2, 30, 6)
+    for P in g.patches:
+        P.geom["hs_surface_pressure"] = d["p%d/hs_surface_pressure" % P.index]
+    before, after = gu.full_states(d, "hs_before", 6), gu.full_states(d, "hs_after", 6)
+    o = Oracle(g); o.set_state(0, before); o.held_suarez(0, 200.0)
+    e = Engine(g)
+    try:
+        with pytest.raises(Exception):
+            e.held_suarez(0, 200.0)                    # inputs not set yet
+        e.set_physics_inputs([d["p%d/hs_surface_pressure" % p] for p in range(6)])
+        e.upload_state(0, before)
+        e.held_suarez(0, 200.0)
+        e.sync()
+        got = e.download_state(0)
+        assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_CALL
+        assert max(gu.prognostic_errors(got, after)) < TOL_CALL
+    finally:
+        e.close()
+
+
 def test_hundred_steps_ne4_L10():
     """North-star gate: fp64 state difference < 1e-10 after 100 ARS343 steps (vs the oracle, same inputs)."""
     from tempestmodel_amd.engine import Engine

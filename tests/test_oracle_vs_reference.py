@@ -137,6 +137,22 @@ def test_tracer_steps_vs_reference():
         assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-10
 
 
+def test_held_suarez_physics_vs_reference():
+    """SURVEY 8(f) item 1: HeldSuarezPhysics::Perform.  Bit for bit on identical inputs (same libm on the CPU)."""
+    d = gu.load("physics_hs_ne2_L30_p6.npz")
+    g, _ = gu.make_grid(2, 30, 6)
+    for P in g.patches:
+        P.geom["hs_surface_pressure"] = d["p%d/hs_surface_pressure" % P.index]
+        assert np.max(np.abs(P.lat - d["p%d/hs_latitude" % P.index])[1:-1, 1:-1]) < 1e-15
+    o = Oracle(g)
+    before, after = gu.full_states(d, "hs_before", 6), gu.full_states(d, "hs_after", 6)
+    o.set_state(0, before)
+    o.held_suarez(0, 200.0)
+    assert max(gu.prognostic_errors(o.get_state(0), after)) < 1e-15
+    ch = gu.prognostic_errors(before, after)
+    assert ch[0] > 1e-5 and ch[2] > 1e-7 and ch[3] == 0.0 and ch[4] == 0.0     # friction and heating both acted
+
+
 def test_hundred_reference_steps_ne4_L10():
     """North-star gate on the CPU side: the C oracle stays within 1e-10 of the real reference over 100 ARS343
     steps (ne4 L10 dt 200 s, from the reference's state after 2 steps)."""
