@@ -212,6 +212,38 @@ def test_held_suarez_physics():
         e.close()
 
 
+@pytest.mark.parametrize("ne,L,npatch,ntr", [
+    (2, 3, 6, 0),        # minimum level count the engine accepts
+    (4, 5, 96, 0),       # one element per patch: every column sits on a patch boundary
+    (6, 7, 24, 1),       # odd level count, 3x3 elements per patch, one tracer
+    (3, 33, 6, 0),       # more levels than a 32-entry anything
+])
+def test_unusual_sizes_vs_oracle(ne, L, npatch, ntr):
+    """Edge sizes: two ARS343 steps and one Strang step against the C oracle (developed start state from the oracle)."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    g, states = gu.make_grid(ne, L, npatch, ntracers=ntr)
+    o = Oracle(g); o.set_state(0, states)
+    if ntr:
+        o.set_tracers(0, [g.initial_tracers[p] for p in range(npatch)])
+    assert o.step_ars343(100.0) == 0
+    e = Engine(g); e.upload_state(0, o.get_state(0))
+    if ntr:
+        e.upload_tracers(0, o.get_tracers(0))
+    try:
+        for _ in range(2):
+            assert o.step_ars343(100.0) == 0
+            e.step_ars343(100.0)
+        assert o.step("strang", 100.0, first=True) == 0
+        e.step("strang", 100.0, first=True)
+        e.sync()
+        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) < TOL_STEPS
+        if ntr:
+            assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) < 1e-11
+    finally:
+        e.close()
+
+
 def test_hundred_steps_ne4_L10():
     """North-star gate: fp64 state difference < 1e-10 after 100 ARS343 steps (vs the oracle, same inputs)."""
     from tempestmodel_amd.engine import Engine
