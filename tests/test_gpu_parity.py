@@ -480,17 +480,20 @@ def test_production_step_is_bit_identical_to_the_reference_call_sequence():
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3, 8])
-def test_multirank_device_path_loopback(n_ranks):
+@pytest.mark.parametrize("n_ranks,ntr", [(2, 0), (3, 0), (8, 0), (4, 2)])
+def test_multirank_device_path_loopback(n_ranks, ntr):
     """The N>1 device path on ONE GPU: n engines (ranks 0..n-1 of the same 24-patch grid) in one process,
     transport replaced by device copies in wire order (tmx_debug_dss_loopback).  Two full ARS343 steps
     issued call by call on every 'rank' must reproduce the single-engine result bit for bit."""
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps_ne4_L6_p24.npz")
-    g, _ = gu.make_grid(4, 6, 24)
+    g, _ = gu.make_grid(4, 6, 24, ntracers=ntr)
     start = gu.expand_compact(d, "step1", g)
     single = Engine(g)
     ranks = [Engine(g, rank=r, n_ranks=n_ranks) for r in range(n_ranks)]
+    if ntr:        # tracer slabs travel in the same exchange
+        for e in [single] + ranks:
+            e.upload_tracers(0, [g.initial_tracers[p] for p in range(24)])
 
     class Lockstep:
         """Issues every call on all rank engines; DSS goes through the loopback exchange."""
@@ -523,6 +526,10 @@ def test_multirank_device_path_loopback(n_ranks):
                 dn = np.max(np.abs(got[p][0][[0, 1, 2, 4]] - ref[p][0][[0, 1, 2, 4]]) / np.max(np.abs(ref[p][0][[0, 1, 2, 4]]), axis=(1, 2, 3), keepdims=True))
                 de = np.max(np.abs(got[p][1][3] - ref[p][1][3])) / max(np.max(np.abs(ref[p][1][3])), 1e-300)
                 assert dn == 0.0 and de == 0.0, (e.rank, p, dn, de)
+            if ntr:
+                tg, tr = e.download_tracers(3), single.download_tracers(3)
+                for p in e.local_patches:
+                    assert np.array_equal(tg[p][:, 1:-1, 1:-1], tr[p][:, 1:-1, 1:-1]), (e.rank, p)
         assert sum(len(e.local_patches) for e in ranks) == 24
         assert all(e.info(4) > 0 for e in ranks)       # every rank really has ghost columns
     finally:
