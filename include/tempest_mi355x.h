@@ -276,6 +276,12 @@ int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
  * RCCL transport is replaced by device-to-device copies in wire order, everything else (packing, ghost
  * indexing, DSS with remote members) is the production path. */
 int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int instance);
+/* Same transport replacement for WHOLE production calls (tmx_step, tmx_h_step_after_subcycle, tmx_apply_dss ...):
+ * registers the n engines as one loopback group; afterwards every exchange of a member packs, waits at a barrier for
+ * the other members, copies its peers' send segments into its ghost buffer and waits again.  The caller drives each
+ * member from its own host thread (one thread per engine, as one MPI rank is one thread in the reference).
+ * n = 0 dissolves the group of engines[0]. */
+int tmx_debug_loopback_group(tmx_engine ** engines, int n);
 /* Grouped ncclSend/ncclRecv to self through the engine's communicator and stream. */
 int tmx_debug_comm_selftest(tmx_engine * e);
 

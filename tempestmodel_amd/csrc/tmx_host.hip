@@ -1,5 +1,6 @@
 // tmx_host.hip -- host side of the engine: C ABI, HBM layout, DSS groups, exchange plan, step drivers.
 #include "tmx_internal.h"
+#include <pthread.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -1049,8 +1050,53 @@ extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double d
 	return v_step_implicit_impl(e, iinit, iupd, dt, iupd);
 }
 
+// test hook (tmx_debug_loopback_group): rank engines of one process, one host thread each
+struct LoopbackGroup {
+	std::vector<tmx_engine *> members;
+	pthread_barrier_t barrier;
+};
+
+static int exchange_loopback(tmx_engine * e, const KParams & p, double * x) {
+	LoopbackGroup * G = e->lb;
+	const int n = (int)G->members.size(), me = e->cfg.rank;
+	tmxk_pack(e, p, x);
+	HIPCHK(hipStreamSynchronize(e->stream));
+	pthread_barrier_wait(&G->barrier);                  // every member has packed
+	for (int s_ = 0; s_ < n; s_++) {
+		if (s_ == me) continue;
+		tmx_engine * S = G->members[s_];
+		const int ns = S->send_rank_off[me + 1] - S->send_rank_off[me], nr = e->recv_rank_off[s_ + 1] - e->recv_rank_off[s_];
+		REQUIRE(ns == nr, TMX_ERR_INVALID, "rank %d sends %d columns to rank %d which expects %d", s_, ns, me, nr);
+		if (ns == 0) continue;
+		HIPCHK(hipMemcpyAsync(e->d_ghost + (size_t)e->nslab * e->recv_rank_off[s_], S->d_sendbuf + (size_t)S->nslab * S->send_rank_off[me],
+			(size_t)ns * S->nslab * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	}
+	HIPCHK(hipStreamSynchronize(e->stream));
+	pthread_barrier_wait(&G->barrier);                  // nobody repacks before everyone has copied
+	return TMX_OK;
+}
+
+extern "C" int tmx_debug_loopback_group(tmx_engine ** engines, int n) {
+	REQUIRE(engines && engines[0] && n >= 0, TMX_ERR_INVALID, "tmx_debug_loopback_group: bad argument");
+	if (n == 0) {
+		LoopbackGroup * G = engines[0]->lb;
+		if (G) { for (tmx_engine * m : G->members) m->lb = nullptr; pthread_barrier_destroy(&G->barrier); delete G; }
+		return TMX_OK;
+	}
+	LoopbackGroup * G = new LoopbackGroup();
+	for (int a = 0; a < n; a++) {
+		tmx_engine * e = engines[a];
+		REQUIRE(e && e->finalized && e->cfg.n_ranks == n && e->cfg.rank == a && !e->lb, TMX_ERR_INVALID, "engine %d is not rank %d of %d (or already grouped)", a, a, n);
+		G->members.push_back(e);
+	}
+	pthread_barrier_init(&G->barrier, nullptr, (unsigned)n);
+	for (tmx_engine * m : G->members) m->lb = G;
+	return TMX_OK;
+}
+
 static int exchange(tmx_engine * e, const KParams & p, double * x) {
 	if (e->cfg.n_ranks == 1 || (e->nsend == 0 && e->nghost == 0)) return TMX_OK;
+	if (e->lb) return exchange_loopback(e, p, x);
 	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
 	// ONE message per neighbour rank per exchange (the reference aggregates its ExchangeBuffers the same

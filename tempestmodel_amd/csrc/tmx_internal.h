@@ -117,6 +117,7 @@ struct tmx_engine {
 	size_t hbm_bytes = 0;
 
 	// comm
+	struct LoopbackGroup * lb = nullptr;     // test hook: in-process group of rank engines sharing one barrier
 	void * comm = nullptr;                   // ncclComm_t
 	void * nccl_lib = nullptr;
 

@@ -367,6 +367,22 @@ class Engine:
         if code != 0:
             raise TempestError(code, lib.tmx_last_error().decode())
 
+    @staticmethod
+    def loopback_group(engines):
+        """Test hook: make ``engines`` (ranks 0..n-1, one host thread each) exchange through device copies
+        (tmx_debug_loopback_group); an empty second call dissolves the group."""
+        lib = load_library()
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        code = lib.tmx_debug_loopback_group(arr, len(engines))
+        if code != 0:
+            raise TempestError(code, lib.tmx_last_error().decode())
+
+    @staticmethod
+    def loopback_dissolve(engine):
+        lib = load_library()
+        arr = (C.c_void_p * 1)(engine.h)
+        lib.tmx_debug_loopback_group(arr, 0)
+
     def profile_enable(self, on=True):
         self._chk(self.lib.tmx_profile_enable(self.h, 1 if on else 0))
 

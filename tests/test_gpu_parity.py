@@ -538,6 +538,54 @@ def test_multirank_device_path_loopback(n_ranks, ntr):
             e.close()
 
 
+@pytest.mark.parametrize("n_ranks,scheme", [(4, "ars343"), (8, "ars343"), (3, "strang")])
+def test_multirank_production_steps_loopback(n_ranks, scheme):
+    """The production call (tmx_step: fused program, exchanges inside) on n rank engines, one host thread each, with the
+    wire replaced by device copies (tmx_debug_loopback_group): three whole steps are bit-identical to one engine."""
+    import threading
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step1", g)
+    single = Engine(g)
+    ranks = [Engine(g, rank=r, n_ranks=n_ranks) for r in range(n_ranks)]
+    try:
+        single.upload_state(0, start)
+        for k in range(3):
+            single.step(scheme, 200.0, first=(k == 0))
+        single.sync()
+        ref = single.download_state(0)
+        for e in ranks:
+            e.upload_state(0, start)
+        Engine.loopback_group(ranks)
+        errors = []
+
+        def run(e):
+            try:
+                for k in range(3):
+                    e.step(scheme, 200.0, first=(k == 0))
+                e.sync()
+            except Exception as ex:        # a failing member must not leave the others at the barrier silently
+                errors.append(ex)
+
+        th = [threading.Thread(target=run, args=(e,)) for e in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errors and not any(t.is_alive() for t in th), errors
+        Engine.loopback_dissolve(ranks[0])
+        for e in ranks:
+            got = e.download_state(0)
+            for p in e.local_patches:
+                assert np.array_equal(got[p][0][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), (e.rank, p)
+                assert np.array_equal(got[p][1][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), (e.rank, p)
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()
+
+
 def test_rccl_transport_selftest():
     """Library resolution + communicator + grouped send/recv on the engine's stream (1 rank, to self)."""
     from tempestmodel_amd.engine import Engine
