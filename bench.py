@@ -222,7 +222,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 3, 3)
         print(json.dumps(out))
     eng.close()
