@@ -2,7 +2,7 @@
 reference (MKL dgbsv) over 100 ARS343 steps at ne15 L30 -- i.e. how far two correct CPU implementations drift apart.
 Needs oracle/_ref (build container only).  Prints per-variable max-norm relative differences (U V rhotheta W rho)."""
 import sys, os, subprocess, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
 import golden_util as gu, tmxd
 from oracle_lib import Oracle
 ne,L,dt=15,30,300.0

@@ -1,5 +1,5 @@
 import sys, numpy as np, ctypes as C
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
 import golden_util as gu
 from oracle_lib import Oracle, lib, dgbsv, _pd
 ne, L = 6, 30

@@ -333,7 +333,7 @@ def test_hundred_steps_ne15_L30():
             # U, V, rho*theta, rho: the north-star tolerance
             assert max(errs[c] for c in (0, 1, 2, 4)) < TOL_STEPS, errs
             # W: after 100 steps at this size the reference's own sensitivity to last-bit changes is 2e-10 in W
-            # (C oracle with its own LAPACK restatement vs the reference with MKL, tools/lapack_sensitivity_ne15.py;
+            # (C oracle with its own LAPACK restatement vs the reference with MKL, tests/analysis/lapack_sensitivity_ne15.py;
             # glibc exp/log vs correctly rounded exp/log alone: 3e-11 at ne4) -- W is the small residual of the
             # hydrostatic balance.  The GPU differs from the oracle only through ocml's exp/log (<= 1 ulp).
             assert errs[3] < TOL_W_NE15, errs
