@@ -1097,6 +1097,10 @@ extern "C" int tmx_debug_loopback_group(tmx_engine ** engines, int n) {
 static int exchange(tmx_engine * e, const KParams & p, double * x) {
 	if (e->cfg.n_ranks == 1 || (e->nsend == 0 && e->nghost == 0)) return TMX_OK;
 	if (e->lb) return exchange_loopback(e, p, x);
+	// timing aid: a lone rank engine of an N-rank layout with the wire left out (results are then wrong at the rank
+	// boundary; used only by tools/rank_share_timing.py to measure the per-rank compute share of a step)
+	static const bool skip = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
+	if (skip) { tmxk_pack(e, p, x); return TMX_OK; }
 	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
 	// ONE message per neighbour rank per exchange (the reference aggregates its ExchangeBuffers the same

@@ -1739,7 +1739,19 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 // (Tried and dropped: detecting a wave-uniform pivot row with a ballot and swapping registers at compile time
 // instead of 160 v_cndmask per step, and skipping the update of all-zero fill-in columns -- neither changed the
 // time, the kernel is bound by HBM traffic at ne30 and by dependent-issue latency on small grids.)
-template <bool SPARSE>
+template <int PV>
+__device__ __forceinline__ void lu_swap_static(double (&R)[5][TMX_BW], double (&b)[5]) {
+	if (PV == 0) return;
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) { const double t = R[0][c]; R[0][c] = R[PV][c]; R[PV][c] = t; }
+	const double t = b[0]; b[0] = b[PV]; b[PV] = t;
+}
+
+// UNI: when every lane of the wavefront picks the same pivot row (the normal case: neighbouring columns have
+// nearly identical matrices) the interchange is a compile-time register swap instead of 160 v_cndmask; lanes that
+// disagree take the select path.  Only used where the register budget allows it (the elimination wavefront of
+// k_vi_pair); in the one-wavefront kernel it spills to AGPRs and gains nothing.
+template <bool SPARSE, bool UNI = false>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -1751,18 +1763,29 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		const double v = fabs(R[r][0]);
 		if (v > amax) { amax = v; pv = r; }
 	}
-#pragma unroll
-	for (int r = 1; r < 5; r++) {
-		const bool sw = (pv == r);
-#pragma unroll
-		for (int c = 0; c < TMX_BW; c++) {
-			const double a0 = R[0][c], ar = R[r][c];
-			R[0][c] = sw ? ar : a0;
-			R[r][c] = sw ? a0 : ar;
+	const int pv0 = __builtin_amdgcn_readfirstlane(pv);
+	if (UNI && __builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
+		switch (pv0) {
+			case 1: lu_swap_static<1>(R, b); break;
+			case 2: lu_swap_static<2>(R, b); break;
+			case 3: lu_swap_static<3>(R, b); break;
+			case 4: lu_swap_static<4>(R, b); break;
+			default: break;
 		}
-		const double b0 = b[0], br = b[r];
-		b[0] = sw ? br : b0;
-		b[r] = sw ? b0 : br;
+	} else {
+#pragma unroll
+		for (int r = 1; r < 5; r++) {
+			const bool sw = (pv == r);
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				const double a0 = R[0][c], ar = R[r][c];
+				R[0][c] = sw ? ar : a0;
+				R[r][c] = sw ? a0 : ar;
+			}
+			const double b0 = b[0], br = b[r];
+			b[0] = sw ? br : b0;
+			b[r] = sw ? b0 : br;
+		}
 	}
 	if (R[0][0] == 0.0) singular = true;
 #pragma unroll
@@ -2035,11 +2058,11 @@ __global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double
 					R[4][c] = rW[c];
 				}
 				b[3] = fP; b[4] = fW;
-				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 0, NUS, u, rR, fR, umask);      // pivot 0 takes in row 5
+				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 0, NUS, u, rR, fR, umask);      // pivot 0 takes in row 5
 			} else {
-				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
-				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
-				lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
+				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
+				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
 			}
 		}
 		__syncthreads();
@@ -2048,7 +2071,7 @@ __global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
+		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
 	}
 	if (singular) atomicExch(flag, 1);
 	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-rank compute share of an ARS343 step at N ranks, measured on ONE GPU: a lone rank-0 engine of the N-rank
+24-patch ne30 layout runs whole steps with the wire left out (TMX_DEBUG_SKIP_EXCHANGE: packing still runs, nothing is
+sent, results at the rank boundary are wrong).  What a multi-GPU step costs besides the exchange itself."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["TMX_DEBUG_SKIP_EXCHANGE"] = "1"
+from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
+from tempestmodel_amd.engine import Engine
+
+grid = CubedSphereGrid(30, 30, 30000.0, ppd=2)
+states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
+for n in (1, 2, 4, 8):
+    e = Engine(grid, rank=0, n_ranks=n)
+    e.upload_state(0, states)
+    for _ in range(3):
+        e.step_ars343(150.0)
+    e.sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        e.step_ars343(150.0)
+    e.sync()
+    wall = (time.perf_counter() - t0) / 20
+    e.profile_enable(True); e.profile_reset()
+    for _ in range(10):
+        e.step_ars343(150.0)
+    e.sync()
+    prof = e.profile()
+    print("ranks %d: rank-0 share %d patches, %.3f ms/step without the wire" % (n, len(e.local_patches), 1e3 * wall),
+          {k: round(v[0] / 10, 3) for k, v in prof.items() if v[1]})
+    e.close()
