@@ -2081,7 +2081,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	if (e->nunique == 0) return;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
-	// The pair kernel shortens the per-column dependent chain (134 vs 166 us on a small grid) but needs every
+	// The pair kernel shortens the per-column dependent chain (124 vs 166 us on a small grid) but needs every
 	// wavefront alone on its SIMD: two pairs per workgroup = one workgroup per CU.  Measured: 137-140 us up to 211
 	// workgroups, 273 us from 243 on (the dispatcher then doubles up on some CUs while others idle), where the
 	// one-wavefront kernel takes 186 us.  So it is used below 200 workgroups -- i.e. on the per-GPU share of the
