@@ -223,7 +223,7 @@ def main():
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ne, L, dt, 3, 3)
+            out["cpu_baseline"] = cpu_baseline(ne, L, dt, 6, 6)      # ~15 s of CPU work (1 warm-up + 6 timed steps)
         print(json.dumps(out))
     eng.close()
     if world > 1:
