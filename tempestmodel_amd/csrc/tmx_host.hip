@@ -163,6 +163,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 	if (!e) return;
 	if (!plan_only(e)) {
 		if (e->stream) hipStreamSynchronize(e->stream);
+		if (e->xstream) { hipStreamSynchronize(e->xstream); hipStreamDestroy(e->xstream); hipEventDestroy(e->ev_pack); hipEventDestroy(e->ev_recv); }
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
@@ -595,9 +596,17 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 			}
 			key[g] = { best, (int)g };
 		}
-		std::sort(key.begin(), key.end());
+		// groups with a member on another rank go last: the DSS of the others does not wait for the exchange
+		std::vector<char> remote(groups.size(), 0);
+		for (size_t g = 0; g < groups.size(); g++)
+			for (int id : groups[g].ids) if (e->patches[node_of(id).patch].owner != me) remote[g] = 1;
+		std::sort(key.begin(), key.end(), [&](const std::pair<int, int> & a, const std::pair<int, int> & b) {
+			if (remote[a.second] != remote[b.second]) return remote[a.second] < remote[b.second];
+			return a < b;
+		});
 		std::vector<Grp> sorted(groups.size());
-		for (size_t g = 0; g < groups.size(); g++) sorted[g] = groups[key[g].second];
+		e->ngroups_local = 0;
+		for (size_t g = 0; g < groups.size(); g++) { sorted[g] = groups[key[g].second]; if (!remote[key[g].second]) e->ngroups_local++; }
 		groups.swap(sorted);
 	}
 	e->send_rank_off.assign(NR + 1, 0); e->recv_rank_off.assign(NR + 1, 0);
@@ -1094,7 +1103,12 @@ extern "C" int tmx_debug_loopback_group(tmx_engine ** engines, int n) {
 	return TMX_OK;
 }
 
-static int exchange(tmx_engine * e, const KParams & p, double * x) {
+// Exchange of the boundary columns of instance x.  ONE message per neighbour rank (the reference aggregates its
+// ExchangeBuffers the same way, Connectivity.cpp:928-993): buffers are [peer][slab][count_peer], contiguous per peer.
+// The grouped send/recv runs on a second stream between two events, so that the DSS of the groups without remote
+// members (the great majority) overlaps the wire; *overlapped tells the caller to wait for ev_recv before the rest.
+static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overlapped = nullptr) {
+	if (overlapped) *overlapped = false;
 	if (e->cfg.n_ranks == 1 || (e->nsend == 0 && e->nghost == 0)) return TMX_OK;
 	if (e->lb) return exchange_loopback(e, p, x);
 	// timing aid: a lone rank engine of an N-rank layout with the wire left out (results are then wrong at the rank
@@ -1103,16 +1117,24 @@ static int exchange(tmx_engine * e, const KParams & p, double * x) {
 	if (skip) { tmxk_pack(e, p, x); return TMX_OK; }
 	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
-	// ONE message per neighbour rank per exchange (the reference aggregates its ExchangeBuffers the same
-	// way, Connectivity.cpp:928-993): buffers are [peer][slab][count_peer], contiguous per peer.
 	tmxk_pack(e, p, x);
+	hipStream_t ws = e->stream;
+	if (overlapped && e->xstream) {
+		HIPCHK(hipEventRecord(e->ev_pack, e->stream));
+		HIPCHK(hipStreamWaitEvent(e->xstream, e->ev_pack, 0));
+		ws = e->xstream;
+	}
 	NCCLCHK(g_nccl.GroupStart());
 	for (int rk = 0; rk < e->cfg.n_ranks; rk++) {
 		const int ns = e->send_rank_off[rk + 1] - e->send_rank_off[rk], nr = e->recv_rank_off[rk + 1] - e->recv_rank_off[rk];
-		if (ns) NCCLCHK(g_nccl.Send(e->d_sendbuf + (size_t)e->nslab * e->send_rank_off[rk], (size_t)ns * e->nslab, 8 /* ncclFloat64 */, rk, e->comm, e->stream));
-		if (nr) NCCLCHK(g_nccl.Recv(e->d_ghost + (size_t)e->nslab * e->recv_rank_off[rk], (size_t)nr * e->nslab, 8, rk, e->comm, e->stream));
+		if (ns) NCCLCHK(g_nccl.Send(e->d_sendbuf + (size_t)e->nslab * e->send_rank_off[rk], (size_t)ns * e->nslab, 8 /* ncclFloat64 */, rk, e->comm, ws));
+		if (nr) NCCLCHK(g_nccl.Recv(e->d_ghost + (size_t)e->nslab * e->recv_rank_off[rk], (size_t)nr * e->nslab, 8, rk, e->comm, ws));
 	}
 	NCCLCHK(g_nccl.GroupEnd());
+	if (ws != e->stream) {
+		HIPCHK(hipEventRecord(e->ev_recv, ws));
+		*overlapped = true;
+	}
 	return TMX_OK;
 }
 
@@ -1144,7 +1166,8 @@ extern "C" int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int ix) {
 	HIPCHK(hipDeviceSynchronize());     // device-to-device copies may still be in flight on the null stream
 	for (int a = 0; a < n; a++) {
 		tmx_engine * e = engines[a];
-		tmxk_dss(e, make_params(e), inst(e, ix));
+		tmxk_dss(e, make_params(e), inst(e, ix), 0, e->ngroups_local);
+		tmxk_dss(e, make_params(e), inst(e, ix), e->ngroups_local, e->ngroups);
 		if ((r = launch_check("dss (loopback)"))) return r;
 	}
 	return TMX_OK;
@@ -1176,9 +1199,17 @@ extern "C" int tmx_debug_comm_selftest(tmx_engine * e) {
 extern "C" int tmx_apply_dss(tmx_engine * e, int ix) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
 	KParams p = make_params(e);
-	if ((r = exchange(e, p, inst(e, ix)))) return r;
+	bool overlapped = false;
+	if ((r = exchange(e, p, inst(e, ix), &overlapped))) return r;
 	ProfScope ps(e, TMX_K_DSS);
-	tmxk_dss(e, p, inst(e, ix));
+	if (e->cfg.n_ranks > 1 && e->ngroups_local < e->ngroups) {
+		// groups whose members all live on this rank first (they overlap the wire), then the ones with remote members
+		tmxk_dss(e, p, inst(e, ix), 0, e->ngroups_local);
+		if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
+		tmxk_dss(e, p, inst(e, ix), e->ngroups_local, e->ngroups);
+	} else {
+		tmxk_dss(e, p, inst(e, ix), 0, e->ngroups);
+	}
 	return launch_check("apply_dss");
 }
 
@@ -1527,6 +1558,11 @@ extern "C" int tmx_comm_unique_id(unsigned char id[128]) {
 }
 
 extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
+	if (e && !e->xstream && e->cfg.device != -2 && !getenv("TMX_NO_EXCHANGE_OVERLAP")) {
+		// second stream + events for the exchange / interior-DSS overlap
+		if (hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking) != hipSuccess) e->xstream = nullptr;
+		else { hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming); hipEventCreateWithFlags(&e->ev_recv, hipEventDisableTiming); }
+	}
 	REQUIRE(e && id && !plan_only(e), TMX_ERR_INVALID, "tmx_comm_init: bad argument");
 	int r = load_rccl();
 	if (r) return r;

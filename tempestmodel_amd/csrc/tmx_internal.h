@@ -92,11 +92,14 @@ struct tmx_engine {
 	// device
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t xstream = nullptr;           // exchange stream (multi-rank): the wire overlaps the DSS of rank-local groups
+	hipEvent_t ev_pack = nullptr, ev_recv = nullptr;
 	double * d_state = nullptr;
 	double * d_g2d = nullptr, * d_g3n = nullptr, * d_g3e = nullptr, * d_ops = nullptr;
 	double * d_scratch = nullptr;            // [L][NS] (u x zeta)_xi hand-off between the two H kernels
 	// DSS
 	int ngroups = 0, nxgroups = 0, nghost = 0;
+	int ngroups_local = 0;                   // groups [0, ngroups_local) have no member on another rank
 	int * d_grp_cols = nullptr;              // [ngroups][4] column index (>= NS: ghost NS+idx), -1 = none
 	int * d_grp_n = nullptr;                 // [ngroups] member count (2..4); high bit 8 = cross-panel, index in bits 16+
 	int * d_grp_x = nullptr;                 // [ngroups] index into the cross-panel matrices or -1
@@ -142,7 +145,7 @@ void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, dou
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
-void tmxk_dss(tmx_engine * e, const KParams & p, double * x);
+void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1);
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v);
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);

@@ -452,13 +452,14 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 // by the neighbouring group tiles while they still sit in that XCD's L2 (74 -> 68 us).
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
-	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat, int nt)
+	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat, int nt, int g0)
 {
+	// groups [g0, ngroups) of the engine's list
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int bx, by;
-	if (!xcd_tile((ngroups + 63) / 64, (L + 1 + 3) / 4, bx, by)) return;
-	const int g = bx * 64 + threadIdx.x;
+	if (!xcd_tile((ngroups - g0 + 63) / 64, (L + 1 + 3) / 4, bx, by)) return;
+	const int g = g0 + bx * 64 + threadIdx.x;
 	const int kk = by * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (g >= ngroups || kk > L) return;
 	const int n = gn[g];
@@ -536,13 +537,13 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	}
 }
 
-void tmxk_dss(tmx_engine * e, const KParams & p, double * x) {
-	if (e->ngroups == 0) return;
-	const int nx = (e->ngroups + 63) / 64, ny = (p.L + 1 + 3) / 4;
+void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1) {
+	if (g1 <= g0) return;
+	const int nx = (g1 - g0 + 63) / 64, ny = (p.L + 1 + 3) / 4;
 	dim3 blk(64, 4), grd(8 * ((nx + 7) / 8) * ny);
 	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, (const int *)e->d_ghost_base,
-		(const int *)e->d_ghost_stride, e->ngroups,
-		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat, e->nt);
+		(const int *)e->d_ghost_stride, g1,
+		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat, e->nt, g0);
 }
 
 // HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
