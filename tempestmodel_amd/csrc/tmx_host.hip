@@ -1185,14 +1185,30 @@ extern "C" int tmx_debug_comm_selftest(tmx_engine * e) {
 	for (int i = 0; i < n; i++) h[i] = 0.5 * i + 1.0;
 	HIPCHK(hipMemcpy(a, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(b, 0, n * sizeof(double)));
-	NCCLCHK(g_nccl.GroupStart());
-	NCCLCHK(g_nccl.Send(a, (size_t)n, 8, e->cfg.rank, e->comm, e->stream));
-	NCCLCHK(g_nccl.Recv(b, (size_t)n, 8, e->cfg.rank, e->comm, e->stream));
-	NCCLCHK(g_nccl.GroupEnd());
-	HIPCHK(hipStreamSynchronize(e->stream));
-	HIPCHK(hipMemcpy(g.data(), b, n * sizeof(double), hipMemcpyDeviceToHost));
+	// the choreography of exchange(): producer on the engine's stream, event, grouped send/recv on the exchange
+	// stream, event, consumer back on the engine's stream -- three rounds so that buffer reuse is ordered too
+	for (int round = 0; round < 3; round++) {
+		HIPCHK(hipMemcpyAsync(a, h.data(), n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+		hipStream_t ws = e->stream;
+		if (e->xstream) {
+			HIPCHK(hipEventRecord(e->ev_pack, e->stream));
+			HIPCHK(hipStreamWaitEvent(e->xstream, e->ev_pack, 0));
+			ws = e->xstream;
+		}
+		NCCLCHK(g_nccl.GroupStart());
+		NCCLCHK(g_nccl.Send(a, (size_t)n, 8, e->cfg.rank, e->comm, ws));
+		NCCLCHK(g_nccl.Recv(b, (size_t)n, 8, e->cfg.rank, e->comm, ws));
+		NCCLCHK(g_nccl.GroupEnd());
+		if (e->xstream) {
+			HIPCHK(hipEventRecord(e->ev_recv, ws));
+			HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
+		}
+		HIPCHK(hipMemcpyAsync(g.data(), b, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipStreamSynchronize(e->stream));
+		for (int i = 0; i < n; i++) REQUIRE(g[i] == h[i], TMX_ERR_COMM, "RCCL self send/recv returned wrong data at %d (round %d)", i, round);
+		for (int i = 0; i < n; i++) { h[i] = h[i] * 1.5 + round; g[i] = 0.0; }
+	}
 	hipFree(a); hipFree(b);
-	for (int i = 0; i < n; i++) REQUIRE(g[i] == h[i], TMX_ERR_COMM, "RCCL self send/recv returned wrong data at %d", i);
 	return TMX_OK;
 }
 
