@@ -1740,18 +1740,61 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 // (Tried and dropped: detecting a wave-uniform pivot row with a ballot and swapping registers at compile time
 // instead of 160 v_cndmask per step, and skipping the update of all-zero fill-in columns -- neither changed the
 // time, the kernel is bound by HBM traffic at ne30 and by dependent-issue latency on small grids.)
-template <int PV>
-__device__ __forceinline__ void lu_swap_static(double (&R)[5][TMX_BW], double (&b)[5]) {
-	if (PV == 0) return;
+// Tail of a pivot step shared by both paths: store the U row (row 0 of the window after the interchange, given as
+// piv / pb), sparse fill-in entries only where some lane is non-zero.
+template <bool SPARSE>
+__device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
+	int jcol, int NUS, int u, int * umask)
+{
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) { const double t = R[0][c]; R[0][c] = R[PV][c]; R[PV][c] = t; }
-	const double t = b[0]; b[0] = b[PV]; b[PV] = t;
+	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = piv[c];
+	int mask = 0;
+#pragma unroll
+	for (int c = 4; c < TMX_BW; c++) {
+		if (!SPARSE || __builtin_amdgcn_ballot_w64(piv[c] != 0.0) != 0) {
+			AB[((size_t)jcol * TMX_BW + c) * NUS + u] = piv[c];
+			mask |= 1 << c;
+		}
+	}
+	if (threadIdx.x == 0) umask[jcol] = mask;
+	RHS[(size_t)jcol * NUS + u] = pb;
 }
 
-// UNI: when every lane of the wavefront picks the same pivot row (the normal case: neighbouring columns have
-// nearly identical matrices) the interchange is a compile-time register swap instead of 160 v_cndmask; lanes that
-// disagree take the select path.  Only used where the register budget allows it (the elimination wavefront of
-// k_vi_pair); in the one-wavefront kernel it spills to AGPRs and gains nothing.
+// Pivot step when every lane of the wavefront picked window row PV (the normal case: neighbouring columns have
+// nearly identical matrices).  The interchange is a compile-time renaming and the rank-1 update writes straight
+// into the slid position -- new row r-1, column c-1  <-  (row that sits at r after the swap)[c] - l_r * pivot[c] --
+// so neither the 160 v_cndmask of the per-lane interchange nor the 36 moves of the slide are executed.  Only the
+// pivot row and old row 0 are copied aside, because their slots are overwritten before their last use.
+// Same multiplications and subtractions on the same operands as the generic path: bit-identical.
+template <bool SPARSE, int PV>
+__device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
+	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
+	const double * inrow, double inb, int * umask)
+{
+	double piv[TMX_BW], t0[TMX_BW];
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) { piv[c] = R[PV][c]; t0[c] = R[0][c]; }
+	const double pb = b[PV], tb0 = b[0];
+	if (piv[0] == 0.0) singular = true;
+	lu_store_urow<SPARSE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+	const double rcp = 1.0 / piv[0];
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		// after the interchange position r holds old row r, except position PV, which holds old row 0
+		const double l = ((r == PV) ? t0[0] : R[r][0]) * rcp;
+#pragma unroll
+		for (int c = 1; c < TMX_BW; c++) R[r - 1][c - 1] = ((r == PV) ? t0[c] : R[r][c]) - l * piv[c];
+		R[r - 1][TMX_BW - 1] = 0.0;
+		b[r - 1] = ((r == PV) ? tb0 : b[r]) - pb * l;
+	}
+#pragma unroll
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c];
+	b[4] = inb;
+}
+
+// One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
+// the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
+// the per-lane select path below.
 template <bool SPARSE, bool UNI = false>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
@@ -1764,43 +1807,33 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		const double v = fabs(R[r][0]);
 		if (v > amax) { amax = v; pv = r; }
 	}
-	const int pv0 = __builtin_amdgcn_readfirstlane(pv);
-	if (UNI && __builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
-		switch (pv0) {
-			case 1: lu_swap_static<1>(R, b); break;
-			case 2: lu_swap_static<2>(R, b); break;
-			case 3: lu_swap_static<3>(R, b); break;
-			case 4: lu_swap_static<4>(R, b); break;
-			default: break;
-		}
-	} else {
-#pragma unroll
-		for (int r = 1; r < 5; r++) {
-			const bool sw = (pv == r);
-#pragma unroll
-			for (int c = 0; c < TMX_BW; c++) {
-				const double a0 = R[0][c], ar = R[r][c];
-				R[0][c] = sw ? ar : a0;
-				R[r][c] = sw ? a0 : ar;
+	if (UNI) {
+		const int pv0 = __builtin_amdgcn_readfirstlane(pv);
+		if (__builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
+			switch (pv0) {
+				case 0: lu_pivot_tail_uniform<SPARSE, 0>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 1: lu_pivot_tail_uniform<SPARSE, 1>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 2: lu_pivot_tail_uniform<SPARSE, 2>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 3: lu_pivot_tail_uniform<SPARSE, 3>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				default: lu_pivot_tail_uniform<SPARSE, 4>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
-			const double b0 = b[0], br = b[r];
-			b[0] = sw ? br : b0;
-			b[r] = sw ? b0 : br;
 		}
+	}
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		const bool sw = (pv == r);
+#pragma unroll
+		for (int c = 0; c < TMX_BW; c++) {
+			const double a0 = R[0][c], ar = R[r][c];
+			R[0][c] = sw ? ar : a0;
+			R[r][c] = sw ? a0 : ar;
+		}
+		const double b0 = b[0], br = b[r];
+		b[0] = sw ? br : b0;
+		b[r] = sw ? b0 : br;
 	}
 	if (R[0][0] == 0.0) singular = true;
-#pragma unroll
-	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
-	int mask = 0;
-#pragma unroll
-	for (int c = 4; c < TMX_BW; c++) {
-		if (!SPARSE || __builtin_amdgcn_ballot_w64(R[0][c] != 0.0) != 0) {
-			AB[((size_t)jcol * TMX_BW + c) * NUS + u] = R[0][c];
-			mask |= 1 << c;
-		}
-	}
-	if (threadIdx.x == 0) umask[jcol] = mask;
-	RHS[(size_t)jcol * NUS + u] = b[0];
+	lu_store_urow<SPARSE>(R[0], b[0], AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / R[0][0];
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -1872,7 +1905,7 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 #undef BACK_ROW
 }
 
-template <bool CARRY, bool SPARSE, bool CLOSED>
+template <bool CARRY, bool SPARSE, bool CLOSED, bool UNI = false>
 __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
@@ -1925,7 +1958,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	}
 	b[0] = fP; b[1] = fW; b[2] = fR; b[3] = gP; b[4] = gW;
 	bool singular = false;
-	lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 0, NUS, u, sR, gR, umask);      // pivot 0 takes in row 5
+	lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 0, NUS, u, sR, gR, umask);      // pivot 0 takes in row 5
 	// Drain the prologue's loads here, once: otherwise the per-column constants loaded before the loop count as
 	// "possibly still in flight" at the loop header and the compiler waits vmcnt(0) -- i.e. for all U-row
 	// stores of the previous block row -- at their first use in EVERY iteration.
@@ -1944,9 +1977,9 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 		nN = load_node<MM>(p, mcol, xin, m + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, m + 2, col, etal);   // used two blocks from now
 		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 		TMARK(t_asm);
-		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
-		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
-		lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
+		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
+		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
 		TMARK(t_lu);
 	}
 #ifdef TMX_VI_TIMING
@@ -1956,7 +1989,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
+		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
 	}
 	if (singular) atomicExch(flag, 1);
 
@@ -2101,10 +2134,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		return;
 	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
-		hipLaunchKernelGGL((k_vi_fused<C_, S_, true>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
+		hipLaunchKernelGGL((k_vi_fused<C_, S_, true, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
 			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \
 	else \
-		hipLaunchKernelGGL((k_vi_fused<C_, S_, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
+		hipLaunchKernelGGL((k_vi_fused<C_, S_, false, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
 			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); } while (0)
 	if (!e->vi_carry) LAUNCH_VI(false, true);
 	else if (sparse) LAUNCH_VI(true, true);
