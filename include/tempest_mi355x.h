@@ -69,7 +69,7 @@ typedef struct {
 	int    n_patches;          /* total number of patches of the grid (all ranks)              */
 	int    n_instances;        /* state instances per patch (ARS343: 7)                        */
 	int    n_tracers;          /* EquationSet::GetTracers(); tracer densities on levels (nonhydrostatic set only) */
-	int    hypervis_order;     /* 0 or 4                                                       */
+	int    hypervis_order;     /* 0, 2 (viscosity) or 4 (two-pass hyperviscosity): HorizontalDynamicsFEM ctor */
 	double element_delta_a;    /* GridPatchGLL::GetElementDeltaA()                             */
 	double reference_length;   /* Grid::GetReferenceLength()                                   */
 	double grav, Rd, cp, p0;   /* PhysicalConstants::GetG/GetR/GetCp/GetP0                     */

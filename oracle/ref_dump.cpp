@@ -252,7 +252,7 @@ int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 
 	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp", tcase = "jw";
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0;
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0, hvorder = 4;
 	double dt = 200.0, ztop = 30000.0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -270,6 +270,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--geom") { geom = atoi(v); i++; }
 		else if (a == "--every") { every = atoi(v); i++; }
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
+		else if (a == "--hypervis") { hvorder = atoi(v); i++; }      // hyperviscosity order 4 (default) or 2
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--ztop") { ztop = atof(v); i++; }
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
@@ -306,7 +307,9 @@ try {
 	else if (scheme == "strang") model.SetTimestepScheme(new TimestepSchemeStrang(model));
 	else { fprintf(stderr, "bad scheme\n"); return 2; }
 
-	HorizontalDynamicsFEM * pH = new HorizontalDynamicsFEM(model, 4, 4, 1.0e15, 1.0e15, 1.0e15, 0.0);
+	// order 2 is plain viscosity: coefficients of a sensible magnitude for it (the 1e15 defaults belong to order 4)
+	const double dNu = (hvorder == 2) ? 2.0e5 : 1.0e15;
+	HorizontalDynamicsFEM * pH = new HorizontalDynamicsFEM(model, 4, hvorder, dNu, dNu, dNu, 0.0);
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
 	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
@@ -346,6 +349,7 @@ try {
 	w.iscalar("cfg/npatch", pGrid->GetActivePatchCount());
 	w.iscalar("cfg/ninstances", model.GetComponentDataInstances());
 	w.iscalar("cfg/ntracers", ntracers);
+	w.iscalar("cfg/hypervis_order", hvorder);
 	w.scalar("cfg/dt", dt);
 	if (geom && w.fp) {
 		dumpGeometry(w, model, pGrid);

@@ -1189,7 +1189,17 @@ static void rayleigh_friction(const orc_grid * g, orc_state * s, int iupd, doubl
 
 void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt) {
 	orc_copy(g, s, iinit, iupd);
-	if (!(g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0)) {
+	if (g->nu_scalar == 0.0 && g->nu_div == 0.0 && g->nu_vort == 0.0) {
+		/* no hyperdiffusion */
+	} else if (g->hypervis_order == 0) {
+	} else if (g->hypervis_order == 2) {
+		/* viscosity (HorizontalDynamicsFEM.cpp:2672-2686): one pass, coefficients not scaled with the grid spacing */
+		scalar_hyperdiff(g, s, iinit, iupd, dt, g->nu_scalar, 0);
+		tracer_hyperdiff(g, s, iinit, iupd, dt, g->nu_scalar, 0);
+		vector_hyperdiff(g, s, iinit, iupd, -dt, g->nu_div, g->nu_vort, 0);
+		filter_negative_tracers_h(g, s, iupd);
+		orc_apply_dss(g, s, iupd);
+	} else {
 		orc_zero(g, s, iwork);
 		scalar_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);
 		tracer_hyperdiff(g, s, iinit, iwork, 1.0, 1.0, 0);

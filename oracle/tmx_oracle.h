@@ -85,6 +85,7 @@ typedef struct {
 	const orc_patch * patches;
 	int shallow_water;                 /* 1: ShallowWaterEquations (U,V,H; H kept in slot 2, one level)  */
 	int ntracers;                      /* EquationSet::GetTracers(); tracer densities live on levels      */
+	int hypervis_order;                /* 4 (two-pass hyperviscosity), 2 (viscosity) or 0 (none); HorizontalDynamicsFEM ctor */
 } orc_grid;
 
 /* state: node[inst*npatch + p], redge[inst*npatch + p] */

@@ -121,7 +121,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg->vertical_order == 1, TMX_ERR_UNSUPPORTED, "vertical order %d unsupported (1 only)", cfg->vertical_order);
 	REQUIRE(cfg->n_tracers >= 0 && cfg->n_tracers <= 16, TMX_ERR_UNSUPPORTED, "0..16 tracers supported, got %d", cfg->n_tracers);
 	REQUIRE(cfg->n_tracers == 0 || cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC, TMX_ERR_UNSUPPORTED, "tracers are supported with the nonhydrostatic equation set only");
-	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0 or 4)", cfg->hypervis_order);
+	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 2 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0, 2 or 4)", cfg->hypervis_order);
 	REQUIRE(cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC || cfg->equation_set == TMX_EQN_SHALLOW_WATER,
 		TMX_ERR_UNSUPPORTED, "equation set %d unsupported", cfg->equation_set);
 	if (cfg->equation_set == TMX_EQN_SHALLOW_WATER) REQUIRE(cfg->levels == 1, TMX_ERR_INVALID, "shallow water needs levels == 1");
@@ -1238,6 +1238,14 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	KParams p = make_params(e);
 	if ((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0) {
 		if ((r = tmx_copy_data(e, iinit, iupd))) return r;
+	} else if (c.hypervis_order == 2) {
+		// viscosity (HorizontalDynamicsFEM.cpp:2672-2686): one pass from the initial instance, coefficients not scaled
+		// with the grid spacing; the scalar part runs with +dt and the vector part with -dt, which the kernel's single
+		// dt expresses exactly through the sign of nu_scalar ((-dt) * (-nu) is the same product)
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), -dt, -c.nu_scalar, c.nu_div, c.nu_vort);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), dt, c.nu_scalar, 1); }
+		if ((r = launch_check("viscosity pass"))) return r;
+		if ((r = tmx_apply_dss(e, iupd))) return r;
 	} else {
 		double scale = 1.0;
 		if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);

@@ -13,6 +13,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
   percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
   percall_tracers_ne3_L6_p6.npz / steps_tracers_ne3_L6_p6.npz   JW + 2 tracer densities (rows H8, V8)
+  steps_visc2_ne3_L5_p6.npz   three ARS343 steps with hyperviscosity order 2
   physics_hs_ne2_L30_p6.npz   HeldSuarezPhysics::Perform input/output (SURVEY 8f-1)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
@@ -120,6 +121,12 @@ def main():
     rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
     rec.update(compact_states(d, 6))
     save("steps_tracers_ne3_L6_p6.npz", rec)
+
+    # hyperviscosity order 2 (plain viscosity, one pass; HorizontalDynamicsFEM.cpp:2672-2686), nu = 2e5 m^2/s
+    d, _ = run(["--hypervis", "2", "--mode", "steps", "--ne", "3", "--levels", "5", "--dt", "300", "--steps", "3", "--geom", "0"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+    rec.update(compact_states(d, 6))
+    save("steps_visc2_ne3_L5_p6.npz", rec)
 
     # column physics.  HeldSuarezPhysics::Perform on the JW state after 2 steps (ne2, L30: the
     # boundary-layer friction only reaches the lowest levels)

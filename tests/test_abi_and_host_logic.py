@@ -49,7 +49,7 @@ def test_unsupported_configurations_are_rejected():
     cfg.n_patches, cfg.n_instances, cfg.hypervis_order = 6, 7, 4
     cfg.n_ranks, cfg.device = 1, -2
     h = ctypes.c_void_p()
-    for field, bad in (("horizontal_order", 5), ("vertical_order", 2), ("n_tracers", 17), ("n_tracers", -1), ("hypervis_order", 2), ("abi_version", 99)):
+    for field, bad in (("horizontal_order", 5), ("vertical_order", 2), ("n_tracers", 17), ("n_tracers", -1), ("hypervis_order", 3), ("abi_version", 99)):
         c2 = eng.TmxConfig.from_buffer_copy(cfg)
         setattr(c2, field, bad)
         assert lib.tmx_create(ctypes.byref(c2), ctypes.byref(h)) != 0

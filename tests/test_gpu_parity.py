@@ -186,6 +186,28 @@ def test_tracer_steps_vs_reference_and_oracle():
         e.close()
 
 
+def test_viscosity_order_2_steps():
+    """Hyperviscosity order 2 (one viscosity pass): ARS343 steps vs the C oracle and the reference fixture."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("steps_visc2_ne3_L5_p6.npz")
+    g, _ = gu.make_grid(3, 5, 6)
+    nu = (2.0e5, 2.0e5, 2.0e5)
+    start = gu.expand_compact(d, "step1", g)
+    o = Oracle(g, nu=nu, hypervis_order=2); o.set_state(0, start)
+    e = Engine(g, nu=nu, hypervis_order=2); e.upload_state(0, start)
+    try:
+        for step in (2, 3):
+            assert o.step_ars343(300.0) == 0
+            e.step_ars343(300.0)
+            e.sync()
+            got = e.download_state(0)
+            assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_STEPS
+            assert max(gu.prognostic_errors(got, gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS
+    finally:
+        e.close()
+
+
 def test_held_suarez_physics():
     """the column physics kernel against the C oracle and the reference's own output
     (HeldSuarezPhysics::Perform on the JW state after 2 steps); only exp/log/pow/sin/cos differ from the CPU."""

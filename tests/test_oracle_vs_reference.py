@@ -95,6 +95,17 @@ def test_ars343_steps_from_developed_state(fixture, ne, L, npatch, dt, tags):
     assert abs(cs[4] - ref[4]) < 1e-12 * abs(ref[4])
 
 
+def test_viscosity_order_2_steps_vs_reference():
+    """HorizontalDynamicsFEM with hyperviscosity order 2 (one viscosity pass, nu = 2e5): ARS343 steps vs the reference."""
+    d = gu.load("steps_visc2_ne3_L5_p6.npz")
+    g, _ = gu.make_grid(3, 5, 6)
+    o = Oracle(g, nu=(2.0e5, 2.0e5, 2.0e5), hypervis_order=2)
+    o.set_state(0, gu.expand_compact(d, "step1", g))
+    for step in (2, 3):
+        assert o.step_ars343(300.0) == 0
+        assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-11
+
+
 def test_tracer_percall_chain():
     """tracer flux divergence + element filter in H.StepExplicit, tracer DSS, the implicit column
     tracer update (tridiagonal dgbtrf/dgbtrs) + column filter in V.StepImplicit, tracer hyperdiffusion + filter in
