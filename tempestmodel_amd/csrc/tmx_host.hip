@@ -139,6 +139,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
 	if (const char * m = getenv("TMX_VI_PAIR")) e->vi_pair = (atoi(m) != 0) ? 1 : 0;
+	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
 	if (!plan_only(e)) {
 		int ndev = 0;
@@ -752,8 +753,11 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	HIPCHK(hipMalloc((void **)&e->d_ghost, gb)); HIPCHK(hipMemset(e->d_ghost, 0, gb)); bytes += gb;
 	HIPCHK(hipMalloc((void **)&e->d_sendbuf, sb)); bytes += sb;
 	const int n = TMX_FTOT * (L + 1);
-	const size_t abb = (size_t)n * TMX_BW * e->NUS * sizeof(double), rb = (size_t)n * e->NUS * sizeof(double);
-	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); bytes += abb;
+	// column-solve scratch: per-wavefront U-row streams [NUS/64][n][9 + 1][64] plus a zero page (fused / pair kernels);
+	// the split cross-check kernels keep the band matrix [n][9][NUS] and the right-hand sides [n][NUS] in the same buffers
+	const size_t zpage = 64 * sizeof(double);
+	const size_t abb = (size_t)n * (TMX_BW + 1) * e->NUS * sizeof(double) + zpage, rb = (size_t)n * e->NUS * sizeof(double);
+	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); HIPCHK(hipMemset((char *)e->d_ab + abb - zpage, 0, zpage)); bytes += abb;
 	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
 	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
 	e->hbm_bytes = bytes;

@@ -128,6 +128,7 @@ struct tmx_engine {
 	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
+	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
 	bool prof = false;
 	ProfSlot prof_slots[TMX_K_COUNT];

@@ -1742,22 +1742,31 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 // time, the kernel is bound by HBM traffic at ne30 and by dependent-issue latency on small grids.)
 // Tail of a pivot step shared by both paths: store the U row (row 0 of the window after the interchange, given as
 // piv / pb), sparse fill-in entries only where some lane is non-zero.
+// U rows and transformed right-hand side of the fused / pair kernels: one contiguous stream per wavefront,
+// [wavefront][matrix row][9 entries + rhs][64 lanes], so that the forward loop appends and the back substitution
+// reads 5 KB rows back to back instead of ten 512-byte pieces 389 KB apart.  `AB` below is the lane's pointer into
+// its wavefront's stream (vi_stream_base), NUS / RHS / u are unused by these two helpers.
+#define TMX_UW (TMX_BW + 1)
+__device__ __forceinline__ double * vi_stream_base(double * AB, int n, int u) {
+	return AB + ((size_t)(u >> 6) * n * TMX_UW) * 64 + (u & 63);
+}
+
 template <bool SPARSE>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
 #pragma unroll
-	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_BW + c) * NUS + u] = piv[c];
+	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
 	int mask = 0;
 #pragma unroll
 	for (int c = 4; c < TMX_BW; c++) {
 		if (!SPARSE || __builtin_amdgcn_ballot_w64(piv[c] != 0.0) != 0) {
-			AB[((size_t)jcol * TMX_BW + c) * NUS + u] = piv[c];
+			AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
 			mask |= 1 << c;
 		}
 	}
 	if (threadIdx.x == 0) umask[jcol] = mask;
-	RHS[(size_t)jcol * NUS + u] = pb;
+	AB[((size_t)jcol * TMX_UW + TMX_BW) * 64] = pb;
 }
 
 // Pivot step when every lane of the wavefront picked window row PV (the normal case: neighbouring columns have
@@ -1766,7 +1775,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 // so neither the 160 v_cndmask of the per-lane interchange nor the 36 moves of the slide are executed.  Only the
 // pivot row and old row 0 are copied aside, because their slots are overwritten before their last use.
 // Same multiplications and subtractions on the same operands as the generic path: bit-identical.
-template <bool SPARSE, int PV>
+template <bool SPARSE, int PV, int IS = 1>
 __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -1788,14 +1797,14 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 		b[r - 1] = ((r == PV) ? tb0 : b[r]) - pb * l;
 	}
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c];
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
 }
 
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
 // the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
 // the per-lane select path below.
-template <bool SPARSE, bool UNI = false>
+template <bool SPARSE, bool UNI = false, int IS = 1>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -1811,11 +1820,11 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		const int pv0 = __builtin_amdgcn_readfirstlane(pv);
 		if (__builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
 			switch (pv0) {
-				case 0: lu_pivot_tail_uniform<SPARSE, 0>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 1: lu_pivot_tail_uniform<SPARSE, 1>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 2: lu_pivot_tail_uniform<SPARSE, 2>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 3: lu_pivot_tail_uniform<SPARSE, 3>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				default: lu_pivot_tail_uniform<SPARSE, 4>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				default: lu_pivot_tail_uniform<SPARSE, 4, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
 		}
 	}
@@ -1850,15 +1859,55 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		b[r] = b[r + 1];
 	}
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c];
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
 }
 
 // Back substitution (dtbsv order) over the U rows and transformed right-hand side the elimination left in the
 // HBM scratch, result x0 - delta scattered to the column and its in-patch duplicates.  Rows are consumed three per
-// loop trip from three register sets; the loads that refill a set are issued right after it is consumed, i.e.
-// three rows (one trip) ahead of their use, without register-to-register rotation (which would force the wait
-// into the same trip).  n = 3(L+1) is a multiple of 3.
+// loop trip (rho, W, rho*theta of one level) from three register sets; the loads that refill a set are issued right
+// after it is consumed, i.e. three rows ahead of their use, without register-to-register rotation.  Everything the
+// trip computes and loads sits in ONE basic block with a FIXED number of loads per row: a fill-in entry that the
+// elimination did not store (umask) is read from a zero page behind RHS through a scalar-selected base instead of
+// being skipped by a branch, the level-L slots that have no slab are peeled off into the first trip, and the result
+// stores (the only conditional memory operations: duplicates exist for some lanes only) come last.  With
+// branches between the rows the compiler could neither overlap one row's division with the next rows' partial sums
+// nor count the loads in flight (it then waits for nearly all of them at every use: 1 180 cycles per row).
+// n = 3(L+1).
+struct URow { double u[TMX_BW]; double y, x0; };
+
+template <int COMP>
+__device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS, int u, int col, int NUS,
+	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, const int * umask, const double * zp)
+{
+	const int rr = row < 0 ? 0 : row;
+	const int mk = __builtin_amdgcn_readfirstlane(umask[rr]);
+	const double * rb = AB + (size_t)rr * TMX_UW * 64;
+#pragma unroll
+	for (int c = 0; c < 4; c++) d.u[c] = rb[c * 64];
+#pragma unroll
+	for (int c = 4; c < TMX_BW; c++) {
+		const double * bp = (mk & (1 << c)) ? rb + c * 64 : zp;
+		d.u[c] = bp[0];
+	}
+	d.y = rb[TMX_BW * 64];
+	const int k = rr / TMX_FTOT;
+	const int kc = (COMP == 1 || k < L) ? k : L - 1;      // level-L slots of rho*theta / rho have no slab: value unused
+	const int slab = (COMP == 0) ? TMX_SLAB_T(L, kc) : ((COMP == 1) ? TMX_SLAB_W(L, kc) : TMX_SLAB_R(L, kc));
+	d.x0 = xin[(size_t)slab * NS + col];
+}
+
+__device__ __forceinline__ double vi_back_row(const URow & s, double (&xw)[TMX_BW - 1]) {
+	double acc = s.y;
+#pragma unroll
+	for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * s.u[c];
+	const double xr = acc / s.u[0];
+#pragma unroll
+	for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];
+	xw[0] = xr;
+	return xr;
+}
+
 __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int u, int col, int NUS,
 	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, double * xup,
 	const int * __restrict__ udep, const int * umask)
@@ -1869,40 +1918,49 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
-	double ua[TMX_BW], ub[TMX_BW], uc[TMX_BW], ya, yb, yc, xa, xb, xc;
-	// slab of matrix row `row` (level k, component c); the unused level-L slots of rho*theta / rho map to -1
-#define ROW_SLAB(row) (((row) % TMX_FTOT) == 1 ? TMX_SLAB_W(L, (row) / TMX_FTOT) : \
-		(((row) / TMX_FTOT) == L ? -1 : (((row) % TMX_FTOT) == 0 ? TMX_SLAB_T(L, (row) / TMX_FTOT) : TMX_SLAB_R(L, (row) / TMX_FTOT))))
-#define LOAD_UROW(dst, ydst, xdst, row) do { const int rr_ = (row) < 0 ? 0 : (row); \
-		const int mk_ = __builtin_amdgcn_readfirstlane(umask[rr_]); \
-		_Pragma("unroll") for (int c = 0; c < 4; c++) dst[c] = AB[((size_t)rr_ * TMX_BW + c) * NUS + u]; \
-		_Pragma("unroll") for (int c = 4; c < TMX_BW; c++) dst[c] = (mk_ & (1 << c)) ? AB[((size_t)rr_ * TMX_BW + c) * NUS + u] : 0.0; \
-		ydst = RHS[(size_t)rr_ * NUS + u]; \
-		const int sl_ = ROW_SLAB(rr_); xdst = (sl_ >= 0) ? xin[(size_t)sl_ * NS + col] : 0.0; } while (0)
-#define BACK_ROW(ur, yr, x0r, row) do { \
-		double acc = yr; \
-		_Pragma("unroll") for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c]; \
-		const double xr = acc / ur[0]; \
-		_Pragma("unroll") for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1]; \
-		xw[0] = xr; \
-		const int slab = ROW_SLAB(row); \
-		if (slab >= 0) { \
-			const double val = x0r - xr; \
-			xup[(size_t)slab * NS + col] = val; \
-			_Pragma("unroll") for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[(size_t)slab * NS + dep[t]] = val; \
-		} } while (0)
-	LOAD_UROW(ua, ya, xa, n - 1); LOAD_UROW(ub, yb, xb, n - 2); LOAD_UROW(uc, yc, xc, n - 3);
-	for (int r = n - 1; r >= 2; r -= 3) {
-		BACK_ROW(ua, ya, xa, r);
-		LOAD_UROW(ua, ya, xa, r - 3);
-		BACK_ROW(ub, yb, xb, r - 1);
-		LOAD_UROW(ub, yb, xb, r - 4);
-		BACK_ROW(uc, yc, xc, r - 2);
-		LOAD_UROW(uc, yc, xc, r - 5);
+	// zero page: 64 doubles behind the streams; AB is the lane's stream pointer (vi_stream_base)
+	const double * zp = RHS + (u & 63);
+	// two trips (six rows) of register sets: a set is refilled for the trip after next right after it is consumed,
+	// so five rows = 55 loads are in flight (vmcnt holds 63) -- the back substitution of a full grid is HBM-bound
+	URow A, B, C, D, E, F;      // A,D: rows 3k+2 (rho); B,E: 3k+1 (W); C,F: 3k (rho*theta)
+#define LOADROW(S, COMP, row) vi_load_urow<COMP>(S, row, L, NS, u, col, NUS, AB, RHS, xin, umask, zp)
+	LOADROW(A, 2, n - 1); LOADROW(B, 1, n - 2); LOADROW(C, 0, n - 3);
+	LOADROW(D, 2, n - 4); LOADROW(E, 1, n - 5); LOADROW(F, 0, n - 6);
+	{
+		// level L: only W has a slab
+		vi_back_row(A, xw);
+		LOADROW(A, 2, n - 7);
+		const double vb = B.x0 - vi_back_row(B, xw);
+		LOADROW(B, 1, n - 8);
+		vi_back_row(C, xw);
+		LOADROW(C, 0, n - 9);
+		const size_t sW = (size_t)TMX_SLAB_W(L, L) * NS;
+		xup[sW + col] = vb;
+#pragma unroll
+		for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[sW + dep[t]] = vb;
 	}
-#undef ROW_SLAB
-#undef LOAD_UROW
-#undef BACK_ROW
+	// one level: rows 3k+2, 3k+1, 3k from the sets (X, Y, Z), which are refilled with the rows of level k - 2
+#define TRIP(X, Y, Z, k) do { \
+		const int k_ = (k); \
+		const double va = X.x0 - vi_back_row(X, xw); \
+		LOADROW(X, 2, 3 * k_ - 4); \
+		const double vb = Y.x0 - vi_back_row(Y, xw); \
+		LOADROW(Y, 1, 3 * k_ - 5); \
+		const double vc = Z.x0 - vi_back_row(Z, xw); \
+		LOADROW(Z, 0, 3 * k_ - 6); \
+		const size_t sR = (size_t)TMX_SLAB_R(L, k_) * NS, sW = (size_t)TMX_SLAB_W(L, k_) * NS, sT = (size_t)TMX_SLAB_T(L, k_) * NS; \
+		xup[sR + col] = va; xup[sW + col] = vb; xup[sT + col] = vc; \
+		_Pragma("unroll") for (int t = 0; t < 3; t++) \
+			if (dep[t] >= 0) { xup[sR + dep[t]] = va; xup[sW + dep[t]] = vb; xup[sT + dep[t]] = vc; } \
+	} while (0)
+	int k = L - 1;
+	for (; k >= 1; k -= 2) {
+		TRIP(D, E, F, k);
+		TRIP(A, B, C, k - 1);
+	}
+	if (k == 0) TRIP(D, E, F, 0);
+#undef TRIP
+#undef LOADROW
 }
 
 template <bool CARRY, bool SPARSE, bool CLOSED, bool UNI = false>
@@ -1926,6 +1984,8 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	if (u >= nunique) return;
 	const int n = TMX_FTOT * (L + 1);
 	const int col = ucol[u];
+	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
+	AB = vi_stream_base(AB, n, u);            // this lane's slot in its wavefront's U-row stream
 	ColConst cc;
 	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
 	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
@@ -2008,7 +2068,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 // (cycle counts in DESIGN.md), which is what bounds the kernel on small per-GPU grids.  Same statements on the
 // same operands: bit-identical to k_vi_fused.
 template <bool SPARSE, bool CLOSED, int PAIRS>
-__global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
+__global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
 {
@@ -2030,6 +2090,8 @@ __global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double
 	if (u >= nunique) return;          // both wavefronts drop the same lanes; each keeps at least one
 	const int n = TMX_FTOT * (L + 1);
 	const int col = ucol[u];
+	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
+	AB = vi_stream_base(AB, n, u);            // this lane's slot in its wavefront's U-row stream
 
 	if (role == 0) {
 		// ---- producer: assemble block rows 0..L ----
@@ -2060,8 +2122,10 @@ __global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double
 	}
 
 	// ---- consumer: pivoted band elimination on the 5x9 register window ----
+	// The incoming block row stays in the LDS ring until the pivot step that takes it in (stride-64 reads inside
+	// lu_pivot_step) instead of being copied to 30 registers first: the consumer then fits the register budget of
+	// two wavefronts per SIMD, which is what lets the pair kernel run on grids with more pairs than CUs x 2.
 	double R[5][TMX_BW], b[5];
-	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP = 0.0, fW = 0.0, fR = 0.0;
 	bool singular = false;
 #pragma unroll
 	for (int r = 0; r < 5; r++) {
@@ -2073,30 +2137,28 @@ __global__ __launch_bounds__(128 * PAIRS) void k_vi_pair(KParams p, const double
 		if (t >= 1) {
 			const int m = t - 1;
 			const double * q = ring + (size_t)(m & 1) * NQ * 64 + lane;
-#pragma unroll
-			for (int c = 0; c < TMX_BW; c++) { rP[c] = q[c * 64]; rW[c] = q[(TMX_BW + c) * 64]; rR[c] = q[(2 * TMX_BW + c) * 64]; }
-			fP = q[(3 * TMX_BW) * 64]; fW = q[(3 * TMX_BW + 1) * 64]; fR = q[(3 * TMX_BW + 2) * 64];
+			const double * qP = q, * qW = q + TMX_BW * 64, * qR = q + 2 * TMX_BW * 64, * qf = q + 3 * TMX_BW * 64;
 			if (m == 0) {
 				// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
 #pragma unroll
 				for (int c = 0; c < TMX_BW; c++) {
-					R[0][c] = (c + 4 < TMX_BW) ? rP[c + 4] : 0.0;
-					R[1][c] = (c + 3 < TMX_BW) ? rW[c + 3] : 0.0;
-					R[2][c] = (c + 2 < TMX_BW) ? rR[c + 2] : 0.0;
+					R[0][c] = (c + 4 < TMX_BW) ? qP[(c + 4) * 64] : 0.0;
+					R[1][c] = (c + 3 < TMX_BW) ? qW[(c + 3) * 64] : 0.0;
+					R[2][c] = (c + 2 < TMX_BW) ? qR[(c + 2) * 64] : 0.0;
 				}
-				b[0] = fP; b[1] = fW; b[2] = fR;
+				b[0] = qf[0]; b[1] = qf[64]; b[2] = qf[128];
 			} else if (m == 1) {
 #pragma unroll
 				for (int c = 0; c < TMX_BW; c++) {
-					R[3][c] = (c + 1 < TMX_BW) ? rP[c + 1] : 0.0;
-					R[4][c] = rW[c];
+					R[3][c] = (c + 1 < TMX_BW) ? qP[(c + 1) * 64] : 0.0;
+					R[4][c] = qW[c * 64];
 				}
-				b[3] = fP; b[4] = fW;
-				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 0, NUS, u, rR, fR, umask);      // pivot 0 takes in row 5
+				b[3] = qf[0]; b[4] = qf[64];
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask);      // pivot 0 takes in row 5
 			} else {
-				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
-				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
-				lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask);
 			}
 		}
 		__syncthreads();
@@ -2115,22 +2177,23 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	if (e->nunique == 0) return;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
-	// The pair kernel shortens the per-column dependent chain (124 vs 166 us on a small grid) but needs every
-	// wavefront alone on its SIMD: two pairs per workgroup = one workgroup per CU.  Measured: 137-140 us up to 211
-	// workgroups, 273 us from 243 on (the dispatcher then doubles up on some CUs while others idle), where the
-	// one-wavefront kernel takes 186 us.  So it is used below 200 workgroups -- i.e. on the per-GPU share of the
-	// ne30 grid from 2 GPUs up -- and the one-wavefront kernel above.
+	// The pair kernel shortens the per-column dependent chain to max(assembly, elimination) and is built for two
+	// wavefronts per SIMD (256 registers), so all pairs of a grid of up to 512 workgroups (2 per CU) are resident
+	// at once.  Measured per launch: ne30 on one GPU (760 column groups) 211 us against 229 us for the
+	// one-wavefront kernel; 190 groups 95 us with one pair per workgroup (every workgroup alone on a CU), 104 us with
+	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  Beyond 512 workgroups the grid no
+	// longer fits in one round and the one-wavefront kernel is used.
 	const int ngrp = (e->nunique + 63) / 64;
-	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry && (ngrp + 1) / 2 <= 200);
+	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry && (ngrp + 1) / 2 <= 512);
 	if (use_pair) {
-		const size_t lds2 = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) +
-			2 * ((size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int));
-		if (p.closed)
-			hipLaunchKernelGGL((k_vi_pair<true, true, 2>), dim3((ngrp + 1) / 2), dim3(64, 4), lds2, e->stream, p, xin, xup, dt,
-				e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
-		else
-			hipLaunchKernelGGL((k_vi_pair<true, false, 2>), dim3((ngrp + 1) / 2), dim3(64, 4), lds2, e->stream, p, xin, xup, dt,
-				e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
+		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double);
+		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
+		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
+#define LAUNCH_PAIR(CL_, NP_) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+			e->stream, p, xin, xup, dt, e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag)
+		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
+		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
+#undef LAUNCH_PAIR
 		return;
 	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
