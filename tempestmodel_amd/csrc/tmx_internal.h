@@ -59,6 +59,9 @@ struct PatchInfo {
 	std::vector<double> htrans;
 };
 
+struct StepGraphKey { int scheme, first, last; double dt; };
+struct StepGraph { StepGraphKey key; hipGraphExec_t exec = nullptr; };
+
 struct ProfSlot { double ms = 0.0; long long n = 0; };
 
 struct tmx_engine {
@@ -131,6 +134,8 @@ struct tmx_engine {
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
 	bool prof = false;
+	bool use_graph = false;                  // TMX_GRAPH=1: replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
+	std::vector<StepGraph> graphs;
 	ProfSlot prof_slots[TMX_K_COUNT];
 	std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
 };

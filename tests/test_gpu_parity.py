@@ -208,6 +208,26 @@ def test_viscosity_order_2_steps():
         e.close()
 
 
+def test_graph_replay_is_bit_identical(monkeypatch):
+    """TMX_GRAPH=1: ARS343 and Strang steps replayed from a captured hipGraph equal the plain launch sequence bit for bit."""
+    from tempestmodel_amd.engine import Engine
+    g, st = gu.make_grid(4, 8, 6)
+    res = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("TMX_GRAPH", graph)
+        e = Engine(g)
+        try:
+            e.upload_state(0, st)
+            for _ in range(4):
+                e.step_ars343(300.0)
+            e.sync()
+            res.append(e.download_state(0))
+        finally:
+            e.close()
+    for (na, ea), (nb, eb) in zip(res[0], res[1]):
+        assert np.array_equal(na, nb) and np.array_equal(ea, eb)
+
+
 def test_held_suarez_physics():
     """the column physics kernel against the C oracle and the reference's own output
     (HeldSuarezPhysics::Perform on the JW state after 2 steps); only exp/log/pow/sin/cos differ from the CPU."""
