@@ -190,6 +190,7 @@ static void dumpGeometry(TmxdWriter & w, Model & model, GridGLL * pGrid) {
 		dump3(w, pn + "z_interfaces", pPatch->GetZInterfaces());
 		dump4(w, pn + "ref_node", pPatch->GetReferenceState(DataLocation_Node));
 		dump4(w, pn + "ref_redge", pPatch->GetReferenceState(DataLocation_REdge));
+		if (pGrid->GetModel().GetEquationSet().GetTracers() > 0) dump4(w, pn + "ref_tracers", pPatch->GetReferenceTracers());
 		if (pGrid->HasRayleighFriction()) {
 			dump3(w, pn + "rayleigh_node", pPatch->GetRayleighStrength(DataLocation_Node));
 			dump3(w, pn + "rayleigh_redge", pPatch->GetRayleighStrength(DataLocation_REdge));
@@ -253,7 +254,8 @@ int main(int argc, char ** argv) {
 
 	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp", tcase = "jw";
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0, hvorder = 4;
-	double dt = 200.0, ztop = 30000.0;
+	double dt = 200.0, ztop = 30000.0, planet = 1.0, udiffS = 0.0, udiffV = 0.0;
+	bool fExplicitVertical = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		const char * v = (i + 1 < argc) ? argv[i+1] : "";
@@ -273,6 +275,9 @@ int main(int argc, char ** argv) {
 		else if (a == "--hypervis") { hvorder = atoi(v); i++; }      // hyperviscosity order 4 (default) or 2
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--ztop") { ztop = atof(v); i++; }
+		else if (a == "--planet") { planet = atof(v); i++; }          // reduced-planet factor X (with --udiff)
+		else if (a == "--udiff") { udiffS = atof(v); udiffV = atof((i + 2 < argc) ? argv[i+2] : "0"); i += 2; }   // uniform diffusion K_scalar K_vector
+		else if (a == "--explicitvertical") { fExplicitVertical = true; }
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 
@@ -313,7 +318,7 @@ try {
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
 	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
-	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, false, true, false));
+	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, fExplicitVertical, true, false));
 	model.SetVerticalDynamics(pV);
 
 	GridCSGLL * pGrid = new GridCSGLL(model);
@@ -332,6 +337,9 @@ try {
 		// ScharMountainSphereTest.cpp defaults (:417-441): reduced planet X = 500, no rotation, Rayleigh layer above 20 km
 		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
 		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
+	} else if (udiffS != 0.0 || udiffV != 0.0 || planet != 1.0) {
+		model.SetTestCase(new JWSmallPlanetDiffusion(ztop, ePert, ntracers, planet, udiffS, udiffV));
+		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * planet);   // as ScharMountainSphereTest.cpp:375 scales it
 	} else if (ntracers > 0) {
 		model.SetTestCase(new JWWithTracers(0.0, ztop, ePert, ntracers));
 	} else {
@@ -350,6 +358,11 @@ try {
 	w.iscalar("cfg/ninstances", model.GetComponentDataInstances());
 	w.iscalar("cfg/ntracers", ntracers);
 	w.iscalar("cfg/hypervis_order", hvorder);
+	w.iscalar("cfg/fully_explicit", fExplicitVertical ? 1 : 0);
+	w.iscalar("cfg/uniform_diffusion", pGrid->HasUniformDiffusion() ? 1 : 0);
+	w.scalar("cfg/udiff_scalar", pGrid->GetScalarUniformDiffusionCoeff());
+	w.scalar("cfg/udiff_vector", pGrid->GetVectorUniformDiffusionCoeff());
+	w.scalar("cfg/ztop", pGrid->GetZtop());
 	w.scalar("cfg/dt", dt);
 	if (geom && w.fp) {
 		dumpGeometry(w, model, pGrid);

@@ -34,4 +34,31 @@ private:
 	int m_nTracers;
 };
 
+
+// Test INPUT of our own for the configuration of the DCMIP2016 supercell (test/dcmip2016/SupercellTest.cpp:99-113:
+// planet reduced by X, no rotation, uniform diffusion, --explicitvertical) without its Fortran physics: the
+// Jablonowski-Williamson state on a reduced planet, uniform diffusion coefficients, and a reference state that
+// differs from the initial state (0.9 x), so that every "state minus reference state" term is exercised.
+class JWSmallPlanetDiffusion : public JWWithTracers {
+public:
+	JWSmallPlanetDiffusion(double dZtop, PerturbationType e, int nTracers, double dEarthScaling, double dKs, double dKv) :
+		JWWithTracers(0.0, dZtop, e, nTracers), m_nT(nTracers), m_dX(dEarthScaling), m_dKs(dKs), m_dKv(dKv) { }
+	virtual void EvaluatePhysicalConstants(PhysicalConstants & phys) const {
+		JWWithTracers::EvaluatePhysicalConstants(phys);
+		phys.SetOmega(0.0);
+		phys.SetEarthRadius(phys.GetEarthRadius() / m_dX);
+	}
+	virtual void GetUniformDiffusionCoeffs(double & dScalar, double & dVector) const { dScalar = m_dKs; dVector = m_dKv; }
+	virtual void EvaluateReferenceState(const PhysicalConstants & phys, double dZ, double dLon, double dLat,
+		double * dState, double * dTracer) const {
+		Time time;
+		JWWithTracers::EvaluatePointwiseState(phys, time, dZ, dLon, dLat, dState, dTracer);
+		for (int c = 0; c < 5; c++) dState[c] *= 0.9;
+		for (int c = 0; c < m_nT; c++) dTracer[c] *= 0.8;
+	}
+private:
+	int m_nT;
+	double m_dX, m_dKs, m_dKv;
+};
+
 #endif

@@ -121,6 +121,9 @@ static void filter_negative_tracers_h(const orc_grid * g, orc_state * s, int iup
 	}
 }
 
+static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally, int comp, int remove_ref);
+static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally, int from_ref);
+
 void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	if (g->shallow_water) { sw_step_explicit(g, s, iinit, iupd, dt); return; }
 	const int L = g->L;
@@ -275,6 +278,19 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 						const double q = tin[(((size_t)c * na + iA) * nb + iB) * L + k];
 						taf[i][j] = M3(Jn, iA, iB, k) * AUX(ConUa, i, j, k) * q;
 						tbf[i][j] = M3(Jn, iA, iB, k) * AUX(ConUb, i, j, k) * q;
+						if (g->uniform_diffusion) {
+							/* uniform diffusion of the tracer mixing ratio (:1105-1148) */
+							double daq = 0.0, dbq = 0.0;
+							for (int m = 0; m < NP; m++) {
+								daq += tin[(((size_t)c * na + eA + m) * nb + iB) * L + k] / NI(RIx, eA + m, iB, k) * D[m * NP + i];
+								dbq += tin[(((size_t)c * na + iA) * nb + eB + m) * L + k] / NI(RIx, iA, eB + m, k) * D[m * NP + j];
+							}
+							daq *= inv_da; dbq *= inv_da;
+							const double cdaq = M4(CA, iA, iB, k, 0) * daq + M4(CA, iA, iB, k, 1) * dbq;
+							const double cdbq = M4(CA, iA, iB, k, 1) * daq + M4(CB, iA, iB, k, 1) * dbq;
+							taf[i][j] -= g->udiff_scalar * M3(Jn, iA, iB, k) * NI(RIx, iA, iB, k) * cdaq;
+							tbf[i][j] -= g->udiff_scalar * M3(Jn, iA, iB, k) * NI(RIx, iA, iB, k) * cdbq;
+						}
 					}
 					for (int i = 0; i < NP; i++)
 					for (int j = 0; j < NP; j++) {
@@ -308,6 +324,13 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 	free(aux); free(fa_r); free(colbuf);
 #undef AUX
 #undef FLX
+	if (g->uniform_diffusion) {
+		/* HorizontalDynamicsFEM::StepExplicit, :1817-1859: uniform diffusion of (state - reference state) */
+		vector_hyperdiff_s(g, s, iinit, iupd, dt, -g->udiff_vector, -g->udiff_vector, 0, 0);
+		vector_hyperdiff_s(g, s, iinit, iupd, dt, g->udiff_vector, g->udiff_vector, 0, 1);
+		scalar_hyperdiff_c(g, s, iinit, iupd, dt, g->udiff_scalar, 0, PIx, 1);
+		scalar_hyperdiff_c(g, s, iinit, iupd, dt, g->udiff_vector, 0, WIx, 1);
+	}
 	filter_negative_tracers_h(g, s, iupd);      /* HorizontalDynamicsFEM::StepExplicit, :1862 */
 }
 
@@ -324,8 +347,11 @@ static void penalty_apply(const orc_grid * g, const double * w, const double * i
 	for (int a = 1; a < L; a++) out[a] += buf[a] * w[a - 1];
 }
 
+static void v_step_fully_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
+
 void orc_v_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	if (g->shallow_water) return;      /* VerticalDynamicsStub (TempestInitialize.h:362-365) */
+	if (g->fully_explicit) { v_step_fully_explicit(g, s, iinit, iupd, dt); return; }
 	const int L = g->L;
 	double * xidot = (double *)malloc(sizeof(double) * (L + 1));
 	double * w = (double *)malloc(sizeof(double) * (L + 1));
@@ -580,7 +606,7 @@ enum { FP = 0, FW = 1, FR = 2, FTOT = 3, OFFD = 4, LDAB = 13 };
 typedef struct {
 	double *un, *vn, *ue, *ve, *dua, *dub;             /* U,V on nodes/edges, d/dxi on edges   */
 	double *pn, *wn, *rn, *pe, *we, *re;               /* rhotheta, W, rho on nodes / edges     */
-	double *exn, *dpe, *xdn, *xde, *ddw, *mf, *pf, *dmf, *dpf, *ke, *dke, *uw, *aux;
+	double *exn, *dpe, *xdn, *xde, *ddw, *mf, *pf, *dmf, *dpf, *ke, *dke, *uw, *aux, *udd, *udr;
 } colwork;
 
 static double * dalloc(int n) { return (double *)calloc((size_t)n, sizeof(double)); }
@@ -660,6 +686,21 @@ static void column_f_jacobian(const orc_grid * g, const orc_patch * P, const dou
 		const double cb = M4E(CBe, iA, iB, k, 0) * ua + M4E(CBe, iA, iB, k, 1) * ub + M4E(CBe, iA, iB, k, 2) * ux;
 		const double curl = -ca * w->dua[k] - cb * w->dub[k];
 		F[VECF(FW, k)] += (w->dke[k] + curl);
+	}
+	if (g->uniform_diffusion) {
+		/* uniform diffusion of rho*theta and W in the vertical (PrepareColumn :2104-2160, BuildF :2593-2635):
+		 * second xi-derivative of (column - reference column), W not diffused on the boundaries */
+		const double cs = g->udiff_scalar / (g->ztop * g->ztop), cvv = g->udiff_vector / (g->ztop * g->ztop);
+		for (int k = 0; k < L; k++) w->aux[k] = P->ref_node[(((size_t)PIx * na + iA) * nb + iB) * L + k];
+		op_apply(g, ORC_OP_DIFFDIFF_N2N, w->pn, w->udd);
+		op_apply(g, ORC_OP_DIFFDIFF_N2N, w->aux, w->udr);
+		for (int k = 0; k < L; k++) w->udd[k] = w->udd[k] - w->udr[k];
+		for (int k = 0; k < L; k++) F[VECF(FP, k)] -= cs * w->udd[k];
+		for (int k = 0; k <= L; k++) w->aux[k] = P->ref_redge[(((size_t)WIx * na + iA) * nb + iB) * (L + 1) + k];
+		op_apply(g, ORC_OP_DIFFDIFF_E2E, w->aux, w->udr);
+		for (int k = 0; k <= L; k++) w->udd[k] = w->ddw[k] - w->udr[k];
+		w->udd[0] = 0.0; w->udd[L] = 0.0;
+		for (int k = 0; k <= L; k++) F[VECF(FW, k)] -= cvv * w->udd[k];
 	}
 	/* upwinding (:2640-2712): weights |xidot| at interfaces 1..L-1 */
 	const double upc = 0.5 * (1.0 / (double)L);            /* m_dUpwindCoeff (:394-395) */
@@ -795,13 +836,15 @@ static void update_column_tracers(const orc_grid * g, const orc_patch * P, int i
 	for (int k = 1; k < L; k++)
 		xd0[k] = M4E(CXe, iA, iB, k, 0) * w->ue[k] + M4E(CXe, iA, iB, k, 1) * w->ve[k] + M4E(CXe, iA, iB, k, 2) * x0[VECF(FW, k)];
 	xd0[0] = 0.0; xd0[L] = 0.0;
-	/* dRhoQ_k / dRhoQ_n (:3959-3976) */
+	/* dRhoQ_k / dRhoQ_n (:3959-3976); off-diagonal terms only with implicit advection (:3910-3912) */
+	if (!g->fully_explicit)
 	for (int k = 0; k < L; k++)
 		for (int m = g->opb[ORC_OP_DIFF_E2N][k]; m < g->ope[ORC_OP_DIFF_E2N][k]; m++)
 			for (int n = g->opb[ORC_OP_INTERP_N2E][m]; n < g->ope[ORC_OP_INTERP_N2E][m]; n++)
 				TMAT(n, k) += Cdiff[(size_t)k * ndiff + m] * Je[((size_t)iA * nb + iB) * (L + 1) + m]
 					/ Jn[((size_t)iA * nb + iB) * L + k] * Cint[(size_t)m * nint + n] * xd0[m];
 	/* upwinding in the Jacobian (:3978-4016) */
+	if (!g->fully_explicit)
 	for (int a = 1; a < L; a++) {
 		const double weight = fabs(xd0[a]);
 		for (int k = a - 1; k < a; k++)
@@ -812,24 +855,34 @@ static void update_column_tracers(const orc_grid * g, const orc_patch * P, int i
 				TMAT(n, k) -= weight * Cpr[(size_t)k * npr + n];
 	}
 	for (int k = 0; k < L; k++) TMAT(k, k) += 1.0 / dt;
-	/* xi_dot with the UPDATED W (:4059-4086) */
+	/* xi_dot with the UPDATED W, fully explicit: with the initial W (:4047-4086) */
 	for (int k = 1; k < L; k++)
 		xd1[k] = M4E(CXe, iA, iB, k, 0) * w->ue[k] + M4E(CXe, iA, iB, k, 1) * w->ve[k]
-			+ M4E(CXe, iA, iB, k, 2) * eup[(((size_t)WIx * na + iA) * nb + iB) * (L + 1) + k];
+			+ M4E(CXe, iA, iB, k, 2) * (g->fully_explicit ? x0[VECF(FW, k)] : eup[(((size_t)WIx * na + iA) * nb + iB) * (L + 1) + k]);
 	xd1[0] = 0.0; xd1[L] = 0.0;
 	for (int c = 0; c < nt; c++) {
 		for (int k = 0; k < L; k++) qn[k] = tin[(((size_t)c * na + iA) * nb + iB) * L + k];
 		op_apply(g, ORC_OP_INTERP_N2E, qn, qe);
 		for (int k = 0; k <= L; k++) mf[k] = Je[((size_t)iA * nb + iB) * (L + 1) + k] * qe[k] * xd1[k];
+		if (g->uniform_diffusion) {
+			/* uniform diffusion of (mixing ratio - reference mixing ratio) (:4117-4141) */
+			for (int k = 0; k < L; k++) {
+				aux[k] = qn[k] / w->rn[k];
+				aux[k] -= P->ref_tracer[(((size_t)c * na + iA) * nb + iB) * L + k] / P->ref_node[(((size_t)RIx * na + iA) * nb + iB) * L + k];
+			}
+			op_apply(g, ORC_OP_DIFF_N2E, aux, buf);
+			for (int k = 1; k < L; k++) mf[k] -= g->udiff_scalar * w->re[k] * buf[k];
+		}
 		mf[0] = 0.0; mf[L] = 0.0;
 		op_apply(g, ORC_OP_DIFF_E2N, mf, dmf);
 		for (int k = 0; k < L; k++) Fq[k] = dmf[k] / Jn[((size_t)iA * nb + iB) * L + k];
-		/* upwinding with the initial xi_dot (:4153-4181) */
-		for (int a = 0; a < L - 1; a++) ww[a] = fabs(xd0[a + 1]);
+		/* upwinding with the initial xi_dot (:4153-4181); fully explicit: m_dXiDotREdge, the same numbers */
+		for (int a = 0; a < L - 1; a++) ww[a] = fabs(g->fully_explicit ? xd1[a + 1] : xd0[a + 1]);
 		for (int k = 0; k < L; k++) aux[k] = 0.0;
 		penalty_apply(g, ww, qn, aux, buf);
 		for (int k = 0; k < L; k++) Fq[k] -= aux[k];
 		/* implicit velocity correction (:4183-4233) */
+		if (!g->fully_explicit)
 		for (int a = 1; a < L; a++) {
 			double sw;
 			if (xd0[a] > 0.0) sw = 1.0 * M4E(CXe, iA, iB, a, 2);
@@ -880,6 +933,7 @@ static void filter_negative_tracers_v(const orc_grid * g, orc_state * s, int iup
 }
 
 int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	if (g->fully_explicit) return 0;      /* VerticalDynamicsFEM::StepImplicit, :1239-1242 */
 	if (g->shallow_water) return 0;    /* VerticalDynamicsStub */
 	const int L = g->L;
 	const int n = FTOT * (L + 1);
@@ -974,7 +1028,10 @@ int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, 
 /* StepAfterSubCycle (HorizontalDynamicsFEM.cpp:1867-2203, 2207-2414, 2637-2726;                */
 /* GridPatchCSGLL.cpp:1132-1305)                                                               */
 
-static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally) {
+/* comp < 0: components 2..4; comp >= 2: that component only (iComponent); remove_ref: psi = initial - reference
+ * state (fRemoveRefState, :2056-2066) */
+static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally,
+	int comp, int remove_ref) {
 	const int L = g->L;
 	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
@@ -985,9 +1042,11 @@ static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 		const int na = P->na, nb = P->nb;
 		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
 		for (int c = 2; c < 5; c++) {
+			if (comp >= 0 && c != comp) continue;
 			const int Lk = (c == WIx) ? L + 1 : L;
 			const double * Jc = (c == WIx) ? P->g[ORC_G_JAC_E] : P->g[ORC_G_JAC];
 			const double * xin = ((c == WIx) ? s->redge[iinit * g->npatch + p] : s->node[iinit * g->npatch + p]) + (size_t)c * na * nb * Lk;
+			const double * xrf = remove_ref ? (((c == WIx) ? P->ref_redge : P->ref_node) + (size_t)c * na * nb * Lk) : NULL;
 			double * xup = ((c == WIx) ? s->redge[iupd * g->npatch + p] : s->node[iupd * g->npatch + p]) + (size_t)c * na * nb * Lk;
 #define XI(i,j,k) xin[((size_t)(i) * nb + (j)) * Lk + (k)]
 #define XU(i,j,k) xup[((size_t)(i) * nb + (j)) * Lk + (k)]
@@ -996,14 +1055,19 @@ static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 			for (int b = 0; b < P->neb; b++)
 			for (int k = 0; k < Lk; k++) {
 				const int eA = a * NP + 1, eB = b * NP + 1;
-				double ga[NP][NP], gb[NP][NP];
+				double ga[NP][NP], gb[NP][NP], psi[NP][NP];
+				for (int i = 0; i < NP; i++)
+				for (int j = 0; j < NP; j++) {
+					psi[i][j] = XI(eA + i, eB + j, k);
+					if (xrf) psi[i][j] -= xrf[((size_t)(eA + i) * nb + (eB + j)) * Lk + k];
+				}
 				for (int i = 0; i < NP; i++)
 				for (int j = 0; j < NP; j++) {
 					const int iA = eA + i, iB = eB + j;
 					double da = 0.0, db = 0.0;
 					for (int q = 0; q < NP; q++) {
-						da += XI(eA + q, iB, k) * D[q * NP + i];
-						db += XI(iA, eB + q, k) * D[q * NP + j];
+						da += psi[q][j] * D[q * NP + i];
+						db += psi[i][q] * D[q * NP + j];
 					}
 					da *= inv_da; db *= inv_da;
 					ga[i][j] = JC(iA, iB, k) * (C2A[(iA * nb + iB) * 2 + 0] * da + C2A[(iA * nb + iB) * 2 + 1] * db);
@@ -1027,6 +1091,10 @@ static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 #undef JC
 		}
 	}
+}
+
+static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally) {
+	scalar_hyperdiff_c(g, s, iinit, iupd, dt, nu, scale_locally, -1, 0);
 }
 
 /* ApplyScalarHyperdiffusion, tracer branch (iType == 1, :1999-2035): the same Laplacian on every tracer density */
@@ -1085,7 +1153,8 @@ static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 	}
 }
 
-static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally) {
+/* from_ref: iDataInitial == DATA_INDEX_REFERENCE, the source is the reference state (:2249-2253, :2304-2308) */
+static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally, int from_ref) {
 	const int L = g->L;
 	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
@@ -1099,7 +1168,7 @@ static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 		const int na = P->na, nb = P->nb;
 		const double * J2 = P->g[ORC_G_JAC2D];
 		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
-		const double * nin = s->node[iinit * g->npatch + p];
+		const double * nin = from_ref ? P->ref_node : s->node[iinit * g->npatch + p];
 		double * nup = s->node[iupd * g->npatch + p];
 		for (int a = 0; a < P->nea; a++)
 		for (int b = 0; b < P->neb; b++)
@@ -1145,6 +1214,10 @@ static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 			}
 		}
 	}
+}
+
+static void vector_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally) {
+	vector_hyperdiff_s(g, s, iinit, iupd, dt, nud, nuv, scale_locally, 0);
 }
 
 /* HorizontalDynamicsFEM::ApplyRayleighFriction (HorizontalDynamicsFEM.cpp:2420-2570): where the strength is
@@ -1375,6 +1448,49 @@ void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int
 	free(x0); free(F); free(AB);
 }
 
+/* VerticalDynamicsFEM::StepExplicit with fFullyExplicit (--explicitvertical; :745-812, :984-1105): per column
+ * Evaluate (= PrepareColumn + BuildF at the initial column) and rho*theta, W, rho -= dt F; tracers by
+ * UpdateColumnTracers in its explicit branch; then the upwind penalty of U, V with dt |xi_dot| of that column and,
+ * with uniform diffusion, the vertical diffusion of (U, V) - (U, V)_ref. */
+static void v_step_fully_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
+	const int L = g->L;
+	const int n = FTOT * (L + 1);
+	double * x0 = dalloc(n), * F = dalloc(n), * AB = dalloc(n * LDAB);
+	double * wts = dalloc(L + 1), * buf = dalloc(L + 2), * dd = dalloc(L + 1), * ddr = dalloc(L + 1), * col = dalloc(L + 1);
+	colwork w; colwork_init(&w, L);
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		const double * nin = s->node[iinit * g->npatch + p];
+		const double * ein = s->redge[iinit * g->npatch + p];
+		double * nup = s->node[iupd * g->npatch + p];
+		double * eup = s->redge[iupd * g->npatch + p];
+		for (int iA = 1; iA < na - 1; iA++)
+		for (int iB = 1; iB < nb - 1; iB++) {
+			column_f_jacobian(g, P, nin, ein, iA, iB, dt, x0, F, AB, &w);
+			for (int k = 0; k < L; k++) NU(PIx, iA, iB, k) -= dt * F[VECF(FP, k)];
+			for (int k = 0; k <= L; k++) EU(WIx, iA, iB, k) -= dt * F[VECF(FW, k)];
+			for (int k = 0; k < L; k++) NU(RIx, iA, iB, k) -= dt * F[VECF(FR, k)];
+			if (has_tracers(g, s))
+				update_column_tracers(g, P, iA, iB, dt, x0, &w, eup, s->tracer[iinit * g->npatch + p], s->tracer[iupd * g->npatch + p]);
+			for (int a = 0; a < L - 1; a++) wts[a] = dt * fabs(w.xde[a + 1]);
+			penalty_apply(g, wts, &NI(UIx, iA, iB, 0), &NU(UIx, iA, iB, 0), buf);
+			penalty_apply(g, wts, &NI(VIx, iA, iB, 0), &NU(VIx, iA, iB, 0), buf);
+			if (g->uniform_diffusion) {
+				const double cf = g->udiff_vector / (g->ztop * g->ztop);
+				for (int c = UIx; c <= VIx; c++) {
+					op_apply(g, ORC_OP_DIFFDIFF_N2N, c == UIx ? w.un : w.vn, dd);
+					for (int k = 0; k < L; k++) col[k] = P->ref_node[(((size_t)c * na + iA) * nb + iB) * L + k];
+					op_apply(g, ORC_OP_DIFFDIFF_N2N, col, ddr);
+					for (int k = 0; k < L; k++) NU(c, iA, iB, k) += dt * cf * (dd[k] - ddr[k]);
+				}
+			}
+		}
+	}
+	colwork_free(&w);
+	free(x0); free(F); free(AB); free(wts); free(buf); free(dd); free(ddr); free(col);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* the other steppers of the path, call for call as the reference issues them                   */
 
@@ -1466,7 +1582,8 @@ int orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last,
 		const double half = 0.5 * dt;
 		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
 		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
-		if (first) VI(0, 0, half); else orc_linear_combine(g, s, carry, 2, 0);
+		if (first) VI(0, 0, half);
+		else { orc_linear_combine(g, s, carry, 2, 0); filter_negative_tracers_v(g, s, 0); }      /* TimestepSchemeStrang.cpp:476-481 */
 		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, dt / 5.0);
 		orc_copy(g, s, 0, 2); hvd(g, s, 1, 2, dt / 5.0);
 		orc_copy(g, s, 0, 3); hvd(g, s, 2, 3, dt / 3.0);

@@ -66,6 +66,7 @@ typedef struct {
 	 * and the reference state [5][na][nb][L] / [5][na][nb][L+1] (GridPatch::GetReferenceState)                */
 	const double * ray_node; const double * ray_redge;
 	const double * ref_node; const double * ref_redge;
+	const double * ref_tracer;         /* [ntracers][na][nb][L] GridPatch::GetReferenceTracers (uniform diffusion of tracers; may be NULL) */
 	const double * area_node;          /* [na][nb][L] GridPatch::GetElementAreaNode (tracer filters; NULL without tracers) */
 	const double * lat;                /* [na][nb] GridPatch::GetLatitude (column physics; may be NULL) */
 	const double * surf_p;             /* [na][nb] the "surface pressure" HeldSuarezPhysics::Perform forms from the interface slots (may be NULL) */
@@ -86,6 +87,10 @@ typedef struct {
 	int shallow_water;                 /* 1: ShallowWaterEquations (U,V,H; H kept in slot 2, one level)  */
 	int ntracers;                      /* EquationSet::GetTracers(); tracer densities live on levels      */
 	int hypervis_order;                /* 4 (two-pass hyperviscosity), 2 (viscosity) or 0 (none); HorizontalDynamicsFEM ctor */
+	int fully_explicit;                /* VerticalDynamicsFEM ctor fFullyExplicit (--explicitvertical): StepExplicit applies -dt F, StepImplicit does nothing */
+	int uniform_diffusion;             /* Grid::HasUniformDiffusion(); supported with fully_explicit only */
+	double udiff_scalar, udiff_vector; /* Grid::GetScalarUniformDiffusionCoeff / GetVectorUniformDiffusionCoeff [m^2/s] */
+	double ztop;                       /* Grid::GetZtop() */
 } orc_grid;
 
 /* state: node[inst*npatch + p], redge[inst*npatch + p] */

@@ -1310,7 +1310,7 @@ static void ars343_tableau(double * u2, double * u3, double * u4, double * dexp,
 // small program, and run_program folds neighbouring calls into one kernel pass where the result is
 // bit-identical (see the rules there).
 
-enum OpKind { OP_COPY, OP_LINCOMB, OP_HEXP, OP_VEXP, OP_DSS, OP_VIMP, OP_VITE, OP_HVIS };
+enum OpKind { OP_COPY, OP_LINCOMB, OP_HEXP, OP_VEXP, OP_DSS, OP_VIMP, OP_VITE, OP_HVIS, OP_VFILT };
 struct Op {
 	int kind, a, b, c;
 	double coef;
@@ -1325,6 +1325,7 @@ static void P_v(Program & p, int i, int u, double c) { Op o = { OP_VEXP, i, u, 0
 static void P_hv(Program & p, int i, int u, double c) { P_h(p, i, u, c); P_v(p, i, u, c); }
 static void P_dss(Program & p, int i) { Op o = { OP_DSS, i, 0, 0, 0.0, { 0 }, 0 }; p.push_back(o); }
 static void P_vimp(Program & p, int i, int u, double c) { Op o = { OP_VIMP, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
+static void P_vfilt(Program & p, int u) { Op o = { OP_VFILT, u, u, 0, 0.0, { 0 }, 0 }; p.push_back(o); }
 static void P_vite(Program & p, int i, int u, double c) { Op o = { OP_VITE, i, u, 0, c, { 0 }, 0 }; p.push_back(o); }
 static void P_hvis(Program & p, int i, int u, int w, double c) { Op o = { OP_HVIS, i, u, w, c, { 0 }, 0 }; p.push_back(o); }
 static void P_lc(Program & p, const double * cf, int n, int dst) {
@@ -1396,7 +1397,7 @@ static int build_program(int scheme, int first, int last, double dt, Program & p
 		const double half = 0.5 * dt;
 		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
 		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
-		if (first) P_vimp(p, 0, 0, half); else P_lc(p, carry, 2, 0);
+		if (first) P_vimp(p, 0, 0, half); else { P_lc(p, carry, 2, 0); P_vfilt(p, 0); }      // FilterNegativeTracers(0), :476-481
 		P_copy(p, 0, 1); P_hv(p, 0, 1, dt / 5.0); P_dss(p, 1);
 		P_copy(p, 0, 2); P_hv(p, 1, 2, dt / 5.0); P_dss(p, 2);
 		P_copy(p, 0, 3); P_hv(p, 2, 3, dt / 3.0); P_dss(p, 3);
@@ -1516,6 +1517,10 @@ static int run_program(tmx_engine * e, const Program & p) {
 			break;
 		case OP_VIMP:
 			if ((r = tmx_v_step_implicit(e, o.a, o.b, o.coef))) return r;
+			break;
+		case OP_VFILT:
+			// VerticalDynamics::FilterNegativeTracers(instance): nothing without tracers
+			if (e->nt > 0) { ProfScope ps(e, TMX_K_LINCOMB); tmxk_v_filter_tracers(e, make_params(e), inst(e, o.a)); if ((r = launch_check("v_filter_tracers"))) return r; }
 			break;
 		case OP_VITE:
 			if ((r = vi_terms_explicit(e, o.a, o.b, o.coef))) return r;

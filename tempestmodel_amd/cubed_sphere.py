@@ -736,6 +736,9 @@ class CubedSphereGrid:
                 tr = test.evaluate_tracers(self.phys, z, lon, lat, out["state_node"][RIX])
                 self.initial_tracers = getattr(self, "initial_tracers", {})
                 self.initial_tracers[P.index] = np.stack([np.broadcast_to(t, z.shape) for t in tr], 0).copy()
+                if hasattr(test, "evaluate_reference_tracers"):      # GridPatch::GetReferenceTracers
+                    rt = test.evaluate_reference_tracers(self.phys, z, lon, lat, out["state_node"][RIX])
+                    g["ref_tracers"] = np.stack([np.broadcast_to(t, z.shape) for t in rt], 0).copy()
             # Rayleigh friction strength on levels and interfaces, every node incl. halo (GridPatchCSGLL.cpp:663-683)
             if getattr(test, "has_rayleigh_friction", False):
                 g["rayleigh_node"] = test.evaluate_rayleigh_strength(g["z_levels"])
@@ -884,6 +887,34 @@ class BaroclinicWaveJW:
             ulon = ulon + np.where(gc < 1.0, self.Up * np.exp(-gc * gc), 0.0)
         zero = np.zeros_like(ulon)
         return [ulon, zero, theta, zero.copy(), rho]
+
+
+class BaroclinicWaveJWSmallPlanet(BaroclinicWaveJW):
+    """The configuration of the DCMIP2016 supercell (test/dcmip2016/SupercellTest.cpp:99-113: planet reduced by X, no
+    rotation, uniform diffusion K_scalar / K_vector, --explicitvertical) driven by the Jablonowski-Williamson state:
+    mirror of oracle/test_inputs.h's JWSmallPlanetDiffusion (a test input).  The reference state is 0.9 x the
+    pointwise state (tracers 0.8 x), so that "state minus reference state" is non-trivial everywhere."""
+
+    def __init__(self, ztop=30000.0, pert="exp", ntracers=0, X=120.0, udiff=(1500.0, 500.0)):
+        BaroclinicWaveJW.__init__(self, 0.0, ztop, pert, ntracers=ntracers)
+        self.X = X
+        self.uniform_diffusion = tuple(udiff)
+
+    @property
+    def reference_length(self):
+        return 0.5 * math.pi / 30.0 * self.X
+
+    def evaluate_physical_constants(self, phys):
+        BaroclinicWaveJW.evaluate_physical_constants(self, phys)
+        phys.omega = 0.0
+        phys.earth_radius = phys.earth_radius / self.X
+
+    def evaluate_pointwise(self, phys, z, lon, lat, reference=False):
+        st = BaroclinicWaveJW.evaluate_pointwise(self, phys, z, lon, lat, reference=False)
+        return [0.9 * v for v in st] if reference else st
+
+    def evaluate_reference_tracers(self, phys, z, lon, lat, rho):
+        return [0.8 * t for t in self.evaluate_tracers(phys, z, lon, lat, rho)]
 
 
 class ScharMountainSphere:
