@@ -23,6 +23,7 @@
 #include "CubedSphereTrans.h"
 #include "HorizontalDynamics.h"
 #include "VerticalDynamics.h"
+#include "VerticalDynamicsFEM.h"
 #include "TimestepScheme.h"
 #include "Exception.h"
 #include "WorkflowProcess.h"
@@ -45,6 +46,10 @@ public:
 			it = s_map.insert(std::make_pair(&model, new MI355XEngine(model))).first;
 		}
 		return *(it->second);
+	}
+
+	void SetFullyExplicit(bool fFullyExplicit) {
+		m_fFullyExplicit = fFullyExplicit;
 	}
 
 	void SetViscosity(double dNuScalar, double dNuDiv, double dNuVort, int nOrder) {
@@ -100,7 +105,7 @@ public:
 private:
 	MI355XEngine(Model & model) :
 		m_model(model), m_pEngine(NULL),
-		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4)
+		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4), m_fFullyExplicit(false)
 	{ }
 
 	GridGLL * Grid() {
@@ -157,6 +162,18 @@ private:
 		cfg.equation_set =
 			(m_model.GetEquationSet().GetType() == EquationSet::ShallowWaterEquations)
 				? TMX_EQN_SHALLOW_WATER : TMX_EQN_PRIMITIVE_NONHYDROSTATIC;
+		// --explicitvertical: either announced by VerticalDynamicsMI355X (parity mode) or read from the reference's own
+		// VerticalDynamicsFEM when only the TimestepScheme is replaced (production mode)
+		bool fFullyExplicit = m_fFullyExplicit;
+		VerticalDynamicsFEM * pVFEM = dynamic_cast<VerticalDynamicsFEM *>(m_model.GetVerticalDynamics());
+		if (pVFEM != NULL) {
+			fFullyExplicit = pVFEM->IsFullyExplicit();
+		}
+		cfg.fully_explicit = fFullyExplicit ? 1 : 0;
+		cfg.uniform_diffusion = pGrid->HasUniformDiffusion() ? 1 : 0;
+		cfg.uniform_diffusion_scalar = pGrid->GetScalarUniformDiffusionCoeff();
+		cfg.uniform_diffusion_vector = pGrid->GetVectorUniformDiffusionCoeff();
+		cfg.ztop = pGrid->GetZtop();
 		Check(tmx_create(&cfg, &m_pEngine));
 
 		// 1-D spectral-element matrices and the ten column operators
@@ -326,6 +343,17 @@ private:
 		}
 		Check(tmx_finalize(m_pEngine));
 
+		// reference state the uniform diffusion is taken relative to (Grid::HasUniformDiffusion)
+		if (pGrid->HasUniformDiffusion()) {
+			for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+				GridPatch * pPatch = pGrid->GetActivePatch(n);
+				Check(tmx_set_patch_reference_state(m_pEngine, pPatch->GetPatchIndex(),
+					&(pPatch->GetReferenceState(DataLocation_Node)[0][0][0][0]),
+					&(pPatch->GetReferenceState(DataLocation_REdge)[0][0][0][0]),
+					(cfg.n_tracers > 0) ? &(pPatch->GetReferenceTracers()[0][0][0][0]) : NULL));
+			}
+		}
+
 #ifdef TEMPEST_MPIOMP
 		if (nRanks > 1) {
 			unsigned char id[128];
@@ -343,6 +371,7 @@ private:
 	tmx_engine * m_pEngine;
 	double m_dNuScalar, m_dNuDiv, m_dNuVort;
 	int m_nHypervisOrder;
+	bool m_fFullyExplicit;
 };
 
 ///////////////////////////////////////////////////////////////////////////////
@@ -385,9 +414,11 @@ public:
 ///	</summary>
 class VerticalDynamicsMI355X : public VerticalDynamics {
 public:
-	VerticalDynamicsMI355X(Model & model, int nHorizontalOrder, int nVerticalOrder) :
+	VerticalDynamicsMI355X(Model & model, int nHorizontalOrder, int nVerticalOrder, bool fFullyExplicit = false) :
 		VerticalDynamics(model)
-	{ }
+	{
+		MI355XEngine::For(model).SetFullyExplicit(fFullyExplicit);
+	}
 
 	virtual void StepExplicit(int iDataInitial, int iDataUpdate, const Time & time, double dDeltaT) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);

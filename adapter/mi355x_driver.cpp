@@ -54,10 +54,10 @@ public:
 	VerticalDynamicsFEM m_ref;
 	VerticalDynamicsMI355X m_dev;
 	bool m_fDevice;
-	VSwitch(Model & model) :
+	VSwitch(Model & model, bool fFullyExplicit) :
 		VerticalDynamics(model),
-		m_ref(model, 4, 1, 0, false, true, false),
-		m_dev(model, 4, 1),
+		m_ref(model, 4, 1, 0, fFullyExplicit, true, false),
+		m_dev(model, 4, 1, fFullyExplicit),
 		m_fDevice(false) { }
 	virtual void Initialize() { static_cast<VerticalDynamics &>(m_ref).Initialize(); }
 	virtual void StepExplicit(int a, int b, const Time & t, double dt) {
@@ -148,7 +148,10 @@ try {
 
 	TSwitch * pT = new TSwitch(model);
 	HSwitch * pH = new HSwitch(model);
-	VSwitch * pV = new VSwitch(model);
+	// --case supercell: the configuration of test/dcmip2016/SupercellTest.cpp (planet / 120, no rotation, uniform
+	// diffusion 1500 / 500 m^2/s, --explicitvertical) without its Fortran physics, driven by the JW state
+	const bool fSupercell = (tcase == "supercell");
+	VSwitch * pV = new VSwitch(model, fSupercell);
 	model.SetTimestepScheme(pT);
 	model.SetHorizontalDynamics(pH);
 	model.SetVerticalDynamics(pV);
@@ -163,6 +166,9 @@ try {
 		// ScharMountainSphereTest.cpp defaults: reduced planet X = 500, no rotation, Rayleigh layer above 20 km
 		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
 		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
+	} else if (fSupercell) {
+		model.SetTestCase(new JWSmallPlanetDiffusion(ztop, BaroclinicWaveJWTest::PerturbationType_Exp, ntracers, 120.0, 1500.0, 500.0));
+		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 120.0);
 	} else if (ntracers > 0) {
 		model.SetTestCase(new JWWithTracers(0.0, ztop, BaroclinicWaveJWTest::PerturbationType_Exp, ntracers));
 	} else {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 4
+#define TMX_ABI_VERSION 5
 
 #define TMX_OK                 0
 #define TMX_ERR_INVALID       -1   /* bad argument / call order                      */
@@ -77,6 +77,12 @@ typedef struct {
 	int    rank, n_ranks;      /* this process / number of processes sharing the grid          */
 	int    device;             /* HIP device ordinal, -1 = current, -2 = plan only (no GPU)    */
 	int    equation_set;       /* EquationSet::Type (src/atm/EquationSet.h): TMX_EQN_*          */
+	int    fully_explicit;     /* VerticalDynamicsFEM ctor fFullyExplicit (--explicitvertical, TempestInitialize.h:372-379):
+	                              V.StepExplicit applies -dt F of the column, V.StepImplicit does nothing       */
+	int    uniform_diffusion;  /* Grid::HasUniformDiffusion() (src/atm/Grid.cpp:399-415); requires fully_explicit and
+	                              tmx_set_patch_reference_state on every owned patch                           */
+	double uniform_diffusion_scalar, uniform_diffusion_vector;   /* Grid::GetScalar/VectorUniformDiffusionCoeff() [m^2/s] */
+	double ztop;               /* Grid::GetZtop() (vertical uniform diffusion divides by ztop^2); unused otherwise  */
 } tmx_config;
 
 #define TMX_EQN_PRIMITIVE_NONHYDROSTATIC 0   /* 5 components U,V,rho*theta,W,rho                        */
@@ -166,6 +172,16 @@ int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const double * x_nod
  * W towards the reference state wherever the strength is non-zero.  Not available for the shallow-water set. */
 int tmx_set_patch_rayleigh(tmx_engine * e, int patch, const double * strength_node, const double * strength_redge,
 	const double * ref_node, const double * ref_redge);
+
+/* Per owned patch, required when cfg.uniform_diffusion != 0: the reference state the uniform diffusion is taken
+ * relative to.  ref_node [5][na][nb][L] / ref_redge [5][na][nb][L+1] = GridPatch::GetReferenceState(DataLocation_Node /
+ * _REdge), ref_tracers [n_tracers][na][nb][L] = GridPatch::GetReferenceTracers() (NULL when n_tracers == 0); same
+ * layout as tmx_upload_state.  Used by: the uniform-diffusion extras of HorizontalDynamicsFEM::StepExplicit
+ * (src/atm/HorizontalDynamicsFEM.cpp:1817-1859; tracer fluxes :1105-1148), the vertical diffusion of U,V in
+ * VerticalDynamicsFEM::StepExplicit (src/atm/VerticalDynamicsFEM.cpp:1059-1105), of rho*theta and W in BuildF
+ * (:2593-2635) and of the tracer mixing ratios in UpdateColumnTracers (:4117-4141). */
+int tmx_set_patch_reference_state(tmx_engine * e, int patch, const double * ref_node, const double * ref_redge,
+	const double * ref_tracers);
 
 /* Builds the HBM layout, DSS groups, unique-column lists and exchange plan. */
 int tmx_finalize(tmx_engine * e);

@@ -122,6 +122,14 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg->n_tracers >= 0 && cfg->n_tracers <= 16, TMX_ERR_UNSUPPORTED, "0..16 tracers supported, got %d", cfg->n_tracers);
 	REQUIRE(cfg->n_tracers == 0 || cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC, TMX_ERR_UNSUPPORTED, "tracers are supported with the nonhydrostatic equation set only");
 	REQUIRE(cfg->hypervis_order == 4 || cfg->hypervis_order == 2 || cfg->hypervis_order == 0, TMX_ERR_UNSUPPORTED, "hyperviscosity order %d unsupported (0, 2 or 4)", cfg->hypervis_order);
+	REQUIRE((cfg->fully_explicit == 0 || cfg->fully_explicit == 1) && (cfg->uniform_diffusion == 0 || cfg->uniform_diffusion == 1), TMX_ERR_INVALID, "fully_explicit / uniform_diffusion must be 0 or 1");
+	REQUIRE(!(cfg->fully_explicit || cfg->uniform_diffusion) || cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC, TMX_ERR_UNSUPPORTED,
+		"fully explicit vertical dynamics / uniform diffusion need the nonhydrostatic equation set");
+	// With implicit vertical dynamics the reference's StepExplicit diffuses whatever column the previous StepImplicit
+	// left in m_dStateNode (SetupReferenceColumn is not called there, VerticalDynamicsFEM.cpp:745-812 vs :1059-1105)
+	// and its tracer update throws "Not implemented" (:3914-3917): no stock case uses that combination.
+	REQUIRE(!cfg->uniform_diffusion || cfg->fully_explicit, TMX_ERR_UNSUPPORTED, "uniform diffusion is supported with fully explicit vertical dynamics only (the supercell configuration)");
+	REQUIRE(!cfg->uniform_diffusion || cfg->ztop > 0.0, TMX_ERR_INVALID, "uniform diffusion needs cfg.ztop > 0");
 	REQUIRE(cfg->equation_set == TMX_EQN_PRIMITIVE_NONHYDROSTATIC || cfg->equation_set == TMX_EQN_SHALLOW_WATER,
 		TMX_ERR_UNSUPPORTED, "equation set %d unsupported", cfg->equation_set);
 	if (cfg->equation_set == TMX_EQN_SHALLOW_WATER) REQUIRE(cfg->levels == 1, TMX_ERR_INVALID, "shallow water needs levels == 1");
@@ -135,6 +143,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->nt = cfg->n_tracers;
 	e->nslab = 5 * e->L + 1 + e->nt * e->L;
 	e->sw = (cfg->equation_set == TMX_EQN_SHALLOW_WATER);
+	e->fully_explicit = cfg->fully_explicit != 0; e->udiff = cfg->uniform_diffusion != 0;
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
@@ -169,7 +178,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->xstream) { hipStreamSynchronize(e->xstream); hipStreamDestroy(e->xstream); hipEventDestroy(e->ev_pack); hipEventDestroy(e->ev_recv); }
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
-		free_dev(e->d_state); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
@@ -716,6 +725,11 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		std::vector<double>().swap(e->h_area);
 		HIPCHK(hipMalloc((void **)&e->d_w0, (size_t)(L + 1) * NS * sizeof(double))); bytes += (size_t)(L + 1) * NS * sizeof(double);
 	}
+	if (e->udiff) {
+		// reference state in the layout of a state instance (filled by tmx_set_patch_reference_state)
+		const size_t rb = (size_t)e->nslab * NS * sizeof(double);
+		HIPCHK(hipMalloc((void **)&e->d_ref, rb)); HIPCHK(hipMemset(e->d_ref, 0, rb)); bytes += rb;
+	}
 	{
 		int nset = 0;
 		for (int lp : e->local_patches) nset += e->patches[lp].rayleigh_set ? 1 : 0;
@@ -775,6 +789,40 @@ static int check_state_args(tmx_engine * e, int patch, int instance) {
 	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
 	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not local", patch);
 	REQUIRE(instance >= 0 && instance < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range", instance);
+	return TMX_OK;
+}
+
+// GridPatch::GetReferenceState / GetReferenceTracers -> the reference "instance" of the uniform diffusion
+extern "C" int tmx_set_patch_reference_state(tmx_engine * e, int patch, const double * ref_node, const double * ref_redge, const double * ref_tracers) {
+	int r = check_state_args(e, patch, 0);
+	if (r) return r;
+	REQUIRE(e->udiff, TMX_ERR_INVALID, "tmx_set_patch_reference_state: the engine was created without uniform diffusion");
+	REQUIRE(ref_node && ref_redge && (ref_tracers || e->nt == 0), TMX_ERR_INVALID, "tmx_set_patch_reference_state: null array");
+	PatchInfo & P = e->patches[patch];
+	const int L = e->L, na = P.na, nb = P.nb;
+	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
+	std::vector<double> buf((size_t)e->nslab * ncp);
+	const int nodevar[4] = { 0, 1, 2, 4 };
+	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
+		const int c = col_of(P, i, j) - c0;
+		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
+			buf[(size_t)(v * L + k) * ncp + c] = ref_node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k];
+		for (int k = 0; k <= L; k++)
+			buf[(size_t)(4 * L + k) * ncp + c] = ref_redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k];
+		for (int v = 0; v < e->nt; v++) for (int k = 0; k < L; k++)
+			buf[(size_t)TMX_SLAB_Q(L, v, k) * ncp + c] = ref_tracers[(((size_t)v * na + i) * nb + j) * L + k];
+	}
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpy2D(e->d_ref + c0, (size_t)e->NS * sizeof(double), buf.data(), (size_t)ncp * sizeof(double),
+		(size_t)ncp * sizeof(double), e->nslab, hipMemcpyHostToDevice));
+	P.ref_set = true;
+	return TMX_OK;
+}
+
+static int check_reference_state(tmx_engine * e) {
+	if (!e->udiff) return TMX_OK;
+	for (int lp : e->local_patches)
+		REQUIRE(e->patches[lp].ref_set, TMX_ERR_INVALID, "uniform diffusion: tmx_set_patch_reference_state was not called for patch %d", lp);
 	return TMX_OK;
 }
 
@@ -962,6 +1010,30 @@ extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int
 // ---------------------------------------------------------------------------------------------
 // dynamics
 
+// uniform-diffusion extras at the end of HorizontalDynamicsFEM::StepExplicit (:1817-1859)
+static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt) {
+	if (!e->udiff) return TMX_OK;
+	int r; if ((r = check_reference_state(e))) return r;
+	tmxk_uniform_diffusion(e, make_params(e), inst(e, iinit), e->d_ref, inst(e, iupd), dt, e->cfg.uniform_diffusion_scalar, e->cfg.uniform_diffusion_vector);
+	return TMX_OK;
+}
+
+// VerticalDynamicsFEM::StepExplicit beyond the upwind penalty of U,V (which tmxk_v_explicit / the fused explicit kernel
+// apply): in the fully explicit mode -dt F on rho*theta, W, rho (:745-790) and the explicit tracer update (:792-800),
+// and with uniform diffusion the vertical diffusion of U,V (:1059-1105).
+static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt) {
+	if (!e->fully_explicit) return TMX_OK;
+	int r; if ((r = check_reference_state(e))) return r;
+	const KParams p = make_params(e);
+	tmxk_vi_terms_explicit(e, p, inst(e, iinit), inst(e, iupd), dt);
+	if (e->nt > 0)
+		REQUIRE(tmxk_vi_tracers_explicit(e, p, inst(e, iinit), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
+			"tracer column update: %d levels do not fit the LDS working set", e->L);
+	if (e->udiff)
+		tmxk_v_uniform_diffusion_uv(e, p, inst(e, iinit), e->d_ref, inst(e, iupd), dt, e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
+	return TMX_OK;
+}
+
 extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
@@ -970,6 +1042,7 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	if (e->sw) tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
 	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
 	return launch_check("h_step_explicit");
 }
 
@@ -994,7 +1067,8 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul);
 	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 1, n, src, cf, premul);
+	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul);
 	if (e->nt > 0) {
 		// tracers: the combination is formed on the tracer slabs first, the tracer kernel then updates in place
 		const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
@@ -1003,6 +1077,10 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 		tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
 		tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	}
+	int r;
+	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
+	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
 	return launch_check("hv_step_explicit(lincomb)");
 }
 
@@ -1011,8 +1089,12 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 // CopyData(initial -> update) is folded in).  Bit-identical to the separate calls.
 static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 1);
+	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1);
 	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
+	int r;
+	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
+	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
 	return launch_check("hv_step_explicit");
 }
 
@@ -1029,6 +1111,7 @@ extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "V StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_V_EXPLICIT);
 	tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
 	return launch_check("v_step_explicit");
 }
 
@@ -1062,6 +1145,10 @@ static int v_step_implicit_impl(tmx_engine * e, int iinit, int iupd, double dt, 
 }
 
 extern "C" int tmx_v_step_implicit(tmx_engine * e, int iinit, int iupd, double dt) {
+	if (e && e->fully_explicit) {      // VerticalDynamicsFEM::StepImplicit, :1239-1242: nothing to do
+		int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
+		return TMX_OK;
+	}
 	return v_step_implicit_impl(e, iinit, iupd, dt, iupd);
 }
 
@@ -1492,7 +1579,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 			{
 				size_t j = i + 1;
 				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
-				if (!e->sw && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
+				if (!e->sw && !e->fully_explicit && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
 					if ((r = copy_uv(e, o.a, o.b))) return r;
 					if ((r = v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a))) return r;
 					i = j; break;

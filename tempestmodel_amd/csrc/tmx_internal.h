@@ -51,7 +51,7 @@ struct KParams {
 };
 
 struct PatchInfo {
-	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false, physics_set = false;
+	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false, physics_set = false, ref_set = false;
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
@@ -133,6 +133,9 @@ struct tmx_engine {
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
+	bool fully_explicit = false, udiff = false;   // cfg.fully_explicit / cfg.uniform_diffusion
+	std::vector<double> h_ref;               // reference state in slab layout until tmx_finalize
+	double * d_ref = nullptr;                // [nslab][NS] reference state + reference tracers (uniform diffusion)
 	bool prof = false;
 	bool use_graph = false;                  // TMX_GRAPH=1: replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
 	std::vector<StepGraph> graphs;
@@ -163,3 +166,6 @@ void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);
 int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
 void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);
+int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout, double dt, double ks, double kv);
+void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double * xin, const double * xref, double * xup, double dt, double cf);

@@ -600,13 +600,15 @@ void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
 // rho q <- base - dt / J * (weak divergence of J u^a rho q, J u^b rho q) with the mass-flux base of the state
 // update (same contravariant velocities, recomputed here), then per element and level: clip negatives, rescale the
 // positive values so that the element mass is unchanged.
+// UD: uniform diffusion of the tracer mixing ratio q / rho in the fluxes (HorizontalDynamicsFEM.cpp:1105-1148), ks = K_scalar.
+template <bool UD>
 __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const double * __restrict__ area,
-	const double * __restrict__ xin, const double * xbase, double * xup, double dt)
+	const double * __restrict__ xin, const double * xbase, double * xup, double dt, double ks)
 {
-	__shared__ double s[4][4][64];
-	__shared__ double sS[16];
+	__shared__ double s[4][5][64];
+	__shared__ double sS[16], sD[16];
 	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
-	if (ty * 64 + lane < 16) sS[ty * 64 + lane] = p.stiff[ty * 64 + lane];
+	if (ty * 64 + lane < 16) { sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + lane;
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	const int kc = (k < L) ? k : L - 1;
 	const unsigned cb = (unsigned)col * 8u;
 	double fa = 0.0, fb = 0.0, invJ = 0.0, ar = 0.0;
+	double dc2a0 = 0.0, dc2a1 = 0.0, dc2b1 = 0.0, djn = 0.0, rho = 1.0;      // uniform diffusion only
 	if (act) {
 		const double ua = ldu(xin + TMX_SLAB_U(L, kc) * NS, cb), ub = ldu(xin + TMX_SLAB_V(L, kc) * NS, cb);
 		const double we0 = ldu(xin + TMX_SLAB_W(L, kc) * NS, cb), we1 = ldu(xin + TMX_SLAB_W(L, kc + 1) * NS, cb);
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 		const double conUb = c2a1 * ua + c2b1 * ub + cb2 * ux;
 		fa = jn * conUa; fb = jn * conUb; invJ = 1.0 / jn;
 		ar = ldu(area + (size_t)kc * NS, cb);
+		if (UD) { dc2a0 = c2a0; dc2a1 = c2a1; dc2b1 = c2b1; djn = jn; rho = ldu(xin + TMX_SLAB_R(L, kc) * NS, cb); }
 	}
 	s[ty][3][lane] = ar;
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
@@ -634,8 +638,25 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
 		const double qv = act ? ldu(xin + so, cb) : 0.0;
 		const double bv = act ? ldu(xbase + so, cb) : 0.0;
+		double taf = fa * qv, tbf = fb * qv;
+		if (UD) {
+			__syncthreads();
+			s[ty][4][lane] = qv / rho;
+			__syncthreads();
+			double daq = 0.0, dbq = 0.0;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				daq += s[ty][4][eb + 4 * t + j] * sD[t * 4 + i];
+				dbq += s[ty][4][eb + 4 * i + t] * sD[t * 4 + j];
+			}
+			daq *= p.inv_da; dbq *= p.inv_da;
+			const double cdaq = dc2a0 * daq + dc2a1 * dbq;
+			const double cdbq = dc2a1 * daq + dc2b1 * dbq;
+			taf -= ks * djn * rho * cdaq;
+			tbf -= ks * djn * rho * cdbq;
+		}
 		__syncthreads();
-		s[ty][0][lane] = fa * qv; s[ty][1][lane] = fb * qv;
+		s[ty][0][lane] = taf; s[ty][1][lane] = tbf;
 		__syncthreads();
 		double da = 0.0, db = 0.0;
 #pragma unroll
@@ -663,7 +684,10 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_h_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt);
+	if (e->udiff)
+		hipLaunchKernelGGL(k_h_tracers<true>, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar);
+	else
+		hipLaunchKernelGGL(k_h_tracers<false>, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0);
 }
 
 // ApplyScalarHyperdiffusion, tracer branch (HorizontalDynamicsFEM.cpp:1999-2035, :2076-2165) and, after the second
@@ -748,8 +772,13 @@ void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsr
 // runs in place and the state kernel has already overwritten it), xup: update instance (updated W; receives the tracers),
 // xbase: instance holding the tracer values the update is subtracted from (the update instance itself in the
 // reference; the initial instance when the preceding CopyData was fused away).
+// expl (fully explicit vertical mode, :3910-3912, :4047-4063, :4117-4141, :4166-4170, :4193): every stored column is
+// advanced on its own (ucol == udep == nullptr; the update instance has not been through the DSS yet), the matrix is
+// the diagonal 1/dt (dgbtrs then is one division per level), xi_dot comes from the initial W for both uses, there
+// is no velocity correction, and with ks != 0 the mass flux carries the uniform diffusion of q / rho - (q / rho)_ref.
 __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
-	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag)
+	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag,
+	int expl, double ks, const double * __restrict__ xref)
 {
 	extern __shared__ double smt[];
 	const int L = p.L, lane = threadIdx.x;
@@ -761,9 +790,11 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 	double * qn = xd1 + (size_t)(L + 1) * 64;    // [L][64] tracer density of the column
 	const int u = blockIdx.x * 64 + lane;
 	if (u >= nunique) return;
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;
 	const MetCol mc = met_col(p, col);
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	double * mixr = A;                       // explicit mode: [L][64] q / rho - (q / rho)_ref   (the matrix is not stored)
+	double * rhoe = A + (size_t)L * 64;      // explicit mode: [L+1][64] rho on interfaces
 #define ABW(i_, j_) A[((size_t)(j_) * 4 + 2 + (i_) - (j_)) * 64 + lane]
 	// U,V on interfaces (InterpolateNodeToREdge of the initial column), xi_dot initial / updated (:3943-3957, :4059-4086)
 	for (int k = 0; k <= L; k++) {
@@ -781,7 +812,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 			double e0, e1, e2;
 			metric_edge(p, mc, k, col, e0, e1, e2);
 			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)k * NS + col];
-			x1v = e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
+			x1v = expl ? x0v : e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
 		}
 		xd0[(size_t)k * 64 + lane] = x0v; xd1[(size_t)k * 64 + lane] = x1v;
 	}
@@ -814,10 +845,29 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 
 	int dep[3];
 #pragma unroll
-	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	for (int t = 0; t < 3; t++) dep[t] = udep ? udep[u * 3 + t] : -1;
 	bool singular = false;
+	if (expl && ks != 0.0) {
+		// rho on interfaces: InterpolateNodeToREdge of the initial column (PrepareColumn :1905-1916)
+		for (int m = 0; m <= L; m++) {
+			double re = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				re += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * xin[(size_t)TMX_SLAB_R(L, l) * NS + col];
+			}
+			rhoe[(size_t)m * 64 + lane] = re;
+		}
+	}
 	for (int c = 0; c < nt; c++) {
 		for (int k = 0; k < L; k++) qn[(size_t)k * 64 + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		if (expl && ks != 0.0)
+			for (int k = 0; k < L; k++) {
+				double a = qn[(size_t)k * 64 + lane] / xin[(size_t)TMX_SLAB_R(L, k) * NS + col];
+				a -= xref[(size_t)TMX_SLAB_Q(L, c, k) * NS + col] / xref[(size_t)TMX_SLAB_R(L, k) * NS + col];
+				mixr[(size_t)k * 64 + lane] = a;
+			}
 		// mass flux with the updated xi_dot, its divergence (:4092-4140)
 		for (int k = 0; k < L; k++) {
 			double mf[2];
@@ -831,6 +881,16 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn[(size_t)l * 64 + lane];
 				}
 				mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd1[(size_t)m * 64 + lane];
+				if (expl && ks != 0.0 && m > 0 && m < L) {
+					double dq = 0.0;       // DifferentiateNodeToREdge of the mixing-ratio difference
+#pragma unroll
+					for (int off = -2; off <= 1; off++) {
+						const int l = m + off;
+						if (l < 0 || l >= L) continue;
+						dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mixr[(size_t)l * 64 + lane];
+					}
+					mf[mo] -= ks * rhoe[(size_t)m * 64 + lane] * dq;
+				}
 			}
 			double dmf = 0.0;
 			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
@@ -853,6 +913,17 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 				aux += b * fabs(xd0[(size_t)k * 64 + lane]);
 			}
 			F[(size_t)k * 64 + lane] -= aux;
+		}
+		if (expl) {
+			// diagonal matrix 1/dt: dgbtrs leaves b_j / (1/dt)
+			const double idt = 1.0 / dt;
+			for (int k = 0; k < L; k++) {
+				const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
+				double bj = F[(size_t)k * 64 + lane];
+				if (bj != 0.0) bj /= idt;
+				xup[so + col] = xbase[so + col] - bj;
+			}
+			continue;
 		}
 		// implicit velocity correction (:4183-4233)
 		for (int a = 1; a < L; a++) {
@@ -925,7 +996,19 @@ int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	if (lds > 160 * 1024) return -1;
 	hipFuncSetAttribute((const void *)k_vi_tracers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipLaunchKernelGGL(k_vi_tracers, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt,
-		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag);
+		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag, 0, 0.0, (const double *)nullptr);
+	return 0;
+}
+
+// UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
+int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	if (e->nt == 0 || p.ncol == 0) return 0;
+	const size_t lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 64 * sizeof(double);
+	if (lds > 160 * 1024) return -1;
+	hipFuncSetAttribute((const void *)k_vi_tracers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(k_vi_tracers, dim3((p.ncol + 63) / 64), dim3(64), lds, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS,
+		(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag, 1,
+		e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
 	return 0;
 }
 
@@ -1133,6 +1216,146 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	double dt, double nu_s, double nu_d, double nu_v) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
 	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (src/atm/HorizontalDynamicsFEM.cpp:1817-1859):
+//   ApplyVectorHyperdiffusion(initial, update, dt, -K_v, -K_v)          U,V -= dt * (-K_v) * vector Laplacian(U,V)
+//   ApplyVectorHyperdiffusion(REFERENCE, update, dt, +K_v, +K_v)        U,V -= dt * (+K_v) * vector Laplacian(U,V)_ref
+//   ApplyScalarHyperdiffusion(initial, update, dt, K_s, comp 2, remove ref)   rho*theta, psi = initial - reference
+//   ApplyScalarHyperdiffusion(initial, update, dt, K_v, comp 3, remove ref)   W on interfaces
+// in that order per variable, one launch; the update instance is modified in place.  Same element kernels as
+// k_hypervis (ApplyScalarHyperdiffusion :1867-2203, ApplyVectorHyperdiffusion :2207-2414).
+__global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const double * __restrict__ xsrc,
+	const double * __restrict__ xref, double * xout, double dt, double ks, double kv)
+{
+	__shared__ double s[4][10][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int tid = ty * 64 + lane;
+	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + lane;
+	const int kk = blockIdx.y * 4 + ty;
+	const bool actw = (kk <= L) && (col < p.ncol);
+	const bool actn = (kk < L) && (col < p.ncol);
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+
+	double psiT = 0, psiW = 0, ua = 0, ub = 0, ra = 0, rb = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
+	if (actw) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		psiW -= xref[TMX_SLAB_W(L, kk) * NS + col];
+	}
+	if (actn) {
+		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+		psiT -= xref[TMX_SLAB_T(L, kk) * NS + col];
+		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col]; ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+		ra = xref[TMX_SLAB_U(L, kk) * NS + col]; rb = xref[TMX_SLAB_V(L, kk) * NS + col];
+	}
+	s[ty][0][lane] = psiT; s[ty][1][lane] = psiW;
+	s[ty][2][lane] = ua; s[ty][3][lane] = ub; s[ty][4][lane] = j2d * (c2a0 * ua + c2a1 * ub); s[ty][5][lane] = j2d * (c2a1 * ua + c2b1 * ub);
+	s[ty][6][lane] = ra; s[ty][7][lane] = rb; s[ty][8][lane] = j2d * (c2a0 * ra + c2a1 * rb); s[ty][9][lane] = j2d * (c2a1 * ra + c2b1 * rb);
+	__syncthreads();
+
+	double daT = 0, dbT = 0, daW = 0, dbW = 0;
+	double daub = 0, dbua = 0, dajua = 0, dbjub = 0, daubr = 0, dbuar = 0, dajuar = 0, dbjubr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+		daT += s[ty][0][la] * Da; dbT += s[ty][0][lb] * Db;
+		daW += s[ty][1][la] * Da; dbW += s[ty][1][lb] * Db;
+		daub += s[ty][3][la] * Da; dbua += s[ty][2][lb] * Db;
+		dajua += s[ty][4][la] * Da; dbjub += s[ty][5][lb] * Db;
+		daubr += s[ty][7][la] * Da; dbuar += s[ty][6][lb] * Db;
+		dajuar += s[ty][8][la] * Da; dbjubr += s[ty][9][lb] * Db;
+	}
+	const double ida = p.inv_da;
+	daT *= ida; dbT *= ida; daW *= ida; dbW *= ida;
+	daub *= ida; dbua *= ida; dajua *= ida; dbjub *= ida;
+	daubr *= ida; dbuar *= ida; dajuar *= ida; dbjubr *= ida;
+	const double invJ2 = 1.0 / j2d;
+	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+	const double dvr = (dajuar + dbjubr) * invJ2, clr = (daubr - dbuar) * invJ2;
+	__syncthreads();
+	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
+	s[ty][2][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][3][lane] = je * (c2a1 * daW + c2b1 * dbW);
+	s[ty][4][lane] = dv; s[ty][5][lane] = cl; s[ty][6][lane] = dvr; s[ty][7][lane] = clr;
+	__syncthreads();
+	if (!actw) return;
+
+	double uaT = 0, ubT = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0, dadr = 0, dbdr = 0, dacr = 0, dbcr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+		uaT += s[ty][0][la] * Sa; ubT += s[ty][1][lb] * Sb;
+		uaW += s[ty][2][la] * Sa; ubW += s[ty][3][lb] * Sb;
+		dad -= Sa * s[ty][4][la]; dbd -= Sb * s[ty][4][lb];
+		dac -= Sa * s[ty][5][la]; dbc -= Sb * s[ty][5][lb];
+		dadr -= Sa * s[ty][6][la]; dbdr -= Sb * s[ty][6][lb];
+		dacr -= Sa * s[ty][7][la]; dbcr -= Sb * s[ty][7][lb];
+	}
+	uaT *= ida; ubT *= ida; uaW *= ida; ubW *= ida;
+	dad *= ida; dbd *= ida; dac *= ida; dbc *= ida; dadr *= ida; dbdr *= ida; dacr *= ida; dbcr *= ida;
+	{
+		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
+		xout[o] = xout[o] - dt * (1.0 / je) * kv * (uaW + ubW);
+	}
+	if (actn) {
+		size_t o = TMX_SLAB_T(L, kk) * NS + col;
+		xout[o] = xout[o] - dt * (1.0 / jn) * ks * (uaT + ubT);
+		const double nkv = -kv;
+		const double upa = nkv * dad - nkv * j2d * (c2a1 * dac + c2b1 * dbc);
+		const double upb = nkv * dbd + nkv * j2d * (c2a0 * dac + c2a1 * dbc);
+		const double upar = kv * dadr - kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
+		const double upbr = kv * dbdr + kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
+		o = TMX_SLAB_U(L, kk) * NS + col;
+		double v = xout[o]; v -= dt * upa; v -= dt * upar; xout[o] = v;
+		o = TMX_SLAB_V(L, kk) * NS + col;
+		v = xout[o]; v -= dt * upb; v -= dt * upbr; xout[o] = v;
+	}
+}
+
+void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout,
+	double dt, double ks, double kv) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_uniform_diffusion, grd, blk, 0, e->stream, p, xsrc, xref, xout, dt, ks, kv);
+}
+
+// Vertical uniform diffusion of U, V in VerticalDynamicsFEM::StepExplicit (src/atm/VerticalDynamicsFEM.cpp:1059-1105):
+// update += dt * K_v / ztop^2 * (DiffDiffNodeToNode(U) - DiffDiffNodeToNode(U_ref)), same for V.
+__global__ __launch_bounds__(256) void k_v_uniform_diffusion_uv(KParams p, const double * __restrict__ xin,
+	const double * __restrict__ xref, double * __restrict__ xup, double dt, double cf)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k >= L || col >= p.ncol) return;
+#pragma unroll
+	for (int v = 0; v < 2; v++) {
+		const int sb = v * L;
+		double dd = 0.0, ddr = 0.0;
+#pragma unroll
+		for (int off = -2; off <= 2; off++) {
+			const int l = k + off;
+			if (l < 0 || l >= L) continue;
+			const double c = OPC(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+			dd += c * xin[(size_t)(sb + l) * NS + col];
+			ddr += c * xref[(size_t)(sb + l) * NS + col];
+		}
+		xup[(size_t)(sb + k) * NS + col] += dt * cf * (dd - ddr);
+	}
+}
+
+void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double * xin, const double * xref, double * xup, double dt, double cf) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_v_uniform_diffusion_uv, grd, blk, 0, e->stream, p, xin, xref, xup, dt, cf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1564,10 +1787,14 @@ struct BlkCarry {
 // block row k from node levels A = k-1, B = k, C = k+1 and interfaces a = k-1, b = k, c = k+1
 // column-operator coefficients from the LDS copy (ds_read: no vector-memory round trip, no vmcnt wait behind the U-row stores)
 #define OPCL(op, k, off) opsl[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
-template <bool CARRY>
+// UD: the uniform-diffusion terms of BuildF (VerticalDynamicsFEM.cpp:2593-2635), udP = K_s / ztop^2 * second derivative
+// of (rho*theta - reference) on level k, udW = K_v / ztop^2 * the same for W on interface k, subtracted where the
+// reference subtracts them (before the upwinding terms); only the fully explicit mode evaluates them.
+template <bool CARRY, bool UD = false>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
-	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy)
+	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy,
+	double udP = 0.0, double udW = 0.0)
 {
 	const int L = p.L;
 #pragma unroll
@@ -1607,6 +1834,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		double dpf = 0.0; dpf += de0 * pf0; dpf += de1 * pf1;
 		fR = dmf * invJ;
 		fP += dpf * invJ;
+		if (UD) fP -= udP;
 		const double wlo = fabs(xd0), whi = fabs(xd1);
 		const double pl0 = OPCL(TMX_OP_PENALTY_LEFT, k, 0), pl1 = OPCL(TMX_OP_PENALTY_LEFT, k, 1);
 		const double pr0 = OPCL(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPCL(TMX_OP_PENALTY_RIGHT, k, 0);
@@ -1693,6 +1921,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			const double curl = -ca * dua - cb * dub;
 			fW += (dke + curl);
 		}
+		if (UD) fW -= udW;
 		const double ddm = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, -1), dd0 = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 0), ddp = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, 1);
 		double ddw = 0.0; ddw += ddm * wem; ddw += dd0 * we0; ddw += ddp * wep;
 		fW -= cc.upc * fabs(xde) * ddw;
@@ -2213,8 +2442,11 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 // VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612):
 // update -= dt * F(initial) for rho*theta, W, rho on EVERY column (F = BuildF of the initial column).
 
+// UD (fully explicit mode with uniform diffusion): F additionally holds the vertical diffusion of rho*theta and W
+// relative to the reference column xref (cs = K_s / ztop^2, cw = K_v / ztop^2).
+template <bool UD>
 __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double dt)
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cs, double cw)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -2230,7 +2462,35 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 	const EdgeLev eA = load_edge(p, mcol, xin, k - 1, col), eB = load_edge(p, mcol, xin, k, col), eC = load_edge(p, mcol, xin, k + 1, col);
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
 	BlkCarry cy;
-	compute_block<false>(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
+	double udP = 0.0, udW = 0.0;
+	if (UD) {
+		// PrepareColumn :2104-2160: DiffDiff of the column minus DiffDiff of the reference column; W not on the boundaries
+		if (k < L) {
+			double dd = 0.0, ddr = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 2; off++) {
+				const int l = k + off;
+				if (l < 0 || l >= L) continue;
+				const double c = OPC(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+				dd += c * xin[(size_t)TMX_SLAB_T(L, l) * NS + col];
+				ddr += c * xref[(size_t)TMX_SLAB_T(L, l) * NS + col];
+			}
+			udP = cs * (dd - ddr);
+		}
+		if (k > 0 && k < L) {
+			double dd = 0.0, ddr = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 2; off++) {
+				const int l = k + off;
+				if (l < 0 || l > L) continue;
+				const double c = OPC(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, off);
+				dd += c * xin[(size_t)TMX_SLAB_W(L, l) * NS + col];
+				ddr += c * xref[(size_t)TMX_SLAB_W(L, l) * NS + col];
+			}
+			udW = cw * (dd - ddr);
+		}
+	}
+	compute_block<false, UD>(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, udP, udW);
 	if (k < L) {
 		xup[TMX_SLAB_T(L, k) * NS + col] -= dt * fP;
 		xup[TMX_SLAB_R(L, k) * NS + col] -= dt * fR;
@@ -2240,7 +2500,12 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_vi_terms_explicit, grd, blk, 0, e->stream, p, xin, xup, dt);
+	if (e->udiff && e->fully_explicit) {
+		const double z2 = e->cfg.ztop * e->cfg.ztop;
+		hipLaunchKernelGGL(k_vi_terms_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
+			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2);
+	} else
+		hipLaunchKernelGGL(k_vi_terms_explicit<false>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0);
 }
 
 

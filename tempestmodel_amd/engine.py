@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TMX_LIBRARY: developer override to A/B an alternative build of the same ABI (e.g. the -DTMX_VI_TIMING variant)
 LIB_PATH = os.environ.get("TMX_LIBRARY") or os.path.join(_HERE, "libtempest_mi355x.so")
 
-TMX_ABI_VERSION = 4
+TMX_ABI_VERSION = 5
 OP_NAMES = ["interp_node_to_redge", "interp_redge_to_node", "diff_node_to_node", "diff_node_to_redge",
             "diff_redge_to_node", "diff_redge_to_redge", "diffdiff_node_to_node", "diffdiff_redge_to_redge",
             "penalty_left", "penalty_right"]
@@ -44,7 +44,9 @@ class TmxConfig(C.Structure):
                 ("element_delta_a", C.c_double), ("reference_length", C.c_double),
                 ("grav", C.c_double), ("Rd", C.c_double), ("cp", C.c_double), ("p0", C.c_double),
                 ("nu_scalar", C.c_double), ("nu_div", C.c_double), ("nu_vort", C.c_double),
-                ("rank", C.c_int), ("n_ranks", C.c_int), ("device", C.c_int), ("equation_set", C.c_int)]
+                ("rank", C.c_int), ("n_ranks", C.c_int), ("device", C.c_int), ("equation_set", C.c_int),
+                ("fully_explicit", C.c_int), ("uniform_diffusion", C.c_int),
+                ("uniform_diffusion_scalar", C.c_double), ("uniform_diffusion_vector", C.c_double), ("ztop", C.c_double)]
 
 
 class TmxPatchGeometry(C.Structure):
@@ -90,6 +92,7 @@ def load_library():
     lib.tmx_download_state.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PD]
     lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
+    lib.tmx_set_patch_reference_state.argtypes = [C.c_void_p, C.c_int, PD, PD, PD]
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
@@ -119,7 +122,9 @@ class Engine:
     (or anything exposing the same reference-layout arrays)."""
 
     def __init__(self, grid, n_instances=7, nu=(1.0e15, 1.0e15, 1.0e15), hypervis_order=4,
-                 rank=0, n_ranks=1, owner=None, device=-1):
+                 rank=0, n_ranks=1, owner=None, device=-1, fully_explicit=False, uniform_diffusion=None):
+        """``fully_explicit``: VerticalDynamicsFEM's --explicitvertical mode; ``uniform_diffusion``: (K_scalar, K_vector)
+        of Grid::HasUniformDiffusion (reference state and tracers are taken from ``grid.patches[*].geom``)."""
         self.lib = load_library()
         self.grid = grid
         self.L = grid.L
@@ -132,6 +137,12 @@ class Engine:
         self.ntracers = int(getattr(grid, "ntracers", 0))
         cfg.levels, cfg.n_patches, cfg.n_instances, cfg.n_tracers = grid.L, self.npatch, n_instances, self.ntracers
         cfg.hypervis_order = hypervis_order
+        cfg.fully_explicit = 1 if fully_explicit else 0
+        self.uniform_diffusion = uniform_diffusion
+        cfg.ztop = float(getattr(grid, "ztop", 0.0))
+        if uniform_diffusion is not None:
+            cfg.uniform_diffusion = 1
+            cfg.uniform_diffusion_scalar, cfg.uniform_diffusion_vector = uniform_diffusion
         cfg.element_delta_a, cfg.reference_length = grid.delta_a, grid.reference_length
         ph = grid.phys
         cfg.grav, cfg.Rd, cfg.cp, cfg.p0 = ph.g, ph.Rd, ph.cp, ph.p0
@@ -221,6 +232,14 @@ class Engine:
                         self.h, P.index, _pd(fx[0]), _pd(fx[1]), _pd(fx[2]), float(g.phys.earth_radius),
                         _pd(fx[3]), _pd(fx[4])))
         self._chk(self.lib.tmx_finalize(self.h))
+        if self.uniform_diffusion is not None and not self.plan_only:
+            for P in g.patches:
+                if self.owner[P.index] != self.rank:
+                    continue
+                rf = [np.ascontiguousarray(P.geom[nm], dtype=np.float64) for nm in ("ref_node", "ref_redge")]
+                rt = np.ascontiguousarray(P.geom["ref_tracers"], dtype=np.float64) if self.ntracers else None
+                self._chk(self.lib.tmx_set_patch_reference_state(self.h, P.index, _pd(rf[0]), _pd(rf[1]),
+                                                                 _pd(rt) if rt is not None else None))
 
     @property
     def local_patches(self):

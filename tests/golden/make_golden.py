@@ -14,6 +14,9 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
   percall_tracers_ne3_L6_p6.npz / steps_tracers_ne3_L6_p6.npz   JW + 2 tracer densities (rows H8, V8)
   steps_visc2_ne3_L5_p6.npz   three ARS343 steps with hyperviscosity order 2
+  percall_udiff_ne3_L6_p6.npz / steps_udiff_{ars343,strang}_ne3_L6_p6.npz   the supercell configuration without its
+                          Fortran physics: planet / 120, no rotation, uniform diffusion 1500 / 500 m^2/s,
+                          --explicitvertical, 2 tracers (BASELINE config 4)
   physics_hs_ne2_L30_p6.npz   HeldSuarezPhysics::Perform input/output (SURVEY 8f-1)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
@@ -121,6 +124,19 @@ def main():
     rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
     rec.update(compact_states(d, 6))
     save("steps_tracers_ne3_L6_p6.npz", rec)
+
+    # BASELINE config 4 (DCMIP2016 supercell) without the Fortran physics: uniform diffusion + fully explicit vertical
+    ud = ["--planet", "120", "--udiff", "1500", "500", "--explicitvertical", "--tracers", "2", "--ne", "3", "--levels", "6", "--dt", "1"]
+    d, _ = run(ud + ["--mode", "percall", "--warm", "1"], tmp)
+    drop_ud = tuple(x for x in drop if x != "element_area_node")      # keeps ref_node / ref_redge / ref_tracers
+    d = {k: v for k, v in d.items() if k.split("/")[-1] not in drop_ud and not k.startswith("state/initial")
+         and not k.startswith("state/hypervis") and not k.startswith("state/lincomb")}
+    save("percall_udiff_ne3_L6_p6.npz", d)
+    for sch in ("ars343", "strang"):
+        d, _ = run(ud + ["--mode", "steps", "--scheme", sch, "--steps", "3", "--geom", "0"], tmp)
+        rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
+        rec.update(compact_states(d, 6))
+        save("steps_udiff_%s_ne3_L6_p6.npz" % sch, rec)
 
     # hyperviscosity order 2 (plain viscosity, one pass; HorizontalDynamicsFEM.cpp:2672-2686), nu = 2e5 m^2/s
     d, _ = run(["--hypervis", "2", "--mode", "steps", "--ne", "3", "--levels", "5", "--dt", "300", "--steps", "3", "--geom", "0"], tmp)

@@ -25,6 +25,9 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("parity", ["--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6"]),
     # Held-Suarez forcing as a WorkflowProcess after every step (HeldSuarezPhysicsMI355X)
     ("production", ["--physics", "1", "--ne", "2", "--levels", "30", "--steps", "3", "--patches", "6"]),
+    # BASELINE config 4 dynamics: planet / 120, uniform diffusion, --explicitvertical, two tracers (dt 1 s)
+    ("production", ["--case", "supercell", "--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6", "--dt", "1"]),
+    ("parity", ["--case", "supercell", "--tracers", "2", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6", "--dt", "1"]),
 ])
 def test_reference_driver_with_adapter_plugins(mode, args):
     if not os.path.exists(BIN):

@@ -186,6 +186,82 @@ def test_tracer_steps_vs_reference_and_oracle():
         e.close()
 
 
+UDIFF = (1500.0, 500.0)
+
+
+def test_uniform_diffusion_explicit_vertical_percall():
+    """BASELINE config 4 (supercell) dynamics on the device: uniform diffusion in H.StepExplicit and the fully explicit
+    V.StepExplicit with two tracers, call by call against the C oracle and the reference's own output."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("percall_udiff_ne3_L6_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, case="smallplanet", ntracers=2)
+    dt = float(d["cfg/dt"][0]); sdt = dt * gu.ARS343_GAMMA
+    e = Engine(g, fully_explicit=True, uniform_diffusion=UDIFF); o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF)
+    try:
+        st, tr = gu.full_states(d, "warm", 6), gu.full_tracers(d, "warm", 6)
+        o.set_state(0, st); o.set_tracers(0, tr); e.upload_state(0, st); e.upload_tracers(0, tr)
+
+        def cmp(ie, io, tag):
+            e.sync()
+            gs, gt = e.download_state(ie), e.download_tracers(ie)
+            assert max(gu.prognostic_errors(gs, o.get_state(io))) < TOL_CALL, tag
+            assert max(gu.tracer_errors(gt, o.get_tracers(io))) < TOL_CALL, tag
+            assert max(gu.prognostic_errors(gs, gu.full_states(d, tag, 6))) < TOL_CALL, tag
+            assert max(gu.tracer_errors(gt, gu.full_tracers(d, tag, 6))) < TOL_CALL, tag
+
+        o.copy_data(0, 1); e.copy_data(0, 1)
+        o.h_step_explicit(0, 1, sdt); e.h_step_explicit(0, 1, sdt); cmp(1, 1, "h_explicit")
+        o.v_step_explicit(0, 1, sdt); e.v_step_explicit(0, 1, sdt); cmp(1, 1, "v_explicit")
+        o.apply_dss(1); e.apply_dss(1); cmp(1, 1, "dss")
+        o.copy_data(1, 2); e.copy_data(1, 2)
+        assert o.v_step_implicit(2, 2, sdt) == 0
+        e.v_step_implicit(2, 2, sdt); cmp(2, 2, "v_implicit")
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("scheme", ["ars343", "strang"])
+def test_uniform_diffusion_explicit_vertical_steps(scheme):
+    """Whole steps of the supercell configuration through the production program (fused paths included)."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("steps_udiff_%s_ne3_L6_p6.npz" % scheme)
+    g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    st, tr = gu.expand_compact(d, "initial", g), gu.expand_compact_tracers(d, "initial", g)
+    o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF); o.set_state(0, st); o.set_tracers(0, tr)
+    e = Engine(g, fully_explicit=True, uniform_diffusion=UDIFF); e.upload_state(0, st); e.upload_tracers(0, tr)
+    try:
+        for step in (1, 2, 3):
+            assert o.step(scheme, 1.0, first=(step == 1)) == 0
+            e.step(scheme, 1.0, first=(step == 1))
+            e.sync()
+            gs, gt = e.download_state(0), e.download_tracers(0)
+            assert max(gu.prognostic_errors(gs, o.get_state(0))) < TOL_STEPS, step
+            assert max(gu.tracer_errors(gt, o.get_tracers(0))) < 1e-11, step
+            assert max(gu.prognostic_errors(gs, gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS, step
+            assert max(gu.tracer_errors(gt, gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-11, step
+    finally:
+        e.close()
+
+
+def test_explicit_vertical_without_diffusion_matches_oracle():
+    """--explicitvertical alone (no uniform diffusion, no tracers): ARS343 and Strang steps against the C oracle."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    g, st = gu.make_grid(3, 6, 6, case="smallplanet")
+    o = Oracle(g, fully_explicit=True); o.set_state(0, st)
+    e = Engine(g, fully_explicit=True); e.upload_state(0, st)
+    try:
+        for step, scheme in enumerate(("ars343", "ars343", "strang", "strang")):
+            assert o.step(scheme, 1.0, first=(step == 2)) == 0
+            e.step(scheme, 1.0, first=(step == 2))
+        e.sync()
+        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) < TOL_STEPS
+    finally:
+        e.close()
+
+
 def test_viscosity_order_2_steps():
     """Hyperviscosity order 2 (one viscosity pass): ARS343 steps vs the C oracle and the reference fixture."""
     from tempestmodel_amd.engine import Engine

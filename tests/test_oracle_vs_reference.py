@@ -106,6 +106,52 @@ def test_viscosity_order_2_steps_vs_reference():
         assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-11
 
 
+UDIFF = (1500.0, 500.0)      # K_scalar, K_vector of test/dcmip2016/SupercellTest.cpp:107-113
+
+
+def test_uniform_diffusion_explicit_vertical_percall():
+    """BASELINE config 4 without its Fortran physics: uniform diffusion of state minus
+    reference state in H.StepExplicit (vector / scalar Laplacians, tracer fluxes) and the fully explicit
+    V.StepExplicit (Evaluate, -dt F, explicit tracer update, vertical diffusion of U,V, rho*theta, W, tracers) on the
+    reference's own inputs -- bit for bit; V.StepImplicit does nothing."""
+    d = gu.load("percall_udiff_ne3_L6_p6.npz")
+    assert int(d["cfg/fully_explicit"][0]) == 1 and int(d["cfg/uniform_diffusion"][0]) == 1
+    g, _ = gu.grid_from_fixture(d, override=True, case="smallplanet", ntracers=2)
+    dt = float(d["cfg/dt"][0]); sdt = dt * gu.ARS343_GAMMA
+    o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF)
+    o.set_state(0, gu.full_states(d, "warm", 6)); o.set_tracers(0, gu.full_tracers(d, "warm", 6))
+    o.copy_data(0, 1)
+    o.h_step_explicit(0, 1, sdt)
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "h_explicit", 6))) < 1e-15
+    assert max(gu.tracer_errors(o.get_tracers(1), gu.full_tracers(d, "h_explicit", 6))) < 1e-15
+    o.v_step_explicit(0, 1, sdt)
+    assert max(gu.prognostic_errors(o.get_state(1), gu.full_states(d, "v_explicit", 6))) < 1e-15
+    assert max(gu.tracer_errors(o.get_tracers(1), gu.full_tracers(d, "v_explicit", 6))) < 1e-15
+    o.apply_dss(1)
+    o.copy_data(1, 2)
+    assert o.v_step_implicit(2, 2, sdt) == 0
+    assert max(gu.prognostic_errors(o.get_state(2), gu.full_states(d, "v_implicit", 6))) < 1e-15
+    # the diffusion terms matter at this size: without them the same call is off by far more than rounding
+    o2 = Oracle(g, fully_explicit=True)
+    o2.set_state(0, gu.full_states(d, "warm", 6)); o2.set_tracers(0, gu.full_tracers(d, "warm", 6))
+    o2.copy_data(0, 1); o2.h_step_explicit(0, 1, sdt); o2.v_step_explicit(0, 1, sdt)
+    assert max(gu.prognostic_errors(o2.get_state(1), gu.full_states(d, "v_explicit", 6))) > 1e-8
+
+
+@pytest.mark.parametrize("scheme", ["ars343", "strang"])
+def test_uniform_diffusion_explicit_vertical_steps(scheme):
+    """Three whole steps of the supercell configuration (ARS343, and Strang incl. its FilterNegativeTracers after the
+    carry-over combination) against the reference."""
+    d = gu.load("steps_udiff_%s_ne3_L6_p6.npz" % scheme)
+    g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF)
+    o.set_state(0, gu.expand_compact(d, "initial", g)); o.set_tracers(0, gu.expand_compact_tracers(d, "initial", g))
+    for step in (1, 2, 3):
+        assert o.step(scheme, 1.0, first=(step == 1)) == 0
+        assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-12
+        assert max(gu.tracer_errors(o.get_tracers(0), gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-13
+
+
 def test_tracer_percall_chain():
     """tracer flux divergence + element filter in H.StepExplicit, tracer DSS, the implicit column
     tracer update (tridiagonal dgbtrf/dgbtrs) + column filter in V.StepImplicit, tracer hyperdiffusion + filter in
