@@ -41,7 +41,7 @@ OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_ass
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
-OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused"], "dss": ["k_dss"],
+OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair"], "dss": ["k_dss"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
 
 
@@ -195,7 +195,7 @@ def main():
         avg_ms = op_time[dom] / op_launches[dom]
         local_points = points / world
         achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
-        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_fused",
+        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group; k_vi_fused beyond 512 workgroups)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
         out = {
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
