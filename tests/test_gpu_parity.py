@@ -764,3 +764,51 @@ def test_shallow_water_test2_strang():
         assert max(gu.prognostic_errors(got, _sw_ref(d, "step10", g))[:3]) < 1e-12
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("scheme", ["ars343", "strang"])
+def test_multirank_supercell_configuration_loopback(scheme):
+    """The supercell configuration (uniform diffusion relative to the per-rank reference state, fully explicit vertical
+    mode, two tracers) on 4 rank engines through the loopback wire: three production steps bit-identical to one engine."""
+    import threading
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(4, 6, 24, case="smallplanet", ntracers=2)
+    tr = [g.initial_tracers[p] for p in range(24)]
+    kw = dict(fully_explicit=True, uniform_diffusion=UDIFF)
+    single = Engine(g, **kw)
+    ranks = [Engine(g, rank=r, n_ranks=4, **kw) for r in range(4)]
+    try:
+        for e in [single] + ranks:
+            e.upload_state(0, start); e.upload_tracers(0, tr)
+        for k in range(3):
+            single.step(scheme, 1.0, first=(k == 0))
+        single.sync()
+        ref, reft = single.download_state(0), single.download_tracers(0)
+        Engine.loopback_group(ranks)
+        errors = []
+
+        def run(e):
+            try:
+                for k in range(3):
+                    e.step(scheme, 1.0, first=(k == 0))
+                e.sync()
+            except Exception as ex:
+                errors.append(ex)
+
+        th = [threading.Thread(target=run, args=(e,)) for e in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errors and not any(t.is_alive() for t in th), errors
+        Engine.loopback_dissolve(ranks[0])
+        for e in ranks:
+            got, gott = e.download_state(0), e.download_tracers(0)
+            for p in e.local_patches:
+                assert np.array_equal(got[p][0][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), (e.rank, p)
+                assert np.array_equal(got[p][1][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), (e.rank, p)
+                assert np.array_equal(gott[p][:, 1:-1, 1:-1], reft[p][:, 1:-1, 1:-1]), (e.rank, p)
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()

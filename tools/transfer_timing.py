@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Host <-> device state transfer time at the drop-in boundary (tmx_upload_state / tmx_download_state: the reference's
+[var][A+2][B+2][L] arrays <-> slab layout), whole instance, ne30 L30, 24 patches.  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
+from tempestmodel_amd.engine import Engine
+
+ne = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+g = CubedSphereGrid(ne, 30, 30000.0, ppd=2)
+st = g.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
+e = Engine(g)
+nbytes = sum(n.nbytes + r.nbytes for n, r in st)
+for name, fn in (("upload", lambda: e.upload_state(0, st)), ("download", lambda: e.download_state(0))):
+    fn(); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fn()
+    e.sync()
+    dt = (time.perf_counter() - t0) / 3
+    print("%s: %.1f ms per instance (%.0f MB host arrays incl. halo, %.2f GB/s)" % (name, dt * 1e3, nbytes / 1e6, nbytes / dt / 1e9))
+e.close()
