@@ -54,6 +54,14 @@ def test_unsupported_configurations_are_rejected():
         setattr(c2, field, bad)
         assert lib.tmx_create(ctypes.byref(c2), ctypes.byref(h)) != 0
         assert len(lib.tmx_last_error()) > 0
+    # uniform diffusion needs the fully explicit vertical mode and ztop; with both it is accepted
+    c2 = eng.TmxConfig.from_buffer_copy(cfg); c2.uniform_diffusion = 1; c2.ztop = 2.0e4
+    assert lib.tmx_create(ctypes.byref(c2), ctypes.byref(h)) != 0 and b"fully explicit" in lib.tmx_last_error()
+    c2.fully_explicit = 1; c2.ztop = 0.0
+    assert lib.tmx_create(ctypes.byref(c2), ctypes.byref(h)) != 0
+    c2.ztop = 2.0e4
+    assert lib.tmx_create(ctypes.byref(c2), ctypes.byref(h)) == 0
+    lib.tmx_destroy(h)
     assert lib.tmx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     lib.tmx_destroy(h)
 
