@@ -207,7 +207,8 @@ def main():
             "config": {"workload": "Jablonowski-Williamson baroclinic wave, cubed sphere ne%d np4 L%d, ztop 30 km, "
                                    "ARS343 dt=%gs, hyperviscosity order 4, %d patches" % (ne, L, dt, len(grid.patches)),
                        "elements": n_el, "dof_per_step": dof_per_step, "dt_s": dt,
-                       "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world)},
+                       "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world),
+                       "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,

@@ -271,7 +271,7 @@ enum {
 	TMX_INFO_DSS_GROUPS,          /* co-located node groups touching this rank          */
 	TMX_INFO_LOCAL_ELEMENTS,
 	TMX_INFO_GHOST_COLUMNS,       /* remote copies received per exchange                */
-	TMX_INFO_HBM_BYTES,           /* device bytes allocated (low 31 bits of MiB)        */
+	TMX_INFO_HBM_BYTES,           /* device bytes allocated by the engine on this rank   */
 	TMX_INFO_METRIC_CLOSED_FORM   /* 1: 3-D metric evaluated in registers, 0: streamed  */
 };
 long long tmx_info(tmx_engine * e, int what);
