@@ -195,7 +195,7 @@ def main():
         avg_ms = op_time[dom] / op_launches[dom]
         local_points = points / world
         achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
-        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group; k_vi_fused beyond 512 workgroups)",
+        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
         out = {
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),

@@ -2407,13 +2407,13 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
 	// The pair kernel shortens the per-column dependent chain to max(assembly, elimination) and is built for two
-	// wavefronts per SIMD (256 registers), so all pairs of a grid of up to 512 workgroups (2 per CU) are resident
-	// at once.  Measured per launch: ne30 on one GPU (760 column groups) 211 us against 229 us for the
-	// one-wavefront kernel; 190 groups 95 us with one pair per workgroup (every workgroup alone on a CU), 104 us with
-	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  Beyond 512 workgroups the grid no
-	// longer fits in one round and the one-wavefront kernel is used.
+	// wavefronts per SIMD (256 registers): the 1024 SIMDs hold 1024 pairs at once.  Measured per launch: ne30 on one
+	// GPU (760 column groups) 197-211 us against 229 us for the one-wavefront kernel; ne60 (3038 groups, three rounds)
+	// 840 us against 899 us; 190 groups 95 us with one pair per workgroup (every workgroup alone on a CU), 104 us with
+	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  So it is the production kernel at every
+	// size; the one-wavefront kernel stays as TMX_VI_PAIR=0 (bit-identical, tested).
 	const int ngrp = (e->nunique + 63) / 64;
-	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry && (ngrp + 1) / 2 <= 512);
+	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
 	if (use_pair) {
 		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double);
 		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
