@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <map>
 #include <numeric>
+#include <functional>
+#include <thread>
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -175,6 +177,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 	if (!plan_only(e)) {
 		if (e->stream) hipStreamSynchronize(e->stream);
 		for (auto & g : e->graphs) hipGraphExecDestroy(g.exec);
+		if (e->h_stage) hipHostFree(e->h_stage);
 		if (e->xstream) { hipStreamSynchronize(e->xstream); hipStreamDestroy(e->xstream); hipEventDestroy(e->ev_pack); hipEventDestroy(e->ev_recv); }
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
@@ -792,6 +795,61 @@ static int check_state_args(tmx_engine * e, int patch, int instance) {
 	return TMX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Host <-> slab transposition at the ABI boundary.  The reference keeps a column contiguous ([var][i][j][k]); the
+// device keeps a level contiguous over columns ([slab][column]).  The staging buffer is walked in tiles of 64
+// device columns (= 4 elements: 64 x L doubles per variable stay in L1 while all levels of the tile are moved) and
+// the tiles are dealt to a few host threads -- the naive column-at-a-time loop read one double per cache line
+// (measured at ne30 L30: download 45 -> see DESIGN.md section 5).
+static void host_parallel(int ntiles, const std::function<void(int, int)> & fn) {
+	int nthr = (int)std::thread::hardware_concurrency();
+	if (nthr > 8) nthr = 8;
+	if (nthr < 1 || ntiles < 4 * nthr) { fn(0, ntiles); return; }
+	std::vector<std::thread> th;
+	const int per = (ntiles + nthr - 1) / nthr;
+	for (int t = 0; t < nthr; t++) {
+		const int a = t * per, b = std::min(ntiles, a + per);
+		if (a < b) th.emplace_back(fn, a, b);
+	}
+	for (auto & x : th) x.join();
+}
+
+// pinned staging buffer of the engine (grown on demand): no per-call allocation / zero fill, DMA at full PCIe rate
+static double * stage_buffer(tmx_engine * e, size_t n) {
+	if (e->h_stage_n < n) {
+		if (e->h_stage) hipHostFree(e->h_stage);
+		e->h_stage = nullptr; e->h_stage_n = 0;
+		if (hipHostMalloc((void **)&e->h_stage, n * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		e->h_stage_n = n;
+	}
+	return e->h_stage;
+}
+
+// host node offset (i * nb + j) of every device column of the patch, device order
+static const std::vector<int> & host_offsets(tmx_engine * e, int patch) {
+	PatchInfo & P = e->patches[patch];
+	if (P.hoff.empty()) {
+		const int c0 = P.elem_base * TMX_NQ;
+		P.hoff.assign((size_t)P.nea * P.neb * TMX_NQ, 0);
+		for (int i = 1; i < P.na - 1; i++) for (int j = 1; j < P.nb - 1; j++) P.hoff[col_of(P, i, j) - c0] = i * P.nb + j;
+	}
+	return P.hoff;
+}
+
+// one variable: host[(var_off + hoff[c]) * nlev + k]  <->  buf[(slab0 + k) * ncp + c], columns [ca, cb)
+static inline void xpose_to_buf(const double * host, size_t var_off, int nlev, double * buf, int slab0, int ncp, const int * hoff, int ca, int cb) {
+	for (int k = 0; k < nlev; k++) {
+		double * row = buf + (size_t)(slab0 + k) * ncp;
+		for (int c = ca; c < cb; c++) row[c] = host[(var_off + hoff[c]) * nlev + k];
+	}
+}
+static inline void xpose_to_host(double * host, size_t var_off, int nlev, const double * buf, int slab0, int ncp, const int * hoff, int ca, int cb) {
+	for (int k = 0; k < nlev; k++) {
+		const double * row = buf + (size_t)(slab0 + k) * ncp;
+		for (int c = ca; c < cb; c++) host[(var_off + hoff[c]) * nlev + k] = row[c];
+	}
+}
+
 // GridPatch::GetReferenceState / GetReferenceTracers -> the reference "instance" of the uniform diffusion
 extern "C" int tmx_set_patch_reference_state(tmx_engine * e, int patch, const double * ref_node, const double * ref_redge, const double * ref_tracers) {
 	int r = check_state_args(e, patch, 0);
@@ -834,19 +892,25 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
 	const int nstate = 5 * L + 1;          // state slabs; tracer slabs are moved by tmx_upload_tracers
-	std::vector<double> buf((size_t)nstate * ncp);
+	HIPCHK(hipStreamSynchronize(e->stream));      // the staging buffer may still feed an earlier copy
+	double * bufp = stage_buffer(e, (size_t)nstate * ncp);
+	REQUIRE(bufp, TMX_ERR_DEVICE, "cannot allocate the pinned staging buffer");
+	struct { double * p; double * data() const { return p; } } buf = { bufp };
 	const int nodevar[4] = { 0, 1, 2, 4 };
-	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
-		const int c = col_of(P, i, j) - c0;
-		if (e->sw) {        // node is [3][na][nb][1]: U, V, H -> slabs U, V, "rho*theta"
-			for (int v = 0; v < 3; v++) buf[(size_t)v * ncp + c] = node[((size_t)v * na + i) * nb + j];
-			continue;
+	const int * hoff = host_offsets(e, patch).data();
+	const size_t nn = (size_t)na * nb;
+	const bool sw = e->sw;
+	host_parallel((ncp + 63) / 64, [&](int ta, int tb) {
+		for (int t = ta; t < tb; t++) {
+			const int ca = t * 64, cb = std::min(ncp, ca + 64);
+			if (sw) {        // node is [3][na][nb][1]: U, V, H -> slabs U, V, "rho*theta"
+				for (int v = 0; v < 3; v++) xpose_to_buf(node, (size_t)v * nn, 1, buf.data(), v, ncp, hoff, ca, cb);
+				continue;
+			}
+			for (int v = 0; v < 4; v++) xpose_to_buf(node, (size_t)nodevar[v] * nn, L, buf.data(), v * L, ncp, hoff, ca, cb);
+			xpose_to_buf(redge, (size_t)3 * nn, L + 1, buf.data(), 4 * L, ncp, hoff, ca, cb);
 		}
-		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
-			buf[(size_t)(v * L + k) * ncp + c] = node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k];
-		for (int k = 0; k <= L; k++)
-			buf[(size_t)(4 * L + k) * ncp + c] = redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k];
-	}
+	});
 	HIPCHK(hipStreamSynchronize(e->stream));
 	HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + c0, (size_t)e->NS * sizeof(double),
 		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), nstate, hipMemcpyHostToDevice));
@@ -900,46 +964,55 @@ extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, doubl
 	const int L = e->L, na = P.na, nb = P.nb;
 	const int ncp = P.nea * P.neb * TMX_NQ, c0 = P.elem_base * TMX_NQ;
 	const int nstate = 5 * L + 1;
-	std::vector<double> buf((size_t)nstate * ncp);
+	double * bufp = stage_buffer(e, (size_t)nstate * ncp);
+	REQUIRE(bufp, TMX_ERR_DEVICE, "cannot allocate the pinned staging buffer");
+	struct { double * p; double * data() const { return p; } } buf = { bufp };
 	HIPCHK(hipStreamSynchronize(e->stream));
 	HIPCHK(hipMemcpy2D(buf.data(), (size_t)ncp * sizeof(double), e->d_state + (size_t)instance * e->inst_stride + c0,
 		(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), nstate, hipMemcpyDeviceToHost));
 	const int nodevar[4] = { 0, 1, 2, 4 };
 	const double * ops = e->h_ops.data();
 	auto opc = [&](int op, int k, int off) { return ops[((size_t)op * (L + 1) + k) * TMX_OPW + (off + 2)]; };
-	std::vector<double> colU(L), colV(L), colW(L + 1);
-	for (int i = 1; i < na - 1; i++) for (int j = 1; j < nb - 1; j++) {
-		const int c = col_of(P, i, j) - c0;
-		if (e->sw) {
-			for (int v = 0; v < 3; v++) node[((size_t)v * na + i) * nb + j] = buf[(size_t)v * ncp + c];
-			continue;
-		}
-		for (int v = 0; v < 4; v++) for (int k = 0; k < L; k++)
-			node[(((size_t)nodevar[v] * na + i) * nb + j) * L + k] = buf[(size_t)(v * L + k) * ncp + c];
-		for (int k = 0; k <= L; k++)
-			redge[(((size_t)3 * na + i) * nb + j) * (L + 1) + k] = buf[(size_t)(4 * L + k) * ncp + c];
-		// derived slots the reference keeps beside the prognostic ones (HorizontalDynamicsFEM.cpp:817-831)
-		for (int k = 0; k < L; k++) { colU[k] = buf[(size_t)(0 * L + k) * ncp + c]; colV[k] = buf[(size_t)(1 * L + k) * ncp + c]; }
-		for (int k = 0; k <= L; k++) colW[k] = buf[(size_t)(4 * L + k) * ncp + c];
-		for (int k = 0; k < L; k++) {
-			double w = 0.0;
-			w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * colW[k];
-			w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * colW[k + 1];
-			node[(((size_t)3 * na + i) * nb + j) * L + k] = w;
-		}
-		for (int k = 0; k <= L; k++) {
-			double ue = 0.0, ve = 0.0;
-			for (int off = -2; off <= 1; off++) {
-				const int l = k + off;
-				if (l < 0 || l >= L) continue;
-				const double cc = opc(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
-				if (cc == 0.0) continue;
-				ue += cc * colU[l]; ve += cc * colV[l];
+	const int * hoff = host_offsets(e, patch).data();
+	const size_t nn = (size_t)na * nb;
+	const bool sw = e->sw;
+	host_parallel((ncp + 63) / 64, [&](int ta, int tb) {
+		for (int t = ta; t < tb; t++) {
+			const int ca = t * 64, cb = std::min(ncp, ca + 64);
+			if (sw) {
+				for (int v = 0; v < 3; v++) xpose_to_host(node, (size_t)v * nn, 1, buf.data(), v, ncp, hoff, ca, cb);
+				continue;
 			}
-			redge[(((size_t)0 * na + i) * nb + j) * (L + 1) + k] = ue;
-			redge[(((size_t)1 * na + i) * nb + j) * (L + 1) + k] = ve;
+			for (int v = 0; v < 4; v++) xpose_to_host(node, (size_t)nodevar[v] * nn, L, buf.data(), v * L, ncp, hoff, ca, cb);
+			xpose_to_host(redge, (size_t)3 * nn, L + 1, buf.data(), 4 * L, ncp, hoff, ca, cb);
+			// derived slots the reference keeps beside the prognostic ones (HorizontalDynamicsFEM.cpp:817-831):
+			// W on levels, U and V on interfaces, from the columns just written (contiguous on the host)
+			for (int c = ca; c < cb; c++) {
+				const size_t ho = hoff[c];
+				const double * colU = node + ((size_t)0 * nn + ho) * L, * colV = node + ((size_t)1 * nn + ho) * L;
+				const double * colW = redge + ((size_t)3 * nn + ho) * (L + 1);
+				double * wn = node + ((size_t)3 * nn + ho) * L;
+				double * ue_ = redge + ((size_t)0 * nn + ho) * (L + 1), * ve_ = redge + ((size_t)1 * nn + ho) * (L + 1);
+				for (int k = 0; k < L; k++) {
+					double w = 0.0;
+					w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * colW[k];
+					w += opc(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * colW[k + 1];
+					wn[k] = w;
+				}
+				for (int k = 0; k <= L; k++) {
+					double ue = 0.0, ve = 0.0;
+					for (int off = -2; off <= 1; off++) {
+						const int l = k + off;
+						if (l < 0 || l >= L) continue;
+						const double cc = opc(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
+						if (cc == 0.0) continue;
+						ue += cc * colU[l]; ve += cc * colV[l];
+					}
+					ue_[k] = ue; ve_[k] = ve;
+				}
+			}
 		}
-	}
+	});
 	return TMX_OK;
 }
 

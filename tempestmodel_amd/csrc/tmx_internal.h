@@ -57,6 +57,7 @@ struct PatchInfo {
 	int elem_base = -1;                      // first local element, -1 if not owned
 	std::vector<int> hi, hj, hsp, hsi, hsj, hspanel;
 	std::vector<double> htrans;
+	std::vector<int> hoff;                   // host node offset i * nb + j of every device column (built on first transfer)
 };
 
 struct StepGraphKey { int scheme, first, last; double dt; };
@@ -136,6 +137,7 @@ struct tmx_engine {
 	bool fully_explicit = false, udiff = false;   // cfg.fully_explicit / cfg.uniform_diffusion
 	std::vector<double> h_ref;               // reference state in slab layout until tmx_finalize
 	double * d_ref = nullptr;                // [nslab][NS] reference state + reference tracers (uniform diffusion)
+	double * h_stage = nullptr; size_t h_stage_n = 0;   // pinned host staging buffer of tmx_upload_state / tmx_download_state
 	bool prof = false;
 	bool use_graph = false;                  // TMX_GRAPH=1: replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
 	std::vector<StepGraph> graphs;

@@ -21,4 +21,20 @@ for name, fn in (("upload", lambda: e.upload_state(0, st)), ("download", lambda:
     e.sync()
     dt = (time.perf_counter() - t0) / 3
     print("%s: %.1f ms per instance (%.0f MB host arrays incl. halo, %.2f GB/s)" % (name, dt * 1e3, nbytes / 1e6, nbytes / dt / 1e9))
+# the C calls alone, into preallocated host arrays (what the adapter does with the reference's own DataArray4D storage)
+import ctypes as C
+PD = C.POINTER(C.c_double)
+outs = [(np.zeros_like(n), np.zeros_like(r)) for n, r in st]
+for name in ("tmx_upload_state", "tmx_download_state"):
+    fn = getattr(e.lib, name)
+    def call():
+        for p, (n, r) in enumerate(outs if name == "tmx_download_state" else st):
+            assert fn(e.h, p, 0, n.ctypes.data_as(PD), r.ctypes.data_as(PD)) == 0
+    call(); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        call()
+    e.sync()
+    dt = (time.perf_counter() - t0) / 3
+    print("%s (C calls only): %.1f ms per instance, %.2f GB/s" % (name, dt * 1e3, nbytes / dt / 1e9))
 e.close()
