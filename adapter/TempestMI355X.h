@@ -445,18 +445,55 @@ public:
 ///	</summary>
 class TimestepSchemeARS343_MI355X : public TimestepScheme {
 public:
-	TimestepSchemeARS343_MI355X(Model & model) : TimestepScheme(model) { }
+	TimestepSchemeARS343_MI355X(Model & model) :
+		TimestepScheme(model), m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fHostNewer(true) { }
 
 	virtual int GetComponentDataInstances() const { return 7; }   // TimestepSchemeARS343.h:48-56
 	virtual int GetTracerDataInstances() const { return 7; }
 
+	///	<summary>
+	///		Host synchronisation policy.  1 (default): instance 0 is uploaded before and downloaded after every
+	///		step, so any reference code may read or modify it on the host between steps (output managers,
+	///		WorkflowProcess physics, error norms; Model.cpp:477-509) -- at ne30 L30 that is ~23 ms of transfers
+	///		around a 1.7 ms step.  n > 1: the state stays on the device; it is downloaded every n-th step and on
+	///		the last step (fLastStep), and uploaded again only after MarkHostModified().
+	///	</summary>
+	void SetHostSyncInterval(int nSteps) { m_nHostSyncInterval = (nSteps < 1) ? 1 : nSteps; }
+
+	///	<summary>
+	///		The host copy of instance 0 was changed outside the scheme: upload it before the next step.
+	///	</summary>
+	void MarkHostModified() { m_fHostNewer = true; }
+
+	///	<summary>
+	///		Bring the host copy of instance 0 up to date now (e.g. from an output manager).
+	///	</summary>
+	void Flush() {
+		if (m_nStepsSinceSync > 0) {
+			MI355XEngine & eng = MI355XEngine::For(m_model);
+			MI355XEngine::Check(tmx_sync(eng.Handle()));
+			eng.Download(0);
+			m_nStepsSinceSync = 0;
+		}
+	}
+
 	virtual void Step(bool fFirstStep, bool fLastStep, const Time & time, double dDeltaT) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);
-		eng.Upload(0);
+		if (m_fHostNewer || m_nHostSyncInterval == 1) {
+			eng.Upload(0);
+			m_fHostNewer = false;
+		}
 		MI355XEngine::Check(tmx_step_ars343(eng.Handle(), dDeltaT));
-		MI355XEngine::Check(tmx_sync(eng.Handle()));
-		eng.Download(0);
+		m_nStepsSinceSync++;
+		if (m_nHostSyncInterval == 1 || fLastStep || m_nStepsSinceSync >= m_nHostSyncInterval) {
+			Flush();
+		}
 	}
+
+private:
+	int m_nHostSyncInterval;
+	int m_nStepsSinceSync;
+	bool m_fHostNewer;
 };
 
 ///////////////////////////////////////////////////////////////////////////////

@@ -116,7 +116,7 @@ static void restore(GridGLL * pGrid, const Snapshot & s) {
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 	std::string mode = "production", tcase = "jw";
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0;
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -131,6 +131,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--tol") { tol = atof(v); i++; }
 		else if (a == "--case") { tcase = v; i++; }
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
+		else if (a == "--hostsync") { hostsync = atoi(v); i++; }    // production mode: host synchronisation interval (steps)
 		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing after every step
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
@@ -187,10 +188,11 @@ try {
 	save(pGrid, ref);
 
 	restore(pGrid, start);
-	if (mode == "production") { pT->m_fDevice = true; }
+	if (mode == "production") { pT->m_fDevice = true; pT->m_dev.SetHostSyncInterval(hostsync); pT->m_dev.MarkHostModified(); }
 	else if (mode == "parity") { pH->m_fDevice = true; pV->m_fDevice = true; }
 	else { fprintf(stderr, "bad mode\n"); return 2; }
 	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (physics) hsDev.Perform(time); }
+	pT->m_dev.Flush();      // deferred host synchronisation (--hostsync > 1): bring instance 0 back before comparing
 	save(pGrid, got);
 
 	// compare prognostic slots on interior nodes

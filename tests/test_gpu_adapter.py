@@ -18,6 +18,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6"]),
     ("production", ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
     ("parity", ["--ne", "4", "--levels", "10", "--steps", "3", "--patches", "6"]),
+    # state kept on the device between steps (SetHostSyncInterval), downloaded once at the end
+    ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6", "--hostsync", "100"]),
     # row H7: Schar mountain on the reduced-radius sphere, Rayleigh layer (dt 0.5 s)
     ("production", ["--case", "schar", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6", "--dt", "0.5"]),
     # rows H8 / V8: two tracer densities
