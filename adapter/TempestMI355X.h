@@ -438,6 +438,28 @@ public:
 		MI355XEngine::Check(tmx_sync(eng.Handle()));
 		eng.Download(iDataUpdate);
 	}
+
+	// ARK232 only (TimestepSchemeARK232.cpp:167-225)
+	virtual void StepImplicitTermsExplicitly(int iDataInitial, int iDataUpdate, const Time & time, double dDeltaT) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		if (iDataUpdate != iDataInitial) {
+			eng.Upload(iDataUpdate);
+		}
+		MI355XEngine::Check(tmx_v_step_implicit_terms_explicitly(eng.Handle(), iDataInitial, iDataUpdate, dDeltaT));
+		eng.Download(iDataUpdate);
+	}
+
+	// TimestepSchemeStrang.cpp:242, :480
+	virtual void FilterNegativeTracers(int iDataUpdate) {
+		if (m_model.GetEquationSet().GetTracers() == 0) {
+			return;
+		}
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataUpdate);
+		MI355XEngine::Check(tmx_v_filter_negative_tracers(eng.Handle(), iDataUpdate));
+		eng.Download(iDataUpdate);
+	}
 };
 
 ///	<summary>

@@ -66,19 +66,30 @@ public:
 	virtual void StepImplicit(int a, int b, const Time & t, double dt) {
 		if (m_fDevice) m_dev.StepImplicit(a, b, t, dt); else static_cast<VerticalDynamics &>(m_ref).StepImplicit(a, b, t, dt);
 	}
+	virtual void StepImplicitTermsExplicitly(int a, int b, const Time & t, double dt) {
+		if (m_fDevice) m_dev.StepImplicitTermsExplicitly(a, b, t, dt); else static_cast<VerticalDynamics &>(m_ref).StepImplicitTermsExplicitly(a, b, t, dt);
+	}
+	virtual void FilterNegativeTracers(int a) {
+		if (m_fDevice) m_dev.FilterNegativeTracers(a); else static_cast<VerticalDynamics &>(m_ref).FilterNegativeTracers(a);
+	}
 };
 
 class TSwitch : public TimestepScheme {
 public:
-	TimestepSchemeARS343 m_ref;
+	TimestepScheme * m_pRef;      // the reference's own scheme: ARS343 (default) or, for parity mode, ARK232 / ARS232
 	TimestepSchemeARS343_MI355X m_dev;
 	bool m_fDevice;
-	TSwitch(Model & model) : TimestepScheme(model), m_ref(model), m_dev(model), m_fDevice(false) { }
-	virtual int GetComponentDataInstances() const { return static_cast<const TimestepScheme &>(m_ref).GetComponentDataInstances(); }
-	virtual int GetTracerDataInstances() const { return static_cast<const TimestepScheme &>(m_ref).GetTracerDataInstances(); }
-	virtual void Initialize() { static_cast<TimestepScheme &>(m_ref).Initialize(); }
+	TSwitch(Model & model, const std::string & scheme) : TimestepScheme(model), m_pRef(NULL), m_dev(model), m_fDevice(false) {
+		if (scheme == "ark232") m_pRef = new TimestepSchemeARK232(model);
+		else if (scheme == "ars232") m_pRef = new TimestepSchemeARS232(model);
+		else m_pRef = new TimestepSchemeARS343(model);
+	}
+	virtual ~TSwitch() { delete m_pRef; }
+	virtual int GetComponentDataInstances() const { return m_pRef->GetComponentDataInstances(); }
+	virtual int GetTracerDataInstances() const { return m_pRef->GetTracerDataInstances(); }
+	virtual void Initialize() { m_pRef->Initialize(); }
 	virtual void Step(bool f, bool l, const Time & t, double dt) {
-		if (m_fDevice) m_dev.Step(f, l, t, dt); else static_cast<TimestepScheme &>(m_ref).Step(f, l, t, dt);
+		if (m_fDevice) m_dev.Step(f, l, t, dt); else m_pRef->Step(f, l, t, dt);
 	}
 };
 
@@ -115,7 +126,7 @@ static void restore(GridGLL * pGrid, const Snapshot & s) {
 
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
-	std::string mode = "production", tcase = "jw";
+	std::string mode = "production", tcase = "jw", scheme = "ars343";
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
 	for (int i = 1; i < argc; i++) {
@@ -130,6 +141,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--tol") { tol = atof(v); i++; }
 		else if (a == "--case") { tcase = v; i++; }
+		else if (a == "--scheme") { scheme = v; i++; }                // parity mode: ars343 (default), ark232, ars232
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--hostsync") { hostsync = atoi(v); i++; }    // production mode: host synchronisation interval (steps)
 		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing after every step
@@ -147,7 +159,8 @@ try {
 	model.SetDeltaT(timeDeltaT);
 	model.SetEndTime(model.GetStartTime());
 
-	TSwitch * pT = new TSwitch(model);
+	if (mode == "production" && scheme != "ars343") { fprintf(stderr, "production mode replaces TimestepSchemeARS343 only\n"); return 2; }
+	TSwitch * pT = new TSwitch(model, scheme);
 	HSwitch * pH = new HSwitch(model);
 	// --case supercell: the configuration of test/dcmip2016/SupercellTest.cpp (planet / 120, no rotation, uniform
 	// diffusion 1500 / 500 m^2/s, --explicitvertical) without its Fortran physics, driven by the JW state

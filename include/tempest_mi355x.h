@@ -239,6 +239,12 @@ int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_AR
  * on every column (used by ARK232). */
 int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int i_initial, int i_update, double dt);
 
+/* VerticalDynamics::FilterNegativeTracers(iDataUpdate) (src/atm/VerticalDynamics.h:123-126; VerticalDynamicsFEM.cpp:
+ * 4286-4347): per stored column and tracer, clip negative densities and rescale the positive ones so that the
+ * column mass is unchanged.  Called by TimestepSchemeStrang after its carry-over combination
+ * (TimestepSchemeStrang.cpp:242, :480); a no-op without tracers. */
+int tmx_v_filter_negative_tracers(tmx_engine * e, int instance);
+
 /* ---- column physics as a WorkflowProcess on the device ------------------------ */
 
 /* Per owned patch: latitude [na][nb] (GridPatch::GetLatitude) and the "surface pressure" [na][nb] that

@@ -1630,6 +1630,14 @@ extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, i
 	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	return launch_check("v_step_implicit_terms_explicitly");
 }
+extern "C" int tmx_v_filter_negative_tracers(tmx_engine * e, int instance) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	if (e->nt == 0) return TMX_OK;
+	ProfScope ps(e, TMX_K_LINCOMB);
+	tmxk_v_filter_tracers(e, make_params(e), inst(e, instance));
+	return launch_check("v_filter_negative_tracers");
+}
+
 static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { return tmx_v_step_implicit_terms_explicitly(e, iinit, iupd, dt); }
 
 static int run_program(tmx_engine * e, const Program & p) {
@@ -1680,7 +1688,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 			break;
 		case OP_VFILT:
 			// VerticalDynamics::FilterNegativeTracers(instance): nothing without tracers
-			if (e->nt > 0) { ProfScope ps(e, TMX_K_LINCOMB); tmxk_v_filter_tracers(e, make_params(e), inst(e, o.a)); if ((r = launch_check("v_filter_tracers"))) return r; }
+			if ((r = tmx_v_filter_negative_tracers(e, o.a))) return r;
 			break;
 		case OP_VITE:
 			if ((r = vi_terms_explicit(e, o.a, o.b, o.coef))) return r;

@@ -93,6 +93,7 @@ def load_library():
     lib.tmx_set_patch_metric_factors.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, C.c_double, PD, PD]
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
     lib.tmx_set_patch_reference_state.argtypes = [C.c_void_p, C.c_int, PD, PD, PD]
+    lib.tmx_v_filter_negative_tracers.argtypes = [C.c_void_p, C.c_int]
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
@@ -338,6 +339,9 @@ class Engine:
     @classmethod
     def scheme_instances(cls, scheme):
         return int(load_library().tmx_scheme_instances(cls.SCHEMES[scheme]))
+
+    def v_filter_negative_tracers(self, instance):
+        self._chk(self.lib.tmx_v_filter_negative_tracers(self.h, instance))
 
     def v_step_implicit_terms_explicitly(self, iinit, iupd, dt):
         self._chk(self.lib.tmx_v_step_implicit_terms_explicitly(self.h, iinit, iupd, dt))

@@ -18,6 +18,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6"]),
     ("production", ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
     ("parity", ["--ne", "4", "--levels", "10", "--steps", "3", "--patches", "6"]),
+    # the reference's ARK232 over the plugin classes: StepImplicitTermsExplicitly and the sub-cycled explicit stages
+    ("parity", ["--scheme", "ark232", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6"]),
     # state kept on the device between steps (SetHostSyncInterval), downloaded once at the end
     ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6", "--hostsync", "100"]),
     # row H7: Schar mountain on the reduced-radius sphere, Rayleigh layer (dt 0.5 s)
