@@ -384,7 +384,7 @@ public:
 	HorizontalDynamicsMI355X(
 		Model & model, int nHorizontalOrder, int nHyperviscosityOrder,
 		double dNuScalar, double dNuDiv, double dNuVort
-	) : HorizontalDynamics(model) {
+	) : HorizontalDynamics(model), m_nHyperviscosityOrder(nHyperviscosityOrder) {
 		MI355XEngine::For(model).SetViscosity(dNuScalar, dNuDiv, dNuVort, nHyperviscosityOrder);
 	}
 
@@ -407,6 +407,26 @@ public:
 		eng.Download(iDataUpdate);
 		eng.Download(iDataWorking);
 	}
+
+	// HorizontalDynamicsFEM.cpp:2574-2578 (may be asked before the grid exists: no engine call)
+	virtual int GetSubStepAfterSubCycleCount() {
+		return m_nHyperviscosityOrder / 2;
+	}
+
+	virtual int SubStepAfterSubCycle(int iDataInitial, int iDataUpdate, int iDataWorking, const Time & time, double dDeltaT, int iSubStep) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		eng.Upload(iDataInitial);
+		if (iSubStep == 1) {
+			eng.Upload(iDataWorking);
+		}
+		int iResult = -1;
+		MI355XEngine::Check(tmx_h_substep_after_subcycle(eng.Handle(), iDataInitial, iDataUpdate, iDataWorking, dDeltaT, iSubStep, &iResult));
+		eng.Download(iResult);
+		return iResult;
+	}
+
+private:
+	int m_nHyperviscosityOrder;
 };
 
 ///	<summary>

@@ -237,6 +237,17 @@ int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_AR
 
 /* VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612): update -= dt F(initial)
  * on every column (used by ARK232). */
+/* HorizontalDynamics::GetSubStepAfterSubCycleCount() / SubStepAfterSubCycle(iInit,iUpd,iWork,time,dt,iSubStep)
+ * (src/atm/HorizontalDynamics.h:128-147, HorizontalDynamicsFEM.cpp:2574-2633): the two halves of the hyperviscosity
+ * step without the DSS calls, for callers that exchange between them (Model::SubStep).  Sub-step 0 leaves the
+ * Laplacians of the initial instance in the working instance; sub-step 1 forms the update instance, filters the
+ * tracers and applies Rayleigh friction.  *result_instance = the instance holding the output (as the reference's
+ * return value).  Sub-step 0, tmx_apply_dss(work), sub-step 1, tmx_apply_dss(update) equals tmx_h_step_after_subcycle
+ * bit for bit when there is no Rayleigh friction (which the full call applies after the last DSS). */
+int tmx_h_substep_after_subcycle_count(tmx_engine * e);
+int tmx_h_substep_after_subcycle(tmx_engine * e, int i_initial, int i_update, int i_working, double dt, int i_substep,
+	int * result_instance);
+
 int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int i_initial, int i_update, double dt);
 
 /* VerticalDynamics::FilterNegativeTracers(iDataUpdate) (src/atm/VerticalDynamics.h:123-126; VerticalDynamicsFEM.cpp:

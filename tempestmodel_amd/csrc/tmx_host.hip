@@ -1433,6 +1433,39 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	return TMX_OK;
 }
 
+// HorizontalDynamics::GetSubStepAfterSubCycleCount / SubStepAfterSubCycle (HorizontalDynamicsFEM.cpp:2574-2633): the two
+// halves of the hyperviscosity step WITHOUT the DSS calls -- the caller (Model::SubStep, Model.cpp:286-) exchanges
+// between them.  Sub-step 0: working <- Laplacians of initial; sub-step 1: update <- initial - dt nu Laplacians of
+// working, tracer filter, Rayleigh friction.  *result receives the instance that holds the sub-step's output.
+extern "C" int tmx_h_substep_after_subcycle_count(tmx_engine * e) {
+	if (!e) return -1;
+	return e->cfg.hypervis_order / 2;
+}
+
+extern "C" int tmx_h_substep_after_subcycle(tmx_engine * e, int iinit, int iupd, int iwork, double dt, int isubstep, int * result) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd)) || (r = check_inst(e, iwork))) return r;
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "SubStepAfterSubCycle with the shallow-water equation set is not supported");
+	REQUIRE(isubstep == 0 || isubstep == 1, TMX_ERR_INVALID, "Invalid iSubStep %d", isubstep);
+	REQUIRE(iinit != iwork && iupd != iwork, TMX_ERR_INVALID, "SubStepAfterSubCycle: working data must be distinct from initial and update data");
+	const tmx_config & c = e->cfg;
+	KParams p = make_params(e);
+	ProfScope ps(e, TMX_K_HYPERVIS);
+	if (isubstep == 0) {
+		tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0);
+		if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0);
+		if (result) *result = iwork;
+		return launch_check("hypervis sub-step 0");
+	}
+	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "SubStepAfterSubCycle: initial and update data must be distinct");
+	double scale = 1.0;
+	if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
+	tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale);
+	if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, 1);
+	if (e->rayleigh) tmxk_rayleigh(e, p, inst(e, iupd), dt);
+	if (result) *result = iupd;
+	return launch_check("hypervis sub-step 1");
+}
+
 static bool hypervis_active(const tmx_engine * e) {
 	const tmx_config & c = e->cfg;
 	return !((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0);

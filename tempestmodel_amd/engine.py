@@ -94,6 +94,8 @@ def load_library():
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
     lib.tmx_set_patch_reference_state.argtypes = [C.c_void_p, C.c_int, PD, PD, PD]
     lib.tmx_v_filter_negative_tracers.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_h_substep_after_subcycle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
+    lib.tmx_h_substep_after_subcycle_count.argtypes = [C.c_void_p]
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
@@ -339,6 +341,12 @@ class Engine:
     @classmethod
     def scheme_instances(cls, scheme):
         return int(load_library().tmx_scheme_instances(cls.SCHEMES[scheme]))
+
+    def h_substep_after_subcycle(self, iinit, iupd, iwork, dt, isubstep):
+        """HorizontalDynamicsFEM.SubStepAfterSubCycle; returns the instance holding the output."""
+        out = C.c_int(-1)
+        self._chk(self.lib.tmx_h_substep_after_subcycle(self.h, iinit, iupd, iwork, dt, isubstep, C.byref(out)))
+        return out.value
 
     def v_filter_negative_tracers(self, instance):
         self._chk(self.lib.tmx_v_filter_negative_tracers(self.h, instance))

@@ -284,6 +284,34 @@ def test_viscosity_order_2_steps():
         e.close()
 
 
+def test_substep_after_subcycle_equals_step_after_subcycle():
+    """HorizontalDynamicsFEM::SubStepAfterSubCycle (the two halves of the hyperviscosity step, DSS done by the caller)
+    reproduces StepAfterSubCycle bit for bit, with and without tracers."""
+    from tempestmodel_amd.engine import Engine
+    for ntr in (0, 2):
+        g, st = gu.make_grid(3, 6, 6, ntracers=ntr)
+        e = Engine(g)
+        try:
+            e.upload_state(0, st)
+            if ntr:
+                e.upload_tracers(0, [g.initial_tracers[p] for p in range(6)])
+            e.step_ars343(200.0)                      # W != 0
+            e.h_step_after_subcycle(0, 1, 2, 200.0)
+            assert e.h_substep_after_subcycle(0, 3, 4, 200.0, 0) == 4
+            e.apply_dss(4)
+            assert e.h_substep_after_subcycle(0, 3, 4, 200.0, 1) == 3
+            e.apply_dss(3)
+            e.sync()
+            for a, b in ((1, 3), (2, 4)):
+                for (na, ea), (nb, eb) in zip(e.download_state(a), e.download_state(b)):
+                    assert np.array_equal(na[[0, 1, 2, 4]], nb[[0, 1, 2, 4]]) and np.array_equal(ea[3], eb[3])
+                if ntr:
+                    for ta, tb in zip(e.download_tracers(a), e.download_tracers(b)):
+                        assert np.array_equal(ta, tb)
+        finally:
+            e.close()
+
+
 def test_graph_replay_is_bit_identical(monkeypatch):
     """TMX_GRAPH=1: ARS343 and Strang steps replayed from a captured hipGraph equal the plain launch sequence bit for bit."""
     from tempestmodel_amd.engine import Engine
