@@ -24,6 +24,8 @@
 #include "HorizontalDynamics.h"
 #include "VerticalDynamics.h"
 #include "VerticalDynamicsFEM.h"
+#include "LinearColumnOperatorFEM.h"
+#include "PolynomialInterp.h"
 #include "TimestepScheme.h"
 #include "Exception.h"
 #include "WorkflowProcess.h"
@@ -77,6 +79,20 @@ public:
 				Check(tmx_upload_tracers(m_pEngine, pPatch->GetPatchIndex(), ixData,
 					&(pPatch->GetDataTracers(ixData)[0][0][0][0])));
 			}
+		}
+	}
+
+	// GridPatch::GetReferenceState / GetReferenceTracers -> device (uniform diffusion, output without the reference state)
+	void SetReferenceState() {
+		Initialize();
+		GridGLL * pGrid = Grid();
+		const bool fTracers = m_model.GetEquationSet().GetTracers() > 0;
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			Check(tmx_set_patch_reference_state(m_pEngine, pPatch->GetPatchIndex(),
+				&(pPatch->GetReferenceState(DataLocation_Node)[0][0][0][0]),
+				&(pPatch->GetReferenceState(DataLocation_REdge)[0][0][0][0]),
+				fTracers ? &(pPatch->GetReferenceTracers()[0][0][0][0]) : NULL));
 		}
 	}
 
@@ -572,6 +588,122 @@ public:
 		eng.Download(0);
 		WorkflowProcess::Perform(time);
 	}
+};
+
+///////////////////////////////////////////////////////////////////////////////
+
+///	<summary>
+///		Grid::ReduceInterpolate (src/atm/Grid.h:390-400) on the device: what OutputManagerReference needs for an output
+///		(OutputManagerReference.cpp:588-628) without bringing the state back to the host.  Same arguments as the
+///		reference call; the per-point data come from the reference's own functions, exactly as
+///		GridPatchCSGLL::InterpolateData (GridPatchCSGLL.cpp:1580-1622) derives them.  The plan is rebuilt when the
+///		sample points or the vertical coordinate change.
+///	</summary>
+class ReduceInterpolateMI355X {
+public:
+	ReduceInterpolateMI355X(Model & model) : m_model(model), m_pPlan(NULL) { }
+
+	~ReduceInterpolateMI355X() {
+		if (m_pPlan != NULL) {
+			tmx_interp_destroy(m_pPlan);
+		}
+	}
+
+	void operator()(
+		DataType eDataType,
+		const DataArray1D<double> & dREta,
+		const DataArray1D<double> & dAlpha,
+		const DataArray1D<double> & dBeta,
+		const DataArray1D<int> & iPatch,
+		DataArray3D<double> & dInterpData,
+		DataLocation eOnlyVariablesAt = DataLocation_None,
+		bool fIncludeReferenceState = true,
+		bool fConvertToPrimitive = true
+	) {
+		if ((eDataType != DataType_State) && (eDataType != DataType_Tracers)) {
+			_EXCEPTIONT("ReduceInterpolateMI355X: only DataType_State and DataType_Tracers live on the device");
+		}
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		tmx_engine * pEngine = eng.Handle();
+		GridGLL * pGrid = dynamic_cast<GridGLL *>(m_model.GetGrid());
+		const int nPoints = dAlpha.GetRows();
+		const int nREta = dREta.GetRows();
+
+		// (re)build the plan
+		std::vector<double> vecKey;
+		for (int k = 0; k < nREta; k++) vecKey.push_back(dREta[k]);
+		for (int i = 0; i < nPoints; i++) { vecKey.push_back(dAlpha[i]); vecKey.push_back(dBeta[i]); vecKey.push_back(iPatch[i]); }
+		if ((m_pPlan == NULL) || (vecKey != m_vecKey)) {
+			if (m_pPlan != NULL) {
+				tmx_interp_destroy(m_pPlan);
+				m_pPlan = NULL;
+			}
+			const int nOrder = pGrid->GetHorizontalOrder();
+			std::vector<int> vecPatch(nPoints), vecA(nPoints, 1), vecB(nPoints, 1);
+			std::vector<double> vecCA(nPoints * nOrder, 0.0), vecCB(nPoints * nOrder, 0.0), vecM(nPoints * 4, 0.0);
+			for (int i = 0; i < nPoints; i++) {
+				vecPatch[i] = iPatch[i];
+				GridPatch * pPatch = NULL;
+				for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+					if (pGrid->GetActivePatch(n)->GetPatchIndex() == iPatch[i]) pPatch = pGrid->GetActivePatch(n);
+				}
+				if (pPatch == NULL) {
+					continue;      // another rank's patch: this rank contributes zeros
+				}
+				const PatchBox & box = pPatch->GetPatchBox();
+				GridPatchGLL * pGLL = dynamic_cast<GridPatchGLL *>(pPatch);
+				int iA = (dAlpha[i] - pPatch->GetAEdge(box.GetAInteriorBegin())) / pGLL->GetElementDeltaA();
+				int iB = (dBeta[i] - pPatch->GetBEdge(box.GetBInteriorBegin())) / pGLL->GetElementDeltaB();
+				if (iA < 0) iA = 0;
+				if (iA >= box.GetAInteriorWidth() / nOrder) iA = box.GetAInteriorWidth() / nOrder - 1;
+				if (iB < 0) iB = 0;
+				if (iB >= box.GetBInteriorWidth() / nOrder) iB = box.GetBInteriorWidth() / nOrder - 1;
+				iA = box.GetHaloElements() + iA * nOrder;
+				iB = box.GetHaloElements() + iB * nOrder;
+				vecA[i] = iA; vecB[i] = iB;
+				PolynomialInterp::LagrangianPolynomialCoeffs(nOrder, &(pPatch->GetAEdges()[iA]), &vecCA[i * nOrder], dAlpha[i]);
+				PolynomialInterp::LagrangianPolynomialCoeffs(nOrder, &(pPatch->GetBEdges()[iB]), &vecCB[i * nOrder], dBeta[i]);
+				CubedSphereTrans::CoVecTransRLLFromABP(tan(dAlpha[i]), tan(dBeta[i]), box.GetPanel(), 1.0, 0.0, vecM[i * 4 + 0], vecM[i * 4 + 2]);
+				CubedSphereTrans::CoVecTransRLLFromABP(tan(dAlpha[i]), tan(dBeta[i]), box.GetPanel(), 0.0, 1.0, vecM[i * 4 + 1], vecM[i * 4 + 3]);
+			}
+			LinearColumnInterpFEM opLevels, opInterfaces;
+			opLevels.Initialize(LinearColumnInterpFEM::InterpSource_Levels, pGrid->GetVerticalOrder(),
+				pGrid->GetREtaLevels(), pGrid->GetREtaInterfaces(), dREta);
+			opInterfaces.Initialize(LinearColumnInterpFEM::InterpSource_Interfaces, pGrid->GetVerticalOrder(),
+				pGrid->GetREtaLevels(), pGrid->GetREtaInterfaces(), dREta);
+			tmx_interp_points pts;
+			pts.n_points = nPoints; pts.n_reta = nREta;
+			pts.patch = &vecPatch[0]; pts.node_a = &vecA[0]; pts.node_b = &vecB[0];
+			pts.coeff_a = &vecCA[0]; pts.coeff_b = &vecCB[0]; pts.rll_from_abp = &vecM[0];
+			pts.op_levels = &(opLevels.GetCoeffs()[0][0]); pts.op_interfaces = &(opInterfaces.GetCoeffs()[0][0]);
+			MI355XEngine::Check(tmx_interp_create(pEngine, &pts, &m_pPlan));
+			m_vecKey = vecKey;
+		}
+
+		if (eDataType == DataType_State) {
+			if (!fIncludeReferenceState) {
+				eng.SetReferenceState();
+			}
+			const int iOnly = (eOnlyVariablesAt == DataLocation_Node) ? 1 : ((eOnlyVariablesAt == DataLocation_REdge) ? 2 : 0);
+			MI355XEngine::Check(tmx_interp_state(pEngine, m_pPlan, 0, iOnly, fIncludeReferenceState ? 1 : 0,
+				fConvertToPrimitive ? 1 : 0, m_model.GetPhysicalConstants().GetEarthRadius(), &(dInterpData[0][0][0])));
+		} else {
+			MI355XEngine::Check(tmx_interp_tracers(pEngine, m_pPlan, 0, &(dInterpData[0][0][0])));
+		}
+#ifdef TEMPEST_MPIOMP
+		// as Grid::ReduceInterpolate (Grid.cpp:962-990): the ranks' partial arrays are summed on rank 0
+		int nRank;
+		MPI_Comm_rank(MPI_COMM_WORLD, &nRank);
+		const int nCount = dInterpData.GetRows() * dInterpData.GetColumns() * dInterpData.GetSubColumns();
+		if (nRank == 0) MPI_Reduce(MPI_IN_PLACE, &(dInterpData[0][0][0]), nCount, MPI_DOUBLE, MPI_SUM, 0, MPI_COMM_WORLD);
+		else MPI_Reduce(&(dInterpData[0][0][0]), NULL, nCount, MPI_DOUBLE, MPI_SUM, 0, MPI_COMM_WORLD);
+#endif
+	}
+
+private:
+	Model & m_model;
+	tmx_interp * m_pPlan;
+	std::vector<double> m_vecKey;
 };
 
 #endif

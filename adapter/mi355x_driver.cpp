@@ -259,6 +259,51 @@ try {
 	status = (worst < tol) ? 0 : 1;
 	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",
 		tmx_info(MI355XEngine::For(model).Handle(), TMX_INFO_METRIC_CLOSED_FORM) == 1 ? "active" : "refused, arrays streamed");
+	// the output interpolation.  Host arrays and device now hold the same instance 0: the reference's
+	// Grid::ReduceInterpolate on the host arrays against ReduceInterpolateMI355X on the device state, both flag sets
+	// OutputManagerReference uses plus the primitive conversion.
+	{
+		const int nlon = 16, nlat = 8, npts = nlon * nlat;
+		DataArray1D<double> dLon(npts), dLat(npts), dAlpha(npts), dBeta(npts);
+		DataArray1D<int> iPatch(npts);
+		for (int j = 0; j < nlat; j++) for (int i = 0; i < nlon; i++) {
+			dLon[j * nlon + i] = (i + 0.5) * 2.0 * M_PI / nlon;
+			dLat[j * nlon + i] = -0.5 * M_PI + (j + 0.5) * M_PI / nlat;
+		}
+		pGrid->ConvertReferenceToPatchCoord(dLon, dLat, dAlpha, dBeta, iPatch);
+		MI355XEngine::For(model).Upload(0);      // parity mode leaves the device copy of instance 0 behind the host's
+		ReduceInterpolateMI355X interp(model);
+		double worstI = 0.0;
+		for (int v = 0; v < 3; v++) {
+			const bool fRef = (v != 1), fPrim = (v == 2);
+			const DataArray1D<double> & dREta = pGrid->GetREtaLevels();
+			DataArray3D<double> a(5, dREta.GetRows(), npts), b(5, dREta.GetRows(), npts);
+			pGrid->ReduceInterpolate(DataType_State, dREta, dAlpha, dBeta, iPatch, a, DataLocation_None, fRef, fPrim);
+			interp(DataType_State, dREta, dAlpha, dBeta, iPatch, b, DataLocation_None, fRef, fPrim);
+			for (int c = 0; c < 5; c++) {
+				double dm = 0.0, sm = 0.0;
+				for (int k = 0; k < dREta.GetRows(); k++) for (int i = 0; i < npts; i++) {
+					dm = std::max(dm, fabs(a[c][k][i] - b[c][k][i])); sm = std::max(sm, fabs(a[c][k][i]));
+				}
+				if (sm > 0.0) worstI = std::max(worstI, dm / sm);
+			}
+		}
+		if (ntracers > 0) {
+			const DataArray1D<double> & dREta = pGrid->GetREtaLevels();
+			DataArray3D<double> a(ntracers, dREta.GetRows(), npts), b(ntracers, dREta.GetRows(), npts);
+			pGrid->ReduceInterpolate(DataType_Tracers, dREta, dAlpha, dBeta, iPatch, a, DataLocation_None, true);
+			interp(DataType_Tracers, dREta, dAlpha, dBeta, iPatch, b, DataLocation_None, true);
+			for (int c = 0; c < ntracers; c++) {
+				double dm = 0.0, sm = 0.0;
+				for (int k = 0; k < dREta.GetRows(); k++) for (int i = 0; i < npts; i++) {
+					dm = std::max(dm, fabs(a[c][k][i] - b[c][k][i])); sm = std::max(sm, fabs(a[c][k][i]));
+				}
+				if (sm > 0.0) worstI = std::max(worstI, dm / sm);
+			}
+		}
+		printf("output interpolation (Grid::ReduceInterpolate vs device, %d points): max rel diff %.3e\n", npts, worstI);
+		if (!(worstI < 1.0e-12)) status = 1;
+	}
 	printf("%s\n", status == 0 ? "ADAPTER_OK" : "ADAPTER_MISMATCH");
 } catch (Exception & e) {
 	std::cout << e.ToString() << std::endl;

@@ -176,7 +176,7 @@ int tmx_set_patch_rayleigh(tmx_engine * e, int patch, const double * strength_no
 /* Per owned patch, required when cfg.uniform_diffusion != 0: the reference state the uniform diffusion is taken
  * relative to.  ref_node [5][na][nb][L] / ref_redge [5][na][nb][L+1] = GridPatch::GetReferenceState(DataLocation_Node /
  * _REdge), ref_tracers [n_tracers][na][nb][L] = GridPatch::GetReferenceTracers() (NULL when n_tracers == 0); same
- * layout as tmx_upload_state.  Used by: the uniform-diffusion extras of HorizontalDynamicsFEM::StepExplicit
+ * layout as tmx_upload_state.  Also accepted without uniform diffusion (tmx_interp_state can subtract it).  Used by: the uniform-diffusion extras of HorizontalDynamicsFEM::StepExplicit
  * (src/atm/HorizontalDynamicsFEM.cpp:1817-1859; tracer fluxes :1105-1148), the vertical diffusion of U,V in
  * VerticalDynamicsFEM::StepExplicit (src/atm/VerticalDynamicsFEM.cpp:1059-1105), of rho*theta and W in BuildF
  * (:2593-2635) and of the tracer mixing ratios in UpdateColumnTracers (:4117-4141). */
@@ -237,6 +237,36 @@ int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_AR
 
 /* VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612): update -= dt F(initial)
  * on every column (used by ARK232). */
+/* ---- output interpolation: Grid::ReduceInterpolate (src/atm/Grid.cpp:867-992) ->
+ * GridPatchCSGLL::InterpolateData (src/atm/GridPatchCSGLL.cpp:1365-1780), what OutputManagerReference calls for every
+ * output (src/atm/OutputManagerReference.cpp:588-628).  The state stays on the device; only the interpolated fields
+ * [component][n_reta][n_points] come back.  The caller passes, per sample point, what it gets from the reference's own
+ * functions (as for the halo transforms): patch index and (alpha, beta)-derived quantities
+ *   node_a / node_b  first node of the containing element incl. the halo offset (iA, iB of GridPatchCSGLL.cpp:1588-1611)
+ *   coeff_a/_b       PolynomialInterp::LagrangianPolynomialCoeffs over GetAEdges()[iA..iA+3] / GetBEdges()[iB..iB+3]
+ *   rll_from_abp     2x2 matrix of CubedSphereTrans::CoVecTransRLLFromABP(tan alpha, tan beta, panel, ...) probed with
+ *                    unit vectors, row-major (lon; lat) x (alpha, beta); may be NULL if convert_to_primitive is never used
+ *   op_levels / op_interfaces   dense coefficients [n_reta][L] / [n_reta][L+1] of LinearColumnInterpFEM::Initialize(
+ *                    InterpSource_Levels / _Interfaces, vertical order, REtaLevels, REtaInterfaces, dREta)
+ * Points on patches of other ranks produce zeros (the reference sums the ranks' arrays with MPI_Reduce). */
+typedef struct tmx_interp tmx_interp;
+typedef struct {
+	int n_points, n_reta;
+	const int * patch; const int * node_a; const int * node_b;
+	const double * coeff_a; const double * coeff_b;
+	const double * rll_from_abp;
+	const double * op_levels; const double * op_interfaces;
+} tmx_interp_points;
+int tmx_interp_create(tmx_engine * e, const tmx_interp_points * points, tmx_interp ** out);
+void tmx_interp_destroy(tmx_interp * plan);
+/* DataType_State: out[5][n_reta][n_points].  only_variables_at: 0 DataLocation_None (all), 1 levels only, 2 interfaces
+ * only (skipped rows are zero); include_reference_state = 0 subtracts the interpolated reference state (needs
+ * tmx_set_patch_reference_state); convert_to_primitive: W / d_xi R, (U,V) -> zonal / meridional velocity. */
+int tmx_interp_state(tmx_engine * e, tmx_interp * plan, int instance, int only_variables_at, int include_reference_state,
+	int convert_to_primitive, double earth_radius, double * out);
+/* DataType_Tracers: out[n_tracers][n_reta][n_points]. */
+int tmx_interp_tracers(tmx_engine * e, tmx_interp * plan, int instance, double * out);
+
 /* HorizontalDynamics::GetSubStepAfterSubCycleCount() / SubStepAfterSubCycle(iInit,iUpd,iWork,time,dt,iSubStep)
  * (src/atm/HorizontalDynamics.h:128-147, HorizontalDynamicsFEM.cpp:2574-2633): the two halves of the hyperviscosity
  * step without the DSS calls, for callers that exchange between them (Model::SubStep).  Sub-step 0 leaves the

@@ -33,6 +33,8 @@
 #include "GridPatchCSGLL.h"
 #include "HeldSuarezPhysics.h"
 #include "CubedSphereTrans.h"
+#include "PolynomialInterp.h"
+#include "LinearColumnOperatorFEM.h"
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -439,6 +441,88 @@ try {
 		HeldSuarezPhysics hs(model, timeDeltaT);
 		hs.Perform(time);
 		dumpState(w, pGrid, "hs_after", 0);
+
+	} else if (mode == "interp") {
+		// Grid::ReduceInterpolate (src/atm/Grid.cpp:867-992 -> GridPatchCSGLL::InterpolateData,
+		// GridPatchCSGLL.cpp:1365-1780), the interpolation behind OutputManagerReference (OutputManagerReference.cpp:
+		// 588-628), on instance 0 after the warm-up steps.  Dumped: the sample points exactly as the output manager
+		// derives them (ConvertReferenceToPatchCoord), the per-point quantities a caller obtains from the reference's
+		// own functions (element origin, Lagrange coefficients, RLL transform matrix, vertical operators), and the
+		// outputs for the flag combinations.
+		const int nlon = 12, nlat = 6, npts = nlon * nlat + 2;
+		DataArray1D<double> dLon(npts), dLat(npts), dAlpha(npts), dBeta(npts);
+		DataArray1D<int> iPatch(npts);
+		for (int j = 0; j < nlat; j++) for (int i = 0; i < nlon; i++) {
+			dLon[j * nlon + i] = (i + 0.37) * 2.0 * M_PI / nlon;
+			dLat[j * nlon + i] = -0.5 * M_PI + (j + 0.41) * M_PI / nlat;
+		}
+		dLon[npts - 2] = 0.0; dLat[npts - 2] = 0.0;                     // centre of panel 0: a GLL node when ne is even
+		dLon[npts - 1] = 0.25 * M_PI; dLat[npts - 1] = 0.1;             // on the edge between panels 0 and 1
+		pGrid->ConvertReferenceToPatchCoord(dLon, dLat, dAlpha, dBeta, iPatch);
+		const int nreta = 5;
+		DataArray1D<double> dREta(nreta);
+		const double reta_v[5] = { 0.0, 0.13, 0.5, 0.777, 1.0 };
+		for (int k = 0; k < nreta; k++) dREta[k] = reta_v[k];
+		std::vector<double> va(npts), vb(npts), vreta(nreta), ca(npts * 4), cb(npts * 4), mat(npts * 4);
+		std::vector<int> vp(npts), via(npts), vib(npts);
+		for (int q = 0; q < npts; q++) {
+			va[q] = dAlpha[q]; vb[q] = dBeta[q]; vp[q] = iPatch[q];
+			GridPatch * pPatch = NULL;
+			for (int n = 0; n < pGrid->GetActivePatchCount(); n++)
+				if (pGrid->GetActivePatch(n)->GetPatchIndex() == iPatch[q]) pPatch = pGrid->GetActivePatch(n);
+			const PatchBox & box = pPatch->GetPatchBox();
+			GridPatchGLL * pGLL = dynamic_cast<GridPatchGLL *>(pPatch);
+			int iA = (int)((dAlpha[q] - pPatch->GetAEdge(box.GetAInteriorBegin())) / pGLL->GetElementDeltaA());
+			int iB = (int)((dBeta[q] - pPatch->GetBEdge(box.GetBInteriorBegin())) / pGLL->GetElementDeltaB());
+			if (iA < 0) iA = 0;
+			if (iA >= box.GetAInteriorWidth() / 4) iA = box.GetAInteriorWidth() / 4 - 1;
+			if (iB < 0) iB = 0;
+			if (iB >= box.GetBInteriorWidth() / 4) iB = box.GetBInteriorWidth() / 4 - 1;
+			iA = box.GetHaloElements() + iA * 4; iB = box.GetHaloElements() + iB * 4;
+			via[q] = iA; vib[q] = iB;
+			PolynomialInterp::LagrangianPolynomialCoeffs(4, &(pPatch->GetAEdges()[iA]), &ca[q * 4], dAlpha[q]);
+			PolynomialInterp::LagrangianPolynomialCoeffs(4, &(pPatch->GetBEdges()[iB]), &cb[q * 4], dBeta[q]);
+			// the covariant (alpha, beta) -> (lon, lat) map is linear: probe it with unit vectors, as for the halo transforms
+			CubedSphereTrans::CoVecTransRLLFromABP(tan(dAlpha[q]), tan(dBeta[q]), box.GetPanel(), 1.0, 0.0, mat[q * 4 + 0], mat[q * 4 + 2]);
+			CubedSphereTrans::CoVecTransRLLFromABP(tan(dAlpha[q]), tan(dBeta[q]), box.GetPanel(), 0.0, 1.0, mat[q * 4 + 1], mat[q * 4 + 3]);
+		}
+		for (int k = 0; k < nreta; k++) vreta[k] = dREta[k];
+		w.rec("interp/alpha", 0, std::vector<size_t>(1, npts), &va[0]);
+		w.rec("interp/beta", 0, std::vector<size_t>(1, npts), &vb[0]);
+		w.rec("interp/patch", 1, std::vector<size_t>(1, npts), &vp[0]);
+		w.rec("interp/node_a", 1, std::vector<size_t>(1, npts), &via[0]);
+		w.rec("interp/node_b", 1, std::vector<size_t>(1, npts), &vib[0]);
+		{ std::vector<size_t> d2(2); d2[0] = npts; d2[1] = 4;
+		  w.rec("interp/coeff_a", 0, d2, &ca[0]); w.rec("interp/coeff_b", 0, d2, &cb[0]); w.rec("interp/rll_from_abp", 0, d2, &mat[0]); }
+		w.rec("interp/reta", 0, std::vector<size_t>(1, nreta), &vreta[0]);
+		w.scalar("interp/earth_radius", model.GetPhysicalConstants().GetEarthRadius());
+		for (int src = 0; src < 2; src++) {
+			LinearColumnInterpFEM op;
+			op.Initialize(src ? LinearColumnInterpFEM::InterpSource_Interfaces : LinearColumnInterpFEM::InterpSource_Levels,
+				1, pGrid->GetREtaLevels(), pGrid->GetREtaInterfaces(), dREta);
+			dump2(w, src ? "interp/op_interfaces" : "interp/op_levels", op.GetCoeffs());
+		}
+		dumpState(w, pGrid, "interp_in", 0);
+		const int nc = 5;
+		for (int inc = 0; inc < 2; inc++) for (int prim = 0; prim < 2; prim++) {
+			DataArray3D<double> out(nc, nreta, npts);
+			pGrid->ReduceInterpolate(DataType_State, dREta, dAlpha, dBeta, iPatch, out, DataLocation_None, inc != 0, prim != 0);
+			char nm[64]; snprintf(nm, 64, "interp/state_ref%d_prim%d", inc, prim);
+			std::vector<size_t> d3(3); d3[0] = nc; d3[1] = nreta; d3[2] = npts;
+			w.rec(nm, 0, d3, &out[0][0][0]);
+		}
+		{
+			DataArray3D<double> out(nc, nreta, npts);
+			pGrid->ReduceInterpolate(DataType_State, dREta, dAlpha, dBeta, iPatch, out, DataLocation_Node, true, false);
+			std::vector<size_t> d3(3); d3[0] = nc; d3[1] = nreta; d3[2] = npts;
+			w.rec("interp/state_nodes_only", 0, d3, &out[0][0][0]);
+		}
+		if (ntracers > 0) {
+			DataArray3D<double> out(ntracers, nreta, npts);
+			pGrid->ReduceInterpolate(DataType_Tracers, dREta, dAlpha, dBeta, iPatch, out, DataLocation_None, true);
+			std::vector<size_t> d3(3); d3[0] = ntracers; d3[1] = nreta; d3[2] = npts;
+			w.rec("interp/tracers", 0, d3, &out[0][0][0]);
+		}
 
 	} else if (mode == "steps") {
 		for (int s = 0; s < nsteps; s++) {

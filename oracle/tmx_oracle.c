@@ -1665,3 +1665,86 @@ static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int i
 		}
 	}
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Output interpolation: Grid::ReduceInterpolate -> GridPatchCSGLL::InterpolateData              */
+/* (Grid.cpp:867-992, GridPatchCSGLL.cpp:1365-1780); SURVEY 8(f) item 4                          */
+
+static void interp_column_apply(const double * C, int nout, int nin, const double * in, double * out) {
+	/* LinearColumnOperator::Apply: out[k] = sum over the row's [begin, end) of C[k][l] in[l]; outside it C is zero */
+	for (int k = 0; k < nout; k++) {
+		double a = 0.0;
+		for (int l = 0; l < nin; l++) if (C[(size_t)k * nin + l] != 0.0) a += C[(size_t)k * nin + l] * in[l];
+		out[k] = a;
+	}
+}
+
+static void interpolate_field(const orc_grid * g, const orc_interp * q, int pt, const double * x, const double * xref, int nlev,
+	const double * divide_by, const double * op, double * out_col, double * col)
+{
+	const orc_patch * P = &g->patches[q->patch[pt]];
+	const int nb = P->nb, iA = q->node_a[pt], iB = q->node_b[pt];
+	const double * ca = q->coeff_a + (size_t)pt * NP, * cb = q->coeff_b + (size_t)pt * NP;
+	for (int k = 0; k < nlev; k++) {
+		col[k] = 0.0;
+		for (int m = 0; m < NP; m++)
+		for (int n = 0; n < NP; n++) {
+			const double v = x[((size_t)(iA + m) * nb + (iB + n)) * nlev + k];
+			if (divide_by) col[k] += ca[m] * cb[n] * v / divide_by[(((size_t)iA * nb + iB) * nlev + k) * 3 + 2];
+			else col[k] += ca[m] * cb[n] * v;
+		}
+		if (xref)
+			for (int m = 0; m < NP; m++)
+			for (int n = 0; n < NP; n++)
+				col[k] -= ca[m] * cb[n] * xref[((size_t)(iA + m) * nb + (iB + n)) * nlev + k];
+	}
+	interp_column_apply(op, q->nreta, nlev, col, out_col);
+}
+
+void orc_interpolate_state(const orc_grid * g, const orc_state * s, int ix, const orc_interp * q, int only_at,
+	int include_reference_state, int convert_to_primitive, double earth_radius, double * out)
+{
+	const int L = g->L, npts = q->npts, nreta = q->nreta;
+	double * col = dalloc(L + 2), * oc = dalloc(nreta);
+	memset(out, 0, sizeof(double) * 5 * nreta * npts);
+	for (int pt = 0; pt < npts; pt++) {
+		const int p = q->patch[pt];
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		for (int c = 0; c < 5; c++) {
+			const int edge = (c == WIx);
+			if ((only_at == 1 && edge) || (only_at == 2 && !edge)) continue;
+			const int nlev = edge ? L + 1 : L;
+			const double * x = (edge ? s->redge[ix * g->npatch + p] : s->node[ix * g->npatch + p]) + (size_t)c * na * nb * nlev;
+			const double * xr = include_reference_state ? NULL : ((edge ? P->ref_redge : P->ref_node) + (size_t)c * na * nb * nlev);
+			const double * dv = (c == WIx && convert_to_primitive) ? P->g[ORC_G_DR_E] : NULL;
+			interpolate_field(g, q, pt, x, xr, nlev, dv, edge ? q->op_interfaces : q->op_levels, oc, col);
+			for (int k = 0; k < nreta; k++) out[((size_t)c * nreta + k) * npts + pt] = oc[k];
+		}
+		if (convert_to_primitive)
+			for (int k = 0; k < nreta; k++) {
+				const double ua = out[((size_t)UIx * nreta + k) * npts + pt] / earth_radius;
+				const double ub = out[((size_t)VIx * nreta + k) * npts + pt] / earth_radius;
+				const double * M = q->rll + (size_t)pt * 4;
+				out[((size_t)UIx * nreta + k) * npts + pt] = M[0] * ua + M[1] * ub;
+				out[((size_t)VIx * nreta + k) * npts + pt] = M[2] * ua + M[3] * ub;
+			}
+	}
+	free(col); free(oc);
+}
+
+void orc_interpolate_tracers(const orc_grid * g, const orc_state * s, int ix, const orc_interp * q, double * out) {
+	const int L = g->L, npts = q->npts, nreta = q->nreta;
+	double * col = dalloc(L + 2), * oc = dalloc(nreta);
+	memset(out, 0, sizeof(double) * g->ntracers * nreta * npts);
+	for (int pt = 0; pt < npts; pt++) {
+		const int p = q->patch[pt];
+		const orc_patch * P = &g->patches[p];
+		for (int c = 0; c < g->ntracers; c++) {
+			const double * x = s->tracer[ix * g->npatch + p] + (size_t)c * P->na * P->nb * L;
+			interpolate_field(g, q, pt, x, NULL, L, NULL, q->op_levels, oc, col);
+			for (int k = 0; k < nreta; k++) out[((size_t)c * nreta + k) * npts + pt] = oc[k];
+		}
+	}
+	free(col); free(oc);
+}

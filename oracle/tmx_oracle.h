@@ -101,6 +101,25 @@ typedef struct {
 	double ** tracer;                  /* tracer[inst*npatch + p] = [ntracers][na][nb][L] (GridPatch::GetDataTracers), NULL if none */
 } orc_state;
 
+/* Sample points of Grid::ReduceInterpolate (src/atm/Grid.cpp:867-992), with the per-point quantities the caller
+ * derives from the reference's own functions: element origin node (iA, iB of GridPatchCSGLL.cpp:1588-1611), Lagrange
+ * coefficients (PolynomialInterp::LagrangianPolynomialCoeffs), the 2x2 matrix of CubedSphereTrans::
+ * CoVecTransRLLFromABP, and the dense coefficients of the two LinearColumnInterpFEM operators. */
+typedef struct {
+	int npts, nreta;
+	const int * patch; const int * node_a; const int * node_b;
+	const double * coeff_a; const double * coeff_b;     /* [npts][4] */
+	const double * rll;                                 /* [npts][4] row-major (lon; lat) x (alpha, beta) */
+	const double * op_levels;                           /* [nreta][L]   */
+	const double * op_interfaces;                       /* [nreta][L+1] */
+} orc_interp;
+
+/* GridPatchCSGLL::InterpolateData (GridPatchCSGLL.cpp:1365-1780) summed over patches: out[5][nreta][npts] (State;
+ * only_at: 0 all variables, 1 levels only, 2 interfaces only -- skipped rows stay zero) / out[ntracers][nreta][npts] */
+void orc_interpolate_state(const orc_grid * g, const orc_state * s, int ix, const orc_interp * q, int only_at,
+	int include_reference_state, int convert_to_primitive, double earth_radius, double * out);
+void orc_interpolate_tracers(const orc_grid * g, const orc_state * s, int ix, const orc_interp * q, double * out);
+
 void orc_copy(const orc_grid * g, orc_state * s, int src, int dst);
 void orc_zero(const orc_grid * g, orc_state * s, int ix);
 void orc_linear_combine(const orc_grid * g, orc_state * s, const double * coeff, int ncoeff, int dst);

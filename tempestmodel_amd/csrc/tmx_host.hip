@@ -854,7 +854,10 @@ static inline void xpose_to_host(double * host, size_t var_off, int nlev, const 
 extern "C" int tmx_set_patch_reference_state(tmx_engine * e, int patch, const double * ref_node, const double * ref_redge, const double * ref_tracers) {
 	int r = check_state_args(e, patch, 0);
 	if (r) return r;
-	REQUIRE(e->udiff, TMX_ERR_INVALID, "tmx_set_patch_reference_state: the engine was created without uniform diffusion");
+	if (!e->d_ref) {      // engines without uniform diffusion keep a reference state only if the caller provides one (tmx_interp_state)
+		const size_t rb = (size_t)e->nslab * e->NS * sizeof(double);
+		HIPCHK(hipMalloc((void **)&e->d_ref, rb)); HIPCHK(hipMemset(e->d_ref, 0, rb)); e->hbm_bytes += rb;
+	}
 	REQUIRE(ref_node && ref_redge && (ref_tracers || e->nt == 0), TMX_ERR_INVALID, "tmx_set_patch_reference_state: null array");
 	PatchInfo & P = e->patches[patch];
 	const int L = e->L, na = P.na, nb = P.nb;
@@ -1663,6 +1666,96 @@ extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, i
 	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	return launch_check("v_step_implicit_terms_explicitly");
 }
+// ---------------------------------------------------------------------------------------------
+// output interpolation (Grid::ReduceInterpolate)
+
+struct tmx_interp {
+	tmx_engine * owner = nullptr;
+	int npts = 0, nreta = 0;
+	bool has_rll = false;
+	int * d_col0 = nullptr;
+	double * d_ca = nullptr, * d_cb = nullptr, * d_rll = nullptr, * d_opn = nullptr, * d_ope = nullptr, * d_out = nullptr;
+	size_t out_n = 0;
+};
+
+extern "C" void tmx_interp_destroy(tmx_interp * q) {
+	if (!q) return;
+	if (q->owner && q->owner->stream) hipStreamSynchronize(q->owner->stream);
+	hipFree(q->d_col0); hipFree(q->d_ca); hipFree(q->d_cb); hipFree(q->d_rll); hipFree(q->d_opn); hipFree(q->d_ope); hipFree(q->d_out);
+	delete q;
+}
+
+extern "C" int tmx_interp_create(tmx_engine * e, const tmx_interp_points * pts, tmx_interp ** out) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(pts && out, TMX_ERR_INVALID, "tmx_interp_create: null argument");
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "output interpolation with the shallow-water equation set is not supported");
+	REQUIRE(pts->n_points > 0 && pts->n_reta > 0 && pts->patch && pts->node_a && pts->node_b && pts->coeff_a && pts->coeff_b &&
+		pts->op_levels && pts->op_interfaces, TMX_ERR_INVALID, "tmx_interp_create: incomplete point description");
+	const int n = pts->n_points, L = e->L;
+	std::vector<int> col0(n, -1);
+	for (int i = 0; i < n; i++) {
+		const int pi = pts->patch[i];
+		REQUIRE(pi >= 0 && pi < e->cfg.n_patches, TMX_ERR_INVALID, "interpolation point %d: patch %d out of range", i, pi);
+		const PatchInfo & P = e->patches[pi];
+		if (P.owner != e->cfg.rank) continue;
+		const int a = pts->node_a[i], b = pts->node_b[i];
+		REQUIRE(a >= 1 && b >= 1 && a + TMX_NP <= P.na - 1 && b + TMX_NP <= P.nb - 1 && (a - 1) % TMX_NP == 0 && (b - 1) % TMX_NP == 0,
+			TMX_ERR_INVALID, "interpolation point %d: (%d, %d) is not the first node of an element of patch %d", i, a, b, pi);
+		col0[i] = col_of(P, a, b);
+	}
+	tmx_interp * q = new tmx_interp();
+	q->owner = e; q->npts = n; q->nreta = pts->n_reta; q->has_rll = pts->rll_from_abp != nullptr;
+	auto up = [&](auto ** d, const auto * hsrc, size_t cnt) -> bool {
+		if (hipMalloc((void **)d, cnt * sizeof(**d)) != hipSuccess) return false;
+		return hipMemcpy(*d, hsrc, cnt * sizeof(**d), hipMemcpyHostToDevice) == hipSuccess;
+	};
+	bool ok = up(&q->d_col0, col0.data(), (size_t)n) && up(&q->d_ca, pts->coeff_a, (size_t)n * 4) && up(&q->d_cb, pts->coeff_b, (size_t)n * 4) &&
+		up(&q->d_opn, pts->op_levels, (size_t)pts->n_reta * L) && up(&q->d_ope, pts->op_interfaces, (size_t)pts->n_reta * (L + 1));
+	if (ok && q->has_rll) ok = up(&q->d_rll, pts->rll_from_abp, (size_t)n * 4);
+	q->out_n = (size_t)std::max(5, e->nt) * pts->n_reta * n;
+	if (ok) ok = hipMalloc((void **)&q->d_out, q->out_n * sizeof(double)) == hipSuccess;
+	if (!ok) { (void)hipGetLastError(); tmx_interp_destroy(q); tmx_set_error("tmx_interp_create: device allocation failed"); return TMX_ERR_DEVICE; }
+	*out = q;
+	return TMX_OK;
+}
+
+static InterpArgs interp_args(const tmx_interp * q) {
+	InterpArgs a;
+	a.npts = q->npts; a.nreta = q->nreta; a.col0 = q->d_col0; a.ca = q->d_ca; a.cb = q->d_cb; a.rll = q->d_rll; a.opn = q->d_opn; a.ope = q->d_ope;
+	return a;
+}
+
+extern "C" int tmx_interp_state(tmx_engine * e, tmx_interp * q, int instance, int only_at, int include_ref, int primitive,
+	double earth_radius, double * out) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	REQUIRE(q && q->owner == e && out, TMX_ERR_INVALID, "tmx_interp_state: bad plan / null output");
+	REQUIRE(only_at >= 0 && only_at <= 2, TMX_ERR_INVALID, "tmx_interp_state: only_variables_at must be 0, 1 or 2");
+	REQUIRE(!primitive || q->has_rll, TMX_ERR_INVALID, "tmx_interp_state: convert_to_primitive needs rll_from_abp in the plan");
+	REQUIRE(!primitive || earth_radius > 0.0, TMX_ERR_INVALID, "tmx_interp_state: earth_radius must be positive");
+	const double * xref = nullptr;
+	if (!include_ref) {
+		for (int lp : e->local_patches)
+			REQUIRE(e->patches[lp].ref_set, TMX_ERR_INVALID, "tmx_interp_state without the reference state: tmx_set_patch_reference_state was not called for patch %d", lp);
+		xref = e->d_ref;
+	}
+	tmxk_interp_state(e, make_params(e), interp_args(q), inst(e, instance), xref, only_at, primitive ? 1 : 0, earth_radius, q->d_out);
+	if ((r = launch_check("interp_state"))) return r;
+	HIPCHK(hipMemcpyAsync(out, q->d_out, (size_t)5 * q->nreta * q->npts * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return TMX_OK;
+}
+
+extern "C" int tmx_interp_tracers(tmx_engine * e, tmx_interp * q, int instance, double * out) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	REQUIRE(q && q->owner == e && out, TMX_ERR_INVALID, "tmx_interp_tracers: bad plan / null output");
+	REQUIRE(e->nt > 0, TMX_ERR_INVALID, "Unable to Interpolate with no tracers.");
+	tmxk_interp_tracers(e, make_params(e), interp_args(q), inst(e, instance), q->d_out);
+	if ((r = launch_check("interp_tracers"))) return r;
+	HIPCHK(hipMemcpyAsync(out, q->d_out, (size_t)e->nt * q->nreta * q->npts * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return TMX_OK;
+}
+
 extern "C" int tmx_v_filter_negative_tracers(tmx_engine * e, int instance) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
 	if (e->nt == 0) return TMX_OK;

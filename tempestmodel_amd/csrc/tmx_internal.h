@@ -168,6 +168,16 @@ void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);
 int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
 void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);
+struct InterpArgs {
+	int npts, nreta;
+	const int * col0;          // [npts] device column of the element's first node, -1: not on this rank
+	const double * ca, * cb;   // [npts][4] Lagrange coefficients
+	const double * rll;        // [npts][4] (lon; lat) x (alpha, beta), or nullptr
+	const double * opn, * ope; // [nreta][L], [nreta][L+1] vertical interpolation operators
+};
+void tmxk_interp_state(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, const double * xref,
+	int only_at, int primitive, double earth_radius, double * out);
+void tmxk_interp_tracers(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, double * out);
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout, double dt, double ks, double kv);
 void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double * xin, const double * xref, double * xup, double dt, double cf);

@@ -1359,6 +1359,96 @@ void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Output interpolation: GridPatchCSGLL::InterpolateData (src/atm/GridPatchCSGLL.cpp:1365-1780) for DataType_State /
+// DataType_Tracers.  One thread per (sample point, output level r); per field: the column value at source level l
+// is the 4 x 4 Lagrange sum over the containing element (16 consecutive device columns), minus the same sum over the
+// reference state when it is removed, then LinearColumnInterpFEM::Apply over the source levels with non-zero
+// coefficient.  Same statements in the same order as the reference / the C oracle.
+__device__ __forceinline__ double interp_point(const double * __restrict__ x, const double * __restrict__ xref, size_t NS,
+	int slab0, int nlev, int col0, const double (&ca)[4], const double (&cb)[4], const double * __restrict__ oprow, bool divide, double dv)
+{
+	double acc = 0.0;
+	for (int l = 0; l < nlev; l++) {
+		const double oc = oprow[l];
+		if (oc == 0.0) continue;
+		const size_t so = (size_t)(slab0 + l) * NS + col0;
+		double v = 0.0;
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+#pragma unroll
+			for (int n = 0; n < 4; n++) {
+				if (divide) v += ca[m] * cb[n] * x[so + m * 4 + n] / dv;
+				else v += ca[m] * cb[n] * x[so + m * 4 + n];
+			}
+		if (xref) {
+#pragma unroll
+			for (int m = 0; m < 4; m++)
+#pragma unroll
+				for (int n = 0; n < 4; n++) v -= ca[m] * cb[n] * xref[so + m * 4 + n];
+		}
+		acc += oc * v;
+	}
+	return acc;
+}
+
+__global__ __launch_bounds__(256) void k_interp_state(KParams p, InterpArgs a, const double * __restrict__ x, const double * __restrict__ xref,
+	int only_at, int primitive, double earth_radius, double * __restrict__ out)
+{
+	const int pt = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+	if (pt >= a.npts) return;
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS, plane = (size_t)a.nreta * a.npts, o = (size_t)r * a.npts + pt;
+	const int col0 = a.col0[pt];
+	double res[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+	if (col0 >= 0) {
+		double ca[4], cb[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++) { ca[m] = a.ca[(size_t)pt * 4 + m]; cb[m] = a.cb[(size_t)pt * 4 + m]; }
+		const double * on = a.opn + (size_t)r * L, * oe = a.ope + (size_t)r * (L + 1);
+		if (only_at != 2) {
+			res[0] = interp_point(x, xref, NS, TMX_SLAB_U(L, 0), L, col0, ca, cb, on, false, 1.0);
+			res[1] = interp_point(x, xref, NS, TMX_SLAB_V(L, 0), L, col0, ca, cb, on, false, 1.0);
+			res[2] = interp_point(x, xref, NS, TMX_SLAB_T(L, 0), L, col0, ca, cb, on, false, 1.0);
+			res[4] = interp_point(x, xref, NS, TMX_SLAB_R(L, 0), L, col0, ca, cb, on, false, 1.0);
+		}
+		if (only_at != 1)
+			res[3] = interp_point(x, xref, NS, TMX_SLAB_W(L, 0), L + 1, col0, ca, cb, oe, primitive != 0, p.g2d[G2_DRX * NS + col0]);
+		if (primitive) {
+			const double ua = res[0] / earth_radius, ub = res[1] / earth_radius;
+			const double * M = a.rll + (size_t)pt * 4;
+			res[0] = M[0] * ua + M[1] * ub;
+			res[1] = M[2] * ua + M[3] * ub;
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < 5; c++) out[(size_t)c * plane + o] = res[c];
+}
+
+__global__ __launch_bounds__(256) void k_interp_tracers(KParams p, InterpArgs a, int nt, const double * __restrict__ x, double * __restrict__ out)
+{
+	const int pt = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+	if (pt >= a.npts) return;
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS, plane = (size_t)a.nreta * a.npts, o = (size_t)r * a.npts + pt;
+	const int col0 = a.col0[pt];
+	double ca[4] = { 0, 0, 0, 0 }, cb[4] = { 0, 0, 0, 0 };
+	if (col0 >= 0) {
+#pragma unroll
+		for (int m = 0; m < 4; m++) { ca[m] = a.ca[(size_t)pt * 4 + m]; cb[m] = a.cb[(size_t)pt * 4 + m]; }
+	}
+	for (int c = 0; c < nt; c++)
+		out[(size_t)c * plane + o] = (col0 >= 0) ? interp_point(x, nullptr, NS, TMX_SLAB_Q(L, c, 0), L, col0, ca, cb, a.opn + (size_t)r * L, false, 1.0) : 0.0;
+}
+
+void tmxk_interp_state(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, const double * xref,
+	int only_at, int primitive, double earth_radius, double * out) {
+	hipLaunchKernelGGL(k_interp_state, dim3((a.npts + 255) / 256, a.nreta), dim3(256), 0, e->stream, p, a, x, xref, only_at, primitive, earth_radius, out);
+}
+void tmxk_interp_tracers(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, double * out) {
+	hipLaunchKernelGGL(k_interp_tracers, dim3((a.npts + 255) / 256, a.nreta), dim3(256), 0, e->stream, p, a, e->nt, x, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // stage algebra: X_d <- c_d X_d + sum_m c_m X_m, accumulated in the reference's order
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508)
 

@@ -49,6 +49,11 @@ class TmxConfig(C.Structure):
                 ("uniform_diffusion_scalar", C.c_double), ("uniform_diffusion_vector", C.c_double), ("ztop", C.c_double)]
 
 
+class TmxInterpPoints(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("n_reta", C.c_int), ("patch", PI), ("node_a", PI), ("node_b", PI),
+                ("coeff_a", PD), ("coeff_b", PD), ("rll_from_abp", PD), ("op_levels", PD), ("op_interfaces", PD)]
+
+
 class TmxPatchGeometry(C.Structure):
     _fields_ = [(n, PD) for n in GEOM_FIELDS]
 
@@ -94,6 +99,11 @@ def load_library():
     lib.tmx_set_patch_rayleigh.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD]
     lib.tmx_set_patch_reference_state.argtypes = [C.c_void_p, C.c_int, PD, PD, PD]
     lib.tmx_v_filter_negative_tracers.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_interp_create.argtypes = [C.c_void_p, C.POINTER(TmxInterpPoints), C.POINTER(C.c_void_p)]
+    lib.tmx_interp_destroy.argtypes = [C.c_void_p]
+    lib.tmx_interp_destroy.restype = None
+    lib.tmx_interp_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, PD]
+    lib.tmx_interp_tracers.argtypes = [C.c_void_p, C.c_void_p, C.c_int, PD]
     lib.tmx_h_substep_after_subcycle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
     lib.tmx_h_substep_after_subcycle_count.argtypes = [C.c_void_p]
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
@@ -347,6 +357,52 @@ class Engine:
         out = C.c_int(-1)
         self._chk(self.lib.tmx_h_substep_after_subcycle(self.h, iinit, iupd, iwork, dt, isubstep, C.byref(out)))
         return out.value
+
+    # -- output interpolation (Grid::ReduceInterpolate) ---------------------------------------------
+    def interp_create(self, pts):
+        """pts: dict with patch, node_a, node_b, coeff_a, coeff_b, rll_from_abp, op_levels, op_interfaces (see the header)."""
+        q = TmxInterpPoints()
+        keep = []
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a); return a
+        pa = arr(pts["patch"], np.int32)
+        q.n_points, q.n_reta = len(pa), pts["op_levels"].shape[0]
+        q.patch, q.node_a, q.node_b = _pi(pa), _pi(arr(pts["node_a"], np.int32)), _pi(arr(pts["node_b"], np.int32))
+        q.coeff_a, q.coeff_b = _pd(arr(pts["coeff_a"], np.float64)), _pd(arr(pts["coeff_b"], np.float64))
+        if pts.get("rll_from_abp") is not None:
+            q.rll_from_abp = _pd(arr(pts["rll_from_abp"], np.float64))
+        q.op_levels, q.op_interfaces = _pd(arr(pts["op_levels"], np.float64)), _pd(arr(pts["op_interfaces"], np.float64))
+        h = C.c_void_p()
+        self._chk(self.lib.tmx_interp_create(self.h, C.byref(q), C.byref(h)))
+        return (h, q.n_points, q.n_reta)
+
+    def interp_destroy(self, plan):
+        self.lib.tmx_interp_destroy(plan[0])
+
+    def interp_state(self, plan, instance, only_at=0, include_reference_state=True, convert_to_primitive=True,
+                     earth_radius=6.37122e6):
+        out = np.zeros((5, plan[2], plan[1]))
+        self._chk(self.lib.tmx_interp_state(self.h, plan[0], instance, int(only_at), int(include_reference_state),
+                                            int(convert_to_primitive), float(earth_radius), _pd(out)))
+        return out
+
+    def interp_tracers(self, plan, instance):
+        out = np.zeros((self.ntracers, plan[2], plan[1]))
+        self._chk(self.lib.tmx_interp_tracers(self.h, plan[0], instance, _pd(out)))
+        return out
+
+    def set_reference_state(self):
+        """tmx_set_patch_reference_state from the grid's geometry (also done by the constructor with uniform diffusion)."""
+        for P in self.grid.patches:
+            if self.owner[P.index] != self.rank:
+                continue
+            rf = [np.ascontiguousarray(P.geom[nm], dtype=np.float64) for nm in ("ref_node", "ref_redge")]
+            rt = np.ascontiguousarray(P.geom["ref_tracers"], dtype=np.float64) if self.ntracers and "ref_tracers" in P.geom else None
+            if self.ntracers and rt is None:
+                rt = np.zeros((self.ntracers, P.na, P.nb, self.L))
+            self._chk(self.lib.tmx_set_patch_reference_state(self.h, P.index, _pd(rf[0]), _pd(rf[1]),
+                                                             _pd(rt) if rt is not None else None))
 
     def v_filter_negative_tracers(self, instance):
         self._chk(self.lib.tmx_v_filter_negative_tracers(self.h, instance))

@@ -17,6 +17,8 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   percall_udiff_ne3_L6_p6.npz / steps_udiff_{ars343,strang}_ne3_L6_p6.npz   the supercell configuration without its
                           Fortran physics: planet / 120, no rotation, uniform diffusion 1500 / 500 m^2/s,
                           --explicitvertical, 2 tracers (BASELINE config 4)
+  interp_ne4_L6_p6.npz     Grid::ReduceInterpolate (OutputManagerReference's interpolation, SURVEY 8f-4): sample points,
+                          per-point coefficients, state and outputs for the flag combinations
   physics_hs_ne2_L30_p6.npz   HeldSuarezPhysics::Perform input/output (SURVEY 8f-1)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
   known_answers.json      area-weighted checksums printed by the reference
@@ -143,6 +145,13 @@ def main():
     rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
     rec.update(compact_states(d, 6))
     save("steps_visc2_ne3_L5_p6.npz", rec)
+
+    # output interpolation
+    d, _ = run(["--mode", "interp", "--warm", "2", "--ne", "4", "--levels", "6", "--dt", "200", "--tracers", "2"], tmp)
+    keep_geom = ("deriv_r_redge", "ref_node", "ref_redge")
+    d = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("interp/") or k.startswith("state/interp_in")
+         or k.split("/")[-1] in keep_geom}
+    save("interp_ne4_L6_p6.npz", d)
 
     # column physics.  HeldSuarezPhysics::Perform on the JW state after 2 steps (ne2, L30: the
     # boundary-layer friction only reaches the lowest levels)

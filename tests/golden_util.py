@@ -104,3 +104,17 @@ def prognostic_errors(got, ref, interior=True):
             m = max(m, float(np.max(np.abs(a - b)))); s = max(s, float(np.max(np.abs(b))))
         errs.append(m / s if s > 0 else m)
     return errs
+
+
+def interp_case(d):
+    """Grid, state, tracers and sample-point description of the output-interpolation fixture (interp_ne4_L6_p6.npz)."""
+    g, _ = make_grid(4, 6, 6, ntracers=2)
+    for P in g.patches:
+        for nm in ("deriv_r_redge", "ref_node", "ref_redge"):
+            P.geom[nm] = d["p%d/%s" % (P.index, nm)]
+    pts = {k.split("/")[1]: v for k, v in d.items() if k.startswith("interp/")}
+    return g, full_states(d, "interp_in", 6), full_tracers(d, "interp_in", 6), pts
+
+
+def interp_rel(x, y):
+    return max(float(np.max(np.abs(x[c] - y[c])) / max(np.max(np.abs(y[c])), 1e-300)) for c in range(x.shape[0]))

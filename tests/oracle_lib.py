@@ -44,6 +44,11 @@ class OrcGrid(C.Structure):
                 ("udiff_scalar", C.c_double), ("udiff_vector", C.c_double), ("ztop", C.c_double)]
 
 
+class OrcInterp(C.Structure):
+    _fields_ = [("npts", C.c_int), ("nreta", C.c_int), ("patch", PI), ("node_a", PI), ("node_b", PI),
+                ("coeff_a", PD), ("coeff_b", PD), ("rll", PD), ("op_levels", PD), ("op_interfaces", PD)]
+
+
 class OrcState(C.Structure):
     _fields_ = [("ninst", C.c_int), ("node", C.POINTER(PD)), ("redge", C.POINTER(PD)), ("tracer", C.POINTER(PD))]
 
@@ -235,6 +240,41 @@ class Oracle:
     def step(self, scheme, dt, first=False, last=False):
         return lib().orc_step(C.byref(self.cgrid), C.byref(self.cstate), self.SCHEMES[scheme],
                               int(first), int(last), C.c_double(dt))
+
+    def _interp(self, pts):
+        """pts: dict with patch, node_a, node_b (int), coeff_a, coeff_b, rll_from_abp [n][4], op_levels, op_interfaces."""
+        q = OrcInterp()
+        keep = []
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a); return a
+        pa = arr(pts["patch"], np.int32)
+        q.npts, q.nreta = len(pa), pts["op_levels"].shape[0]
+        q.patch, q.node_a, q.node_b = _pi(pa), _pi(arr(pts["node_a"], np.int32)), _pi(arr(pts["node_b"], np.int32))
+        q.coeff_a, q.coeff_b = _pd(arr(pts["coeff_a"], np.float64)), _pd(arr(pts["coeff_b"], np.float64))
+        q.rll = _pd(arr(pts["rll_from_abp"], np.float64))
+        q.op_levels, q.op_interfaces = _pd(arr(pts["op_levels"], np.float64)), _pd(arr(pts["op_interfaces"], np.float64))
+        return q, keep
+
+    def interpolate_state(self, ix, pts, only_at=0, include_reference_state=True, convert_to_primitive=True,
+                          earth_radius=6.37122e6):
+        """Grid::ReduceInterpolate(DataType_State, ...) -> [5][nreta][npts]."""
+        q, keep = self._interp(pts)
+        if not include_reference_state:
+            for P in self.grid.patches:
+                for fld in ("ref_node", "ref_redge"):
+                    a = np.ascontiguousarray(P.geom[fld], dtype=np.float64)
+                    self._keep.append(a)
+                    setattr(self.cpatches[P.index], fld, _pd(a))
+        out = np.zeros((5, q.nreta, q.npts))
+        lib().orc_interpolate_state(C.byref(self.cgrid), C.byref(self.cstate), ix, C.byref(q), int(only_at),
+                                    int(include_reference_state), int(convert_to_primitive), C.c_double(earth_radius), _pd(out))
+        return out
+
+    def interpolate_tracers(self, ix, pts):
+        q, keep = self._interp(pts)
+        out = np.zeros((self.ntracers, q.nreta, q.npts))
+        lib().orc_interpolate_tracers(C.byref(self.cgrid), C.byref(self.cstate), ix, C.byref(q), _pd(out))
+        return out
 
     def held_suarez(self, ix, dt):
         lib().orc_held_suarez(C.byref(self.cgrid), C.byref(self.cstate), ix, C.c_double(dt))

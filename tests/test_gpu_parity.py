@@ -312,6 +312,35 @@ def test_substep_after_subcycle_equals_step_after_subcycle():
             e.close()
 
 
+def test_output_interpolation():
+    """SURVEY 8(f) item 4: Grid::ReduceInterpolate on the device (tmx_interp_state / tmx_interp_tracers) against the C
+    oracle and the reference's own output, every flag combination."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("interp_ne4_L6_p6.npz")
+    g, st, tr, pts = gu.interp_case(d)
+    a = float(d["interp/earth_radius"][0])
+    o = Oracle(g); o.set_state(0, st); o.set_tracers(0, tr)
+    e = Engine(g)
+    try:
+        e.upload_state(0, st); e.upload_tracers(0, tr)
+        e.set_reference_state()
+        plan = e.interp_create(pts)
+        for inc in (0, 1):
+            for prim in (0, 1):
+                got = e.interp_state(plan, 0, 0, bool(inc), bool(prim), a)
+                assert gu.interp_rel(got, o.interpolate_state(0, pts, 0, bool(inc), bool(prim), a)) < 1e-14, (inc, prim)
+                assert gu.interp_rel(got, d["interp/state_ref%d_prim%d" % (inc, prim)]) < 1e-14, (inc, prim)
+        for only in (1, 2):
+            got = e.interp_state(plan, 0, only, True, False, a)
+            assert gu.interp_rel(got, o.interpolate_state(0, pts, only, True, False, a)) < 1e-14
+        assert gu.interp_rel(e.interp_state(plan, 0, 1, True, False, a), d["interp/state_nodes_only"]) < 1e-14
+        assert gu.interp_rel(e.interp_tracers(plan, 0), d["interp/tracers"]) < 1e-14
+        e.interp_destroy(plan)
+    finally:
+        e.close()
+
+
 def test_graph_replay_is_bit_identical(monkeypatch):
     """TMX_GRAPH=1: ARS343 and Strang steps replayed from a captured hipGraph equal the plain launch sequence bit for bit."""
     from tempestmodel_amd.engine import Engine

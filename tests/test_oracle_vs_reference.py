@@ -194,6 +194,27 @@ def test_tracer_steps_vs_reference():
         assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-10
 
 
+def test_output_interpolation_vs_reference():
+    """SURVEY 8(f) item 4: Grid::ReduceInterpolate (the interpolation behind OutputManagerReference) for the state with
+    every flag combination and for the tracers -- bit for bit, except (U,V) in primitive form where the probed 2x2
+    matrix of CoVecTransRLLFromABP rounds differently (1 ulp)."""
+    d = gu.load("interp_ne4_L6_p6.npz")
+    g, st, tr, pts = gu.interp_case(d)
+    o = Oracle(g)
+    o.set_state(0, st); o.set_tracers(0, tr)
+    a = float(d["interp/earth_radius"][0])
+    for inc in (0, 1):
+        for prim in (0, 1):
+            got = o.interpolate_state(0, pts, 0, bool(inc), bool(prim), a)
+            want = d["interp/state_ref%d_prim%d" % (inc, prim)]
+            assert gu.interp_rel(got, want) < (1e-15 if prim else 1e-300), (inc, prim)
+    got = o.interpolate_state(0, pts, 1, True, False, a)
+    assert gu.interp_rel(got, d["interp/state_nodes_only"]) == 0.0 and np.all(got[3] == 0.0)
+    assert gu.interp_rel(o.interpolate_tracers(0, pts), d["interp/tracers"]) == 0.0
+    # the sample includes a GLL node (panel centre) and a point on a panel edge; every value is finite and non-trivial
+    assert np.isfinite(d["interp/state_ref1_prim1"]).all() and np.abs(d["interp/state_ref1_prim1"][2]).min() > 0.0
+
+
 def test_held_suarez_physics_vs_reference():
     """SURVEY 8(f) item 1: HeldSuarezPhysics::Perform.  Bit for bit on identical inputs (same libm on the CPU)."""
     d = gu.load("physics_hs_ne2_L30_p6.npz")
