@@ -2441,6 +2441,12 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	}
 
 	// ---- consumer: pivoted band elimination on the 5x9 register window ----
+	// Two wavefronts per SIMD: the elimination is the critical role, the assembly has slack (101 k against 146 k cycles
+	// per column), so the consumer takes issue priority wherever it shares a SIMD (same-box A/B at ne30, three alternations
+	// each: 202 -> 185 us per launch on one box, 213 -> 206 us on another; -DTMX_NO_SETPRIO builds without it).
+#ifndef TMX_NO_SETPRIO
+	__builtin_amdgcn_s_setprio(3);
+#endif
 	// The incoming block row stays in the LDS ring until the pivot step that takes it in (stride-64 reads inside
 	// lu_pivot_step) instead of being copied to 30 registers first: the consumer then fits the register budget of
 	// two wavefronts per SIMD, which is what lets the pair kernel run on grids with more pairs than CUs x 2.
