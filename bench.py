@@ -219,7 +219,10 @@ def main():
                                                 / max(op_time[op] / op_launches[op] * 1e-3, 1e-12) / 1e9,
                                                 "traffic": measured_traffic(op, ne, L, world, op_launches[op] / args.steps)}
                                            for op in OP_KERNELS},
-                         "whole_step_algorithmic_GBs": ALG_BYTES_PER_STEP * points * args.steps / wall / 1e9},
+                         "whole_step_algorithmic_GBs": ALG_BYTES_PER_STEP * points * args.steps / wall / 1e9,
+                         "mfma_utilisation": 0.0,      # no MFMA instruction in any kernel: the contractions are 4x4 per element
+                                                       # and level (fp64, ~2 flop/B), every kernel is bandwidth- or issue-bound
+                         },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
         }
