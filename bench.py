@@ -16,6 +16,7 @@ reference's own closed-form initial state, resident in HBM.  Rank 0 prints ONE J
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
@@ -61,6 +62,33 @@ def measured_traffic(op, ne, L, world, launches_per_step):
                 per_step += row["hbm_bytes_per_launch"] * row["launches"] / tab["steps"]
         return per_step / launches_per_step if per_step > 0 and launches_per_step > 0 else None
     except Exception:
+        return None
+
+
+def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
+    """The same real reference under its own MPI decomposition (one patch per rank, 6 ranks = the reference's minimum
+    patch count): reported beside the one-core baseline so that the host comparison does not rest on a single core.
+    None when mpiexec or the binary is missing or the run fails."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "tmx_ref_dump")
+    mpiexec = next((c for c in ("/opt/conda/bin/mpiexec", "mpiexec") if shutil.which(c)), None)
+    if not (os.path.exists(ref_bin) and mpiexec) or (os.cpu_count() or 1) < nranks:
+        return None
+    try:
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        out = subprocess.run([mpiexec, "-np", str(nranks), ref_bin, "--mode", "time", "--ne", str(ne), "--levels", str(L),
+                              "--dt", str(dt), "--steps", str(nsteps_ref), "--warm", "1", "--patches", str(nranks)],
+                             env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True, timeout=600).stdout
+        import re
+        tm = [float(v) for v in re.findall(r"min_s=([0-9.]+)", out)]      # one line per rank (lines of different ranks may interleave)
+        if len(tm) < max(1, nranks - 1):
+            return None
+        t = max(tm)
+        return {"value": 6 * ne * ne * 16 * L * 5 / t, "unit": "element-DOF-updates/s", "cores": nranks, "kind": "reference",
+                "sample": "real reference binary under mpiexec -np %d (one patch per rank), ne%d L%d ARS343 dt=%gs, slowest rank's "
+                          "min of %d steps after 1 warm-up step; %.3f s/step" % (nranks, ne, L, dt, nsteps_ref, t),
+                "sypd": dt / t / 365.0}
+    except Exception as ex:
+        sys.stderr.write("MPI reference baseline failed (%s)\n" % ex)
         return None
 
 
@@ -228,6 +256,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 6, 6)      # ~15 s of CPU work (1 warm-up + 6 timed steps)
+            mpi = cpu_baseline_mpi(ne, L, dt, 6)                     # + the reference's own 6-rank MPI run, ~20 core-seconds
+            if mpi is not None:
+                out["cpu_baseline_mpi"] = mpi
         print(json.dumps(out))
     eng.close()
     if world > 1:
