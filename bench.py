@@ -12,6 +12,7 @@ reference's own closed-form initial state, resident in HBM.  Rank 0 prints ONE J
   roofline    dominant operation: algorithmic bytes / measured device time (HIP events)
   cpu_baseline  the real reference (oracle/_ref, "reference") when its binary travelled with the
               snapshot, else the C oracle ("port"), timed on 1 host core on a bounded sample
+  cpu_baseline_mpi  (extra) the same reference binary under `mpiexec -np 6`, when mpiexec is there
 """
 import argparse
 import json
