@@ -143,7 +143,10 @@ def test_uniform_diffusion_explicit_vertical_steps(scheme):
     """Three whole steps of the supercell configuration (ARS343, and Strang incl. its FilterNegativeTracers after the
     carry-over combination) against the reference."""
     d = gu.load("steps_udiff_%s_ne3_L6_p6.npz" % scheme)
-    g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    g, synth = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    # the host-side synthesiser reproduces the reference's initial state and tracers of this configuration
+    assert max(gu.prognostic_errors(synth, gu.expand_compact(d, "initial", g))) < 1e-13
+    assert max(gu.tracer_errors([g.initial_tracers[p] for p in range(6)], gu.expand_compact_tracers(d, "initial", g))) < 1e-13
     o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF)
     o.set_state(0, gu.expand_compact(d, "initial", g)); o.set_tracers(0, gu.expand_compact_tracers(d, "initial", g))
     for step in (1, 2, 3):
