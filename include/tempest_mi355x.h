@@ -330,9 +330,12 @@ long long tmx_info(tmx_engine * e, int what);
  * what = 2: DSS groups, (n, col0..col3) with col >= NS meaning ghost NS + index
  * what = 3: (NS, ncol, n_unique, n_groups, n_cross_panel_groups)
  * what = 4: per group, index into the cross-panel matrices or -1
+ * what = 5: per group, 2 bits per member: the member's pairing in the reference's averaging order (groups of four,
+ *           members stored as [m0, alpha partner, beta partner, diagonal]: 0 {01|23}, 1 {02|13}, 2 {03|12}; cube
+ *           corners: 0 = (x + next) + previous, 1 = (x + previous) + next)
  * Returns the number of ints written (needed, when out == NULL), -1 on error. */
 int tmx_plan_get(tmx_engine * e, int what, int * out, int cap);
-/* [n_cross][4][8] doubles: per member the 2x2 matrix into the frame of member 0 and the 2x2 back. */
+/* [n_cross][4][4][4] doubles: [member m][partner q] the 2x2 matrix rotating q's (U,V) into the frame of m's patch. */
 int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
 
 /* Test hooks (tests/ only): n engines = ranks 0..n-1 of one grid inside ONE process on one device; the

@@ -13,6 +13,9 @@
 //   --mode steps   : instance-0 state after each of N real TimestepScheme::Step calls
 //                    (+ area-weighted checksums), optionally with geometry.
 //   --mode time    : wall time per step of the real reference (CPU baseline "reference").
+//   --mode kessler : state + tracers before / after one KesslerPhysics::Perform (supercell case)
+//   --case heldsuarez | supercell, --physics hs | kessler : the stock HeldSuarezTest / SupercellTest set-ups with
+//                    their WorkflowProcess performed after every step, as Model::Go does (Model.cpp:470-481).
 //
 // Call sites mirrored (not copied): Model::Go init sequence (src/atm/Model.cpp:316-356),
 // _TempestSetupCubedSphereModel (src/atm/TempestInitialize.h:476-586).
@@ -26,6 +29,16 @@
 #define main tmx_unused_schar_main
 #include "ScharMountainSphereTest.cpp"
 #undef main
+#define main tmx_unused_heldsuarez_main
+#include "HeldSuarezTest.cpp"
+#undef main
+// BASELINE config 4: the DCMIP2016 supercell with its Kessler microphysics.  SupercellTest.cpp and KesslerPhysics.cpp
+// are the reference's own translation units (test/dcmip2016), their Fortran halves (interface/supercell_test.f90,
+// interface/kessler.f90) are compiled by oracle/Makefile with /opt/rocm/bin/amdflang -O3 (= mk/defs.make:35).
+#define main tmx_unused_supercell_main
+#include "SupercellTest.cpp"
+#undef main
+#include "KesslerPhysics.h"
 
 #include "test_inputs.h"
 
@@ -257,7 +270,9 @@ int main(int argc, char ** argv) {
 	std::string mode = "steps", out = "", scheme = "ars343", pert = "exp", tcase = "jw";
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0, hvorder = 4;
 	double dt = 200.0, ztop = 30000.0, planet = 1.0, udiffS = 0.0, udiffV = 0.0;
-	bool fExplicitVertical = false;
+	bool fExplicitVertical = false, fZtopGiven = false;
+	std::string physics = "none";
+	double nuArg = -1.0, moisten = 0.0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		const char * v = (i + 1 < argc) ? argv[i+1] : "";
@@ -276,7 +291,10 @@ int main(int argc, char ** argv) {
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--hypervis") { hvorder = atoi(v); i++; }      // hyperviscosity order 4 (default) or 2
 		else if (a == "--dt") { dt = atof(v); i++; }
-		else if (a == "--ztop") { ztop = atof(v); i++; }
+		else if (a == "--ztop") { ztop = atof(v); fZtopGiven = true; i++; }
+		else if (a == "--nu") { nuArg = atof(v); i++; }               // hyperviscosity coefficient (all three), default per case
+		else if (a == "--moisten") { moisten = atof(v); i++; }        // --mode kessler: second call on a moistened copy
+		else if (a == "--physics") { physics = v; i++; }              // hs | kessler: WorkflowProcess after every step
 		else if (a == "--planet") { planet = atof(v); i++; }          // reduced-planet factor X (with --udiff)
 		else if (a == "--udiff") { udiffS = atof(v); udiffV = atof((i + 2 < argc) ? argv[i+2] : "0"); i += 2; }   // uniform diffusion K_scalar K_vector
 		else if (a == "--explicitvertical") { fExplicitVertical = true; }
@@ -287,14 +305,26 @@ try {
 	AnnounceSetVerbosityLevel(0);
 
 	const bool fSW = (tcase == "sw2");
+	const bool fHS = (tcase == "heldsuarez"), fSC = (tcase == "supercell");
 	if (fSW) { levels = 1; }
+	if (fHS && !fZtopGiven) ztop = 35000.0;             // HeldSuarezTest.cpp:336
+	if (fSC) {
+		if (!fZtopGiven) ztop = 20000.0;                // DCMIP2016 supercell: 40 levels of 500 m
+		ntracers = 3;
+		if (planet == 1.0) planet = 120.0;              // SupercellTest.cpp:249
+		if (!fExplicitVertical) { fprintf(stderr, "supercell needs --explicitvertical (VerticalDynamicsFEM.cpp:3914-3917)\n"); return 2; }
+	}
 	// tracers are declared on the EquationSet before the Model exists (as test/dcmip2016/SupercellTest.cpp:271-281 does)
 	EquationSet eqn(fSW ? EquationSet::ShallowWaterEquations : EquationSet::PrimitiveNonhydrostaticEquations);
+	if (fSC) {
+		eqn.InsertTracer("RhoQv", "RhoQv"); eqn.InsertTracer("RhoQc", "RhoQc"); eqn.InsertTracer("RhoQr", "RhoQr");   // SupercellTest.cpp:271-275
+	} else
 	for (int c = 0; c < ntracers; c++) {
 		char nm[16]; snprintf(nm, 16, "RhoQ%d", c);
 		eqn.InsertTracer(nm, nm);
 	}
 	UserDataMeta metaUserData;
+	if (fSC) metaUserData.InsertDataItem2D("PRECT");    // SupercellTest.cpp:279
 	Model model(eqn, metaUserData);
 
 	int isec = (int)dt;
@@ -315,7 +345,9 @@ try {
 	else { fprintf(stderr, "bad scheme\n"); return 2; }
 
 	// order 2 is plain viscosity: coefficients of a sensible magnitude for it (the 1e15 defaults belong to order 4)
-	const double dNu = (hvorder == 2) ? 2.0e5 : 1.0e15;
+	// supercell: the DCMIP2016 set-up has the uniform diffusion as its only dissipation (--nu* 0 on the reference's
+	// command line; with SupercellTest.cpp:285's reference length / X the 1e15 defaults would be scaled UP by X^3.2)
+	const double dNu = (nuArg >= 0.0) ? nuArg : (fSC ? 0.0 : ((hvorder == 2) ? 2.0e5 : 1.0e15));
 	HorizontalDynamicsFEM * pH = new HorizontalDynamicsFEM(model, 4, hvorder, dNu, dNu, dNu, 0.0);
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
@@ -335,6 +367,11 @@ try {
 		                : BaroclinicWaveJWTest::PerturbationType_None;
 	if (fSW) {
 		model.SetTestCase(new ShallowWaterTestCase2(2998.104995, 38.61068277, 0.0));   // SWTest2.cpp defaults
+	} else if (fHS) {
+		model.SetTestCase(new HeldSuarezTest(30000.0, 25.0, ztop));          // HeldSuarezTest.cpp:336-338 defaults
+	} else if (fSC) {
+		model.GetGrid()->SetReferenceLength(model.GetGrid()->GetReferenceLength() / planet);   // SupercellTest.cpp:285-286
+		model.SetTestCase(new SupercellTest(ztop, planet));
 	} else if (tcase == "schar") {
 		// ScharMountainSphereTest.cpp defaults (:417-441): reduced planet X = 500, no rotation, Rayleigh layer above 20 km
 		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
@@ -366,6 +403,7 @@ try {
 	w.scalar("cfg/udiff_vector", pGrid->GetVectorUniformDiffusionCoeff());
 	w.scalar("cfg/ztop", pGrid->GetZtop());
 	w.scalar("cfg/dt", dt);
+	w.scalar("cfg/nu", dNu);
 	if (geom && w.fp) {
 		dumpGeometry(w, model, pGrid);
 		dumpHaloTransforms(w, pGrid);
@@ -374,6 +412,37 @@ try {
 	Time time = model.GetStartTime();
 	TimestepScheme * pTS = model.GetTimestepScheme();
 
+	// WorkflowProcess of the stock test, performed after every step like Model::Go does (Model.cpp:470-481)
+	WorkflowProcess * pPhysics = NULL;
+	if (physics == "hs") pPhysics = new HeldSuarezPhysics(model, timeDeltaT);
+	else if (physics == "kessler") pPhysics = new KesslerPhysics(model, timeDeltaT);
+	else if (physics != "none") { fprintf(stderr, "bad --physics\n"); return 2; }
+	if (pPhysics) pPhysics->Initialize(time);
+	w.iscalar("cfg/physics", (physics == "hs") ? 1 : ((physics == "kessler") ? 2 : 0));
+	if (physics == "hs") {
+		// inputs of HeldSuarezPhysics::Perform that are not part of the prognostic state (see --mode physics)
+		const PhysicalConstants & phys = model.GetPhysicalConstants();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			const PatchBox & box = pPatch->GetPatchBox();
+			const DataArray4D<double> & dE = pPatch->GetDataState(0, DataLocation_REdge);
+			DataArray2D<double> ps(box.GetATotalWidth(), box.GetBTotalWidth());
+			for (int i = 0; i < box.GetATotalWidth(); i++)
+			for (int j = 0; j < box.GetBTotalWidth(); j++)
+				ps[i][j] = phys.PressureFromRhoTheta(dE[4][i][j][0] * dE[2][i][j][0]);
+			dump2(w, pname(pPatch->GetPatchIndex()) + "hs_surface_pressure", ps);
+			dump2(w, pname(pPatch->GetPatchIndex()) + "hs_latitude", pPatch->GetLatitude());
+		}
+		w.scalar("phys/gamma", phys.GetGamma());
+		w.scalar("phys/kappa", phys.GetKappa());
+	}
+	if (physics == "kessler") {
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			dump3(w, pname(pPatch->GetPatchIndex()) + "kessler_z_levels", pPatch->GetZLevels());
+		}
+	}
+
 	printChecksums(pGrid, "initial", &w);
 	dumpState(w, pGrid, "initial", 0);
 
@@ -381,6 +450,7 @@ try {
 	for (int s = 0; s < nwarm; s++) {
 		pTS->Step(s == 0, false, time, dt);
 		time += timeDeltaT;
+		if (pPhysics) pPhysics->Perform(time);
 	}
 	if (nwarm > 0) {
 		printChecksums(pGrid, "warm", &w);
@@ -441,6 +511,43 @@ try {
 		HeldSuarezPhysics hs(model, timeDeltaT);
 		hs.Perform(time);
 		dumpState(w, pGrid, "hs_after", 0);
+
+	} else if (mode == "kessler") {
+		// SURVEY 8(f) item 1, second half: KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285 ->
+		// interface/kessler.f90) on instance 0; --physics kessler is implied.
+		if (physics != "kessler") { fprintf(stderr, "--mode kessler needs --physics kessler\n"); return 2; }
+		dumpState(w, pGrid, "kessler_before", 0);
+		pPhysics->Perform(time);
+		dumpState(w, pGrid, "kessler_after", 0);
+		if (moisten > 0.0) {
+			// Second call on a test INPUT of our own: the same state with the vapour scaled up and cloud / rain water
+			// added in closed form, so that condensation, autoconversion, accretion, sedimentation (with sub-cycling)
+			// and evaporation all act -- on the coarse grids of the fixtures the stock supercell never forms cloud.
+			for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+				GridPatch * pPatch = pGrid->GetActivePatch(n);
+				const PatchBox & box = pPatch->GetPatchBox();
+				DataArray4D<double> & dT = pPatch->GetDataTracers(0);
+				const DataArray4D<double> & dN = pPatch->GetDataState(0, DataLocation_Node);
+				const DataArray2D<double> & dLon = pPatch->GetLongitude();
+				const DataArray2D<double> & dLat = pPatch->GetLatitude();
+				const DataArray3D<double> & dZ = pPatch->GetZLevels();
+				for (int i = box.GetAInteriorBegin(); i < box.GetAInteriorEnd(); i++)
+				for (int j = box.GetBInteriorBegin(); j < box.GetBInteriorEnd(); j++)
+				for (int k = 0; k < pGrid->GetRElements(); k++) {
+					const double s1 = 0.5 * (1.0 + sin(3.0 * dLon[i][j]) * cos(2.0 * dLat[i][j]));
+					dT[0][i][j][k] *= 1.0 + (moisten - 1.0) * s1;
+					dT[1][i][j][k] = dN[4][i][j][k] * ((dZ[i][j][k] < 9000.0) ? 0.003 * s1 * s1 : 0.0);
+					dT[2][i][j][k] = dN[4][i][j][k] * ((dZ[i][j][k] < 12000.0 && s1 > 0.3) ? 0.006 * (s1 - 0.3) : 0.0);
+				}
+			}
+			dumpState(w, pGrid, "kessler_moist_before", 0);
+			pPhysics->Perform(time);
+			dumpState(w, pGrid, "kessler_moist_after", 0);
+		}
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			dump3(w, pname(pPatch->GetPatchIndex()) + "kessler_prect", pPatch->GetUserData2D());
+		}
 
 	} else if (mode == "interp") {
 		// Grid::ReduceInterpolate (src/atm/Grid.cpp:867-992 -> GridPatchCSGLL::InterpolateData,
@@ -528,6 +635,7 @@ try {
 		for (int s = 0; s < nsteps; s++) {
 			pTS->Step((s == 0) && (nwarm == 0), false, time, dt);
 			time += timeDeltaT;
+			if (pPhysics) pPhysics->Perform(time);
 			if (((s + 1) % every == 0) || (s == nsteps - 1)) {
 				char tag[32]; snprintf(tag, 32, "step%d", s + 1);
 				printChecksums(pGrid, tag, &w);

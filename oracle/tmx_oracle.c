@@ -545,6 +545,17 @@ static void dss_tracers(const orc_grid * g, orc_state * s, int ix) {
 /* banded LU with partial pivoting: LAPACK dgbsv = dgbtrf(unblocked dgbtf2) + dgbtrs            */
 /* (third-party; call site src/base/LinearAlgebra.cpp:156-202 <- VerticalDynamicsFEM.cpp:1457)  */
 
+/* Rounding of the update a - l*u: LAPACK's dgbtf2 / dgbtrs / dtbsv are built from the BLAS calls dger / dtbsv, and
+ * every optimised BLAS on a CPU with FMA units (MKL, OpenBLAS) evaluates them with fused multiply-adds.  Measured
+ * (tests/analysis/lapack_spread.py): the reference linked with MKL and with OpenBLAS's netlib LAPACK agree BIT FOR
+ * BIT after 100 steps, and orc_dgbsv reproduces both bit for bit on the per-call fixtures only when its three
+ * update statements are fused as well.  orc_lu_fma = 1 (default) is therefore the reference's arithmetic on any
+ * FMA-capable host; 0 = separate multiply and subtract (a BLAS without FMA), kept for the sensitivity analysis. */
+static int orc_lu_fma = 1;
+void orc_set_lu_fma(int on) { orc_lu_fma = on; }
+int orc_get_lu_fma(void) { return orc_lu_fma; }
+static inline double lu_upd(double a, double l, double u) { return orc_lu_fma ? fma(-l, u, a) : a - l * u; }
+
 int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double * b) {
 	const int kv = ku + kl;
 #define AB(i,j) ab[(size_t)(j) * ldab + (kv + (i) - (j))]   /* full-matrix (i,j), 0-based */
@@ -568,7 +579,7 @@ int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double *
 				for (int i = 1; i <= km; i++) AB(j + i, j) *= r;
 				for (int c = j + 1; c <= ju; c++) {
 					const double u = AB(j, c);
-					if (u != 0.0) for (int i = 1; i <= km; i++) AB(j + i, c) -= AB(j + i, j) * u;
+					if (u != 0.0) for (int i = 1; i <= km; i++) AB(j + i, c) = lu_upd(AB(j + i, c), AB(j + i, j), u);
 				}
 			}
 		} else if (info == 0) info = j + 1;
@@ -579,7 +590,7 @@ int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double *
 		const int lm = (kl < n - 1 - j) ? kl : n - 1 - j;
 		const int l = ipiv[j];
 		if (l != j) { double tmp = b[l]; b[l] = b[j]; b[j] = tmp; }
-		for (int i = 1; i <= lm; i++) b[j + i] -= b[j] * AB(j + i, j);
+		for (int i = 1; i <= lm; i++) b[j + i] = lu_upd(b[j + i], b[j], AB(j + i, j));
 	}
 	/* backward: U x = y, U has kl+ku super-diagonals (column-oriented, as dtbsv) */
 	for (int j = n - 1; j >= 0; j--) {
@@ -587,7 +598,7 @@ int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double *
 			b[j] /= AB(j, j);
 			const double t = b[j];
 			int lo = j - kv; if (lo < 0) lo = 0;
-			for (int i = j - 1; i >= lo; i--) b[i] -= t * AB(i, j);
+			for (int i = j - 1; i >= lo; i--) b[i] = lu_upd(b[i], t, AB(i, j));
 		}
 	}
 #undef AB
@@ -1338,6 +1349,134 @@ void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt) {
 		}
 #undef NN
 	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Column physics: Kessler warm-rain microphysics of the DCMIP2016 supercell (BASELINE config 4).           */
+/* orc_kessler_column restates SUBROUTINE KESSLER (test/dcmip2016/interface/kessler.f90:64-185) as the       */
+/* reference's build compiles it: the makefiles pass no default-real-8 flag (mk/defs.make:35: F90FLAGS += -O3), */
+/* so the locals r, rhalf, velqr, sed, pc (kessler.f90:93) are SINGLE precision, real literals without a d0   */
+/* exponent (.001, 0.1364, .875, .2046, .525, .5, 1.) are single precision values promoted to double, and the  */
+/* specific intrinsics AMAX1 / AMIN1 convert their arguments to single precision and return single precision  */
+/* (verified on the object amdflang -O3 produces: tests/test_oracle_vs_reference.py::test_kessler_column_*,    */
+/* bit for bit on the committed vectors of tests/golden/kessler_columns.npz).  MAX / DIM are generic: double.  */
+
+static inline double f4(double x) { return (double)(float)x; }
+static inline double amax1_2(double a, double b) { const float x = (float)a, y = (float)b; return (double)((x > y) ? x : y); }
+static inline double amin1_3(double a, double b, double c) {
+	const float x = (float)a, y = (float)b, z = (float)c;
+	const float m = (x < y) ? x : y;
+	return (double)((m < z) ? m : z);
+}
+
+void orc_kessler_column(double * theta, double * qv, double * qc, double * qr, const double * rho, const double * pk,
+	double dt, const double * z, int nz, double * precl_out)
+{
+	float * r = (float *)malloc(sizeof(float) * 5 * nz);
+	float * rhalf = r + nz, * velqr = r + 2 * nz, * sed = r + 3 * nz, * pc = r + 4 * nz;
+	const double f2x = 17.27;
+	const double f5 = 237.3 * f2x * 2500000.0 / 1003.0;
+	const double xk = .2875, psl = 1000.0, rhoqr = 1000.0;
+	const double e1364 = (double)0.1364f, e875 = (double)0.875f, e2046 = (double)0.2046f, e525 = (double)0.525f;
+	const double c001 = (double)0.001f, half = (double)0.5f;
+	const double inv_xk = (double)1.0f / xk;
+	for (int k = 0; k < nz; k++) {                                   /* :107-115 */
+		r[k] = (float)(0.001 * rho[k]);
+		rhalf[k] = (float)sqrt(rho[0] / rho[k]);
+		pc[k] = (float)(3.8 / (pow(pk[k], inv_xk) * psl));
+		velqr[k] = (float)(36.34 * pow(qr[k] * (double)r[k], e1364) * (double)rhalf[k]);
+	}
+	double dt_max = dt;                                              /* :118-123 */
+	for (int k = 0; k < nz - 1; k++)
+		if (velqr[k] != 0.0f) {
+			const double c = 0.8 * (z[k + 1] - z[k]) / (double)velqr[k];
+			dt_max = (dt_max < c) ? dt_max : c;
+		}
+	const int rainsplit = (int)ceil(dt / dt_max);                    /* :126-127 */
+	const double dt0 = dt / (double)rainsplit;
+	double precl = 0.0;
+	for (int nt = 1; nt <= rainsplit; nt++) {
+		precl = precl + rho[0] * qr[0] * (double)velqr[0] / rhoqr;   /* :135 */
+		for (int k = 0; k < nz - 1; k++)                             /* :138-141 */
+			sed[k] = (float)(dt0 * ((double)r[k + 1] * qr[k + 1] * (double)velqr[k + 1] - (double)r[k] * qr[k] * (double)velqr[k])
+				/ ((double)r[k] * (z[k + 1] - z[k])));
+		sed[nz - 1] = (float)(-dt0 * qr[nz - 1] * (double)velqr[nz - 1] / (half * (z[nz - 1] - z[nz - 2])));
+		for (int k = 0; k < nz; k++) {                               /* :144-165 */
+			const double qrprod = qc[k] - (qc[k] - dt0 * amax1_2(c001 * (qc[k] - .001), 0.0)) / (1.0 + dt0 * 2.2 * pow(qr[k], e875));
+			qc[k] = amax1_2(qc[k] - qrprod, 0.0);
+			qr[k] = amax1_2(qr[k] + qrprod + (double)sed[k], 0.0);
+			const double pt = pk[k] * theta[k];
+			const double qvs = (double)pc[k] * exp(f2x * (pt - 273.0) / (pt - 36.0));
+			const double pt36 = pt - 36.0;
+			const double prod = (qv[k] - qvs) / (1.0 + qvs * f5 / (pt36 * pt36));
+			const double rq = (double)r[k] * qr[k];
+			const double dimv = (qvs - qv[k] > 0.0) ? qvs - qv[k] : 0.0;
+			const double ern = amin1_3(dt0 * (((1.6 + 124.9 * pow(rq, e2046)) * pow(rq, e525))
+					/ (2550000.0 * (double)pc[k] / (3.8 * qvs) + 540000.0)) * (dimv / ((double)r[k] * qvs)),
+				amax1_2(-prod - qc[k], 0.0), qr[k]);
+			const double mx = (prod > -qc[k]) ? prod : -qc[k];
+			theta[k] = theta[k] + 2500000.0 / (1003.0 * pk[k]) * (amax1_2(prod, -qc[k]) - ern);
+			qv[k] = amax1_2(qv[k] - mx + ern, 0.0);
+			qc[k] = qc[k] + mx;
+			qr[k] = qr[k] - ern;
+		}
+		if (nt != rainsplit)                                         /* :168-172 */
+			for (int k = 0; k < nz; k++)
+				velqr[k] = (float)(36.34 * pow(qr[k] * (double)r[k], e1364) * (double)rhalf[k]);
+	}
+	*precl_out = precl / (double)rainsplit;
+	free(r);
+}
+
+/* KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285), Lorenz staggering / FORMULATION_RHOTHETA_PI:
+ * rho*theta on levels (:156-158, :265-268).  tracers 0,1,2 = RhoQv, RhoQc, RhoQr.  zlev[p] = GridPatch::GetZLevels()
+ * [na][nb][L]; prect[p] (may be NULL) = UserData2D item 0 [na][nb], accumulated precipitation (:234). */
+void orc_kessler(const orc_grid * g, orc_state * s, int ix, double dt, const double * const * zlev, double * const * prect) {
+	const int L = g->L;
+	const double gamma = g->cp / (g->cp - g->Rd);
+	const double pscal = g->p0 * pow(g->Rd / g->p0, gamma);
+	double * buf = (double *)malloc(sizeof(double) * 8 * L);
+	double * qv = buf, * qc = buf + L, * qr = buf + 2 * L, * rho = buf + 3 * L, * zc = buf + 4 * L, * pk = buf + 5 * L,
+		* th = buf + 6 * L, * thv = buf + 7 * L;
+	for (int p = 0; p < g->npatch; p++) {
+		const orc_patch * P = &g->patches[p];
+		const int na = P->na, nb = P->nb;
+		double * nn = s->node[ix * g->npatch + p];
+		double * tr = s->tracer[ix * g->npatch + p];
+#define NN(c,i,j,k) nn[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+#define TR(c,i,j,k) tr[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+		for (int i = 1; i < na - 1; i++)
+		for (int j = 1; j < nb - 1; j++) {
+			for (int k = 0; k < L; k++) thv[k] = NN(PIx, i, j, k) / NN(RIx, i, j, k);
+			for (int k = 0; k < L; k++) {
+				const double dRho = NN(RIx, i, j, k);
+				const double dRhoD = dRho - TR(0, i, j, k) - TR(1, i, j, k) - TR(2, i, j, k);
+				const double pr = pscal * exp(log(dRho * thv[k]) * gamma);
+				const double tv = pr / (dRho * g->Rd);
+				qv[k] = TR(0, i, j, k) / NN(RIx, i, j, k); if (qv[k] < 0.0) qv[k] = 0.0;
+				qc[k] = TR(1, i, j, k) / NN(RIx, i, j, k); if (qc[k] < 0.0) qc[k] = 0.0;
+				qr[k] = TR(2, i, j, k) / NN(RIx, i, j, k); if (qr[k] < 0.0) qr[k] = 0.0;
+				th[k] = thv[k] / (1.0 + 0.61 * qv[k]);
+				rho[k] = dRhoD;
+				zc[k] = zlev[p][((size_t)i * nb + j) * L + k];
+				pk[k] = tv / thv[k];
+			}
+			double precl = 0.0;
+			orc_kessler_column(th, qv, qc, qr, rho, pk, dt, zc, L, &precl);
+			if (prect && prect[p]) prect[p][(size_t)i * nb + j] += precl * dt;
+			for (int k = 0; k < L; k++) {
+				NN(RIx, i, j, k) = rho[k] / (1.0 - qv[k] - qc[k] - qr[k]);
+				TR(0, i, j, k) = qv[k] * NN(RIx, i, j, k);
+				TR(1, i, j, k) = qc[k] * NN(RIx, i, j, k);
+				TR(2, i, j, k) = qr[k] * NN(RIx, i, j, k);
+			}
+			for (int k = 0; k < L; k++)
+				NN(PIx, i, j, k) = NN(RIx, i, j, k) * th[k] * (1.0 + 0.61 * qv[k]);
+		}
+#undef NN
+#undef TR
+	}
+	free(buf);
 }
 
 /* ------------------------------------------------------------------------------------------ */

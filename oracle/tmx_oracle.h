@@ -137,9 +137,20 @@ int  orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last
 /* HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301) on instance ix */
 void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt);
 
+/* SURVEY 8(f) item 1, second half: the Kessler microphysics of the DCMIP2016 supercell.  orc_kessler_column =
+ * SUBROUTINE KESSLER (test/dcmip2016/interface/kessler.f90:64-185, mixed single/double arithmetic as compiled),
+ * orc_kessler = KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285) on instance ix with tracers
+ * RhoQv, RhoQc, RhoQr; zlev[p] = [na][nb][L] level heights, prect[p] = [na][nb] accumulated precipitation or NULL. */
+void orc_kessler_column(double * theta, double * qv, double * qc, double * qr, const double * rho, const double * pk,
+	double dt, const double * z, int nz, double * precl_out);
+void orc_kessler(const orc_grid * g, orc_state * s, int ix, double dt, const double * const * zlev, double * const * prect);
+
 /* banded LU with partial pivoting, LAPACK dgbsv semantics (1 rhs); ab is [n][ldab] column-major band
  * storage with ldab = 2*kl+ku+1, entry (i,j) at ab[j*ldab + kl+ku+i-j].  Returns info. */
 int orc_dgbsv(int n, int kl, int ku, double * ab, int ldab, int * ipiv, double * b);
+/* 1 (default): the three update statements of the band LU are fused multiply-adds, as in MKL / OpenBLAS; 0: mul + sub */
+void orc_set_lu_fma(int on);
+int orc_get_lu_fma(void);
 
 /* single-column implicit pieces, exposed for unit tests: builds F and the band Jacobian of one column */
 void orc_column_f_jacobian(const orc_grid * g, const orc_patch * p, const double * node, const double * redge,

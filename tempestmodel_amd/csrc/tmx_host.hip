@@ -182,7 +182,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_xmat);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -510,7 +510,7 @@ template <class T> static int dev_upload(T ** d, const std::vector<T> & h, size_
 
 // plan data kept on the host for introspection (tests of the N>1 logic)
 struct PlanHost {
-	std::vector<int> grp_cols, grp_n, grp_x;
+	std::vector<int> grp_cols, grp_n, grp_x, grp_type;
 	std::vector<double> xmat;
 	std::vector<int> send_nodes;   // triples (patch,i,j) in send order
 	std::vector<int> recv_nodes;   // triples (patch,i,j) in ghost order
@@ -568,17 +568,6 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		const int loc = id - (int)poff[p];
 		return NodeRef{ p, loc / e->patches[p].nb, loc % e->patches[p].nb };
 	};
-	// panel transform lookup: (dst patch node adjacent to a ring entry whose source panel is sp) -> matrix
-	auto find_trans = [&](const NodeRef & dst, int src_panel, double * M) -> bool {
-		const PatchInfo & P = e->patches[dst.patch];
-		for (size_t m = 0; m < P.hi.size(); m++) {
-			if (P.hsp[m] < 0 || P.hspanel[m] != src_panel) continue;
-			const int xi = std::min(std::max(P.hi[m], 1), P.na - 2), xj = std::min(std::max(P.hj[m], 1), P.nb - 2);
-			if (xi == dst.i && xj == dst.j) { memcpy(M, &P.htrans[4 * m], 4 * sizeof(double)); return true; }
-		}
-		return false;
-	};
-
 	// ---- exchange lists: (owner s -> needer r) node ids
 	std::vector<std::vector<int>> send_to(NR), recv_from(NR);
 	struct Grp { std::vector<int> ids; };
@@ -646,43 +635,106 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	e->nghost = e->recv_rank_off[NR];
 	e->nghost_pad = std::max(e->nghost, 1);
 
-	// ---- device group tables
+	// ---- device group tables, in the reference's own averaging order
+	// GridCSGLL::ApplyDSS (GridCSGLL.cpp:560-781) averages inside every patch (halo ring included) first across the
+	// alpha seams, then across the beta seams: a node shared by four copies becomes
+	//     0.5 * (0.5 * (x + x_alpha) + 0.5 * (x_beta + x_diag)),
+	// with the partners named in the frame of the node's OWN patch, halo values first rotated into that frame
+	// (TransformHaloVelocities, GridPatchCSGLL.cpp:1783-1924).  The sums commute but do not associate, so the copies
+	// of a node on patches whose alpha axes are not parallel (panel edges towards panels 4 / 5) receive results that
+	// differ in the last bit -- in the reference, and therefore here.  Per group the members are stored as
+	// [m0, alpha partner, beta partner, diagonal] of member m0, and every member gets a 2-bit pairing type relative to
+	// that order (0: {01|23}, 1: {02|13}, 2: {03|12}); cube corners (three copies, (1/3) * ((x + x_alpha) + x_beta),
+	// :735-781) get the order of their two partners (0: next, previous; 1: previous, next).  The covector matrices are
+	// kept per (member, partner): exactly the matrix of the ring entry through which the member's patch sees the partner.
+	std::vector<std::vector<int>> ring(np);
+	for (int p = 0; p < np; p++) {
+		const PatchInfo & P = e->patches[p];
+		ring[p].assign((size_t)P.na * P.nb, -1);
+		for (size_t h = 0; h < P.hi.size(); h++) ring[p][(size_t)P.hi[h] * P.nb + P.hj[h]] = (int)h;
+	}
+	// node id seen by patch p at extended (ring included) position (i, j); h = ring entry or -1
+	auto ext = [&](int p, int i, int j, int & h) -> int {
+		const PatchInfo & P = e->patches[p];
+		h = -1;
+		if (i >= 1 && i < P.na - 1 && j >= 1 && j < P.nb - 1) return nid(p, i, j);
+		h = ring[p][(size_t)i * P.nb + j];
+		if (h < 0 || P.hsp[h] < 0) { h = -1; return -1; }
+		return nid(P.hsp[h], P.hsi[h], P.hsj[h]);
+	};
+	auto seam = [&](int c) -> int { const int q = (c - 1) % TMX_NP; return (q == 0) ? c - 1 : ((q == TMX_NP - 1) ? c + 1 : -1); };
+	struct Roles { int id[3]; int h[3]; };      // alpha partner, beta partner, diagonal: node id (-1 none) and ring entry
+	auto roles_of = [&](int id) -> Roles {
+		const NodeRef nr = node_of(id);
+		Roles r;
+		const int ia = seam(nr.i), jb = seam(nr.j);
+		r.id[0] = (ia >= 0) ? ext(nr.patch, ia, nr.j, r.h[0]) : (r.h[0] = -1, -1);
+		r.id[1] = (jb >= 0) ? ext(nr.patch, nr.i, jb, r.h[1]) : (r.h[1] = -1, -1);
+		r.id[2] = (ia >= 0 && jb >= 0) ? ext(nr.patch, ia, jb, r.h[2]) : (r.h[2] = -1, -1);
+		return r;
+	};
 	e->ngroups = (int)groups.size();
 	plan.grp_cols.assign((size_t)e->ngroups * 4, -1);
 	plan.grp_n.assign(e->ngroups, 0);
 	plan.grp_x.assign(e->ngroups, -1);
+	plan.grp_type.assign(e->ngroups, 0);
 	for (int g = 0; g < e->ngroups; g++) {
-		const std::vector<int> & ids = groups[g].ids;
-		plan.grp_n[g] = (int)ids.size();
+		std::vector<int> ids = groups[g].ids;
+		const int n = (int)ids.size();
+		// order: [m0, alpha partner, beta partner, diagonal] of the first member
+		{
+			const Roles r0 = roles_of(ids[0]);
+			std::vector<int> ord(1, ids[0]);
+			if (n == 4) { ord.push_back(r0.id[0]); ord.push_back(r0.id[1]); ord.push_back(r0.id[2]); }
+			else if (n == 3) { ord.push_back(r0.id[0]); ord.push_back(r0.id[1]); }
+			else ord.push_back((r0.id[0] >= 0) ? r0.id[0] : r0.id[1]);
+			std::vector<int> chk = ord; std::sort(chk.begin(), chk.end());
+			REQUIRE(chk == ids, TMX_ERR_INVALID, "DSS group %d: the seam / halo partners of a node are not the group's members", g);
+			ids = ord;
+		}
+		plan.grp_n[g] = n;
+		auto pos = [&](int id) { for (int t = 0; t < n; t++) if (ids[t] == id) return t; return -1; };
+		double M[64];
+		for (int t = 0; t < 16; t++) { M[4 * t] = 1; M[4 * t + 1] = 0; M[4 * t + 2] = 0; M[4 * t + 3] = 1; }
 		bool cross = false;
-		for (size_t m = 0; m < ids.size(); m++) {
-			NodeRef nr = node_of(ids[m]);
+		int type = 0;
+		for (int m = 0; m < n; m++) {
+			const NodeRef nr = node_of(ids[m]);
 			const PatchInfo & P = e->patches[nr.patch];
 			plan.grp_cols[(size_t)g * 4 + m] = (P.owner == me) ? col_of(P, nr.i, nr.j) : e->NS + ghost_index[ids[m]];
-			if (P.panel != e->patches[node_of(ids[0]).patch].panel) cross = true;
-		}
-		if (cross) {
-			plan.grp_x[g] = (int)(plan.xmat.size() / 32);
-			const NodeRef f = node_of(ids[0]);
-			const int fpanel = e->patches[f.patch].panel;
-			double M[32];
-			for (int m = 0; m < 4; m++) { double * A = M + m * 8; A[0] = 1; A[1] = 0; A[2] = 0; A[3] = 1; A[4] = 1; A[5] = 0; A[6] = 0; A[7] = 1; }
-			for (size_t m = 0; m < ids.size(); m++) {
-				NodeRef nr = node_of(ids[m]);
-				const int mp = e->patches[nr.patch].panel;
-				if (mp == fpanel) continue;
-				// A: member panel -> frame panel (looked up at a frame-panel member); B: frame -> member panel
-				bool okA = false, okB = find_trans(nr, fpanel, M + m * 8 + 4);
-				for (size_t t = 0; t < ids.size() && !okA; t++) {
-					NodeRef nt = node_of(ids[t]);
-					if (e->patches[nt.patch].panel == fpanel) okA = find_trans(nt, mp, M + m * 8);
-				}
-				REQUIRE(okA && okB, TMX_ERR_INVALID, "missing covector transform between panels %d and %d", mp, fpanel);
+			const Roles r = roles_of(ids[m]);
+			int ty = 0;
+			if (n == 4) {
+				const int pa = pos(r.id[0]), pb = pos(r.id[1]), pd = pos(r.id[2]);
+				REQUIRE(pa >= 0 && pb >= 0 && pd >= 0 && pa != pb && pa != pd && pb != pd && pa != m && pb != m && pd != m,
+					TMX_ERR_INVALID, "DSS group %d: inconsistent partners of member %d", g, m);
+				const int lo = std::min(m, pa), hi = std::max(m, pa);
+				ty = ((lo == 0 && hi == 1) || (lo == 2 && hi == 3)) ? 0 : (((lo == 0 && hi == 2) || (lo == 1 && hi == 3)) ? 1 : 2);
+			} else if (n == 3) {
+				const int pa = pos(r.id[0]), pb = pos(r.id[1]);
+				REQUIRE(pa >= 0 && pb >= 0 && pa != pb && pa != m && pb != m && r.id[2] < 0, TMX_ERR_INVALID, "DSS group %d: inconsistent cube-corner partners", g);
+				ty = (pa == (m + 1) % 3) ? 0 : 1;
+			} else {
+				const int pp = pos((r.id[0] >= 0) ? r.id[0] : r.id[1]);
+				REQUIRE(pp == 1 - m && (r.id[0] < 0 || r.id[1] < 0), TMX_ERR_INVALID, "DSS group %d: inconsistent edge partners", g);
 			}
-			plan.xmat.insert(plan.xmat.end(), M, M + 32);
+			type |= ty << (2 * m);
+			// covector matrices: partner seen through a ring entry whose source lies on another panel
+			for (int t = 0; t < 3; t++) {
+				if (r.id[t] < 0 || r.h[t] < 0) continue;
+				if (P.hspanel[r.h[t]] == P.panel) continue;
+				REQUIRE(!P.htrans.empty(), TMX_ERR_INVALID, "covector transforms of patch %d not set", nr.patch);
+				memcpy(M + (m * 4 + pos(r.id[t])) * 4, &P.htrans[4 * (size_t)r.h[t]], 4 * sizeof(double));
+				cross = true;
+			}
+		}
+		plan.grp_type[g] = type;
+		if (cross) {
+			plan.grp_x[g] = (int)(plan.xmat.size() / 64);
+			plan.xmat.insert(plan.xmat.end(), M, M + 64);
 		}
 	}
-	e->nxgroups = (int)(plan.xmat.size() / 32);
+	e->nxgroups = (int)(plan.xmat.size() / 64);
 
 	// ---- unique columns of the implicit solve and their in-patch duplicates (VerticalDynamicsFEM.cpp:1315-1337, 1543-1633)
 	for (int p : e->local_patches) {
@@ -749,6 +801,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	if ((r = dev_upload(&e->d_grp_cols, plan.grp_cols, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_n, plan.grp_n, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
+	if ((r = dev_upload(&e->d_grp_type, plan.grp_type, &bytes))) return r;
 	if ((r = dev_upload(&e->d_xmat, plan.xmat, &bytes))) return r;
 	if ((r = dev_upload(&e->d_send_cols, plan.send_cols, &bytes))) return r;
 	{
@@ -1968,12 +2021,15 @@ extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 		v.push_back(e->NS); v.push_back(e->ncol); v.push_back(e->nunique); v.push_back(e->ngroups); v.push_back(e->nxgroups);
 	} else if (what == 4) {
 		v = plan.grp_x;
+	} else if (what == 5) {
+		v = plan.grp_type;
 	} else return -1;
 	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
 	return (int)v.size();
 }
 
-// cross-panel covector matrices of the DSS groups: [n_cross][4 members][A(2x2) to frame, B(2x2) from frame]
+// cross-panel covector matrices of the DSS groups: [n_cross][member m][partner q][2x2], the matrix that rotates q's
+// (U,V) into the frame of m's patch (identity where q == m or both lie on one panel)
 extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 	if (!e || !e->finalized) return -1;
 	PlanHost & plan = g_plans[e];

@@ -107,6 +107,7 @@ struct tmx_engine {
 	int * d_grp_cols = nullptr;              // [ngroups][4] column index (>= NS: ghost NS+idx), -1 = none
 	int * d_grp_n = nullptr;                 // [ngroups] member count (2..4); high bit 8 = cross-panel, index in bits 16+
 	int * d_grp_x = nullptr;                 // [ngroups] index into the cross-panel matrices or -1
+	int * d_grp_type = nullptr;              // [ngroups] 2 bits per member: pairing type in the reference's averaging order
 	double * d_xmat = nullptr;               // [nxgroups][4][2][4]: per member A (to frame) and B (from frame)
 	double * d_ghost = nullptr;              // [nslab][nghost_pad] received remote copies
 	double * d_sendbuf = nullptr;

@@ -13,8 +13,17 @@
 //
 // Reference behaviour restated (file:line under the reference tree) is cited per kernel.
 #include "tmx_internal.h"
+#include "tmx_refmath.h"
 
 #define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads)
+
+// Update statement a - l*u of the band LU (dgbtf2's rank-1 update, dgbtrs' forward sweep, dtbsv's column sweep).
+// LAPACK builds them from dger / dtbsv, and the optimised BLAS libraries the reference links (MKL, OpenBLAS) evaluate
+// those with fused multiply-adds: the reference linked against either agrees BIT FOR BIT, and the C oracle reproduces
+// its implicit step bit for bit only with the update fused (tests/golden/lapack_spread.json,
+// test_percall_chain).  So the fused form IS the reference's arithmetic; everything else in this file stays unfused
+// (-ffp-contract=off), as the reference's own C++ is compiled without FMA contraction.
+#define LU_UPD(a, l, u) __builtin_fma(-(l), (u), (a))
 
 #define OPC(op, k, off) p.ops[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
 
@@ -133,7 +142,7 @@ __device__ __forceinline__ void metric_edge(const KParams & p, const MetCol & m,
 
 __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double rt) {
 	// PhysicalConstants::ExnerPressureFromRhoTheta (src/atm/PhysicalConstants.h:397-399)
-	return p.cp * exp(p.Rd / (p.cp - p.Rd) * log(p.Rd / p.p0 * rt));
+	return p.cp * tmx_ref_exp(p.Rd / (p.cp - p.Rd) * tmx_ref_log(p.Rd / p.p0 * rt));      // glibc's exp / log, bit for bit (tmx_refmath.h)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,19 +449,38 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 }
 
 // ---------------------------------------------------------------------------------------------
-// DSS: average co-located copies (GridCSGLL::ApplyDSS, src/atm/GridCSGLL.cpp:435-781) expressed
-// per group of co-located nodes instead of per patch edge: 2 copies -> 1/2 sum, 4 -> pairwise
-// halves, 3 (cube corner) -> 1/3 sum.  (U,V) of copies on other panels are rotated with the
-// covector panel transform first (GridPatchCSGLL.cpp:1783-1924).  Copies owned by other ranks are
-// read from the ghost buffer filled by the exchange.
+// DSS: average co-located copies (GridCSGLL::ApplyDSS, src/atm/GridCSGLL.cpp:435-781) expressed per group of
+// co-located nodes instead of per patch edge, in the reference's own order of operations so that the result is the
+// reference's bit for bit: two copies 0.5 * (x + y); four copies 0.5 * (0.5 * (x + x_alpha) + 0.5 * (x_beta + x_diag))
+// with the partners named in the frame of the member's own patch (alpha seams are averaged before beta seams); cube
+// corners (1/3) * ((x + x_alpha) + x_beta).  The host stores the members as [m0, alpha, beta, diagonal] of m0 and a
+// 2-bit pairing type per member (tmx_host.hip, "device group tables"); within one panel every member has type 0 and
+// all copies receive the same bits, on panel edges with rotated axes the copies differ in the last bit exactly as
+// they do in the reference.  (U,V) of copies on other panels are rotated into the member's frame with the covector
+// panel transform of the ring entry through which its patch sees them (GridPatchCSGLL.cpp:1783-1924).  Copies owned
+// by other ranks are read from the ghost buffer filled by the exchange.
 
 // Every load of the group (5 slabs x up to 4 copies) is issued before the first use, so a wave keeps up to
 // 20 gathers in flight (measured 90 -> 74 us per call at ne30 L30 against loading slab by slab), and the tiles
 // of one XCD run level-major, so that the partially used 128-byte element rows of a 4-level tile are completed
 // by the neighbouring group tiles while they still sit in that XCD's L2 (74 -> 68 us).
+template <int M>
+__device__ __forceinline__ double dss_combine(const double (&w)[4], int n, int gt) {
+	const int ty = (gt >> (2 * M)) & 3;
+	if (n == 2) return 0.5 * (w[0] + w[1]);
+	if (n == 4) {
+		const double p0 = (ty == 0) ? w[0] + w[1] : ((ty == 1) ? w[0] + w[2] : w[0] + w[3]);
+		const double p1 = (ty == 0) ? w[2] + w[3] : ((ty == 1) ? w[1] + w[3] : w[1] + w[2]);
+		return 0.5 * (0.5 * p0 + 0.5 * p1);
+	}
+	constexpr int NX = (M + 1) % 3, PV = (M + 2) % 3;
+	const double first = ty ? w[PV] : w[NX], second = ty ? w[NX] : w[PV];
+	return (1.0 / 3.0) * ((w[M < 3 ? M : 0] + first) + second);
+}
+
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
-	const int * __restrict__ gn, const int * __restrict__ gx, const double * __restrict__ xmat, int nt, int g0)
+	const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int nt, int g0)
 {
 	// groups [g0, ngroups) of the engine's list
 	const int L = p.L;
@@ -466,6 +494,7 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	const int4 c4 = *(const int4 *)(gcols + g * 4);
 	const int c[4] = { c4.x, c4.y, c4.z, c4.w };
 	const int xi = gx[g];
+	const int gt = gtype[g];
 	const double * ptr[4]; size_t str[4]; bool loc[4];
 #pragma unroll
 	for (int m = 0; m < 4; m++) {
@@ -485,38 +514,29 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	for (int t = 0; t < 5; t++)
 #pragma unroll
 		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
-	auto avg = [&](const double * w) -> double {
-		if (n == 2) return 0.5 * (w[0] + w[1]);
-		if (n == 4) return 0.5 * (0.5 * (w[0] + w[1]) + 0.5 * (w[2] + w[3]));
-		return (1.0 / 3.0) * (w[0] + w[1] + w[2]);
+	// gt == 0 with two or four copies: every member has the same pairing, one value for all of them
+	const bool same = (gt == 0) && (n != 3);
+	auto scalar = [&](const double (&w)[4], double (&o)[4]) {
+		if (same) { const double a = dss_combine<0>(w, n, 0); o[0] = a; o[1] = a; o[2] = a; o[3] = a; }
+		else { o[0] = dss_combine<0>(w, n, gt); o[1] = dss_combine<1>(w, n, gt); o[2] = dss_combine<2>(w, n, gt); o[3] = dss_combine<3>(w, n, gt); }
 	};
 	double out[5][4];
 #pragma unroll
-	for (int t = 0; t < 3; t++) {
-		const double a = avg(v[t]);
-#pragma unroll
-		for (int m = 0; m < 4; m++) out[t][m] = a;
-	}
+	for (int t = 0; t < 3; t++) scalar(v[t], out[t]);
 	if (xi < 0) {
-		const double a3 = avg(v[3]), a4 = avg(v[4]);
-#pragma unroll
-		for (int m = 0; m < 4; m++) { out[3][m] = a3; out[4][m] = a4; }
+		scalar(v[3], out[3]); scalar(v[4], out[4]);
 	} else {
-		const double * M = xmat + (size_t)xi * 32;
-		double va[4] = { 0, 0, 0, 0 }, vb[4] = { 0, 0, 0, 0 };
-#pragma unroll
-		for (int m = 0; m < 4; m++) if (m < n) {
-			const double * A = M + m * 8;
-			va[m] = A[0] * v[3][m] + A[1] * v[4][m];
-			vb[m] = A[2] * v[3][m] + A[3] * v[4][m];
-		}
-		const double aa = avg(va), ab = avg(vb);
-#pragma unroll
-		for (int m = 0; m < 4; m++) if (m < n) {
-			const double * B = M + m * 8 + 4;
-			out[3][m] = B[0] * aa + B[1] * ab;
-			out[4][m] = B[2] * aa + B[3] * ab;
-		}
+		const double * Mx = xmat + (size_t)xi * 64;
+#define DSS_VEC(M_) do { \
+			double wa[4] = { 0, 0, 0, 0 }, wb[4] = { 0, 0, 0, 0 }; \
+			_Pragma("unroll") for (int q = 0; q < 4; q++) if (q < n) { \
+				const double * T = Mx + (M_ * 4 + q) * 4; \
+				if (q == M_) { wa[q] = v[3][q]; wb[q] = v[4][q]; } \
+				else { wa[q] = T[0] * v[3][q] + T[1] * v[4][q]; wb[q] = T[2] * v[3][q] + T[3] * v[4][q]; } \
+			} \
+			out[3][M_] = dss_combine<M_>(wa, n, gt); out[4][M_] = dss_combine<M_>(wb, n, gt); } while (0)
+		DSS_VEC(0); DSS_VEC(1); DSS_VEC(2); DSS_VEC(3);
+#undef DSS_VEC
 	}
 #pragma unroll
 	for (int t = 0; t < 5; t++)
@@ -527,12 +547,12 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	if (lev) {
 		for (int q = 0; q < nt; q++) {
 			const size_t sl = (size_t)TMX_SLAB_Q(L, q, kk);
-			double w[4];
+			double w[4], o[4];
 #pragma unroll
 			for (int m = 0; m < 4; m++) w[m] = (m < n) ? ptr[m][sl * str[m]] : 0.0;
-			const double a = avg(w);
+			scalar(w, o);
 #pragma unroll
-			for (int m = 0; m < 4; m++) if (loc[m]) x[sl * NS + c[m]] = a;
+			for (int m = 0; m < 4; m++) if (loc[m]) x[sl * NS + c[m]] = o[m];
 		}
 	}
 }
@@ -543,7 +563,7 @@ void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1) {
 	dim3 blk(64, 4), grd(8 * ((nx + 7) / 8) * ny);
 	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, (const int *)e->d_ghost_base,
 		(const int *)e->d_ghost_stride, g1,
-		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const double *)e->d_xmat, e->nt, g0);
+		(const int *)e->d_grp_cols, (const int *)e->d_grp_n, (const int *)e->d_grp_x, (const int *)e->d_grp_type, (const double *)e->d_xmat, e->nt, g0);
 }
 
 // HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
@@ -959,13 +979,13 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 					ABW(jj + 1, jj) *= r;
 					for (int cc = jj + 1; cc <= ju; cc++) {
 						const double uu = ABW(jj, cc);
-						if (uu != 0.0) ABW(jj + 1, cc) -= ABW(jj + 1, jj) * uu;
+						if (uu != 0.0) ABW(jj + 1, cc) = LU_UPD(ABW(jj + 1, cc), ABW(jj + 1, jj), uu);
 					}
 				}
 				// forward substitution of this column (dgbtrs): interchange, then eliminate
 				if (jj < L - 1) {
 					if (jp) { const double tmp = F[(size_t)(jj + 1) * 64 + lane]; F[(size_t)(jj + 1) * 64 + lane] = F[(size_t)jj * 64 + lane]; F[(size_t)jj * 64 + lane] = tmp; }
-					F[(size_t)(jj + 1) * 64 + lane] -= F[(size_t)jj * 64 + lane] * ABW(jj + 1, jj);
+					F[(size_t)(jj + 1) * 64 + lane] = LU_UPD(F[(size_t)(jj + 1) * 64 + lane], F[(size_t)jj * 64 + lane], ABW(jj + 1, jj));
 				}
 			} else singular = true;
 		}
@@ -975,7 +995,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 				bj /= ABW(jj, jj);
 				F[(size_t)jj * 64 + lane] = bj;
 				const int lo = (jj - 2 < 0) ? 0 : jj - 2;
-				for (int ii = jj - 1; ii >= lo; ii--) F[(size_t)ii * 64 + lane] -= bj * ABW(ii, jj);
+				for (int ii = jj - 1; ii >= lo; ii--) F[(size_t)ii * 64 + lane] = LU_UPD(F[(size_t)ii * 64 + lane], bj, ABW(ii, jj));
 			}
 		}
 		for (int k = 0; k < L; k++) {
@@ -1056,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	const double ps = ldu(p.g2d + G2_PS * NS, cb), lat = ldu(p.g2d + G2_LAT * NS, cb);
 	const double rho = ldu(x + TMX_SLAB_R(L, k) * NS, cb), rt = ldu(x + TMX_SLAB_T(L, k) * NS, cb);
 	{
-		const double pr = pscal * exp(log(rho * rt) * gamma);
+		const double pr = pscal * tmx_ref_exp(tmx_ref_log(rho * rt) * gamma);
 		const double sigma = pr / ps;
 		double bs = (sigma - bsig) / (1.0 - bsig);
 		if (bs < 0.0) bs = 0.0;
@@ -1064,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 		stu(x + TMX_SLAB_U(L, k) * NS, cb, u / (1.0 + kf * bs * dt));
 		stu(x + TMX_SLAB_V(L, k) * NS, cb, v / (1.0 + kf * bs * dt));
 	}
-	const double pr = pscal * exp(log(rt) * gamma);
+	const double pr = pscal * tmx_ref_exp(tmx_ref_log(rt) * gamma);
 	const double sigma = pr / ps;
 	double bs = (sigma - bsig) / (1.0 - bsig);
 	if (bs < 0.0) bs = 0.0;
@@ -1072,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	const double sl = sin(lat), cl = cos(lat);
 	const double c4 = cl * cl * cl * cl;
 	const double kt = ka + (ks - ka) * bs * c4;
-	double teq = tmax - dty * sl * sl - dthz * log(pr / p.p0) * cl * cl;
+	double teq = tmax - dty * sl * sl - dthz * tmx_ref_log(pr / p.p0) * cl * cl;
 	teq *= pow(pr / p.p0, kappa);
 	if (teq < tmin) teq = tmin;
 	const double ddh = -kt / gamma * (1.0 + (gamma - 1.0) * teq / T);
@@ -1767,8 +1787,8 @@ __global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, 
 		for (int r = 1; r < 5; r++) {
 			const double l = R[r][0] * rcp;
 #pragma unroll
-			for (int c = 1; c < TMX_BW; c++) R[r][c] -= l * R[0][c];
-			b[r] -= b[0] * l;
+			for (int c = 1; c < TMX_BW; c++) R[r][c] = LU_UPD(R[r][c], l, R[0][c]);
+			b[r] = LU_UPD(b[r], b[0], l);
 		}
 		// slide the window: drop the pivot row and the pivot column, take in matrix row jcol + 5
 #pragma unroll
@@ -1805,7 +1825,7 @@ __global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, 
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) ur[c] = AB[((size_t)r * TMX_BW + c) * NUS + u];
 #pragma unroll
-		for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * ur[c];
+		for (int c = TMX_BW - 1; c >= 1; c--) acc = LU_UPD(acc, xw[c - 1], ur[c]);
 		const double xr = acc / ur[0];
 #pragma unroll
 		for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];
@@ -2111,9 +2131,9 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 		// after the interchange position r holds old row r, except position PV, which holds old row 0
 		const double l = ((r == PV) ? t0[0] : R[r][0]) * rcp;
 #pragma unroll
-		for (int c = 1; c < TMX_BW; c++) R[r - 1][c - 1] = ((r == PV) ? t0[c] : R[r][c]) - l * piv[c];
+		for (int c = 1; c < TMX_BW; c++) R[r - 1][c - 1] = LU_UPD((r == PV) ? t0[c] : R[r][c], l, piv[c]);
 		R[r - 1][TMX_BW - 1] = 0.0;
-		b[r - 1] = ((r == PV) ? tb0 : b[r]) - pb * l;
+		b[r - 1] = LU_UPD((r == PV) ? tb0 : b[r], pb, l);
 	}
 #pragma unroll
 	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
@@ -2167,8 +2187,8 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	for (int r = 1; r < 5; r++) {
 		const double l = R[r][0] * rcp;
 #pragma unroll
-		for (int c = 1; c < TMX_BW; c++) R[r][c] -= l * R[0][c];
-		b[r] -= b[0] * l;
+		for (int c = 1; c < TMX_BW; c++) R[r][c] = LU_UPD(R[r][c], l, R[0][c]);
+		b[r] = LU_UPD(b[r], b[0], l);
 	}
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
@@ -2219,7 +2239,7 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 __device__ __forceinline__ double vi_back_row(const URow & s, double (&xw)[TMX_BW - 1]) {
 	double acc = s.y;
 #pragma unroll
-	for (int c = TMX_BW - 1; c >= 1; c--) acc -= xw[c - 1] * s.u[c];
+	for (int c = TMX_BW - 1; c >= 1; c--) acc = LU_UPD(acc, xw[c - 1], s.u[c]);
 	const double xr = acc / s.u[0];
 #pragma unroll
 	for (int c = TMX_BW - 2; c >= 1; c--) xw[c] = xw[c - 1];

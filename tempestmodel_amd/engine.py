@@ -428,7 +428,7 @@ class Engine:
         n = self.lib.tmx_plan_get_matrices(self.h, None, 0)
         a = np.zeros(max(n, 1), dtype=np.float64)
         self.lib.tmx_plan_get_matrices(self.h, _pd(a), n)
-        return a[:n].reshape(-1, 4, 2, 2, 2)
+        return a[:n].reshape(-1, 4, 4, 2, 2)      # [cross group][member m][partner q][2x2]
 
     def comm_init(self, unique_id):
         self._chk(self.lib.tmx_comm_init(self.h, unique_id))

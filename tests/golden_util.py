@@ -4,6 +4,19 @@ import numpy as np
 from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW, BaroclinicWaveJWSmallPlanet, ScharMountainSphere
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# TMX_PARITY_REPORT=<file>: every error vector computed by prognostic_errors / tracer_errors is appended to <file>
+# with the calling test and line, so that one run shows which comparisons are bit-exact and which are not.
+_REPORT = os.environ.get("TMX_PARITY_REPORT")
+
+
+def _report(kind, errs):
+    if not _REPORT:
+        return
+    import inspect
+    fr = inspect.stack()[2]
+    with open(_REPORT, "a") as f:
+        f.write("%s:%d %s %s %s\n" % (os.path.basename(fr.filename), fr.lineno, fr.function, kind, " ".join("%.2e" % v for v in errs)))
 ARS343_GAMMA = 0.4358665215084590
 
 
@@ -44,7 +57,30 @@ def grid_from_fixture(d, override=True, case="jw", ntracers=0):
             g.ops[nm] = (d["op/%s/coeff" % nm], d["op/%s/begin" % nm], d["op/%s/end" % nm])
         g.dx = d["op/dx_basis_1d"]
         g.stiff = d["op/stiffness_1d"]
+        override_halo_transforms(g, d)
     return g, states
+
+
+def override_halo_transforms(g, d):
+    """Replace the synthesised covector panel transforms of the halo ring by the reference's own (probed from
+    CubedSphereTrans::CoVecPanelTrans by the dump driver, ``halo_trans/p*/e*``): the synthesiser derives them from the 3-D
+    embedding, which agrees to 1e-15 but not bit for bit, and the DSS of (U,V) on panel edges sees the difference."""
+    n = 0
+    for P in g.patches:
+        h = P.halo
+        for e in range(4):
+            key = "halo_trans/p%d/e%d" % (P.index, e)
+            if key not in d:
+                continue
+            M = d[key]
+            for m in range(len(h["i"])):
+                i, j = h["i"][m], h["j"][m]
+                on = (e == 0 and i == P.na - 1) or (e == 1 and j == P.nb - 1) or (e == 2 and i == 0) or (e == 3 and j == 0)
+                if not on or h["src_patch"][m] < 0 or h["src_panel"][m] != d[key + "_srcpanel"][0]:
+                    continue
+                h["trans"][m] = M[j if e in (0, 2) else i]
+                n += 1
+    return n
 
 
 def full_states(d, tag, npatch):
@@ -74,6 +110,7 @@ def tracer_errors(got, ref):
         num = max(float(np.max(np.abs(a[c, 1:-1, 1:-1] - b[c, 1:-1, 1:-1]))) for a, b in zip(got, ref))
         den = max(float(np.max(np.abs(b[c, 1:-1, 1:-1]))) for b in ref)
         errs.append(num / den if den > 0 else num)
+    _report("tracers", errs)
     return errs
 
 
@@ -103,6 +140,7 @@ def prognostic_errors(got, ref, interior=True):
                 a = a[1:-1, 1:-1]; b = b[1:-1, 1:-1]
             m = max(m, float(np.max(np.abs(a - b)))); s = max(s, float(np.max(np.abs(b))))
         errs.append(m / s if s > 0 else m)
+    _report("state", errs)
     return errs
 
 

@@ -1,0 +1,28 @@
+/* tests/native/refmath_check.c -- CPU build of tempestmodel_amd/csrc/tmx_refmath.h against the libm of this image,
+ * bit for bit, on the argument ranges of the hot path and on wide ranges.  Built and run by
+ * tests/test_abi_and_host_logic.py::test_refmath_is_glibc_bit_for_bit. */
+#include <stdio.h>
+#include <stdlib.h>
+#include "tmx_refmath.h"   /* -I tempestmodel_amd/csrc */
+static uint64_t s = 88172645463325252ull;
+static double rnd(void){ s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) * (1.0/9007199254740992.0); }
+int main(int argc,char**argv){
+	long n = argc>1? atol(argv[1]) : 20000000, bad_e=0,bad_l=0;
+	for(long i=0;i<n;i++){
+		double x;
+		int m=i%4;
+		if(m==0) x = -2.0 + 2.5*rnd();             /* exponent arguments of the Exner function */
+		else if(m==1) x = -700.0 + 1400.0*rnd();
+		else if(m==2) x = ldexp(rnd()-0.5, (int)(40*rnd())-30);
+		else x = 5.0*rnd()-2.5;
+		if(tmx_ref_exp(x)!=exp(x)){ if(bad_e<5) printf("exp mismatch %a: %a vs %a\n",x,tmx_ref_exp(x),exp(x)); bad_e++; }
+		double y;
+		if(m==0) y = 0.05 + 1.1*rnd();              /* R/p0*rho*theta */
+		else if(m==1) y = 0.9375 + (1.0647-0.9375)*rnd();
+		else if(m==2) y = ldexp(0.5+rnd(), (int)(2000*rnd())-1000);
+		else y = 1e5*rnd();
+		if(tmx_ref_log(y)!=log(y)){ if(bad_l<5) printf("log mismatch %a: %a vs %a\n",y,tmx_ref_log(y),log(y)); bad_l++; }
+	}
+	printf("n=%ld exp mismatches %ld log mismatches %ld\n",n,bad_e,bad_l);
+	return (bad_e||bad_l)?1:0;
+}

@@ -106,3 +106,16 @@ def test_two_rank_plans_are_mutually_consistent():
             assert len(a) > 0
     for e in es:
         e.close()
+
+
+def test_refmath_is_glibc_bit_for_bit(tmp_path):
+    """tempestmodel_amd/csrc/tmx_refmath.h (the exp / log the device evaluates in the Exner function) restates glibc's
+    FMA-build exp / log; its CPU build must agree with this image's libm bit for bit: 2e7 arguments, half of them on
+    the ranges the hot path uses (R/p0 * rho*theta in (0.05, 1.15), including the near-1 branch of log)."""
+    import subprocess
+    exe = str(tmp_path / "refmath_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "tempestmodel_amd", "csrc"), "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "refmath_check.c"), "-lm"], check=True)
+    r = subprocess.run([exe, "20000000"], stdout=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0, r.stdout
+    assert "exp mismatches 0 log mismatches 0" in r.stdout

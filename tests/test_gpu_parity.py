@@ -6,9 +6,16 @@ import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 
-TOL_CALL = 1e-12      # one hot-path call, relative to the max abs value of each variable
-TOL_STEPS = 1e-10     # north-star tolerance for multi-step state differences
-TOL_W_NE15 = 5e-10    # W after 100 steps at ne15 L30: see test_hundred_steps_ne15_L30
+# Parity bar of this file:
+#  * device vs C oracle on IDENTICAL inputs: bit for bit (EXACT) -- every operation of the path is IEEE-exact on both
+#    sides, the band LU uses the fused update of the reference's BLAS, exp / log are glibc's (tmx_refmath.h);
+#  * device vs the REAL reference where the fixture carries the reference's own inputs (geometry, operators, halo
+#    transforms: the per-call fixtures, the live ne15 run): bit for bit as well -- the oracle is the reference there;
+#  * device vs reference fixtures on a SYNTHESISED grid (tempestmodel_amd/cubed_sphere.py reproduces the reference's
+#    geometry to 1e-15, not bit for bit): the north-star tolerance 1e-10, every variable, no exception.
+EXACT = 0.0
+TOL_CALL = EXACT      # one hot-path call
+TOL_STEPS = 1e-10     # north-star tolerance for multi-step state differences on synthesised inputs
 
 
 @pytest.fixture(scope="module", params=["jw", "schar"])
@@ -31,7 +38,7 @@ def percall(request):
 def _cmp(e, o, ie, io, tol, what):
     e.sync()
     errs = gu.prognostic_errors(e.download_state(ie), o.get_state(io))
-    assert max(errs) < tol, (what, errs)
+    assert max(errs) <= tol, (what, errs)
     return errs
 
 
@@ -46,25 +53,25 @@ def test_percall_chain_vs_oracle_and_reference(percall):
     o.copy_data(0, 1); e.copy_data(0, 1)
     o.h_step_explicit(0, 1, sdt); e.h_step_explicit(0, 1, sdt)
     _cmp(e, o, 1, 1, TOL_CALL, "h_explicit")
-    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "h_explicit", npatch))) < TOL_CALL
+    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "h_explicit", npatch))) == 0.0
     o.v_step_explicit(0, 1, sdt); e.v_step_explicit(0, 1, sdt)
     _cmp(e, o, 1, 1, TOL_CALL, "v_explicit")
-    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "v_explicit", npatch))) < TOL_CALL
+    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "v_explicit", npatch))) == 0.0
     o.apply_dss(1); e.apply_dss(1)
     _cmp(e, o, 1, 1, TOL_CALL, "dss")
-    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "dss", npatch))) < TOL_CALL
+    assert max(gu.prognostic_errors(e.download_state(1), gu.full_states(d, "dss", npatch))) == 0.0
     o.copy_data(1, 2); e.copy_data(1, 2)
     assert o.v_step_implicit(2, 2, sdt) == 0
     e.v_step_implicit(2, 2, sdt)
-    _cmp(e, o, 2, 2, 1e-11, "v_implicit")
-    assert max(gu.prognostic_errors(e.download_state(2), gu.full_states(d, "v_implicit", npatch))) < 1e-11
+    _cmp(e, o, 2, 2, EXACT, "v_implicit")
+    assert max(gu.prognostic_errors(e.download_state(2), gu.full_states(d, "v_implicit", npatch))) == 0.0
     o.h_step_after_subcycle(2, 3, 4, dt); e.h_step_after_subcycle(2, 3, 4, dt)
-    _cmp(e, o, 4, 4, 1e-11, "hypervis work")
-    _cmp(e, o, 3, 3, 1e-11, "hypervis")
-    assert max(gu.prognostic_errors(e.download_state(3), gu.full_states(d, "hypervis", npatch))) < 1e-11
+    _cmp(e, o, 4, 4, EXACT, "hypervis work")
+    _cmp(e, o, 3, 3, EXACT, "hypervis")
+    assert max(gu.prognostic_errors(e.download_state(3), gu.full_states(d, "hypervis", npatch))) == 0.0
     cf = [0.25, -0.5, 1.75, 0.5, 0, 0, 0]
     o.linear_combine_data(cf, 3); e.linear_combine_data(cf, 3)
-    _cmp(e, o, 3, 3, 1e-11, "lincomb")
+    _cmp(e, o, 3, 3, EXACT, "lincomb")
 
 
 def test_download_fills_derived_slots(percall):
@@ -143,7 +150,7 @@ def test_ars343_steps_vs_reference_and_oracle(fixture, ne, L, npatch, dt, tags):
                 step += 1
             e.sync()
             got = e.download_state(0)
-            assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_STEPS, tag
+            assert max(gu.prognostic_errors(got, o.get_state(0))) == 0.0, tag
             assert max(gu.prognostic_errors(got, gu.expand_compact(d, tag, g))) < TOL_STEPS, tag
     finally:
         e.close()
@@ -167,9 +174,9 @@ def test_tracer_percall_chain():
         def cmp(ie, io, tag, tol):
             e.sync()
             got = e.download_tracers(ie)
-            assert max(gu.tracer_errors(got, o.get_tracers(io))) < tol, tag
-            assert max(gu.tracer_errors(got, gu.full_tracers(d, tag, 6))) < tol, tag
-            assert max(gu.prognostic_errors(e.download_state(ie), o.get_state(io))) < 1e-11, tag
+            assert max(gu.tracer_errors(got, o.get_tracers(io))) == 0.0, tag
+            assert max(gu.tracer_errors(got, gu.full_tracers(d, tag, 6))) == 0.0, tag
+            assert max(gu.prognostic_errors(e.download_state(ie), o.get_state(io))) == 0.0, tag
 
         o.copy_data(0, 1); e.copy_data(0, 1)
         o.h_step_explicit(0, 1, sdt); e.h_step_explicit(0, 1, sdt); cmp(1, 1, "h_explicit", TOL_CALL)
@@ -202,14 +209,14 @@ def test_tracer_steps_vs_reference_and_oracle():
             e.step_ars343(200.0)
             e.sync()
             got = e.download_tracers(0)
-            assert max(gu.tracer_errors(got, o.get_tracers(0))) < 1e-11, step
+            assert max(gu.tracer_errors(got, o.get_tracers(0))) == 0.0, step
             assert max(gu.tracer_errors(got, gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-11, step
             assert max(gu.prognostic_errors(e.download_state(0), gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS, step
         for _ in range(2):
             assert o.step("ars232", 200.0) == 0
             e.step("ars232", 200.0)
         e.sync()
-        assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) < 1e-11
+        assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) == 0.0
     finally:
         e.close()
 
@@ -233,10 +240,10 @@ def test_uniform_diffusion_explicit_vertical_percall():
         def cmp(ie, io, tag):
             e.sync()
             gs, gt = e.download_state(ie), e.download_tracers(ie)
-            assert max(gu.prognostic_errors(gs, o.get_state(io))) < TOL_CALL, tag
-            assert max(gu.tracer_errors(gt, o.get_tracers(io))) < TOL_CALL, tag
-            assert max(gu.prognostic_errors(gs, gu.full_states(d, tag, 6))) < TOL_CALL, tag
-            assert max(gu.tracer_errors(gt, gu.full_tracers(d, tag, 6))) < TOL_CALL, tag
+            assert max(gu.prognostic_errors(gs, o.get_state(io))) == 0.0, tag
+            assert max(gu.tracer_errors(gt, o.get_tracers(io))) == 0.0, tag
+            assert max(gu.prognostic_errors(gs, gu.full_states(d, tag, 6))) == 0.0, tag
+            assert max(gu.tracer_errors(gt, gu.full_tracers(d, tag, 6))) == 0.0, tag
 
         o.copy_data(0, 1); e.copy_data(0, 1)
         o.h_step_explicit(0, 1, sdt); e.h_step_explicit(0, 1, sdt); cmp(1, 1, "h_explicit")
@@ -265,8 +272,8 @@ def test_uniform_diffusion_explicit_vertical_steps(scheme):
             e.step(scheme, 1.0, first=(step == 1))
             e.sync()
             gs, gt = e.download_state(0), e.download_tracers(0)
-            assert max(gu.prognostic_errors(gs, o.get_state(0))) < TOL_STEPS, step
-            assert max(gu.tracer_errors(gt, o.get_tracers(0))) < 1e-11, step
+            assert max(gu.prognostic_errors(gs, o.get_state(0))) == 0.0, step
+            assert max(gu.tracer_errors(gt, o.get_tracers(0))) == 0.0, step
             assert max(gu.prognostic_errors(gs, gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS, step
             assert max(gu.tracer_errors(gt, gu.expand_compact_tracers(d, "step%d" % step, g))) < 1e-11, step
     finally:
@@ -285,7 +292,7 @@ def test_explicit_vertical_without_diffusion_matches_oracle():
             assert o.step(scheme, 1.0, first=(step == 2)) == 0
             e.step(scheme, 1.0, first=(step == 2))
         e.sync()
-        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) < TOL_STEPS
+        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) == 0.0
     finally:
         e.close()
 
@@ -306,7 +313,7 @@ def test_viscosity_order_2_steps():
             e.step_ars343(300.0)
             e.sync()
             got = e.download_state(0)
-            assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_STEPS
+            assert max(gu.prognostic_errors(got, o.get_state(0))) == 0.0
             assert max(gu.prognostic_errors(got, gu.expand_compact(d, "step%d" % step, g))) < TOL_STEPS
     finally:
         e.close()
@@ -409,8 +416,9 @@ def test_held_suarez_physics():
         e.held_suarez(0, 200.0)
         e.sync()
         got = e.download_state(0)
-        assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_CALL
-        assert max(gu.prognostic_errors(got, after)) < TOL_CALL
+        # pow / sin / cos of the forcing are ocml's on the device and glibc's in the oracle: rounding-level tolerance
+        assert max(gu.prognostic_errors(got, o.get_state(0))) < 1e-12
+        assert max(gu.prognostic_errors(got, after)) < 1e-12
     finally:
         e.close()
 
@@ -440,15 +448,16 @@ def test_unusual_sizes_vs_oracle(ne, L, npatch, ntr):
         assert o.step("strang", 100.0, first=True) == 0
         e.step("strang", 100.0, first=True)
         e.sync()
-        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) < TOL_STEPS
+        assert max(gu.prognostic_errors(e.download_state(0), o.get_state(0))) == 0.0
         if ntr:
-            assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) < 1e-11
+            assert max(gu.tracer_errors(e.download_tracers(0), o.get_tracers(0))) == 0.0
     finally:
         e.close()
 
 
 def test_hundred_steps_ne4_L10():
-    """North-star gate: fp64 state difference < 1e-10 after 100 ARS343 steps (vs the oracle, same inputs)."""
+    """North-star gate (fp64 state difference < 1e-10 after 100 ARS343 steps) against the oracle on identical inputs:
+    the device reproduces it BIT FOR BIT."""
     from tempestmodel_amd.engine import Engine
     from oracle_lib import Oracle
     g, states = gu.make_grid(4, 10, 6)
@@ -464,13 +473,14 @@ def test_hundred_steps_ne4_L10():
         e.sync()
         errs = gu.prognostic_errors(e.download_state(0), o.get_state(0))
         print("100 steps:", errs)
-        assert max(errs) < TOL_STEPS, errs
+        assert max(errs) == 0.0, errs
     finally:
         e.close()
 
 
 def test_hundred_steps_ne4_L10_vs_reference():
-    """Same gate against the REAL reference: 100 ARS343 steps from its state after 2 steps (golden fixture)."""
+    """Same gate against the REAL reference: 100 ARS343 steps from its state after 2 steps (golden fixture), on the
+    synthesised grid (inputs agree with the reference's to 1e-15, not bit for bit)."""
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps100_ne4_L10_p6.npz")
     g, _ = gu.make_grid(4, 10, 6)
@@ -487,16 +497,16 @@ def test_hundred_steps_ne4_L10_vs_reference():
 
 
 def test_hundred_steps_ne15_L30():
-    """North-star gate at BASELINE config 2 (ne15 np4 L30, dt 300 s): fp64 state difference < 1e-10 after 100
-    ARS343 steps.  The start state is developed (2 steps).  Checked against the C oracle on identical inputs,
-    and against the real reference binary (oracle/_ref/tmx_ref_dump, built in the build container and shipped
-    with the snapshot) when it is present -- that run starts from the reference's own state after 2 steps."""
+    """North-star gate at BASELINE config 2 (ne15 np4 L30, dt 300 s): fp64 state difference < 1e-10 after 100 ARS343
+    steps, every variable.  Where the real reference binary travelled with the snapshot (oracle/_ref/tmx_ref_dump,
+    built in the build container) it runs here, on the GPU box's host, and hands over ITS OWN inputs (geometry,
+    operators, halo transforms, state after 2 steps): the device then reproduces the reference's state after 100
+    further steps bit for bit.  Without the binary the run is checked against the C oracle on the synthesised grid."""
     import os, subprocess, tempfile
     import tmxd
     from tempestmodel_amd.engine import Engine
     from oracle_lib import Oracle
     ne, L, dt = 15, 30, 300.0
-    g, states = gu.make_grid(ne, L, 6)
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump")
     ref_end = None
     if os.path.exists(ref_bin):
@@ -504,13 +514,15 @@ def test_hundred_steps_ne15_L30():
             out = os.path.join(td, "ref.tmxd")
             env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
             subprocess.run([ref_bin, "--mode", "steps", "--ne", str(ne), "--levels", str(L), "--dt", str(dt), "--warm", "2",
-                            "--steps", "100", "--every", "100", "--geom", "0", "--out", out], env=env, check=True,
+                            "--steps", "100", "--every", "100", "--geom", "1", "--out", out], env=env, check=True,
                            stdout=subprocess.DEVNULL, timeout=1500)
             rd = tmxd.read(out)
+        g, _ = gu.grid_from_fixture(rd, override=True)
         start = gu.full_states(rd, "warm", 6)
         ref_end = gu.full_states(rd, "step100", 6)
         del rd
     else:
+        g, states = gu.make_grid(ne, L, 6)
         o0 = Oracle(g); o0.set_state(0, states)
         for _ in range(2):
             assert o0.step_ars343(dt) == 0
@@ -526,20 +538,12 @@ def test_hundred_steps_ne15_L30():
             assert o.step_ars343(dt) == 0
         errs_o = gu.prognostic_errors(got, o.get_state(0))
         print("ne15 L30, 100 steps vs C oracle:", errs_o)
-        errs_r = gu.prognostic_errors(got, ref_end) if ref_end is not None else None
-        if errs_r is not None:
-            print("ne15 L30, 100 steps vs real reference:", errs_r)
-            print("   (C oracle vs real reference:", gu.prognostic_errors(o.get_state(0), ref_end), ")")
-        for errs in (errs_o, errs_r):
-            if errs is None:
-                continue
-            # U, V, rho*theta, rho: the north-star tolerance
-            assert max(errs[c] for c in (0, 1, 2, 4)) < TOL_STEPS, errs
-            # W: after 100 steps at this size the reference's own sensitivity to last-bit changes is 2e-10 in W
-            # (C oracle with its own LAPACK restatement vs the reference with MKL, tests/analysis/lapack_sensitivity_ne15.py;
-            # glibc exp/log vs correctly rounded exp/log alone: 3e-11 at ne4) -- W is the small residual of the
-            # hydrostatic balance.  The GPU differs from the oracle only through ocml's exp/log (<= 1 ulp).
-            assert errs[3] < TOL_W_NE15, errs
+        assert max(errs_o) == 0.0, errs_o
+        if ref_end is not None:
+            errs_r = gu.prognostic_errors(got, ref_end)
+            print("ne15 L30, 100 steps vs real reference (its own inputs):", errs_r)
+            assert max(errs_r) < TOL_STEPS, errs_r          # the gate
+            assert max(errs_r) == 0.0, errs_r               # and in fact bit for bit
     finally:
         e.close()
 
@@ -822,7 +826,7 @@ def test_other_time_schemes(scheme):
             e.step(scheme, 400.0)
         e.sync()
         got = e.download_state(0)
-        assert max(gu.prognostic_errors(got, o.get_state(0))) < TOL_STEPS
+        assert max(gu.prognostic_errors(got, o.get_state(0))) == 0.0
         assert max(gu.prognostic_errors(got, gu.expand_compact(d, "%s_step3" % scheme, g))) < TOL_STEPS
     finally:
         e.close()
@@ -845,7 +849,7 @@ def test_shallow_water_test2_strang():
             e.step("strang", 200.0, first=(n == 0))
         e.sync()
         got = e.download_state(0)
-        assert max(gu.prognostic_errors(got, o.get_state(0))[:3]) < 1e-12
+        assert max(gu.prognostic_errors(got, o.get_state(0))[:3]) == 0.0
         assert max(gu.prognostic_errors(got, _sw_ref(d, "step10", g))[:3]) < 1e-12
     finally:
         e.close()
