@@ -300,6 +300,19 @@ int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const double * latit
  * host-side WorkflowProcess forces (src/atm/Model.cpp:477-481). */
 int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt);
 
+/* Kessler warm-rain microphysics of the DCMIP2016 supercell (BASELINE config 4): KesslerPhysics::Perform
+ * (test/dcmip2016/KesslerPhysics.cpp:83-285) around SUBROUTINE KESSLER (test/dcmip2016/interface/kessler.f90:64-185),
+ * a WorkflowProcess like the Held-Suarez forcing (Model.cpp:470-481).  Needs n_tracers >= 3 with tracers 0,1,2 =
+ * RhoQv, RhoQc, RhoQr (SupercellTest.cpp:271-275).
+ * tmx_set_patch_level_heights: per owned patch z_levels [na][nb][L] = GridPatch::GetZLevels() (KesslerPhysics.cpp:141).
+ * tmx_physics_kessler: Perform on `instance` with dDeltaT = dt; updates rho, rho*theta and the three tracer densities and
+ *   adds precl * dt to the accumulated precipitation (UserData2D item 0 "PRECT", KesslerPhysics.cpp:234).
+ * tmx_download_precipitation: the accumulated precipitation of a patch into prect [na][nb] (interior nodes written);
+ *   reset != 0 zeroes the device accumulator afterwards. */
+int tmx_set_patch_level_heights(tmx_engine * e, int patch, const double * z_levels);
+int tmx_physics_kessler(tmx_engine * e, int instance, double dt);
+int tmx_download_precipitation(tmx_engine * e, int patch, double * prect, int reset);
+
 /* Wait for the engine's stream; reports a deferred TMX_ERR_SINGULAR from column solves. */
 int tmx_sync(tmx_engine * e);
 

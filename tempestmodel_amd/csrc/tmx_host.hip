@@ -182,7 +182,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -1942,6 +1942,70 @@ extern "C" int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt) 
 	ProfScope ps(e, TMX_K_LINCOMB);
 	tmxk_held_suarez(e, make_params(e), inst(e, instance), dt);
 	return launch_check("physics_held_suarez");
+}
+
+// ---- Kessler microphysics (BASELINE config 4) ----
+extern "C" int tmx_set_patch_level_heights(tmx_engine * e, int patch, const double * z_levels) {
+	REQUIRE(e && z_levels, TMX_ERR_INVALID, "tmx_set_patch_level_heights: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "column physics with the shallow-water equation set is not supported");
+	int r = ensure_layout(e);
+	if (r) return r;
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
+	const int L = e->L;
+	const size_t NS = e->NS;
+	if (e->h_zlev.empty()) e->h_zlev.assign((size_t)L * NS, 0.0);
+	for (int i = 1; i < P.na - 1; i++)
+	for (int j = 1; j < P.nb - 1; j++) {
+		const int c = col_of(P, i, j);
+		for (int k = 0; k < L; k++) e->h_zlev[(size_t)k * NS + c] = z_levels[((size_t)i * P.nb + j) * L + k];
+	}
+	P.zlev_set = true; e->zlev_dirty = true;
+	return TMX_OK;
+}
+
+extern "C" int tmx_physics_kessler(tmx_engine * e, int instance, double dt) {
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "Kessler physics with the shallow-water equation set is not supported");
+	REQUIRE(e->nt >= 3, TMX_ERR_INVALID, "Kessler physics needs the tracers RhoQv, RhoQc, RhoQr (n_tracers >= 3)");
+	REQUIRE(dt > 0.0, TMX_ERR_INVALID, "tmx_physics_kessler: dt must be positive");
+	for (int lp : e->local_patches)
+		REQUIRE(e->patches[lp].zlev_set, TMX_ERR_INVALID, "tmx_set_patch_level_heights was not called for patch %d", lp);
+	const size_t NS = e->NS; const int L = e->L;
+	if (!e->d_zlev) {
+		HIPCHK(hipMalloc((void **)&e->d_zlev, (size_t)L * NS * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&e->d_prect, NS * sizeof(double)));
+		HIPCHK(hipMemset(e->d_prect, 0, NS * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&e->d_kes, (size_t)8 * L * NS * sizeof(double)));
+		e->hbm_bytes += (size_t)(9 * L + 1) * NS * sizeof(double);
+	}
+	if (e->zlev_dirty) {
+		HIPCHK(hipStreamSynchronize(e->stream));
+		HIPCHK(hipMemcpy(e->d_zlev, e->h_zlev.data(), (size_t)L * NS * sizeof(double), hipMemcpyHostToDevice));
+		e->zlev_dirty = false;
+	}
+	ProfScope ps(e, TMX_K_LINCOMB);
+	tmxk_kessler(e, make_params(e), inst(e, instance), dt);
+	return launch_check("physics_kessler");
+}
+
+extern "C" int tmx_download_precipitation(tmx_engine * e, int patch, double * prect, int reset) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(prect, TMX_ERR_INVALID, "tmx_download_precipitation: null argument");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
+	PatchInfo & P = e->patches[patch];
+	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
+	std::vector<double> v((size_t)P.nea * P.neb * TMX_NQ, 0.0);
+	const int c0 = P.elem_base * TMX_NQ;
+	if (e->d_prect) {
+		HIPCHK(hipStreamSynchronize(e->stream));
+		HIPCHK(hipMemcpy(v.data(), e->d_prect + c0, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+		if (reset) HIPCHK(hipMemset(e->d_prect + c0, 0, v.size() * sizeof(double)));
+	}
+	for (int i = 1; i < P.na - 1; i++)
+	for (int j = 1; j < P.nb - 1; j++) prect[(size_t)i * P.nb + j] = v[col_of(P, i, j) - c0];
+	return TMX_OK;
 }
 
 extern "C" int tmx_sync(tmx_engine * e) {

@@ -51,7 +51,7 @@ struct KParams {
 };
 
 struct PatchInfo {
-	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false, physics_set = false, ref_set = false;
+	bool defined = false, halo_set = false, geom_set = false, metric_ok = false, rayleigh_set = false, physics_set = false, ref_set = false, zlev_set = false;
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
@@ -122,6 +122,9 @@ struct tmx_engine {
 	double * d_ab = nullptr;                 // [3(L+1)*9][NUS] band rows, overwritten by U rows
 	double * d_rhs = nullptr;                // [3(L+1)][NUS]
 	int * d_flag = nullptr;                  // singular-pivot flag
+	// Kessler microphysics (tmx_physics_kessler): level heights [L][NS], accumulated precipitation [NS], column work arrays [8][L][NS]
+	std::vector<double> h_zlev; bool zlev_dirty = false;
+	double * d_zlev = nullptr, * d_prect = nullptr, * d_kes = nullptr;
 	size_t hbm_bytes = 0;
 
 	// comm
@@ -164,6 +167,7 @@ void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const doub
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
 void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt);
+void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);

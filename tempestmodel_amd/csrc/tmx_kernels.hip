@@ -796,6 +796,9 @@ void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsr
 // advanced on its own (ucol == udep == nullptr; the update instance has not been through the DSS yet), the matrix is
 // the diagonal 1/dt (dgbtrs then is one division per level), xi_dot comes from the initial W for both uses, there
 // is no velocity correction, and with ks != 0 the mass flux carries the uniform diffusion of q / rho - (q / rho)_ref.
+// LW = columns per workgroup (the lane stride of the LDS arrays): 64, or 32 when (8L + 2) x 512 bytes exceed the 160 KB of a
+// CU (L >= 40, e.g. the 40 levels of the DCMIP2016 supercell) -- half-filled wavefronts, twice the workgroups.
+template <int LW>
 __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
 	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag,
 	int expl, double ks, const double * __restrict__ xref)
@@ -803,19 +806,19 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 	extern __shared__ double smt[];
 	const int L = p.L, lane = threadIdx.x;
 	const size_t NS = (size_t)p.NS;
-	double * A = smt;                        // [L][4][64] band matrix, rebuilt and factorised per tracer
-	double * F = A + (size_t)L * 4 * 64;     // [L][64] right-hand side / solution
-	double * xd0 = F + (size_t)L * 64;       // [L+1][64] xi_dot of the initial column on interfaces
-	double * xd1 = xd0 + (size_t)(L + 1) * 64;   // [L+1][64] xi_dot with the updated W
-	double * qn = xd1 + (size_t)(L + 1) * 64;    // [L][64] tracer density of the column
-	const int u = blockIdx.x * 64 + lane;
-	if (u >= nunique) return;
+	double * A = smt;                        // [L][4][LW] band matrix, rebuilt and factorised per tracer
+	double * F = A + (size_t)L * 4 * LW;     // [L][LW] right-hand side / solution
+	double * xd0 = F + (size_t)L * LW;       // [L+1][LW] xi_dot of the initial column on interfaces
+	double * xd1 = xd0 + (size_t)(L + 1) * LW;   // [L+1][LW] xi_dot with the updated W
+	double * qn = xd1 + (size_t)(L + 1) * LW;    // [L][LW] tracer density of the column
+	const int u = blockIdx.x * LW + lane;
+	if (lane >= LW || u >= nunique) return;
 	const int col = ucol ? ucol[u] : u;
 	const MetCol mc = met_col(p, col);
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
-	double * mixr = A;                       // explicit mode: [L][64] q / rho - (q / rho)_ref   (the matrix is not stored)
-	double * rhoe = A + (size_t)L * 64;      // explicit mode: [L+1][64] rho on interfaces
-#define ABW(i_, j_) A[((size_t)(j_) * 4 + 2 + (i_) - (j_)) * 64 + lane]
+	double * mixr = A;                       // explicit mode: [L][LW] q / rho - (q / rho)_ref   (the matrix is not stored)
+	double * rhoe = A + (size_t)L * LW;      // explicit mode: [L+1][LW] rho on interfaces
+#define ABW(i_, j_) A[((size_t)(j_) * 4 + 2 + (i_) - (j_)) * LW + lane]
 	// U,V on interfaces (InterpolateNodeToREdge of the initial column), xi_dot initial / updated (:3943-3957, :4059-4086)
 	for (int k = 0; k <= L; k++) {
 		double x0v = 0.0, x1v = 0.0;
@@ -834,12 +837,12 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)k * NS + col];
 			x1v = expl ? x0v : e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
 		}
-		xd0[(size_t)k * 64 + lane] = x0v; xd1[(size_t)k * 64 + lane] = x1v;
+		xd0[(size_t)k * LW + lane] = x0v; xd1[(size_t)k * LW + lane] = x1v;
 	}
 	// The matrix (the same for every tracer; the reference factorises it once) is cheap to rebuild from xi_dot, which
 	// keeps the LDS footprint at (8L + 2) x 512 bytes.
 	auto assemble = [&]() {
-		for (int t = 0; t < L * 4; t++) A[(size_t)t * 64 + lane] = 0.0;
+		for (int t = 0; t < L * 4; t++) A[(size_t)t * LW + lane] = 0.0;
 		// d F_k / d q_n: DiffREdgeToNode x J_e / J_n x InterpNodeToREdge x xi_dot (:3959-3976); J is level-independent
 		for (int k = 0; k < L; k++)
 			for (int mo = 0; mo <= 1; mo++) {
@@ -849,12 +852,12 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 					const int n = m + no;                      // InterpNodeToREdge row m: nodes m-1, m (two-sided at the ends)
 					if (n < 0 || n >= L) continue;
 					if (n - k < -1 || n - k > 1) continue;     // outside the band the coefficient is structurally zero
-					ABW(k, n) += dc * je / jn * OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, no) * xd0[(size_t)m * 64 + lane];
+					ABW(k, n) += dc * je / jn * OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, no) * xd0[(size_t)m * LW + lane];
 				}
 			}
 		// upwinding in the Jacobian (:3978-4016): interface a, weight |xi_dot_a|
 		for (int a = 1; a < L; a++) {
-			const double wgt = fabs(xd0[(size_t)a * 64 + lane]);
+			const double wgt = fabs(xd0[(size_t)a * LW + lane]);
 			ABW(a - 1, a - 1) -= wgt * OPC(TMX_OP_PENALTY_LEFT, a - 1, 0);
 			ABW(a - 1, a) -= wgt * OPC(TMX_OP_PENALTY_LEFT, a - 1, 1);
 			ABW(a, a - 1) -= wgt * OPC(TMX_OP_PENALTY_RIGHT, a, -1);
@@ -877,16 +880,16 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 				if (l < 0 || l >= L) continue;
 				re += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * xin[(size_t)TMX_SLAB_R(L, l) * NS + col];
 			}
-			rhoe[(size_t)m * 64 + lane] = re;
+			rhoe[(size_t)m * LW + lane] = re;
 		}
 	}
 	for (int c = 0; c < nt; c++) {
-		for (int k = 0; k < L; k++) qn[(size_t)k * 64 + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		for (int k = 0; k < L; k++) qn[(size_t)k * LW + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
 		if (expl && ks != 0.0)
 			for (int k = 0; k < L; k++) {
-				double a = qn[(size_t)k * 64 + lane] / xin[(size_t)TMX_SLAB_R(L, k) * NS + col];
+				double a = qn[(size_t)k * LW + lane] / xin[(size_t)TMX_SLAB_R(L, k) * NS + col];
 				a -= xref[(size_t)TMX_SLAB_Q(L, c, k) * NS + col] / xref[(size_t)TMX_SLAB_R(L, k) * NS + col];
-				mixr[(size_t)k * 64 + lane] = a;
+				mixr[(size_t)k * LW + lane] = a;
 			}
 		// mass flux with the updated xi_dot, its divergence (:4092-4140)
 		for (int k = 0; k < L; k++) {
@@ -898,48 +901,48 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 				for (int off = -2; off <= 1; off++) {
 					const int l = m + off;
 					if (l < 0 || l >= L) continue;
-					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn[(size_t)l * 64 + lane];
+					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn[(size_t)l * LW + lane];
 				}
-				mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd1[(size_t)m * 64 + lane];
+				mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd1[(size_t)m * LW + lane];
 				if (expl && ks != 0.0 && m > 0 && m < L) {
 					double dq = 0.0;       // DifferentiateNodeToREdge of the mixing-ratio difference
 #pragma unroll
 					for (int off = -2; off <= 1; off++) {
 						const int l = m + off;
 						if (l < 0 || l >= L) continue;
-						dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mixr[(size_t)l * 64 + lane];
+						dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mixr[(size_t)l * LW + lane];
 					}
-					mf[mo] -= ks * rhoe[(size_t)m * 64 + lane] * dq;
+					mf[mo] -= ks * rhoe[(size_t)m * LW + lane] * dq;
 				}
 			}
 			double dmf = 0.0;
 			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
 			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[1];
-			F[(size_t)k * 64 + lane] = dmf / jn;
+			F[(size_t)k * LW + lane] = dmf / jn;
 		}
 		// upwinding with the initial xi_dot (LinearColumnDiscPenaltyFEM::Apply; :4153-4181)
 		for (int k = 0; k < L; k++) {
 			double aux = 0.0;
 			if (k < L - 1) {
 				double b = 0.0;
-				b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn[(size_t)k * 64 + lane];
-				b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn[(size_t)(k + 1) * 64 + lane];
-				aux += b * fabs(xd0[(size_t)(k + 1) * 64 + lane]);
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn[(size_t)k * LW + lane];
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn[(size_t)(k + 1) * LW + lane];
+				aux += b * fabs(xd0[(size_t)(k + 1) * LW + lane]);
 			}
 			if (k > 0) {
 				double b = 0.0;
-				b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn[(size_t)(k - 1) * 64 + lane];
-				b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn[(size_t)k * 64 + lane];
-				aux += b * fabs(xd0[(size_t)k * 64 + lane]);
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn[(size_t)(k - 1) * LW + lane];
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn[(size_t)k * LW + lane];
+				aux += b * fabs(xd0[(size_t)k * LW + lane]);
 			}
-			F[(size_t)k * 64 + lane] -= aux;
+			F[(size_t)k * LW + lane] -= aux;
 		}
 		if (expl) {
 			// diagonal matrix 1/dt: dgbtrs leaves b_j / (1/dt)
 			const double idt = 1.0 / dt;
 			for (int k = 0; k < L; k++) {
 				const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
-				double bj = F[(size_t)k * 64 + lane];
+				double bj = F[(size_t)k * LW + lane];
 				if (bj != 0.0) bj /= idt;
 				xup[so + col] = xbase[so + col] - bj;
 			}
@@ -947,19 +950,19 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 		}
 		// implicit velocity correction (:4183-4233)
 		for (int a = 1; a < L; a++) {
-			const double xa = xd0[(size_t)a * 64 + lane];
+			const double xa = xd0[(size_t)a * LW + lane];
 			double e0, e1, e2;
 			metric_edge(p, mc, a, col, e0, e1, e2);
 			const double sw = (xa > 0.0) ? 1.0 * e2 : ((xa < 0.0) ? -1.0 * e2 : 0.0);
 			const double jump = sw * (xup[(size_t)TMX_SLAB_W(L, a) * NS + col] - w0[(size_t)a * NS + col]);
-			double f = F[(size_t)(a - 1) * 64 + lane];
-			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 0) * qn[(size_t)(a - 1) * 64 + lane] * jump;
-			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 1) * qn[(size_t)a * 64 + lane] * jump;
-			F[(size_t)(a - 1) * 64 + lane] = f;
-			f = F[(size_t)a * 64 + lane];
-			f -= OPC(TMX_OP_PENALTY_RIGHT, a, -1) * qn[(size_t)(a - 1) * 64 + lane] * jump;
-			f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * 64 + lane] * jump;
-			F[(size_t)a * 64 + lane] = f;
+			double f = F[(size_t)(a - 1) * LW + lane];
+			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 0) * qn[(size_t)(a - 1) * LW + lane] * jump;
+			f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 1) * qn[(size_t)a * LW + lane] * jump;
+			F[(size_t)(a - 1) * LW + lane] = f;
+			f = F[(size_t)a * LW + lane];
+			f -= OPC(TMX_OP_PENALTY_RIGHT, a, -1) * qn[(size_t)(a - 1) * LW + lane] * jump;
+			f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * LW + lane] * jump;
+			F[(size_t)a * LW + lane] = f;
 		}
 		// dgbtf2 (kl = ku = 1, kv = 2) on a fresh matrix, forward substitution with the interchanges, dtbsv
 		assemble();
@@ -984,23 +987,23 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 				}
 				// forward substitution of this column (dgbtrs): interchange, then eliminate
 				if (jj < L - 1) {
-					if (jp) { const double tmp = F[(size_t)(jj + 1) * 64 + lane]; F[(size_t)(jj + 1) * 64 + lane] = F[(size_t)jj * 64 + lane]; F[(size_t)jj * 64 + lane] = tmp; }
-					F[(size_t)(jj + 1) * 64 + lane] = LU_UPD(F[(size_t)(jj + 1) * 64 + lane], F[(size_t)jj * 64 + lane], ABW(jj + 1, jj));
+					if (jp) { const double tmp = F[(size_t)(jj + 1) * LW + lane]; F[(size_t)(jj + 1) * LW + lane] = F[(size_t)jj * LW + lane]; F[(size_t)jj * LW + lane] = tmp; }
+					F[(size_t)(jj + 1) * LW + lane] = LU_UPD(F[(size_t)(jj + 1) * LW + lane], F[(size_t)jj * LW + lane], ABW(jj + 1, jj));
 				}
 			} else singular = true;
 		}
 		for (int jj = L - 1; jj >= 0; jj--) {
-			double bj = F[(size_t)jj * 64 + lane];
+			double bj = F[(size_t)jj * LW + lane];
 			if (bj != 0.0) {
 				bj /= ABW(jj, jj);
-				F[(size_t)jj * 64 + lane] = bj;
+				F[(size_t)jj * LW + lane] = bj;
 				const int lo = (jj - 2 < 0) ? 0 : jj - 2;
-				for (int ii = jj - 1; ii >= lo; ii--) F[(size_t)ii * 64 + lane] = LU_UPD(F[(size_t)ii * 64 + lane], bj, ABW(ii, jj));
+				for (int ii = jj - 1; ii >= lo; ii--) F[(size_t)ii * LW + lane] = LU_UPD(F[(size_t)ii * LW + lane], bj, ABW(ii, jj));
 			}
 		}
 		for (int k = 0; k < L; k++) {
 			const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
-			const double val = xbase[so + col] - F[(size_t)k * 64 + lane];
+			const double val = xbase[so + col] - F[(size_t)k * LW + lane];
 			xup[so + col] = val;
 #pragma unroll
 			for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[so + dep[t]] = val;
@@ -1010,25 +1013,38 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 #undef ABW
 }
 
+// lanes per workgroup such that the LDS working set (8L + 2) x LW x 8 bytes fits one CU
+static int vi_tracers_lanes(int L, size_t & lds) {
+	for (int lw = 64; lw >= 32; lw >>= 1) {
+		lds = ((size_t)L * 4 + (size_t)L * 2 + (size_t)(L + 1) * 2) * lw * sizeof(double);
+		if (lds <= 160 * 1024) return lw;
+	}
+	return 0;
+}
+
 int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
 	if (e->nunique == 0 || e->nt == 0) return 0;
-	const size_t lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 64 * sizeof(double);
-	if (lds > 160 * 1024) return -1;
-	hipFuncSetAttribute((const void *)k_vi_tracers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(k_vi_tracers, dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt,
-		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag, 0, 0.0, (const double *)nullptr);
+	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
+	if (!lw) return -1;
+#define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+	hipLaunchKernelGGL(k_vi_tracers<LW_>, dim3((e->nunique + LW_ - 1) / LW_), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
+		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag, 0, 0.0, (const double *)nullptr); } while (0)
+	if (lw == 64) LAUNCH_VT(64); else LAUNCH_VT(32);
+#undef LAUNCH_VT
 	return 0;
 }
 
 // UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
-	const size_t lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 64 * sizeof(double);
-	if (lds > 160 * 1024) return -1;
-	hipFuncSetAttribute((const void *)k_vi_tracers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(k_vi_tracers, dim3((p.ncol + 63) / 64), dim3(64), lds, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS,
-		(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag, 1,
-		e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
+	if (!lw) return -1;
+#define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+	hipLaunchKernelGGL(k_vi_tracers<LW_>, dim3((p.ncol + LW_ - 1) / LW_), dim3(64), lds, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS, \
+		(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag, 1, \
+		e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref); } while (0)
+	if (lw == 64) LAUNCH_VT(64); else LAUNCH_VT(32);
+#undef LAUNCH_VT
 	return 0;
 }
 
@@ -1106,6 +1122,134 @@ void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt) 
 	const double pscal = p.p0 * pow(p.Rd / p.p0, gamma);
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
 	hipLaunchKernelGGL(k_held_suarez, grd, blk, 0, e->stream, p, x, dt, gamma, kappa, pscal);
+}
+
+// Column physics: KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285) around SUBROUTINE KESSLER
+// (test/dcmip2016/interface/kessler.f90:64-185), Lorenz staggering / FORMULATION_RHOTHETA_PI; tracers 0,1,2 = RhoQv,
+// RhoQc, RhoQr.  One lane per stored column (the reference visits every interior node of a patch, duplicated element-edge
+// nodes included), three sweeps over the levels; the column's work arrays live in an HBM scratch [8][L][NS] (coalesced
+// across lanes) instead of the Fortran automatic arrays.  The arithmetic is the subroutine's as the reference's build
+// compiles it (mk/defs.make:35: no default-real-8 flag): r, rhalf, velqr, sed, pc are SINGLE precision, real literals
+// without d0 are single precision values promoted to double, AMAX1 / AMIN1 convert their arguments to single precision
+// (oracle/tmx_oracle.c:orc_kessler_column is the same restatement, bit for bit against the compiled Fortran).
+// Level k only reads levels k and k+1 of the previous state of the sub-cycle (upstream sedimentation), so the
+// sedimentation term is formed on the fly while sweeping upwards.
+__device__ __forceinline__ double kes_amax1(double a, double b) { const float x = (float)a, y = (float)b; return (double)((x > y) ? x : y); }
+__device__ __forceinline__ double kes_amin1(double a, double b, double c) {
+	const float x = (float)a, y = (float)b, z = (float)c;
+	const float m = (x < y) ? x : y;
+	return (double)((m < z) ? m : z);
+}
+__device__ __forceinline__ float kes_velqr(double qr, float r, float rhalf) {
+	return (float)(36.34 * pow(qr * (double)r, (double)0.1364f) * (double)rhalf);      // kessler.f90:113, :170
+}
+
+enum { KES_TH = 0, KES_QV, KES_QC, KES_QR, KES_PK, KES_RHOD, KES_PC, KES_VEL, KES_NF };
+
+__global__ __launch_bounds__(256) void k_kessler(KParams p, double * __restrict__ x, const double * __restrict__ zlev,
+	double * __restrict__ w, double * __restrict__ prect, double dt, double gamma, double pscal)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= p.ncol) return;
+#define WK(f, k) w[((size_t)(f) * L + (k)) * NS + col]
+	const double xk = .2875, psl = 1000.0, rhoqr = 1000.0, f2x = 17.27;
+	const double f5 = 237.3 * f2x * 2500000.0 / 1003.0;
+	const double inv_xk = (double)1.0f / xk;
+	// ---- KesslerPhysics.cpp:147-220: column inputs; kessler.f90:107-123: r, rhalf, pc, velqr, CFL limit ----
+	double rhod0 = 0.0, dt_max = dt;
+	float vel_prev = 0.0f; double z_prev = 0.0;
+	for (int k = 0; k < L; k++) {
+		const double rho = x[(size_t)TMX_SLAB_R(L, k) * NS + col], rt = x[(size_t)TMX_SLAB_T(L, k) * NS + col];
+		const double t0 = x[(size_t)TMX_SLAB_Q(L, 0, k) * NS + col], t1 = x[(size_t)TMX_SLAB_Q(L, 1, k) * NS + col], t2 = x[(size_t)TMX_SLAB_Q(L, 2, k) * NS + col];
+		const double thv = rt / rho;
+		const double rhod = rho - t0 - t1 - t2;
+		const double pr = pscal * tmx_ref_exp(tmx_ref_log(rho * thv) * gamma);
+		const double tv = pr / (rho * p.Rd);
+		double qv = t0 / rho; if (qv < 0.0) qv = 0.0;
+		double qc = t1 / rho; if (qc < 0.0) qc = 0.0;
+		double qr = t2 / rho; if (qr < 0.0) qr = 0.0;
+		const double th = thv / (1.0 + 0.61 * qv);
+		const double pk = tv / thv;
+		if (k == 0) rhod0 = rhod;
+		const float r = (float)(0.001 * rhod);
+		const float rhalf = (float)sqrt(rhod0 / rhod);
+		const float pc = (float)(3.8 / (pow(pk, inv_xk) * psl));
+		const float vel = kes_velqr(qr, r, rhalf);
+		const double z = zlev[(size_t)k * NS + col];
+		if (k > 0 && vel_prev != 0.0f) { const double c = 0.8 * (z - z_prev) / (double)vel_prev; dt_max = (dt_max < c) ? dt_max : c; }
+		vel_prev = vel; z_prev = z;
+		WK(KES_TH, k) = th; WK(KES_QV, k) = qv; WK(KES_QC, k) = qc; WK(KES_QR, k) = qr;
+		WK(KES_PK, k) = pk; WK(KES_RHOD, k) = rhod; WK(KES_PC, k) = (double)pc; WK(KES_VEL, k) = (double)vel;
+	}
+	const int rainsplit = (int)ceil(dt / dt_max);           // kessler.f90:126-127
+	const double dt0 = dt / (double)rainsplit;
+	double precl = 0.0;
+	for (int nt = 1; nt <= rainsplit; nt++) {
+		// level k of the sweep needs the PREVIOUS values of level k+1: they are read before level k+1 is updated
+		double qr_k = WK(KES_QR, 0), rhod_k = WK(KES_RHOD, 0), z_k = zlev[col];
+		float vel_k = (float)WK(KES_VEL, 0), r_k = (float)(0.001 * rhod_k);
+		precl = precl + rhod_k * qr_k * (double)vel_k / rhoqr;          // :135
+		double z_km = 0.0;
+		for (int k = 0; k < L; k++) {
+			float sed;
+			double qr_n = 0.0, rhod_n = 0.0, z_n = 0.0; float vel_n = 0.0f, r_n = 0.0f;
+			if (k < L - 1) {
+				qr_n = WK(KES_QR, k + 1); rhod_n = WK(KES_RHOD, k + 1); z_n = zlev[(size_t)(k + 1) * NS + col];
+				vel_n = (float)WK(KES_VEL, k + 1); r_n = (float)(0.001 * rhod_n);
+				sed = (float)(dt0 * ((double)r_n * qr_n * (double)vel_n - (double)r_k * qr_k * (double)vel_k) / ((double)r_k * (z_n - z_k)));     // :139-141
+			} else {
+				sed = (float)(-dt0 * qr_k * (double)vel_k / ((double)0.5f * (z_k - z_km)));       // :142
+			}
+			double th = WK(KES_TH, k), qv = WK(KES_QV, k), qc = WK(KES_QC, k), qr = qr_k;
+			const double pk = WK(KES_PK, k), pc = WK(KES_PC, k);
+			// :147-165
+			const double qrprod = qc - (qc - dt0 * kes_amax1((double)0.001f * (qc - .001), 0.0)) / (1.0 + dt0 * 2.2 * pow(qr, (double)0.875f));
+			qc = kes_amax1(qc - qrprod, 0.0);
+			qr = kes_amax1(qr + qrprod + (double)sed, 0.0);
+			const double pt = pk * th;
+			const double qvs = pc * tmx_ref_exp(f2x * (pt - 273.0) / (pt - 36.0));
+			const double pt36 = pt - 36.0;
+			const double prod = (qv - qvs) / (1.0 + qvs * f5 / (pt36 * pt36));
+			const double rq = (double)r_k * qr;
+			const double dimv = (qvs - qv > 0.0) ? qvs - qv : 0.0;
+			const double ern = kes_amin1(dt0 * (((1.6 + 124.9 * pow(rq, (double)0.2046f)) * pow(rq, (double)0.525f))
+					/ (2550000.0 * pc / (3.8 * qvs) + 540000.0)) * (dimv / ((double)r_k * qvs)),
+				kes_amax1(-prod - qc, 0.0), qr);
+			const double mx = (prod > -qc) ? prod : -qc;
+			th = th + 2500000.0 / (1003.0 * pk) * (kes_amax1(prod, -qc) - ern);
+			qv = kes_amax1(qv - mx + ern, 0.0);
+			qc = qc + mx;
+			qr = qr - ern;
+			WK(KES_TH, k) = th; WK(KES_QV, k) = qv; WK(KES_QC, k) = qc; WK(KES_QR, k) = qr;
+			if (nt != rainsplit) {                                        // :168-172
+				const float rhalf = (float)sqrt(rhod0 / rhod_k);
+				WK(KES_VEL, k) = (double)kes_velqr(qr, r_k, rhalf);
+			}
+			z_km = z_k;
+			qr_k = qr_n; rhod_k = rhod_n; z_k = z_n; vel_k = vel_n; r_k = r_n;
+		}
+	}
+	precl = precl / (double)rainsplit;
+	prect[col] += precl * dt;                                           // KesslerPhysics.cpp:234
+	// ---- KesslerPhysics.cpp:237-271: back to densities ----
+	for (int k = 0; k < L; k++) {
+		const double qv = WK(KES_QV, k), qc = WK(KES_QC, k), qr = WK(KES_QR, k), th = WK(KES_TH, k);
+		const double rho = WK(KES_RHOD, k) / (1.0 - qv - qc - qr);
+		x[(size_t)TMX_SLAB_R(L, k) * NS + col] = rho;
+		x[(size_t)TMX_SLAB_Q(L, 0, k) * NS + col] = qv * rho;
+		x[(size_t)TMX_SLAB_Q(L, 1, k) * NS + col] = qc * rho;
+		x[(size_t)TMX_SLAB_Q(L, 2, k) * NS + col] = qr * rho;
+		x[(size_t)TMX_SLAB_T(L, k) * NS + col] = rho * th * (1.0 + 0.61 * qv);
+	}
+#undef WK
+}
+
+void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt) {
+	const double gamma = p.cp / (p.cp - p.Rd);
+	const double pscal = p.p0 * pow(p.Rd / p.p0, gamma);
+	hipLaunchKernelGGL(k_kessler, dim3((p.ncol + 255) / 256), dim3(256), 0, e->stream, p, x, (const double *)e->d_zlev, e->d_kes, e->d_prect, dt, gamma, pscal);
 }
 
 // gather the copies other ranks need into the send buffer, one contiguous message per peer:

@@ -962,6 +962,47 @@ class ScharMountainSphere:
         return [u, zero.copy(), phys.rhotheta_from_pressure(p) / rho, zero.copy(), rho]
 
 
+class FlatPlanetCase:
+    """Grid set-up of the stock tests whose STATE is taken from reference dumps rather than synthesised: flat topography,
+    planet reduced by X, rotation on or off, optional uniform diffusion / Rayleigh layer flags.  Used for the DCMIP2016
+    supercell (test/dcmip2016/SupercellTest.cpp:99-113, 285-286: X = 120, no rotation, K = 1500 / 500 m^2/s, reference
+    length / X; its initial state comes out of Fortran, interface/supercell_test.f90) and for the Held-Suarez test
+    (test/nonhydro_sphere/HeldSuarezTest.cpp: X = 1, ztop 35 km, Rayleigh strength 0.0 x profile (:319), initial state
+    perturbed with rand()).  evaluate_pointwise returns a resting isothermal placeholder."""
+
+    def __init__(self, ztop, X=1.0, rotating=True, ntracers=0, udiff=None, rayleigh=False, scale_reference_length=None):
+        self.ztop, self.X, self.rotating, self.ntracers = ztop, X, rotating, ntracers
+        if udiff is not None:
+            self.uniform_diffusion = tuple(udiff)
+        self.has_rayleigh_friction = bool(rayleigh)
+        self._ref_scale = scale_reference_length
+
+    @property
+    def reference_length(self):
+        return None if self._ref_scale is None else 0.5 * math.pi / 30.0 * self._ref_scale
+
+    def evaluate_physical_constants(self, phys):
+        if not self.rotating:
+            phys.omega = 0.0
+        phys.earth_radius = phys.earth_radius / self.X
+
+    def evaluate_topography(self, phys, lon, lat):
+        return np.zeros_like(lon)
+
+    def evaluate_rayleigh_strength(self, z):
+        return np.zeros_like(z)
+
+    def evaluate_tracers(self, phys, z, lon, lat, rho):
+        return [np.zeros_like(z) for _ in range(self.ntracers)]
+
+    def evaluate_pointwise(self, phys, z, lon, lat, reference=False):
+        H = phys.Rd * 280.0 / phys.g
+        p = phys.p0 * np.exp(-z / H)
+        rho = p / phys.g / H
+        zero = np.zeros_like(z)
+        return [zero.copy(), zero.copy(), phys.rhotheta_from_pressure(p) / rho, zero.copy(), rho]
+
+
 class ShallowWaterTest2:
     """Williamson et al. (1992) test 2, steady geostrophic flow, as evaluated by
     test/shallowwater_sphere/SWTest2.cpp:59-118 (defaults of its command line: h0, u0, alpha = 0)."""

@@ -108,6 +108,9 @@ def load_library():
     lib.tmx_h_substep_after_subcycle_count.argtypes = [C.c_void_p]
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.tmx_set_patch_level_heights.argtypes = [C.c_void_p, C.c_int, PD]
+    lib.tmx_physics_kessler.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.tmx_download_precipitation.argtypes = [C.c_void_p, C.c_int, PD, C.c_int]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_download_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
@@ -297,6 +300,25 @@ class Engine:
     def held_suarez(self, instance, dt):
         """HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301)."""
         self._chk(self.lib.tmx_physics_held_suarez(self.h, instance, dt))
+
+    def set_level_heights(self, z_levels=None):
+        """``z_levels[p] = [na][nb][L]`` (GridPatch::GetZLevels); default: the grid's own."""
+        for p in self.local_patches:
+            z = np.ascontiguousarray(self.grid.patches[p].geom["z_levels"] if z_levels is None else z_levels[p], dtype=np.float64)
+            self._chk(self.lib.tmx_set_patch_level_heights(self.h, p, _pd(z)))
+
+    def kessler(self, instance, dt):
+        """KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285 + interface/kessler.f90)."""
+        self._chk(self.lib.tmx_physics_kessler(self.h, instance, dt))
+
+    def download_precipitation(self, reset=False):
+        out = {}
+        for p in self.local_patches:
+            P = self.grid.patches[p]
+            a = np.zeros((P.na, P.nb))
+            self._chk(self.lib.tmx_download_precipitation(self.h, p, _pd(a), 1 if reset else 0))
+            out[p] = a
+        return out
 
     def upload_tracers(self, instance, tracers):
         """``tracers[p] = [n_tracers][na][nb][L]`` (GridPatch::GetDataTracers) for every patch (remote ones ignored)."""

@@ -21,6 +21,14 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
                           per-point coefficients, state and outputs for the flag combinations
   physics_hs_ne2_L30_p6.npz   HeldSuarezPhysics::Perform input/output (SURVEY 8f-1)
   steps100_ne4_L10_p6.npz north-star gate: state after 2 warm-up steps and after 100 further ARS343 steps (ne4, L10)
+  supercell_ne2_L40_p6.npz  BASELINE config 4, the stock DCMIP2016 supercell (test/dcmip2016/SupercellTest.cpp + Kessler
+                          microphysics, Fortran halves compiled with amdflang -O3): reference state, state after 2 steps
+                          (each followed by KesslerPhysics::Perform), one more Perform call on it, a Perform call on a
+                          moistened copy (test input: all Kessler branches act), and the state after 3 further steps
+  kessler_columns.npz     SUBROUTINE KESSLER (interface/kessler.f90, compiled) on 3 x 96 columns: inputs and outputs
+  heldsuarez_ne3_L60_p6.npz  BASELINE config 5 shape, the stock HeldSuarezTest at L60: state after 2 steps and after 10
+                          further steps, HeldSuarezPhysics::Perform after every step
+  lapack_spread.json      (tests/analysis/lapack_spread.py) reference-vs-reference spread over two LAPACKs
   known_answers.json      area-weighted checksums printed by the reference
 """
 import json
@@ -64,14 +72,107 @@ def compact_states(d, npatch):
     return out
 
 
+def flat_geometry(d):
+    """Geometry, operators and halo transforms of a dump made with --geom 1 on a FLAT grid, with the level-independent
+    3-D metric arrays cut to one level (golden_util.grid_from_fixture broadcasts them back): the reference's own inputs
+    at a few hundred KB, so that the fixture can be compared bit for bit."""
+    keep3 = ("jacobian", "jacobian_redge", "contra_metric_a", "contra_metric_b", "contra_metric_xi", "contra_metric_a_redge",
+             "contra_metric_b_redge", "contra_metric_xi_redge", "deriv_r_node", "deriv_r_redge", "element_area_node")
+    keep2 = ("jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "coriolis_f", "topography", "topography_deriv")
+    out = {}
+    for k, v in d.items():
+        if k.startswith(("grid/", "op/", "halo_trans/", "phys/")):
+            out[k] = v
+        elif k[0] == "p" and "/" in k:
+            nm = k.split("/")[1]
+            if nm in keep2:
+                out[k] = v
+            elif nm in keep3:
+                assert all(np.array_equal(v[:, :, 0], v[:, :, kk]) for kk in range(v.shape[2])), k
+                out[k] = v[:, :, :1].copy()
+    return out
+
+
 def save(name, rec):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **{k.replace("/", "__"): v for k, v in rec.items()})
     print(name, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def gen_supercell(tmp):
+    # BASELINE config 4: the stock supercell with Kessler physics after every step (ne2, L40, dt 0.5 s)
+    sc = ["--case", "supercell", "--explicitvertical", "--physics", "kessler", "--ne", "2", "--levels", "40", "--dt", "0.5"]
+    d, _ = run(sc + ["--mode", "kessler", "--moisten", "1.5", "--warm", "2", "--geom", "1"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("phys/") or k.startswith("grid/")}
+    rec.update(flat_geometry(d))
+    cs = compact_states(d, 6)
+    rec.update({k.replace("kessler_before", "warm"): v for k, v in cs.items() if k.split("/")[1].startswith("kessler")})
+    for p in range(6):
+        for nm in ("ref_node", "ref_redge", "ref_tracers", "kessler_prect"):
+            rec["p%d/%s" % (p, nm)] = d["p%d/%s" % (p, nm)]
+    rec["p0/kessler_z_levels"] = d["p0/kessler_z_levels"]
+    for p in range(6):      # flat topography: one column of heights serves every node
+        assert np.array_equal(d["p%d/kessler_z_levels" % p], np.broadcast_to(d["p0/kessler_z_levels"][1, 1], d["p%d/kessler_z_levels" % p].shape))
+    d2, _ = run(sc + ["--mode", "steps", "--warm", "2", "--steps", "3", "--every", "3", "--geom", "0"], tmp)
+    cs2 = compact_states(d2, 6)
+    for k, v in cs2.items():
+        if k.split("/")[1] == "warm":
+            assert np.array_equal(v, rec[k]), k         # the two runs share their first two steps
+        if k.split("/")[1] == "step3":
+            rec[k] = v
+    rec["checksum/step3"] = d2["checksum/step3"]
+    save("supercell_ne2_L40_p6.npz", rec)
+
+
+def gen_kessler_columns():
+    # SUBROUTINE KESSLER alone (the compiled Fortran, oracle/_ref/libkessler_ref.so) on synthetic columns
+    import ctypes as C
+    kl = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libkessler_ref.so"))
+    PD = C.POINTER(C.c_double)
+    rng = np.random.default_rng(20161)
+    rec = {}
+    for gi, nz in enumerate((12, 40, 60)):
+        ncol = 96
+        inp = np.zeros((7, ncol, nz)); out = np.zeros((4, ncol, nz)); dts = np.zeros(ncol); precl = np.zeros(ncol)
+        for c in range(ncol):
+            dz = rng.uniform(100, 800, nz); z = np.cumsum(dz) - dz / 2
+            pk = np.exp(-z / rng.uniform(7000, 9000)) ** 0.2875
+            theta = rng.uniform(285, 305) + z * rng.uniform(0.002, 0.006) + rng.normal(0, 0.5, nz)
+            rho = rng.uniform(1.0, 1.2) * np.exp(-z / 8000)
+            qv = np.clip(rng.uniform(0, 0.02, nz) * np.exp(-z / 3000), 0, None)
+            mode = c % 4
+            qc = np.where(rng.random(nz) < 0.5, rng.uniform(0, 0.004, nz), 0.0) if mode > 0 else np.zeros(nz)
+            qr = np.where(rng.random(nz) < 0.5, rng.uniform(0, 0.01, nz), 0.0) if mode > 1 else np.zeros(nz)
+            dts[c] = float(rng.choice([0.5, 1.0, 5.0, 30.0, 150.0]))
+            inp[:, c] = (theta, qv, qc, qr, rho, pk, z)
+            a = [np.ascontiguousarray(x) for x in (theta, qv, qc, qr, rho, pk, z)]
+            pr = C.c_double(0); dtc = C.c_double(dts[c]); n = C.c_int(nz)
+            kl.kessler_(*[x.ctypes.data_as(PD) for x in a[:6]], C.byref(dtc), a[6].ctypes.data_as(PD), C.byref(n), C.byref(pr))
+            out[:, c] = a[:4]; precl[c] = pr.value
+        rec["g%d/in" % gi] = inp; rec["g%d/out" % gi] = out; rec["g%d/dt" % gi] = dts; rec["g%d/precl" % gi] = precl
+    save("kessler_columns.npz", rec)
+
+
+def gen_heldsuarez(tmp):
+    # BASELINE config 5 shape: the stock Held-Suarez test at L60 (ne3, dt 200 s), forcing after every step
+    hs = ["--case", "heldsuarez", "--physics", "hs", "--ne", "3", "--levels", "60", "--dt", "200"]
+    d, _ = run(hs + ["--mode", "steps", "--warm", "2", "--steps", "10", "--every", "10", "--geom", "1"], tmp)
+    rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("phys/") or k.startswith("checksum/") or "hs_" in k}
+    rec.update(flat_geometry(d))
+    cs = compact_states(d, 6)
+    rec.update({k: v for k, v in cs.items() if k.split("/")[1] in ("warm", "step10")})
+    save("heldsuarez_ne3_L60_p6.npz", rec)
+
+
+
+
 def main():
     tmp = "/tmp/tmx_golden.tmxd"
+    if len(sys.argv) > 1:       # regenerate only the named fixtures: supercell, kessler, heldsuarez
+        for nm in sys.argv[1:]:
+            {"supercell": lambda: gen_supercell(tmp), "kessler": gen_kessler_columns, "heldsuarez": lambda: gen_heldsuarez(tmp)}[nm]()
+        os.remove(tmp) if os.path.exists(tmp) else None
+        return
     drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge",
             "a_nodes", "b_nodes")
     d, _ = run(["--mode", "percall", "--ne", "3", "--levels", "5", "--dt", "300", "--warm", "2"], tmp)
@@ -177,6 +278,10 @@ def main():
     rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("checksum/")}
     rec.update(compact_states(d, 6))
     save("steps_schar_ne3_L6_p6.npz", rec)
+
+    gen_supercell(tmp)
+    gen_kessler_columns()
+    gen_heldsuarez(tmp)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

@@ -1,7 +1,8 @@
 """Helpers shared by the parity tests: fixture loading and grid construction."""
 import os
 import numpy as np
-from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW, BaroclinicWaveJWSmallPlanet, ScharMountainSphere
+from tempestmodel_amd.cubed_sphere import (CubedSphereGrid, BaroclinicWaveJW, BaroclinicWaveJWSmallPlanet, ScharMountainSphere,
+                                           FlatPlanetCase)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -35,6 +36,10 @@ def make_grid(ne, L, npatch, ztop=30000.0, pert="exp", case="jw", ntracers=0):
         test = BaroclinicWaveJW(0.0, ztop, pert, ntracers=ntracers)
     elif case == "smallplanet":
         test = BaroclinicWaveJWSmallPlanet(ztop, pert, ntracers=ntracers)
+    elif case == "supercell":       # SupercellTest.cpp: X = 120, no rotation, uniform diffusion, reference length / X
+        test = FlatPlanetCase(ztop, X=120.0, rotating=False, ntracers=3, udiff=(1500.0, 500.0), scale_reference_length=1.0 / 120.0)
+    elif case == "heldsuarez":      # HeldSuarezTest.cpp: HasRayleighFriction() with strength 0.0 x profile
+        test = FlatPlanetCase(ztop, rayleigh=True)
     else:
         test = ScharMountainSphere(ztop=ztop)
     states = g.evaluate_test_case(test)
@@ -52,7 +57,12 @@ def grid_from_fixture(d, override=True, case="jw", ntracers=0):
             for nm in list(P.geom):
                 k = "p%d/%s" % (P.index, nm)
                 if k in d:
-                    P.geom[nm] = d[k]
+                    v = d[k]
+                    have = np.shape(P.geom[nm])
+                    if v.ndim >= 3 and v.shape != have and v.shape[2] == 1:
+                        # flat topography: the fixture keeps ONE level of the level-independent 3-D arrays
+                        v = np.broadcast_to(v, have).copy()
+                    P.geom[nm] = v
         for nm in g.ops:
             g.ops[nm] = (d["op/%s/coeff" % nm], d["op/%s/begin" % nm], d["op/%s/end" % nm])
         g.dx = d["op/dx_basis_1d"]

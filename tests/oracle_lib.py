@@ -279,8 +279,29 @@ class Oracle:
     def held_suarez(self, ix, dt):
         lib().orc_held_suarez(C.byref(self.cgrid), C.byref(self.cstate), ix, C.c_double(dt))
 
+    def kessler(self, ix, dt, z_levels, prect=None):
+        """KesslerPhysics::Perform on instance ix; z_levels: per patch [na][nb][L]; prect: per patch [na][nb], accumulated in place."""
+        zl = [np.ascontiguousarray(z, dtype=np.float64) for z in z_levels]
+        zp = (PD * self.npatch)(*[_pd(z) for z in zl])
+        pp = None
+        if prect is not None:
+            for a in prect:
+                assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+            pp = (PD * self.npatch)(*[_pd(a) for a in prect])
+        lib().orc_kessler(C.byref(self.cgrid), C.byref(self.cstate), ix, C.c_double(dt), zp, pp)
+
     def v_step_implicit_terms_explicitly(self, iinit, iupd, dt):
         lib().orc_v_step_implicit_terms_explicitly(C.byref(self.cgrid), C.byref(self.cstate), iinit, iupd, C.c_double(dt))
+
+
+def kessler_column(theta, qv, qc, qr, rho, pk, dt, z):
+    """orc_kessler_column on copies; returns (theta, qv, qc, qr, precl)."""
+    a = [np.ascontiguousarray(x, dtype=np.float64).copy() for x in (theta, qv, qc, qr)]
+    b = [np.ascontiguousarray(x, dtype=np.float64) for x in (rho, pk, z)]
+    pr = C.c_double(0.0)
+    lib().orc_kessler_column(_pd(a[0]), _pd(a[1]), _pd(a[2]), _pd(a[3]), _pd(b[0]), _pd(b[1]), C.c_double(dt), _pd(b[2]),
+                             C.c_int(len(a[0])), C.byref(pr))
+    return a[0], a[1], a[2], a[3], pr.value
 
 
 def dgbsv(ab, b, kl, ku):

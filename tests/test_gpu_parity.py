@@ -901,3 +901,80 @@ def test_multirank_supercell_configuration_loopback(scheme):
         single.close()
         for e in ranks:
             e.close()
+
+
+# ---- BASELINE config 4: the stock DCMIP2016 supercell with Kessler microphysics -------------------------------
+
+def _supercell_case():
+    d = gu.load("supercell_ne2_L40_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, case="supercell")      # the reference's own (flat) geometry
+    for P in g.patches:
+        for nm in ("ref_node", "ref_redge", "ref_tracers"):
+            P.geom[nm] = d["p%d/%s" % (P.index, nm)]
+    return d, g
+
+
+def test_kessler_physics_on_the_supercell_state():
+    """KesslerPhysics::Perform on the device against the reference dump: the stock supercell state after 2 steps
+    (no cloud yet: nearly the identity) and a moistened copy on which every branch of SUBROUTINE KESSLER acts.  The
+    device differs from the reference only through ocml's pow (exp / log / sqrt are the reference's): rounding level,
+    with the single-precision locals of the Fortran at most flipping an ulp of a REAL(4) now and then."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d, g = _supercell_case()
+    dt = float(d["cfg/dt"][0])
+    e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0))
+    try:
+        e.set_level_heights()
+        for before, after in (("warm", "kessler_after"), ("kessler_moist_before", "kessler_moist_after")):
+            st = gu.expand_compact(d, before, g); tr = gu.expand_compact_tracers(d, before, g)
+            e.upload_state(0, st); e.upload_tracers(0, tr)
+            o = Oracle(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0))
+            o.set_state(0, st); o.set_tracers(0, tr)
+            o.kessler(0, dt, [P.geom["z_levels"] for P in g.patches])
+            e.kessler(0, dt); e.sync()
+            gs, gt = e.download_state(0), e.download_tracers(0)
+            errs_o = gu.prognostic_errors(gs, o.get_state(0)); terr_o = gu.tracer_errors(gt, o.get_tracers(0))
+            errs_r = gu.prognostic_errors(gs, gu.expand_compact(d, after, g)); terr_r = gu.tracer_errors(gt, gu.expand_compact_tracers(d, after, g))
+            print(after, "vs oracle", errs_o, terr_o, "vs reference", errs_r, terr_r)
+            assert max(errs_o) < 1e-12 and max(errs_r) < 1e-12, (after, errs_o, errs_r)
+            assert max(terr_o) < 1e-9 and max(terr_r) < 1e-9, (after, terr_o, terr_r)
+        pr = e.download_precipitation()
+        for P in g.patches:
+            ref = d["p%d/kessler_prect" % P.index][0][1:-1, 1:-1]
+            assert np.max(np.abs(pr[P.index][1:-1, 1:-1] - ref)) <= 1e-9 * max(np.max(ref), 1e-300)
+        assert max(float(np.max(a)) for a in pr.values()) > 1e-6
+    finally:
+        e.close()
+
+
+def test_supercell_steps_with_kessler():
+    """BASELINE config 4 end to end at ne2 L40: SupercellTest's own state (reference dump after 2 steps), 3 ARS343 steps
+    with uniform diffusion, fully explicit vertical dynamics, three tracers, nu = 0, KesslerPhysics::Perform after every
+    step (Model.cpp:470-481) -- against the oracle on identical inputs and against the reference's state."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d, g = _supercell_case()
+    dt = float(d["cfg/dt"][0])
+    st = gu.expand_compact(d, "warm", g); tr = gu.expand_compact_tracers(d, "warm", g)
+    o = Oracle(g, nu=(0.0, 0.0, 0.0), fully_explicit=True, uniform_diffusion=(1500.0, 500.0))
+    o.set_state(0, st); o.set_tracers(0, tr)
+    e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0))
+    try:
+        e.set_level_heights()
+        e.upload_state(0, st); e.upload_tracers(0, tr)
+        zl = [P.geom["z_levels"] for P in g.patches]
+        for _ in range(3):
+            assert o.step_ars343(dt) == 0
+            o.kessler(0, dt, zl)
+            e.step_ars343(dt)
+            e.kessler(0, dt)
+        e.sync()
+        gs, gt = e.download_state(0), e.download_tracers(0)
+        errs_o = gu.prognostic_errors(gs, o.get_state(0)); terr_o = gu.tracer_errors(gt, o.get_tracers(0))
+        errs_r = gu.prognostic_errors(gs, gu.expand_compact(d, "step3", g)); terr_r = gu.tracer_errors(gt, gu.expand_compact_tracers(d, "step3", g))
+        print("supercell 3 steps vs oracle", errs_o, terr_o, "vs reference", errs_r, terr_r)
+        assert max(errs_o) < TOL_STEPS and max(errs_r) < TOL_STEPS
+        assert max(terr_o[:1]) < TOL_STEPS and max(terr_r[:1]) < TOL_STEPS
+    finally:
+        e.close()

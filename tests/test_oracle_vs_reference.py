@@ -393,3 +393,99 @@ def test_lu_fma_switch():
     finally:
         lib().orc_set_lu_fma(1)
     assert out[1] == 0.0 and 0.0 < out[0] < 1e-12, out
+
+
+# ---- BASELINE config 4: DCMIP2016 supercell with Kessler microphysics -------------------------------------------
+
+def test_kessler_column_known_answers():
+    """orc_kessler_column against SUBROUTINE KESSLER as the reference's build compiles it (amdflang -O3, mixed single /
+    double precision): 3 x 96 columns (12, 40, 60 levels; dry, cloudy, raining; dt 0.5 .. 150 s so that the rain
+    sub-cycling acts), bit for bit."""
+    from oracle_lib import kessler_column
+    d = gu.load("kessler_columns.npz")
+    split = 0
+    for gi in range(3):
+        inp, out, dts, precl = d["g%d/in" % gi], d["g%d/out" % gi], d["g%d/dt" % gi], d["g%d/precl" % gi]
+        for c in range(inp.shape[1]):
+            th, qv, qc, qr, pr = kessler_column(*inp[:6, c], dts[c], inp[6, c])
+            for got, ref in zip((th, qv, qc, qr), out[:, c]):
+                assert np.array_equal(got, ref), (gi, c)
+            assert pr == precl[c]
+            split += int(np.any(out[3, c] != inp[3, c]))
+    assert split > 100          # rain changed in most columns
+
+
+def _supercell():
+    d = gu.load("supercell_ne2_L40_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, case="supercell")      # the reference's own (flat) geometry
+    assert g.L == 40 and abs(g.ztop - 20000.0) < 1e-9
+    for P in g.patches:
+        for nm in ("ref_node", "ref_redge", "ref_tracers"):
+            P.geom[nm] = d["p%d/%s" % (P.index, nm)]
+        # flat topography: the reference's level heights are one column, and the synthesised ones equal them
+        zl = np.broadcast_to(d["p0/kessler_z_levels"][1, 1], P.geom["z_levels"].shape)
+        assert np.array_equal(P.geom["z_levels"], zl)
+    return d, g
+
+
+def test_kessler_physics_on_the_supercell_state():
+    """KesslerPhysics::Perform on the stock supercell state after 2 steps (nearly a no-op there: no cloud yet) and on a
+    moistened copy where condensation, autoconversion, accretion, sedimentation and evaporation all act: bit for bit."""
+    d, g = _supercell()
+    dt = float(d["cfg/dt"][0])
+    for before, after in (("warm", "kessler_after"), ("kessler_moist_before", "kessler_moist_after")):
+        o = Oracle(g, fully_explicit=True, uniform_diffusion=UDIFF)
+        o.set_state(0, gu.expand_compact(d, before, g)); o.set_tracers(0, gu.expand_compact_tracers(d, before, g))
+        prect = [np.zeros((P.na, P.nb)) for P in g.patches]
+        o.kessler(0, dt, [P.geom["z_levels"] for P in g.patches], prect)
+        want = gu.expand_compact(d, after, g)
+        assert max(gu.prognostic_errors(o.get_state(0), want)) == 0.0, after
+        assert max(gu.tracer_errors(o.get_tracers(0), gu.expand_compact_tracers(d, after, g))) == 0.0, after
+    # accumulated precipitation after both calls (UserData2D "PRECT", KesslerPhysics.cpp:234): second call only rains
+    got = max(float(np.max(p_)) for p_ in prect)
+    assert got > 1e-6
+    for P, a in zip(g.patches, prect):
+        assert np.array_equal(a[1:-1, 1:-1], d["p%d/kessler_prect" % P.index][0][1:-1, 1:-1])
+    changed = gu.prognostic_errors(gu.expand_compact(d, "kessler_moist_after", g), gu.expand_compact(d, "kessler_moist_before", g))
+    assert changed[2] > 1e-3 and changed[4] > 1e-6          # rho*theta and rho moved
+
+
+def test_supercell_steps_with_kessler():
+    """The stock supercell end to end: 3 ARS343 steps (uniform diffusion, fully explicit vertical dynamics, nu = 0),
+    KesslerPhysics::Perform after every step as Model::Go does (Model.cpp:470-481), from the reference's state after 2
+    such steps, on the reference's own grid: bit for bit."""
+    d, g = _supercell()
+    dt = float(d["cfg/dt"][0])
+    assert float(d["cfg/nu"][0]) == 0.0 and int(d["cfg/fully_explicit"][0]) == 1 and int(d["cfg/ntracers"][0]) == 3
+    o = Oracle(g, nu=(0.0, 0.0, 0.0), fully_explicit=True, uniform_diffusion=UDIFF)
+    o.set_state(0, gu.expand_compact(d, "warm", g)); o.set_tracers(0, gu.expand_compact_tracers(d, "warm", g))
+    zl = [P.geom["z_levels"] for P in g.patches]
+    for _ in range(3):
+        assert o.step_ars343(dt) == 0
+        o.kessler(0, dt, zl)
+    errs = gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step3", g))
+    terr = gu.tracer_errors(o.get_tracers(0), gu.expand_compact_tracers(d, "step3", g))
+    assert max(errs) == 0.0, errs
+    assert max(terr) == 0.0, terr
+
+
+# ---- BASELINE config 5 shape: Held-Suarez at L60 ---------------------------------------------------------------
+
+def test_held_suarez_steps_L60():
+    """The stock HeldSuarezTest (ztop 35 km, Rayleigh layer of strength zero, ARS343 dt 200 s) at ne3 L60: 10 steps of
+    dynamics + HeldSuarezPhysics::Perform after every step from the reference's state after 2 such steps."""
+    d = gu.load("heldsuarez_ne3_L60_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, case="heldsuarez")     # the reference's own (flat) geometry
+    assert g.L == 60 and abs(g.ztop - 35000.0) < 1e-9
+    for P in g.patches:
+        P.geom["hs_surface_pressure"] = d["p%d/hs_surface_pressure" % P.index]
+        assert np.max(np.abs(P.lat - d["p%d/hs_latitude" % P.index])[1:-1, 1:-1]) < 1e-15
+        P.lat = d["p%d/hs_latitude" % P.index]          # the reference's own latitudes (the forcing takes sin / cos of them)
+    dt = float(d["cfg/dt"][0])
+    o = Oracle(g)
+    o.set_state(0, gu.expand_compact(d, "warm", g))
+    for _ in range(10):
+        assert o.step_ars343(dt) == 0
+        o.held_suarez(0, dt)
+    errs = gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step10", g))
+    assert max(errs) == 0.0, errs           # bit for bit
