@@ -291,8 +291,11 @@ int tmx_v_filter_negative_tracers(tmx_engine * e, int instance);
 /* Per owned patch: latitude [na][nb] (GridPatch::GetLatitude) and the "surface pressure" [na][nb] that
  * HeldSuarezPhysics::Perform forms as PhysicalConstants::PressureFromRhoTheta(REdge[rho][i][j][0] * REdge[rhotheta][i][j][0])
  * (src/atm/HeldSuarezPhysics.cpp:99-101).  With Lorenz staggering nothing on this path updates those interface
- * slots after the test case filled them, and the engine does not store them, so the caller evaluates the
- * expression on its own arrays (the adapter does, with the reference's PhysicalConstants) and hands it over. */
+ * slots except Grid::CopyData / ZeroData / LinearCombineData, which run over whole arrays and so change them by one
+ * rounding per combination.  surface_pressure == NULL (recommended, what the adapter passes): the engine carries those two
+ * entries per column ("surface slots", taken from the redge array of tmx_upload_state and written back by
+ * tmx_download_state) through the same stage algebra and forms the pressure from them, bit for bit as the reference;
+ * surface_pressure != NULL pins the value the caller computed (constant in time).  All patches use one mode. */
 int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const double * latitude, const double * surface_pressure);
 /* HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301) on `instance` with dDeltaT = dt: backward-Euler
  * boundary-layer friction on U,V and the relaxation of rho*theta towards the Held-Suarez equilibrium temperature.

@@ -1304,8 +1304,10 @@ void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int
 /* (rho*theta on levels).  Boundary-layer friction on U,V by backward Euler, Newtonian relaxation of       */
 /* rho*theta towards the Held-Suarez equilibrium temperature with the "Ullrich update" (:239-247).         */
 /* Quirks of the reference kept as they are: the friction's sigma uses PressureFromRhoTheta(rho * rhotheta) */
-/* (:107-110), and the surface pressure comes from the interface slots of rho and rho*theta (:99-101),     */
-/* which nothing updates with this staggering -- it is an input here (orc_patch.surf_p).                   */
+/* (:107-110), and the surface pressure comes from the interface slots of rho and rho*theta (:113-116),    */
+/* scratch entries with this staggering that only the whole-array stage algebra (orc_copy / orc_zero /      */
+/* orc_linear_combine, as Grid::CopyData ...) touches -- read here exactly as the reference reads them.     */
+/* orc_patch.surf_p, when not NULL, pins the value instead (tests of the forcing in isolation).             */
 
 void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt) {
 	const int L = g->L;
@@ -1317,10 +1319,13 @@ void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt) {
 		const orc_patch * P = &g->patches[p];
 		const int na = P->na, nb = P->nb;
 		double * nn = s->node[ix * g->npatch + p];
+		const double * ee = s->redge[ix * g->npatch + p];
 #define NN(c,i,j,k) nn[(((size_t)(c) * na + (i)) * nb + (j)) * L + (k)]
+#define EE(c,i,j,k) ee[(((size_t)(c) * na + (i)) * nb + (j)) * (L + 1) + (k)]
 		for (int i = 1; i < na - 1; i++)
 		for (int j = 1; j < nb - 1; j++) {
-			const double ps = P->surf_p[(size_t)i * nb + j];
+			const double ps = P->surf_p ? P->surf_p[(size_t)i * nb + j]
+				: pscal * exp(log(EE(RIx, i, j, 0) * EE(PIx, i, j, 0)) * gamma);
 			for (int k = 0; k < L; k++) {
 				const double pr = pscal * exp(log(NN(RIx, i, j, k) * NN(PIx, i, j, k)) * gamma);
 				const double sigma = pr / ps;
@@ -1348,6 +1353,7 @@ void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt) {
 			}
 		}
 #undef NN
+#undef EE
 	}
 }
 

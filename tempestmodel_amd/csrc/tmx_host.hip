@@ -281,7 +281,9 @@ static int ensure_layout(tmx_engine * e) {
 	e->ne_local = ne;
 	e->ncol = ne * TMX_NQ;
 	e->NS = ((e->ncol + TMX_TILE - 1) / TMX_TILE) * TMX_TILE;
-	e->inst_stride = (size_t)e->nslab * e->NS;
+	// + 2 "surface slots" behind the exchanged slabs: the interface-level-0 entries of rho and rho*theta of the reference's
+	// REdge array, which nothing but the stage algebra touches and HeldSuarezPhysics reads (see surface_copy below)
+	e->inst_stride = (size_t)(e->nslab + 2) * e->NS;
 	const size_t NS = e->NS; const int L = e->L;
 	e->h_g2d.assign((size_t)G2_COUNT * NS, 0.0);
 	e->h_g3n.assign((size_t)G3N_COUNT * L * NS, 0.0);
@@ -431,7 +433,11 @@ extern "C" int tmx_set_patch_metric_factors(tmx_engine * e, int patch, const dou
 
 // Column physics inputs (latitude, Held-Suarez surface pressure) into two 2-D slabs
 extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const double * latitude, const double * surface_pressure) {
-	REQUIRE(e && latitude && surface_pressure, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs: null argument");
+	REQUIRE(e && latitude, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs: null argument");
+	// surface_pressure == NULL: the forcing forms it from the tracked surface slots, as the reference does (see surface_copy)
+	REQUIRE(e->patches_with_physics == 0 || e->track_surface == (surface_pressure == nullptr), TMX_ERR_INVALID,
+		"tmx_set_patch_physics_inputs: every patch must use the same surface-pressure mode");
+	e->track_surface = (surface_pressure == nullptr);
 	REQUIRE(patch >= 0 && patch < e->cfg.n_patches, TMX_ERR_INVALID, "patch index out of range");
 	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "column physics with the shallow-water equation set is not supported");
 	int r = ensure_layout(e);
@@ -445,7 +451,7 @@ extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const dou
 	for (int j = 1; j < P.nb - 1; j++) {
 		const int c = col_of(P, i, j);
 		lat[c - c0] = latitude[(size_t)i * P.nb + j];
-		ps[c - c0] = surface_pressure[(size_t)i * P.nb + j];
+		ps[c - c0] = surface_pressure ? surface_pressure[(size_t)i * P.nb + j] : 0.0;
 		if (!e->finalized) { e->h_g2d[G2_LAT * NS + c] = lat[c - c0]; e->h_g2d[G2_PS * NS + c] = ps[c - c0]; }
 	}
 	if (e->finalized && !plan_only(e)) {       // may be refreshed at any time (the caller owns the source arrays)
@@ -453,6 +459,7 @@ extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const dou
 		HIPCHK(hipMemcpy(e->d_g2d + G2_LAT * NS + c0, lat.data(), lat.size() * sizeof(double), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(e->d_g2d + G2_PS * NS + c0, ps.data(), ps.size() * sizeof(double), hipMemcpyHostToDevice));
 	}
+	if (!P.physics_set) e->patches_with_physics++;
 	P.physics_set = true;
 	return TMX_OK;
 }
@@ -970,6 +977,16 @@ extern "C" int tmx_upload_state(tmx_engine * e, int patch, int instance, const d
 	HIPCHK(hipStreamSynchronize(e->stream));
 	HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + c0, (size_t)e->NS * sizeof(double),
 		buf.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), nstate, hipMemcpyHostToDevice));
+	if (!sw) {
+		// surface slots: interface-level-0 entries of rho (REdge component 4) and rho*theta (component 2), see surface_copy
+		std::vector<double> ss((size_t)2 * ncp);
+		for (int c = 0; c < ncp; c++) {
+			ss[c] = redge[((size_t)4 * nn + hoff[c]) * (L + 1)];
+			ss[(size_t)ncp + c] = redge[((size_t)2 * nn + hoff[c]) * (L + 1)];
+		}
+		HIPCHK(hipMemcpy2D(e->d_state + (size_t)instance * e->inst_stride + (size_t)e->nslab * e->NS + c0, (size_t)e->NS * sizeof(double),
+			ss.data(), (size_t)ncp * sizeof(double), (size_t)ncp * sizeof(double), 2, hipMemcpyHostToDevice));
+	}
 	return TMX_OK;
 }
 
@@ -1032,6 +1049,16 @@ extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, doubl
 	const int * hoff = host_offsets(e, patch).data();
 	const size_t nn = (size_t)na * nb;
 	const bool sw = e->sw;
+	if (!sw && e->track_surface) {
+		// tracked surface slots back into the interface-level-0 entries of rho and rho*theta (see surface_copy)
+		std::vector<double> ss((size_t)2 * ncp);
+		HIPCHK(hipMemcpy2D(ss.data(), (size_t)ncp * sizeof(double), e->d_state + (size_t)instance * e->inst_stride + (size_t)e->nslab * e->NS + c0,
+			(size_t)e->NS * sizeof(double), (size_t)ncp * sizeof(double), 2, hipMemcpyDeviceToHost));
+		for (int c = 0; c < ncp; c++) {
+			redge[((size_t)4 * nn + hoff[c]) * (L + 1)] = ss[c];
+			redge[((size_t)2 * nn + hoff[c]) * (L + 1)] = ss[(size_t)ncp + c];
+		}
+	}
 	host_parallel((ncp + 63) / 64, [&](int ta, int tb) {
 		for (int t = ta; t < tb; t++) {
 			const int ca = t * 64, cb = std::min(ncp, ca + 64);
@@ -1095,6 +1122,34 @@ static int check_inst(tmx_engine * e, int ix) {
 	return TMX_OK;
 }
 static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)ix * e->inst_stride; }
+
+// Surface slots.  HeldSuarezPhysics::Perform forms its "surface pressure" from dataREdge[RIx][i][j][0] *
+// dataREdge[TIx][i][j][0] (HeldSuarezPhysics.cpp:113-116).  With Lorenz staggering rho and rho*theta live on levels and
+// those interface entries are scratch: the test case fills them and afterwards ONLY Grid::CopyData / ZeroData /
+// LinearCombineData -- which run over whole arrays (GridPatch.cpp:1402-1553) -- change them, by a rounding error per
+// combination.  To reproduce the forcing bit for bit the engine carries the two entries per column through the same
+// stage algebra: they sit behind the state of every instance, whole-instance copies / combinations include them for
+// free, and the fused paths below (which never materialise the copy or combination) update them separately -- only
+// when a caller asked for tracked surface slots (tmx_set_patch_physics_inputs with surface_pressure == NULL).
+static double * surface_slots(tmx_engine * e, int ix) { return inst(e, ix) + (size_t)e->nslab * e->NS; }
+static int surface_copy(tmx_engine * e, int src, int dst) {
+	if (!e->track_surface || src == dst) return TMX_OK;
+	HIPCHK(hipMemcpyAsync(surface_slots(e, dst), surface_slots(e, src), (size_t)2 * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	return TMX_OK;
+}
+static int surface_zero(tmx_engine * e, int ix) {
+	if (!e->track_surface) return TMX_OK;
+	HIPCHK(hipMemsetAsync(surface_slots(e, ix), 0, (size_t)2 * e->NS * sizeof(double), e->stream));
+	return TMX_OK;
+}
+static int surface_lincomb(tmx_engine * e, int dst, int n, const double * const * src, const double * cf, int premul) {
+	if (!e->track_surface) return TMX_OK;
+	const size_t off = (size_t)e->nslab * e->NS;
+	const double * s2[12];
+	for (int m = 0; m < n; m++) s2[m] = src[m] + off;
+	tmxk_lincomb(e, (size_t)2 * e->NS, surface_slots(e, dst), n, s2, cf, premul);
+	return TMX_OK;
+}
 
 static int launch_check(const char * what) {
 	hipError_t r = hipGetLastError();
@@ -1207,6 +1262,7 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 		tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	}
 	int r;
+	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
 	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
@@ -1221,6 +1277,7 @@ static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, doub
 	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1);
 	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
 	int r;
+	if ((r = surface_copy(e, ibase, iupd))) return r;       // the folded CopyData(base -> update)
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
 	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
@@ -1231,7 +1288,7 @@ static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, doub
 static int copy_uv(tmx_engine * e, int src, int dst) {
 	ProfScope ps(e, TMX_K_LINCOMB);
 	HIPCHK(hipMemcpyAsync(inst(e, dst), inst(e, src), (size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-	return TMX_OK;
+	return surface_copy(e, src, dst);
 }
 
 extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double dt) {
@@ -1461,6 +1518,7 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	if ((c.nu_scalar == 0.0 && c.nu_div == 0.0 && c.nu_vort == 0.0) || c.hypervis_order == 0) {
 		if ((r = tmx_copy_data(e, iinit, iupd))) return r;
 	} else if (c.hypervis_order == 2) {
+		if ((r = surface_copy(e, iinit, iupd))) return r;       // CopyData(initial -> update), :2663-2664
 		// viscosity (HorizontalDynamicsFEM.cpp:2672-2686): one pass from the initial instance, coefficients not scaled
 		// with the grid spacing; the scalar part runs with +dt and the vector part with -dt, which the kernel's single
 		// dt expresses exactly through the sign of nu_scalar ((-dt) * (-nu) is the same product)
@@ -1471,6 +1529,7 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 	} else {
 		double scale = 1.0;
 		if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
+		if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;     // CopyData :2663, ZeroData :2693
 		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0);
 		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0); }
 		if ((r = launch_check("hypervis pass 1"))) return r;
@@ -1940,7 +1999,7 @@ extern "C" int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt) 
 	for (int lp : e->local_patches)
 		REQUIRE(e->patches[lp].physics_set, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs was not called for patch %d", lp);
 	ProfScope ps(e, TMX_K_LINCOMB);
-	tmxk_held_suarez(e, make_params(e), inst(e, instance), dt);
+	tmxk_held_suarez(e, make_params(e), inst(e, instance), e->track_surface ? surface_slots(e, instance) : nullptr, dt);
 	return launch_check("physics_held_suarez");
 }
 

@@ -122,6 +122,7 @@ struct tmx_engine {
 	double * d_ab = nullptr;                 // [3(L+1)*9][NUS] band rows, overwritten by U rows
 	double * d_rhs = nullptr;                // [3(L+1)][NUS]
 	int * d_flag = nullptr;                  // singular-pivot flag
+	bool track_surface = false; int patches_with_physics = 0;     // surface slots carried through the stage algebra (tmx_host.hip: surface_copy)
 	// Kessler microphysics (tmx_physics_kessler): level heights [L][NS], accumulated precipitation [NS], column work arrays [8][L][NS]
 	std::vector<double> h_zlev; bool zlev_dirty = false;
 	double * d_zlev = nullptr, * d_prect = nullptr, * d_kes = nullptr;
@@ -166,7 +167,7 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
-void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt);
+void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt);
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);

@@ -1078,8 +1078,10 @@ void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x) {
 // Column physics: HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301), Lorenz staggering.  Pointwise
 // in (column, level): backward-Euler boundary-layer friction on U,V (sigma from PressureFromRhoTheta(rho * rhotheta),
 // :107-126, as the reference writes it) and relaxation of rho*theta towards the equilibrium temperature with the
-// "Ullrich update" (:186-247).  The surface pressure is an input (tmx_set_patch_physics_inputs).
-__global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restrict__ x, double dt, double gamma, double kappa, double pscal)
+// "Ullrich update" (:186-247).  The surface pressure is PressureFromRhoTheta(rho_e0 * rhotheta_e0) of the tracked surface
+// slots (`surf` = [2][NS]: what the reference finds in the interface entries of rho and rho*theta, :113-116), or, when the
+// caller pinned it, the input of tmx_set_patch_physics_inputs.
+__global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restrict__ x, const double * __restrict__ surf, double dt, double gamma, double kappa, double pscal)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -1089,7 +1091,8 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	const unsigned cb = (unsigned)col * 8u;
 	const double bsig = 0.7, kf = 1.0 / 86400.0, ka = (1.0 / 40.0) / 86400.0, ks = (1.0 / 4.0) / 86400.0;
 	const double dty = 60.0, dthz = 10.0, tmin = 200.0, tmax = 315.0;
-	const double ps = ldu(p.g2d + G2_PS * NS, cb), lat = ldu(p.g2d + G2_LAT * NS, cb);
+	const double lat = ldu(p.g2d + G2_LAT * NS, cb);
+	const double ps = surf ? pscal * tmx_ref_exp(tmx_ref_log(ldu(surf, cb) * ldu(surf + NS, cb)) * gamma) : ldu(p.g2d + G2_PS * NS, cb);
 	const double rho = ldu(x + TMX_SLAB_R(L, k) * NS, cb), rt = ldu(x + TMX_SLAB_T(L, k) * NS, cb);
 	{
 		const double pr = pscal * tmx_ref_exp(tmx_ref_log(rho * rt) * gamma);
@@ -1116,12 +1119,12 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	stu(x + TMX_SLAB_T(L, k) * NS, cb, rt * (1.0 + dt / (1.0 - dt * ddh) * dh));
 }
 
-void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, double dt) {
+void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt) {
 	// PhysicalConstants::GetGamma / GetKappa / pressure scaling (src/atm/PhysicalConstants.h:355-376), host libm as in the reference
 	const double gamma = p.cp / (p.cp - p.Rd), kappa = p.Rd / p.cp;
 	const double pscal = p.p0 * pow(p.Rd / p.p0, gamma);
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_held_suarez, grd, blk, 0, e->stream, p, x, dt, gamma, kappa, pscal);
+	hipLaunchKernelGGL(k_held_suarez, grd, blk, 0, e->stream, p, x, surf, dt, gamma, kappa, pscal);
 }
 
 // Column physics: KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285) around SUBROUTINE KESSLER

@@ -288,14 +288,15 @@ class Engine:
         return out
 
     # -- column physics (WorkflowProcess on the device) -----------------------------------------------
-    def set_physics_inputs(self, surface_pressure):
-        """``surface_pressure[p] = [na][nb]``: what HeldSuarezPhysics::Perform computes from the interface slots
-        (HeldSuarezPhysics.cpp:99-101); latitude comes from the grid (GridPatch::GetLatitude)."""
+    def set_physics_inputs(self, surface_pressure=None):
+        """Latitude comes from the grid (GridPatch::GetLatitude).  ``surface_pressure=None``: the engine tracks the
+        interface slots HeldSuarezPhysics::Perform reads (HeldSuarezPhysics.cpp:113-116) through the stage algebra, as
+        the reference does; ``surface_pressure[p] = [na][nb]`` pins the value instead."""
         for p in self.local_patches:
             P = self.grid.patches[p]
             la = np.ascontiguousarray(P.lat, dtype=np.float64)
-            sp = np.ascontiguousarray(surface_pressure[p], dtype=np.float64)
-            self._chk(self.lib.tmx_set_patch_physics_inputs(self.h, p, _pd(la), _pd(sp)))
+            sp = None if surface_pressure is None else np.ascontiguousarray(surface_pressure[p], dtype=np.float64)
+            self._chk(self.lib.tmx_set_patch_physics_inputs(self.h, p, _pd(la), None if sp is None else _pd(sp)))
 
     def held_suarez(self, instance, dt):
         """HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301)."""

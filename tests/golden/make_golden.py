@@ -57,12 +57,15 @@ def run(args, out):
     return tmxd.read(out), sums
 
 
-def compact_states(d, npatch):
-    """Keep only prognostic slots on interior nodes: node comps (U,V,rhotheta,rho), redge comp W."""
+def compact_states(d, npatch, surface_slots=False):
+    """Keep only prognostic slots on interior nodes: node comps (U,V,rhotheta,rho), redge comp W.  surface_slots: also the
+    interface-level-0 scratch entries of rho*theta and rho (redge comps 2, 4), which HeldSuarezPhysics reads."""
     out = {}
     for k, v in d.items():
         if not k.startswith("state/"):
             continue
+        if surface_slots and k.endswith("/redge"):
+            out[k + "0"] = v[[2, 4], 1:-1, 1:-1, 0]
         if k.endswith("/node"):
             out[k] = v[[0, 1, 2, 4], 1:-1, 1:-1]
         elif k.endswith("/tracers"):
@@ -159,7 +162,7 @@ def gen_heldsuarez(tmp):
     d, _ = run(hs + ["--mode", "steps", "--warm", "2", "--steps", "10", "--every", "10", "--geom", "1"], tmp)
     rec = {k: v for k, v in d.items() if k.startswith("cfg/") or k.startswith("phys/") or k.startswith("checksum/") or "hs_" in k}
     rec.update(flat_geometry(d))
-    cs = compact_states(d, 6)
+    cs = compact_states(d, 6, surface_slots=True)
     rec.update({k: v for k, v in cs.items() if k.split("/")[1] in ("warm", "step10")})
     save("heldsuarez_ne3_L60_p6.npz", rec)
 

@@ -133,6 +133,9 @@ def expand_compact(d, tag, grid):
         n = np.zeros((5, P.na, P.nb, L)); e = np.zeros((5, P.na, P.nb, L + 1))
         n[[0, 1, 2, 4], 1:-1, 1:-1] = d["state/%s/p%d/node" % (tag, P.index)]
         e[3, 1:-1, 1:-1] = d["state/%s/p%d/redge" % (tag, P.index)]
+        k0 = "state/%s/p%d/redge0" % (tag, P.index)
+        if k0 in d:     # interface-level-0 scratch entries of rho*theta and rho (what HeldSuarezPhysics reads as "surface")
+            e[[2, 4], 1:-1, 1:-1, 0] = d[k0]
         out.append((n, e))
     return out
 

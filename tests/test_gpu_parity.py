@@ -978,3 +978,46 @@ def test_supercell_steps_with_kessler():
         assert max(terr_o[:1]) < TOL_STEPS and max(terr_r[:1]) < TOL_STEPS
     finally:
         e.close()
+
+
+# ---- BASELINE config 5 shape: the stock Held-Suarez test at L60 ------------------------------------------------
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_held_suarez_steps_L60(graph, monkeypatch):
+    """HeldSuarezTest (ztop 35 km, Rayleigh layer of strength zero) at ne3 L60: 10 ARS343 steps with
+    HeldSuarezPhysics::Perform after every step (Model.cpp:470-481), from the reference's state after 2 such steps, on
+    the reference's own grid; the forcing reads the tracked surface slots.  graph: the step replayed from a hipGraph
+    (TMX_GRAPH=1, BASELINE config 5's 'hipGraph-captured timestep').  The oracle equals the reference bit for bit here
+    (tests/test_oracle_vs_reference.py); the device differs from both only through ocml's pow / sin / cos in the forcing."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    if graph:
+        monkeypatch.setenv("TMX_GRAPH", "1")
+    d = gu.load("heldsuarez_ne3_L60_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, case="heldsuarez")
+    for P in g.patches:
+        P.lat = d["p%d/hs_latitude" % P.index]
+    dt = float(d["cfg/dt"][0])
+    start = gu.expand_compact(d, "warm", g)
+    o = Oracle(g); o.set_state(0, start)
+    e = Engine(g)
+    try:
+        e.set_physics_inputs(None)
+        e.upload_state(0, start)
+        for _ in range(10):
+            assert o.step_ars343(dt) == 0
+            o.held_suarez(0, dt)
+            e.step_ars343(dt)
+            e.held_suarez(0, dt)
+        e.sync()
+        got = e.download_state(0)
+        errs_o = gu.prognostic_errors(got, o.get_state(0))
+        errs_r = gu.prognostic_errors(got, gu.expand_compact(d, "step10", g))
+        print("Held-Suarez L60, 10 steps (graph=%s): vs oracle %s vs reference %s" % (graph, errs_o, errs_r))
+        assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step10", g))) == 0.0
+        assert max(errs_o) < TOL_STEPS and max(errs_r) < TOL_STEPS
+        # the tracked surface slots came back with the state: the reference's interface entries, bit for bit
+        for (gn, ge), (on, oe) in zip(got, o.get_state(0)):
+            assert np.array_equal(ge[[2, 4], 1:-1, 1:-1, 0], oe[[2, 4], 1:-1, 1:-1, 0])
+    finally:
+        e.close()

@@ -478,7 +478,6 @@ def test_held_suarez_steps_L60():
     g, _ = gu.grid_from_fixture(d, override=True, case="heldsuarez")     # the reference's own (flat) geometry
     assert g.L == 60 and abs(g.ztop - 35000.0) < 1e-9
     for P in g.patches:
-        P.geom["hs_surface_pressure"] = d["p%d/hs_surface_pressure" % P.index]
         assert np.max(np.abs(P.lat - d["p%d/hs_latitude" % P.index])[1:-1, 1:-1]) < 1e-15
         P.lat = d["p%d/hs_latitude" % P.index]          # the reference's own latitudes (the forcing takes sin / cos of them)
     dt = float(d["cfg/dt"][0])
