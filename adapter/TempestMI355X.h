@@ -4,8 +4,11 @@
 // (include/tempest_mi355x.h).  Compiles against the reference headers (src/atm, src/base) and
 // contains no reference code; this is the file a Tempest maintainer adds.
 //
-//   TimestepSchemeARS343_MI355X  production mode: the whole IMEX step runs on the GPU, the host
-//                                arrays are refreshed (instance 0) at the end of every Step.
+//   TimestepScheme*_MI355X       production mode (ARS343, ARS232, ARS222, ARS443, ARK232, Strang): the whole step runs on
+//                                the GPU; the host arrays (instance 0) are refreshed per MI355XEngine's host
+//                                synchronisation policy (every step by default).
+//   HeldSuarezPhysicsMI355X /    the column physics WorkflowProcesses on the device, sharing that policy.
+//   KesslerPhysicsMI355X
 //   HorizontalDynamicsMI355X /   parity mode: the reference's own TimestepScheme, Grid::CopyData,
 //   VerticalDynamicsMI355X       LinearCombineData and ApplyDSS keep running on the host arrays; every
 //                                call uploads the instances it reads and downloads the one it writes.
@@ -66,6 +69,51 @@ public:
 
 	tmx_engine * Handle() { Initialize(); return m_pEngine; }
 
+	// ---- where the current copy of instance 0 lives (shared by the TimestepScheme and the WorkflowProcess plugins) ----
+	//
+	// Host synchronisation policy.  Interval 1 (default): instance 0 is uploaded before and downloaded after every device
+	// operation on it, so any reference code may read or modify it on the host in between (output managers, host-side
+	// WorkflowProcesses, error norms; Model.cpp:477-509, :695) -- at ne30 L30 that is ~23 ms of transfers around a 1.7 ms
+	// step.  Interval n > 1: the state stays on the device; the host copy is refreshed every n-th step, on the last step
+	// and on Flush(), and uploaded again only after MarkHostModified().
+	void SetHostSyncInterval(int nSteps) { m_nHostSyncInterval = (nSteps < 1) ? 1 : nSteps; }
+	int GetHostSyncInterval() const { return m_nHostSyncInterval; }
+
+	///	Instances whose content survives from one Step to the next: instance 0, plus instance 1 for the Strang stepper
+	///	(its carry-over, TimestepSchemeStrang.cpp:639-657).  They move together between host and device.
+	void SetCarriedInstances(int nInstances) { m_nCarried = (nInstances < 1) ? 1 : nInstances; }
+
+	///	The host copy of instance 0 was changed outside the plugins: upload it before the next device operation.
+	void MarkHostModified() { m_fHostNewer = true; m_fDeviceNewer = false; }
+
+	///	Make the device copy of instance 0 current (called by every plugin before it touches instance 0 on the device).
+	void EnsureDevice() {
+		if (m_fHostNewer || (m_nHostSyncInterval == 1)) {
+			for (int ix = 0; ix < m_nCarried; ix++) Upload(ix);
+			m_fHostNewer = false;
+		}
+	}
+
+	///	A plugin changed instance 0 on the device.  fStep: a time step was completed (counts towards the interval).
+	void DeviceModified(bool fStep, bool fForceSync) {
+		m_fDeviceNewer = true;
+		if (fStep) m_nStepsSinceSync++;
+		if ((m_nHostSyncInterval == 1) || fForceSync || (m_nStepsSinceSync >= m_nHostSyncInterval)) {
+			Flush();
+		}
+	}
+
+	///	Bring the host copy of instance 0 up to date now (output managers, ComputeErrorNorms, end of run).
+	void Flush() {
+		if (m_fDeviceNewer) {
+			Initialize();
+			Check(tmx_sync(m_pEngine));
+			for (int ix = 0; ix < m_nCarried; ix++) Download(ix);
+			m_fDeviceNewer = false;
+		}
+		m_nStepsSinceSync = 0;
+	}
+
 	// GridPatch::GetDataState arrays -> device
 	void Upload(int ixData) {
 		Initialize();
@@ -121,7 +169,8 @@ public:
 private:
 	MI355XEngine(Model & model) :
 		m_model(model), m_pEngine(NULL),
-		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4), m_fFullyExplicit(false)
+		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4), m_fFullyExplicit(false),
+		m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fHostNewer(true), m_fDeviceNewer(false), m_nCarried(1)
 	{ }
 
 	GridGLL * Grid() {
@@ -175,6 +224,21 @@ private:
 		cfg.rank = nRank;
 		cfg.n_ranks = nRanks;
 		cfg.device = -1;
+#ifdef TEMPEST_MPIOMP
+		if (nRanks > 1) {
+			// one rank = one GPU: bind by the rank's index among the ranks of its node (a plain `mpiexec -np N` would
+			// otherwise put every rank on device 0, and tmx_comm_init rejects two ranks on one device)
+			MPI_Comm commNode;
+			MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, nRank, MPI_INFO_NULL, &commNode);
+			int nLocalRank = 0;
+			MPI_Comm_rank(commNode, &nLocalRank);
+			MPI_Comm_free(&commNode);
+			const int nDevices = tmx_device_count();
+			if (nDevices > 0) {
+				cfg.device = nLocalRank % nDevices;
+			}
+		}
+#endif
 		cfg.equation_set =
 			(m_model.GetEquationSet().GetType() == EquationSet::ShallowWaterEquations)
 				? TMX_EQN_SHALLOW_WATER : TMX_EQN_PRIMITIVE_NONHYDROSTATIC;
@@ -388,6 +452,11 @@ private:
 	double m_dNuScalar, m_dNuDiv, m_dNuVort;
 	int m_nHypervisOrder;
 	bool m_fFullyExplicit;
+	int m_nHostSyncInterval;
+	int m_nStepsSinceSync;
+	bool m_fHostNewer;
+	bool m_fDeviceNewer;
+	int m_nCarried;
 };
 
 ///////////////////////////////////////////////////////////////////////////////
@@ -499,95 +568,154 @@ public:
 };
 
 ///	<summary>
-///		Drop-in for TimestepSchemeARS343: the whole step on the device.
+///		Drop-in for the reference's IMEX / split steppers: the whole TimestepScheme::Step on the device.  One class
+///		per scheme id of the C ABI; the instance counts are the ones of the scheme it stands in for
+///		(tmx_scheme_instances), because patch allocation uses them (GridPatch.cpp:334-374).
 ///	</summary>
-class TimestepSchemeARS343_MI355X : public TimestepScheme {
+class TimestepSchemeMI355X : public TimestepScheme {
 public:
-	TimestepSchemeARS343_MI355X(Model & model) :
-		TimestepScheme(model), m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fHostNewer(true) { }
-
-	virtual int GetComponentDataInstances() const { return 7; }   // TimestepSchemeARS343.h:48-56
-	virtual int GetTracerDataInstances() const { return 7; }
-
-	///	<summary>
-	///		Host synchronisation policy.  1 (default): instance 0 is uploaded before and downloaded after every
-	///		step, so any reference code may read or modify it on the host between steps (output managers,
-	///		WorkflowProcess physics, error norms; Model.cpp:477-509) -- at ne30 L30 that is ~23 ms of transfers
-	///		around a 1.7 ms step.  n > 1: the state stays on the device; it is downloaded every n-th step and on
-	///		the last step (fLastStep), and uploaded again only after MarkHostModified().
-	///	</summary>
-	void SetHostSyncInterval(int nSteps) { m_nHostSyncInterval = (nSteps < 1) ? 1 : nSteps; }
-
-	///	<summary>
-	///		The host copy of instance 0 was changed outside the scheme: upload it before the next step.
-	///	</summary>
-	void MarkHostModified() { m_fHostNewer = true; }
-
-	///	<summary>
-	///		Bring the host copy of instance 0 up to date now (e.g. from an output manager).
-	///	</summary>
-	void Flush() {
-		if (m_nStepsSinceSync > 0) {
-			MI355XEngine & eng = MI355XEngine::For(m_model);
-			MI355XEngine::Check(tmx_sync(eng.Handle()));
-			eng.Download(0);
-			m_nStepsSinceSync = 0;
+	TimestepSchemeMI355X(Model & model, int iScheme) :
+		TimestepScheme(model), m_iScheme(iScheme)
+	{
+		if (tmx_scheme_instances(iScheme) <= 0) {
+			_EXCEPTIONT("TimestepSchemeMI355X: unknown scheme id");
 		}
 	}
+
+	virtual int GetComponentDataInstances() const { return tmx_scheme_instances(m_iScheme); }
+	virtual int GetTracerDataInstances() const { return tmx_scheme_instances(m_iScheme); }
+
+	///	Host synchronisation policy and hooks: see MI355XEngine.
+	void SetHostSyncInterval(int nSteps) { MI355XEngine::For(m_model).SetHostSyncInterval(nSteps); }
+	void MarkHostModified() { MI355XEngine::For(m_model).MarkHostModified(); }
+	void Flush() { MI355XEngine::For(m_model).Flush(); }
 
 	virtual void Step(bool fFirstStep, bool fLastStep, const Time & time, double dDeltaT) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);
-		if (m_fHostNewer || m_nHostSyncInterval == 1) {
-			eng.Upload(0);
-			m_fHostNewer = false;
-		}
-		MI355XEngine::Check(tmx_step_ars343(eng.Handle(), dDeltaT));
-		m_nStepsSinceSync++;
-		if (m_nHostSyncInterval == 1 || fLastStep || m_nStepsSinceSync >= m_nHostSyncInterval) {
-			Flush();
-		}
+		eng.SetCarriedInstances((m_iScheme == TMX_SCHEME_STRANG) ? 2 : 1);
+		eng.EnsureDevice();
+		MI355XEngine::Check(tmx_step(eng.Handle(), m_iScheme, fFirstStep ? 1 : 0, fLastStep ? 1 : 0, dDeltaT));
+		eng.DeviceModified(true, fLastStep);
 	}
 
 private:
-	int m_nHostSyncInterval;
-	int m_nStepsSinceSync;
-	bool m_fHostNewer;
+	int m_iScheme;
 };
+
+#define TMX_DEFINE_SCHEME(Name, Id) \
+	class Name : public TimestepSchemeMI355X { public: Name(Model & model) : TimestepSchemeMI355X(model, Id) { } }
+TMX_DEFINE_SCHEME(TimestepSchemeARS343_MI355X, TMX_SCHEME_ARS343);     // src/atm/TimestepSchemeARS343.cpp
+TMX_DEFINE_SCHEME(TimestepSchemeARS232_MI355X, TMX_SCHEME_ARS232);     // TimestepSchemeARS232.cpp
+TMX_DEFINE_SCHEME(TimestepSchemeARS222_MI355X, TMX_SCHEME_ARS222);     // TimestepSchemeARS222.cpp
+TMX_DEFINE_SCHEME(TimestepSchemeARS443_MI355X, TMX_SCHEME_ARS443);     // TimestepSchemeARS443.cpp
+TMX_DEFINE_SCHEME(TimestepSchemeARK232_MI355X, TMX_SCHEME_ARK232);     // TimestepSchemeARK232.cpp
+TMX_DEFINE_SCHEME(TimestepSchemeStrang_MI355X, TMX_SCHEME_STRANG);     // TimestepSchemeStrang.cpp (KGU35, off-centering 0)
+#undef TMX_DEFINE_SCHEME
 
 ///////////////////////////////////////////////////////////////////////////////
 
 ///	<summary>
 ///		HeldSuarezPhysics (src/atm/HeldSuarezPhysics.h) on the device: a WorkflowProcess with the same constructor,
-///		attached with Model::AttachWorkflowProcess exactly like the reference class.
+///		attached with Model::AttachWorkflowProcess exactly like the reference class.  The state stays on the device
+///		between the time step and the forcing (MI355XEngine's host synchronisation policy decides when the host copy is
+///		refreshed); the "surface pressure" of HeldSuarezPhysics.cpp:113-116 is formed on the device from the interface
+///		entries the engine tracks through the stage algebra.
 ///	</summary>
 class HeldSuarezPhysicsMI355X : public WorkflowProcess {
 public:
 	HeldSuarezPhysicsMI355X(Model & model, const Time & timeFrequency) :
-		WorkflowProcess(model, timeFrequency) { }
+		WorkflowProcess(model, timeFrequency), m_fInputsSet(false) { }
+
+	///	Model::Go calls this after the geometric terms exist and before the first step (Model.cpp:343-366): the engine
+	///	must know from the first step on that the surface slots are to be carried through the stage algebra.
+	virtual void Initialize(const Time & timeStart) {
+		WorkflowProcess::Initialize(timeStart);
+		RegisterInputs();
+	}
+
+	void RegisterInputs() {
+		if (m_fInputsSet) {
+			return;
+		}
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		tmx_engine * pEngine = eng.Handle();
+		Grid * pGrid = m_model.GetGrid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			MI355XEngine::Check(tmx_set_patch_physics_inputs(pEngine, pPatch->GetPatchIndex(),
+				&(pPatch->GetLatitude()[0][0]), NULL));
+		}
+		m_fInputsSet = true;
+		// the surface slots travel with the state: make the host copy current, then have it uploaded again
+		eng.Flush();
+		eng.MarkHostModified();
+	}
+
+	virtual void Perform(const Time & time) {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		tmx_engine * pEngine = eng.Handle();
+		RegisterInputs();      // late attachment: from here on (the step just taken ran without tracked surface slots)
+		eng.EnsureDevice();
+		MI355XEngine::Check(tmx_physics_held_suarez(pEngine, 0, m_timeFrequency.GetSeconds()));
+		eng.DeviceModified(false, false);
+		WorkflowProcess::Perform(time);
+	}
+
+private:
+	bool m_fInputsSet;
+};
+
+///	<summary>
+///		KesslerPhysics (test/dcmip2016/KesslerPhysics.h) on the device: same constructor, same attachment.  The
+///		accumulated precipitation (UserData2D item 0, KesslerPhysics.cpp:234) is kept on the device and written to the
+///		patch's UserData2D by FlushPrecipitation() (called whenever the host copy of the state is refreshed here).
+///	</summary>
+class KesslerPhysicsMI355X : public WorkflowProcess {
+public:
+	KesslerPhysicsMI355X(Model & model, const Time & timeFrequency) :
+		WorkflowProcess(model, timeFrequency), m_fInputsSet(false) { }
+
+	void FlushPrecipitation() {
+		MI355XEngine & eng = MI355XEngine::For(m_model);
+		Grid * pGrid = m_model.GetGrid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			DataArray3D<double> & dataUserData2D = pPatch->GetUserData2D();
+			if (dataUserData2D.GetRows() == 0) {
+				_EXCEPTIONT("Insufficient entries in UserData2D");
+			}
+			// the device accumulator is added to the host array and reset, so that the host array keeps the running total
+			const PatchBox & box = pPatch->GetPatchBox();
+			DataArray2D<double> dAcc(box.GetATotalWidth(), box.GetBTotalWidth());
+			MI355XEngine::Check(tmx_download_precipitation(eng.Handle(), pPatch->GetPatchIndex(), &(dAcc[0][0]), 1));
+			for (int i = box.GetAInteriorBegin(); i < box.GetAInteriorEnd(); i++)
+			for (int j = box.GetBInteriorBegin(); j < box.GetBInteriorEnd(); j++)
+				dataUserData2D[0][i][j] += dAcc[i][j];
+		}
+	}
 
 	virtual void Perform(const Time & time) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);
 		tmx_engine * pEngine = eng.Handle();
 		Grid * pGrid = m_model.GetGrid();
-		const PhysicalConstants & phys = m_model.GetPhysicalConstants();
-		// the "surface pressure" of HeldSuarezPhysics.cpp:99-101, formed on the reference's own arrays
-		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
-			GridPatch * pPatch = pGrid->GetActivePatch(n);
-			const PatchBox & box = pPatch->GetPatchBox();
-			const DataArray4D<double> & dataREdge = pPatch->GetDataState(0, DataLocation_REdge);
-			DataArray2D<double> dPs(box.GetATotalWidth(), box.GetBTotalWidth());
-			for (int i = 0; i < box.GetATotalWidth(); i++)
-			for (int j = 0; j < box.GetBTotalWidth(); j++)
-				dPs[i][j] = phys.PressureFromRhoTheta(dataREdge[4][i][j][0] * dataREdge[2][i][j][0]);
-			MI355XEngine::Check(tmx_set_patch_physics_inputs(pEngine, pPatch->GetPatchIndex(),
-				&(pPatch->GetLatitude()[0][0]), &(dPs[0][0])));
+		if (!m_fInputsSet) {
+			for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+				GridPatch * pPatch = pGrid->GetActivePatch(n);
+				MI355XEngine::Check(tmx_set_patch_level_heights(pEngine, pPatch->GetPatchIndex(), &(pPatch->GetZLevels()[0][0][0])));
+			}
+			m_fInputsSet = true;
 		}
-		eng.Upload(0);
-		MI355XEngine::Check(tmx_physics_held_suarez(pEngine, 0, m_timeFrequency.GetSeconds()));
-		MI355XEngine::Check(tmx_sync(pEngine));
-		eng.Download(0);
+		eng.EnsureDevice();
+		MI355XEngine::Check(tmx_physics_kessler(pEngine, 0, m_timeFrequency.GetSeconds()));
+		eng.DeviceModified(false, false);
+		if (eng.GetHostSyncInterval() == 1) {
+			FlushPrecipitation();
+		}
 		WorkflowProcess::Perform(time);
 	}
+
+private:
+	bool m_fInputsSet;
 };
 
 ///////////////////////////////////////////////////////////////////////////////

@@ -19,10 +19,21 @@
 #define main tmx_unused_schar_main
 #include "ScharMountainSphereTest.cpp"
 #undef main
+// the stock test cases of BASELINE configs 1, 4 and 5, each from its own translation unit
+#define main tmx_unused_sw2_main
+#include "SWTest2.cpp"
+#undef main
+#define main tmx_unused_heldsuarez_main
+#include "HeldSuarezTest.cpp"
+#undef main
+#define main tmx_unused_supercell_main
+#include "SupercellTest.cpp"
+#undef main
 #include "test_inputs.h"       // JWWithTracers: the JW state plus closed-form tracer densities (a test input of ours)
 
 #include "TempestMI355X.h"
 #include "HeldSuarezPhysics.h"
+#include "KesslerPhysics.h"
 
 #include <cstdio>
 #include <cstring>
@@ -35,10 +46,10 @@ public:
 	HorizontalDynamicsFEM m_ref;
 	HorizontalDynamicsMI355X m_dev;
 	bool m_fDevice;
-	HSwitch(Model & model) :
+	HSwitch(Model & model, double dNu) :
 		HorizontalDynamics(model),
-		m_ref(model, 4, 4, 1.0e15, 1.0e15, 1.0e15, 0.0),
-		m_dev(model, 4, 4, 1.0e15, 1.0e15, 1.0e15),
+		m_ref(model, 4, 4, dNu, dNu, dNu, 0.0),
+		m_dev(model, 4, 4, dNu, dNu, dNu),
 		m_fDevice(false) { }
 	virtual void Initialize() { static_cast<HorizontalDynamics &>(m_ref).Initialize(); }
 	virtual void StepExplicit(int a, int b, const Time & t, double dt) {
@@ -76,12 +87,24 @@ public:
 
 class TSwitch : public TimestepScheme {
 public:
-	TimestepScheme * m_pRef;      // the reference's own scheme: ARS343 (default) or, for parity mode, ARK232 / ARS232
-	TimestepSchemeARS343_MI355X m_dev;
+	TimestepScheme * m_pRef;      // the reference's own scheme
+	TimestepSchemeMI355X m_dev;   // its device drop-in (production mode)
 	bool m_fDevice;
-	TSwitch(Model & model, const std::string & scheme) : TimestepScheme(model), m_pRef(NULL), m_dev(model), m_fDevice(false) {
+	static int SchemeId(const std::string & scheme) {
+		if (scheme == "ars343") return TMX_SCHEME_ARS343;
+		if (scheme == "ars232") return TMX_SCHEME_ARS232;
+		if (scheme == "ars222") return TMX_SCHEME_ARS222;
+		if (scheme == "ars443") return TMX_SCHEME_ARS443;
+		if (scheme == "ark232") return TMX_SCHEME_ARK232;
+		if (scheme == "strang") return TMX_SCHEME_STRANG;
+		_EXCEPTIONT("unknown --scheme");
+	}
+	TSwitch(Model & model, const std::string & scheme) : TimestepScheme(model), m_pRef(NULL), m_dev(model, SchemeId(scheme)), m_fDevice(false) {
 		if (scheme == "ark232") m_pRef = new TimestepSchemeARK232(model);
 		else if (scheme == "ars232") m_pRef = new TimestepSchemeARS232(model);
+		else if (scheme == "ars222") m_pRef = new TimestepSchemeARS222(model);
+		else if (scheme == "ars443") m_pRef = new TimestepSchemeARS443(model);
+		else if (scheme == "strang") m_pRef = new TimestepSchemeStrang(model);
 		else m_pRef = new TimestepSchemeARS343(model);
 	}
 	virtual ~TSwitch() { delete m_pRef; }
@@ -95,30 +118,31 @@ public:
 
 typedef std::vector< std::vector<double> > Snapshot;
 
-static void save(GridGLL * pGrid, Snapshot & s) {
+// instance ix of every patch: node array, redge array, tracer array (possibly empty)
+static void save(GridGLL * pGrid, Snapshot & s, int ix = 0) {
 	s.clear();
 	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
 		GridPatch * p = pGrid->GetActivePatch(n);
 		for (int loc = 0; loc < 2; loc++) {
-			DataArray4D<double> & d = p->GetDataState(0, loc ? DataLocation_REdge : DataLocation_Node);
+			DataArray4D<double> & d = p->GetDataState(ix, loc ? DataLocation_REdge : DataLocation_Node);
 			s.push_back(std::vector<double>(&d[0][0][0][0], &d[0][0][0][0] + d.GetTotalSize()));
 		}
-		DataArray4D<double> & t = p->GetDataTracers(0);
+		DataArray4D<double> & t = p->GetDataTracers(ix);
 		if (t.GetSize(0) > 0) s.push_back(std::vector<double>(&t[0][0][0][0], &t[0][0][0][0] + t.GetTotalSize()));
 		else s.push_back(std::vector<double>());
 	}
 }
 
-static void restore(GridGLL * pGrid, const Snapshot & s) {
+static void restore(GridGLL * pGrid, const Snapshot & s, int ix = 0) {
 	int q = 0;
 	for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
 		GridPatch * p = pGrid->GetActivePatch(n);
 		for (int loc = 0; loc < 2; loc++) {
-			DataArray4D<double> & d = p->GetDataState(0, loc ? DataLocation_REdge : DataLocation_Node);
+			DataArray4D<double> & d = p->GetDataState(ix, loc ? DataLocation_REdge : DataLocation_Node);
 			memcpy(&d[0][0][0][0], &s[q][0], s[q].size() * sizeof(double));
 			q++;
 		}
-		DataArray4D<double> & t = p->GetDataTracers(0);
+		DataArray4D<double> & t = p->GetDataTracers(ix);
 		if (t.GetSize(0) > 0) memcpy(&t[0][0][0][0], &s[q][0], s[q].size() * sizeof(double));
 		q++;
 	}
@@ -128,7 +152,8 @@ int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 	std::string mode = "production", tcase = "jw", scheme = "ars343";
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
-	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10;
+	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10, nu = 1.0e15;
+	bool fZtopGiven = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		const char * v = (i + 1 < argc) ? argv[i+1] : "";
@@ -144,31 +169,42 @@ int main(int argc, char ** argv) {
 		else if (a == "--scheme") { scheme = v; i++; }                // parity mode: ars343 (default), ark232, ars232
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--hostsync") { hostsync = atoi(v); i++; }    // production mode: host synchronisation interval (steps)
-		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing after every step
+		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing, 2: Kessler microphysics, after every step
+		else if (a == "--ztop") { ztop = atof(v); fZtopGiven = true; i++; }
+		else if (a == "--nu") { nu = atof(v); i++; }
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	int status = 1;
 try {
 	AnnounceSetVerbosityLevel(0);
-	EquationSet eqn(EquationSet::PrimitiveNonhydrostaticEquations);
-	for (int c = 0; c < ntracers; c++) { char nm[16]; snprintf(nm, 16, "RhoQ%d", c); eqn.InsertTracer(nm, nm); }
+	// stock test cases: --case sw2 (BASELINE config 1: SWTest2, Strang), heldsuarez (config 5: HeldSuarezTest + forcing),
+	// supercellreal (config 4: SupercellTest + Kessler, --explicitvertical, nu = 0)
+	const bool fSW = (tcase == "sw2"), fHS = (tcase == "heldsuarez"), fSCReal = (tcase == "supercellreal");
+	if (fSW) { levels = 1; if (scheme == "ars343") scheme = "strang"; }
+	if (fHS) { if (!fZtopGiven) ztop = 35000.0; physics = 1; }
+	if (fSCReal) { if (!fZtopGiven) ztop = 20000.0; ntracers = 3; physics = 2; nu = 0.0; }
+	EquationSet eqn(fSW ? EquationSet::ShallowWaterEquations : EquationSet::PrimitiveNonhydrostaticEquations);
+	if (fSCReal) { eqn.InsertTracer("RhoQv", "RhoQv"); eqn.InsertTracer("RhoQc", "RhoQc"); eqn.InsertTracer("RhoQr", "RhoQr"); }
+	else for (int c = 0; c < ntracers; c++) { char nm[16]; snprintf(nm, 16, "RhoQ%d", c); eqn.InsertTracer(nm, nm); }
 	UserDataMeta metaUserData;
+	if (fSCReal) metaUserData.InsertDataItem2D("PRECT");
 	Model model(eqn, metaUserData);
 	const int isec = (int)dt, iusec = (int)((dt - isec) * 1.0e6 + 0.5);
 	Time timeDeltaT(0, 0, 0, isec, iusec, Time::CalendarNoLeap, Time::TypeDelta);
 	model.SetDeltaT(timeDeltaT);
 	model.SetEndTime(model.GetStartTime());
 
-	if (mode == "production" && scheme != "ars343") { fprintf(stderr, "production mode replaces TimestepSchemeARS343 only\n"); return 2; }
+	if (fSW && mode != "production") { fprintf(stderr, "--case sw2 runs in production mode\n"); return 2; }
 	TSwitch * pT = new TSwitch(model, scheme);
-	HSwitch * pH = new HSwitch(model);
+	HSwitch * pH = new HSwitch(model, nu);
 	// --case supercell: the configuration of test/dcmip2016/SupercellTest.cpp (planet / 120, no rotation, uniform
 	// diffusion 1500 / 500 m^2/s, --explicitvertical) without its Fortran physics, driven by the JW state
 	const bool fSupercell = (tcase == "supercell");
-	VSwitch * pV = new VSwitch(model, fSupercell);
+	VSwitch * pV = fSW ? NULL : new VSwitch(model, fSupercell || fSCReal);
 	model.SetTimestepScheme(pT);
 	model.SetHorizontalDynamics(pH);
-	model.SetVerticalDynamics(pV);
+	if (fSW) model.SetVerticalDynamics(new VerticalDynamicsStub(model));      // TempestInitialize.h:362-365
+	else model.SetVerticalDynamics(pV);
 
 	GridCSGLL * pGrid = new GridCSGLL(model);
 	pGrid->DefineParameters();
@@ -176,7 +212,14 @@ try {
 		Grid::VerticalDiscretization_FiniteElement, Grid::VerticalStaggering_Lorenz);
 	pGrid->InitializeDataLocal();
 	model.SetGrid(pGrid, npatch);
-	if (tcase == "schar") {
+	if (fSW) {
+		model.SetTestCase(new ShallowWaterTestCase2(2998.104995, 38.61068277, 0.0));      // SWTest2.cpp defaults
+	} else if (fHS) {
+		model.SetTestCase(new HeldSuarezTest(30000.0, 25.0, ztop));                         // HeldSuarezTest.cpp:336-338
+	} else if (fSCReal) {
+		model.GetGrid()->SetReferenceLength(model.GetGrid()->GetReferenceLength() / 120.0); // SupercellTest.cpp:285-286
+		model.SetTestCase(new SupercellTest(ztop, 120.0));
+	} else if (tcase == "schar") {
 		// ScharMountainSphereTest.cpp defaults: reduced planet X = 500, no rotation, Rayleigh layer above 20 km
 		model.SetTestCase(new ScharMountainSphereTest(ztop, 500.0, 0.0, 45.0, 0.0, 250.0, 5000.0, 4000.0, 300.0, 20.0, 0.0, 20000.0, 25.0));
 		model.GetGrid()->SetReferenceLength(0.5 * M_PI / 30.0 * 500.0);
@@ -190,23 +233,52 @@ try {
 	}
 	model.Go();     // initialisation only (end time == start time)
 
+	// column physics as WorkflowProcess (Model::Go calls Perform after every step, Model.cpp:470-481)
+	WorkflowProcess * pPhysRef = NULL, * pPhysDev = NULL;
+	KesslerPhysicsMI355X * pKesDev = NULL;
+	if (physics == 1) { pPhysRef = new HeldSuarezPhysics(model, timeDeltaT); pPhysDev = new HeldSuarezPhysicsMI355X(model, timeDeltaT); }
+	if (physics == 2) { pPhysRef = new KesslerPhysics(model, timeDeltaT); pKesDev = new KesslerPhysicsMI355X(model, timeDeltaT); pPhysDev = pKesDev; }
+	if (pPhysRef) pPhysRef->Initialize(model.GetStartTime());
+	if (pPhysDev) pPhysDev->Initialize(model.GetStartTime());       // as Model::Go does for attached processes
+
 	Time time = model.GetStartTime();
-	for (int s = 0; s < nwarm; s++) { pT->Step(s == 0, false, time, dt); time += timeDeltaT; }
-	Snapshot start, ref, got;
+	for (int s = 0; s < nwarm; s++) { pT->Step(s == 0, false, time, dt); time += timeDeltaT; if (pPhysRef) pPhysRef->Perform(time); }
+	Snapshot start, start1, ref, got;
 	save(pGrid, start);
-	// column physics as WorkflowProcess (Model::Go calls Perform after every step, Model.cpp:477-481)
-	HeldSuarezPhysics hsRef(model, timeDeltaT);
-	HeldSuarezPhysicsMI355X hsDev(model, timeDeltaT);
-	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (physics) hsRef.Perform(time); }
+	save(pGrid, start1, 1);       // the Strang stepper carries instance 1 over to the next step
+	std::vector< std::vector<double> > prect0, prectRef, prectDev;
+	auto savePrect = [&](std::vector< std::vector<double> > & out) {
+		out.clear();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			DataArray3D<double> & u = pGrid->GetActivePatch(n)->GetUserData2D();
+			out.push_back((u.GetRows() > 0) ? std::vector<double>(&u[0][0][0], &u[0][0][0] + u.GetTotalSize()) : std::vector<double>());
+		}
+	};
+	auto restorePrect = [&](const std::vector< std::vector<double> > & in) {
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			DataArray3D<double> & u = pGrid->GetActivePatch(n)->GetUserData2D();
+			if (u.GetRows() > 0) memcpy(&u[0][0][0], &in[n][0], in[n].size() * sizeof(double));
+		}
+	};
+	savePrect(prect0);
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysRef) pPhysRef->Perform(time); }
 	save(pGrid, ref);
+	savePrect(prectRef);
 
 	restore(pGrid, start);
-	if (mode == "production") { pT->m_fDevice = true; pT->m_dev.SetHostSyncInterval(hostsync); pT->m_dev.MarkHostModified(); }
+	restore(pGrid, start1, 1);
+	restorePrect(prect0);
+	MI355XEngine & engine = MI355XEngine::For(model);
+	if (mode == "production") { pT->m_fDevice = true; engine.SetHostSyncInterval(hostsync); engine.MarkHostModified(); }
 	else if (mode == "parity") { pH->m_fDevice = true; pV->m_fDevice = true; }
 	else { fprintf(stderr, "bad mode\n"); return 2; }
-	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (physics) hsDev.Perform(time); }
-	pT->m_dev.Flush();      // deferred host synchronisation (--hostsync > 1): bring instance 0 back before comparing
+	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
+	// deferred host synchronisation (--hostsync > 1): what a driver does at the reference's host sync points
+	// (OutputManager::ManageOutput / FinalOutput, ComputeErrorNorms: Model.cpp:484-509, :695)
+	engine.Flush();
+	if (pKesDev && hostsync > 1) pKesDev->FlushPrecipitation();
 	save(pGrid, got);
+	savePrect(prectDev);
 
 	// compare prognostic slots on interior nodes
 	const int L = levels;
@@ -230,6 +302,7 @@ try {
 		for (int loc = 0; loc < 2; loc++, q++) {
 			const int Lk = loc ? L + 1 : L;
 			for (int c = 0; c < 5; c++) {
+				if (fSW && (c >= 3 || loc == 1)) continue;      // shallow water: U, V, H on the one level
 				if ((c == 3) != (loc == 1)) continue;
 				for (int i = 1; i < nA - 1; i++) for (int j = 1; j < nB - 1; j++) for (int k = 0; k < Lk; k++) {
 					const size_t o = (((size_t)c * nA + i) * nB + j) * Lk + k;
@@ -253,16 +326,26 @@ try {
 		printf("  tracers %.3e", r);
 		if (r > worst) worst = r;
 	}
+	if (physics == 2) {
+		double dm = 0.0, sm = 0.0;
+		for (size_t n = 0; n < prectRef.size(); n++) for (size_t t = 0; t < prectRef[n].size(); t++) {
+			dm = std::max(dm, fabs(prectDev[n][t] - prectRef[n][t])); sm = std::max(sm, fabs(prectRef[n][t]));
+		}
+		const double r = (sm > 0) ? dm / sm : dm;
+		printf("  precipitation %.3e", r);
+		if (r > worst) worst = r;
+	}
 	if (pGrid->HasRayleighFriction()) printf("  [Rayleigh friction active]");
-	if (physics) printf("  [Held-Suarez physics after every step]");
-	printf("\n");
+	if (physics == 1) printf("  [Held-Suarez physics after every step]");
+	if (physics == 2) printf("  [Kessler physics after every step]");
+	printf("  scheme=%s case=%s hostsync=%d\n", scheme.c_str(), tcase.c_str(), hostsync);
 	status = (worst < tol) ? 0 : 1;
 	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",
 		tmx_info(MI355XEngine::For(model).Handle(), TMX_INFO_METRIC_CLOSED_FORM) == 1 ? "active" : "refused, arrays streamed");
 	// the output interpolation.  Host arrays and device now hold the same instance 0: the reference's
 	// Grid::ReduceInterpolate on the host arrays against ReduceInterpolateMI355X on the device state, both flag sets
 	// OutputManagerReference uses plus the primitive conversion.
-	{
+	if (!fSW) {
 		const int nlon = 16, nlat = 8, npts = nlon * nlat;
 		DataArray1D<double> dLon(npts), dLat(npts), dAlpha(npts), dBeta(npts);
 		DataArray1D<int> iPatch(npts);
@@ -271,7 +354,7 @@ try {
 			dLat[j * nlon + i] = -0.5 * M_PI + (j + 0.5) * M_PI / nlat;
 		}
 		pGrid->ConvertReferenceToPatchCoord(dLon, dLat, dAlpha, dBeta, iPatch);
-		MI355XEngine::For(model).Upload(0);      // parity mode leaves the device copy of instance 0 behind the host's
+		engine.MarkHostModified(); engine.EnsureDevice();      // parity mode leaves the device copy of instance 0 behind the host's
 		ReduceInterpolateMI355X interp(model);
 		double worstI = 0.0;
 		for (int v = 0; v < 3; v++) {

@@ -321,6 +321,10 @@ int tmx_sync(tmx_engine * e);
 
 /* ---- multi-GPU (one engine per rank) -------------------------------------------------------- */
 
+/* Number of HIP devices visible to this process (0 if none): lets the caller bind rank -> device before tmx_create
+ * (cfg.device); two ranks of one communicator on the same device make tmx_comm_init fail with TMX_ERR_DEVICE. */
+int tmx_device_count(void);
+
 /* 128-byte RCCL unique id, created on rank 0 and broadcast by the host (the reference's
  * MPI_COMM_WORLD, src/atm/TempestInitialize.h:715-727). */
 int tmx_comm_unique_id(unsigned char id[128]);

@@ -2084,6 +2084,12 @@ extern "C" int tmx_sync(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // multi-GPU
 
+extern "C" int tmx_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
 extern "C" int tmx_comm_unique_id(unsigned char id[128]) {
 	int r = load_rccl();
 	if (r) return r;
@@ -2105,7 +2111,17 @@ extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
 	HIPCHK(hipSetDevice(e->device));
 	nccl_uid u;
 	memcpy(u.internal, id, 128);
-	NCCLCHK(g_nccl.CommInitRank(&e->comm, e->cfg.n_ranks, u, e->cfg.rank));
+	{
+		const int nr = g_nccl.CommInitRank(&e->comm, e->cfg.n_ranks, u, e->cfg.rank);
+		if (nr != 0) {
+			// the usual cause: several ranks of one node on the same HIP device (RCCL: "Duplicate GPU detected")
+			tmx_set_error("ncclCommInitRank failed (RCCL error %d) for rank %d of %d on HIP device %d: every rank needs a GPU of its own "
+				"-- set tmx_config.device per rank (tmx_device_count(), node-local rank) or restrict HIP_VISIBLE_DEVICES per rank",
+				nr, e->cfg.rank, e->cfg.n_ranks, e->device);
+			e->comm = nullptr;
+			return TMX_ERR_DEVICE;
+		}
+	}
 	return TMX_OK;
 }
 
