@@ -322,6 +322,14 @@ private:
 			Check(tmx_define_patch(m_pEngine, n, box.GetPanel(),
 				box.GetAInteriorWidth() / nOrder, box.GetBInteriorWidth() / nOrder,
 				pGrid->GetPatchProcessor(n), ixNeighbor));
+			{
+				// GridPatchGLL::InitializeCoordinateData (GridPatchGLL.cpp:67-75) for a patch this rank may not hold: the
+				// difference of the first two element-edge coordinates of the patch, from the same GridSpacing
+				const int iA0 = box.GetAGlobalInteriorBegin(), iB0 = box.GetBGlobalInteriorBegin();
+				const double dDeltaA = glspacing.GetEdge(iA0 + nOrder) - glspacing.GetEdge(iA0);
+				const double dDeltaB = glspacing.GetEdge(iB0 + nOrder) - glspacing.GetEdge(iB0);
+				Check(tmx_set_patch_element_spacing(m_pEngine, n, dDeltaA, dDeltaB));
+			}
 		}
 
 		for (int n = 0; n < nPatches; n++) {

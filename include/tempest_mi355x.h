@@ -139,6 +139,13 @@ int tmx_define_patch(tmx_engine * e, int patch, int panel, int elems_a, int elem
  * panel transform applied to (U,V) arriving there.  Stands in for the ExchangeBuffer registry and
  * GridPatchCSGLL::TransformHaloVelocities (src/atm/Connectivity.cpp:797-924,
  * src/atm/GridPatchCSGLL.cpp:1783-1924, src/atm/CubedSphereTrans.h:1751-1823). */
+/* GridPatchGLL::GetElementDeltaA() / GetElementDeltaB() of one patch (any patch of the grid, owned or not; before
+ * tmx_finalize).  The reference forms them as the difference of two element-edge coordinates of the patch
+ * (src/atm/GridPatchGLL.cpp:67-75): they differ from pi / (2 ne), and between patches, in the last bits, and every
+ * horizontal derivative is scaled with the patch's own 1 / delta (HorizontalDynamicsFEM.cpp:837-838, 1013-1016, 1957-1958,
+ * 1973 ...).  Optional: without the call tmx_config.element_delta_a serves both directions. */
+int tmx_set_patch_element_spacing(tmx_engine * e, int patch, double delta_a, double delta_b);
+
 int tmx_set_patch_halo(tmx_engine * e, int patch, int n, const int * halo_i, const int * halo_j,
 	const int * src_patch, const int * src_i, const int * src_j, const int * src_panel,
 	const double * trans);

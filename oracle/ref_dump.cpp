@@ -179,6 +179,7 @@ static void dumpGeometry(TmxdWriter & w, Model & model, GridGLL * pGrid) {
 		for (int d = 0; d < 8; d++) inb[d] = pPatch->GetNeighborPanel((Direction)d);
 		w.i32(pn + "neighbor_panels", D1(8), inb);
 		w.scalar(pn + "element_delta_a", pPatch->GetElementDeltaA());
+		w.scalar(pn + "element_delta_b", pPatch->GetElementDeltaB());
 		w.f64(pn + "a_nodes", D1(pPatch->GetANodes().GetRows()), &(pPatch->GetANodes()[0]));
 		w.f64(pn + "b_nodes", D1(pPatch->GetBNodes().GetRows()), &(pPatch->GetBNodes()[0]));
 		dump2(w, pn + "lon", pPatch->GetLongitude());

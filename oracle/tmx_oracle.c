@@ -121,13 +121,17 @@ static void filter_negative_tracers_h(const orc_grid * g, orc_state * s, int iup
 	}
 }
 
+/* element spacing of a patch: GridPatchGLL::GetElementDeltaA / B (GridPatchGLL.cpp:67-75: a difference of two edge
+ * coordinates of the patch, so not exactly pi / (2 ne) and not the same on every patch); 0 in orc_patch = the grid's delta_a */
+static inline double patch_da(const orc_grid * g, const orc_patch * P) { return (P->delta_a > 0.0) ? P->delta_a : g->delta_a; }
+static inline double patch_db(const orc_grid * g, const orc_patch * P) { return (P->delta_b > 0.0) ? P->delta_b : g->delta_a; }
+
 static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally, int comp, int remove_ref);
 static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally, int from_ref);
 
 void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	if (g->shallow_water) { sw_step_explicit(g, s, iinit, iupd, dt); return; }
 	const int L = g->L;
-	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx;      /* D[s*4+i]  = dDxBasis1D(s,i)   */
 	const double * S = g->stiff;   /* S[i*4+s]  = dStiffness1D(i,s) */
 
@@ -141,6 +145,7 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
+		const double inv_da = 1.0 / patch_da(g, P), inv_db = 1.0 / patch_db(g, P);
 		const int na = P->na, nb = P->nb;
 		double * nin = s->node[iinit * g->npatch + p];
 		double * ein = s->redge[iinit * g->npatch + p];
@@ -205,7 +210,7 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 					dbua += NI(UIx, iA, eB + q, k) * D[q * NP + j];
 					dbux += AUX(CovUx, i, q, k) * D[q * NP + j];
 				}
-				daub *= inv_da; daux *= inv_da; dbua *= inv_da; dbux *= inv_da;
+				daub *= inv_da; daux *= inv_da; dbua *= inv_db; dbux *= inv_db;
 				const double cua = AUX(ConUa, i, j, k), cub = AUX(ConUb, i, j, k), cux = AUX(ConUx, i, j, k);
 				const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
 				AUX(UCZA, i, j, k) = cub * jzx - cux * jzb;
@@ -246,8 +251,8 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 					dbp += AUX(EXN, i, q, k) * D[q * NP + j];
 					dbke += AUX(KE, i, q, k) * D[q * NP + j];
 				}
-				darf *= inv_da; dbrf *= inv_da; dapf *= inv_da; dbpf *= inv_da;
-				dap *= inv_da; dbp *= inv_da; dake *= inv_da; dbke *= inv_da;
+				darf *= inv_da; dbrf *= inv_db; dapf *= inv_da; dbpf *= inv_db;
+				dap *= inv_da; dbp *= inv_db; dake *= inv_da; dbke *= inv_db;
 				double upa = 0.0, upb = 0.0;
 				upa += AUX(UCZA, i, j, k);
 				upb += AUX(UCZB, i, j, k);
@@ -285,7 +290,7 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 								daq += tin[(((size_t)c * na + eA + m) * nb + iB) * L + k] / NI(RIx, eA + m, iB, k) * D[m * NP + i];
 								dbq += tin[(((size_t)c * na + iA) * nb + eB + m) * L + k] / NI(RIx, iA, eB + m, k) * D[m * NP + j];
 							}
-							daq *= inv_da; dbq *= inv_da;
+							daq *= inv_da; dbq *= inv_db;
 							const double cdaq = M4(CA, iA, iB, k, 0) * daq + M4(CA, iA, iB, k, 1) * dbq;
 							const double cdbq = M4(CA, iA, iB, k, 1) * daq + M4(CB, iA, iB, k, 1) * dbq;
 							taf[i][j] -= g->udiff_scalar * M3(Jn, iA, iB, k) * NI(RIx, iA, iB, k) * cdaq;
@@ -301,7 +306,7 @@ void orc_h_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd,
 							da -= taf[q][j] * S[i * NP + q];
 							db -= tbf[i][q] * S[j * NP + q];
 						}
-						da *= inv_da; db *= inv_da;
+						da *= inv_da; db *= inv_db;
 						tup[(((size_t)c * na + iA) * nb + iB) * L + k] -= dt * invJ * (da + db);
 					}
 				}
@@ -1044,12 +1049,12 @@ int orc_v_step_implicit(const orc_grid * g, orc_state * s, int iinit, int iupd, 
 static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally,
 	int comp, int remove_ref) {
 	const int L = g->L;
-	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
-	double local_nu = nu;
-	if (scale_locally && g->ref_length != 0.0) local_nu *= pow(g->delta_a / g->ref_length, 3.2);
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
+		const double inv_da = 1.0 / patch_da(g, P), inv_db = 1.0 / patch_db(g, P);
+		double local_nu = nu;
+		if (scale_locally && g->ref_length != 0.0) local_nu *= pow(patch_da(g, P) / g->ref_length, 3.2);
 		const int na = P->na, nb = P->nb;
 		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
 		for (int c = 2; c < 5; c++) {
@@ -1080,7 +1085,7 @@ static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int
 						da += psi[q][j] * D[q * NP + i];
 						db += psi[i][q] * D[q * NP + j];
 					}
-					da *= inv_da; db *= inv_da;
+					da *= inv_da; db *= inv_db;
 					ga[i][j] = JC(iA, iB, k) * (C2A[(iA * nb + iB) * 2 + 0] * da + C2A[(iA * nb + iB) * 2 + 1] * db);
 					gb[i][j] = JC(iA, iB, k) * (C2B[(iA * nb + iB) * 2 + 0] * da + C2B[(iA * nb + iB) * 2 + 1] * db);
 				}
@@ -1093,7 +1098,7 @@ static void scalar_hyperdiff_c(const orc_grid * g, orc_state * s, int iinit, int
 						ua += ga[q][j] * S[i * NP + q];
 						ub += gb[i][q] * S[j * NP + q];
 					}
-					ua *= inv_da; ub *= inv_da;
+					ua *= inv_da; ub *= inv_db;
 					XU(iA, iB, k) -= dt * invJ * local_nu * (ua + ub);
 				}
 			}
@@ -1112,12 +1117,12 @@ static void scalar_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nu, int scale_locally) {
 	if (!has_tracers(g, s)) return;
 	const int L = g->L;
-	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
-	double local_nu = nu;
-	if (scale_locally && g->ref_length != 0.0) local_nu *= pow(g->delta_a / g->ref_length, 3.2);
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
+		const double inv_da = 1.0 / patch_da(g, P), inv_db = 1.0 / patch_db(g, P);
+		double local_nu = nu;
+		if (scale_locally && g->ref_length != 0.0) local_nu *= pow(patch_da(g, P) / g->ref_length, 3.2);
 		const int na = P->na, nb = P->nb, Lk = L;
 		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
 		const double * Jc = P->g[ORC_G_JAC];
@@ -1140,7 +1145,7 @@ static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 						da += XI(eA + q, iB, k) * D[q * NP + i];
 						db += XI(iA, eB + q, k) * D[q * NP + j];
 					}
-					da *= inv_da; db *= inv_da;
+					da *= inv_da; db *= inv_db;
 					ga[i][j] = JC(iA, iB, k) * (C2A[(iA * nb + iB) * 2 + 0] * da + C2A[(iA * nb + iB) * 2 + 1] * db);
 					gb[i][j] = JC(iA, iB, k) * (C2B[(iA * nb + iB) * 2 + 0] * da + C2B[(iA * nb + iB) * 2 + 1] * db);
 				}
@@ -1153,7 +1158,7 @@ static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 						ua += ga[q][j] * S[i * NP + q];
 						ub += gb[i][q] * S[j * NP + q];
 					}
-					ua *= inv_da; ub *= inv_da;
+					ua *= inv_da; ub *= inv_db;
 					XU(iA, iB, k) -= dt * invJ * local_nu * (ua + ub);
 				}
 			}
@@ -1167,15 +1172,15 @@ static void tracer_hyperdiff(const orc_grid * g, orc_state * s, int iinit, int i
 /* from_ref: iDataInitial == DATA_INDEX_REFERENCE, the source is the reference state (:2249-2253, :2304-2308) */
 static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt, double nud, double nuv, int scale_locally, int from_ref) {
 	const int L = g->L;
-	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
-	double lnd = nud, lnv = nuv;
-	if (scale_locally && g->ref_length != 0.0) {
-		lnd = lnd * pow(g->delta_a / g->ref_length, 3.2);
-		lnv = lnv * pow(g->delta_a / g->ref_length, 3.2);
-	}
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
+		const double inv_da = 1.0 / patch_da(g, P), inv_db = 1.0 / patch_db(g, P);
+		double lnd = nud, lnv = nuv;
+		if (scale_locally && g->ref_length != 0.0) {
+			lnd = lnd * pow(patch_da(g, P) / g->ref_length, 3.2);
+			lnv = lnv * pow(patch_da(g, P) / g->ref_length, 3.2);
+		}
 		const int na = P->na, nb = P->nb;
 		const double * J2 = P->g[ORC_G_JAC2D];
 		const double * C2A = P->g[ORC_G_CM2A], * C2B = P->g[ORC_G_CM2B];
@@ -1202,7 +1207,7 @@ static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int
 					dajua += J2[(eA + q) * nb + iB] * cua[q][j] * D[q * NP + i];
 					dbjub += J2[iA * nb + eB + q] * cub[i][q] * D[q * NP + j];
 				}
-				daub *= inv_da; dbua *= inv_da; dajua *= inv_da; dbjub *= inv_da;
+				daub *= inv_da; dbua *= inv_db; dajua *= inv_da; dbjub *= inv_db;
 				const double invJ2 = 1.0 / J2[iA * nb + iB];
 				dv[i][j] = (dajua + dbjub) * invJ2;
 				cl[i][j] = (daub - dbua) * invJ2;
@@ -1217,7 +1222,7 @@ static void vector_hyperdiff_s(const orc_grid * g, orc_state * s, int iinit, int
 					dac -= S[i * NP + q] * cl[q][j];
 					dbc -= S[j * NP + q] * cl[i][q];
 				}
-				dad *= inv_da; dbd *= inv_da; dac *= inv_da; dbc *= inv_da;
+				dad *= inv_da; dbd *= inv_db; dac *= inv_da; dbc *= inv_db;
 				const double upa = lnd * dad - lnv * J2[iA * nb + iB] * (C2B[(iA * nb + iB) * 2 + 0] * dac + C2B[(iA * nb + iB) * 2 + 1] * dbc);
 				const double upb = lnd * dbd + lnv * J2[iA * nb + iB] * (C2A[(iA * nb + iB) * 2 + 0] * dac + C2A[(iA * nb + iB) * 2 + 1] * dbc);
 				NU(UIx, iA, iB, k) -= dt * upa;
@@ -1750,10 +1755,10 @@ int orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last,
 
 static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt) {
 	const int L = 1;
-	const double inv_da = 1.0 / g->delta_a;
 	const double * D = g->dx, * S = g->stiff;
 	for (int p = 0; p < g->npatch; p++) {
 		const orc_patch * P = &g->patches[p];
+		const double inv_da = 1.0 / patch_da(g, P), inv_db = 1.0 / patch_db(g, P);
 		const int na = P->na, nb = P->nb;
 		const double * nin = s->node[iinit * g->npatch + p];
 		double * nup = s->node[iupd * g->npatch + p];
@@ -1795,7 +1800,7 @@ static void sw_step_explicit(const orc_grid * g, orc_state * s, int iinit, int i
 					dbke += ke[i][q] * D[q * NP + j];
 				}
 				dafa *= inv_da; daub *= inv_da; dake *= inv_da;
-				dbfb *= inv_da; dbua *= inv_da; dbke *= inv_da;
+				dbfb *= inv_db; dbua *= inv_db; dbke *= inv_db;
 				double upa = 0.0, upb = 0.0;
 				const double zeta = (daub - dbua);
 				const double ucza = cub[i][j] * zeta, uczb = -cua[i][j] * zeta;

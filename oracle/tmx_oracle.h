@@ -70,6 +70,7 @@ typedef struct {
 	const double * area_node;          /* [na][nb][L] GridPatch::GetElementAreaNode (tracer filters; NULL without tracers) */
 	const double * lat;                /* [na][nb] GridPatch::GetLatitude (column physics; may be NULL) */
 	const double * surf_p;             /* [na][nb] the "surface pressure" HeldSuarezPhysics::Perform forms from the interface slots (may be NULL) */
+	double delta_a, delta_b;           /* GridPatchGLL::GetElementDeltaA / B of this patch; 0 = orc_grid.delta_a */
 } orc_patch;
 
 typedef struct {

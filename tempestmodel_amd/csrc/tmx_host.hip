@@ -249,6 +249,19 @@ extern "C" int tmx_define_patch(tmx_engine * e, int patch, int panel, int elems_
 	return TMX_OK;
 }
 
+// GridPatchGLL::GetElementDeltaA / GetElementDeltaB of one patch.  The reference forms them as the difference of two
+// element-edge coordinates of the patch (GridPatchGLL.cpp:67-75), so they differ from pi / (2 ne) -- and from patch to
+// patch -- in the last bits, and every horizontal derivative is scaled with the patch's own 1 / delta (HorizontalDynamicsFEM.
+// cpp:837-838, 1957-1958 ...).  Optional: without the call cfg.element_delta_a serves both directions of the patch.
+extern "C" int tmx_set_patch_element_spacing(tmx_engine * e, int patch, double delta_a, double delta_b) {
+	REQUIRE(e, TMX_ERR_INVALID, "tmx_set_patch_element_spacing: null engine");
+	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].defined, TMX_ERR_INVALID, "patch %d not defined", patch);
+	REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_patch_element_spacing after tmx_finalize");
+	REQUIRE(delta_a > 0.0 && delta_b > 0.0, TMX_ERR_INVALID, "element spacing must be positive");
+	e->patches[patch].da = delta_a; e->patches[patch].db = delta_b;
+	return TMX_OK;
+}
+
 extern "C" int tmx_set_patch_halo(tmx_engine * e, int patch, int n, const int * halo_i, const int * halo_j,
 	const int * src_patch, const int * src_i, const int * src_j, const int * src_panel, const double * trans)
 {
@@ -774,6 +787,16 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	e->metric_closed = !e->sw && !e->h_eta.empty();
 	for (int lp : e->local_patches) e->metric_closed = e->metric_closed && e->patches[lp].metric_ok;
 	if (const char * m = getenv("TMX_METRIC")) if (strcmp(m, "stored") == 0) e->metric_closed = false;
+	// per-column element spacing and local hyperviscosity scale of the column's patch
+	for (int lp : e->local_patches) {
+		const PatchInfo & P = e->patches[lp];
+		const double da = (P.da > 0.0) ? P.da : e->cfg.element_delta_a, db = (P.db > 0.0) ? P.db : e->cfg.element_delta_a;
+		const double ida = 1.0 / da, idb = 1.0 / db;
+		const double nus = (e->cfg.reference_length != 0.0) ? pow(da / e->cfg.reference_length, 3.2) : 1.0;
+		for (int c = P.elem_base * TMX_NQ; c < (P.elem_base + P.nea * P.neb) * TMX_NQ; c++) {
+			e->h_g2d[G2_IDA * e->NS + c] = ida; e->h_g2d[G2_IDB * e->NS + c] = idb; e->h_g2d[G2_NUS * e->NS + c] = nus;
+		}
+	}
 	if ((r = dev_upload(&e->d_g2d, e->h_g2d, &bytes))) return r;
 	if (e->metric_closed) {
 		if ((r = dev_upload(&e->d_eta, e->h_eta, &bytes))) return r;
@@ -835,7 +858,21 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// column-solve scratch: per-wavefront U-row streams [NUS/64][n][9 + 1][64] plus a zero page (fused / pair kernels);
 	// the split cross-check kernels keep the band matrix [n][9][NUS] and the right-hand sides [n][NUS] in the same buffers
 	const size_t zpage = 64 * sizeof(double);
-	const size_t abb = (size_t)n * (TMX_BW + 1) * e->NUS * sizeof(double) + zpage, rb = (size_t)n * e->NUS * sizeof(double);
+	// Columns per wavefront of the two-wavefront column kernel.  A pair (assembly + elimination wavefront) is the unit of
+	// residency: 512 pairs give every SIMD of the 256 CUs one wavefront, 1024 two.  With 64 columns per pair a grid
+	// such as ne30 (760 groups) loads 124 CUs twice and 132 once and the kernel runs as long as the doubly loaded ones;
+	// with ceil(nunique / (512 m)) columns per pair (48 at ne30) every SIMD carries the same number of wavefronts.
+	{
+		const int ngrp64 = (e->nunique + 63) / 64;
+		e->vi_cpw = 64;
+		// (measured at ne30: 56 columns per wavefront = 64; 48 and 40, which would load every SIMD evenly, are 70 % SLOWER --
+		// the kernel is not bound by the doubly loaded CUs; the knob stays for experiments, the default is 64)
+		(void)ngrp64;
+		if (const char * m = getenv("TMX_VI_CPW")) { const int c = atoi(m); if (c >= 1 && c <= 64) e->vi_cpw = c; }
+		const int ngrp = (e->nunique + e->vi_cpw - 1) / e->vi_cpw + 2;
+		e->vi_stream_cols = std::max(e->NUS, ngrp * 64);
+	}
+	const size_t abb = (size_t)n * (TMX_BW + 1) * e->vi_stream_cols * sizeof(double) + zpage, rb = (size_t)n * e->NUS * sizeof(double);
 	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); HIPCHK(hipMemset((char *)e->d_ab + abb - zpage, 0, zpage)); bytes += abb;
 	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
 	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
@@ -1522,20 +1559,20 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 		// viscosity (HorizontalDynamicsFEM.cpp:2672-2686): one pass from the initial instance, coefficients not scaled
 		// with the grid spacing; the scalar part runs with +dt and the vector part with -dt, which the kernel's single
 		// dt expresses exactly through the sign of nu_scalar ((-dt) * (-nu) is the same product)
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), -dt, -c.nu_scalar, c.nu_div, c.nu_vort);
-		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), dt, c.nu_scalar, 1); }
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), -dt, -c.nu_scalar, c.nu_div, c.nu_vort, 0);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), inst(e, iinit), inst(e, iupd), dt, c.nu_scalar, 1, 0); }
 		if ((r = launch_check("viscosity pass"))) return r;
 		if ((r = tmx_apply_dss(e, iupd))) return r;
 	} else {
-		double scale = 1.0;
-		if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
+		// second pass: coefficients scaled with the patch's (delta_alpha / reference length)^3.2, per column (G2_NUS)
+		const int scale = (c.reference_length != 0.0) ? 1 : 0;
 		if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;     // CopyData :2663, ZeroData :2693
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0);
-		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0); }
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0); }
 		if ((r = launch_check("hypervis pass 1"))) return r;
 		if ((r = tmx_apply_dss(e, iwork))) return r;
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale);
-		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, 1); }
+		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale); }
 		if ((r = launch_check("hypervis pass 2"))) return r;
 		if ((r = tmx_apply_dss(e, iupd))) return r;
 	}
@@ -1566,16 +1603,15 @@ extern "C" int tmx_h_substep_after_subcycle(tmx_engine * e, int iinit, int iupd,
 	KParams p = make_params(e);
 	ProfScope ps(e, TMX_K_HYPERVIS);
 	if (isubstep == 0) {
-		tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0);
-		if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0);
+		tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+		if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0);
 		if (result) *result = iwork;
 		return launch_check("hypervis sub-step 0");
 	}
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "SubStepAfterSubCycle: initial and update data must be distinct");
-	double scale = 1.0;
-	if (c.reference_length != 0.0) scale = pow(c.element_delta_a / c.reference_length, 3.2);
-	tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, c.nu_div * scale, c.nu_vort * scale);
-	if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar * scale, 1);
+	const int scale = (c.reference_length != 0.0) ? 1 : 0;
+	tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+	if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale);
 	if (e->rayleigh) tmxk_rayleigh(e, p, inst(e, iupd), dt);
 	if (result) *result = iupd;
 	return launch_check("hypervis sub-step 1");

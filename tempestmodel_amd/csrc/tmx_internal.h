@@ -27,7 +27,10 @@ enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS,
 	G2_LAT, G2_PS,      // column physics inputs (tmx_set_patch_physics_inputs): latitude, Held-Suarez surface pressure
 	// factors of the closed-form 3-D metric (tmx_set_patch_metric_factors): -s/d_xi R, 1+Y^2, XY, 1+X^2,
 	// d_alpha zs, d_beta zs, 1/d_xi R, 1/(d_xi R)^2
-	G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2, G2_COUNT };
+	G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2,
+	// element spacing of the column's patch (tmx_set_patch_element_spacing): 1 / delta_alpha, 1 / delta_beta and the local
+	// hyperviscosity scale (delta_alpha / reference length)^3.2 (HorizontalDynamicsFEM.cpp:1973)
+	G2_IDA, G2_IDB, G2_NUS, G2_COUNT };
 // 3-D node geometry [field][L][NS]
 enum { G3N_CA2 = 0, G3N_CB2, G3N_CX2, G3N_DRA, G3N_DRB, G3N_COUNT };
 // 3-D interface geometry [field][L+1][NS]
@@ -55,6 +58,7 @@ struct PatchInfo {
 	int panel = -1, nea = 0, neb = 0, na = 0, nb = 0, owner = 0;
 	int nbp[8];
 	int elem_base = -1;                      // first local element, -1 if not owned
+	double da = 0.0, db = 0.0;               // GridPatchGLL::GetElementDeltaA / B of this patch (0: cfg.element_delta_a)
 	std::vector<int> hi, hj, hsp, hsi, hsj, hspanel;
 	std::vector<double> htrans;
 	std::vector<int> hoff;                   // host node offset i * nb + j of every device column (built on first transfer)
@@ -137,6 +141,7 @@ struct tmx_engine {
 	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
+	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
 	bool fully_explicit = false, udiff = false;   // cfg.fully_explicit / cfg.uniform_diffusion
@@ -163,7 +168,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1);
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
-	double dt, double nu_s, double nu_d, double nu_v);
+	double dt, double nu_s, double nu_d, double nu_v, int scale_locally);
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
@@ -171,7 +176,7 @@ void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const doubl
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
-void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter);
+void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale_locally);
 int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
 void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);
 struct InterpArgs {

@@ -265,10 +265,10 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		dbrf -= s[ty][7][lb] * S;
 		dbpf -= s[ty][8][lb] * S;
 	}
-	const double ida = p.inv_da;
-	daub *= ida; daux *= ida; dbua *= ida; dbux *= ida;
-	darf *= ida; dbrf *= ida; dapf *= ida; dbpf *= ida;
-	dap *= ida; dbp *= ida; dake *= ida; dbke *= ida;
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];      // 1 / element spacing of the column's patch
+	daub *= ida; daux *= ida; dbua *= idb; dbux *= idb;
+	darf *= ida; dbrf *= idb; dapf *= ida; dbpf *= idb;
+	dap *= ida; dbp *= idb; dake *= ida; dbke *= idb;
 
 	// u x zeta (:1011-1037)
 	const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
@@ -464,18 +464,20 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 // 20 gathers in flight (measured 90 -> 74 us per call at ne30 L30 against loading slab by slab), and the tiles
 // of one XCD run level-major, so that the partially used 128-byte element rows of a 4-level tile are completed
 // by the neighbouring group tiles while they still sit in that XCD's L2 (74 -> 68 us).
+// member M's combination of the copies w0..w3 (values already in M's frame); ty = M's 2-bit pairing type
 template <int M>
-__device__ __forceinline__ double dss_combine(const double (&w)[4], int n, int gt) {
-	const int ty = (gt >> (2 * M)) & 3;
-	if (n == 2) return 0.5 * (w[0] + w[1]);
+__device__ __forceinline__ double dss_combine(double w0, double w1, double w2, double w3, int n, int ty) {
+	if (n == 2) return 0.5 * (w0 + w1);
 	if (n == 4) {
-		const double p0 = (ty == 0) ? w[0] + w[1] : ((ty == 1) ? w[0] + w[2] : w[0] + w[3]);
-		const double p1 = (ty == 0) ? w[2] + w[3] : ((ty == 1) ? w[1] + w[3] : w[1] + w[2]);
+		const double p0 = (ty == 0) ? w0 + w1 : ((ty == 1) ? w0 + w2 : w0 + w3);
+		const double p1 = (ty == 0) ? w2 + w3 : ((ty == 1) ? w1 + w3 : w1 + w2);
 		return 0.5 * (0.5 * p0 + 0.5 * p1);
 	}
-	constexpr int NX = (M + 1) % 3, PV = (M + 2) % 3;
-	const double first = ty ? w[PV] : w[NX], second = ty ? w[NX] : w[PV];
-	return (1.0 / 3.0) * ((w[M < 3 ? M : 0] + first) + second);
+	// cube corner: (1/3) * ((x + first) + second), first = next member (ty 0) or previous member (ty 1)
+	const double me = (M == 0) ? w0 : ((M == 1) ? w1 : w2);
+	const double nx = (M == 0) ? w1 : ((M == 1) ? w2 : w0);
+	const double pv = (M == 0) ? w2 : ((M == 1) ? w0 : w1);
+	return (1.0 / 3.0) * ((me + (ty ? pv : nx)) + (ty ? nx : pv));
 }
 
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
@@ -516,27 +518,28 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
 	// gt == 0 with two or four copies: every member has the same pairing, one value for all of them
 	const bool same = (gt == 0) && (n != 3);
-	auto scalar = [&](const double (&w)[4], double (&o)[4]) {
-		if (same) { const double a = dss_combine<0>(w, n, 0); o[0] = a; o[1] = a; o[2] = a; o[3] = a; }
-		else { o[0] = dss_combine<0>(w, n, gt); o[1] = dss_combine<1>(w, n, gt); o[2] = dss_combine<2>(w, n, gt); o[3] = dss_combine<3>(w, n, gt); }
-	};
+	const int t0 = gt & 3, t1 = (gt >> 2) & 3, t2 = (gt >> 4) & 3, t3 = (gt >> 6) & 3;
+#define DSS_SCALAR(W0, W1, W2, W3, O0, O1, O2, O3) do { \
+		if (same) { const double a_ = dss_combine<0>(W0, W1, W2, W3, n, 0); O0 = a_; O1 = a_; O2 = a_; O3 = a_; } \
+		else { O0 = dss_combine<0>(W0, W1, W2, W3, n, t0); O1 = dss_combine<1>(W0, W1, W2, W3, n, t1); \
+		       O2 = dss_combine<2>(W0, W1, W2, W3, n, t2); O3 = dss_combine<3>(W0, W1, W2, W3, n, t3); } } while (0)
 	double out[5][4];
 #pragma unroll
-	for (int t = 0; t < 3; t++) scalar(v[t], out[t]);
+	for (int t = 0; t < 3; t++) DSS_SCALAR(v[t][0], v[t][1], v[t][2], v[t][3], out[t][0], out[t][1], out[t][2], out[t][3]);
 	if (xi < 0) {
-		scalar(v[3], out[3]); scalar(v[4], out[4]);
+		DSS_SCALAR(v[3][0], v[3][1], v[3][2], v[3][3], out[3][0], out[3][1], out[3][2], out[3][3]);
+		DSS_SCALAR(v[4][0], v[4][1], v[4][2], v[4][3], out[4][0], out[4][1], out[4][2], out[4][3]);
 	} else {
+		// copies on other panels: every member sees the others rotated into its own frame
 		const double * Mx = xmat + (size_t)xi * 64;
-#define DSS_VEC(M_) do { \
-			double wa[4] = { 0, 0, 0, 0 }, wb[4] = { 0, 0, 0, 0 }; \
-			_Pragma("unroll") for (int q = 0; q < 4; q++) if (q < n) { \
-				const double * T = Mx + (M_ * 4 + q) * 4; \
-				if (q == M_) { wa[q] = v[3][q]; wb[q] = v[4][q]; } \
-				else { wa[q] = T[0] * v[3][q] + T[1] * v[4][q]; wb[q] = T[2] * v[3][q] + T[3] * v[4][q]; } \
-			} \
-			out[3][M_] = dss_combine<M_>(wa, n, gt); out[4][M_] = dss_combine<M_>(wb, n, gt); } while (0)
-		DSS_VEC(0); DSS_VEC(1); DSS_VEC(2); DSS_VEC(3);
+#define DSS_ROT(M_, Q_, A_, B_) do { if (Q_ == M_ || Q_ >= n) { A_ = v[3][Q_]; B_ = v[4][Q_]; } else { const double * T_ = Mx + (M_ * 4 + Q_) * 4; \
+			A_ = T_[0] * v[3][Q_] + T_[1] * v[4][Q_]; B_ = T_[2] * v[3][Q_] + T_[3] * v[4][Q_]; } } while (0)
+#define DSS_VEC(M_, TY_) do { double a0, a1, a2, a3, b0, b1, b2, b3; \
+			DSS_ROT(M_, 0, a0, b0); DSS_ROT(M_, 1, a1, b1); DSS_ROT(M_, 2, a2, b2); DSS_ROT(M_, 3, a3, b3); \
+			out[3][M_] = dss_combine<M_>(a0, a1, a2, a3, n, TY_); out[4][M_] = dss_combine<M_>(b0, b1, b2, b3, n, TY_); } while (0)
+		DSS_VEC(0, t0); DSS_VEC(1, t1); DSS_VEC(2, t2); DSS_VEC(3, t3);
 #undef DSS_VEC
+#undef DSS_ROT
 	}
 #pragma unroll
 	for (int t = 0; t < 5; t++)
@@ -547,14 +550,17 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	if (lev) {
 		for (int q = 0; q < nt; q++) {
 			const size_t sl = (size_t)TMX_SLAB_Q(L, q, kk);
-			double w[4], o[4];
-#pragma unroll
-			for (int m = 0; m < 4; m++) w[m] = (m < n) ? ptr[m][sl * str[m]] : 0.0;
-			scalar(w, o);
-#pragma unroll
-			for (int m = 0; m < 4; m++) if (loc[m]) x[sl * NS + c[m]] = o[m];
+			const double w0 = (0 < n) ? ptr[0][sl * str[0]] : 0.0, w1 = (1 < n) ? ptr[1][sl * str[1]] : 0.0;
+			const double w2 = (2 < n) ? ptr[2][sl * str[2]] : 0.0, w3 = (3 < n) ? ptr[3][sl * str[3]] : 0.0;
+			double o0, o1, o2, o3;
+			DSS_SCALAR(w0, w1, w2, w3, o0, o1, o2, o3);
+			if (loc[0]) x[sl * NS + c[0]] = o0;
+			if (loc[1]) x[sl * NS + c[1]] = o1;
+			if (loc[2]) x[sl * NS + c[2]] = o2;
+			if (loc[3]) x[sl * NS + c[3]] = o3;
 		}
 	}
+#undef DSS_SCALAR
 }
 
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1) {
@@ -632,6 +638,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + lane;
+	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
 	const int k = blockIdx.y * 4 + ty;
 	const bool act = (k < L) && (col < p.ncol);
 	const int kc = (k < L) ? k : L - 1;
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 				daq += s[ty][4][eb + 4 * t + j] * sD[t * 4 + i];
 				dbq += s[ty][4][eb + 4 * i + t] * sD[t * 4 + j];
 			}
-			daq *= p.inv_da; dbq *= p.inv_da;
+			daq *= ida; dbq *= idb;
 			const double cdaq = dc2a0 * daq + dc2a1 * dbq;
 			const double cdbq = dc2a1 * daq + dc2b1 * dbq;
 			taf -= ks * djn * rho * cdaq;
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 			da -= s[ty][0][eb + 4 * t + j] * sS[i * 4 + t];
 			db -= s[ty][1][eb + 4 * i + t] * sS[j * 4 + t];
 		}
-		da *= p.inv_da; db *= p.inv_da;
+		da *= ida; db *= idb;
 		double out = bv - dt * invJ * (da + db);
 		s[ty][2][lane] = out;
 		__syncthreads();
@@ -713,7 +720,7 @@ void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 // ApplyScalarHyperdiffusion, tracer branch (HorizontalDynamicsFEM.cpp:1999-2035, :2076-2165) and, after the second
 // pass, FilterNegativeTracers (:2707).  xbase == nullptr: base 0 (the zeroed working instance of the first pass).
 __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, const double * __restrict__ area,
-	const double * __restrict__ xsrc, const double * xbase, double * xout, double dt, double nu, int filter)
+	const double * __restrict__ xsrc, const double * xbase, double * xout, double dt, double nu_in, int filter, int scale)
 {
 	__shared__ double s[4][4][64];
 	__shared__ double sD[16], sS[16];
@@ -722,6 +729,8 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + lane;
+	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
+	const double nu = nu_in * (scale ? p.g2d[G2_NUS * (size_t)p.NS + col] : 1.0);
 	const int k = blockIdx.y * 4 + ty;
 	const bool act = (k < L) && (col < p.ncol);
 	const int kc = (k < L) ? k : L - 1;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 			da += s[ty][0][eb + 4 * t + j] * sD[t * 4 + i];
 			db += s[ty][0][eb + 4 * i + t] * sD[t * 4 + j];
 		}
-		da *= p.inv_da; db *= p.inv_da;
+		da *= ida; db *= idb;
 		s[ty][1][lane] = jn * (c2a0 * da + c2a1 * db);
 		s[ty][2][lane] = jn * (c2a1 * da + c2b1 * db);
 		__syncthreads();
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 			ua += s[ty][1][eb + 4 * t + j] * sS[i * 4 + t];
 			ub += s[ty][2][eb + 4 * i + t] * sS[j * 4 + t];
 		}
-		ua *= p.inv_da; ub *= p.inv_da;
+		ua *= ida; ub *= idb;
 		double out = bv - dt * (1.0 / jn) * nu * (ua + ub);
 		if (filter) {
 			__syncthreads();
@@ -778,9 +787,9 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 	}
 }
 
-void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter) {
+void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_hypervis_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xsrc, xbase, xout, dt, nu, filter);
+	hipLaunchKernelGGL(k_hypervis_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xsrc, xbase, xout, dt, nu, filter, scale);
 }
 
 // VerticalDynamicsFEM::UpdateColumnTracers (VerticalDynamicsFEM.cpp:3783-4282), implicit mode, vertical order 1:
@@ -1281,8 +1290,9 @@ void tmxk_pack(tmx_engine * e, const KParams & p, const double * x) {
 // out = base - dt * (...)(src); base = 0 when xbase == nullptr (first pass into the zeroed work
 // instance), otherwise the instance that StepAfterSubCycle copied into the update instance.
 
+// scale != 0: the coefficients are multiplied by the patch's (delta_alpha / reference length)^3.2 (fScaleNuLocally, :1968-1975)
 __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
-	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s, double nu_d, double nu_v)
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale)
 {
 	__shared__ double s[4][8][64];
 	__shared__ double sD[16], sS[16];
@@ -1328,9 +1338,11 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 		daub += s[ty][4][la] * Da; dbua += s[ty][3][lb] * Db;
 		dajua += s[ty][5][la] * Da; dbjub += s[ty][6][lb] * Db;
 	}
-	const double ida = p.inv_da;
-	daT *= ida; dbT *= ida; daR *= ida; dbR *= ida; daW *= ida; dbW *= ida;
-	daub *= ida; dbua *= ida; dajua *= ida; dbjub *= ida;
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	const double nsc = scale ? p.g2d[G2_NUS * NS + col] : 1.0;
+	const double nu_s = nu_s_in * nsc, nu_d = nu_d_in * nsc, nu_v = nu_v_in * nsc;
+	daT *= ida; dbT *= idb; daR *= ida; dbR *= idb; daW *= ida; dbW *= idb;
+	daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
 	const double invJ2 = 1.0 / j2d;
 	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
 	__syncthreads();
@@ -1352,8 +1364,8 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 		dad -= Sa * s[ty][6][la]; dbd -= Sb * s[ty][6][lb];
 		dac -= Sa * s[ty][7][la]; dbc -= Sb * s[ty][7][lb];
 	}
-	uaT *= ida; ubT *= ida; uaR *= ida; ubR *= ida; uaW *= ida; ubW *= ida;
-	dad *= ida; dbd *= ida; dac *= ida; dbc *= ida;
+	uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
+	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
 
 	{
 		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
@@ -1380,9 +1392,9 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 }
 
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
-	double dt, double nu_s, double nu_d, double nu_v) {
+	double dt, double nu_s, double nu_d, double nu_v, int scale) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v);
+	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1441,10 +1453,10 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 		daubr += s[ty][7][la] * Da; dbuar += s[ty][6][lb] * Db;
 		dajuar += s[ty][8][la] * Da; dbjubr += s[ty][9][lb] * Db;
 	}
-	const double ida = p.inv_da;
-	daT *= ida; dbT *= ida; daW *= ida; dbW *= ida;
-	daub *= ida; dbua *= ida; dajua *= ida; dbjub *= ida;
-	daubr *= ida; dbuar *= ida; dajuar *= ida; dbjubr *= ida;
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	daT *= ida; dbT *= idb; daW *= ida; dbW *= idb;
+	daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+	daubr *= ida; dbuar *= idb; dajuar *= ida; dbjubr *= idb;
 	const double invJ2 = 1.0 / j2d;
 	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
 	const double dvr = (dajuar + dbjubr) * invJ2, clr = (daubr - dbuar) * invJ2;
@@ -1467,8 +1479,8 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 		dadr -= Sa * s[ty][6][la]; dbdr -= Sb * s[ty][6][lb];
 		dacr -= Sa * s[ty][7][la]; dbcr -= Sb * s[ty][7][lb];
 	}
-	uaT *= ida; ubT *= ida; uaW *= ida; ubW *= ida;
-	dad *= ida; dbd *= ida; dac *= ida; dbc *= ida; dadr *= ida; dbdr *= ida; dacr *= ida; dbcr *= ida;
+	uaT *= ida; ubT *= idb; uaW *= ida; ubW *= idb;
+	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb; dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
 	{
 		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
 		xout[o] = xout[o] - dt * (1.0 / je) * kv * (uaW + ubW);
@@ -2236,6 +2248,10 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 __device__ __forceinline__ double * vi_stream_base(double * AB, int n, int u) {
 	return AB + ((size_t)(u >> 6) * n * TMX_UW) * 64 + (u & 63);
 }
+// the same with the column group and the lane given separately (groups of fewer than 64 columns, k_vi_pair)
+__device__ __forceinline__ double * vi_stream_base_g(double * AB, int n, int grp, int lane) {
+	return AB + ((size_t)grp * n * TMX_UW) * 64 + lane;
+}
 
 template <bool SPARSE>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
@@ -2396,7 +2412,7 @@ __device__ __forceinline__ double vi_back_row(const URow & s, double (&xw)[TMX_B
 
 __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int u, int col, int NUS,
 	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, double * xup,
-	const int * __restrict__ udep, const int * umask)
+	const int * __restrict__ udep, const int * umask, int zlane = -1)
 {
 	int dep[3];
 #pragma unroll
@@ -2405,7 +2421,7 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
 	// zero page: 64 doubles behind the streams; AB is the lane's stream pointer (vi_stream_base)
-	const double * zp = RHS + (u & 63);
+	const double * zp = RHS + ((zlane >= 0) ? zlane : (u & 63));
 	// two trips (six rows) of register sets: a set is refilled for the trip after next right after it is consumed,
 	// so five rows = 55 loads are in flight (vmcnt holds 63) -- the back substitution of a full grid is HBM-bound
 	URow A, B, C, D, E, F;      // A,D: rows 3k+2 (rho); B,E: 3k+1 (W); C,F: 3k (rho*theta)
@@ -2556,7 +2572,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 template <bool SPARSE, bool CLOSED, int PAIRS>
 __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
-	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag)
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw)
 {
 	extern __shared__ double opsl_mem[];
 	double * opsl = opsl_mem;
@@ -2572,12 +2588,17 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += 128 * PAIRS) etal[t] = p.eta[t];
 	__syncthreads();
 	const size_t NS = (size_t)p.NS;
-	const int u = (blockIdx.x * PAIRS + pair) * 64 + lane;
-	if (u >= nunique) return;          // both wavefronts drop the same lanes; each keeps at least one
+	// cpw columns per wavefront (64, or fewer so that the column groups fill every SIMD of the chip evenly: tmxk_vi_fused).
+	// Lanes beyond the group's columns do not return -- the block-row loops below are full of workgroup barriers -- they
+	// redo the group's last column (the last column of the grid in a trailing, empty group): same values to the same
+	// addresses of the state, a stream slot of their own.
+	const int grp = blockIdx.x * PAIRS + pair;
+	const int ulast = min(nunique, (grp + 1) * cpw) - 1;
+	const int u = (grp * cpw < nunique) ? min(grp * cpw + min(lane, cpw - 1), ulast) : nunique - 1;
 	const int n = TMX_FTOT * (L + 1);
 	const int col = ucol[u];
 	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
-	AB = vi_stream_base(AB, n, u);            // this lane's slot in its wavefront's U-row stream
+	AB = vi_stream_base_g(AB, n, grp, lane);  // this lane's slot in its wavefront's U-row stream
 
 	if (role == 0) {
 		// ---- producer: assemble block rows 0..L ----
@@ -2662,7 +2683,7 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
 	}
 	if (singular) atomicExch(flag, 1);
-	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask);
+	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
 }
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
@@ -2675,14 +2696,15 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	// 840 us against 899 us; 190 groups 95 us with one pair per workgroup (every workgroup alone on a CU), 104 us with
 	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  So it is the production kernel at every
 	// size; the one-wavefront kernel stays as TMX_VI_PAIR=0 (bit-identical, tested).
-	const int ngrp = (e->nunique + 63) / 64;
 	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
+	const int cpw = use_pair ? e->vi_cpw : 64;
+	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
 		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double);
 		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 #define LAUNCH_PAIR(CL_, NP_) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
-			e->stream, p, xin, xup, dt, e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag)
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR
@@ -2690,10 +2712,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, true, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
-			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \
+			e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \
 	else \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, false, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
-			e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); } while (0)
+			e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); } while (0)
 	if (!e->vi_carry) LAUNCH_VI(false, true);
 	else if (sparse) LAUNCH_VI(true, true);
 	else LAUNCH_VI(true, false);
@@ -2817,8 +2839,8 @@ __global__ __launch_bounds__(64) void k_sw_explicit(KParams p, const double * __
 		dbua += s[0][lb] * sD[t * 4 + j];
 		dbke += s[2][lb] * sD[t * 4 + j];
 	}
-	const double ida = p.inv_da;
-	dafa *= ida; daub *= ida; dake *= ida; dbfb *= ida; dbua *= ida; dbke *= ida;
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	dafa *= ida; daub *= ida; dake *= ida; dbfb *= idb; dbua *= idb; dbke *= idb;
 	double upa = 0.0, upb = 0.0;
 	const double zeta = (daub - dbua);
 	const double ucza = cub * zeta, uczb = -cua * zeta;

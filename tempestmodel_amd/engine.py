@@ -109,6 +109,7 @@ def load_library():
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_set_patch_level_heights.argtypes = [C.c_void_p, C.c_int, PD]
+    lib.tmx_set_patch_element_spacing.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
     lib.tmx_physics_kessler.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_download_precipitation.argtypes = [C.c_void_p, C.c_int, PD, C.c_int]
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
@@ -215,6 +216,8 @@ class Engine:
             nbp = (C.c_int * 8)(*[int(v) for v in P.neighbor_panels])
             self._chk(self.lib.tmx_define_patch(self.h, P.index, P.panel, (P.ga1 - P.ga0) // g.np,
                                                 (P.gb1 - P.gb0) // g.np, self.owner[P.index], nbp))
+            if getattr(P, "delta_a", 0.0):      # the reference's own per-patch element spacing (fixtures that carry it)
+                self._chk(self.lib.tmx_set_patch_element_spacing(self.h, P.index, float(P.delta_a), float(getattr(P, "delta_b", P.delta_a))))
         for P in g.patches:
             hh = P.halo
             arrs = [np.ascontiguousarray(hh[k], dtype=np.int32) for k in

@@ -81,7 +81,8 @@ def flat_geometry(d):
     at a few hundred KB, so that the fixture can be compared bit for bit."""
     keep3 = ("jacobian", "jacobian_redge", "contra_metric_a", "contra_metric_b", "contra_metric_xi", "contra_metric_a_redge",
              "contra_metric_b_redge", "contra_metric_xi_redge", "deriv_r_node", "deriv_r_redge", "element_area_node")
-    keep2 = ("jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "coriolis_f", "topography", "topography_deriv")
+    keep2 = ("jacobian2d", "contra_metric_2d_a", "contra_metric_2d_b", "coriolis_f", "topography", "topography_deriv",
+             "element_delta_a", "element_delta_b")
     out = {}
     for k, v in d.items():
         if k.startswith(("grid/", "op/", "halo_trans/", "phys/")):

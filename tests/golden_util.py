@@ -68,6 +68,10 @@ def grid_from_fixture(d, override=True, case="jw", ntracers=0):
         g.dx = d["op/dx_basis_1d"]
         g.stiff = d["op/stiffness_1d"]
         override_halo_transforms(g, d)
+        for P in g.patches:     # GridPatchGLL::GetElementDeltaA / B: per patch, not exactly pi / (2 ne)
+            if "p%d/element_delta_a" % P.index in d:
+                P.delta_a = float(d["p%d/element_delta_a" % P.index][0])
+                P.delta_b = float(d["p%d/element_delta_b" % P.index][0]) if "p%d/element_delta_b" % P.index in d else P.delta_a
     return g, states
 
 

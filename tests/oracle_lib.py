@@ -28,7 +28,7 @@ class OrcPatch(C.Structure):
                 ("hi", PI), ("hj", PI), ("hsp", PI), ("hsi", PI), ("hsj", PI), ("hspanel", PI),
                 ("htrans", PD),
                 ("ray_node", PD), ("ray_redge", PD), ("ref_node", PD), ("ref_redge", PD), ("ref_tracer", PD), ("area_node", PD),
-                ("lat", PD), ("surf_p", PD)]
+                ("lat", PD), ("surf_p", PD), ("delta_a", C.c_double), ("delta_b", C.c_double)]
 
 
 class OrcGrid(C.Structure):
@@ -133,6 +133,8 @@ class Oracle:
             la = np.ascontiguousarray(P.lat, dtype=np.float64)
             self._keep.append(la)
             cp.lat = _pd(la)
+            cp.delta_a = float(getattr(P, "delta_a", 0.0) or 0.0)
+            cp.delta_b = float(getattr(P, "delta_b", 0.0) or 0.0)
             if "hs_surface_pressure" in P.geom:
                 sp = np.ascontiguousarray(P.geom["hs_surface_pressure"], dtype=np.float64)
                 self._keep.append(sp)

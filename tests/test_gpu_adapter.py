@@ -18,6 +18,11 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--ne", "4", "--levels", "10", "--steps", "5", "--patches", "6"]),
     ("production", ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
     ("parity", ["--ne", "4", "--levels", "10", "--steps", "3", "--patches", "6"]),
+    # element counts that are not powers of two: the reference's per-patch element spacing (a difference of edge
+    # coordinates, GridPatchGLL.cpp:67-75) is not pi / (2 ne) there, and with 24 patches it need not be one value
+    ("production", ["--ne", "6", "--levels", "8", "--steps", "3", "--patches", "24"]),
+    ("production", ["--ne", "5", "--levels", "6", "--steps", "3", "--patches", "6"]),
+    ("production", ["--ne", "10", "--levels", "6", "--steps", "2", "--patches", "24"]),
     # the reference's ARK232 over the plugin classes: StepImplicitTermsExplicitly and the sub-cycled explicit stages
     ("parity", ["--scheme", "ark232", "--ne", "3", "--levels", "6", "--steps", "2", "--patches", "6"]),
     # state kept on the device between steps (SetHostSyncInterval), downloaded once at the end
