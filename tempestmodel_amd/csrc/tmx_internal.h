@@ -49,6 +49,7 @@ struct KParams {
 	int closed;             // 1: evaluate the 3-D metric from the G2_M* factors (g3n / g3e are null)
 	double inv_da;
 	double grav, Rd, cp, p0;
+	const int * quads;      // not null: blockIdx.x indexes this list of 64-column tiles (boundary-first / interior launches of a multi-rank stage)
 	double dx[16];          // dx[s*4+i]    = dDxBasis1D(s,i)
 	double stiff[16];       // stiff[i*4+s] = dStiffness1D(i,s)
 };
@@ -141,6 +142,10 @@ struct tmx_engine {
 	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
+	// boundary-first launches (ranks > 1): 64-column tiles holding a column another rank needs, and the others
+	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_quads_early = 0, n_quads_late = 0, launch_tiles = 0; bool split_stage = false, split_overlapped = false;
+	bool use_mfma = false;                   // TMX_MFMA=1: 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
+	int vi_group = -1, vi_group_max = 4608;     // lane-group column kernel: -1 auto (nunique <= vi_group_max: measured 71-77 us against 99 us per launch at 2 166 / 3 750 columns, 148 against 100 at 8 214), 0 off, 1 on (TMX_VI_GROUP, TMX_VI_GROUP_MAX)
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)

@@ -154,18 +154,29 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 // registers -- same statements in the same order, so the result is bit-identical to the two calls.
 // The H-only values of levels 0,1 are kept in `uv01` for the bottom boundary condition of W, which the
 // reference evaluates before V.StepExplicit runs (HorizontalDynamicsFEM.cpp:1615-1638).
-template <bool FUSE_V, int NT>
+// MF (opt-in, TMX_MFMA=1): the twelve 4x4 contractions of a wavefront's four elements as v_mfma_f64_4x4x4_4b_f64 instead
+// of LDS reads + VALU.  Lane layout of that instruction, probed on gfx950 with exact integer data (tools/probe/
+// mfma_f64_probe.hip): A[m][k] of block b at lane m + 4b + 16k, B[k][n] at lane n + 4b + 16k, D[m][n] at lane n + 4b + 16m.
+// With the lane -> node map  lane = j + 4 e + 16 i  (j beta node, e element, i alpha node) a field IS the B operand
+// of the alpha contraction (k = alpha node), the result lands on the lane of its own node, and no LDS is touched; the
+// beta contraction takes the field as A with alpha and beta exchanged, one in-register lane transpose (two
+// ds_bpermute_b32) per field.  Global accesses stay one contiguous 512-byte row per wavefront (the map permutes lanes
+// inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
+// results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
+template <bool FUSE_V, int NT, bool MF>
 __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
 {
-	__shared__ double s[KT_H][9][64];
+	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
 	__shared__ double sD[16], sS[16];
 	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
-	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	if (!MF && tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	// column of this lane: element-major (e, i, j) in memory; MF: lane = j + 4 e + 16 i
+	const int tile = p.quads ? p.quads[blockIdx.x] : blockIdx.x;       // 64-column tile of this workgroup
+	const int col = MF ? tile * 64 + ((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3) : tile * 64 + lane;
 	const int k = blockIdx.y * KT_H + ty;
 	const bool act = (k < L) && (col < p.ncol);
 
@@ -230,6 +241,28 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
 	const double exn = act ? exner_from_rhotheta(p, rt) : 0.0;
 	const double fa = jn * conUa, fb = jn * conUb;
+	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
+	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+	if (MF) {
+		// operator entries of this lane: D[k][m] and S[m][k] with m = lane & 3, k = lane >> 4 (A of the alpha contraction
+		// d/d_alpha f (i,j) = sum_t D[t][i] f(t,j), B of the beta contraction d/d_beta f (i,j) = sum_t f(i,t) D[t][j])
+		const int m_ = lane & 3, k_ = lane >> 4;
+		const double cD = p.dx[k_ * 4 + m_], cS = p.stiff[m_ * 4 + k_];
+		// alpha <-> beta exchange inside the element: value of lane (lane >> 4) + 4 e + 16 (lane & 3)
+		const int src = (k_ + (lane & 12) + 16 * m_) * 4;
+		auto tr = [&](double v) -> double {
+			const long long b = __double_as_longlong(v);
+			const int lo = __builtin_amdgcn_ds_bpermute(src, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(src, (int)(b >> 32));
+			return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+		};
+#define MFMA4(A_, B_) __builtin_amdgcn_mfma_f64_4x4x4f64((A_), (B_), 0.0, 0, 0, 0)
+		daub = MFMA4(cD, ub); daux = MFMA4(cD, ux); dap = MFMA4(cD, exn); dake = MFMA4(cD, ke);
+		darf = -MFMA4(cS, fa * rh); dapf = -MFMA4(cS, fa * rt);
+		dbua = MFMA4(tr(ua), cD); dbux = MFMA4(tr(ux), cD); dbp = MFMA4(tr(exn), cD); dbke = MFMA4(tr(ke), cD);
+		dbrf = -MFMA4(tr(fb * rh), cS); dbpf = -MFMA4(tr(fb * rt), cS);
+#undef MFMA4
+		if (!act) return;
+	} else {
 	s[ty][0][lane] = ua;  s[ty][1][lane] = ub;  s[ty][2][lane] = ux;
 	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
 	s[ty][5][lane] = fa * rh; s[ty][6][lane] = fa * rt;
@@ -241,8 +274,6 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 #endif
 
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
-	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
-	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
 #pragma unroll
 	for (int t = 0; t < 4; t++) {
 		const int la = eb + 4 * t + j;        // node (t, j)
@@ -264,6 +295,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		dbke += s[ty][4][lb] * D;
 		dbrf -= s[ty][7][lb] * S;
 		dbpf -= s[ty][8][lb] * S;
+	}
 	}
 	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];      // 1 / element spacing of the column's patch
 	daub *= ida; daux *= ida; dbua *= idb; dbux *= idb;
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k > L || col >= p.ncol) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
@@ -364,13 +396,15 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
-	dim3 blk(64, KT_H), grd(p.NS / 64, (p.L + KT_H - 1) / KT_H);
+	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
+	dim3 blk(64, KT_H), grd(ntile, (p.L + KT_H - 1) / KT_H);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
-	dim3 blk2(64, 4), grd2(p.NS / 64, (p.L + 1 + 3) / 4);
+	dim3 blk2(64, 4), grd2(ntile, (p.L + 1 + 3) / 4);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
 #define LAUNCH_HV(NT_) do { \
-		if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
-		else hipLaunchKernelGGL((k_h_explicit<false, NT_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
 		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HV(0); break;
@@ -1301,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + lane;
 	const int kk = blockIdx.y * 4 + ty;
 	const bool actw = (kk <= L) && (col < p.ncol);     // interface level (W)
 	const bool actn = (kk < L) && (col < p.ncol);      // model level (U,V,rho*theta,rho)
@@ -1393,7 +1427,7 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v, int scale) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	dim3 blk(64, 4), grd(p.quads ? e->launch_tiles : p.NS / 64, (p.L + 1 + 3) / 4);
 	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
 }
 
@@ -2257,6 +2291,10 @@ template <bool SPARSE>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
+#ifdef TMX_ABL_NO_USTORE     // ablation builds: elimination without the U-row stream (one value kept alive)
+	if (piv[0] == 12345.678 && pb == 1.0) AB[0] = piv[1];
+	return;
+#endif
 #pragma unroll
 	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
 	int mask = 0;
@@ -2683,7 +2721,194 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
 	}
 	if (singular) atomicExch(flag, 1);
+#ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
 	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// V implicit for FEW columns per GPU (the per-rank share of a strong-scaling run: ne30 over 8 ranks leaves 6 075 unique
+// columns for 1 024 SIMDs): one column per 16-lane group, four columns per wavefront.  The one-lane-per-column kernels
+// above are bound there by the dependent chain of one column (93 pivot steps of ~270 instructions each, plus the
+// assembly of 31 block rows one after the other) while most of the chip idles; here the chain is cut across lanes:
+//   * assembly: lane c of a group evaluates block row t0 + c (compute_block without the carry-over: same arithmetic on the
+//     same operands), 16 block rows at a time into an LDS ring -- two rounds instead of 31 sequential evaluations;
+//   * elimination: lane c <= 8 holds COLUMN c of the 5 x 9 pivot window, lane 15 the right-hand side.  Lane 0 finds the
+//     pivot row (first maximum) and the multipliers; pivot index and multipliers reach the group by DPP row broadcast,
+//     the row interchange is four selects per lane, the rank-1 update four fused multiply-adds per lane, and the
+//     window slides one column to the left by a DPP row shift (lanes 12-15 are masked out of the shift, so the
+//     right-hand side stays put and the idle lanes 9-14 keep feeding zeros into column 8);
+//   * the U rows go to the same HBM scratch as in the other kernels (one contiguous stream per wavefront,
+//     [row][10][4 columns]); the back substitution runs on lane 0 of each group in dtbsv order.
+// Every multiplication, fused update and division is the one of lu_pivot_step / vi_back_row: results are bit-identical
+// to k_vi_pair (test_fused_column_kernels_are_bit_identical_to_split_kernels).  Per wavefront-instruction this kernel
+// serves 4 columns instead of 64, so it only pays while the chip has SIMDs to spare: tmxk_vi_fused picks it by size.
+template <int SRC> __device__ __forceinline__ double grp_bcast(double v) {
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + SRC, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + SRC, 0xf, 0xf, false);
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// lanes 0..11 of every 16-lane row take the value of the next lane, lanes 12..15 keep their own
+__device__ __forceinline__ double grp_shift_left(double v) {
+	const long long b = __double_as_longlong(v);
+	const int l0 = (int)(b & 0xffffffffll), h0 = (int)(b >> 32);
+	const int lo = __builtin_amdgcn_update_dpp(l0, l0, 0x101, 0xf, 0x7, false);
+	const int hi = __builtin_amdgcn_update_dpp(h0, h0, 0x101, 0xf, 0x7, false);
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <bool CLOSED>
+__global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, double * xup, double dt,
+	int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, double * __restrict__ AB, int * __restrict__ flag)
+{
+	constexpr int MM = CLOSED ? 1 : 2;
+	constexpr int NQ = 3 * TMX_BW + 3;              // doubles per block row: three band rows and their right-hand sides
+	__shared__ double blk[4][16][NQ];               // ring of 16 block rows per column
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+	const int n = TMX_FTOT * (L + 1);
+	const int uraw = blockIdx.x * 4 + g;
+	const bool valid = uraw < nunique;
+	const int u = valid ? uraw : nunique - 1;       // a trailing, empty group redoes the last column (no stores)
+	const int col = ucol[u];
+	double * stream = AB + (size_t)blockIdx.x * n * 64 + lane;   // [row][4 columns][16 lanes]: entry c of U row j at (j * 64 + g * 16 + c); lane 15 = rhs
+
+	ColConst cc;
+	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+	const MetCol mcol = met_col(p, col);
+
+	// block rows [t0, t0 + 16) into the ring, one per lane
+	auto assemble = [&](int t0) {
+		const int t = t0 + c;
+		if (t <= L) {
+			const NodeLev nA = load_node<MM>(p, mcol, xin, t - 1, col, p.eta), nB = load_node<MM>(p, mcol, xin, t, col, p.eta),
+				nC = load_node<MM>(p, mcol, xin, t + 1, col, p.eta);
+			const EdgeLev eA = load_edge<MM>(p, mcol, xin, t - 1, col, p.eta), eB = load_edge<MM>(p, mcol, xin, t, col, p.eta),
+				eC = load_edge<MM>(p, mcol, xin, t + 1, col, p.eta);
+			double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+			BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			compute_block<false>(p, p.ops, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
+			double * q = &blk[g][c][0];
+#pragma unroll
+			for (int d = 0; d < TMX_BW; d++) { q[d] = rP[d]; q[TMX_BW + d] = rW[d]; q[2 * TMX_BW + d] = rR[d]; }
+			q[3 * TMX_BW] = fP; q[3 * TMX_BW + 1] = fW; q[3 * TMX_BW + 2] = fR;
+		}
+	};
+	// band entry d of matrix row r / its right-hand side, from the ring
+	auto band = [&](int r, int d) -> double { const int t = r / 3; return blk[g][t & 15][(r - 3 * t) * TMX_BW + d]; };
+	auto rhs = [&](int r) -> double { const int t = r / 3; return blk[g][t & 15][3 * TMX_BW + (r - 3 * t)]; };
+
+#ifdef TMX_VI_TIMING
+	const long long tg0 = __builtin_readcyclecounter();
+#endif
+	assemble(0);
+	__syncthreads();      // one wavefront per workgroup: orders the ring writes before the other lanes' reads
+#ifdef TMX_VI_TIMING
+	const long long tg1 = __builtin_readcyclecounter();
+#endif
+	// window column c (lanes 0..8: matrix column j + c; lane 15: right-hand side; lanes 9..14: zeros), rows j .. j + 4
+	double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+	if (c <= 8) {
+		// row r, window column c <-> band entry d = c - r + 4 (inside the band for c <= r + 4)
+		w0 = (c <= 4) ? band(0, c + 4) : 0.0;
+		w1 = (c <= 5) ? band(1, c + 3) : 0.0;
+		w2 = (c <= 6) ? band(2, c + 2) : 0.0;
+		w3 = (c <= 7) ? band(3, c + 1) : 0.0;
+		w4 = band(4, c);
+	} else if (c == 15) { w0 = rhs(0); w1 = rhs(1); w2 = rhs(2); w3 = rhs(3); w4 = rhs(4); }
+	bool singular = false;
+	for (int j = 0; j < n; j++) {
+		const int rin = j + 5;
+		// the ring holds 16 block rows = 48 matrix rows: when row 48 m comes up, all rows below it have entered the window
+		if (rin < n && rin % 48 == 0) { assemble(rin / 3); __syncthreads(); }
+		double in = 0.0;
+		if (rin < n) { if (c <= 8) in = band(rin, c); else if (c == 15) in = rhs(rin); }
+		// pivot search on column 0 (lane 0 of the group): first maximum, as dgbtf2's idamax
+		int pv = 0;
+		double amax = fabs(w0);
+		{ const double v = fabs(w1); if (v > amax) { amax = v; pv = 1; } }
+		{ const double v = fabs(w2); if (v > amax) { amax = v; pv = 2; } }
+		{ const double v = fabs(w3); if (v > amax) { amax = v; pv = 3; } }
+		{ const double v = fabs(w4); if (v > amax) { amax = v; pv = 4; } }
+		pv = __builtin_amdgcn_update_dpp(0, pv, 0x150, 0xf, 0xf, false);
+		// interchange: the pivot row's entry of this column, old row 0 into the pivot row's place
+		const double pr = (pv == 0) ? w0 : ((pv == 1) ? w1 : ((pv == 2) ? w2 : ((pv == 3) ? w3 : w4)));
+		const double t0 = w0;
+		w1 = (pv == 1) ? t0 : w1; w2 = (pv == 2) ? t0 : w2; w3 = (pv == 3) ? t0 : w3; w4 = (pv == 4) ? t0 : w4;
+		// U row j: entries 0..8 from lanes 0..8, transformed right-hand side from lane 15 (lanes 9..14 write their zeros:
+		// one unconditional, fully coalesced 512-byte store per row)
+		stream[(size_t)j * 64] = pr;
+		// multipliers from lane 0
+		if (c == 0 && pr == 0.0) singular = true;
+		const double rcp = 1.0 / pr;
+		const double l1 = grp_bcast<0>(w1 * rcp), l2 = grp_bcast<0>(w2 * rcp), l3 = grp_bcast<0>(w3 * rcp), l4 = grp_bcast<0>(w4 * rcp);
+		// rank-1 update (and forward substitution on lane 15), then slide: rows up, columns one lane to the left
+		w0 = grp_shift_left(LU_UPD(w1, l1, pr));
+		w1 = grp_shift_left(LU_UPD(w2, l2, pr));
+		w2 = grp_shift_left(LU_UPD(w3, l3, pr));
+		w3 = grp_shift_left(LU_UPD(w4, l4, pr));
+		w4 = in;
+	}
+	if (singular) atomicExch(flag, 1);
+#ifdef TMX_VI_TIMING
+	const long long tg2 = __builtin_readcyclecounter();
+#endif
+
+	// Back substitution (dtbsv order).  Every lane loads its own entry of a U row (one coalesced load per row, four rows
+	// in flight, no other vector-memory operation in the loop so that the waits are counted exactly); the row is gathered
+	// to every lane of the group by DPP broadcasts and all lanes carry the same sequential chain (vi_back_row).  The
+	// solution goes to LDS; afterwards the 16 lanes of a group form x0 - delta for the rows ROW = lane, lane + 16, ... and
+	// store them (column and in-patch duplicates) in parallel.
+	{
+		double * xsol = &blk[g][0][0];          // the ring is free now: n <= 16 * NQ doubles per column
+		double xw[TMX_BW - 1];
+#pragma unroll
+		for (int q = 0; q < TMX_BW - 1; q++) xw[q] = 0.0;
+		auto fetch = [&](int j) -> double { return stream[(size_t)(j < 0 ? 0 : j) * 64]; };
+		double f0 = fetch(n - 1), f1 = fetch(n - 2), f2 = fetch(n - 3), f3 = fetch(n - 4);
+		auto row = [&](int j, double mine) {
+			URow s_;
+			s_.u[0] = grp_bcast<0>(mine); s_.u[1] = grp_bcast<1>(mine); s_.u[2] = grp_bcast<2>(mine); s_.u[3] = grp_bcast<3>(mine);
+			s_.u[4] = grp_bcast<4>(mine); s_.u[5] = grp_bcast<5>(mine); s_.u[6] = grp_bcast<6>(mine); s_.u[7] = grp_bcast<7>(mine);
+			s_.u[8] = grp_bcast<8>(mine); s_.y = grp_bcast<15>(mine);
+			const double xr = vi_back_row(s_, xw);
+			if (c == 0) xsol[j] = xr;
+		};
+		int j = n - 1;
+		for (; j >= 3; j -= 4) {
+			row(j, f0);     f0 = fetch(j - 4);
+			row(j - 1, f1); f1 = fetch(j - 5);
+			row(j - 2, f2); f2 = fetch(j - 6);
+			row(j - 3, f3); f3 = fetch(j - 7);
+		}
+		if (j >= 0) row(j, f0);
+		if (j >= 1) row(j - 1, f1);
+		if (j >= 2) row(j - 2, f2);
+		__syncthreads();
+		if (valid) {
+			int dep[3];
+#pragma unroll
+			for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+			for (int r = c; r < n; r += 16) {
+				const int k = r / TMX_FTOT, comp = r - k * TMX_FTOT;
+				if (comp != 1 && k >= L) continue;                 // level-L slots of rho*theta / rho have no slab
+				const size_t so = (size_t)((comp == 0) ? TMX_SLAB_T(L, k) : ((comp == 1) ? TMX_SLAB_W(L, k) : TMX_SLAB_R(L, k))) * NS;
+				const double val = xin[so + col] - xsol[r];
+				xup[so + col] = val;
+#pragma unroll
+				for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[so + dep[t]] = val;
+			}
+		}
+	}
+#ifdef TMX_VI_TIMING
+	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
+		printf("vi group timing block %d: first assembly round %lld cycles, elimination (+ later rounds) %lld, back substitution %lld\n",
+			(int)blockIdx.x, tg1 - tg0, tg2 - tg1, (long long)__builtin_readcyclecounter() - tg2);
+#endif
 }
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
@@ -2696,6 +2921,13 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	// 840 us against 899 us; 190 groups 95 us with one pair per workgroup (every workgroup alone on a CU), 104 us with
 	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  So it is the production kernel at every
 	// size; the one-wavefront kernel stays as TMX_VI_PAIR=0 (bit-identical, tested).
+	// few columns for the chip (strong-scaling share): one column per 16-lane group
+	if (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max)) {
+		const int nwg = (e->nunique + 3) / 4;
+		if (p.closed) hipLaunchKernelGGL((k_vi_group<true>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_flag);
+		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_flag);
+		return;
+	}
 	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
 	const int cpw = use_pair ? e->vi_cpw : 64;
 	const int ngrp = (e->nunique + cpw - 1) / cpw;

@@ -66,11 +66,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("TMX_LIBRARY") or LIB_PATH      # TMX_LIBRARY: an experimental build of the same library (tools/ablate.sh)
+    if not os.path.exists(path):
         raise ImportError("libtempest_mi355x.so is missing at %s -- build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
-                          "this package has no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          "this package has no CPU fallback" % path)
+    lib = C.CDLL(path)
     lib.tmx_last_error.restype = C.c_char_p
     lib.tmx_info.restype = C.c_longlong
     lib.tmx_destroy.restype = None

@@ -1024,3 +1024,31 @@ def test_held_suarez_steps_L60(graph, monkeypatch):
             assert np.array_equal(ge[[2, 4], 1:-1, 1:-1, 0], oe[[2, 4], 1:-1, 1:-1, 0])
     finally:
         e.close()
+
+
+def test_mfma_contractions_agree_to_rounding(monkeypatch):
+    """TMX_MFMA=1: the 4x4 contractions of the fused explicit kernel on the matrix unit (v_mfma_f64_4x4x4_4b_f64).  The
+    matrix unit accumulates with fused multiply-adds, so the result is NOT the reference's bit for bit (which is why the
+    path is opt-in): three whole steps agree with the oracle to 1e-13 (W, the residual of the hydrostatic balance: 1e-11)."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    monkeypatch.setenv("TMX_MFMA", "1")
+    d = gu.load("percall_ne3_L5_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True)
+    dt = float(d["cfg/dt"][0])
+    start = gu.full_states(d, "warm", 6)
+    o = Oracle(g); o.set_state(0, start)
+    e = Engine(g); e.upload_state(0, start)
+    try:
+        worst = 0.0
+        for _ in range(3):
+            assert o.step_ars343(dt) == 0
+            e.step_ars343(dt)
+            e.sync()
+            errs = gu.prognostic_errors(e.download_state(0), o.get_state(0))
+            worst = max(worst, max(errs))
+            assert max(errs[c] for c in (0, 1, 2, 4)) < 1e-13 and errs[3] < 1e-11, errs      # W amplifies last-bit changes
+        print("MFMA contractions, 3 steps vs oracle:", errs)
+        assert worst > 0.0          # it really is a different arithmetic (otherwise the opt-in would be pointless)
+    finally:
+        e.close()
