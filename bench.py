@@ -13,6 +13,11 @@ reference's own closed-form initial state, resident in HBM.  Rank 0 prints ONE J
   cpu_baseline  the real reference (oracle/_ref, "reference") when its binary travelled with the
               snapshot, else the C oracle ("port"), timed on 1 host core on a bounded sample
   cpu_baseline_mpi  (extra) the same reference binary under `mpiexec -np 6`, when mpiexec is there
+  cpu_baseline_allcores  (extra) the reference under `mpiexec -np 24` on its 24-patch layout when the host has >= 24 cores
+
+The timed region starts from a DEVELOPED state: `--develop` (10) untimed steps precede the W warm-up steps, so that W != 0
+and the pivot pattern of the column solve is the one of a running model; the fraction of pivot steps that
+took the wave-uniform path during the profiled steps is reported as roofline.uniform_pivot_fraction.
 """
 import argparse
 import json
@@ -38,21 +43,26 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 #   lincomb    : the copies left un-fused (device copies of whole / partial instances); no SURVEY row of its own
 ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 216.0, "lincomb": 0.0}
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
+# What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
+OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
+            "v_implicit": "latency (dependent pivot chain of one column per lane: forward 86 us compute + 28 us U-row stores, "
+                          "back substitution 78 us on the U-row read-back; profiles/r02_column_solve_ablation.txt)"}
 # engine profile slots (HIP events) that make up each operation
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
-OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair"], "dss": ["k_dss"],
+OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
 
 
 def measured_traffic(op, ne, L, world, launches_per_step):
     """HBM bytes per launch of the operation from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  The table was
-    taken at ne30 L30 on one GPU; for any other workload the traffic is not known -> None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (ne == 30 and L == 30 and world == 1 and os.path.exists(path)):
+    separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  One table per
+    workload shape, profiles/r02_pmc_traffic_ne<ne>_L<L>_n<ranks>.json (n > 1: the share of rank 0, taken with a lone
+    rank-0 engine of the n-rank layout, tools/rank_share_timing.py); a shape without a table -> None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
+    if not os.path.exists(path):
         return None
     try:
         tab = json.load(open(path))
@@ -64,6 +74,22 @@ def measured_traffic(op, ne, L, world, launches_per_step):
         return per_step / launches_per_step if per_step > 0 and launches_per_step > 0 else None
     except Exception:
         return None
+
+
+def mfma_report():
+    """MFMA utilisation of the path that ran (measured offline with rocprofv3 counters, profiles/r02_mfma_ab.json) and the
+    A/B of the opt-in matrix-unit contractions against the default LDS + VALU ones."""
+    path = os.path.join(ROOT, "profiles", "r02_mfma_ab.json")
+    ab = None
+    try:
+        ab = json.load(open(path))
+    except Exception:
+        pass
+    on = os.environ.get("TMX_MFMA", "0") not in ("", "0")
+    active = 0.0
+    if on and ab and "mfma_busy_fraction_of_explicit_kernel" in ab.get("TMX_MFMA=1", {}):
+        active = ab["TMX_MFMA=1"]["mfma_busy_fraction_of_explicit_kernel"]
+    return {"active": active, "ab": ab}
 
 
 def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
@@ -91,6 +117,15 @@ def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
     except Exception as ex:
         sys.stderr.write("MPI reference baseline failed (%s)\n" % ex)
         return None
+
+
+def cpu_baseline_allcores(ne, L, dt, nsteps_ref):
+    """The reference on its 24-patch layout under mpiexec -np 24 ('N = all physical cores, stated'), when the
+    host has at least 24 cores; the same routine as the 6-rank run."""
+    if (os.cpu_count() or 1) < 24:
+        return None
+    b = cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=24)
+    return b
 
 
 def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
@@ -141,6 +176,7 @@ def main():
     ap.add_argument("--dt", type=float, default=150.0)
     ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +216,8 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    for _ in range(args.develop):       # developed state: W != 0, realistic pivot pattern (not part of W or K)
+        eng.step_ars343(dt)
     for _ in range(args.warmup):
         eng.step_ars343(dt)
     barrier()
@@ -192,12 +230,14 @@ def main():
     # engine's stream (kept out of the timed region: the event markers cost a few % of wall time)
     eng.profile_enable(True)
     eng.profile_reset()
+    eng.pivot_stats(True)
     t1 = time.perf_counter()
     for _ in range(args.steps):
         eng.step_ars343(dt)
     barrier()
     wall_prof = time.perf_counter() - t1
     prof = eng.profile()
+    pivot = eng.pivot_stats(False)
     eng.profile_enable(False)
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -228,6 +268,19 @@ def main():
         achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
         kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
+        if dom == "v_implicit" and eng.info(1) <= 4608:
+            kernel_name = "k_vi_group (one column per 16-lane group)"
+        mfma = mfma_report()
+
+        def per_op(op):
+            # algorithmic figure (SURVEY 8d row x points) beside the counter-measured one: the 8d rows are not lower bounds for
+            # fused passes (hypervis reads less than its row says), so "measured_GBs" is the rate to judge those by
+            ms = op_time[op] / op_launches[op]
+            tr = measured_traffic(op, ne, L, world, op_launches[op] / args.steps)
+            return {"launches_per_step": op_launches[op] / args.steps, "ms_per_launch": ms,
+                    "achieved_GBs": ALG_BYTES[op] * local_points / max(ms * 1e-3, 1e-12) / 1e9,
+                    "traffic": tr, "measured_GBs": (tr / max(ms * 1e-3, 1e-12) / 1e9) if tr else None,
+                    "bound": OP_BOUND[op]}
         out = {
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
             "value": value, "unit": "element-DOF-updates/s",
@@ -244,24 +297,26 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
-                         "per_operation": {op: {"launches_per_step": op_launches[op] / args.steps,
-                                                "ms_per_launch": op_time[op] / op_launches[op],
-                                                "achieved_GBs": ALG_BYTES[op] * local_points
-                                                / max(op_time[op] / op_launches[op] * 1e-3, 1e-12) / 1e9,
-                                                "traffic": measured_traffic(op, ne, L, world, op_launches[op] / args.steps)}
-                                           for op in OP_KERNELS},
+                         "per_operation": {op: per_op(op) for op in OP_KERNELS},
+                         "limited_by": OP_BOUND[dom],
+                         "uniform_pivot_fraction": (pivot[0] / pivot[1]) if pivot[1] else None,
                          "whole_step_algorithmic_GBs": ALG_BYTES_PER_STEP * points * args.steps / wall / 1e9,
-                         "mfma_utilisation": 0.0,      # no MFMA instruction in any kernel: the contractions are 4x4 per element
-                                                       # and level (fp64, ~2 flop/B), every kernel is bandwidth- or issue-bound
+                         # default path: no MFMA instruction is issued (the bit-exact contractions are LDS + VALU); with TMX_MFMA=1
+                         # the fused explicit kernel issues 12 v_mfma_f64_4x4x4_4b per point: counters in profiles/r02_mfma_ab.json
+                         "mfma_utilisation": mfma["active"], "mfma_ab": mfma["ab"],
                          },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
+            "developed_steps": args.develop, "host_cpu_count": os.cpu_count(),
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 6, 6)      # ~15 s of CPU work (1 warm-up + 6 timed steps)
             mpi = cpu_baseline_mpi(ne, L, dt, 6)                     # + the reference's own 6-rank MPI run, ~20 core-seconds
             if mpi is not None:
                 out["cpu_baseline_mpi"] = mpi
+            allc = cpu_baseline_allcores(ne, L, dt, 4)              # + 24 ranks on the 24-patch layout where the host has them
+            if allc is not None:
+                out["cpu_baseline_allcores"] = allc
         print(json.dumps(out))
     eng.close()
     if world > 1:

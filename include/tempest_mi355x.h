@@ -233,10 +233,14 @@ int tmx_h_step_after_subcycle(tmx_engine * e, int i_initial, int i_update, int i
  * asynchronous on the engine's stream.  Each is the reference's own call sequence:
  *   ARS343  src/atm/TimestepSchemeARS343.cpp:150-236     ARS232  src/atm/TimestepSchemeARS232.cpp:52-150
  *   ARS222  src/atm/TimestepSchemeARS222.cpp:51-119      ARK232  src/atm/TimestepSchemeARK232.cpp:53-225
- *   STRANG  src/atm/TimestepSchemeStrang.cpp:450-674 (KinnmarkGrayUllrich35, off-centering 0: the default
- *           --timescheme of every reference test, TempestInitialize.h:142)
+ *   STRANG  src/atm/TimestepSchemeStrang.cpp:450-674 with KinnmarkGrayUllrich35 (the default --timescheme of every
+ *           reference test, TempestInitialize.h:142); STRANG_FE / _RK4 / _SSP3 / _SSPRK53 are the same step with the
+ *           constructor's other ExplicitDiscretization values (TimestepSchemeStrang.h:39-45, .cpp:39-51,484-648)
  * first_step / last_step have the meaning of TimestepScheme::Step's fFirstStep / fLastStep. */
-enum { TMX_SCHEME_ARS343 = 0, TMX_SCHEME_ARS232, TMX_SCHEME_ARS222, TMX_SCHEME_ARS443, TMX_SCHEME_ARK232, TMX_SCHEME_STRANG };
+enum { TMX_SCHEME_ARS343 = 0, TMX_SCHEME_ARS232, TMX_SCHEME_ARS222, TMX_SCHEME_ARS443, TMX_SCHEME_ARK232, TMX_SCHEME_STRANG,
+       TMX_SCHEME_STRANG_FE, TMX_SCHEME_STRANG_RK4, TMX_SCHEME_STRANG_SSP3, TMX_SCHEME_STRANG_SSPRK53 };
+/* dOffCentering of TimestepSchemeStrang's constructor (TimestepSchemeStrang.cpp:25-37,58-61,651-660), in [0, 1]; 0 by default. */
+int tmx_set_strang_off_centering(tmx_engine * e, double off_centering);
 int tmx_step(tmx_engine * e, int scheme, int first_step, int last_step, double dt);
 /* TimestepScheme::GetComponentDataInstances of that scheme (-1: unknown). */
 int tmx_scheme_instances(int scheme);
@@ -377,6 +381,10 @@ int tmx_debug_dss_loopback(tmx_engine ** engines, int n, int instance);
 int tmx_debug_loopback_group(tmx_engine ** engines, int n);
 /* Grouped ncclSend/ncclRecv to self through the engine's communicator and stream. */
 int tmx_debug_comm_selftest(tmx_engine * e);
+
+/* Pivot statistics of the column solve (bench.py): enable != 0 starts counting, 0 stops; out (may be NULL) receives
+ * {pivot steps in which all 64 columns of a wavefront chose the same pivot row, all pivot steps} counted so far. */
+int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long long out[2]);
 
 /* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.
  * kernel ids: TMX_K_* below.  Profiling is off by default (no events recorded). */

@@ -272,8 +272,8 @@ int main(int argc, char ** argv) {
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 0, geom = 1, every = 1, ntracers = 0, hvorder = 4;
 	double dt = 200.0, ztop = 30000.0, planet = 1.0, udiffS = 0.0, udiffV = 0.0;
 	bool fExplicitVertical = false, fZtopGiven = false;
-	std::string physics = "none";
-	double nuArg = -1.0, moisten = 0.0;
+	std::string physics = "none", vmethod = "v1";
+	double nuArg = -1.0, moisten = 0.0, offCentering = 0.0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		const char * v = (i + 1 < argc) ? argv[i+1] : "";
@@ -295,6 +295,8 @@ int main(int argc, char ** argv) {
 		else if (a == "--ztop") { ztop = atof(v); fZtopGiven = true; i++; }
 		else if (a == "--nu") { nuArg = atof(v); i++; }               // hyperviscosity coefficient (all three), default per case
 		else if (a == "--moisten") { moisten = atof(v); i++; }        // --mode kessler: second call on a moistened copy
+		else if (a == "--offcentering") { offCentering = atof(v); i++; }   // TimestepSchemeStrang ctor argument
+		else if (a == "--vmethod") { vmethod = v; i++; }              // v1 (VerticalDynamicsFEM) | schur (VerticalDynamicsSchur, with --vdisc FV)
 		else if (a == "--physics") { physics = v; i++; }              // hs | kessler: WorkflowProcess after every step
 		else if (a == "--planet") { planet = atof(v); i++; }          // reduced-planet factor X (with --udiff)
 		else if (a == "--udiff") { udiffS = atof(v); udiffV = atof((i + 2 < argc) ? argv[i+2] : "0"); i += 2; }   // uniform diffusion K_scalar K_vector
@@ -342,7 +344,11 @@ try {
 	else if (scheme == "ark232") model.SetTimestepScheme(new TimestepSchemeARK232(model));
 	else if (scheme == "ars222") model.SetTimestepScheme(new TimestepSchemeARS222(model));
 	else if (scheme == "ars443") model.SetTimestepScheme(new TimestepSchemeARS443(model));
-	else if (scheme == "strang") model.SetTimestepScheme(new TimestepSchemeStrang(model));
+	else if (scheme == "strang") model.SetTimestepScheme(new TimestepSchemeStrang(model, offCentering));
+	else if (scheme == "strang_fe") model.SetTimestepScheme(new TimestepSchemeStrang(model, offCentering, TimestepSchemeStrang::ForwardEuler));
+	else if (scheme == "strang_rk4") model.SetTimestepScheme(new TimestepSchemeStrang(model, offCentering, TimestepSchemeStrang::RungeKutta4));
+	else if (scheme == "strang_ssp3") model.SetTimestepScheme(new TimestepSchemeStrang(model, offCentering, TimestepSchemeStrang::RungeKuttaSSP3));
+	else if (scheme == "strang_ssprk53") model.SetTimestepScheme(new TimestepSchemeStrang(model, offCentering, TimestepSchemeStrang::RungeKuttaSSPRK53));
 	else { fprintf(stderr, "bad scheme\n"); return 2; }
 
 	// order 2 is plain viscosity: coefficients of a sensible magnitude for it (the 1e15 defaults belong to order 4)
@@ -353,13 +359,15 @@ try {
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
 	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
+	                : (vmethod == "schur") ? (VerticalDynamics *)(new VerticalDynamicsSchur(model, 4, 2, 0, fExplicitVertical, true, false))
 	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, fExplicitVertical, true, false));
 	model.SetVerticalDynamics(pV);
 
 	GridCSGLL * pGrid = new GridCSGLL(model);
 	pGrid->DefineParameters();
-	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, 1,
-		Grid::VerticalDiscretization_FiniteElement, Grid::VerticalStaggering_Lorenz);
+	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, (vmethod == "schur") ? 2 : 1,
+		(vmethod == "schur") ? Grid::VerticalDiscretization_FiniteVolume : Grid::VerticalDiscretization_FiniteElement,
+		getenv("TMX_REF_VSTAGGER_CPH") ? Grid::VerticalStaggering_CharneyPhillips : Grid::VerticalStaggering_Lorenz);
 	pGrid->InitializeDataLocal();
 	model.SetGrid(pGrid, npatch);
 
@@ -641,7 +649,7 @@ try {
 				char tag[32]; snprintf(tag, 32, "step%d", s + 1);
 				printChecksums(pGrid, tag, &w);
 				dumpState(w, pGrid, tag, 0);
-				if (scheme == "strang") {
+				if (scheme.compare(0, 6, "strang") == 0) {
 					// the Strang stepper carries instance 1 over to the next step (TimestepSchemeStrang.cpp:639-657)
 					dumpState(w, pGrid, std::string(tag) + "_carry", 1);
 				}

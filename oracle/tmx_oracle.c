@@ -1650,6 +1650,9 @@ static void hvd(const orc_grid * g, orc_state * s, int i, int u, double c) {
 	orc_apply_dss(g, s, u);
 }
 
+static double g_strang_offc = 0.0;      /* TimestepSchemeStrang constructor argument dOffCentering */
+void orc_set_strang_off_centering(double oc) { g_strang_offc = oc; }
+
 /* scheme: 1 ARS232 (TimestepSchemeARS232.cpp:52-150), 2 ARS222 (TimestepSchemeARS222.cpp:51-119),
  * 3 ARS443 (TimestepSchemeARS443.cpp), 4 ARK232 (TimestepSchemeARK232.cpp:53-225),
  * 5 Strang/KGU35 (TimestepSchemeStrang.cpp:450-674), 0 ARS343 */
@@ -1728,19 +1731,45 @@ int orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last,
 		orc_copy(g, s, 7, 2); orc_h_step_after_subcycle(g, s, 7, 1, 3, dt); orc_copy(g, s, 1, 0);
 		return info;
 	}
-	if (scheme == 5) {
-		const double half = 0.5 * dt;
-		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
-		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+	if (scheme >= 5 && scheme <= 9) {
+		/* TimestepSchemeStrang::Step (TimestepSchemeStrang.cpp:450-674): 5 KinnmarkGrayUllrich35, 6 ForwardEuler, 7 RungeKutta4,
+		 * 8 RungeKuttaSSP3, 9 RungeKuttaSSPRK53 (:484-648, combinations :53-117); off-centering of the constructor */
+		const double half = 0.5 * dt, oc = g_strang_offc;
+		const double carry[2] = { 1.0, 1.0 }, offc[2] = { (2.0 - oc) / 2.0, oc / 2.0 }, fin[2] = { 1.0, -1.0 };
 		if (first) VI(0, 0, half);
 		else { orc_linear_combine(g, s, carry, 2, 0); filter_negative_tracers_v(g, s, 0); }      /* TimestepSchemeStrang.cpp:476-481 */
-		orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, dt / 5.0);
-		orc_copy(g, s, 0, 2); hvd(g, s, 1, 2, dt / 5.0);
-		orc_copy(g, s, 0, 3); hvd(g, s, 2, 3, dt / 3.0);
-		orc_copy(g, s, 0, 2); hvd(g, s, 3, 2, 2.0 * dt / 3.0);
-		orc_linear_combine(g, s, kgu, 5, 4); hvd(g, s, 2, 4, 3.0 * dt / 4.0);
+		if (scheme == 6) {
+			orc_copy(g, s, 0, 4); hvd(g, s, 0, 4, dt);
+		} else if (scheme == 7) {
+			const double rk4[5] = { -1.0 / 3.0, 1.0 / 3.0, 2.0 / 3.0, 1.0 / 3.0, 0.0 };
+			orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, half);
+			orc_copy(g, s, 0, 2); hvd(g, s, 1, 2, half);
+			orc_copy(g, s, 0, 3); hvd(g, s, 2, 3, dt);
+			orc_linear_combine(g, s, rk4, 5, 4); hvd(g, s, 3, 4, dt / 6.0);
+		} else if (scheme == 8) {
+			const double ca[3] = { 3.0 / 4.0, 1.0 / 4.0, 0.0 }, cb[5] = { 1.0 / 3.0, 0.0, 2.0 / 3.0, 0.0, 0.0 };
+			orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, dt);
+			orc_linear_combine(g, s, ca, 3, 2); hvd(g, s, 1, 2, 0.25 * dt);
+			orc_linear_combine(g, s, cb, 5, 4); hvd(g, s, 2, 4, (2.0 / 3.0) * dt);
+		} else if (scheme == 9) {
+			const double ca[4] = { 0.355909775063327, 0.0, 0.644090224936674, 0.0 };
+			const double cb[4] = { 0.367933791638137, 0.0, 0.0, 0.632066208361863 };
+			const double cc[5] = { 0.762406163401431, 0.0, 0.237593836598569, 0.0, 0.0 };
+			orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, 0.377268915331368 * dt);
+			orc_copy(g, s, 1, 2); hvd(g, s, 1, 2, 0.377268915331368 * dt);
+			orc_linear_combine(g, s, ca, 4, 3); hvd(g, s, 2, 3, 0.242995220537396 * dt);
+			orc_linear_combine(g, s, cb, 4, 0); hvd(g, s, 3, 0, 0.238458932846290 * dt);
+			orc_linear_combine(g, s, cc, 5, 4); hvd(g, s, 0, 4, 0.287632146308408 * dt);
+		} else {
+			const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+			orc_copy(g, s, 0, 1); hvd(g, s, 0, 1, dt / 5.0);
+			orc_copy(g, s, 0, 2); hvd(g, s, 1, 2, dt / 5.0);
+			orc_copy(g, s, 0, 3); hvd(g, s, 2, 3, dt / 3.0);
+			orc_copy(g, s, 0, 2); hvd(g, s, 3, 2, 2.0 * dt / 3.0);
+			orc_linear_combine(g, s, kgu, 5, 4); hvd(g, s, 2, 4, 3.0 * dt / 4.0);
+		}
 		orc_copy(g, s, 4, 1); orc_h_step_after_subcycle(g, s, 4, 1, 2, dt);
-		orc_copy(g, s, 1, 0); VI(0, 0, 0.5 * (1.0 + 0.0) * dt);
+		orc_copy(g, s, 1, 0); VI(0, 0, 0.5 * (1.0 + oc) * dt);
 		orc_linear_combine(g, s, offc, 2, 0);
 		if (!last) orc_linear_combine(g, s, fin, 2, 1);
 		return info;

@@ -132,8 +132,10 @@ void orc_apply_dss(const orc_grid * g, orc_state * s, int ix);
 void orc_h_step_after_subcycle(const orc_grid * g, orc_state * s, int iinit, int iupd, int iwork, double dt);
 int  orc_step_ars343(const orc_grid * g, orc_state * s, double dt);
 void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int iinit, int iupd, double dt);
-/* scheme: 0 ARS343, 1 ARS232, 2 ARS222, 3 ARS443, 4 ARK232, 5 Strang (KGU35) */
+/* scheme: 0 ARS343, 1 ARS232, 2 ARS222, 3 ARS443, 4 ARK232, 5 Strang (KGU35), 6-9 Strang with ForwardEuler / RungeKutta4 /
+ * RungeKuttaSSP3 / RungeKuttaSSPRK53 (TimestepSchemeStrang.h:39-45) */
 int  orc_step(const orc_grid * g, orc_state * s, int scheme, int first, int last, double dt);
+void orc_set_strang_off_centering(double oc);     /* TimestepSchemeStrang ctor dOffCentering, default 0 */
 
 /* HeldSuarezPhysics::Perform (src/atm/HeldSuarezPhysics.cpp:60-301) on instance ix */
 void orc_held_suarez(const orc_grid * g, orc_state * s, int ix, double dt);

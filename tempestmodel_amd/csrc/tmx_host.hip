@@ -8,6 +8,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <functional>
 #include <thread>
@@ -164,9 +165,14 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 			tmx_set_error("tmx_create: no HIP device available (%s); this engine has no CPU path", hipGetErrorString(r));
 			return TMX_ERR_DEVICE;
 		}
-		if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); }
-		HIPCHK(hipGetDevice(&e->device));
-		HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+		if (r == hipSuccess && cfg->device >= 0) r = hipSetDevice(cfg->device);
+		if (r == hipSuccess) r = hipGetDevice(&e->device);
+		if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+		if (r != hipSuccess) {
+			delete e;
+			tmx_set_error("tmx_create: device %d: %s", cfg->device, hipGetErrorString(r));
+			return TMX_ERR_DEVICE;
+		}
 	}
 	*out = e;
 	return TMX_OK;
@@ -174,9 +180,11 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 
 static void free_dev(void * p) { if (p) hipFree(p); }
 static void g_plans_erase(tmx_engine * e);
+static void interp_orphan(tmx_engine * e);
 
 extern "C" void tmx_destroy(tmx_engine * e) {
 	if (!e) return;
+	interp_orphan(e);
 	if (!plan_only(e)) {
 		if (e->stream) hipStreamSynchronize(e->stream);
 		for (auto & g : e->graphs) hipGraphExecDestroy(g.exec);
@@ -185,7 +193,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -540,8 +548,13 @@ struct PlanHost {
 	std::vector<int> send_cols;
 	std::vector<int> ucol, udep;
 };
+// One plan per engine.  Engines may be driven from different host threads (the loopback tests do): the map is only
+// touched under g_plans_mutex; a std::map never moves its values, so the reference handed out stays valid until the
+// engine's own tmx_destroy erases it.
 static std::map<tmx_engine *, PlanHost> g_plans;
-static void g_plans_erase(tmx_engine * e) { g_plans.erase(e); }
+static std::mutex g_plans_mutex;
+static PlanHost & plan_of(tmx_engine * e) { std::lock_guard<std::mutex> lk(g_plans_mutex); return g_plans[e]; }
+static void g_plans_erase(tmx_engine * e) { std::lock_guard<std::mutex> lk(g_plans_mutex); g_plans.erase(e); }
 
 extern "C" int tmx_finalize(tmx_engine * e) {
 	REQUIRE(e, TMX_ERR_INVALID, "tmx_finalize: null engine");
@@ -555,7 +568,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		if (e->patches[p].owner == me && !plan_only(e))
 			REQUIRE(e->patches[p].geom_set, TMX_ERR_INVALID, "geometry of local patch %d not set", p);
 	}
-	PlanHost & plan = g_plans[e];
+	PlanHost & plan = plan_of(e);
 
 	// ---- union-find over all interior nodes of all patches
 	std::vector<size_t> poff(np + 1, 0);
@@ -1778,13 +1791,14 @@ static int scheme_instances(int scheme) {
 		case TMX_SCHEME_ARS222: return 4;
 		case TMX_SCHEME_ARS443: return 10;
 		case TMX_SCHEME_ARK232: return 8;
-		case TMX_SCHEME_STRANG: return 5;
+		case TMX_SCHEME_STRANG: case TMX_SCHEME_STRANG_FE: case TMX_SCHEME_STRANG_RK4: case TMX_SCHEME_STRANG_SSP3:
+		case TMX_SCHEME_STRANG_SSPRK53: return 5;    // TimestepSchemeStrang.h GetComponentDataInstances
 	}
 	return -1;
 }
 
 // U-form combination coefficients shared by the ARS schemes: u_f(stage) from explicit/implicit tableaux
-static int build_program(int scheme, int first, int last, double dt, Program & p) {
+static int build_program(int scheme, int first, int last, double dt, Program & p, double offc = 0.0) {
 	p.clear();
 	if (scheme == TMX_SCHEME_ARS343) {
 		// TimestepSchemeARS343::Step (TimestepSchemeARS343.cpp:150-236)
@@ -1829,20 +1843,45 @@ static int build_program(int scheme, int first, int last, double dt, Program & p
 		P_copy(p, 3, 2); P_hvis(p, 2, 1, 3, dt); P_copy(p, 1, 0);
 		return TMX_OK;
 	}
-	if (scheme == TMX_SCHEME_STRANG) {
-		// TimestepSchemeStrang::Step, KinnmarkGrayUllrich35, off-centering 0 (TimestepSchemeStrang.cpp:450-674)
-		const double half = 0.5 * dt;
-		const double carry[2] = { 1.0, 1.0 }, offc[2] = { 1.0, 0.0 }, fin[2] = { 1.0, -1.0 };
-		const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+	if (scheme == TMX_SCHEME_STRANG || (scheme >= TMX_SCHEME_STRANG_FE && scheme <= TMX_SCHEME_STRANG_SSPRK53)) {
+		// TimestepSchemeStrang::Step (TimestepSchemeStrang.cpp:450-674) with each of its explicit discretisations
+		// (:39-51, combinations :53-117) and the off-centering of its constructor
+		const double half = 0.5 * dt, oc = offc;
+		const double carry[2] = { 1.0, 1.0 }, offcomb[2] = { (2.0 - oc) / 2.0, oc / 2.0 }, fin[2] = { 1.0, -1.0 };
 		if (first) P_vimp(p, 0, 0, half); else { P_lc(p, carry, 2, 0); P_vfilt(p, 0); }      // FilterNegativeTracers(0), :476-481
-		P_copy(p, 0, 1); P_hv(p, 0, 1, dt / 5.0); P_dss(p, 1);
-		P_copy(p, 0, 2); P_hv(p, 1, 2, dt / 5.0); P_dss(p, 2);
-		P_copy(p, 0, 3); P_hv(p, 2, 3, dt / 3.0); P_dss(p, 3);
-		P_copy(p, 0, 2); P_hv(p, 3, 2, 2.0 * dt / 3.0); P_dss(p, 2);
-		P_lc(p, kgu, 5, 4); P_hv(p, 2, 4, 3.0 * dt / 4.0); P_dss(p, 4);
+		if (scheme == TMX_SCHEME_STRANG_FE) {
+			P_copy(p, 0, 4); P_hv(p, 0, 4, dt); P_dss(p, 4);
+		} else if (scheme == TMX_SCHEME_STRANG_RK4) {
+			const double rk4[5] = { -1.0 / 3.0, 1.0 / 3.0, 2.0 / 3.0, 1.0 / 3.0, 0.0 };
+			P_copy(p, 0, 1); P_hv(p, 0, 1, half); P_dss(p, 1);
+			P_copy(p, 0, 2); P_hv(p, 1, 2, half); P_dss(p, 2);
+			P_copy(p, 0, 3); P_hv(p, 2, 3, dt); P_dss(p, 3);
+			P_lc(p, rk4, 5, 4); P_hv(p, 3, 4, dt / 6.0); P_dss(p, 4);
+		} else if (scheme == TMX_SCHEME_STRANG_SSP3) {
+			const double a[3] = { 3.0 / 4.0, 1.0 / 4.0, 0.0 }, b[5] = { 1.0 / 3.0, 0.0, 2.0 / 3.0, 0.0, 0.0 };
+			P_copy(p, 0, 1); P_hv(p, 0, 1, dt); P_dss(p, 1);
+			P_lc(p, a, 3, 2); P_hv(p, 1, 2, 0.25 * dt); P_dss(p, 2);
+			P_lc(p, b, 5, 4); P_hv(p, 2, 4, (2.0 / 3.0) * dt); P_dss(p, 4);
+		} else if (scheme == TMX_SCHEME_STRANG_SSPRK53) {
+			const double a[4] = { 0.355909775063327, 0.0, 0.644090224936674, 0.0 };
+			const double b[4] = { 0.367933791638137, 0.0, 0.0, 0.632066208361863 };
+			const double c[5] = { 0.762406163401431, 0.0, 0.237593836598569, 0.0, 0.0 };
+			P_copy(p, 0, 1); P_hv(p, 0, 1, 0.377268915331368 * dt); P_dss(p, 1);
+			P_copy(p, 1, 2); P_hv(p, 1, 2, 0.377268915331368 * dt); P_dss(p, 2);
+			P_lc(p, a, 4, 3); P_hv(p, 2, 3, 0.242995220537396 * dt); P_dss(p, 3);
+			P_lc(p, b, 4, 0); P_hv(p, 3, 0, 0.238458932846290 * dt); P_dss(p, 0);
+			P_lc(p, c, 5, 4); P_hv(p, 0, 4, 0.287632146308408 * dt); P_dss(p, 4);
+		} else {
+			const double kgu[5] = { -1.0 / 4.0, 5.0 / 4.0, 0.0, 0.0, 0.0 };
+			P_copy(p, 0, 1); P_hv(p, 0, 1, dt / 5.0); P_dss(p, 1);
+			P_copy(p, 0, 2); P_hv(p, 1, 2, dt / 5.0); P_dss(p, 2);
+			P_copy(p, 0, 3); P_hv(p, 2, 3, dt / 3.0); P_dss(p, 3);
+			P_copy(p, 0, 2); P_hv(p, 3, 2, 2.0 * dt / 3.0); P_dss(p, 2);
+			P_lc(p, kgu, 5, 4); P_hv(p, 2, 4, 3.0 * dt / 4.0); P_dss(p, 4);
+		}
 		P_copy(p, 4, 1); P_hvis(p, 4, 1, 2, dt);
-		P_copy(p, 1, 0); P_vimp(p, 0, 0, 0.5 * (1.0 + 0.0) * dt);
-		P_lc(p, offc, 2, 0);
+		P_copy(p, 1, 0); P_vimp(p, 0, 0, 0.5 * (1.0 + oc) * dt);
+		P_lc(p, offcomb, 2, 0);
 		if (!last) P_lc(p, fin, 2, 1);
 		return TMX_OK;
 	}
@@ -1919,9 +1958,19 @@ struct tmx_interp {
 	size_t out_n = 0;
 };
 
+// plans outlive their engine safely: tmx_destroy clears `owner` of every plan the engine still lists
+static void interp_orphan(tmx_engine * e) {
+	for (tmx_interp * q : e->interps) q->owner = nullptr;
+	e->interps.clear();
+}
+
 extern "C" void tmx_interp_destroy(tmx_interp * q) {
 	if (!q) return;
-	if (q->owner && q->owner->stream) hipStreamSynchronize(q->owner->stream);
+	if (q->owner) {
+		if (q->owner->stream) hipStreamSynchronize(q->owner->stream);
+		auto & v = q->owner->interps;
+		v.erase(std::remove(v.begin(), v.end(), q), v.end());
+	}
 	hipFree(q->d_col0); hipFree(q->d_ca); hipFree(q->d_cb); hipFree(q->d_rll); hipFree(q->d_opn); hipFree(q->d_ope); hipFree(q->d_out);
 	delete q;
 }
@@ -1956,6 +2005,7 @@ extern "C" int tmx_interp_create(tmx_engine * e, const tmx_interp_points * pts, 
 	q->out_n = (size_t)std::max(5, e->nt) * pts->n_reta * n;
 	if (ok) ok = hipMalloc((void **)&q->d_out, q->out_n * sizeof(double)) == hipSuccess;
 	if (!ok) { (void)hipGetLastError(); tmx_interp_destroy(q); tmx_set_error("tmx_interp_create: device allocation failed"); return TMX_ERR_DEVICE; }
+	e->interps.push_back(q);
 	*out = q;
 	return TMX_OK;
 }
@@ -2098,7 +2148,7 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	REQUIRE(need > 0, TMX_ERR_INVALID, "unknown time scheme %d", scheme);
 	REQUIRE(e->cfg.n_instances >= need, TMX_ERR_INVALID, "time scheme %d needs %d data instances, engine has %d", scheme, need, e->cfg.n_instances);
 	Program p;
-	if ((r = build_program(scheme, first_step, last_step, dt, p))) return r;
+	if ((r = build_program(scheme, first_step, last_step, dt, p, e->strang_offc))) return r;
 	// Optional (TMX_GRAPH=1): single-rank steps replayed from a hipGraph -- the 20-30 launches of a step are
 	// captured once per (scheme, first, last, dt), every kernel argument being fixed after tmx_finalize, and
 	// relaunched as one graph.  Off by default: the plain sequence is already queued asynchronously far ahead of the
@@ -2131,6 +2181,18 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 		return TMX_OK;
 	}
 	return run_program(e, p);
+}
+
+extern "C" int tmx_set_strang_off_centering(tmx_engine * e, double off_centering) {
+	REQUIRE(e, TMX_ERR_INVALID, "tmx_set_strang_off_centering: null engine");
+	REQUIRE(off_centering >= 0.0 && off_centering <= 1.0, TMX_ERR_INVALID, "off-centering %g outside [0, 1] (TimestepSchemeStrang.cpp:34-36)", off_centering);
+	if (off_centering != e->strang_offc) {
+		if (!plan_only(e) && e->stream) hipStreamSynchronize(e->stream);
+		for (auto & g : e->graphs) hipGraphExecDestroy(g.exec);      // captured steps carry the old coefficients
+		e->graphs.clear();
+	}
+	e->strang_offc = off_centering;
+	return TMX_OK;
 }
 
 extern "C" int tmx_step_ars343(tmx_engine * e, double dt) { return tmx_step(e, TMX_SCHEME_ARS343, 0, 0, dt); }
@@ -2289,7 +2351,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 // (or needed when out == nullptr).
 extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 	if (!e || !e->finalized) return -1;
-	PlanHost & plan = g_plans[e];
+	PlanHost & plan = plan_of(e);
 	std::vector<int> v;
 	if (what == 0 || what == 1) {
 		const std::vector<int> & nodes = what ? plan.recv_nodes : plan.send_nodes;
@@ -2313,9 +2375,24 @@ extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 // (U,V) into the frame of m's patch (identity where q == m or both lie on one panel)
 extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 	if (!e || !e->finalized) return -1;
-	PlanHost & plan = g_plans[e];
+	PlanHost & plan = plan_of(e);
 	if (out) { if ((int)plan.xmat.size() > cap) return -1; memcpy(out, plan.xmat.data(), plan.xmat.size() * sizeof(double)); }
 	return (int)plan.xmat.size();
+}
+
+// Statistics of the two-wavefront column kernel: how many pivot steps found the same pivot row in all 64 columns of a
+// wavefront (the renaming path) out of all pivot steps.  enable = 1 starts counting (zeroed), 0 stops; out (may be NULL)
+// receives {uniform, total} accumulated so far.
+extern "C" int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long long out[2]) {
+	int r; if ((r = check_ready(e))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));
+	if (out) {
+		out[0] = out[1] = 0;
+		if (e->d_pivot_stats) HIPCHK(hipMemcpy(out, e->d_pivot_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	}
+	if (enable && !e->d_pivot_stats) { HIPCHK(hipMalloc((void **)&e->d_pivot_stats, 2 * sizeof(unsigned long long))); HIPCHK(hipMemset(e->d_pivot_stats, 0, 2 * sizeof(unsigned long long))); }
+	if (!enable && e->d_pivot_stats) { (void)hipFree(e->d_pivot_stats); e->d_pivot_stats = nullptr; }
+	return TMX_OK;
 }
 
 extern "C" int tmx_profile_enable(tmx_engine * e, int on) {

@@ -144,6 +144,9 @@ struct tmx_engine {
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
 	// boundary-first launches (ranks > 1): 64-column tiles holding a column another rank needs, and the others
 	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_quads_early = 0, n_quads_late = 0, launch_tiles = 0; bool split_stage = false, split_overlapped = false;
+	std::vector<struct tmx_interp *> interps;          // output-interpolation plans created on this engine and not yet destroyed
+	double strang_offc = 0.0;                          // TimestepSchemeStrang off-centering (tmx_set_strang_off_centering)
+	unsigned long long * d_pivot_stats = nullptr;      // tmx_debug_pivot_stats: {uniform pivot steps, all pivot steps} of k_vi_pair, per wavefront
 	bool use_mfma = false;                   // TMX_MFMA=1: 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
 	int vi_group = -1, vi_group_max = 4608;     // lane-group column kernel: -1 auto (nunique <= vi_group_max: measured 71-77 us against 99 us per launch at 2 166 / 3 750 columns, 148 against 100 at 8 214), 0 off, 1 on (TMX_VI_GROUP, TMX_VI_GROUP_MAX)
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated

@@ -2347,7 +2347,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 template <bool SPARSE, bool UNI = false, int IS = 1>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
-	const double * inrow, double inb, int * umask)
+	const double * inrow, double inb, int * umask, int * n_uniform = nullptr)
 {
 	int pv = 0;
 	double amax = fabs(R[0][0]);
@@ -2359,6 +2359,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	if (UNI) {
 		const int pv0 = __builtin_amdgcn_readfirstlane(pv);
 		if (__builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
+			if (n_uniform) (*n_uniform)++;      // wave-uniform counter (scalar add): pivot steps that took the renaming path
 			switch (pv0) {
 				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
@@ -2610,7 +2611,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 template <bool SPARSE, bool CLOSED, int PAIRS>
 __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
-	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw)
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw, unsigned long long * __restrict__ stats)
 {
 	extern __shared__ double opsl_mem[];
 	double * opsl = opsl_mem;
@@ -2678,6 +2679,7 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	// two wavefronts per SIMD, which is what lets the pair kernel run on grids with more pairs than CUs x 2.
 	double R[5][TMX_BW], b[5];
 	bool singular = false;
+	int nuni = 0;
 #pragma unroll
 	for (int r = 0; r < 5; r++) {
 #pragma unroll
@@ -2705,11 +2707,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 					R[4][c] = qW[c * 64];
 				}
 				b[3] = qf[0]; b[4] = qf[64];
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask);      // pivot 0 takes in row 5
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask, &nuni);      // pivot 0 takes in row 5
 			} else {
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask);
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask);
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
+				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
 			}
 		}
 		__syncthreads();
@@ -2718,9 +2720,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
+		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask, &nuni);
 	}
 	if (singular) atomicExch(flag, 1);
+	// statistics for bench.py (stats = {pivot steps on the wave-uniform path, all pivot steps}, per wavefront)
+	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
 #ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
 	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
 #endif
@@ -2936,7 +2940,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 #define LAUNCH_PAIR(CL_, NP_) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
-			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw)
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR

@@ -110,6 +110,8 @@ def load_library():
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_set_patch_level_heights.argtypes = [C.c_void_p, C.c_int, PD]
+    lib.tmx_set_strang_off_centering.argtypes = [C.c_void_p, C.c_double]
+    lib.tmx_debug_pivot_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.tmx_set_patch_element_spacing.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
     lib.tmx_physics_kessler.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_download_precipitation.argtypes = [C.c_void_p, C.c_int, PD, C.c_int]
@@ -131,8 +133,10 @@ def _pi(a):
 
 def default_owner(npatch, n_ranks):
     """Panel-major block map of patches to ranks (results do not depend on the map)."""
-    per = (npatch + n_ranks - 1) // n_ranks
-    return [min(p // per, n_ranks - 1) for p in range(npatch)]
+    if not 1 <= n_ranks <= npatch:
+        raise ValueError("%d ranks for %d patches: every rank must own at least one patch (use more patches per panel)"
+                         % (n_ranks, npatch))
+    return [p * n_ranks // npatch for p in range(npatch)]      # remainder spread over the ranks, none left empty
 
 
 class Engine:
@@ -312,6 +316,12 @@ class Engine:
             z = np.ascontiguousarray(self.grid.patches[p].geom["z_levels"] if z_levels is None else z_levels[p], dtype=np.float64)
             self._chk(self.lib.tmx_set_patch_level_heights(self.h, p, _pd(z)))
 
+    def pivot_stats(self, enable):
+        """(uniform, total) pivot steps of the two-wavefront column kernel counted so far; enable/disable counting."""
+        out = (C.c_ulonglong * 2)()
+        self._chk(self.lib.tmx_debug_pivot_stats(self.h, 1 if enable else 0, out))
+        return int(out[0]), int(out[1])
+
     def kessler(self, instance, dt):
         """KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285 + interface/kessler.f90)."""
         self._chk(self.lib.tmx_physics_kessler(self.h, instance, dt))
@@ -369,7 +379,11 @@ class Engine:
     def step_ars343(self, dt):
         self._chk(self.lib.tmx_step_ars343(self.h, dt))
 
-    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5}
+    def set_strang_off_centering(self, oc):
+        self._chk(self.lib.tmx_set_strang_off_centering(self.h, float(oc)))
+
+    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5,
+               "strang_fe": 6, "strang_rk4": 7, "strang_ssp3": 8, "strang_ssprk53": 9}
 
     def step(self, scheme, dt, first=False, last=False):
         """TimestepScheme::Step of the named reference scheme (tmx_step)."""

@@ -10,6 +10,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   steps_ne4_L6_p24.npz    24-patch layout: prognostic interior state after 0..3 ARS343 steps
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
+  strang_variants_ne2_L4_p6.npz   Strang with ForwardEuler / RK4 / SSP3 / SSPRK53 and with off-centering: steps 1 and 3
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
   percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
   percall_tracers_ne3_L6_p6.npz / steps_tracers_ne3_L6_p6.npz   JW + 2 tracer densities (rows H8, V8)
@@ -170,11 +171,30 @@ def gen_heldsuarez(tmp):
 
 
 
+STRANG_VARIANTS = (("strang_fe", 0.0, 50.0), ("strang_rk4", 0.0, 400.0), ("strang_ssp3", 0.0, 400.0), ("strang_ssprk53", 0.0, 400.0),
+                   ("strang_rk4", 0.25, 400.0), ("strang", 0.5, 400.0))
+
+
+def gen_strang_variants(tmp):
+    # SURVEY 8a row T3, the other ExplicitDiscretization values of TimestepSchemeStrang (+ a non-zero off-centering): state and
+    # the carried instance 1 after steps 1 and 3 (ne2, L4; forward Euler at a time step it is stable with)
+    rec = {}
+    for scheme, oc, dt in STRANG_VARIANTS:
+        d, _ = run(["--mode", "steps", "--ne", "2", "--levels", "4", "--dt", str(dt), "--steps", "3", "--scheme", scheme,
+                    "--offcentering", str(oc), "--geom", "0"], tmp)
+        name = scheme + ("_oc%02d" % round(100 * oc) if oc else "")
+        for k, v in compact_states(d, 6).items():
+            if k.split("/")[1].split("_")[0] in ("step1", "step3"):
+                rec[k.replace("state/", "state/%s_" % name, 1)] = v
+    save("strang_variants_ne2_L4_p6.npz", rec)
+
+
 def main():
     tmp = "/tmp/tmx_golden.tmxd"
-    if len(sys.argv) > 1:       # regenerate only the named fixtures: supercell, kessler, heldsuarez
+    if len(sys.argv) > 1:       # regenerate only the named fixtures: supercell, kessler, heldsuarez, strang
         for nm in sys.argv[1:]:
-            {"supercell": lambda: gen_supercell(tmp), "kessler": gen_kessler_columns, "heldsuarez": lambda: gen_heldsuarez(tmp)}[nm]()
+            {"supercell": lambda: gen_supercell(tmp), "kessler": gen_kessler_columns, "heldsuarez": lambda: gen_heldsuarez(tmp),
+             "strang": lambda: gen_strang_variants(tmp)}[nm]()
         os.remove(tmp) if os.path.exists(tmp) else None
         return
     drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge",
@@ -286,6 +306,7 @@ def main():
     gen_supercell(tmp)
     gen_kessler_columns()
     gen_heldsuarez(tmp)
+    gen_strang_variants(tmp)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

@@ -237,7 +237,14 @@ class Oracle:
     def step_ars343(self, dt):
         return lib().orc_step_ars343(C.byref(self.cgrid), C.byref(self.cstate), C.c_double(dt))
 
-    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5}
+    def set_strang_off_centering(self, oc):
+        """TimestepSchemeStrang's constructor argument (process-wide in the oracle library; reset it to 0 afterwards)."""
+        f = lib().orc_set_strang_off_centering
+        f.argtypes = [C.c_double]; f.restype = None
+        f(float(oc))
+
+    SCHEMES = {"ars343": 0, "ars232": 1, "ars222": 2, "ars443": 3, "ark232": 4, "strang": 5,
+               "strang_fe": 6, "strang_rk4": 7, "strang_ssp3": 8, "strang_ssprk53": 9}
 
     def step(self, scheme, dt, first=False, last=False):
         return lib().orc_step(C.byref(self.cgrid), C.byref(self.cstate), self.SCHEMES[scheme],

@@ -108,6 +108,19 @@ def test_two_rank_plans_are_mutually_consistent():
         e.close()
 
 
+def test_default_owner_leaves_no_rank_empty():
+    """Patch -> rank map of bench.py / Engine: contiguous blocks, the remainder spread, a clear error past one patch per rank."""
+    from tempestmodel_amd.engine import default_owner
+    for n in range(1, 25):
+        own = default_owner(24, n)
+        assert own == sorted(own) and set(own) == set(range(n))
+        counts = [own.count(r) for r in range(n)]
+        assert max(counts) - min(counts) <= 1
+    assert default_owner(24, 8) == [p // 3 for p in range(24)]
+    with pytest.raises(ValueError, match="at least one patch"):
+        default_owner(6, 8)
+
+
 def test_refmath_is_glibc_bit_for_bit(tmp_path):
     """tempestmodel_amd/csrc/tmx_refmath.h (the exp / log the device evaluates in the Exner function) restates glibc's
     FMA-build exp / log; its CPU build must agree with this image's libm bit for bit: 2e7 arguments, half of them on

@@ -372,8 +372,10 @@ def test_output_interpolation():
         assert gu.interp_rel(e.interp_state(plan, 0, 1, True, False, a), d["interp/state_nodes_only"]) < 1e-14
         assert gu.interp_rel(e.interp_tracers(plan, 0), d["interp/tracers"]) < 1e-14
         e.interp_destroy(plan)
+        late = e.interp_create(pts)          # a plan that outlives its engine is released without touching the engine
     finally:
         e.close()
+    e.interp_destroy(late)
 
 
 def test_graph_replay_is_bit_identical(monkeypatch):

@@ -3,7 +3,7 @@
 WRITE_SIZE pass of the same bench command).  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE
 counts half of the bytes our 8-byte-per-lane coalesced reads move (calibrated on k_lincomb, see `method`), WRITE_SIZE
 is exact (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-usage: pmc_table.py fetch.csv write.csv steps out.json"""
+usage: pmc_table.py fetch.csv write.csv steps out.json [workload text]"""
 import csv, json, sys, collections
 
 def load(path, counter):
@@ -19,8 +19,8 @@ fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
 out = {"steps": steps, "kernels": {},
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --steps S "
-                 "--warmup W --no-cpu-baseline` (ne30 np4 L30, 1 GPU; `steps` = all steps the run executed: warm-up, timed "
-                 "and profiled pass), averages per launch.  Units KiB.  WRITE_SIZE is exact in our access pattern, "
+                 "--warmup W --no-cpu-baseline` (" + (sys.argv[5] if len(sys.argv) > 5 else "ne30 np4 L30, 1 GPU") + "; `steps` = all "
+                 "steps the run executed: development, warm-up, timed and profiled pass), averages per launch.  Units KiB.  WRITE_SIZE is exact in our access pattern, "
                  "FETCH_SIZE counts 1/2 of the bytes (calibrated on a plain copy kernel: r01 k_lincomb wrote 101925.0 KiB "
                  "= one state instance exactly and read 5 instances = 509625 KiB while FETCH_SIZE said 254826 KiB).  "
                  "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."}

@@ -1,14 +1,34 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): kernel-trace stats and the two PMC passes of the bench command.
-# usage: tools/profile_round.sh <tag>        outputs under gpurun_out/<tag>_*
+# Runs on the GPU box (gpurun): kernel-trace stats and the separate PMC passes of the bench command, for the workload
+# shapes bench.py reports traffic for.  Never combines --pmc with a trace domain other than the kernel trace.
+# usage: tools/profile_round.sh <tag> [quick]        outputs under gpurun_out/<tag>_*
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- $CMD > $OUT/${TAG}_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- $CMD > $OUT/${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o ${TAG} -- $CMD > $OUT/${TAG}_write.log 2>&1
-ls -R $OUT | grep -i csv | head -20
+B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline"
+one() {   # name, rocprof args..., -- program
+	local name=$1; shift
+	rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"
+}
+one trace --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- python3 $B
+one fetch --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $B
+one write --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o ${TAG} -- python3 $B
+one valu --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/${TAG}_valu -o ${TAG} -- python3 $B
+one mfma0 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma0 -o ${TAG} -- python3 $B
+export TMX_MFMA=1
+one mfma1 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma1 -o ${TAG} -- python3 $B
+one trace_mfma1 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_mfma1 -o ${TAG} -- python3 $B
+unset TMX_MFMA
+# configs[2] shape (ne15) and the 8-rank share of configs[1] (a lone rank-0 engine of the 8-rank layout, wire left out)
+B15="$R/bench.py --ne 15 --ppd 1 --steps 5 --warmup 2 --develop 3 --no-cpu-baseline"
+one fetch_ne15 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_ne15 -o ${TAG} -- python3 $B15
+one write_ne15 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_ne15 -o ${TAG} -- python3 $B15
+one trace_ne15 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_ne15 -o ${TAG} -- python3 $B15
+S8="$R/tools/rank_share_timing.py 8"
+one fetch_n8 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_n8 -o ${TAG} -- python3 $S8
+one write_n8 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_n8 -o ${TAG} -- python3 $S8
+one trace_n8 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_n8 -o ${TAG} -- python3 $S8
+find $OUT -name "*.csv" | head -60

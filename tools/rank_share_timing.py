@@ -11,7 +11,8 @@ from tempestmodel_amd.engine import Engine
 
 grid = CubedSphereGrid(30, 30, 30000.0, ppd=2)
 states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
-for n in (1, 2, 4, 8):
+RANKS = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]      # e.g. `rank_share_timing.py 8` under rocprofv3
+for n in RANKS:
     e = Engine(grid, rank=0, n_ranks=n)
     e.upload_state(0, states)
     for _ in range(3):
