@@ -30,6 +30,7 @@
 #include "LinearColumnOperatorFEM.h"
 #include "PolynomialInterp.h"
 #include "TimestepScheme.h"
+#include "TimestepSchemeStrang.h"
 #include "Exception.h"
 #include "WorkflowProcess.h"
 
@@ -600,7 +601,7 @@ public:
 
 	virtual void Step(bool fFirstStep, bool fLastStep, const Time & time, double dDeltaT) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);
-		eng.SetCarriedInstances((m_iScheme == TMX_SCHEME_STRANG) ? 2 : 1);
+		eng.SetCarriedInstances((m_iScheme >= TMX_SCHEME_STRANG) ? 2 : 1);      // every Strang variant carries instance 1
 		eng.EnsureDevice();
 		MI355XEngine::Check(tmx_step(eng.Handle(), m_iScheme, fFirstStep ? 1 : 0, fLastStep ? 1 : 0, dDeltaT));
 		eng.DeviceModified(true, fLastStep);
@@ -617,8 +618,45 @@ TMX_DEFINE_SCHEME(TimestepSchemeARS232_MI355X, TMX_SCHEME_ARS232);     // Timest
 TMX_DEFINE_SCHEME(TimestepSchemeARS222_MI355X, TMX_SCHEME_ARS222);     // TimestepSchemeARS222.cpp
 TMX_DEFINE_SCHEME(TimestepSchemeARS443_MI355X, TMX_SCHEME_ARS443);     // TimestepSchemeARS443.cpp
 TMX_DEFINE_SCHEME(TimestepSchemeARK232_MI355X, TMX_SCHEME_ARK232);     // TimestepSchemeARK232.cpp
-TMX_DEFINE_SCHEME(TimestepSchemeStrang_MI355X, TMX_SCHEME_STRANG);     // TimestepSchemeStrang.cpp (KGU35, off-centering 0)
 #undef TMX_DEFINE_SCHEME
+
+///	<summary>
+///		TimestepSchemeStrang with the constructor of the reference class (TimestepSchemeStrang.h:52-56): off-centering and
+///		any of its explicit discretisations.
+///	</summary>
+class TimestepSchemeStrang_MI355X : public TimestepSchemeMI355X {
+public:
+	TimestepSchemeStrang_MI355X(
+		Model & model,
+		double dOffCentering = 0.0,
+		TimestepSchemeStrang::ExplicitDiscretization eExplicitDiscretization = TimestepSchemeStrang::KinnmarkGrayUllrich35
+	) :
+		TimestepSchemeMI355X(model, SchemeId(eExplicitDiscretization)),
+		m_dOffCentering(dOffCentering)
+	{
+		if ((dOffCentering < 0.0) || (dOffCentering > 1.0)) {
+			_EXCEPTIONT("OffCentering parameter out of range [0,1]");
+		}
+	}
+
+	static int SchemeId(TimestepSchemeStrang::ExplicitDiscretization e) {
+		switch (e) {
+			case TimestepSchemeStrang::ForwardEuler: return TMX_SCHEME_STRANG_FE;
+			case TimestepSchemeStrang::RungeKutta4: return TMX_SCHEME_STRANG_RK4;
+			case TimestepSchemeStrang::RungeKuttaSSP3: return TMX_SCHEME_STRANG_SSP3;
+			case TimestepSchemeStrang::RungeKuttaSSPRK53: return TMX_SCHEME_STRANG_SSPRK53;
+			default: return TMX_SCHEME_STRANG;
+		}
+	}
+
+	virtual void Step(bool fFirstStep, bool fLastStep, const Time & time, double dDeltaT) {
+		MI355XEngine::Check(tmx_set_strang_off_centering(MI355XEngine::For(m_model).Handle(), m_dOffCentering));
+		TimestepSchemeMI355X::Step(fFirstStep, fLastStep, time, dDeltaT);
+	}
+
+private:
+	double m_dOffCentering;
+};
 
 ///////////////////////////////////////////////////////////////////////////////
 

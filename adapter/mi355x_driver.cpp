@@ -88,31 +88,36 @@ public:
 class TSwitch : public TimestepScheme {
 public:
 	TimestepScheme * m_pRef;      // the reference's own scheme
-	TimestepSchemeMI355X m_dev;   // its device drop-in (production mode)
+	TimestepSchemeMI355X * m_pDev;   // its device drop-in (production mode)
 	bool m_fDevice;
-	static int SchemeId(const std::string & scheme) {
-		if (scheme == "ars343") return TMX_SCHEME_ARS343;
-		if (scheme == "ars232") return TMX_SCHEME_ARS232;
-		if (scheme == "ars222") return TMX_SCHEME_ARS222;
-		if (scheme == "ars443") return TMX_SCHEME_ARS443;
-		if (scheme == "ark232") return TMX_SCHEME_ARK232;
-		if (scheme == "strang") return TMX_SCHEME_STRANG;
-		_EXCEPTIONT("unknown --scheme");
+	static bool StrangVariant(const std::string & scheme, TimestepSchemeStrang::ExplicitDiscretization & e) {
+		if (scheme == "strang") e = TimestepSchemeStrang::KinnmarkGrayUllrich35;
+		else if (scheme == "strang_fe") e = TimestepSchemeStrang::ForwardEuler;
+		else if (scheme == "strang_rk4") e = TimestepSchemeStrang::RungeKutta4;
+		else if (scheme == "strang_ssp3") e = TimestepSchemeStrang::RungeKuttaSSP3;
+		else if (scheme == "strang_ssprk53") e = TimestepSchemeStrang::RungeKuttaSSPRK53;
+		else return false;
+		return true;
 	}
-	TSwitch(Model & model, const std::string & scheme) : TimestepScheme(model), m_pRef(NULL), m_dev(model, SchemeId(scheme)), m_fDevice(false) {
-		if (scheme == "ark232") m_pRef = new TimestepSchemeARK232(model);
-		else if (scheme == "ars232") m_pRef = new TimestepSchemeARS232(model);
-		else if (scheme == "ars222") m_pRef = new TimestepSchemeARS222(model);
-		else if (scheme == "ars443") m_pRef = new TimestepSchemeARS443(model);
-		else if (scheme == "strang") m_pRef = new TimestepSchemeStrang(model);
-		else m_pRef = new TimestepSchemeARS343(model);
+	TSwitch(Model & model, const std::string & scheme, double dOffCentering) : TimestepScheme(model), m_pRef(NULL), m_pDev(NULL), m_fDevice(false) {
+		TimestepSchemeStrang::ExplicitDiscretization e;
+		if (StrangVariant(scheme, e)) {
+			m_pRef = new TimestepSchemeStrang(model, dOffCentering, e);
+			m_pDev = new TimestepSchemeStrang_MI355X(model, dOffCentering, e);
+		}
+		else if (scheme == "ark232") { m_pRef = new TimestepSchemeARK232(model); m_pDev = new TimestepSchemeARK232_MI355X(model); }
+		else if (scheme == "ars232") { m_pRef = new TimestepSchemeARS232(model); m_pDev = new TimestepSchemeARS232_MI355X(model); }
+		else if (scheme == "ars222") { m_pRef = new TimestepSchemeARS222(model); m_pDev = new TimestepSchemeARS222_MI355X(model); }
+		else if (scheme == "ars443") { m_pRef = new TimestepSchemeARS443(model); m_pDev = new TimestepSchemeARS443_MI355X(model); }
+		else if (scheme == "ars343") { m_pRef = new TimestepSchemeARS343(model); m_pDev = new TimestepSchemeARS343_MI355X(model); }
+		else _EXCEPTIONT("unknown --scheme");
 	}
-	virtual ~TSwitch() { delete m_pRef; }
+	virtual ~TSwitch() { delete m_pRef; delete m_pDev; }
 	virtual int GetComponentDataInstances() const { return m_pRef->GetComponentDataInstances(); }
 	virtual int GetTracerDataInstances() const { return m_pRef->GetTracerDataInstances(); }
 	virtual void Initialize() { m_pRef->Initialize(); }
 	virtual void Step(bool f, bool l, const Time & t, double dt) {
-		if (m_fDevice) m_dev.Step(f, l, t, dt); else m_pRef->Step(f, l, t, dt);
+		if (m_fDevice) m_pDev->Step(f, l, t, dt); else m_pRef->Step(f, l, t, dt);
 	}
 };
 
@@ -151,6 +156,7 @@ static void restore(GridGLL * pGrid, const Snapshot & s, int ix = 0) {
 int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 	std::string mode = "production", tcase = "jw", scheme = "ars343";
+	double offCentering = 0.0;
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10, nu = 1.0e15;
 	bool fZtopGiven = false;
@@ -166,6 +172,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--tol") { tol = atof(v); i++; }
 		else if (a == "--case") { tcase = v; i++; }
+		else if (a == "--offcentering") { offCentering = atof(v); i++; }   // TimestepSchemeStrang constructor argument
 		else if (a == "--scheme") { scheme = v; i++; }                // parity mode: ars343 (default), ark232, ars232
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--hostsync") { hostsync = atoi(v); i++; }    // production mode: host synchronisation interval (steps)
@@ -195,7 +202,7 @@ try {
 	model.SetEndTime(model.GetStartTime());
 
 	if (fSW && mode != "production") { fprintf(stderr, "--case sw2 runs in production mode\n"); return 2; }
-	TSwitch * pT = new TSwitch(model, scheme);
+	TSwitch * pT = new TSwitch(model, scheme, offCentering);
 	HSwitch * pH = new HSwitch(model, nu);
 	// --case supercell: the configuration of test/dcmip2016/SupercellTest.cpp (planet / 120, no rotation, uniform
 	// diffusion 1500 / 500 m^2/s, --explicitvertical) without its Fortran physics, driven by the JW state

@@ -179,9 +179,12 @@ def gen_strang_variants(tmp):
     # SURVEY 8a row T3, the other ExplicitDiscretization values of TimestepSchemeStrang (+ a non-zero off-centering): state and
     # the carried instance 1 after steps 1 and 3 (ne2, L4; forward Euler at a time step it is stable with)
     rec = {}
-    for scheme, oc, dt in STRANG_VARIANTS:
+    for n, (scheme, oc, dt) in enumerate(STRANG_VARIANTS):
         d, _ = run(["--mode", "steps", "--ne", "2", "--levels", "4", "--dt", str(dt), "--steps", "3", "--scheme", scheme,
-                    "--offcentering", str(oc), "--geom", "0"], tmp)
+                    "--offcentering", str(oc), "--geom", "1" if n == 0 else "0"], tmp)
+        if n == 0:      # the reference's own geometry, once: the comparison is bit for bit
+            drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge", "a_nodes", "b_nodes")
+            rec.update({k: v for k, v in d.items() if not k.startswith(("state/", "checksum/")) and k.split("/")[-1] not in drop})
         name = scheme + ("_oc%02d" % round(100 * oc) if oc else "")
         for k, v in compact_states(d, 6).items():
             if k.split("/")[1].split("_")[0] in ("step1", "step3"):

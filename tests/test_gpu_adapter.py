@@ -43,6 +43,10 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--scheme", "ars443", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("production", ["--scheme", "ark232", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("production", ["--scheme", "strang", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
+    ("production", ["--scheme", "strang_rk4", "--offcentering", "0.25", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),
+    ("production", ["--scheme", "strang_ssprk53", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),
+    ("production", ["--scheme", "strang_ssp3", "--ne", "2", "--levels", "4", "--steps", "2", "--patches", "6", "--dt", "400"]),
+    ("production", ["--scheme", "strang_fe", "--ne", "2", "--levels", "4", "--steps", "2", "--patches", "6", "--dt", "50"]),
     # BASELINE config 1: the stock SWTest2 (shallow water, Strang / KGU35) drops in unchanged
     ("production", ["--case", "sw2", "--ne", "8", "--steps", "5", "--patches", "6"]),
     # BASELINE config 5 shape: the stock HeldSuarezTest at L60, forcing on the device after every step; then with the

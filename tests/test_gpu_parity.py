@@ -837,6 +837,45 @@ def test_other_time_schemes(scheme):
         e.close()
 
 
+STRANG_VARIANTS = [("strang_fe", 0.0, 50.0), ("strang_rk4", 0.0, 400.0), ("strang_ssp3", 0.0, 400.0), ("strang_ssprk53", 0.0, 400.0),
+                   ("strang_rk4", 0.25, 400.0), ("strang", 0.5, 400.0)]
+
+
+@pytest.mark.parametrize("scheme,oc,dt", STRANG_VARIANTS)
+def test_strang_explicit_discretisations(scheme, oc, dt):
+    """SURVEY 8a row T3, the rest of it: tmx_step with TimestepSchemeStrang's other ExplicitDiscretization values and a non-zero
+    off-centering (tmx_set_strang_off_centering), two steps from the reference's state after step 1: bit for bit against
+    the reference's state and carried instance after step 3, and the oracle."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("strang_variants_ne2_L4_p6.npz")
+    name = scheme + ("_oc%02d" % round(100 * oc) if oc else "")
+    g, _ = gu.grid_from_fixture(d, override=True)
+    o = Oracle(g, ninst=5)
+    e = Engine(g, n_instances=5)
+    try:
+        assert Engine.scheme_instances(scheme) == 5
+        for setter in (o.set_state, e.upload_state):
+            setter(0, gu.expand_compact(d, "%s_step1" % name, g))
+            setter(1, gu.expand_compact(d, "%s_step1_carry" % name, g))
+        o.set_strang_off_centering(oc); e.set_strang_off_centering(oc)
+        try:
+            for _ in range(2):
+                assert o.step(scheme, dt) == 0
+                e.step(scheme, dt)
+        finally:
+            o.set_strang_off_centering(0.0)
+        e.sync()
+        for inst, tag in ((0, "step3"), (1, "step3_carry")):
+            got = e.download_state(inst)
+            assert max(gu.prognostic_errors(got, o.get_state(inst))) == EXACT
+            assert max(gu.prognostic_errors(got, gu.expand_compact(d, "%s_%s" % (name, tag), g))) == EXACT
+        with pytest.raises(Exception, match="outside"):
+            e.set_strang_off_centering(1.5)
+    finally:
+        e.close()
+
+
 def test_shallow_water_test2_strang():
     """BASELINE config 1 on the GPU: Williamson test 2 (ne8, Strang/KGU35, dt 200 s), 10 steps from the
     analytic initial state vs the reference's dumped state and the oracle."""

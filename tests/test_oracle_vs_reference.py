@@ -316,7 +316,7 @@ def test_strang_explicit_discretisations_vs_reference(scheme, oc, dt):
     reference's state (and carried instance 1) after its first step, against the reference's state after step 3."""
     d = gu.load("strang_variants_ne2_L4_p6.npz")
     name = scheme + ("_oc%02d" % round(100 * oc) if oc else "")
-    g, _ = gu.make_grid(2, 4, 6)
+    g, _ = gu.grid_from_fixture(d, override=True)          # the reference's own geometry
     o = Oracle(g, ninst=5)
     o.set_state(0, gu.expand_compact(d, "%s_step1" % name, g))
     o.set_state(1, gu.expand_compact(d, "%s_step1_carry" % name, g))
