@@ -1592,6 +1592,8 @@ void orc_v_step_implicit_terms_explicitly(const orc_grid * g, orc_state * s, int
 				NU(RIx, iA, iB, k) -= dt * F[VECF(FR, k)];
 			}
 			for (int k = 0; k <= L; k++) EU(WIx, iA, iB, k) -= dt * F[VECF(FW, k)];
+			if (has_tracers(g, s))      /* UpdateColumnTracers(dt, initial, update, ...), VerticalDynamicsFEM.cpp:600-608 */
+				update_column_tracers(g, P, iA, iB, dt, x0, &w, eup, s->tracer[iinit * g->npatch + p], s->tracer[iupd * g->npatch + p]);
 		}
 	}
 	colwork_free(&w);

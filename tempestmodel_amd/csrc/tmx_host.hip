@@ -1941,9 +1941,11 @@ static int build_program(int scheme, int first, int last, double dt, Program & p
 extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, int iupd, double dt) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	REQUIRE(iinit != iupd && dt != 0.0, TMX_ERR_INVALID, "StepImplicitTermsExplicitly: distinct instances and non-zero dt required");
-	REQUIRE(e->nt == 0, TMX_ERR_UNSUPPORTED, "StepImplicitTermsExplicitly (ARK232) with tracers is not supported");
 	ProfScope ps(e, TMX_K_VI_ASSEMBLE);
 	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	if (e->nt > 0)      // UpdateColumnTracers(dt, initial, update, ...) of every column, :600-608
+		REQUIRE(tmxk_vi_tracers_all(e, make_params(e), inst(e, iinit), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
+			"tracer column update: %d levels do not fit the LDS working set", e->L);
 	return launch_check("v_step_implicit_terms_explicitly");
 }
 // ---------------------------------------------------------------------------------------------

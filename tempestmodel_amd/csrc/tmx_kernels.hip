@@ -1091,6 +1091,20 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 	return 0;
 }
 
+// UpdateColumnTracers at the end of StepImplicitTermsExplicitly (VerticalDynamicsFEM.cpp:600-608): the implicit column update
+// of the tracers, on every stored column (the reference loops over all nodes there, :541-542), in place on the update instance
+int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+	if (e->nt == 0 || p.ncol == 0) return 0;
+	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
+	if (!lw) return -1;
+#define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+	hipLaunchKernelGGL(k_vi_tracers<LW_>, dim3((p.ncol + LW_ - 1) / LW_), dim3(64), lds, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS, \
+		(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag, 0, 0.0, (const double *)nullptr); } while (0)
+	if (lw == 64) LAUNCH_VT(64); else LAUNCH_VT(32);
+#undef LAUNCH_VT
+	return 0;
+}
+
 // VerticalDynamicsFEM::FilterNegativeTracers (VerticalDynamicsFEM.cpp:4286-4347): per stored column and tracer
 __global__ __launch_bounds__(256) void k_v_filter_tracers(KParams p, int nt, const double * __restrict__ area, double * x) {
 	const int L = p.L;

@@ -10,6 +10,7 @@ The fixtures are data only: inputs and outputs of the reference's hot-path calls
   steps_ne4_L6_p24.npz    24-patch layout: prognostic interior state after 0..3 ARS343 steps
   steps_ne3_L5_p6.npz     6-patch layout: prognostic interior state after 0,1,2,5,10 steps
   schemes_ne2_L4_p6.npz   ARS232 / ARS222 / ARS443 / ARK232 / Strang: state after steps 1 and 3 (ne2, L4)
+  steps_ark232_tracers_ne2_L5_p6.npz   ARK232 with 2 tracers (StepImplicitTermsExplicitly + tracer column update): steps 1 and 3
   strang_variants_ne2_L4_p6.npz   Strang with ForwardEuler / RK4 / SSP3 / SSPRK53 and with off-centering: steps 1 and 3
   sw2_ne8_strang.npz      Williamson shallow-water test 2 (BASELINE config 1): state after 0, 1, 10 Strang steps
   percall_schar_ne3_L6_p6.npz / steps_schar_ne3_L6_p6.npz   Schar mountain, reduced-radius sphere, Rayleigh layer (row H7)
@@ -192,12 +193,23 @@ def gen_strang_variants(tmp):
     save("strang_variants_ne2_L4_p6.npz", rec)
 
 
+def gen_ark232_tracers(tmp):
+    # SURVEY 8a row V2 with tracers: ARK232 (its first implicit stage is StepImplicitTermsExplicitly, which ends with the implicit
+    # column update of the tracers) on the JW state with 2 tracers, ne2 L5: state + tracers after steps 1 and 3, own geometry
+    d, _ = run(["--mode", "steps", "--ne", "2", "--levels", "5", "--dt", "300", "--steps", "3", "--scheme", "ark232",
+                "--tracers", "2", "--geom", "1"], tmp)
+    drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_redge", "a_nodes", "b_nodes")     # the filters need the areas
+    rec = {k: v for k, v in d.items() if not k.startswith(("state/", "checksum/")) and k.split("/")[-1] not in drop}
+    rec.update({k: v for k, v in compact_states(d, 6).items() if k.split("/")[1] in ("step1", "step3")})
+    save("steps_ark232_tracers_ne2_L5_p6.npz", rec)
+
+
 def main():
     tmp = "/tmp/tmx_golden.tmxd"
     if len(sys.argv) > 1:       # regenerate only the named fixtures: supercell, kessler, heldsuarez, strang
         for nm in sys.argv[1:]:
             {"supercell": lambda: gen_supercell(tmp), "kessler": gen_kessler_columns, "heldsuarez": lambda: gen_heldsuarez(tmp),
-             "strang": lambda: gen_strang_variants(tmp)}[nm]()
+             "strang": lambda: gen_strang_variants(tmp), "ark232_tracers": lambda: gen_ark232_tracers(tmp)}[nm]()
         os.remove(tmp) if os.path.exists(tmp) else None
         return
     drop = ("lon", "lat", "z_levels", "z_interfaces", "element_area_node", "element_area_redge",
@@ -310,6 +322,7 @@ def main():
     gen_kessler_columns()
     gen_heldsuarez(tmp)
     gen_strang_variants(tmp)
+    gen_ark232_tracers(tmp)
 
     # reference stdout known answers (same command as SURVEY.md section 8c)
     _, ka = run(["--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--steps", "3",

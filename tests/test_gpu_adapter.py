@@ -42,6 +42,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--scheme", "ars222", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("production", ["--scheme", "ars443", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("production", ["--scheme", "ark232", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
+    ("production", ["--scheme", "ark232", "--tracers", "2", "--ne", "2", "--levels", "5", "--steps", "3", "--patches", "6", "--dt", "300"]),
+    ("parity", ["--scheme", "ark232", "--tracers", "2", "--ne", "2", "--levels", "5", "--steps", "2", "--patches", "6", "--dt", "300"]),
     ("production", ["--scheme", "strang", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
     ("production", ["--scheme", "strang_rk4", "--offcentering", "0.25", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),
     ("production", ["--scheme", "strang_ssprk53", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),

@@ -221,6 +221,42 @@ def test_tracer_steps_vs_reference_and_oracle():
         e.close()
 
 
+def test_ark232_with_tracers():
+    """SURVEY 8a row V2 with tracers: tmx_step(ARK232) with 2 tracers -- StepImplicitTermsExplicitly followed by the implicit
+    column update of the tracers on every stored column -- against the reference's state / tracers after step 3 and the
+    oracle, bit for bit; and the single call against the oracle on a state whose duplicated nodes differ."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("steps_ark232_tracers_ne2_L5_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, ntracers=2)
+    st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
+    dt = float(d["cfg/dt"][0])
+    o = Oracle(g, ninst=8); o.set_state(0, st); o.set_tracers(0, tr)
+    e = Engine(g, n_instances=8); e.upload_state(0, st); e.upload_tracers(0, tr)
+    try:
+        for _ in range(2):
+            assert o.step("ark232", dt) == 0
+            e.step("ark232", dt)
+        e.sync()
+        got_s, got_t = e.download_state(0), e.download_tracers(0)
+        assert max(gu.tracer_errors(got_t, o.get_tracers(0))) == EXACT
+        assert max(gu.prognostic_errors(got_s, o.get_state(0))) == EXACT
+        assert max(gu.tracer_errors(got_t, gu.expand_compact_tracers(d, "step3", g))) == EXACT
+        assert max(gu.prognostic_errors(got_s, gu.expand_compact(d, "step3", g))) == EXACT
+        # the call on its own, from a state before any DSS (duplicated element-edge columns hold different data: the
+        # reference updates every node from its own column there, VerticalDynamicsFEM.cpp:541-542)
+        o.copy_data(0, 1); o.h_step_explicit(0, 1, dt); o.copy_data(1, 2)
+        e.upload_state(1, o.get_state(1)); e.upload_tracers(1, o.get_tracers(1))
+        e.upload_state(2, o.get_state(2)); e.upload_tracers(2, o.get_tracers(2))
+        o.v_step_implicit_terms_explicitly(1, 2, 0.3 * dt)
+        e.v_step_implicit_terms_explicitly(1, 2, 0.3 * dt)
+        e.sync()
+        assert max(gu.tracer_errors(e.download_tracers(2), o.get_tracers(2))) == EXACT
+        assert max(gu.prognostic_errors(e.download_state(2), o.get_state(2))) == EXACT
+    finally:
+        e.close()
+
+
 UDIFF = (1500.0, 500.0)
 
 

@@ -198,6 +198,20 @@ def test_tracer_steps_vs_reference():
         assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step%d" % step, g))) < 1e-10
 
 
+def test_ark232_with_tracers_vs_reference():
+    """SURVEY 8a row V2 with tracers: ARK232's first implicit stage is StepImplicitTermsExplicitly, which ends with the
+    implicit column update of the tracers (VerticalDynamicsFEM.cpp:600-608).  Two steps from the reference's state and tracers
+    after step 1 against those after step 3, on the reference's own geometry: bit for bit."""
+    d = gu.load("steps_ark232_tracers_ne2_L5_p6.npz")
+    g, _ = gu.grid_from_fixture(d, override=True, ntracers=2)
+    o = Oracle(g, ninst=8)
+    o.set_state(0, gu.expand_compact(d, "step1", g)); o.set_tracers(0, gu.expand_compact_tracers(d, "step1", g))
+    for _ in range(2):
+        assert o.step("ark232", float(d["cfg/dt"][0])) == 0
+    assert max(gu.tracer_errors(o.get_tracers(0), gu.expand_compact_tracers(d, "step3", g))) == 0.0
+    assert max(gu.prognostic_errors(o.get_state(0), gu.expand_compact(d, "step3", g))) == 0.0
+
+
 def test_output_interpolation_vs_reference():
     """SURVEY 8(f) item 4: Grid::ReduceInterpolate (the interpolation behind OutputManagerReference) for the state with
     every flag combination and for the tracers -- bit for bit, except (U,V) in primitive form where the probed 2x2
