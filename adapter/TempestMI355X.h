@@ -161,6 +161,34 @@ public:
 		}
 	}
 
+	///	Restart write, device side: instance 0 of every active patch straight into the bytes of
+	///	GridPatch::GetDataContainerActiveState(), which OutputManagerComposite::Output then writes unchanged
+	///	(OutputManagerComposite.cpp:331-349).  One contiguous device-to-host copy per patch, no host transposition.
+	void WriteActiveStateImage() {
+		Initialize();
+		Check(tmx_sync(m_pEngine));
+		GridGLL * pGrid = Grid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			const DataContainer & dc = pPatch->GetDataContainerActiveState();
+			Check(tmx_pack_active_state(m_pEngine, pPatch->GetPatchIndex(), 0,
+				const_cast<unsigned char *>(dc.GetPointer()), dc.GetTotalByteSize()));
+		}
+		m_fDeviceNewer = false; m_fHostNewer = false; m_nStepsSinceSync = 0;
+	}
+
+	///	Restart read: the active-state containers (as a restart file filled them) -> instance 0 on the device.
+	void ReadActiveStateImage() {
+		Initialize();
+		GridGLL * pGrid = Grid();
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			GridPatch * pPatch = pGrid->GetActivePatch(n);
+			const DataContainer & dc = pPatch->GetDataContainerActiveState();
+			Check(tmx_unpack_active_state(m_pEngine, pPatch->GetPatchIndex(), 0, dc.GetPointer(), dc.GetTotalByteSize()));
+		}
+		m_fDeviceNewer = false; m_fHostNewer = false;
+	}
+
 	~MI355XEngine() {
 		if (m_pEngine != NULL) {
 			tmx_destroy(m_pEngine);

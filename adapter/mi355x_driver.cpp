@@ -157,6 +157,7 @@ int main(int argc, char ** argv) {
 	TempestInitialize(&argc, &argv);
 	std::string mode = "production", tcase = "jw", scheme = "ars343";
 	double offCentering = 0.0;
+	int restartAt = -1, restartStatus = 0;
 	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10, nu = 1.0e15;
 	bool fZtopGiven = false;
@@ -172,6 +173,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--dt") { dt = atof(v); i++; }
 		else if (a == "--tol") { tol = atof(v); i++; }
 		else if (a == "--case") { tcase = v; i++; }
+		else if (a == "--restart") { restartAt = atoi(v); i++; }           // production mode: restart image after K steps
 		else if (a == "--offcentering") { offCentering = atof(v); i++; }   // TimestepSchemeStrang constructor argument
 		else if (a == "--scheme") { scheme = v; i++; }                // parity mode: ars343 (default), ark232, ars232
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
@@ -279,6 +281,45 @@ try {
 	if (mode == "production") { pT->m_fDevice = true; engine.SetHostSyncInterval(hostsync); engine.MarkHostModified(); }
 	else if (mode == "parity") { pH->m_fDevice = true; pV->m_fDevice = true; }
 	else { fprintf(stderr, "bad mode\n"); return 2; }
+	if (restartAt >= 0) {
+		// --restart K (production mode): K steps on the device, the restart image written by the device into the active-state
+		// containers (poisoned first, so that nothing but the image is used), the image read back into a cleared device
+		// instance, and the remaining steps on the device again; then the same with the REFERENCE stepper continuing from
+		// the image on the host.  Both must end where the uninterrupted reference run ends.
+		if (mode != "production" || restartAt > nsteps) { fprintf(stderr, "--restart needs --mode production and K <= steps\n"); return 2; }
+		for (int s = 0; s < restartAt; s++) { pT->Step(false, false, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
+		for (int n = 0; n < pGrid->GetActivePatchCount(); n++) {
+			const DataContainer & dc = pGrid->GetActivePatch(n)->GetDataContainerActiveState();
+			memset(const_cast<unsigned char *>(dc.GetPointer()), 0xff, dc.GetTotalByteSize());
+		}
+		engine.WriteActiveStateImage();
+		Snapshot image;
+		save(pGrid, image);
+		// (a) the reference continues from the image
+		pT->m_fDevice = false;
+		for (int s = restartAt; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysRef) pPhysRef->Perform(time); }
+		Snapshot viaHost;
+		save(pGrid, viaHost);
+		double dh = 0.0;
+		for (size_t a = 0; a < ref.size(); a++) {
+			const PatchBox & box = pGrid->GetActivePatch((int)(a / 3))->GetPatchBox();
+			const int nA = box.GetATotalWidth(), nB = box.GetBTotalWidth();
+			const int Lk = (a % 3 == 1) ? levels + 1 : levels;
+			for (size_t c = 0; c * nA * nB * Lk < ref[a].size(); c++)
+				for (int i = 1; i < nA - 1; i++) for (int j = 1; j < nB - 1; j++) for (int k = 0; k < Lk; k++) {
+					if (a % 3 != 2 && ((c == 3) != (a % 3 == 1))) continue;      // prognostic slots
+					const size_t o = ((c * nA + i) * nB + j) * Lk + k;
+					dh = std::max(dh, fabs(viaHost[a][o] - ref[a][o]));
+				}
+		}
+		printf("restart image written by the device after %d steps, reference stepper continues from it: max abs diff vs the uninterrupted reference run %.3e\n", restartAt, dh);
+		if (dh != 0.0) restartStatus = 1;
+		// (b) the device continues from the image it reads back
+		restore(pGrid, image);
+		pT->m_fDevice = true;
+		engine.ReadActiveStateImage();
+		for (int s = restartAt; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
+	} else
 	for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
 	// deferred host synchronisation (--hostsync > 1): what a driver does at the reference's host sync points
 	// (OutputManager::ManageOutput / FinalOutput, ComputeErrorNorms: Model.cpp:484-509, :695)
@@ -346,7 +387,7 @@ try {
 	if (physics == 1) printf("  [Held-Suarez physics after every step]");
 	if (physics == 2) printf("  [Kessler physics after every step]");
 	printf("  scheme=%s case=%s hostsync=%d\n", scheme.c_str(), tcase.c_str(), hostsync);
-	status = (worst < tol) ? 0 : 1;
+	status = (worst < tol && restartStatus == 0) ? 0 : 1;
 	printf("closed-form metric (factors taken from the reference grid, verified bit for bit): %s\n",
 		tmx_info(MI355XEngine::For(model).Handle(), TMX_INFO_METRIC_CLOSED_FORM) == 1 ? "active" : "refused, arrays streamed");
 	// the output interpolation.  Host arrays and device now hold the same instance 0: the reference's

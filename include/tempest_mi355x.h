@@ -248,6 +248,21 @@ int tmx_step_ars343(tmx_engine * e, double dt);   /* = tmx_step(e, TMX_SCHEME_AR
 
 /* VerticalDynamicsFEM::StepImplicitTermsExplicitly (src/atm/VerticalDynamicsFEM.cpp:439-612): update -= dt F(initial)
  * on every column (used by ARK232). */
+/* ---- restart image: the bytes of GridPatch::GetDataContainerActiveState() (src/atm/GridPatch.cpp:359-361,387),
+ * which OutputManagerComposite::Output writes per patch (src/atm/OutputManagerComposite.cpp:331-349) and a restart reads back:
+ *   8 bytes   patch index (DataArray1D<int> of one entry, padded to sizeof(size_t))
+ *   node   [5][na][nb][L]       redge  [5][na][nb][L+1]       tracers [n_tracers][na][nb][L]
+ * The transposition from the device layout is done ON the device, so the host side of a restart write is one contiguous
+ * device-to-host copy per patch straight into the container (dst = dcActiveState.GetPointer()).  Interior nodes carry every
+ * array the reference keeps there (the prognostic ones, W on levels and U,V on interfaces as HorizontalDynamicsFEM.cpp:817-831
+ * leaves them, and the two interface-level-0 entries described at tmx_set_patch_physics_inputs when they are tracked).  The halo
+ * ring and the interface copies of rho / rho*theta above level 0 are written as zeros: nothing on the path reads them before
+ * the next exchange rewrites the ring, so a run restarted from the image continues bit for bit (tests/test_gpu_adapter.py,
+ * --restart).  tmx_unpack_active_state is the inverse (restart read).  Bytes must equal tmx_active_state_bytes(e, patch). */
+long long tmx_active_state_bytes(tmx_engine * e, int patch);
+int tmx_pack_active_state(tmx_engine * e, int patch, int instance, void * dst, size_t dst_bytes);
+int tmx_unpack_active_state(tmx_engine * e, int patch, int instance, const void * src, size_t src_bytes);
+
 /* ---- output interpolation: Grid::ReduceInterpolate (src/atm/Grid.cpp:867-992) ->
  * GridPatchCSGLL::InterpolateData (src/atm/GridPatchCSGLL.cpp:1365-1780), what OutputManagerReference calls for every
  * output (src/atm/OutputManagerReference.cpp:588-628).  The state stays on the device; only the interpolated fields

@@ -193,7 +193,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -1168,6 +1168,74 @@ extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, doubl
 			}
 		}
 	});
+	return TMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Restart image (second half): the bytes of GridPatch::GetDataContainerActiveState() (GridPatch.cpp:359-361,387),
+// which is what OutputManagerComposite::Output writes per patch (OutputManagerComposite.cpp:331-349) and what a restart reads
+// back.  The transposition from the slab layout runs on the device; the host sees ONE contiguous copy per patch.
+static KParams make_params(const tmx_engine * e);
+static int launch_check(const char * what);
+
+static size_t active_state_doubles(const tmx_engine * e, const PatchInfo & P) {
+	const size_t nn = (size_t)P.na * P.nb;
+	return 5 * nn * e->L + 5 * nn * (e->L + 1) + (size_t)e->nt * nn * e->L;
+}
+
+extern "C" long long tmx_active_state_bytes(tmx_engine * e, int patch) {
+	if (!e || patch < 0 || patch >= e->cfg.n_patches || e->sw) return -1;
+	return (long long)(sizeof(double) * (1 + active_state_doubles(e, e->patches[patch])));      // 8-byte DataArray1D<int> chunk in front
+}
+
+static int image_buffer(tmx_engine * e, size_t n) {
+	if (e->image_n < n) {
+		if (e->d_image) { hipFree(e->d_image); e->hbm_bytes -= e->image_n * sizeof(double); }
+		e->d_image = nullptr; e->image_n = 0;
+		HIPCHK(hipMalloc((void **)&e->d_image, n * sizeof(double)));
+		e->image_n = n; e->hbm_bytes += n * sizeof(double);
+	}
+	return TMX_OK;
+}
+
+extern "C" int tmx_pack_active_state(tmx_engine * e, int patch, int instance, void * dst, size_t dst_bytes) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "restart image with the shallow-water equation set is not supported");
+	const PatchInfo & P = e->patches[patch];
+	const size_t nd = active_state_doubles(e, P);
+	REQUIRE(dst && dst_bytes == sizeof(double) * (1 + nd), TMX_ERR_INVALID, "tmx_pack_active_state: %zu bytes given, the container of patch %d has %zu",
+		dst_bytes, patch, sizeof(double) * (1 + nd));
+	if ((r = image_buffer(e, nd))) return r;
+	HIPCHK(hipMemsetAsync(e->d_image, 0, nd * sizeof(double), e->stream));       // halo ring and the entries nothing on the path reads
+	tmxk_active_state_image(e, make_params(e), true, P.elem_base * TMX_NQ, P.nea * P.neb * TMX_NQ, P.na, P.nb, P.neb,
+		e->d_state + (size_t)instance * e->inst_stride, e->track_surface ? e->d_state + (size_t)instance * e->inst_stride + (size_t)e->nslab * e->NS : nullptr, e->d_image);
+	if ((r = launch_check("pack_active_state"))) return r;
+	unsigned char * out = (unsigned char *)dst;
+	HIPCHK(hipMemcpyAsync(out + sizeof(double), e->d_image, nd * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	memset(out, 0, sizeof(double));
+	const int ix = patch; memcpy(out, &ix, sizeof(int));       // m_iActiveStatePatchIx (GridPatch.cpp:359)
+	return TMX_OK;
+}
+
+extern "C" int tmx_unpack_active_state(tmx_engine * e, int patch, int instance, const void * src, size_t src_bytes) {
+	int r = check_state_args(e, patch, instance);
+	if (r) return r;
+	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "restart image with the shallow-water equation set is not supported");
+	const PatchInfo & P = e->patches[patch];
+	const size_t nd = active_state_doubles(e, P);
+	REQUIRE(src && src_bytes == sizeof(double) * (1 + nd), TMX_ERR_INVALID, "tmx_unpack_active_state: %zu bytes given, the container of patch %d has %zu",
+		src_bytes, patch, sizeof(double) * (1 + nd));
+	int ix = -1; memcpy(&ix, src, sizeof(int));
+	REQUIRE(ix == patch, TMX_ERR_INVALID, "tmx_unpack_active_state: the image is of patch %d, not %d", ix, patch);
+	if ((r = image_buffer(e, nd))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));
+	HIPCHK(hipMemcpyAsync(e->d_image, (const unsigned char *)src + sizeof(double), nd * sizeof(double), hipMemcpyHostToDevice, e->stream));
+	tmxk_active_state_image(e, make_params(e), false, P.elem_base * TMX_NQ, P.nea * P.neb * TMX_NQ, P.na, P.nb, P.neb,
+		e->d_state + (size_t)instance * e->inst_stride, e->d_state + (size_t)instance * e->inst_stride + (size_t)e->nslab * e->NS, e->d_image);
+	if ((r = launch_check("unpack_active_state"))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));      // the caller may reuse src
 	return TMX_OK;
 }
 

@@ -145,6 +145,7 @@ struct tmx_engine {
 	// boundary-first launches (ranks > 1): 64-column tiles holding a column another rank needs, and the others
 	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_quads_early = 0, n_quads_late = 0, launch_tiles = 0; bool split_stage = false, split_overlapped = false;
 	std::vector<struct tmx_interp *> interps;          // output-interpolation plans created on this engine and not yet destroyed
+	double * d_image = nullptr; size_t image_n = 0;     // restart image of one patch (tmx_pack_active_state), grown on demand
 	double strang_offc = 0.0;                          // TimestepSchemeStrang off-centering (tmx_set_strang_off_centering)
 	unsigned long long * d_pivot_stats = nullptr;      // tmx_debug_pivot_stats: {uniform pivot steps, all pivot steps} of k_vi_pair, per wavefront
 	bool use_mfma = false;                   // TMX_MFMA=1: 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
@@ -197,6 +198,7 @@ struct InterpArgs {
 void tmxk_interp_state(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, const double * xref,
 	int only_at, int primitive, double earth_radius, double * out);
 void tmxk_interp_tracers(tmx_engine * e, const KParams & p, const InterpArgs & a, const double * x, double * out);
+void tmxk_active_state_image(tmx_engine * e, const KParams & p, bool pack, int c0, int ncp, int na, int nb, int neb, double * x, double * surf, double * img);
 int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout, double dt, double ks, double kv);

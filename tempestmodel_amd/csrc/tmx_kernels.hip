@@ -1105,6 +1105,113 @@ int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, d
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Restart image: GridPatch::GetDataContainerActiveState() of one patch (GridPatch.cpp:359-361,387), i.e.
+// what OutputManagerComposite::Output writes per patch (OutputManagerComposite.cpp:331-349): after the 8-byte patch index,
+//   node [5][na][nb][L], redge [5][na][nb][L+1], tracers [nt][na][nb][L]      (k fastest, one-node halo ring)
+// One workgroup = 64 device columns (4 elements), one wavefront = one element.  Per variable the slabs of the tile are
+// staged through LDS (coalesced 512 B rows of the slab layout on one side, contiguous L x 8 B columns of the image on the
+// other).  PACK also forms the three derived arrays the reference keeps beside the prognostic ones (W on levels, U and V
+// on interfaces: HorizontalDynamicsFEM.cpp:817-831), with the same statements as tmx_download_state.
+struct ImageArgs {
+	int c0, ncp, na, nb, neb, nt;     // first device column of the patch, its column count, patch box, elements along beta, tracers
+	double * x;                       // instance base (slab layout)
+	double * surf;                    // its two surface slots or nullptr
+	double * img;                     // image, in doubles, header excluded
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_active_state_image(KParams p, ImageArgs a) {
+	extern __shared__ double tile[];          // [L+1][65]
+	const int L = p.L, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t NS = (size_t)p.NS, nn = (size_t)a.na * a.nb;
+	const int cb = blockIdx.x * 64;                 // first patch column of the tile
+	const int cl = cb + threadIdx.x % 64;           // this lane's column when moving slab rows
+	const bool col_ok = cl < a.ncp;
+	const int el = (cb >> 4) + wv;                   // this wavefront's element
+	const bool el_ok = (el << 4) < a.ncp;
+	const int ea = el / a.neb, eb = el % a.neb;
+	// host node offset of column q (0..15) of the wavefront's element
+	auto hoff = [&](int q) { return (size_t)(1 + ea * 4 + (q >> 2)) * a.nb + (1 + eb * 4 + (q & 3)); };
+	double * node = a.img, * redge = a.img + 5 * nn * L, * trc = redge + 5 * nn * (L + 1);
+#define TL(k_, c_) tile[(k_) * 65 + (c_)]
+	// one variable: slabs [slab0, slab0 + nlev) <-> image array `arr` component `comp` with nlev entries per node
+	auto move = [&](int slab0, int nlev, double * arr, int comp) {
+		if (PACK) {
+			for (int k = wv; k < nlev; k += 4) if (col_ok) TL(k, lane) = a.x[(size_t)(slab0 + k) * NS + a.c0 + cl];
+			__syncthreads();
+			if (el_ok)
+				for (int q = 0; q < 16; q++) {
+					double * dst = arr + ((size_t)comp * nn + hoff(q)) * nlev;
+					for (int k = lane; k < nlev; k += 64) dst[k] = TL(k, wv * 16 + q);
+				}
+		} else {
+			if (el_ok)
+				for (int q = 0; q < 16; q++) {
+					const double * src = arr + ((size_t)comp * nn + hoff(q)) * nlev;
+					for (int k = lane; k < nlev; k += 64) TL(k, wv * 16 + q) = src[k];
+				}
+			__syncthreads();
+			for (int k = wv; k < nlev; k += 4) if (col_ok) a.x[(size_t)(slab0 + k) * NS + a.c0 + cl] = TL(k, lane);
+		}
+	};
+	const int nodevar[4] = { 0, 1, 2, 4 };
+	for (int v = 0; v < 4; v++) {
+		move(v * L, L, node, nodevar[v]);
+		if (PACK && v < 2 && el_ok) {
+			// U (v = 0) or V (v = 1) on interfaces from the column in the tile: InterpolateNodeToREdge
+			for (int q = 0; q < 16; q++) {
+				double * dst = redge + ((size_t)v * nn + hoff(q)) * (L + 1);
+				for (int k = lane; k <= L; k += 64) {
+					double ue = 0.0;
+					for (int off = -2; off <= 1; off++) {
+						const int l = k + off;
+						if (l < 0 || l >= L) continue;
+						const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
+						if (cc == 0.0) continue;
+						ue += cc * TL(l, wv * 16 + q);
+					}
+					dst[k] = ue;
+				}
+			}
+		}
+		__syncthreads();
+	}
+	move(4 * L, L + 1, redge, 3);
+	if (PACK && el_ok) {
+		for (int q = 0; q < 16; q++) {      // W on levels: InterpolateREdgeToNode
+			double * dst = node + ((size_t)3 * nn + hoff(q)) * L;
+			for (int k = lane; k < L; k += 64) {
+				double w = 0.0;
+				w += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * TL(k, wv * 16 + q);
+				w += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * TL(k + 1, wv * 16 + q);
+				dst[k] = w;
+			}
+		}
+	}
+	__syncthreads();
+	for (int c = 0; c < a.nt; c++) { move(TMX_SLAB_Q(L, c, 0), L, trc, c); __syncthreads(); }
+	// surface slots: interface-level-0 entries of rho (component 4) and rho*theta (component 2)
+	if (a.surf && el_ok && lane < 16) {
+		const size_t col = (size_t)a.c0 + (el << 4) + lane;
+		double * r4 = redge + ((size_t)4 * nn + hoff(lane)) * (L + 1), * r2 = redge + ((size_t)2 * nn + hoff(lane)) * (L + 1);
+		if (PACK) { *r4 = a.surf[col]; *r2 = a.surf[NS + col]; }
+		else { a.surf[col] = *r4; a.surf[NS + col] = *r2; }
+	}
+#undef TL
+}
+
+void tmxk_active_state_image(tmx_engine * e, const KParams & p, bool pack, int c0, int ncp, int na, int nb, int neb, double * x, double * surf, double * img) {
+	ImageArgs a; a.c0 = c0; a.ncp = ncp; a.na = na; a.nb = nb; a.neb = neb; a.nt = e->nt; a.x = x; a.surf = surf; a.img = img;
+	const size_t lds = (size_t)(p.L + 1) * 65 * sizeof(double);
+	if (lds > 48 * 1024) {
+		hipFuncSetAttribute((const void *)k_active_state_image<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipFuncSetAttribute((const void *)k_active_state_image<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	}
+	if (pack) hipLaunchKernelGGL(k_active_state_image<true>, dim3((ncp + 63) / 64), dim3(256), lds, e->stream, p, a);
+	else hipLaunchKernelGGL(k_active_state_image<false>, dim3((ncp + 63) / 64), dim3(256), lds, e->stream, p, a);
+}
+
 // VerticalDynamicsFEM::FilterNegativeTracers (VerticalDynamicsFEM.cpp:4286-4347): per stored column and tracer
 __global__ __launch_bounds__(256) void k_v_filter_tracers(KParams p, int nt, const double * __restrict__ area, double * x) {
 	const int L = p.L;

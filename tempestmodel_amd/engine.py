@@ -110,6 +110,10 @@ def load_library():
     lib.tmx_set_patch_physics_inputs.argtypes = [C.c_void_p, C.c_int, PD, PD]
     lib.tmx_physics_held_suarez.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.tmx_set_patch_level_heights.argtypes = [C.c_void_p, C.c_int, PD]
+    lib.tmx_active_state_bytes.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_active_state_bytes.restype = C.c_longlong
+    lib.tmx_pack_active_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.tmx_unpack_active_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.tmx_set_strang_off_centering.argtypes = [C.c_void_p, C.c_double]
     lib.tmx_debug_pivot_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.tmx_set_patch_element_spacing.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
@@ -378,6 +382,19 @@ class Engine:
 
     def step_ars343(self, dt):
         self._chk(self.lib.tmx_step_ars343(self.h, dt))
+
+    def pack_active_state(self, patch, instance=0):
+        """Bytes of GridPatch::GetDataContainerActiveState() of the patch, transposed on the device (restart write)."""
+        n = self.lib.tmx_active_state_bytes(self.h, patch)
+        if n < 0:
+            raise TempestError("tmx_active_state_bytes: no image for this engine / patch")
+        buf = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.tmx_pack_active_state(self.h, patch, instance, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def unpack_active_state(self, patch, instance, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        self._chk(self.lib.tmx_unpack_active_state(self.h, patch, instance, image.ctypes.data_as(C.c_void_p), image.size))
 
     def set_strang_off_centering(self, oc):
         self._chk(self.lib.tmx_set_strang_off_centering(self.h, float(oc)))

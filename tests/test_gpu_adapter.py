@@ -45,6 +45,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--scheme", "ark232", "--tracers", "2", "--ne", "2", "--levels", "5", "--steps", "3", "--patches", "6", "--dt", "300"]),
     ("parity", ["--scheme", "ark232", "--tracers", "2", "--ne", "2", "--levels", "5", "--steps", "2", "--patches", "6", "--dt", "300"]),
     ("production", ["--scheme", "strang", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6"]),
+    ("production", ["--restart", "2", "--ne", "3", "--levels", "6", "--steps", "4", "--patches", "6", "--tracers", "2"]),
+    ("production", ["--restart", "2", "--case", "heldsuarez", "--physics", "1", "--ne", "2", "--levels", "12", "--steps", "4", "--patches", "6"]),
     ("production", ["--scheme", "strang_rk4", "--offcentering", "0.25", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),
     ("production", ["--scheme", "strang_ssprk53", "--ne", "2", "--levels", "4", "--steps", "3", "--patches", "6", "--dt", "400"]),
     ("production", ["--scheme", "strang_ssp3", "--ne", "2", "--levels", "4", "--steps", "2", "--patches", "6", "--dt", "400"]),

@@ -414,6 +414,61 @@ def test_output_interpolation():
     e.interp_destroy(late)
 
 
+def test_restart_image_pack_and_unpack():
+    """SURVEY 8(f) item 4, second half: the DataContainer image OutputManagerComposite writes per patch, transposed on the
+    device.  Interior nodes of the image hold exactly what tmx_download_state / tmx_download_tracers deliver (prognostic and
+    derived arrays, the reference's values of test_download_fills_derived_slots), halo ring zero, patch index in front;
+    unpacking the image into another instance reproduces the instance bit for bit, and a run continued from it is identical."""
+    from tempestmodel_amd.engine import Engine, TempestError
+    d = gu.load("steps_tracers_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, ntracers=2)
+    st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
+    e = Engine(g)
+    try:
+        e.upload_state(0, st); e.upload_tracers(0, tr)
+        e.step_ars343(200.0); e.sync()
+        want_s, want_t = e.download_state(0), e.download_tracers(0)
+        L = g.L
+        images = []
+        for P, (wn, we), wt in zip(g.patches, want_s, want_t):
+            img = e.pack_active_state(P.index, 0)
+            images.append(img)
+            nn = P.na * P.nb
+            assert img.size == 8 * (1 + 5 * nn * L + 5 * nn * (L + 1) + 2 * nn * L)
+            assert int(img[:4].view(np.int32)[0]) == P.index and not img[4:8].any()
+            body = img[8:].view(np.float64)
+            node = body[:5 * nn * L].reshape(5, P.na, P.nb, L)
+            redge = body[5 * nn * L:5 * nn * (2 * L + 1)].reshape(5, P.na, P.nb, L + 1)
+            trc = body[5 * nn * (2 * L + 1):].reshape(2, P.na, P.nb, L)
+            assert np.array_equal(node[:, 1:-1, 1:-1], wn[:, 1:-1, 1:-1])
+            assert np.array_equal(redge[[0, 1, 3]][:, 1:-1, 1:-1], we[[0, 1, 3]][:, 1:-1, 1:-1])
+            assert np.array_equal(trc[:, 1:-1, 1:-1], wt[:, 1:-1, 1:-1])
+            for a in (node, redge, trc):       # halo ring
+                assert not a[:, 0].any() and not a[:, -1].any() and not a[:, :, 0].any() and not a[:, :, -1].any()
+        for P, img in zip(g.patches, images):
+            e.unpack_active_state(P.index, 3, img)
+        got_s, got_t = e.download_state(3), e.download_tracers(3)
+        for (an, ae), (bn, be) in zip(got_s, want_s):
+            assert np.array_equal(an[:, 1:-1, 1:-1], bn[:, 1:-1, 1:-1]) and np.array_equal(ae[[0, 1, 3]][:, 1:-1, 1:-1], be[[0, 1, 3]][:, 1:-1, 1:-1])
+        assert all(np.array_equal(a[:, 1:-1, 1:-1], b[:, 1:-1, 1:-1]) for a, b in zip(got_t, want_t))
+        # continue from the image: a second engine that only ever saw the image
+        e2 = Engine(g)
+        try:
+            for P, img in zip(g.patches, images):
+                e2.unpack_active_state(P.index, 0, img)
+            e.step_ars343(200.0); e2.step_ars343(200.0); e.sync(); e2.sync()
+            assert max(gu.prognostic_errors(e2.download_state(0), e.download_state(0))) == EXACT
+            assert max(gu.tracer_errors(e2.download_tracers(0), e.download_tracers(0))) == EXACT
+        finally:
+            e2.close()
+        with pytest.raises(TempestError, match="image is of patch"):
+            e.unpack_active_state(1, 0, images[0])
+        with pytest.raises(TempestError, match="bytes given"):
+            e.unpack_active_state(0, 0, images[0][:-8])
+    finally:
+        e.close()
+
+
 def test_graph_replay_is_bit_identical(monkeypatch):
     """TMX_GRAPH=1: ARS343 and Strang steps replayed from a captured hipGraph equal the plain launch sequence bit for bit."""
     from tempestmodel_amd.engine import Engine

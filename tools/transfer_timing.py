@@ -37,4 +37,20 @@ for name in ("tmx_upload_state", "tmx_download_state"):
     e.sync()
     dt = (time.perf_counter() - t0) / 3
     print("%s (C calls only): %.1f ms per instance, %.2f GB/s" % (name, dt * 1e3, nbytes / dt / 1e9))
+# the restart image: transposition on the device, one contiguous copy per patch (tmx_pack_active_state / tmx_unpack_active_state)
+imgs = [np.zeros(e.lib.tmx_active_state_bytes(e.h, p), dtype=np.uint8) for p in range(len(st))]
+VP = C.c_void_p
+for name in ("tmx_pack_active_state", "tmx_unpack_active_state"):
+    fn = getattr(e.lib, name)
+    def call():
+        for p, im in enumerate(imgs):
+            assert fn(e.h, p, 0, im.ctypes.data_as(VP), im.size) == 0
+    call(); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        call()
+    e.sync()
+    dt = (time.perf_counter() - t0) / 3
+    nb = sum(im.size for im in imgs)
+    print("%s (C calls only, pageable host memory): %.1f ms per instance, %.0f MB image, %.2f GB/s" % (name, dt * 1e3, nb / 1e6, nb / dt / 1e9))
 e.close()
