@@ -2777,6 +2777,9 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 			if (t <= L) {
 				nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
 				nN = load_node<MM>(p, mcol, xin, t + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 2, col, etal);
+#ifdef TMX_ABL_FAST_PRODUCER      // ablation builds: the block row is evaluated once, the ring is refilled with it every time
+				if (t == 0)
+#endif
 				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
 #pragma unroll
@@ -2829,7 +2832,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 				}
 				b[3] = qf[0]; b[4] = qf[64];
 				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask, &nuni);      // pivot 0 takes in row 5
-			} else {
+			} else
+#ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the barrier rhythm
+			if (m < 0)
+#endif
+			{
 				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
 				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
 				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
