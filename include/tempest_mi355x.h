@@ -365,7 +365,9 @@ enum {
 	TMX_INFO_LOCAL_ELEMENTS,
 	TMX_INFO_GHOST_COLUMNS,       /* remote copies received per exchange                */
 	TMX_INFO_HBM_BYTES,           /* device bytes allocated by the engine on this rank   */
-	TMX_INFO_METRIC_CLOSED_FORM   /* 1: 3-D metric evaluated in registers, 0: streamed  */
+	TMX_INFO_METRIC_CLOSED_FORM,  /* 1: 3-D metric evaluated in registers, 0: streamed  */
+	TMX_INFO_EARLY_TILES,         /* 64-column tiles launched before the exchange starts (0: stages are not split) */
+	TMX_INFO_LATE_TILES           /* tiles updated while the exchange is in flight      */
 };
 long long tmx_info(tmx_engine * e, int what);
 

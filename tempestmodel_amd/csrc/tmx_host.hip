@@ -2412,6 +2412,8 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_GHOST_COLUMNS: return e->nghost;
 		case TMX_INFO_HBM_BYTES: return (long long)e->hbm_bytes;
 		case TMX_INFO_METRIC_CLOSED_FORM: return e->metric_closed ? 1 : 0;
+		case TMX_INFO_EARLY_TILES: return e->split_stage ? e->n_quads_early : 0;
+		case TMX_INFO_LATE_TILES: return e->split_stage ? e->n_quads_late : 0;
 	}
 	return -1;
 }

@@ -11,6 +11,7 @@ from tempestmodel_amd.engine import Engine
 
 grid = CubedSphereGrid(30, 30, 30000.0, ppd=2)
 states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
+shares = {}
 RANKS = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]      # e.g. `rank_share_timing.py 8` under rocprofv3
 for n in RANKS:
     e = Engine(grid, rank=0, n_ranks=n)
@@ -30,4 +31,14 @@ for n in RANKS:
     prof = e.profile()
     print("ranks %d: rank-0 share %d patches, %.3f ms/step without the wire" % (n, len(e.local_patches), 1e3 * wall),
           {k: round(v[0] / 10, 3) for k, v in prof.items() if v[1]})
+    shares[n] = 1e3 * wall
     e.close()
+# Critical-path estimate of an N-rank step: the per-rank compute share measured above + the part of the six exchanges per
+# ARS343 step that the boundary-first launch order does not hide.  The wire itself cannot be measured on a one-GPU box; the
+# estimate takes T_X microseconds of exposed latency per exchange (RCCL grouped send/recv of 0.1-0.9 MB to <= 4 peers over
+# xGMI) for two values of T_X.
+if 1 in shares:
+    for tx in (10.0, 30.0):
+        print("exposed exchange latency %2.0f us x 6 per step:" % tx,
+              "  ".join("N=%d %.3f ms -> speed-up %.2f" % (n, shares[n] + (6 * tx * 1e-3 if n > 1 else 0.0),
+                                                          shares[1] / (shares[n] + (6 * tx * 1e-3 if n > 1 else 0.0))) for n in sorted(shares)))
