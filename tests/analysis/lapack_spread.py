@@ -7,7 +7,7 @@ initial state; the max-norm relative difference per variable (U V rho*theta W rh
 spread two *valid builds of the reference itself* show, which is the floor of any meaningful tolerance.
 
 Writes tests/golden/lapack_spread.json (end-state checksums of both binaries + the spread + the C oracle's distance
-to both), which tests/test_oracle_vs_reference.py::test_w_gate_tolerance_follows_reference_spread and
+to both, the oracle running on the reference's own geometry and operators: `--geom 1`), which tests/test_oracle_vs_reference.py::test_w_gate_tolerance_follows_reference_spread and
 tests/test_gpu_parity.py read to set the W tolerance.
 
 usage: python tests/analysis/lapack_spread.py [--cases ne4,ne15]
@@ -28,10 +28,10 @@ from oracle_lib import Oracle  # noqa: E402
 CASES = {"ne4_L10_dt200": (4, 10, 200.0), "ne15_L30_dt300": (15, 30, 300.0)}
 
 
-def run(binary, ne, L, dt, out):
+def run(binary, ne, L, dt, out, geom="0"):
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     txt = subprocess.run([os.path.join(R, "oracle", "_ref", binary), "--mode", "steps", "--ne", str(ne), "--levels", str(L),
-                          "--dt", str(dt), "--warm", "2", "--steps", "100", "--every", "100", "--geom", "0", "--out", out],
+                          "--dt", str(dt), "--warm", "2", "--steps", "100", "--every", "100", "--geom", geom, "--out", out],
                          env=env, check=True, stdout=subprocess.PIPE, universal_newlines=True).stdout
     sums = {}
     for line in txt.splitlines():
@@ -40,7 +40,8 @@ def run(binary, ne, L, dt, out):
             sums[f[1]] = [float(v) for v in f[2:]]
     rd = tmxd.read(out)
     os.remove(out)
-    return gu.full_states(rd, "warm", 6), gu.full_states(rd, "step100", 6), sums
+    grid = gu.grid_from_fixture(rd, override=True)[0] if geom == "1" else None      # the reference's own geometry
+    return gu.full_states(rd, "warm", 6), gu.full_states(rd, "step100", 6), sums, grid
 
 
 def digest(states):
@@ -58,12 +59,11 @@ def main():
     for name, (ne, L, dt) in CASES.items():
         if name.split("_")[0] not in which:
             continue
-        w1, e1, s1 = run("tmx_ref_dump", ne, L, dt, "/tmp/spread_a.tmxd")
-        w2, e2, s2 = run("tmx_ref_dump_lapack2", ne, L, dt, "/tmp/spread_b.tmxd")
+        w1, e1, s1, g = run("tmx_ref_dump", ne, L, dt, "/tmp/spread_a.tmxd", geom="1")
+        w2, e2, s2, _ = run("tmx_ref_dump_lapack2", ne, L, dt, "/tmp/spread_b.tmxd")
         assert digest(w1) != "" and len(w1) == len(w2)
         warm_diff = gu.prognostic_errors(w2, w1)
         spread = gu.prognostic_errors(e2, e1)
-        g, _ = gu.make_grid(ne, L, 6)
         o = Oracle(g); o.set_state(0, w1)
         for _ in range(100):
             assert o.step_ars343(dt) == 0

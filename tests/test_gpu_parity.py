@@ -644,17 +644,59 @@ def test_hundred_steps_ne15_L30():
         e.close()
 
 
+def test_bench_workload_vs_live_reference():
+    """The workload bench.py times (BASELINE config 3's grid: ne30 np4 L30, 24 patches, dt 150 s) at its FULL size against
+    the real reference run live on the GPU box's host: the reference hands over its own geometry, operators, halo
+    transforms and its state after 2 steps; three ARS343 steps later the device state equals the reference's bit for bit.
+    Needs oracle/_ref (built in the build container; it travels with the snapshot)."""
+    import os, subprocess, tempfile
+    import tmxd
+    from tempestmodel_amd.engine import Engine
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    ne, L, dt, npatch = 30, 30, 150.0, 24
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ref.tmxd")
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        subprocess.run([ref_bin, "--mode", "steps", "--ne", str(ne), "--levels", str(L), "--dt", str(dt), "--patches", str(npatch),
+                        "--warm", "2", "--steps", "3", "--every", "3", "--geom", "1", "--out", out], env=env, check=True,
+                       stdout=subprocess.DEVNULL, timeout=1500)
+        rd = tmxd.read(out)
+    g, _ = gu.grid_from_fixture(rd, override=True)
+    assert len(g.patches) == npatch
+    start = gu.full_states(rd, "warm", npatch)
+    ref_end = gu.full_states(rd, "step3", npatch)
+    del rd
+    e = Engine(g)
+    try:
+        e.upload_state(0, start)
+        for _ in range(3):
+            e.step_ars343(dt)
+        e.sync()
+        errs = gu.prognostic_errors(e.download_state(0), ref_end)
+        print("ne30 L30 24 patches, 3 steps vs the live reference:", errs)
+        assert max(errs) == 0.0, errs
+    finally:
+        e.close()
+
+
 def test_fused_column_kernels_are_bit_identical_to_split_kernels():
-    """k_vi_fused (one wavefront per 64 columns), k_vi_pair (assembly and elimination in two wavefronts; what small
-    per-GPU grids run) and k_vi_assemble + k_vi_solve (TMX_VI_MODE=split) perform the same arithmetic:
-    results are bit-identical."""
+    """k_vi_fused (one wavefront per 64 columns), k_vi_pair (assembly and elimination in two wavefronts), k_vi_group (one
+    column per 16-lane group; what small per-GPU grids run) and k_vi_assemble + k_vi_solve (TMX_VI_MODE=split) perform the
+    same arithmetic: results are bit-identical.  The pair kernel also with two pairs per workgroup on an ODD number of
+    column groups (60 columns per wavefront -> 17 groups: the last workgroup's second pair has no columns of its own and must
+    still keep the barrier rhythm) and with ragged last groups."""
     import os
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps_ne4_L6_p24.npz")
     g, _ = gu.make_grid(4, 6, 24)
     start = gu.expand_compact(d, "step2", g)
     out = []
-    for env in ({"TMX_VI_PAIR": "0"}, {"TMX_VI_PAIR": "1"}, {"TMX_VI_MODE": "split"}, {"TMX_VI_PAIR": "0", "TMX_VI_SPARSE": "0"}):
+    for env in ({"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1"}, {"TMX_VI_GROUP": "1"},
+                {"TMX_VI_MODE": "split"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0", "TMX_VI_SPARSE": "0"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_CPW": "37"}):
         os.environ.update(env)
         try:
             e = Engine(g)
