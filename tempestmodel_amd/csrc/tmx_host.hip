@@ -469,19 +469,23 @@ extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const dou
 	PatchInfo & P = e->patches[patch];
 	REQUIRE(P.owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not owned by rank %d", patch, e->cfg.rank);
 	const size_t NS = e->NS;
-	std::vector<double> lat((size_t)P.nea * P.neb * TMX_NQ), ps(lat.size());
+	std::vector<double> lat((size_t)P.nea * P.neb * TMX_NQ), ps(lat.size()), sl(lat.size()), cl(lat.size());
 	const int c0 = P.elem_base * TMX_NQ;
 	for (int i = 1; i < P.na - 1; i++)
 	for (int j = 1; j < P.nb - 1; j++) {
 		const int c = col_of(P, i, j);
 		lat[c - c0] = latitude[(size_t)i * P.nb + j];
 		ps[c - c0] = surface_pressure ? surface_pressure[(size_t)i * P.nb + j] : 0.0;
-		if (!e->finalized) { e->h_g2d[G2_LAT * NS + c] = lat[c - c0]; e->h_g2d[G2_PS * NS + c] = ps[c - c0]; }
+		sl[c - c0] = sin(lat[c - c0]); cl[c - c0] = cos(lat[c - c0]);      // host libm: the values the reference computes per call
+		if (!e->finalized) { e->h_g2d[G2_LAT * NS + c] = lat[c - c0]; e->h_g2d[G2_PS * NS + c] = ps[c - c0];
+			e->h_g2d[G2_SINLAT * NS + c] = sl[c - c0]; e->h_g2d[G2_COSLAT * NS + c] = cl[c - c0]; }
 	}
 	if (e->finalized && !plan_only(e)) {       // may be refreshed at any time (the caller owns the source arrays)
 		HIPCHK(hipStreamSynchronize(e->stream));
 		HIPCHK(hipMemcpy(e->d_g2d + G2_LAT * NS + c0, lat.data(), lat.size() * sizeof(double), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(e->d_g2d + G2_PS * NS + c0, ps.data(), ps.size() * sizeof(double), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(e->d_g2d + G2_SINLAT * NS + c0, sl.data(), sl.size() * sizeof(double), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(e->d_g2d + G2_COSLAT * NS + c0, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
 	}
 	if (!P.physics_set) e->patches_with_physics++;
 	P.physics_set = true;

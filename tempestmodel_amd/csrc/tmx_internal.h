@@ -25,6 +25,7 @@
 // 2-D (per column) geometry slabs
 enum { G2_J2D = 0, G2_F, G2_C2A0, G2_C2A1, G2_C2B1, G2_JN, G2_JE, G2_DRX, G2_ZS,
 	G2_LAT, G2_PS,      // column physics inputs (tmx_set_patch_physics_inputs): latitude, Held-Suarez surface pressure
+	G2_SINLAT, G2_COSLAT,   // sin / cos of the latitude, evaluated ON THE HOST with the libm the reference calls (HeldSuarezPhysics.cpp:186-200)
 	// factors of the closed-form 3-D metric (tmx_set_patch_metric_factors): -s/d_xi R, 1+Y^2, XY, 1+X^2,
 	// d_alpha zs, d_beta zs, 1/d_xi R, 1/(d_xi R)^2
 	G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2,

@@ -514,6 +514,9 @@ __device__ __forceinline__ double dss_combine(double w0, double w1, double w2, d
 	return (1.0 / 3.0) * ((me + (ty ? pv : nx)) + (ty ? nx : pv));
 }
 
+#ifndef TMX_DSS_LPT
+#define TMX_DSS_LPT 1      // slab-levels per thread of k_dss
+#endif
 __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
 	const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int nt, int g0)
@@ -522,10 +525,10 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int bx, by;
-	if (!xcd_tile((ngroups - g0 + 63) / 64, (L + 1 + 3) / 4, bx, by)) return;
+	if (!xcd_tile((ngroups - g0 + 63) / 64, (L + 1 + 4 * TMX_DSS_LPT - 1) / (4 * TMX_DSS_LPT), bx, by)) return;
 	const int g = g0 + bx * 64 + threadIdx.x;
-	const int kk = by * 4 + WAVE_UNIFORM(threadIdx.y);
-	if (g >= ngroups || kk > L) return;
+	const int kk0 = (by * 4 + WAVE_UNIFORM(threadIdx.y)) * TMX_DSS_LPT;
+	if (g >= ngroups || kk0 > L) return;
 	const int n = gn[g];
 	const int4 c4 = *(const int4 *)(gcols + g * 4);
 	const int c[4] = { c4.x, c4.y, c4.z, c4.w };
@@ -540,6 +543,10 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 		else if (loc[m]) { ptr[m] = x + c[m]; str[m] = NS; }
 		else { ptr[m] = ghost + gbase[c[m] - (int)NS]; str[m] = (size_t)gstride[c[m] - (int)NS]; }
 	}
+#pragma unroll
+	for (int rep = 0; rep < TMX_DSS_LPT; rep++) {
+	const int kk = kk0 + rep;
+	if (kk > L) break;
 	const bool lev = (kk < L);
 	int slabs[5];
 	slabs[0] = TMX_SLAB_W(L, kk);
@@ -595,11 +602,12 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 		}
 	}
 #undef DSS_SCALAR
+	}
 }
 
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1) {
 	if (g1 <= g0) return;
-	const int nx = (g1 - g0 + 63) / 64, ny = (p.L + 1 + 3) / 4;
+	const int nx = (g1 - g0 + 63) / 64, ny = (p.L + 1 + 4 * TMX_DSS_LPT - 1) / (4 * TMX_DSS_LPT);
 	dim3 blk(64, 4), grd(8 * ((nx + 7) / 8) * ny);
 	hipLaunchKernelGGL(k_dss, grd, blk, 0, e->stream, p, x, (const double *)e->d_ghost, (const int *)e->d_ghost_base,
 		(const int *)e->d_ghost_stride, g1,
@@ -1255,7 +1263,6 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	const unsigned cb = (unsigned)col * 8u;
 	const double bsig = 0.7, kf = 1.0 / 86400.0, ka = (1.0 / 40.0) / 86400.0, ks = (1.0 / 4.0) / 86400.0;
 	const double dty = 60.0, dthz = 10.0, tmin = 200.0, tmax = 315.0;
-	const double lat = ldu(p.g2d + G2_LAT * NS, cb);
 	const double ps = surf ? pscal * tmx_ref_exp(tmx_ref_log(ldu(surf, cb) * ldu(surf + NS, cb)) * gamma) : ldu(p.g2d + G2_PS * NS, cb);
 	const double rho = ldu(x + TMX_SLAB_R(L, k) * NS, cb), rt = ldu(x + TMX_SLAB_T(L, k) * NS, cb);
 	{
@@ -1272,11 +1279,11 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	double bs = (sigma - bsig) / (1.0 - bsig);
 	if (bs < 0.0) bs = 0.0;
 	const double T = pr / (rho * p.Rd);
-	const double sl = sin(lat), cl = cos(lat);
+	const double sl = ldu(p.g2d + G2_SINLAT * NS, cb), cl = ldu(p.g2d + G2_COSLAT * NS, cb);      // host libm values
 	const double c4 = cl * cl * cl * cl;
 	const double kt = ka + (ks - ka) * bs * c4;
 	double teq = tmax - dty * sl * sl - dthz * tmx_ref_log(pr / p.p0) * cl * cl;
-	teq *= pow(pr / p.p0, kappa);
+	teq *= tmx_ref_pow(pr / p.p0, kappa);      // glibc's pow, bit for bit (tmx_refmath.h)
 	if (teq < tmin) teq = tmin;
 	const double ddh = -kt / gamma * (1.0 + (gamma - 1.0) * teq / T);
 	const double dh = -kt / gamma * (1.0 - teq / T);
@@ -1308,7 +1315,7 @@ __device__ __forceinline__ double kes_amin1(double a, double b, double c) {
 	return (double)((m < z) ? m : z);
 }
 __device__ __forceinline__ float kes_velqr(double qr, float r, float rhalf) {
-	return (float)(36.34 * pow(qr * (double)r, (double)0.1364f) * (double)rhalf);      // kessler.f90:113, :170
+	return (float)(36.34 * tmx_ref_pow(qr * (double)r, (double)0.1364f) * (double)rhalf);      // kessler.f90:113, :170
 }
 
 enum { KES_TH = 0, KES_QV, KES_QC, KES_QR, KES_PK, KES_RHOD, KES_PC, KES_VEL, KES_NF };
@@ -1342,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_kessler(KParams p, double * __restrict_
 		if (k == 0) rhod0 = rhod;
 		const float r = (float)(0.001 * rhod);
 		const float rhalf = (float)sqrt(rhod0 / rhod);
-		const float pc = (float)(3.8 / (pow(pk, inv_xk) * psl));
+		const float pc = (float)(3.8 / (tmx_ref_pow(pk, inv_xk) * psl));
 		const float vel = kes_velqr(qr, r, rhalf);
 		const double z = zlev[(size_t)k * NS + col];
 		if (k > 0 && vel_prev != 0.0f) { const double c = 0.8 * (z - z_prev) / (double)vel_prev; dt_max = (dt_max < c) ? dt_max : c; }
@@ -1372,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_kessler(KParams p, double * __restrict_
 			double th = WK(KES_TH, k), qv = WK(KES_QV, k), qc = WK(KES_QC, k), qr = qr_k;
 			const double pk = WK(KES_PK, k), pc = WK(KES_PC, k);
 			// :147-165
-			const double qrprod = qc - (qc - dt0 * kes_amax1((double)0.001f * (qc - .001), 0.0)) / (1.0 + dt0 * 2.2 * pow(qr, (double)0.875f));
+			const double qrprod = qc - (qc - dt0 * kes_amax1((double)0.001f * (qc - .001), 0.0)) / (1.0 + dt0 * 2.2 * tmx_ref_pow(qr, (double)0.875f));
 			qc = kes_amax1(qc - qrprod, 0.0);
 			qr = kes_amax1(qr + qrprod + (double)sed, 0.0);
 			const double pt = pk * th;
@@ -1381,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_kessler(KParams p, double * __restrict_
 			const double prod = (qv - qvs) / (1.0 + qvs * f5 / (pt36 * pt36));
 			const double rq = (double)r_k * qr;
 			const double dimv = (qvs - qv > 0.0) ? qvs - qv : 0.0;
-			const double ern = kes_amin1(dt0 * (((1.6 + 124.9 * pow(rq, (double)0.2046f)) * pow(rq, (double)0.525f))
+			const double ern = kes_amin1(dt0 * (((1.6 + 124.9 * tmx_ref_pow(rq, (double)0.2046f)) * tmx_ref_pow(rq, (double)0.525f))
 					/ (2550000.0 * pc / (3.8 * qvs) + 540000.0)) * (dimv / ((double)r_k * qvs)),
 				kes_amax1(-prod - qc, 0.0), qr);
 			const double mx = (prod > -qc) ? prod : -qc;

@@ -252,4 +252,196 @@ TMX_RM_FN double tmx_ref_log(double x) {
 	return TMX_RM_FMA(r3, p, TMX_RM_FMA(r2, A0, lo)) + hi;
 }
 
+
+/* ---- pow(x, y): glibc 2.35 sysdeps/ieee754/dbl-64/e_pow.c (same origin), FMA build (multiarch/e_pow-fma.c), main path:
+ * x positive and normal, 2^-65 <= |y| < 2^63, result neither tiny nor huge; anything else goes to the platform's pow.
+ * log(x) is formed as hi + tail (about 68 bits) from __pow_log_data, multiplied by y in double-double, and handed to the exp
+ * kernel above with the tail added to the reduced argument.  Operation order read from __pow_fma of the libm of this image
+ * (llvm-objdump), table by tools/extract_pow_tables.py; verified bit for bit by tests/native/refmath_check.c. */
+TMX_RM_TAB double tmx_rm_powlog_tab[384] = {      /* invc, logc, logctail of __pow_log_data (128 subintervals) */
+	0x1.6a00000000000p+0, -0x1.62c82f2b9c800p-2, 0x1.ab42428375680p-48,
+	0x1.6800000000000p+0, -0x1.5d1bdbf580800p-2, -0x1.ca508d8e0f720p-46,
+	0x1.6600000000000p+0, -0x1.5767717455800p-2, -0x1.362a4d5b6506dp-45,
+	0x1.6400000000000p+0, -0x1.51aad872df800p-2, -0x1.684e49eb067d5p-49,
+	0x1.6200000000000p+0, -0x1.4be5f95777800p-2, -0x1.41b6993293ee0p-47,
+	0x1.6000000000000p+0, -0x1.4618bc21c6000p-2, 0x1.3d82f484c84ccp-46,
+	0x1.5e00000000000p+0, -0x1.404308686a800p-2, 0x1.c42f3ed820b3ap-50,
+	0x1.5c00000000000p+0, -0x1.3a64c55694800p-2, 0x1.0b1c686519460p-45,
+	0x1.5a00000000000p+0, -0x1.347dd9a988000p-2, 0x1.5594dd4c58092p-45,
+	0x1.5800000000000p+0, -0x1.2e8e2bae12000p-2, 0x1.67b1e99b72bd8p-45,
+	0x1.5600000000000p+0, -0x1.2895a13de8800p-2, 0x1.5ca14b6cfb03fp-46,
+	0x1.5600000000000p+0, -0x1.2895a13de8800p-2, 0x1.5ca14b6cfb03fp-46,
+	0x1.5400000000000p+0, -0x1.22941fbcf7800p-2, -0x1.65a242853da76p-46,
+	0x1.5200000000000p+0, -0x1.1c898c1699800p-2, -0x1.fafbc68e75404p-46,
+	0x1.5000000000000p+0, -0x1.1675cababa800p-2, 0x1.f1fc63382a8f0p-46,
+	0x1.4e00000000000p+0, -0x1.1058bf9ae4800p-2, -0x1.6a8c4fd055a66p-45,
+	0x1.4c00000000000p+0, -0x1.0a324e2739000p-2, -0x1.c6bee7ef4030ep-47,
+	0x1.4a00000000000p+0, -0x1.0402594b4d000p-2, -0x1.036b89ef42d7fp-48,
+	0x1.4a00000000000p+0, -0x1.0402594b4d000p-2, -0x1.036b89ef42d7fp-48,
+	0x1.4800000000000p+0, -0x1.fb9186d5e4000p-3, 0x1.d572aab993c87p-47,
+	0x1.4600000000000p+0, -0x1.ef0adcbdc6000p-3, 0x1.b26b79c86af24p-45,
+	0x1.4400000000000p+0, -0x1.e27076e2af000p-3, -0x1.72f4f543fff10p-46,
+	0x1.4200000000000p+0, -0x1.d5c216b4fc000p-3, 0x1.1ba91bbca681bp-45,
+	0x1.4000000000000p+0, -0x1.c8ff7c79aa000p-3, 0x1.7794f689f8434p-45,
+	0x1.4000000000000p+0, -0x1.c8ff7c79aa000p-3, 0x1.7794f689f8434p-45,
+	0x1.3e00000000000p+0, -0x1.bc286742d9000p-3, 0x1.94eb0318bb78fp-46,
+	0x1.3c00000000000p+0, -0x1.af3c94e80c000p-3, 0x1.a4e633fcd9066p-52,
+	0x1.3a00000000000p+0, -0x1.a23bc1fe2b000p-3, -0x1.58c64dc46c1eap-45,
+	0x1.3a00000000000p+0, -0x1.a23bc1fe2b000p-3, -0x1.58c64dc46c1eap-45,
+	0x1.3800000000000p+0, -0x1.9525a9cf45000p-3, -0x1.ad1d904c1d4e3p-45,
+	0x1.3600000000000p+0, -0x1.87fa06520d000p-3, 0x1.bbdbf7fdbfa09p-45,
+	0x1.3400000000000p+0, -0x1.7ab890210e000p-3, 0x1.bdb9072534a58p-45,
+	0x1.3400000000000p+0, -0x1.7ab890210e000p-3, 0x1.bdb9072534a58p-45,
+	0x1.3200000000000p+0, -0x1.6d60fe719d000p-3, -0x1.0e46aa3b2e266p-46,
+	0x1.3000000000000p+0, -0x1.5ff3070a79000p-3, -0x1.e9e439f105039p-46,
+	0x1.3000000000000p+0, -0x1.5ff3070a79000p-3, -0x1.e9e439f105039p-46,
+	0x1.2e00000000000p+0, -0x1.526e5e3a1b000p-3, -0x1.0de8b90075b8fp-45,
+	0x1.2c00000000000p+0, -0x1.44d2b6ccb8000p-3, 0x1.70cc16135783cp-46,
+	0x1.2c00000000000p+0, -0x1.44d2b6ccb8000p-3, 0x1.70cc16135783cp-46,
+	0x1.2a00000000000p+0, -0x1.371fc201e9000p-3, 0x1.178864d27543ap-48,
+	0x1.2800000000000p+0, -0x1.29552f81ff000p-3, -0x1.48d301771c408p-45,
+	0x1.2600000000000p+0, -0x1.1b72ad52f6000p-3, -0x1.e80a41811a396p-45,
+	0x1.2600000000000p+0, -0x1.1b72ad52f6000p-3, -0x1.e80a41811a396p-45,
+	0x1.2400000000000p+0, -0x1.0d77e7cd09000p-3, 0x1.a699688e85bf4p-47,
+	0x1.2400000000000p+0, -0x1.0d77e7cd09000p-3, 0x1.a699688e85bf4p-47,
+	0x1.2200000000000p+0, -0x1.fec9131dbe000p-4, -0x1.575545ca333f2p-45,
+	0x1.2000000000000p+0, -0x1.e27076e2b0000p-4, 0x1.a342c2af0003cp-45,
+	0x1.2000000000000p+0, -0x1.e27076e2b0000p-4, 0x1.a342c2af0003cp-45,
+	0x1.1e00000000000p+0, -0x1.c5e548f5bc000p-4, -0x1.d0c57585fbe06p-46,
+	0x1.1c00000000000p+0, -0x1.a926d3a4ae000p-4, 0x1.53935e85baac8p-45,
+	0x1.1c00000000000p+0, -0x1.a926d3a4ae000p-4, 0x1.53935e85baac8p-45,
+	0x1.1a00000000000p+0, -0x1.8c345d631a000p-4, 0x1.37c294d2f5668p-46,
+	0x1.1a00000000000p+0, -0x1.8c345d631a000p-4, 0x1.37c294d2f5668p-46,
+	0x1.1800000000000p+0, -0x1.6f0d28ae56000p-4, -0x1.69737c93373dap-45,
+	0x1.1600000000000p+0, -0x1.51b073f062000p-4, 0x1.f025b61c65e57p-46,
+	0x1.1600000000000p+0, -0x1.51b073f062000p-4, 0x1.f025b61c65e57p-46,
+	0x1.1400000000000p+0, -0x1.341d7961be000p-4, 0x1.c5edaccf913dfp-45,
+	0x1.1400000000000p+0, -0x1.341d7961be000p-4, 0x1.c5edaccf913dfp-45,
+	0x1.1200000000000p+0, -0x1.16536eea38000p-4, 0x1.47c5e768fa309p-46,
+	0x1.1000000000000p+0, -0x1.f0a30c0118000p-5, 0x1.d599e83368e91p-45,
+	0x1.1000000000000p+0, -0x1.f0a30c0118000p-5, 0x1.d599e83368e91p-45,
+	0x1.0e00000000000p+0, -0x1.b42dd71198000p-5, 0x1.c827ae5d6704cp-46,
+	0x1.0e00000000000p+0, -0x1.b42dd71198000p-5, 0x1.c827ae5d6704cp-46,
+	0x1.0c00000000000p+0, -0x1.77458f632c000p-5, -0x1.cfc4634f2a1eep-45,
+	0x1.0c00000000000p+0, -0x1.77458f632c000p-5, -0x1.cfc4634f2a1eep-45,
+	0x1.0a00000000000p+0, -0x1.39e87b9fec000p-5, 0x1.502b7f526feaap-48,
+	0x1.0a00000000000p+0, -0x1.39e87b9fec000p-5, 0x1.502b7f526feaap-48,
+	0x1.0800000000000p+0, -0x1.f829b0e780000p-6, -0x1.980267c7e09e4p-45,
+	0x1.0800000000000p+0, -0x1.f829b0e780000p-6, -0x1.980267c7e09e4p-45,
+	0x1.0600000000000p+0, -0x1.7b91b07d58000p-6, -0x1.88d5493faa639p-45,
+	0x1.0400000000000p+0, -0x1.fc0a8b0fc0000p-7, -0x1.f1e7cf6d3a69cp-50,
+	0x1.0400000000000p+0, -0x1.fc0a8b0fc0000p-7, -0x1.f1e7cf6d3a69cp-50,
+	0x1.0200000000000p+0, -0x1.fe02a6b100000p-8, -0x1.9e23f0dda40e4p-46,
+	0x1.0200000000000p+0, -0x1.fe02a6b100000p-8, -0x1.9e23f0dda40e4p-46,
+	0x1.0000000000000p+0, 0x0.0p+0, 0x0.0p+0,
+	0x1.0000000000000p+0, 0x0.0p+0, 0x0.0p+0,
+	0x1.fc00000000000p-1, 0x1.0101575890000p-7, -0x1.0c76b999d2be8p-46,
+	0x1.f800000000000p-1, 0x1.0205658938000p-6, -0x1.3dc5b06e2f7d2p-45,
+	0x1.f400000000000p-1, 0x1.8492528c90000p-6, -0x1.aa0ba325a0c34p-45,
+	0x1.f000000000000p-1, 0x1.0415d89e74000p-5, 0x1.111c05cf1d753p-47,
+	0x1.ec00000000000p-1, 0x1.466aed42e0000p-5, -0x1.c167375bdfd28p-45,
+	0x1.e800000000000p-1, 0x1.894aa149fc000p-5, -0x1.97995d05a267dp-46,
+	0x1.e400000000000p-1, 0x1.ccb73cdddc000p-5, -0x1.a68f247d82807p-46,
+	0x1.e200000000000p-1, 0x1.eea31c006c000p-5, -0x1.e113e4fc93b7bp-47,
+	0x1.de00000000000p-1, 0x1.1973bd1466000p-4, -0x1.5325d560d9e9bp-45,
+	0x1.da00000000000p-1, 0x1.3bdf5a7d1e000p-4, 0x1.cc85ea5db4ed7p-45,
+	0x1.d600000000000p-1, 0x1.5e95a4d97a000p-4, -0x1.c69063c5d1d1ep-45,
+	0x1.d400000000000p-1, 0x1.700d30aeac000p-4, 0x1.c1e8da99ded32p-49,
+	0x1.d000000000000p-1, 0x1.9335e5d594000p-4, 0x1.3115c3abd47dap-45,
+	0x1.cc00000000000p-1, 0x1.b6ac88dad6000p-4, -0x1.390802bf768e5p-46,
+	0x1.ca00000000000p-1, 0x1.c885801bc4000p-4, 0x1.646d1c65aacd3p-45,
+	0x1.c600000000000p-1, 0x1.ec739830a2000p-4, -0x1.dc068afe645e0p-45,
+	0x1.c400000000000p-1, 0x1.fe89139dbe000p-4, -0x1.534d64fa10afdp-45,
+	0x1.c000000000000p-1, 0x1.1178e8227e000p-3, 0x1.1ef78ce2d07f2p-45,
+	0x1.be00000000000p-1, 0x1.1aa2b7e23f000p-3, 0x1.ca78e44389934p-45,
+	0x1.ba00000000000p-1, 0x1.2d1610c868000p-3, 0x1.39d6ccb81b4a1p-47,
+	0x1.b800000000000p-1, 0x1.365fcb0159000p-3, 0x1.62fa8234b7289p-51,
+	0x1.b400000000000p-1, 0x1.4913d8333b000p-3, 0x1.5837954fdb678p-45,
+	0x1.b200000000000p-1, 0x1.527e5e4a1b000p-3, 0x1.633e8e5697dc7p-45,
+	0x1.ae00000000000p-1, 0x1.6574ebe8c1000p-3, 0x1.9cf8b2c3c2e78p-46,
+	0x1.ac00000000000p-1, 0x1.6f0128b757000p-3, -0x1.5118de59c21e1p-45,
+	0x1.aa00000000000p-1, 0x1.7898d85445000p-3, -0x1.c661070914305p-46,
+	0x1.a600000000000p-1, 0x1.8beafeb390000p-3, -0x1.73d54aae92cd1p-47,
+	0x1.a400000000000p-1, 0x1.95a5adcf70000p-3, 0x1.7f22858a0ff6fp-47,
+	0x1.a000000000000p-1, 0x1.a93ed3c8ae000p-3, -0x1.8724350562169p-45,
+	0x1.9e00000000000p-1, 0x1.b31d8575bd000p-3, -0x1.c358d4eace1aap-47,
+	0x1.9c00000000000p-1, 0x1.bd087383be000p-3, -0x1.d4bc4595412b6p-45,
+	0x1.9a00000000000p-1, 0x1.c6ffbc6f01000p-3, -0x1.1ec72c5962bd2p-48,
+	0x1.9600000000000p-1, 0x1.db13db0d49000p-3, -0x1.aff2af715b035p-45,
+	0x1.9400000000000p-1, 0x1.e530effe71000p-3, 0x1.212276041f430p-51,
+	0x1.9200000000000p-1, 0x1.ef5ade4dd0000p-3, -0x1.a211565bb8e11p-51,
+	0x1.9000000000000p-1, 0x1.f991c6cb3b000p-3, 0x1.bcbecca0cdf30p-46,
+	0x1.8c00000000000p-1, 0x1.07138604d5800p-2, 0x1.89cdb16ed4e91p-48,
+	0x1.8a00000000000p-1, 0x1.0c42d67616000p-2, 0x1.7188b163ceae9p-45,
+	0x1.8800000000000p-1, 0x1.1178e8227e800p-2, -0x1.c210e63a5f01cp-45,
+	0x1.8600000000000p-1, 0x1.16b5ccbacf800p-2, 0x1.b9acdf7a51681p-45,
+	0x1.8400000000000p-1, 0x1.1bf99635a6800p-2, 0x1.ca6ed5147bdb7p-45,
+	0x1.8200000000000p-1, 0x1.214456d0eb800p-2, 0x1.a87deba46baeap-47,
+	0x1.7e00000000000p-1, 0x1.2bef07cdc9000p-2, 0x1.a9cfa4a5004f4p-45,
+	0x1.7c00000000000p-1, 0x1.314f1e1d36000p-2, -0x1.8e27ad3213cb8p-45,
+	0x1.7a00000000000p-1, 0x1.36b6776be1000p-2, 0x1.16ecdb0f177c8p-46,
+	0x1.7800000000000p-1, 0x1.3c25277333000p-2, 0x1.83b54b606bd5cp-46,
+	0x1.7600000000000p-1, 0x1.419b423d5e800p-2, 0x1.8e436ec90e09dp-47,
+	0x1.7400000000000p-1, 0x1.4718dc271c800p-2, -0x1.f27ce0967d675p-45,
+	0x1.7200000000000p-1, 0x1.4c9e09e173000p-2, -0x1.e20891b0ad8a4p-45,
+	0x1.7000000000000p-1, 0x1.522ae0738a000p-2, 0x1.ebe708164c759p-45,
+	0x1.6e00000000000p-1, 0x1.57bf753c8d000p-2, 0x1.fadedee5d40efp-46,
+	0x1.6c00000000000p-1, 0x1.5d5bddf596000p-2, -0x1.a0b2a08a465dcp-47,
+};
+
+TMX_RM_FN double tmx_ref_pow(double x, double y) {
+	const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+	const double A0 = -0x1.0000000000000p-1, A1 = -0x1.5555555555560p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
+		A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p+0, A6 = 0x1.0002b8b263fc3p+0;
+	const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8000000000000p+52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+	const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+	const unsigned long long ix = tmx_rm_bits(x), iy = tmx_rm_bits(y);
+	const unsigned topx = (unsigned)(ix >> 52), topy = (unsigned)(iy >> 52) & 0x7ffu;
+	if (topx - 1u > 0x7fdu || topy - 0x3beu > 0x7fu) return pow(x, y);
+	/* log_inline */
+	const unsigned long long tmp = ix - 0x3fe6955500000000ull;
+	const unsigned i = (unsigned)(tmp >> 45) & 127u;
+	const int k = (int)((long long)tmp >> 52);
+	const double z = tmx_rm_dbl(ix - (tmp & 0xfff0000000000000ull));
+	const double kd = (double)k;
+	const double invc = tmx_rm_powlog_tab[3 * i], logc = tmx_rm_powlog_tab[3 * i + 1], logctail = tmx_rm_powlog_tab[3 * i + 2];
+	const double r = TMX_RM_FMA(z, invc, -1.0);
+	const double t1 = TMX_RM_FMA(kd, Ln2hi, logc);
+	const double t2 = t1 + r;
+	const double lo1 = TMX_RM_FMA(kd, Ln2lo, logctail);
+	const double lo2 = (t1 - t2) + r;
+	const double ar = A0 * r;
+	const double ar2 = r * ar;
+	const double ar3 = r * ar2;
+	const double hi = t2 + ar2;
+	const double lo3 = TMX_RM_FMA(ar, r, -ar2);
+	const double lo4 = (t2 - hi) + ar2;
+	const double q = TMX_RM_FMA(ar2, TMX_RM_FMA(TMX_RM_FMA(r, A6, A5), ar2, TMX_RM_FMA(r, A4, A3)), TMX_RM_FMA(r, A2, A1));
+	const double lo = TMX_RM_FMA(ar3, q, ((lo1 + lo2) + lo3) + lo4);
+	const double lhi = hi + lo;
+	const double llo = (hi - lhi) + lo;
+	/* y * log(x) in double-double */
+	const double ehi = y * lhi;
+	const double elo = TMX_RM_FMA(y, llo, TMX_RM_FMA(lhi, y, -ehi));
+	/* exp_inline(ehi, elo), sign_bias 0 */
+	const unsigned abstop = (unsigned)(tmx_rm_bits(ehi) >> 52) & 0x7ffu;
+	if (abstop - 0x3c9u >= 0x3fu) return pow(x, y);      /* |y log x| < 2^-54 or >= 512: not on this path */
+	double kk = TMX_RM_FMA(ehi, InvLn2N, Shift);
+	const unsigned long long ki = tmx_rm_bits(kk);
+	kk -= Shift;
+	double rr = TMX_RM_FMA(kk, NegLn2hiN, ehi);
+	rr = TMX_RM_FMA(kk, NegLn2loN, rr);
+	rr += elo;
+	const unsigned idx = 2u * (unsigned)(ki & 127u);
+	const double tail = tmx_rm_dbl(tmx_rm_exp_tab[idx]);
+	const unsigned long long sbits = tmx_rm_exp_tab[idx + 1] + (ki << 45);
+	const double r2 = rr * rr;
+	const double p23 = TMX_RM_FMA(rr, C3, C2);
+	const double p45 = TMX_RM_FMA(rr, C5, C4);
+	double e = TMX_RM_FMA(p23, r2, tail + rr);
+	e = TMX_RM_FMA(p45, r2 * r2, e);
+	const double scale = tmx_rm_dbl(sbits);
+	return TMX_RM_FMA(e, scale, scale);
+}
+
 #endif /* TMX_REFMATH_H */

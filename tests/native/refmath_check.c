@@ -23,6 +23,16 @@ int main(int argc,char**argv){
 		else y = 1e5*rnd();
 		if(tmx_ref_log(y)!=log(y)){ if(bad_l<5) printf("log mismatch %a: %a vs %a\n",y,tmx_ref_log(y),log(y)); bad_l++; }
 	}
-	printf("n=%ld exp mismatches %ld log mismatches %ld\n",n,bad_e,bad_l);
-	return (bad_e||bad_l)?1:0;
+	long bad_p=0;
+	for(long i=0;i<n;i++){
+		double x,y;
+		int m=i%4;
+		if(m==0){ x = 1e-3 + 1.2*rnd(); y = 0.2857142857142857 + 1e-3*(rnd()-0.5); }   /* (p/p0)^kappa of the Held-Suarez forcing */
+		else if(m==1){ x = ldexp(0.5+rnd(), (int)(200*rnd())-100); y = 8.0*(rnd()-0.5); }
+		else if(m==2){ x = 1e-8 + 50.0*rnd(); y = (rnd()<0.5)?0.875:((rnd()<0.5)?0.2046:0.525); }   /* Kessler's exponents */
+		else { x = 0.9 + 0.2*rnd(); y = 2000.0*(rnd()-0.5); }
+		if(tmx_ref_pow(x,y)!=pow(x,y)){ if(bad_p<5) printf("pow mismatch %a %a: %a vs %a\n",x,y,tmx_ref_pow(x,y),pow(x,y)); bad_p++; }
+	}
+	printf("n=%ld exp mismatches %ld log mismatches %ld pow mismatches %ld\n",n,bad_e,bad_l,bad_p);
+	return (bad_e||bad_l||bad_p)?1:0;
 }
