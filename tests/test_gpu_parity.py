@@ -681,6 +681,61 @@ def test_bench_workload_vs_live_reference():
         e.close()
 
 
+LIVE_CASES = [
+    # name, dump-driver arguments, synthesiser case, tracers, engine options, stepper, dt, steps
+    ("jw_tracers_p24", ["--ne", "8", "--levels", "12", "--tracers", "2"], "jw", 2, {}, "ars343", 200.0, 3),
+    ("jw_ark232_oddL_p24", ["--ne", "6", "--levels", "9", "--scheme", "ark232", "--tracers", "1"], "jw", 1, {}, "ark232", 200.0, 3),
+    ("jw_ars443_p24", ["--ne", "10", "--levels", "16", "--scheme", "ars443"], "jw", 0, {}, "ars443", 150.0, 2),
+    ("jw_ars232_visc2_p24", ["--ne", "6", "--levels", "10", "--scheme", "ars232", "--hypervis", "2"], "jw", 0,
+     {"nu": (2.0e5, 2.0e5, 2.0e5), "hypervis_order": 2}, "ars232", 200.0, 3),
+    ("smallplanet_udiff_p24", ["--ne", "6", "--levels", "8", "--planet", "120", "--udiff", "1500", "500", "--explicitvertical", "--tracers", "2"],
+     "smallplanet", 2, {"fully_explicit": True, "uniform_diffusion": (1500.0, 500.0)}, "ars343", 1.0, 3),
+    ("jw_p96", ["--ne", "8", "--levels", "6", "--patches", "96"], "jw", 0, {}, "ars343", 200.0, 2),
+]
+
+
+@pytest.mark.parametrize("name,args,case,ntr,opts,scheme,dt,nsteps", LIVE_CASES, ids=[c[0] for c in LIVE_CASES])
+def test_live_reference_sweep(name, args, case, ntr, opts, scheme, dt, nsteps):
+    """Configurations no committed fixture holds, against the real reference run live on the GPU box's host (its own geometry,
+    operators and halo transforms; state after 2 steps): sub-panel patch layouts (24 and 96 patches) with tracers, odd level
+    counts, the other steppers, order-2 viscosity, the supercell dynamics.  Identical doubles after 2-3 further steps.
+    Needs oracle/_ref."""
+    import os, subprocess, tempfile
+    import tmxd
+    from tempestmodel_amd.engine import Engine
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    npatch = int(args[args.index("--patches") + 1]) if "--patches" in args else 24
+    full = list(args) + ([] if "--patches" in args else ["--patches", "24"])
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ref.tmxd")
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        subprocess.run([ref_bin, "--mode", "steps", "--dt", str(dt), "--warm", "2", "--steps", str(nsteps), "--every", str(nsteps),
+                        "--geom", "1", "--out", out] + full, env=env, check=True, stdout=subprocess.DEVNULL, timeout=1500)
+        rd = tmxd.read(out)
+    g, _ = gu.grid_from_fixture(rd, override=True, case=case, ntracers=ntr)
+    assert len(g.patches) == npatch
+    for P in g.patches:
+        for nm in ("ref_node", "ref_redge", "ref_tracers"):
+            if "p%d/%s" % (P.index, nm) in rd:
+                P.geom[nm] = rd["p%d/%s" % (P.index, nm)]
+    e = Engine(g, n_instances=10, **opts)
+    try:
+        e.upload_state(0, gu.full_states(rd, "warm", npatch))
+        if ntr:
+            e.upload_tracers(0, gu.full_tracers(rd, "warm", npatch))
+        for _ in range(nsteps):
+            e.step(scheme, dt)
+        e.sync()
+        errs = gu.prognostic_errors(e.download_state(0), gu.full_states(rd, "step%d" % nsteps, npatch))
+        terr = gu.tracer_errors(e.download_tracers(0), gu.full_tracers(rd, "step%d" % nsteps, npatch)) if ntr else [0.0]
+        print(name, "vs the live reference:", errs, terr)
+        assert max(errs) == EXACT and max(terr) == EXACT, (errs, terr)
+    finally:
+        e.close()
+
+
 def test_fused_column_kernels_are_bit_identical_to_split_kernels():
     """k_vi_fused (one wavefront per 64 columns), k_vi_pair (assembly and elimination in two wavefronts), k_vi_group (one
     column per 16-lane group; what small per-GPU grids run) and k_vi_assemble + k_vi_solve (TMX_VI_MODE=split) perform the
