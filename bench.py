@@ -45,8 +45,9 @@ ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
 # What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
 OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
-            "v_implicit": "latency (dependent pivot chain of one column per lane: forward 86 us compute + 28 us U-row stores, "
-                          "back substitution 78 us on the U-row read-back; profiles/r02_column_solve_ablation.txt)"}
+            "v_implicit": "forward phase (120 of 197 us): latency / issue of two dependent chains of ~91 us each (block-row assembly, "
+                          "pivoted elimination) sharing SIMDs, U-row stores 24 us; back substitution (77 us): HBM, the 362 MB U-row "
+                          "stream read back at 4.7 TB/s (profiles/r02_column_solve_ablation.txt)"}
 # engine profile slots (HIP events) that make up each operation
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
