@@ -15,7 +15,9 @@
 #include "tmx_internal.h"
 #include "tmx_refmath.h"
 
+#ifndef KT_H
 #define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads)
+#endif
 
 // Update statement a - l*u of the band LU (dgbtf2's rank-1 update, dgbtrs' forward sweep, dtbsv's column sweep).
 // LAPACK builds them from dger / dtbsv, and the optimised BLAS libraries the reference links (MKL, OpenBLAS) evaluate
@@ -1847,7 +1849,6 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 		const int lc = l < 0 ? 0 : (l > L ? L : l);
 		return xin[(size_t)TMX_SLAB_W(L, lc) * NS + col];
 	};
-	const size_t s3e = (size_t)(L + 1) * NS, s3n = (size_t)L * NS;
 	const MetCol mcol = met_col(p, col);
 	auto cxe = [&](int f, int m) -> double {
 		double e0, e1, e2;
@@ -1959,7 +1960,6 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 		double wnm = 0.0; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * wem; wnm += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * we0;
 		double wn0 = 0.0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; wn0 += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * wep;
 		// node metric at k-1, k
-		const size_t om = (size_t)(k - 1) * NS + col, o0 = (size_t)k * NS + col;
 		double ca2m, cb2m, cx2m, ca20, cb20, cx20;
 		metric_node3(p, mcol, k - 1, col, ca2m, cb2m, cx2m);
 		metric_node3(p, mcol, k, col, ca20, cb20, cx20);
