@@ -3008,7 +3008,14 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 #pragma unroll
 		for (int q = 0; q < TMX_BW - 1; q++) xw[q] = 0.0;
 		auto fetch = [&](int j) -> double { return stream[(size_t)(j < 0 ? 0 : j) * 64]; };
-		double f0 = fetch(n - 1), f1 = fetch(n - 2), f2 = fetch(n - 3), f3 = fetch(n - 4);
+		// TMX_GRP_PF rows in flight per lane (4, 16 and 32 measure the same: the elimination loop, not this one, is the chain
+		// that bounds the kernel on the small grids it serves)
+#ifndef TMX_GRP_PF
+#define TMX_GRP_PF 4
+#endif
+		double f[TMX_GRP_PF];
+#pragma unroll
+		for (int q = 0; q < TMX_GRP_PF; q++) f[q] = fetch(n - 1 - q);
 		auto row = [&](int j, double mine) {
 			URow s_;
 			s_.u[0] = grp_bcast<0>(mine); s_.u[1] = grp_bcast<1>(mine); s_.u[2] = grp_bcast<2>(mine); s_.u[3] = grp_bcast<3>(mine);
@@ -3018,15 +3025,12 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 			if (c == 0) xsol[j] = xr;
 		};
 		int j = n - 1;
-		for (; j >= 3; j -= 4) {
-			row(j, f0);     f0 = fetch(j - 4);
-			row(j - 1, f1); f1 = fetch(j - 5);
-			row(j - 2, f2); f2 = fetch(j - 6);
-			row(j - 3, f3); f3 = fetch(j - 7);
+		for (; j >= TMX_GRP_PF - 1; j -= TMX_GRP_PF) {
+#pragma unroll
+			for (int q = 0; q < TMX_GRP_PF; q++) { row(j - q, f[q]); f[q] = fetch(j - q - TMX_GRP_PF); }
 		}
-		if (j >= 0) row(j, f0);
-		if (j >= 1) row(j - 1, f1);
-		if (j >= 2) row(j - 2, f2);
+#pragma unroll
+		for (int q = 0; q < TMX_GRP_PF; q++) if (j - q >= 0) row(j - q, f[q]);
 		__syncthreads();
 		if (valid) {
 			int dep[3];
