@@ -269,7 +269,7 @@ def main():
         achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
         kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
-        if dom == "v_implicit" and eng.info(1) <= 4608:
+        if dom == "v_implicit" and eng.info(1) <= 6400:
             kernel_name = "k_vi_group (one column per 16-lane group)"
         mfma = mfma_report()
 

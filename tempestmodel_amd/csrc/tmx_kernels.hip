@@ -2448,9 +2448,13 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
 {
+	// The last window column of rows 0..3 is zero before every step (the slide clears it; only the incoming row 4 brings an
+	// entry there): written as literals, so that those four zeros do not occupy registers -- they were spilled, and every
+	// reload in this tail sat behind an s_waitcnt vmcnt(0) that also drained the U-row stores of the previous pivot.
+	constexpr int Z = TMX_BW - 1;
 	double piv[TMX_BW], t0[TMX_BW];
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) { piv[c] = R[PV][c]; t0[c] = R[0][c]; }
+	for (int c = 0; c < TMX_BW; c++) { piv[c] = (c == Z && PV != 4) ? 0.0 : R[PV][c]; t0[c] = (c == Z) ? 0.0 : R[0][c]; }
 	const double pb = b[PV], tb0 = b[0];
 	if (piv[0] == 0.0) singular = true;
 	lu_store_urow<SPARSE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
@@ -2460,7 +2464,10 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 		// after the interchange position r holds old row r, except position PV, which holds old row 0
 		const double l = ((r == PV) ? t0[0] : R[r][0]) * rcp;
 #pragma unroll
-		for (int c = 1; c < TMX_BW; c++) R[r - 1][c - 1] = LU_UPD((r == PV) ? t0[c] : R[r][c], l, piv[c]);
+		for (int c = 1; c < TMX_BW; c++) {
+			const double src = (r == PV) ? t0[c] : ((c == Z && r != 4) ? 0.0 : R[r][c]);
+			R[r - 1][c - 1] = LU_UPD(src, l, piv[c]);
+		}
 		R[r - 1][TMX_BW - 1] = 0.0;
 		b[r - 1] = LU_UPD((r == PV) ? tb0 : b[r], pb, l);
 	}
@@ -2884,8 +2891,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 // serves 4 columns instead of 64, so it only pays while the chip has SIMDs to spare: tmxk_vi_fused picks it by size.
 template <int SRC> __device__ __forceinline__ double grp_bcast(double v) {
 	const long long b = __double_as_longlong(v);
-	const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + SRC, 0xf, 0xf, false);
-	const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + SRC, 0xf, 0xf, false);
+	// every lane is written (row and bank masks 0xf), so the "old" operand is never used: passing the value itself spares the
+	// zero-initialisation of the destination the compiler emits for a constant
+	const int l0 = (int)(b & 0xffffffffll), h0 = (int)(b >> 32);
+	const int lo = __builtin_amdgcn_update_dpp(l0, l0, 0x150 + SRC, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(h0, h0, 0x150 + SRC, 0xf, 0xf, false);
 	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // lanes 0..11 of every 16-lane row take the value of the next lane, lanes 12..15 keep their own
@@ -2960,22 +2970,41 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 		w4 = band(4, c);
 	} else if (c == 15) { w0 = rhs(0); w1 = rhs(1); w2 = rhs(2); w3 = rhs(3); w4 = rhs(4); }
 	bool singular = false;
-	for (int j = 0; j < n; j++) {
+	const bool carries = (c <= 8) || (c == 15);      // lanes that hold a window column or the right-hand side
+	const int in_mul = (c <= 8) ? TMX_BW : 1, in_off = (c <= 8) ? c : 3 * TMX_BW;      // slot of this lane's entry of an incoming row
+	// The ring holds 16 block rows = 48 matrix rows; pivot j takes in row j + 5.  The loop runs in segments between two
+	// refills of the ring, so that the segment loop itself contains no vector-memory LOAD: with the refill inside it the
+	// compiler put an s_waitcnt vmcnt(0) at the loop head, which also waits for the previous pivot's U-row store.
+	for (int j = 0; j < n; ) {
+	if (j > 0 && j + 5 < n) { assemble((j + 5) / 3); __syncthreads(); }      // row j + 5 = 48 m comes up: rows below it are in the window
+	const int jend = min(n, ((j + 5) / 48 + 1) * 48 - 5);
+	for (; j < jend; j++) {
 		const int rin = j + 5;
-		// the ring holds 16 block rows = 48 matrix rows: when row 48 m comes up, all rows below it have entered the window
-		if (rin < n && rin % 48 == 0) { assemble(rin / 3); __syncthreads(); }
-		double in = 0.0;
-		if (rin < n) { if (c <= 8) in = band(rin, c); else if (c == 15) in = rhs(rin); }
+		// incoming row: one LDS read per lane, no branch (lanes 9..14 read the rhs slot and drop it); the value is only
+		// needed at the end of the step, so the read's latency is off the pivot chain
+		const int rc = (rin < n) ? rin : n - 1;
+		const int tin = rc / 3;
+		const double vin = blk[g][tin & 15][(rc - 3 * tin) * in_mul + in_off];
 		// pivot search on column 0 (lane 0 of the group): first maximum, as dgbtf2's idamax
-		int pv = 0;
-		double amax = fabs(w0);
-		{ const double v = fabs(w1); if (v > amax) { amax = v; pv = 1; } }
-		{ const double v = fabs(w2); if (v > amax) { amax = v; pv = 2; } }
-		{ const double v = fabs(w3); if (v > amax) { amax = v; pv = 3; } }
-		{ const double v = fabs(w4); if (v > amax) { amax = v; pv = 4; } }
-		pv = __builtin_amdgcn_update_dpp(0, pv, 0x150, 0xf, 0xf, false);
+		// (as a tree: rows 0/1 and 2/3 are compared side by side; strict comparisons keep the lower row on ties, so the result
+		// is the sequential first maximum)
+		int pv;
+		{
+			const double a0 = fabs(w0), a1 = fabs(w1), a2 = fabs(w2), a3 = fabs(w3), a4 = fabs(w4);
+			const bool g1 = a1 > a0, g3 = a3 > a2;
+			const double m01 = g1 ? a1 : a0, m23 = g3 ? a3 : a2;
+			const int i01 = g1 ? 1 : 0, i23 = g3 ? 3 : 2;
+			const bool gh = m23 > m01;
+			const double m03 = gh ? m23 : m01;
+			const int i03 = gh ? i23 : i01;
+			pv = (a4 > m03) ? 4 : i03;
+		}
+		pv = __builtin_amdgcn_update_dpp(pv, pv, 0x150, 0xf, 0xf, false);
 		// interchange: the pivot row's entry of this column, old row 0 into the pivot row's place
-		const double pr = (pv == 0) ? w0 : ((pv == 1) ? w1 : ((pv == 2) ? w2 : ((pv == 3) ? w3 : w4)));
+		// (a chain of selects, not a nested conditional: the compiler turned the latter into divergent branches, five
+		// exec-mask round trips per pivot step)
+		double pr = w0;
+		pr = (pv == 1) ? w1 : pr; pr = (pv == 2) ? w2 : pr; pr = (pv == 3) ? w3 : pr; pr = (pv == 4) ? w4 : pr;
 		const double t0 = w0;
 		w1 = (pv == 1) ? t0 : w1; w2 = (pv == 2) ? t0 : w2; w3 = (pv == 3) ? t0 : w3; w4 = (pv == 4) ? t0 : w4;
 		// U row j: entries 0..8 from lanes 0..8, transformed right-hand side from lane 15 (lanes 9..14 write their zeros:
@@ -2990,7 +3019,8 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 		w1 = grp_shift_left(LU_UPD(w2, l2, pr));
 		w2 = grp_shift_left(LU_UPD(w3, l3, pr));
 		w3 = grp_shift_left(LU_UPD(w4, l4, pr));
-		w4 = in;
+		w4 = (carries && rin < n) ? vin : 0.0;
+	}
 	}
 	if (singular) atomicExch(flag, 1);
 #ifdef TMX_VI_TIMING
