@@ -359,13 +359,13 @@ try {
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
 	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
-	                : (vmethod == "schur") ? (VerticalDynamics *)(new VerticalDynamicsSchur(model, 4, 2, 0, fExplicitVertical, true, false))
+	                : (vmethod == "schur") ? (VerticalDynamics *)(new VerticalDynamicsSchur(model, 4, getenv("TMX_REF_SCHUR_VORDER") ? atoi(getenv("TMX_REF_SCHUR_VORDER")) : 2, 0, fExplicitVertical, true, false))
 	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, fExplicitVertical, true, false));
 	model.SetVerticalDynamics(pV);
 
 	GridCSGLL * pGrid = new GridCSGLL(model);
 	pGrid->DefineParameters();
-	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, (vmethod == "schur") ? 2 : 1,
+	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, (vmethod == "schur") ? (getenv("TMX_REF_SCHUR_VORDER") ? atoi(getenv("TMX_REF_SCHUR_VORDER")) : 2) : 1,
 		(vmethod == "schur") ? Grid::VerticalDiscretization_FiniteVolume : Grid::VerticalDiscretization_FiniteElement,
 		getenv("TMX_REF_VSTAGGER_CPH") ? Grid::VerticalStaggering_CharneyPhillips : Grid::VerticalStaggering_Lorenz);
 	pGrid->InitializeDataLocal();

@@ -18,6 +18,8 @@ run --ne 4 --levels 10 --dt 200
 run --ne 4 --levels 30 --dt 100
 run --ne 4 --levels 10 --dt 200 --pert none
 run --ne 2 --levels 8 --dt 50 --case heldsuarez
+echo "== vertical order 4 (TMX_REF_SCHUR_VORDER=4)" >> $LOG
+TMX_REF_SCHUR_VORDER=4 run --ne 4 --levels 12 --dt 200
 echo "== the same with Charney-Phillips staggering (TMX_REF_VSTAGGER_CPH=1)" >> $LOG
 TMX_REF_VSTAGGER_CPH=1 run --ne 4 --levels 10 --dt 200
 cat $LOG
