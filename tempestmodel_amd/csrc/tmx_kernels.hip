@@ -558,44 +558,9 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 #pragma unroll
 	for (int t = 0; t < 5; t++)
 #pragma unroll
-		for (int m = 0; m < 4; m++) v[t][m] = ptr[m][(size_t)slabs[t] * str[m]];      // unconditional: absent copies point at x[0] with
-		                                                                              // stride 0, the top interface repeats the W slab; unused values
-		                                                                              // are never combined or stored (a conditional load costs a
-		                                                                              // divergent branch each: 20 per thread)
+		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
 	// gt == 0 with two or four copies: every member has the same pairing, one value for all of them
 	const bool same = (gt == 0) && (n != 3);
-	// Fast path, taken when ALL 64 groups of the wavefront are plain seams or corners inside one panel (no cube corner, no
-	// rotated copy: 9 of 10 wavefronts): the two formulas evaluated without a branch, stores member by member.  The general
-	// code below branches on the copy count, the pairing types and the rotation per value -- 475 branches in its ISA.
-	if (__builtin_amdgcn_ballot_w64(!(same && xi < 0)) == 0) {
-		const bool four = (n == 4);
-		double o[5];
-#pragma unroll
-		for (int t = 0; t < 5; t++) {
-			const double p0 = v[t][0] + v[t][1], p1 = v[t][2] + v[t][3];
-			o[t] = four ? 0.5 * (0.5 * p0 + 0.5 * p1) : 0.5 * p0;
-		}
-#pragma unroll
-		for (int m = 0; m < 4; m++) {
-			if (loc[m]) {          // loc[m] implies m < n
-				x[(size_t)slabs[0] * NS + c[m]] = o[0];
-				if (lev) {
-#pragma unroll
-					for (int t = 1; t < 5; t++) x[(size_t)slabs[t] * NS + c[m]] = o[t];
-				}
-			}
-		}
-		if (lev) {
-			for (int q = 0; q < nt; q++) {
-				const size_t sl = (size_t)TMX_SLAB_Q(L, q, kk);
-				const double p0 = ptr[0][sl * str[0]] + ptr[1][sl * str[1]], p1 = ptr[2][sl * str[2]] + ptr[3][sl * str[3]];
-				const double oq = four ? 0.5 * (0.5 * p0 + 0.5 * p1) : 0.5 * p0;
-#pragma unroll
-				for (int m = 0; m < 4; m++) if (loc[m]) x[sl * NS + c[m]] = oq;
-			}
-		}
-		continue;
-	}
 	const int t0 = gt & 3, t1 = (gt >> 2) & 3, t2 = (gt >> 4) & 3, t3 = (gt >> 6) & 3;
 #define DSS_SCALAR(W0, W1, W2, W3, O0, O1, O2, O3) do { \
 		if (same) { const double a_ = dss_combine<0>(W0, W1, W2, W3, n, 0); O0 = a_; O1 = a_; O2 = a_; O3 = a_; } \
@@ -628,7 +593,8 @@ __global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x,
 	if (lev) {
 		for (int q = 0; q < nt; q++) {
 			const size_t sl = (size_t)TMX_SLAB_Q(L, q, kk);
-			const double w0 = ptr[0][sl * str[0]], w1 = ptr[1][sl * str[1]], w2 = ptr[2][sl * str[2]], w3 = ptr[3][sl * str[3]];
+			const double w0 = (0 < n) ? ptr[0][sl * str[0]] : 0.0, w1 = (1 < n) ? ptr[1][sl * str[1]] : 0.0;
+			const double w2 = (2 < n) ? ptr[2][sl * str[2]] : 0.0, w3 = (3 < n) ? ptr[3][sl * str[3]] : 0.0;
 			double o0, o1, o2, o3;
 			DSS_SCALAR(w0, w1, w2, w3, o0, o1, o2, o3);
 			if (loc[0]) x[sl * NS + c[0]] = o0;
