@@ -108,6 +108,22 @@ def test_two_rank_plans_are_mutually_consistent():
         e.close()
 
 
+def test_active_state_image_size_is_the_reference_container_size():
+    """tmx_active_state_bytes = GridPatch::GetDataContainerActiveState().GetTotalByteSize() (GridPatch.cpp:359-361,387;
+    DataContainer.cpp): an 8-byte patch-index chunk, the node and interface state arrays and the tracer array, halo ring
+    included.  Host logic only (plan-only engine)."""
+    from tempestmodel_amd.engine import Engine
+    g, _ = gu.make_grid(3, 5, 6, ntracers=2)
+    e = Engine(g, device=-2)
+    try:
+        for P in g.patches:
+            nn = P.na * P.nb
+            assert e.lib.tmx_active_state_bytes(e.h, P.index) == 8 * (1 + 5 * nn * 5 + 5 * nn * 6 + 2 * nn * 5)
+        assert e.lib.tmx_active_state_bytes(e.h, 99) == -1
+    finally:
+        e.close()
+
+
 def test_default_owner_leaves_no_rank_empty():
     """Patch -> rank map of bench.py / Engine: contiguous blocks, the remainder spread, a clear error past one patch per rank."""
     from tempestmodel_amd.engine import default_owner
