@@ -1090,6 +1090,57 @@ def test_shallow_water_test2_strang():
         e.close()
 
 
+def test_shallow_water_24_patches_vs_live_reference():
+    """BASELINE config 1's case (Williamson test 2, the stock SWTest2) on 24 patches against the real reference run live on the
+    GPU box's host, on the reference's own 2-D geometry: four Strang steps from the analytic initial state (the first with
+    fFirstStep), state and carried instance equal the reference's bit for bit.  Needs oracle/_ref."""
+    import os, subprocess, tempfile
+    import tmxd
+    from tempestmodel_amd.cubed_sphere import CubedSphereGrid
+    from tempestmodel_amd.engine import Engine
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    ne, npatch, dt, nsteps = 8, 24, 200.0, 4
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ref.tmxd")
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        subprocess.run([ref_bin, "--mode", "steps", "--case", "sw2", "--scheme", "strang", "--ne", str(ne), "--patches", str(npatch), "--dt", str(dt),
+                        "--steps", str(nsteps), "--every", str(nsteps), "--geom", "1", "--out", out], env=env, check=True,
+                       stdout=subprocess.DEVNULL, timeout=600)
+        rd = tmxd.read(out)
+    from tempestmodel_amd.cubed_sphere import ShallowWaterTest2
+    g = CubedSphereGrid(ne, 1, 1.0, ppd=2, shallow_water=True)
+    g.evaluate_test_case(ShallowWaterTest2())          # geometry of the synthesiser, replaced by the reference's below
+    for P in g.patches:
+        for nm in list(P.geom):
+            if "p%d/%s" % (P.index, nm) in rd and np.shape(P.geom[nm]) == rd["p%d/%s" % (P.index, nm)].shape:
+                P.geom[nm] = rd["p%d/%s" % (P.index, nm)]
+        P.delta_a = float(rd["p%d/element_delta_a" % P.index][0]); P.delta_b = float(rd["p%d/element_delta_b" % P.index][0])
+    g.dx = rd["op/dx_basis_1d"]; g.stiff = rd["op/stiffness_1d"]
+    gu.override_halo_transforms(g, rd)
+
+    def full(tag):
+        out = []
+        for P in g.patches:
+            n = np.zeros((5, P.na, P.nb, 1)); e_ = np.zeros((5, P.na, P.nb, 2))
+            n[[0, 1, 2]] = rd["state/%s/p%d/node" % (tag, P.index)]
+            out.append((n, e_))
+        return out
+    e = Engine(g, n_instances=5)
+    try:
+        e.upload_state(0, full("initial"))
+        for n in range(nsteps):
+            e.step("strang", dt, first=(n == 0))
+        e.sync()
+        for inst, tag in ((0, "step%d" % nsteps), (1, "step%d_carry" % nsteps)):
+            errs = gu.prognostic_errors(e.download_state(inst), full(tag))[:3]
+            print("shallow water ne8 24 patches, instance %d vs the live reference:" % inst, errs)
+            assert max(errs) == EXACT, errs
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("scheme", ["ars343", "strang"])
 def test_multirank_supercell_configuration_loopback(scheme):
     """The supercell configuration (uniform diffusion relative to the per-rank reference state, fully explicit vertical
