@@ -691,6 +691,8 @@ LIVE_CASES = [
     ("smallplanet_udiff_p24", ["--ne", "6", "--levels", "8", "--planet", "120", "--udiff", "1500", "500", "--explicitvertical", "--tracers", "2"],
      "smallplanet", 2, {"fully_explicit": True, "uniform_diffusion": (1500.0, 500.0)}, "ars343", 1.0, 3),
     ("jw_p96", ["--ne", "8", "--levels", "6", "--patches", "96"], "jw", 0, {}, "ars343", 200.0, 2),
+    ("jw_tracers_L60_p24", ["--ne", "4", "--levels", "60", "--tracers", "3"], "jw", 3, {}, "ars343", 200.0, 2),
+    ("jw_ars232_tracers_oddL_p24", ["--ne", "6", "--levels", "7", "--scheme", "ars232", "--tracers", "2"], "jw", 2, {}, "ars232", 150.0, 2),
     # Schar mountain on the reduced-radius sphere: topography (terrain-following metric with non-zero slopes) and a Rayleigh layer
     ("schar_p24", ["--case", "schar", "--ne", "6", "--levels", "10"], "schar", 0, {}, "ars343", 0.5, 3),
     ("schar_ars222_p6", ["--case", "schar", "--ne", "4", "--levels", "8", "--patches", "6", "--scheme", "ars222"], "schar", 0, {}, "ars222", 0.5, 3),
