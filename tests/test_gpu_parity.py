@@ -1269,6 +1269,45 @@ def test_supercell_steps_with_kessler():
         e.close()
 
 
+def test_supercell_kessler_24_patches_vs_live_reference():
+    """BASELINE config 4's case on 24 patches (ne4 np4 L40: the stock SupercellTest state from the Fortran initialiser,
+    --explicitvertical, uniform diffusion, three tracers, KesslerPhysics::Perform after every step) against the real reference
+    run live on the GPU box's host (about a minute of host time: the initialiser is slow): three steps from its state after one
+    step, state and tracers bit for bit.  Needs oracle/_ref."""
+    import os, subprocess, tempfile
+    import tmxd
+    from tempestmodel_amd.engine import Engine
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    ne, L, npatch, dt, nsteps = 4, 40, 24, 0.5, 3
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ref.tmxd")
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+        subprocess.run([ref_bin, "--case", "supercell", "--explicitvertical", "--physics", "kessler", "--mode", "steps", "--ne", str(ne),
+                        "--levels", str(L), "--dt", str(dt), "--patches", str(npatch), "--warm", "1", "--steps", str(nsteps),
+                        "--every", str(nsteps), "--geom", "1", "--out", out], env=env, check=True, stdout=subprocess.DEVNULL, timeout=1500)
+        rd = tmxd.read(out)
+    g, _ = gu.grid_from_fixture(rd, override=True, case="supercell")
+    for P in g.patches:
+        for nm in ("ref_node", "ref_redge", "ref_tracers"):
+            P.geom[nm] = rd["p%d/%s" % (P.index, nm)]
+    e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0))
+    try:
+        e.set_level_heights()
+        e.upload_state(0, gu.full_states(rd, "warm", npatch)); e.upload_tracers(0, gu.full_tracers(rd, "warm", npatch))
+        for _ in range(nsteps):
+            e.step_ars343(dt)
+            e.kessler(0, dt)
+        e.sync()
+        errs = gu.prognostic_errors(e.download_state(0), gu.full_states(rd, "step%d" % nsteps, npatch))
+        terr = gu.tracer_errors(e.download_tracers(0), gu.full_tracers(rd, "step%d" % nsteps, npatch))
+        print("supercell + Kessler ne4 L40 24 patches, %d steps vs the live reference:" % nsteps, errs, terr)
+        assert max(errs) == EXACT and max(terr) == EXACT, (errs, terr)
+    finally:
+        e.close()
+
+
 # ---- BASELINE config 5 shape: the stock Held-Suarez test at L60 ------------------------------------------------
 
 @pytest.mark.parametrize("graph", [False, True])
