@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
+    ap.add_argument("--physics", default="none", help="hs: tmx_physics_held_suarez after every step (BASELINE config 5's shape; not the headline metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,6 +211,17 @@ def main():
         dist.broadcast(uid, 0)
         eng.comm_init(bytes(uid.cpu().tolist()))
     eng.upload_state(0, states)
+
+    hs = (args.physics == "hs")
+    if hs:
+        eng.set_physics_inputs(None)
+    _step = eng.step_ars343
+
+    def step_with_forcing(dt_):
+        _step(dt_)
+        eng.held_suarez(0, dt_)
+    if hs:
+        eng.step_ars343 = step_with_forcing
 
     def barrier():
         if world > 1:
@@ -309,6 +321,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
             "developed_steps": args.develop, "host_cpu_count": os.cpu_count(),
+            "physics_after_every_step": args.physics,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 6, 6)      # ~15 s of CPU work (1 warm-up + 6 timed steps)
