@@ -1087,9 +1087,143 @@ int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	return 0;
 }
 
+// UpdateColumnTracers in the fully explicit vertical mode, level-parallel.  There the matrix is the diagonal 1/dt, so the
+// update of (column, level, tracer) only needs the column within two levels: one thread per (column, level) evaluates
+// exactly the statements of k_vi_tracers' explicit branch (same operands, same order: bit-identical, tested) instead of one
+// lane walking the whole column out of LDS -- that form took 3.4 ms per launch at ne30 L40 (32 columns per workgroup, 82 KB
+// of LDS each), 75 % of a supercell step.
+__global__ __launch_bounds__(256) void k_v_tracers_explicit(KParams p, int nt, const double * __restrict__ xin, double * xup, double dt,
+	double ks, const double * __restrict__ xref)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k >= L || col >= p.ncol) return;
+	const MetCol mc = met_col(p, col);
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
+	// xi_dot of the initial column on the interfaces k and k+1 (zero at the boundaries)
+	double xd[2];
+#pragma unroll
+	for (int mo = 0; mo <= 1; mo++) {
+		const int m = k + mo;
+		double x0v = 0.0;
+		if (m >= 1 && m <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+				ue += cc * xin[(size_t)TMX_SLAB_U(L, l) * NS + col];
+				ve += cc * xin[(size_t)TMX_SLAB_V(L, l) * NS + col];
+			}
+			double e0, e1, e2;
+			metric_edge(p, mc, m, col, e0, e1, e2);
+			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)m * NS + col];
+		}
+		xd[mo] = x0v;
+	}
+	// rho on the two interfaces (uniform diffusion only)
+	double rhoe[2] = { 0.0, 0.0 };
+	if (ks != 0.0) {
+#pragma unroll
+		for (int mo = 0; mo <= 1; mo++) {
+			const int m = k + mo;
+			double re = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				re += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * xin[(size_t)TMX_SLAB_R(L, l) * NS + col];
+			}
+			rhoe[mo] = re;
+		}
+	}
+	// rho of the five levels k-2 .. k+2 the stencils reach (each value is loaded once and divided once per tracer)
+	double rh5[5] = { 1.0, 1.0, 1.0, 1.0, 1.0 }, rr5[5] = { 1.0, 1.0, 1.0, 1.0, 1.0 };
+	if (ks != 0.0) {
+#pragma unroll
+		for (int t = 0; t < 5; t++) {
+			const int l = k - 2 + t;
+			if (l < 0 || l >= L) continue;
+			rh5[t] = xin[(size_t)TMX_SLAB_R(L, l) * NS + col];
+			rr5[t] = xref[(size_t)TMX_SLAB_R(L, l) * NS + col];
+		}
+	}
+	for (int c = 0; c < nt; c++) {
+		double q5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, mr5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+		for (int t = 0; t < 5; t++) {
+			const int l = k - 2 + t;
+			if (l < 0 || l >= L) continue;
+			q5[t] = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+			if (ks != 0.0) {
+				double a_ = q5[t] / rh5[t];
+				a_ -= xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col] / rr5[t];
+				mr5[t] = a_;
+			}
+		}
+		auto qn = [&](int l) -> double { return q5[l - k + 2]; };          // l in [k-2, k+2], unrolled: a register
+		auto mixr = [&](int l) -> double { return mr5[l - k + 2]; };
+		double mf[2];
+#pragma unroll
+		for (int mo = 0; mo <= 1; mo++) {
+			const int m = k + mo;
+			double qe = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn(l);
+			}
+			mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd[mo];
+			if (ks != 0.0 && m > 0 && m < L) {
+				double dq = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mixr(l);
+				}
+				mf[mo] -= ks * rhoe[mo] * dq;
+			}
+		}
+		double dmf = 0.0;
+		dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
+		dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[1];
+		double F = dmf / jn;
+		double aux = 0.0;
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn(k);
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn(k + 1);
+			aux += b * fabs(xd[1]);
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn(k - 1);
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn(k);
+			aux += b * fabs(xd[0]);
+		}
+		F -= aux;
+		const double idt = 1.0 / dt;
+		if (F != 0.0) F /= idt;
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
+		xup[so + col] = xup[so + col] - F;
+	}
+}
+
 // UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
+	if (!getenv("TMX_VT_COLUMN")) {      // level-parallel form (default); TMX_VT_COLUMN=1: the one-lane-per-column kernel, for A/B and tests
+		dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+		hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
+			e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+		return 0;
+	}
 	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
 	if (!lw) return -1;
 #define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -316,6 +316,34 @@ def test_uniform_diffusion_explicit_vertical_steps(scheme):
         e.close()
 
 
+def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_kernel(monkeypatch):
+    """UpdateColumnTracers in the fully explicit mode: the level-parallel kernel (default) and the one-lane-per-column kernel
+    (TMX_VT_COLUMN=1) give identical doubles, with and without uniform diffusion."""
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_udiff_ars343_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
+    for ud in (UDIFF, None):
+        out = []
+        for column in (False, True):
+            if column:
+                monkeypatch.setenv("TMX_VT_COLUMN", "1")
+            else:
+                monkeypatch.delenv("TMX_VT_COLUMN", raising=False)
+            e = Engine(g, fully_explicit=True, uniform_diffusion=ud)
+            try:
+                e.upload_state(0, st); e.upload_tracers(0, tr)
+                e.copy_data(0, 1)
+                e.v_step_explicit(0, 1, 0.7)
+                e.sync()
+                out.append((e.download_state(1), e.download_tracers(1)))
+            finally:
+                e.close()
+        assert max(gu.tracer_errors(out[0][1], out[1][1])) == EXACT
+        assert max(gu.prognostic_errors(out[0][0], out[1][0])) == EXACT
+        assert any(np.abs(a - b).max() > 0 for a, b in zip(out[0][1], tr))        # the update did something
+
+
 def test_explicit_vertical_without_diffusion_matches_oracle():
     """--explicitvertical alone (no uniform diffusion, no tracers): ARS343 and Strang steps against the C oracle."""
     from tempestmodel_amd.engine import Engine
