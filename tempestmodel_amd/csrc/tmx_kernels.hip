@@ -922,7 +922,8 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 	int dep[3];
 #pragma unroll
 	for (int t = 0; t < 3; t++) dep[t] = udep ? udep[u * 3 + t] : -1;
-	bool singular = false;
+	bool singular = false, factored = false;
+	unsigned long long jpmask = 0, jpmask_hi = 0, zeromask = 0, zeromask_hi = 0;      // interchanges / zero pivots of the factorisation, by column
 	if (expl && ks != 0.0) {
 		// rho on interfaces: InterpolateNodeToREdge of the initial column (PrepareColumn :1905-1916)
 		for (int m = 0; m <= L; m++) {
@@ -1017,33 +1018,44 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 			f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * LW + lane] * jump;
 			F[(size_t)a * LW + lane] = f;
 		}
-		// dgbtf2 (kl = ku = 1, kv = 2) on a fresh matrix, forward substitution with the interchanges, dtbsv
-		assemble();
-		int ju = 0;
-		for (int jj = 0; jj < L; jj++) {
-			if (jj + 2 < L) ABW(jj + 2 - 2, jj + 2) = 0.0;         // fill-in super-diagonal of column jj + kv
-			const int km = (jj < L - 1) ? 1 : 0;
-			int jp = 0;
-			if (km && fabs(ABW(jj + 1, jj)) > fabs(ABW(jj, jj))) jp = 1;
-			const double piv = ABW(jj + jp, jj);
-			if (piv != 0.0) {
-				int tt = jj + 1 + jp; if (tt > L - 1) tt = L - 1;
-				if (tt > ju) ju = tt;
-				if (jp) for (int cc = jj; cc <= ju; cc++) { const double tmp = ABW(jj + 1, cc); ABW(jj + 1, cc) = ABW(jj, cc); ABW(jj, cc) = tmp; }
-				if (km) {
-					const double r = 1.0 / ABW(jj, jj);
-					ABW(jj + 1, jj) *= r;
-					for (int cc = jj + 1; cc <= ju; cc++) {
-						const double uu = ABW(jj, cc);
-						if (uu != 0.0) ABW(jj + 1, cc) = LU_UPD(ABW(jj + 1, cc), ABW(jj + 1, jj), uu);
+		// dgbtf2 (kl = ku = 1, kv = 2) once per column -- the matrix is the same for every tracer, the reference factorises it
+		// once (:4028-4040) --, then per tracer dgbtrs: forward substitution with the stored multipliers and interchanges, dtbsv
+		if (!factored) {
+			factored = true;
+			assemble();
+			int ju = 0;
+			for (int jj = 0; jj < L; jj++) {
+				if (jj + 2 < L) ABW(jj + 2 - 2, jj + 2) = 0.0;         // fill-in super-diagonal of column jj + kv
+				const int km = (jj < L - 1) ? 1 : 0;
+				int jp = 0;
+				if (km && fabs(ABW(jj + 1, jj)) > fabs(ABW(jj, jj))) jp = 1;
+				const double piv = ABW(jj + jp, jj);
+				if (piv != 0.0) {
+					int tt = jj + 1 + jp; if (tt > L - 1) tt = L - 1;
+					if (tt > ju) ju = tt;
+					if (jp) {
+						jpmask |= 1ull << (jj & 63); if (jj >= 64) jpmask_hi |= 1ull << (jj - 64);
+						for (int cc = jj; cc <= ju; cc++) { const double tmp = ABW(jj + 1, cc); ABW(jj + 1, cc) = ABW(jj, cc); ABW(jj, cc) = tmp; }
 					}
-				}
-				// forward substitution of this column (dgbtrs): interchange, then eliminate
-				if (jj < L - 1) {
-					if (jp) { const double tmp = F[(size_t)(jj + 1) * LW + lane]; F[(size_t)(jj + 1) * LW + lane] = F[(size_t)jj * LW + lane]; F[(size_t)jj * LW + lane] = tmp; }
-					F[(size_t)(jj + 1) * LW + lane] = LU_UPD(F[(size_t)(jj + 1) * LW + lane], F[(size_t)jj * LW + lane], ABW(jj + 1, jj));
-				}
-			} else singular = true;
+					if (km) {
+						const double r = 1.0 / ABW(jj, jj);
+						ABW(jj + 1, jj) *= r;
+						for (int cc = jj + 1; cc <= ju; cc++) {
+							const double uu = ABW(jj, cc);
+							if (uu != 0.0) ABW(jj + 1, cc) = LU_UPD(ABW(jj + 1, cc), ABW(jj + 1, jj), uu);
+						}
+					}
+				} else { singular = true; zeromask |= 1ull << (jj & 63); if (jj >= 64) zeromask_hi |= 1ull << (jj - 64); }
+			}
+		}
+		// forward substitution (dgbtrs): interchange, then eliminate; a zero pivot leaves its column untouched, as above
+		for (int jj = 0; jj < L - 1; jj++) {
+			const unsigned long long bit = 1ull << (jj & 63);
+			const bool isz = (jj < 64) ? (zeromask & bit) != 0 : (zeromask_hi & (1ull << (jj - 64))) != 0;
+			if (isz) continue;
+			const bool jp = (jj < 64) ? (jpmask & bit) != 0 : (jpmask_hi & (1ull << (jj - 64))) != 0;
+			if (jp) { const double tmp = F[(size_t)(jj + 1) * LW + lane]; F[(size_t)(jj + 1) * LW + lane] = F[(size_t)jj * LW + lane]; F[(size_t)jj * LW + lane] = tmp; }
+			F[(size_t)(jj + 1) * LW + lane] = LU_UPD(F[(size_t)(jj + 1) * LW + lane], F[(size_t)jj * LW + lane], ABW(jj + 1, jj));
 		}
 		for (int jj = L - 1; jj >= 0; jj--) {
 			double bj = F[(size_t)jj * LW + lane];
@@ -1077,12 +1089,18 @@ static int vi_tracers_lanes(int L, size_t & lds) {
 
 int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
 	if (e->nunique == 0 || e->nt == 0) return 0;
-	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
+	size_t lds; int lw = vi_tracers_lanes(p.L, lds);
 	if (!lw) return -1;
+	// Fewer columns per workgroup = more workgroups per CU: the kernel lives in LDS (dependent read-modify-write chains of
+	// ~100 cycles each) and one 64-column workgroup fills a CU's LDS, i.e. ONE wavefront per CU.  With 16 columns per
+	// workgroup five wavefronts share a CU and hide each other's LDS latency (TMX_VT_LANES: 64, 32, 16, 8 for A/B).
+	int want = 16;
+	if (const char * m = getenv("TMX_VT_LANES")) want = atoi(m);
+	if (want < lw && (want == 32 || want == 16 || want == 8)) { lw = want; lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * lw * sizeof(double); }
 #define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 	hipLaunchKernelGGL(k_vi_tracers<LW_>, dim3((e->nunique + LW_ - 1) / LW_), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
 		e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag, 0, 0.0, (const double *)nullptr); } while (0)
-	if (lw == 64) LAUNCH_VT(64); else LAUNCH_VT(32);
+	if (lw == 64) LAUNCH_VT(64); else if (lw == 32) LAUNCH_VT(32); else if (lw == 16) LAUNCH_VT(16); else LAUNCH_VT(8);
 #undef LAUNCH_VT
 	return 0;
 }
