@@ -1078,6 +1078,222 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 #undef ABW
 }
 
+// The same column update (implicit mode) with the level-parallel parts spread over four lanes per column: a workgroup = one
+// wavefront = 16 columns x 4 row lanes.  Row lane t of a column evaluates xi_dot, the matrix rows, the tracer loads, the
+// right-hand side and the result stores of the levels k = t, t + 4, ...; every matrix entry and every right-hand-side entry is
+// formed by the lane that owns its row, in the order the sequential loops of k_vi_tracers accumulate it (flux terms, upwinding
+// of interface k then k + 1, 1/dt; velocity correction of interface k then k + 1), so the results are bit-identical; only the
+// factorisation and the two substitutions stay on one lane per column.  LDS: (8L + 2) x 16 doubles per workgroup, so that at
+// L = 30 five workgroups share a CU (one with the 64-column form).
+__global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
+	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag)
+{
+	constexpr int LW = 16;
+	extern __shared__ double smt[];
+	const int L = p.L, lane = threadIdx.x & 15, t = threadIdx.x >> 4;
+	const size_t NS = (size_t)p.NS;
+	double * A = smt;                                // [L][4][LW]
+	double * F = A + (size_t)L * 4 * LW;             // [L][LW]
+	double * xd0 = F + (size_t)L * LW;               // [L+1][LW]
+	double * xd1 = xd0 + (size_t)(L + 1) * LW;       // [L+1][LW]
+	double * qn = xd1 + (size_t)(L + 1) * LW;        // [L][LW]
+	const int uraw = blockIdx.x * LW + lane;
+	const bool valid = uraw < nunique;
+	const int u = valid ? uraw : nunique - 1;        // lanes of a ragged last workgroup redo the last column (no stores): barriers below
+	const int col = ucol ? ucol[u] : u;
+	const MetCol mc = met_col(p, col);
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	// row k of the band matrix in slots 0..2 (sub-, main, super-diagonal); after the factorisation: slot 0 of row j + 1 = the
+	// multiplier of step j, slots 1..3 of row j = row j of U (diagonal and the two entries right of it)
+#define AR(k_, s_) A[((size_t)(k_) * 4 + (s_)) * LW + lane]
+	// xi_dot on interfaces, initial and with the updated W (:3943-3957, :4059-4086)
+	for (int k = t; k <= L; k += 4) {
+		double x0v = 0.0, x1v = 0.0;
+		if (k >= 1 && k <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = k + off;
+				if (l < 0 || l >= L) continue;
+				const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, off);
+				ue += cc * xin[(size_t)TMX_SLAB_U(L, l) * NS + col];
+				ve += cc * xin[(size_t)TMX_SLAB_V(L, l) * NS + col];
+			}
+			double e0, e1, e2;
+			metric_edge(p, mc, k, col, e0, e1, e2);
+			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)k * NS + col];
+			x1v = e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
+		}
+		xd0[(size_t)k * LW + lane] = x0v; xd1[(size_t)k * LW + lane] = x1v;
+	}
+	__syncthreads();
+	// matrix rows (:3959-4016), each entry by the owner of its row
+	for (int k = t; k < L; k += 4) {
+#pragma unroll
+		for (int d = -1; d <= 1; d++) {
+			const int n = k + d;
+			if (n < 0 || n >= L) { AR(k, d + 1) = 0.0; continue; }
+			double a = 0.0;
+			// d F_k / d q_n: DiffREdgeToNode x J_e / J_n x InterpNodeToREdge x xi_dot; interface m = k + mo, node n = m + no
+#pragma unroll
+			for (int mo = 0; mo <= 1; mo++) {
+				const int m = k + mo, no = n - m;
+				if (no < -2 || no > 1) continue;
+				a += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, mo) * je / jn * OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, no) * xd0[(size_t)m * LW + lane];
+			}
+			// upwinding: interface a = k (this row as "a"), then a = k + 1 (this row as "a - 1")
+			if (k >= 1 && k <= L - 1) {
+				const double wgt = fabs(xd0[(size_t)k * LW + lane]);
+				if (d == -1) a -= wgt * OPC(TMX_OP_PENALTY_RIGHT, k, -1);
+				if (d == 0) a -= wgt * OPC(TMX_OP_PENALTY_RIGHT, k, 0);
+			}
+			if (k + 1 <= L - 1) {
+				const double wgt = fabs(xd0[(size_t)(k + 1) * LW + lane]);
+				if (d == 0) a -= wgt * OPC(TMX_OP_PENALTY_LEFT, k, 0);
+				if (d == 1) a -= wgt * OPC(TMX_OP_PENALTY_LEFT, k, 1);
+			}
+			if (d == 0) a += 1.0 / dt;
+			AR(k, d + 1) = a;
+		}
+	}
+	__syncthreads();
+	// dgbtf2 (kl = ku = 1, kv = 2), one lane per column, with the pivot candidate row carried in registers: at step j the
+	// candidate has entries (c0, c1) in columns j, j + 1 (the fill-in column j + 2 holds the zero dgbtf2 stores there); row j + 1
+	// is (l, d, u) in columns j .. j + 2.  Interchange when |l| > |c0| (idamax keeps the first of equals), multiplier = the other
+	// row's leading entry x (1 / pivot) (dscal), rank-1 update fused as in LU_UPD, skipped for a zero in the pivot row (dger).
+	bool singular = false;
+	unsigned long long jpmask = 0, jpmask_hi = 0, zeromask = 0, zeromask_hi = 0;
+	if (t == 0) {
+		double c0 = AR(0, 1), c1 = AR(0, 2);
+		double nl = (L > 1) ? AR(1, 0) : 0.0, nd = (L > 1) ? AR(1, 1) : 0.0, nu = (L > 1) ? AR(1, 2) : 0.0;
+		for (int jj = 0; jj < L - 1; jj++) {
+			const double l = nl, d = nd, un = nu;
+			if (jj + 2 < L) { nl = AR(jj + 2, 0); nd = AR(jj + 2, 1); nu = AR(jj + 2, 2); }
+			const bool jp = fabs(l) > fabs(c0);
+			const double piv = jp ? l : c0;
+			if (piv != 0.0) {
+				const double p1 = jp ? d : c1, p2 = jp ? un : 0.0;          // pivot row right of the diagonal
+				const double o0 = jp ? c0 : l, o1 = jp ? c1 : d, o2 = jp ? 0.0 : un;
+				if (jp) { jpmask |= 1ull << (jj & 63); if (jj >= 64) jpmask_hi |= 1ull << (jj - 64); }
+				const double r = 1.0 / piv;
+				const double m = o0 * r;
+				AR(jj, 1) = piv; AR(jj, 2) = p1; AR(jj, 3) = p2; AR(jj + 1, 0) = m;
+				c0 = (p1 != 0.0) ? LU_UPD(o1, m, p1) : o1;
+				c1 = (jp && p2 != 0.0) ? LU_UPD(o2, m, p2) : o2;
+			} else {
+				singular = true; zeromask |= 1ull << (jj & 63); if (jj >= 64) zeromask_hi |= 1ull << (jj - 64);
+				AR(jj, 1) = c0; AR(jj, 2) = c1; AR(jj, 3) = 0.0;       // l == c0 == 0: nothing eliminated, row j + 1 becomes the candidate
+				c0 = d; c1 = un;
+			}
+		}
+		AR(L - 1, 1) = c0; AR(L - 1, 2) = 0.0; AR(L - 1, 3) = 0.0;
+		if (c0 == 0.0) { singular = true; zeromask |= 1ull << ((L - 1) & 63); if (L - 1 >= 64) zeromask_hi |= 1ull << (L - 1 - 64); }
+	}
+	int dep[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) dep[q] = udep ? udep[u * 3 + q] : -1;
+	for (int c = 0; c < nt; c++) {
+		__syncthreads();        // the previous tracer's stores have read F
+		for (int k = t; k < L; k += 4) qn[(size_t)k * LW + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		__syncthreads();
+		for (int k = t; k < L; k += 4) {
+			// mass flux with the updated xi_dot, its divergence (:4092-4140)
+			double mf[2];
+#pragma unroll
+			for (int mo = 0; mo <= 1; mo++) {
+				const int m = k + mo;
+				double qe = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn[(size_t)l * LW + lane];
+				}
+				mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * xd1[(size_t)m * LW + lane];
+			}
+			double dmf = 0.0;
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[1];
+			double f = dmf / jn;
+			// upwinding with the initial xi_dot (:4153-4181)
+			double aux = 0.0;
+			if (k < L - 1) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn[(size_t)k * LW + lane];
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn[(size_t)(k + 1) * LW + lane];
+				aux += b * fabs(xd0[(size_t)(k + 1) * LW + lane]);
+			}
+			if (k > 0) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn[(size_t)(k - 1) * LW + lane];
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn[(size_t)k * LW + lane];
+				aux += b * fabs(xd0[(size_t)k * LW + lane]);
+			}
+			f -= aux;
+			// implicit velocity correction (:4183-4233): interface a = k (this row as "a"), then a = k + 1 (as "a - 1")
+#pragma unroll
+			for (int s_ = 0; s_ <= 1; s_++) {
+				const int a = k + s_;
+				if (a < 1 || a > L - 1) continue;
+				const double xa = xd0[(size_t)a * LW + lane];
+				double e0, e1, e2;
+				metric_edge(p, mc, a, col, e0, e1, e2);
+				const double sw = (xa > 0.0) ? 1.0 * e2 : ((xa < 0.0) ? -1.0 * e2 : 0.0);
+				const double jump = sw * (xup[(size_t)TMX_SLAB_W(L, a) * NS + col] - w0[(size_t)a * NS + col]);
+				if (s_ == 0) {
+					f -= OPC(TMX_OP_PENALTY_RIGHT, a, -1) * qn[(size_t)(a - 1) * LW + lane] * jump;
+					f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * LW + lane] * jump;
+				} else {
+					f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 0) * qn[(size_t)(a - 1) * LW + lane] * jump;
+					f -= OPC(TMX_OP_PENALTY_LEFT, a - 1, 1) * qn[(size_t)a * LW + lane] * jump;
+				}
+			}
+			F[(size_t)k * LW + lane] = f;
+		}
+		__syncthreads();
+		if (t == 0) {
+			// dgbtrs: forward substitution with the stored multipliers and interchanges, the running entry in a register ...
+			double fc = F[lane], fn = (L > 1) ? F[(size_t)LW + lane] : 0.0, mm = (L > 1) ? AR(1, 0) : 0.0;
+			for (int jj = 0; jj < L - 1; jj++) {
+				const double f1 = fn, m = mm;
+				if (jj + 2 < L) { fn = F[(size_t)(jj + 2) * LW + lane]; mm = AR(jj + 2, 0); }
+				const unsigned long long bit = 1ull << (jj & 63);
+				const bool isz = (jj < 64) ? (zeromask & bit) != 0 : (zeromask_hi & (1ull << (jj - 64))) != 0;
+				const bool jp = (jj < 64) ? (jpmask & bit) != 0 : (jpmask_hi & (1ull << (jj - 64))) != 0;
+				const double top = (jp && !isz) ? f1 : fc, bot = (jp && !isz) ? fc : f1;
+				F[(size_t)jj * LW + lane] = top;
+				fc = isz ? bot : LU_UPD(bot, top, m);
+			}
+			// ... then dtbsv (upper, no transpose, non-unit), column oriented: entry j is divided by the diagonal and then leaves
+			// entries j - 1 and j - 2; entry i therefore receives column i + 2 before column i + 1.  b1 = entry j - 1 so far.
+			double cur = fc, b1 = (L > 1) ? F[(size_t)(L - 2) * LW + lane] : 0.0;
+			double dg = AR(L - 1, 1), u1 = (L > 1) ? AR(L - 2, 2) : 0.0, u2 = (L > 2) ? AR(L - 3, 3) : 0.0, fr = (L > 2) ? F[(size_t)(L - 3) * LW + lane] : 0.0;
+			for (int jj = L - 1; jj >= 0; jj--) {
+				const double dgj = dg, u1j = u1, u2j = u2, b2 = fr;
+				if (jj >= 1) dg = AR(jj - 1, 1);
+				if (jj >= 2) u1 = AR(jj - 2, 2);
+				if (jj >= 3) { u2 = AR(jj - 3, 3); fr = F[(size_t)(jj - 3) * LW + lane]; }
+				const bool nz = cur != 0.0;
+				const double x = nz ? cur / dgj : cur;
+				F[(size_t)jj * LW + lane] = x;
+				cur = nz ? LU_UPD(b1, x, u1j) : b1;
+				b1 = nz ? LU_UPD(b2, x, u2j) : b2;
+			}
+		}
+		__syncthreads();
+		if (valid)
+			for (int k = t; k < L; k += 4) {
+				const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
+				const double val = xbase[so + col] - F[(size_t)k * LW + lane];
+				xup[so + col] = val;
+#pragma unroll
+				for (int q = 0; q < 3; q++) if (dep[q] >= 0) xup[so + dep[q]] = val;
+			}
+	}
+	if (singular && valid) atomicExch(flag, 1);
+#undef AR
+}
+
 // lanes per workgroup such that the LDS working set (8L + 2) x LW x 8 bytes fits one CU
 static int vi_tracers_lanes(int L, size_t & lds) {
 	for (int lw = 64; lw >= 32; lw >>= 1) {
@@ -1089,6 +1305,15 @@ static int vi_tracers_lanes(int L, size_t & lds) {
 
 int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
 	if (e->nunique == 0 || e->nt == 0) return 0;
+	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {      // default: 16 columns x 4 row lanes per workgroup
+		const size_t l2 = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 16 * sizeof(double);
+		if (l2 <= 160 * 1024) {
+			hipFuncSetAttribute((const void *)k_vi_tracers_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+			hipLaunchKernelGGL(k_vi_tracers_rows, dim3((e->nunique + 15) / 16), dim3(64), l2, e->stream, p, e->nt, xin, w0, xbase, xup, dt,
+				e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag);
+			return 0;
+		}
+	}
 	size_t lds; int lw = vi_tracers_lanes(p.L, lds);
 	if (!lw) return -1;
 	// Fewer columns per workgroup = more workgroups per CU: the kernel lives in LDS (dependent read-modify-write chains of
@@ -1257,6 +1482,15 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 // of the tracers, on every stored column (the reference loops over all nodes there, :541-542), in place on the update instance
 int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
+	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {
+		const size_t l2 = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 16 * sizeof(double);
+		if (l2 <= 160 * 1024) {
+			hipFuncSetAttribute((const void *)k_vi_tracers_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+			hipLaunchKernelGGL(k_vi_tracers_rows, dim3((p.ncol + 15) / 16), dim3(64), l2, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS,
+				(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag);
+			return 0;
+		}
+	}
 	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);
 	if (!lw) return -1;
 #define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -344,6 +344,34 @@ def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_ke
         assert any(np.abs(a - b).max() > 0 for a, b in zip(out[0][1], tr))        # the update did something
 
 
+def test_row_parallel_implicit_tracer_update_is_bit_identical_to_the_column_kernel(monkeypatch):
+    """UpdateColumnTracers in the implicit mode: the kernel with four row lanes per column (default) and the one-lane-per-column
+    kernel (TMX_VT_ROWS=0) give identical doubles over whole ARS343 steps, and so does ARK232's all-columns form."""
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_tracers_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, ntracers=2)
+    st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
+    for scheme, ninst in (("ars343", None), ("ark232", 8)):
+        out = []
+        for rows in (True, False):
+            if rows:
+                monkeypatch.delenv("TMX_VT_ROWS", raising=False)
+            else:
+                monkeypatch.setenv("TMX_VT_ROWS", "0")
+            e = Engine(g) if ninst is None else Engine(g, n_instances=ninst)
+            try:
+                e.upload_state(0, st); e.upload_tracers(0, tr)
+                for step in range(2):
+                    e.step(scheme, 200.0, first=(step == 0))
+                e.sync()
+                out.append((e.download_state(0), e.download_tracers(0)))
+            finally:
+                e.close()
+        assert max(gu.tracer_errors(out[0][1], out[1][1])) == EXACT, scheme
+        assert max(gu.prognostic_errors(out[0][0], out[1][0])) == EXACT, scheme
+        assert any(np.abs(a - b).max() > 0 for a, b in zip(out[0][1], tr))
+
+
 def test_explicit_vertical_without_diffusion_matches_oracle():
     """--explicitvertical alone (no uniform diffusion, no tracers): ARS343 and Strang steps against the C oracle."""
     from tempestmodel_amd.engine import Engine
