@@ -1078,14 +1078,14 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 #undef ABW
 }
 
-// The same column update (implicit mode) with the level-parallel parts spread over four lanes per column: a workgroup = one
-// wavefront = 16 columns x 4 row lanes.  Row lane t of a column evaluates xi_dot, the matrix rows, the tracer loads, the
-// right-hand side and the result stores of the levels k = t, t + 4, ...; every matrix entry and every right-hand-side entry is
+// The same column update (implicit mode) with the level-parallel parts spread over NR row lanes per column: a workgroup =
+// 16 columns x NR row lanes.  Row lane t of a column evaluates xi_dot, the matrix rows, the tracer loads, the
+// right-hand side and the result stores of the levels k = t, t + NR, ...; every matrix entry and every right-hand-side entry is
 // formed by the lane that owns its row, in the order the sequential loops of k_vi_tracers accumulate it (flux terms, upwinding
 // of interface k then k + 1, 1/dt; velocity correction of interface k then k + 1), so the results are bit-identical; only the
-// factorisation and the two substitutions stay on one lane per column.  LDS: (8L + 2) x 16 doubles per workgroup, so that at
-// L = 30 five workgroups share a CU (one with the 64-column form).
-__global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
+// factorisation and the two substitutions stay on one lane per column (pivot row / running entries in registers, the
+// next row prefetched from LDS).  LDS: (9L + 3) x 16 doubles per workgroup, so that at L = 30 five workgroups share a CU.
+template <int NR> __global__ __launch_bounds__(NR * 16) void k_vi_tracers_rows(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
 	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag)
 {
 	constexpr int LW = 16;
@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 	double * xd0 = F + (size_t)L * LW;               // [L+1][LW]
 	double * xd1 = xd0 + (size_t)(L + 1) * LW;       // [L+1][LW]
 	double * qn = xd1 + (size_t)(L + 1) * LW;        // [L][LW]
+	double * jmp = qn + (size_t)L * LW;              // [L+1][LW] upwind sign x metric x (W updated - W initial) per interface
 	const int uraw = blockIdx.x * LW + lane;
 	const bool valid = uraw < nunique;
 	const int u = valid ? uraw : nunique - 1;        // lanes of a ragged last workgroup redo the last column (no stores): barriers below
@@ -1107,8 +1108,8 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 	// multiplier of step j, slots 1..3 of row j = row j of U (diagonal and the two entries right of it)
 #define AR(k_, s_) A[((size_t)(k_) * 4 + (s_)) * LW + lane]
 	// xi_dot on interfaces, initial and with the updated W (:3943-3957, :4059-4086)
-	for (int k = t; k <= L; k += 4) {
-		double x0v = 0.0, x1v = 0.0;
+	for (int k = t; k <= L; k += NR) {
+		double x0v = 0.0, x1v = 0.0, jv = 0.0;
 		if (k >= 1 && k <= L - 1) {
 			double ue = 0.0, ve = 0.0;
 #pragma unroll
@@ -1121,14 +1122,17 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 			}
 			double e0, e1, e2;
 			metric_edge(p, mc, k, col, e0, e1, e2);
-			x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)k * NS + col];
-			x1v = e0 * ue + e1 * ve + e2 * xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
+			const double wi = w0[(size_t)k * NS + col], wu = xup[(size_t)TMX_SLAB_W(L, k) * NS + col];
+			x0v = e0 * ue + e1 * ve + e2 * wi;
+			x1v = e0 * ue + e1 * ve + e2 * wu;
+			const double sw = (x0v > 0.0) ? 1.0 * e2 : ((x0v < 0.0) ? -1.0 * e2 : 0.0);
+			jv = sw * (wu - wi);
 		}
-		xd0[(size_t)k * LW + lane] = x0v; xd1[(size_t)k * LW + lane] = x1v;
+		xd0[(size_t)k * LW + lane] = x0v; xd1[(size_t)k * LW + lane] = x1v; jmp[(size_t)k * LW + lane] = jv;
 	}
 	__syncthreads();
 	// matrix rows (:3959-4016), each entry by the owner of its row
-	for (int k = t; k < L; k += 4) {
+	for (int k = t; k < L; k += NR) {
 #pragma unroll
 		for (int d = -1; d <= 1; d++) {
 			const int n = k + d;
@@ -1194,9 +1198,9 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 	for (int q = 0; q < 3; q++) dep[q] = udep ? udep[u * 3 + q] : -1;
 	for (int c = 0; c < nt; c++) {
 		__syncthreads();        // the previous tracer's stores have read F
-		for (int k = t; k < L; k += 4) qn[(size_t)k * LW + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+		for (int k = t; k < L; k += NR) qn[(size_t)k * LW + lane] = xin[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
 		__syncthreads();
-		for (int k = t; k < L; k += 4) {
+		for (int k = t; k < L; k += NR) {
 			// mass flux with the updated xi_dot, its divergence (:4092-4140)
 			double mf[2];
 #pragma unroll
@@ -1235,11 +1239,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 			for (int s_ = 0; s_ <= 1; s_++) {
 				const int a = k + s_;
 				if (a < 1 || a > L - 1) continue;
-				const double xa = xd0[(size_t)a * LW + lane];
-				double e0, e1, e2;
-				metric_edge(p, mc, a, col, e0, e1, e2);
-				const double sw = (xa > 0.0) ? 1.0 * e2 : ((xa < 0.0) ? -1.0 * e2 : 0.0);
-				const double jump = sw * (xup[(size_t)TMX_SLAB_W(L, a) * NS + col] - w0[(size_t)a * NS + col]);
+				const double jump = jmp[(size_t)a * LW + lane];
 				if (s_ == 0) {
 					f -= OPC(TMX_OP_PENALTY_RIGHT, a, -1) * qn[(size_t)(a - 1) * LW + lane] * jump;
 					f -= OPC(TMX_OP_PENALTY_RIGHT, a, 0) * qn[(size_t)a * LW + lane] * jump;
@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 		}
 		__syncthreads();
 		if (valid)
-			for (int k = t; k < L; k += 4) {
+			for (int k = t; k < L; k += NR) {
 				const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
 				const double val = xbase[so + col] - F[(size_t)k * LW + lane];
 				xup[so + col] = val;
@@ -1292,6 +1292,21 @@ __global__ __launch_bounds__(64) void k_vi_tracers_rows(KParams p, int nt, const
 	}
 	if (singular && valid) atomicExch(flag, 1);
 #undef AR
+}
+
+static size_t vt_rows_lds(int L) { return ((size_t)L * 4 + (size_t)L * 2 + (size_t)(L + 1) * 3) * 16 * sizeof(double); }
+// row lanes per column of k_vi_tracers_rows: 16 (four wavefronts per 16 columns) up to 48 levels, 32 above; TMX_VT_NR = 4 | 8 | 16 | 32
+static void launch_vt_rows(tmx_engine * e, const KParams & p, int ncols, const double * xin, const double * w0, const double * xbase, double * xup,
+	double dt, const int * ucol, const int * udep, size_t lds)
+{
+	static const int nr_env = getenv("TMX_VT_NR") ? atoi(getenv("TMX_VT_NR")) : 0;
+	const int nr = nr_env ? nr_env : (p.L > 48 ? 32 : 16);       // measured at ne30: L30 1.36 (16) / 1.49 (32) ms, L60 3.50 (16) / 3.25 (32) ms per step
+#define LAUNCH_VTR(NR_) do { \
+		hipFuncSetAttribute((const void *)k_vi_tracers_rows<NR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		hipLaunchKernelGGL(k_vi_tracers_rows<NR_>, dim3((ncols + 15) / 16), dim3(NR_ * 16), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
+			ncols, ucol, udep, e->d_flag); } while (0)
+	if (nr == 4) LAUNCH_VTR(4); else if (nr == 8) LAUNCH_VTR(8); else if (nr == 32) LAUNCH_VTR(32); else LAUNCH_VTR(16);
+#undef LAUNCH_VTR
 }
 
 // lanes per workgroup such that the LDS working set (8L + 2) x LW x 8 bytes fits one CU
@@ -1306,11 +1321,9 @@ static int vi_tracers_lanes(int L, size_t & lds) {
 int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
 	if (e->nunique == 0 || e->nt == 0) return 0;
 	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {      // default: 16 columns x 4 row lanes per workgroup
-		const size_t l2 = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 16 * sizeof(double);
+		const size_t l2 = vt_rows_lds(p.L);
 		if (l2 <= 160 * 1024) {
-			hipFuncSetAttribute((const void *)k_vi_tracers_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-			hipLaunchKernelGGL(k_vi_tracers_rows, dim3((e->nunique + 15) / 16), dim3(64), l2, e->stream, p, e->nt, xin, w0, xbase, xup, dt,
-				e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_flag);
+			launch_vt_rows(e, p, e->nunique, xin, w0, xbase, xup, dt, (const int *)e->d_ucol, (const int *)e->d_udep, l2);
 			return 0;
 		}
 	}
@@ -1483,11 +1496,9 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
 	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {
-		const size_t l2 = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * 16 * sizeof(double);
+		const size_t l2 = vt_rows_lds(p.L);
 		if (l2 <= 160 * 1024) {
-			hipFuncSetAttribute((const void *)k_vi_tracers_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-			hipLaunchKernelGGL(k_vi_tracers_rows, dim3((p.ncol + 15) / 16), dim3(64), l2, e->stream, p, e->nt, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS,
-				(const double *)xup, xup, dt, p.ncol, (const int *)nullptr, (const int *)nullptr, e->d_flag);
+			launch_vt_rows(e, p, p.ncol, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS, (const double *)xup, xup, dt, nullptr, nullptr, l2);
 			return 0;
 		}
 	}
