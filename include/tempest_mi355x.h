@@ -356,6 +356,21 @@ int tmx_device_count(void);
 int tmx_comm_unique_id(unsigned char id[128]);
 int tmx_comm_init(tmx_engine * e, const unsigned char id[128]);
 
+/* Peer-to-peer halo transport, an alternative to the RCCL send/recv of tmx_comm_init for the exchange of
+ * Connectivity.cpp:928-1120 / Grid.cpp:627-685: every rank keeps its ghost columns in a block that its neighbour ranks map
+ * through HIP IPC, the gather kernel of a rank writes its boundary columns straight into the neighbours' blocks (posted
+ * writes over xGMI, no send buffer, no collective), and an arrival counter per neighbour orders the two sides.
+ *   tmx_halo_p2p_blob_bytes: size of a rank's blob (the same on every rank of a layout);
+ *   tmx_halo_p2p_export:     allocate the block, write this rank's blob;
+ *   tmx_halo_p2p_connect:    blobs = the n_ranks blobs in rank order (gathered by the caller with whatever transport it has:
+ *                            the reference's MPI_Allgather, torch.distributed); maps the neighbours and switches the exchange over.
+ * Ranks are separate processes (a process cannot map its own export); they may share a device.  Before tmx_destroy the caller
+ * lets all ranks finish (a barrier): neighbours write into this rank's block.  A neighbour whose message does not arrive within
+ * 20 s makes the next tmx_sync return TMX_ERR_COMM instead of hanging the device. */
+int tmx_halo_p2p_blob_bytes(tmx_engine * e);
+int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob);
+int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs);
+
 /* ---- introspection for tests / bench --------------------------------------------------------- */
 
 enum {

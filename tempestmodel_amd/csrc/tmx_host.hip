@@ -194,6 +194,9 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
+		if (e->d_ghost_own) e->d_ghost = e->d_ghost_own;          // p2p mode pointed d_ghost into the shared block
+		for (void * q : e->p2p_peer) if (q) hipIpcCloseMemHandle(q);
+		free_dev(e->p2p_block); free_dev(e->d_p2p_dst); free_dev(e->d_p2p_flag); free_dev(e->d_send_peer); free_dev(e->d_send_within); free_dev(e->d_p2p_peers);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
 		if (e->stream) hipStreamDestroy(e->stream);
@@ -1569,6 +1572,8 @@ extern "C" int tmx_debug_loopback_group(tmx_engine ** engines, int n) {
 	return TMX_OK;
 }
 
+static size_t p2p_header_bytes(int n_ranks) { return (((size_t)2 * n_ranks * sizeof(unsigned long long)) + 255) / 256 * 256; }
+
 // Exchange of the boundary columns of instance x.  ONE message per neighbour rank (the reference aggregates its
 // ExchangeBuffers the same way, Connectivity.cpp:928-993): buffers are [peer][slab][count_peer], contiguous per peer.
 // The grouped send/recv runs on a second stream between two events, so that the DSS of the groups without remote
@@ -1581,14 +1586,28 @@ static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overla
 	// boundary; used only by tools/rank_share_timing.py to measure the per-rank compute share of a step)
 	static const bool skip = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
 	if (skip) { tmxk_pack(e, p, x); return TMX_OK; }
-	REQUIRE(e->comm, TMX_ERR_COMM, "tmx_comm_init must be called before a multi-rank exchange");
+	REQUIRE(e->comm || e->p2p, TMX_ERR_COMM, "tmx_comm_init or tmx_halo_p2p_connect must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
-	tmxk_pack(e, p, x);
+	const unsigned long long seq = ++e->p2p_seq;
+	const int buf = (int)(seq & 1);
+	if (e->p2p) tmxk_pack_p2p(e, p, x, buf); else tmxk_pack(e, p, x);
 	hipStream_t ws = e->stream;
 	if (overlapped && e->xstream) {
 		HIPCHK(hipEventRecord(e->ev_pack, e->stream));
 		HIPCHK(hipStreamWaitEvent(e->xstream, e->ev_pack, 0));
 		ws = e->xstream;
+	}
+	if (e->p2p) {
+		// the gather has written the neighbours' ghost buffers of this parity; say so and wait for theirs.  Two parities are
+		// enough: a neighbour writes parity b again only after its own averaging of the exchange in between, which needed this
+		// rank's message of that exchange, which this rank sent after the averaging that read parity b.
+		tmxk_p2p_signal_wait(e, ws, buf, seq);
+		e->d_ghost = (double *)((char *)e->p2p_block + p2p_header_bytes(e->cfg.n_ranks)) + (size_t)buf * e->nslab * e->nghost_pad;
+		if (ws != e->stream) {
+			HIPCHK(hipEventRecord(e->ev_recv, ws));
+			*overlapped = true;
+		}
+		return TMX_OK;
 	}
 	NCCLCHK(g_nccl.GroupStart());
 	for (int rk = 0; rk < e->cfg.n_ranks; rk++) {
@@ -2351,6 +2370,11 @@ extern "C" int tmx_sync(tmx_engine * e) {
 	prof_collect(e);
 	int flag = 0;
 	HIPCHK(hipMemcpy(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+	if (flag == 2) {
+		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+		tmx_set_error("halo exchange: a neighbour rank's message did not arrive within 20 s (peer-to-peer transport)");
+		return TMX_ERR_COMM;
+	}
 	if (flag) {
 		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
 		tmx_set_error("column solve failed: exactly singular band matrix (LAPACK dgbsv info > 0)");
@@ -2400,6 +2424,91 @@ extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
 			return TMX_ERR_DEVICE;
 		}
 	}
+	return TMX_OK;
+}
+
+// Peer-to-peer halo transport: instead of RCCL send/recv, every rank maps the ghost buffers of its neighbour ranks (HIP IPC)
+// and its gather kernel writes the boundary columns straight into them; an arrival counter per (parity, source rank) in the
+// same block orders the two sides.  Set-up: every rank exports a blob, the caller all-gathers the blobs (any transport: the
+// reference's MPI, torch.distributed) and hands all of them to tmx_halo_p2p_connect; before tmx_destroy the caller lets every
+// rank finish (a barrier), since neighbours write into this rank's block.  The reference's exchange this replaces:
+// Connectivity.cpp:928-1120 (ExchangeBuffer pack / MPI_Isend / MPI_Irecv / unpack), Grid.cpp:627-685.
+struct p2p_blob_head { hipIpcMemHandle_t handle; unsigned long long ghost_doubles; int n_ranks, rank; };
+
+extern "C" int tmx_halo_p2p_blob_bytes(tmx_engine * e) {
+	if (!e || !e->finalized) return -1;
+	return (int)(sizeof(p2p_blob_head) + sizeof(int) * (e->cfg.n_ranks + 1));
+}
+
+extern "C" int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(blob, TMX_ERR_INVALID, "tmx_halo_p2p_export: null blob");
+	REQUIRE(!plan_only(e) && e->cfg.n_ranks > 1 && !e->lb, TMX_ERR_INVALID, "tmx_halo_p2p_export needs a device engine of a multi-rank layout");
+	HIPCHK(hipSetDevice(e->device));
+	const size_t gd = (size_t)e->nslab * e->nghost_pad;
+	if (!e->p2p_block) {
+		e->p2p_block_bytes = p2p_header_bytes(e->cfg.n_ranks) + 2 * gd * sizeof(double);
+		// fine-grained: writes of other devices and the counters are visible without a cache flush on this side
+		HIPCHK(hipExtMallocWithFlags(&e->p2p_block, e->p2p_block_bytes, hipDeviceMallocFinegrained));
+		HIPCHK(hipMemset(e->p2p_block, 0, e->p2p_block_bytes));
+		HIPCHK(hipDeviceSynchronize());
+		e->hbm_bytes += e->p2p_block_bytes;
+	}
+	p2p_blob_head h;
+	memset(&h, 0, sizeof(h));
+	HIPCHK(hipIpcGetMemHandle(&h.handle, e->p2p_block));
+	h.ghost_doubles = gd; h.n_ranks = e->cfg.n_ranks; h.rank = e->cfg.rank;
+	memcpy(blob, &h, sizeof(h));
+	memcpy(blob + sizeof(h), e->recv_rank_off.data(), sizeof(int) * (e->cfg.n_ranks + 1));
+	return TMX_OK;
+}
+
+extern "C" int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(blobs && e->p2p_block, TMX_ERR_INVALID, "tmx_halo_p2p_connect: call tmx_halo_p2p_export first and pass the blobs of all ranks");
+	REQUIRE(!e->p2p, TMX_ERR_INVALID, "tmx_halo_p2p_connect: already connected");
+	const int NR = e->cfg.n_ranks, me = e->cfg.rank;
+	const size_t bb = (size_t)tmx_halo_p2p_blob_bytes(e), hb = p2p_header_bytes(NR);
+	HIPCHK(hipSetDevice(e->device));
+	e->p2p_peer.assign(NR, nullptr);
+	std::vector<double *> dst(2 * (size_t)NR, nullptr);
+	std::vector<unsigned long long *> flg(2 * (size_t)NR, nullptr);
+	std::vector<int> peers;
+	for (int rk = 0; rk < NR; rk++) {
+		p2p_blob_head h;
+		memcpy(&h, blobs + bb * rk, sizeof(h));
+		const int * roff = (const int *)(blobs + bb * rk + sizeof(h));
+		REQUIRE(h.n_ranks == NR && h.rank == rk, TMX_ERR_INVALID, "tmx_halo_p2p_connect: blob %d is from rank %d of %d", rk, h.rank, h.n_ranks);
+		const int ns = e->send_rank_off[rk + 1] - e->send_rank_off[rk], nr = e->recv_rank_off[rk + 1] - e->recv_rank_off[rk];
+		const int their = roff[me + 1] - roff[me];
+		REQUIRE(rk == me || their == ns, TMX_ERR_INVALID, "rank %d sends %d columns to rank %d which expects %d", me, ns, rk, their);
+		REQUIRE(rk == me || (ns > 0) == (nr > 0), TMX_ERR_INVALID, "halo between ranks %d and %d is one-sided (%d out, %d in)", me, rk, ns, nr);
+		if (rk == me || ns == 0) continue;
+		void * base = nullptr;
+		const hipError_t oe = hipIpcOpenMemHandle(&base, h.handle, hipIpcMemLazyEnablePeerAccess);
+		REQUIRE(oe == hipSuccess, TMX_ERR_COMM, "hipIpcOpenMemHandle of rank %d's halo block failed: %s (ranks of one process cannot map each other; "
+			"HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the driver only supports dmabuf IPC)", rk, hipGetErrorString(oe));
+		e->p2p_peer[rk] = base;
+		peers.push_back(rk);
+		for (int b = 0; b < 2; b++) {
+			dst[(size_t)b * NR + rk] = (double *)((char *)base + hb) + (size_t)b * h.ghost_doubles + (size_t)e->nslab * roff[me];
+			flg[(size_t)b * NR + rk] = (unsigned long long *)base + (size_t)b * NR + me;
+		}
+	}
+	std::vector<int> sp(e->nsend), sw(e->nsend);
+	for (int rk = 0; rk < NR; rk++)
+		for (int t = e->send_rank_off[rk]; t < e->send_rank_off[rk + 1]; t++) { sp[t] = rk; sw[t] = t - e->send_rank_off[rk]; }
+	size_t bytes = 0;
+	if ((r = dev_upload(&e->d_p2p_dst, dst, &bytes)) || (r = dev_upload(&e->d_p2p_flag, flg, &bytes)) || (r = dev_upload(&e->d_send_peer, sp, &bytes))
+		|| (r = dev_upload(&e->d_send_within, sw, &bytes)) || (r = dev_upload(&e->d_p2p_peers, peers, &bytes))) return r;
+	e->hbm_bytes += bytes;
+	e->p2p_npeers = (int)peers.size();
+	if (!e->xstream && !getenv("TMX_NO_EXCHANGE_OVERLAP")) {
+		if (hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking) != hipSuccess) e->xstream = nullptr;
+		else { hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming); hipEventCreateWithFlags(&e->ev_recv, hipEventDisableTiming); }
+	}
+	e->d_ghost_own = e->d_ghost;
+	e->p2p = true;
 	return TMX_OK;
 }
 

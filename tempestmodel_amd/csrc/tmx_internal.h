@@ -121,6 +121,17 @@ struct tmx_engine {
 	int * d_ghost_base = nullptr, * d_ghost_stride = nullptr;
 	int nsend = 0, nghost_pad = 0;
 	std::vector<int> send_rank_off, recv_rank_off;   // per-rank offsets (size n_ranks+1)
+	// peer-to-peer halo transport (tmx_halo_p2p_*): this rank's ghost columns live twice (alternating per exchange) in a
+	// fine-grained block that the neighbour ranks map through HIP IPC and write into directly; [2][n_ranks] arrival counters lead it
+	bool p2p = false;
+	void * p2p_block = nullptr; size_t p2p_block_bytes = 0;
+	std::vector<void *> p2p_peer;             // mapped blocks of the other ranks (nullptr = not a neighbour)
+	double ** d_p2p_dst = nullptr;            // [2][n_ranks] where my message to rank r starts in r's ghost buffer b
+	unsigned long long ** d_p2p_flag = nullptr;   // [2][n_ranks] my arrival counter in rank r's block
+	int * d_send_peer = nullptr, * d_send_within = nullptr;    // [nsend] destination rank of send entry i, its index within the message
+	int * d_p2p_peers = nullptr; int p2p_npeers = 0;     // neighbour ranks
+	unsigned long long p2p_seq = 0;
+	double * d_ghost_own = nullptr;
 	// implicit solve
 	int nunique = 0, NUS = 0;
 	int * d_ucol = nullptr;                  // [nunique]
@@ -181,6 +192,8 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	double dt, double nu_s, double nu_d, double nu_v, int scale_locally);
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
+void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf);
+void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq);
 void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
 void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt);
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);

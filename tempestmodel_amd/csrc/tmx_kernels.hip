@@ -1844,6 +1844,53 @@ void tmxk_pack(tmx_engine * e, const KParams & p, const double * x) {
 		x, (const int *)e->d_send_cols, (const int *)e->d_send_base, (const int *)e->d_send_stride, e->d_sendbuf);
 }
 
+// Peer-to-peer transport (tmx_halo_p2p_connect): the same gather, written straight into the neighbour ranks' ghost buffers
+// (mapped through HIP IPC; over xGMI these are posted writes).  dst[peer] = where this rank's message starts in the peer's
+// buffer of the current parity; within a message the wire layout is the one above, [slab][count_peer].
+__global__ __launch_bounds__(256) void k_pack_p2p(int nslab, size_t NS, int nsend,
+	const double * __restrict__ x, const int * __restrict__ cols, const int * __restrict__ within,
+	const int * __restrict__ stride, const int * __restrict__ peer, double * const * __restrict__ dst)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int sl = blockIdx.y;
+	if (i >= nsend) return;
+	dst[peer[i]][(size_t)sl * stride[i] + within[i]] = x[(size_t)sl * NS + cols[i]];
+}
+
+// After the messages: raise this rank's arrival counter in every neighbour's block to seq (release, system scope: the
+// preceding kernel's writes are complete at its end), then wait until every neighbour has raised its counter here.  A
+// neighbour that never arrives (a rank died) sets the engine's failure flag after 20 s instead of hanging the GPU.
+__global__ __launch_bounds__(64) void k_p2p_signal_wait(int npeers, const int * __restrict__ peers, unsigned long long * const * __restrict__ flag_dst,
+	const unsigned long long * own, unsigned long long seq, int * __restrict__ fail)
+{
+	for (int q = threadIdx.x; q < npeers; q += 64) {
+		__threadfence_system();
+		__hip_atomic_store(flag_dst[peers[q]], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	for (int q = threadIdx.x; q < npeers; q += 64) {
+		const unsigned long long t0 = wall_clock64();
+		while (__hip_atomic_load(own + peers[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+			__builtin_amdgcn_s_sleep(8);
+			if (wall_clock64() - t0 > 2000000000ull) { atomicExch(fail, 2); break; }      // 100 MHz counter
+		}
+	}
+	__threadfence_system();
+}
+
+void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf) {
+	if (e->nsend == 0) return;
+	dim3 blk(256), grd((e->nsend + 255) / 256, e->nslab);
+	hipLaunchKernelGGL(k_pack_p2p, grd, blk, 0, e->stream, e->nslab, (size_t)p.NS, e->nsend,
+		x, (const int *)e->d_send_cols, (const int *)e->d_send_within, (const int *)e->d_send_stride, (const int *)e->d_send_peer,
+		(double * const *)(e->d_p2p_dst + (size_t)buf * e->cfg.n_ranks));
+}
+
+void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq) {
+	hipLaunchKernelGGL(k_p2p_signal_wait, dim3(1), dim3(64), 0, s, e->p2p_npeers, (const int *)e->d_p2p_peers,
+		(unsigned long long * const *)(e->d_p2p_flag + (size_t)buf * e->cfg.n_ranks),
+		(const unsigned long long *)e->p2p_block + (size_t)buf * e->cfg.n_ranks, seq, e->d_flag);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Hyperviscosity pass: scalar Laplacian of rho*theta, W, rho and vector Laplacian of (U,V)
 // (ApplyScalarHyperdiffusion / ApplyVectorHyperdiffusion / ComputeCurlAndDiv,

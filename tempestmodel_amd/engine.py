@@ -122,6 +122,9 @@ def load_library():
     lib.tmx_upload_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_download_tracers.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
     lib.tmx_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.tmx_halo_p2p_blob_bytes.argtypes = [C.c_void_p]
+    lib.tmx_halo_p2p_export.argtypes = [C.c_void_p, C.c_char_p]
+    lib.tmx_halo_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     _lib = lib
     return lib
@@ -487,6 +490,22 @@ class Engine:
         a = np.zeros(max(n, 1), dtype=np.float64)
         self.lib.tmx_plan_get_matrices(self.h, _pd(a), n)
         return a[:n].reshape(-1, 4, 4, 2, 2)      # [cross group][member m][partner q][2x2]
+
+    def halo_p2p_export(self):
+        """This rank's blob for the peer-to-peer halo transport (tmx_halo_p2p_export)."""
+        n = self.lib.tmx_halo_p2p_blob_bytes(self.h)
+        if n <= 0:
+            raise RuntimeError("tmx_halo_p2p_blob_bytes failed")
+        buf = C.create_string_buffer(n)
+        self._chk(self.lib.tmx_halo_p2p_export(self.h, buf))
+        return buf.raw
+
+    def halo_p2p_connect(self, blobs):
+        """blobs: the blobs of all ranks in rank order (all-gathered by the caller)."""
+        n = self.lib.tmx_halo_p2p_blob_bytes(self.h)
+        if len(blobs) != self.n_ranks or any(len(b) != n for b in blobs):
+            raise ValueError("halo_p2p_connect needs one %d-byte blob per rank" % n)
+        self._chk(self.lib.tmx_halo_p2p_connect(self.h, b"".join(blobs)))
 
     def comm_init(self, unique_id):
         self._chk(self.lib.tmx_comm_init(self.h, unique_id))

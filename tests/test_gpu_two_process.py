@@ -1,0 +1,70 @@
+"""Real rank-to-rank halo exchange on the device: every rank is its own process with its own engine, the boundary columns
+travel through the peer-to-peer transport (tmx_halo_p2p_*: HIP IPC mapped ghost buffers, arrival counters), and the ranks'
+results after whole steps of the production program are bit-identical to one engine holding all patches.  The ranks share
+HIP device 0, so this runs on a 1-GPU box (RCCL refuses two ranks on one device; the transport under test has no such limit)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "workers", "p2p_rank.py")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _run_ranks(world, scheme, ntr, steps, out):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out, scheme, str(ntr), str(steps)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, _ = p.communicate()
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+
+
+@pytest.mark.parametrize("world,scheme,ntr", [(2, "ars343", 0), (4, "ars343", 2), (3, "strang", 0)])
+def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr):
+    from tempestmodel_amd.engine import Engine
+    steps = 3
+    g, st = gu.make_grid(4, 6, 24, ntracers=ntr)
+    single = Engine(g)
+    try:
+        single.upload_state(0, st)
+        if ntr:
+            single.upload_tracers(0, [g.initial_tracers[P.index] for P in g.patches])
+        for k in range(steps):
+            single.step(scheme, 200.0, first=(k == 0))
+        single.sync()
+        ref = single.download_state(0)
+        reft = single.download_tracers(0) if ntr else None
+    finally:
+        single.close()
+    with tempfile.TemporaryDirectory() as out:
+        _run_ranks(world, scheme, ntr, steps, out)
+        seen = set()
+        for r in range(world):
+            d = np.load(os.path.join(out, "rank%d.npz" % r))
+            for key in d.files:
+                if key[0] != "n":
+                    continue
+                p = int(key[1:]); seen.add(p)
+                assert np.array_equal(d["n%d" % p][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), (r, p)
+                assert np.array_equal(d["e%d" % p][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), (r, p)
+                if ntr:
+                    assert np.array_equal(d["t%d" % p][:, 1:-1, 1:-1], reft[p][:, 1:-1, 1:-1]), (r, p)
+        assert seen == set(range(24))
