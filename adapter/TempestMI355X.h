@@ -191,13 +191,22 @@ public:
 
 	~MI355XEngine() {
 		if (m_pEngine != NULL) {
+#ifdef TEMPEST_MPIOMP
+			// peer-to-peer transport: the neighbour ranks write into this rank's block until they have finished
+			int fFinalized = 0;
+			MPI_Finalized(&fFinalized);
+			if (m_fPeerToPeer && !fFinalized) {
+				tmx_sync(m_pEngine);
+				MPI_Barrier(MPI_COMM_WORLD);
+			}
+#endif
 			tmx_destroy(m_pEngine);
 		}
 	}
 
 private:
 	MI355XEngine(Model & model) :
-		m_model(model), m_pEngine(NULL),
+		m_model(model), m_pEngine(NULL), m_fPeerToPeer(false),
 		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4), m_fFullyExplicit(false),
 		m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fHostNewer(true), m_fDeviceNewer(false), m_nCarried(1)
 	{ }
@@ -472,7 +481,18 @@ private:
 		}
 
 #ifdef TEMPEST_MPIOMP
-		if (nRanks > 1) {
+		const char * szHalo = getenv("TMX_HALO");
+		if ((nRanks > 1) && (szHalo != NULL) && (std::string(szHalo) == "p2p")) {
+			// peer-to-peer transport: every rank's blob to every rank, then map the neighbours (the ranks may share a device)
+			const int nBlob = tmx_halo_p2p_blob_bytes(m_pEngine);
+			std::vector<unsigned char> vecMine(nBlob), vecAll((size_t)nBlob * nRanks);
+			Check(tmx_halo_p2p_export(m_pEngine, &(vecMine[0])));
+			MPI_Allgather(&(vecMine[0]), nBlob, MPI_BYTE, &(vecAll[0]), nBlob, MPI_BYTE, MPI_COMM_WORLD);
+			Check(tmx_halo_p2p_connect(m_pEngine, &(vecAll[0])));
+			MPI_Barrier(MPI_COMM_WORLD);
+			m_fPeerToPeer = true;
+
+		} else if (nRanks > 1) {
 			unsigned char id[128];
 			if (nRank == 0) {
 				Check(tmx_comm_unique_id(id));
@@ -486,6 +506,7 @@ private:
 private:
 	Model & m_model;
 	tmx_engine * m_pEngine;
+	bool m_fPeerToPeer;
 	double m_dNuScalar, m_dNuDiv, m_dNuVort;
 	int m_nHypervisOrder;
 	bool m_fFullyExplicit;

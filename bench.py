@@ -178,6 +178,10 @@ def main():
     ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
+    ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "rccl"), choices=["rccl", "p2p"],
+                    help="multi-rank halo transport: RCCL send/recv (default) or peer-to-peer writes into IPC-mapped ghost buffers")
+    ap.add_argument("--share-device", action="store_true",
+                    help="all ranks on HIP device 0 (1-GPU box; needs --halo p2p, host rendezvous over gloo): exercises the multi-process path, not a scaling number")
     ap.add_argument("--physics", default="none", help="hs: tmx_physics_held_suarez after every step (BASELINE config 5's shape; not the headline metric)")
     args = ap.parse_args()
 
@@ -190,10 +194,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.share_device:
+        if world > 1 and args.halo != "p2p":
+            sys.exit("--share-device needs --halo p2p (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import golden_util as gu
     from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
@@ -203,7 +214,12 @@ def main():
     grid = CubedSphereGrid(ne, L, 30000.0, ppd=args.ppd)
     states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
     eng = Engine(grid, rank=rank, n_ranks=world, device=local_rank)
-    if world > 1:
+    if world > 1 and args.halo == "p2p":
+        blobs = [None] * world
+        dist.all_gather_object(blobs, eng.halo_p2p_export())
+        eng.halo_p2p_connect(blobs)
+        dist.barrier()
+    elif world > 1:
         if rank == 0:
             uid = torch.tensor(list(Engine.comm_unique_id()), dtype=torch.uint8, device="cuda")
         else:
@@ -253,7 +269,7 @@ def main():
     pivot = eng.pivot_stats(False)
     eng.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.share_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
@@ -304,7 +320,9 @@ def main():
             "config": {"workload": "Jablonowski-Williamson baroclinic wave, cubed sphere ne%d np4 L%d, ztop 30 km, "
                                    "ARS343 dt=%gs, hyperviscosity order 4, %d patches" % (ne, L, dt, len(grid.patches)),
                        "elements": n_el, "dof_per_step": dof_per_step, "dt_s": dt,
-                       "parallelism": "%d patches over %d GPU(s), halo exchange = RCCL send/recv" % (len(grid.patches), world),
+                       "parallelism": "%d patches over %d %s, halo exchange = %s" % (
+                           len(grid.patches), world, "processes sharing ONE GPU (multi-process path check, not a scaling number)" if args.share_device and world > 1 else "GPU(s)",
+                           "peer-to-peer writes into IPC-mapped ghost buffers" if args.halo == "p2p" and world > 1 else "RCCL send/recv"),
                        "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -332,6 +350,8 @@ def main():
             if allc is not None:
                 out["cpu_baseline_allcores"] = allc
         print(json.dumps(out))
+    if world > 1:
+        dist.barrier()        # peer-to-peer transport: neighbours write into this rank's block until they are done
     eng.close()
     if world > 1:
         dist.destroy_process_group()

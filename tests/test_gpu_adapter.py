@@ -77,3 +77,24 @@ def test_reference_driver_with_adapter_plugins(mode, args):
     # the metric factors read from the reference's own grid objects reproduce its arrays bit for bit
     if "sw2" not in args:       # the shallow-water set has no 3-D metric
         assert "verified bit for bit): active" in r.stdout, tail
+
+
+@pytest.mark.parametrize("nranks,args", [
+    (2, ["--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
+    (4, ["--tracers", "2", "--ne", "4", "--levels", "6", "--steps", "3", "--patches", "24"]),
+    (3, ["--scheme", "strang", "--ne", "4", "--levels", "6", "--steps", "3", "--patches", "6"]),
+])
+def test_reference_driver_under_mpi_with_peer_to_peer_halo(nranks, args):
+    """The reference's own MPI run (mpiexec, its patches spread over the ranks, its exchange over MPI) against the adapter in
+    the same processes with the halo on the device (TMX_HALO=p2p: the ranks share the one GPU of the box, their engines
+    exchange through IPC-mapped ghost buffers): every rank reports a zero difference on the patches it owns."""
+    import shutil
+    mpiexec = next((c for c in ("/opt/conda/bin/mpiexec", "mpiexec") if shutil.which(c)), None)
+    if not os.path.exists(BIN) or mpiexec is None:
+        pytest.skip("needs oracle/_ref/tmx_adapter_run and mpiexec")
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", TMX_HALO="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([mpiexec, "-np", str(nranks), BIN, "--mode", "production", "--dt", "200", "--warm", "1", "--tol", "1e-300"] + args,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-24:])
+    print(tail)
+    assert r.returncode == 0 and r.stdout.count("ADAPTER_OK") == nranks and "ADAPTER_MISMATCH" not in r.stdout, tail
