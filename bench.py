@@ -178,8 +178,10 @@ def main():
     ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
-    ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "rccl"), choices=["rccl", "p2p"],
-                    help="multi-rank halo transport: RCCL send/recv (default) or peer-to-peer writes into IPC-mapped ghost buffers")
+    ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "auto"), choices=["auto", "rccl", "p2p"],
+                    help="multi-rank halo transport: RCCL send/recv, peer-to-peer writes into IPC-mapped ghost buffers, or (default) "
+                         "set up both, check that they deliver identical bytes, time them on this machine and keep the faster; "
+                         "falls back to RCCL when the peer-to-peer mapping cannot be set up or disagrees")
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks on HIP device 0 (1-GPU box; needs --halo p2p, host rendezvous over gloo): exercises the multi-process path, not a scaling number")
     ap.add_argument("--physics", default="none", help="hs: tmx_physics_held_suarez after every step (BASELINE config 5's shape; not the headline metric)")
@@ -195,8 +197,11 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
     if args.share_device:
-        if world > 1 and args.halo != "p2p":
+        if world > 1 and args.halo == "rccl":
             sys.exit("--share-device needs --halo p2p (RCCL refuses two ranks on one device)")
+        # TMX_BENCH_AUTO_SELFTEST=1 walks the start-up comparison of --halo auto on a 1-GPU box: "RCCL" is then the
+        # peer-to-peer transport again (there is no second device to give RCCL), so only the bench's own logic is exercised
+        args.halo = "auto" if os.environ.get("TMX_BENCH_AUTO_SELFTEST") == "1" and args.halo == "auto" else "p2p"
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -214,18 +219,92 @@ def main():
     grid = CubedSphereGrid(ne, L, 30000.0, ppd=args.ppd)
     states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
     eng = Engine(grid, rank=rank, n_ranks=world, device=local_rank)
-    if world > 1 and args.halo == "p2p":
-        blobs = [None] * world
-        dist.all_gather_object(blobs, eng.halo_p2p_export())
-        eng.halo_p2p_connect(blobs)
-        dist.barrier()
-    elif world > 1:
-        if rank == 0:
-            uid = torch.tensor(list(Engine.comm_unique_id()), dtype=torch.uint8, device="cuda")
+    halo_note = "RCCL send/recv"
+    if world > 1:
+        hdev = "cpu" if args.share_device else "cuda"
+
+        def agree(flag):          # 1 only if every rank says 1
+            t = torch.tensor([int(flag)], dtype=torch.int32, device=hdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        if args.halo in ("rccl", "auto") and not args.share_device:
+            if rank == 0:
+                uid = torch.tensor(list(Engine.comm_unique_id()), dtype=torch.uint8, device="cuda")
+            else:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            eng.comm_init(bytes(uid.cpu().tolist()))
+        p2p_ok, why = False, ""
+        if args.halo in ("p2p", "auto"):
+            try:
+                blob = eng.halo_p2p_export()
+            except Exception as ex:
+                blob, why = None, str(ex)
+            blobs = [None] * world
+            dist.all_gather_object(blobs, blob)
+            ok = all(b is not None for b in blobs)
+            if ok:
+                try:
+                    eng.halo_p2p_connect(blobs)
+                except Exception as ex:
+                    ok, why = False, str(ex)
+            p2p_ok = agree(ok)
+            dist.barrier()
+            if args.halo == "p2p" and not p2p_ok:
+                sys.exit("--halo p2p: the peer-to-peer mapping could not be set up on every rank (%s)" % why)
+            if p2p_ok:
+                halo_note = "peer-to-peer writes into IPC-mapped ghost buffers"
+            elif ok:
+                eng.halo_p2p_enable(False)
+    eng.upload_state(0, states)
+    if world > 1 and args.halo == "auto" and p2p_ok:
+        # both transports are up: same bytes?  which is faster here?  (instance 1 is scratch until the first step)
+        import numpy as np
+
+        enable = (lambda on: eng.halo_p2p_enable(True)) if args.share_device else eng.halo_p2p_enable
+
+        def dss_result(p2p):
+            enable(p2p)
+            eng.copy_data(0, 1)
+            eng.apply_dss(1)
+            eng.sync()
+            got = eng.download_state(1)
+            return [got[p] for p in eng.local_patches]
+
+        def dss_time(p2p, n=20):
+            enable(p2p)
+            for _ in range(3):
+                eng.apply_dss(1)
+            eng.sync(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.apply_dss(1)
+            eng.sync(); dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / n], dtype=torch.float64, device=hdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        try:
+            a, b = dss_result(True), dss_result(False)
+            same = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+        except Exception as ex:
+            same, why = False, str(ex)
+        if not agree(same):
+            enable(False)
+            halo_note = "RCCL send/recv (auto: the peer-to-peer transport was set up but did not reproduce RCCL's bytes: %s)" % why
+            if rank == 0:
+                sys.stderr.write("bench: peer-to-peer halo disagrees with RCCL, using RCCL\n")
         else:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
-        eng.comm_init(bytes(uid.cpu().tolist()))
+            t_p2p, t_rccl = dss_time(True), dss_time(False)
+            use_p2p = t_p2p <= t_rccl
+            enable(use_p2p)
+            halo_note = "%s (auto: one DSS incl. exchange takes %.1f us peer-to-peer, %.1f us with RCCL send/recv; identical bytes%s)" % (
+                "peer-to-peer writes into IPC-mapped ghost buffers" if use_p2p else "RCCL send/recv", 1e6 * t_p2p, 1e6 * t_rccl,
+                "; SELF-TEST of this comparison on one device: both legs are the peer-to-peer transport" if args.share_device else "")
+        eng.upload_state(0, states)
+    elif world > 1 and args.halo == "auto":
+        halo_note = "RCCL send/recv (auto: peer-to-peer mapping not available: %s)" % why[:200]
     eng.upload_state(0, states)
 
     hs = (args.physics == "hs")
@@ -322,7 +401,7 @@ def main():
                        "elements": n_el, "dof_per_step": dof_per_step, "dt_s": dt,
                        "parallelism": "%d patches over %d %s, halo exchange = %s" % (
                            len(grid.patches), world, "processes sharing ONE GPU (multi-process path check, not a scaling number)" if args.share_device and world > 1 else "GPU(s)",
-                           "peer-to-peer writes into IPC-mapped ghost buffers" if args.halo == "p2p" and world > 1 else "RCCL send/recv"),
+                           halo_note),
                        "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

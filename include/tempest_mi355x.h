@@ -370,6 +370,9 @@ int tmx_comm_init(tmx_engine * e, const unsigned char id[128]);
 int tmx_halo_p2p_blob_bytes(tmx_engine * e);
 int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob);
 int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs);
+/* With both transports set up (tmx_comm_init and tmx_halo_p2p_connect): on = 1 peer-to-peer, on = 0 RCCL.  Every rank
+ * switches at the same point of its program (bench.py times one against the other at start-up and keeps the faster). */
+int tmx_halo_p2p_enable(tmx_engine * e, int on);
 
 /* ---- introspection for tests / bench --------------------------------------------------------- */
 

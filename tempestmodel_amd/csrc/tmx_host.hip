@@ -2466,7 +2466,7 @@ extern "C" int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob) {
 extern "C" int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs) {
 	int r; if ((r = check_ready(e))) return r;
 	REQUIRE(blobs && e->p2p_block, TMX_ERR_INVALID, "tmx_halo_p2p_connect: call tmx_halo_p2p_export first and pass the blobs of all ranks");
-	REQUIRE(!e->p2p, TMX_ERR_INVALID, "tmx_halo_p2p_connect: already connected");
+	REQUIRE(!e->p2p_connected, TMX_ERR_INVALID, "tmx_halo_p2p_connect: already connected");
 	const int NR = e->cfg.n_ranks, me = e->cfg.rank;
 	const size_t bb = (size_t)tmx_halo_p2p_blob_bytes(e), hb = p2p_header_bytes(NR);
 	HIPCHK(hipSetDevice(e->device));
@@ -2509,6 +2509,20 @@ extern "C" int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs)
 	}
 	e->d_ghost_own = e->d_ghost;
 	e->p2p = true;
+	e->p2p_connected = true;
+	return TMX_OK;
+}
+
+// Switch between the two transports of a connected engine (both set up: tmx_comm_init and tmx_halo_p2p_connect), e.g. to time
+// them against each other at start-up.  Every rank must switch at the same point of the program, with no exchange in flight.
+extern "C" int tmx_halo_p2p_enable(tmx_engine * e, int on) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(e->p2p_connected, TMX_ERR_INVALID, "tmx_halo_p2p_enable: tmx_halo_p2p_connect first");
+	REQUIRE(on || e->comm, TMX_ERR_INVALID, "tmx_halo_p2p_enable(0): no RCCL communicator to fall back to (tmx_comm_init)");
+	HIPCHK(hipStreamSynchronize(e->stream));
+	if (e->xstream) HIPCHK(hipStreamSynchronize(e->xstream));
+	e->p2p = on != 0;
+	if (!e->p2p) e->d_ghost = e->d_ghost_own;
 	return TMX_OK;
 }
 

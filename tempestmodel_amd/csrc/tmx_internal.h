@@ -123,7 +123,7 @@ struct tmx_engine {
 	std::vector<int> send_rank_off, recv_rank_off;   // per-rank offsets (size n_ranks+1)
 	// peer-to-peer halo transport (tmx_halo_p2p_*): this rank's ghost columns live twice (alternating per exchange) in a
 	// fine-grained block that the neighbour ranks map through HIP IPC and write into directly; [2][n_ranks] arrival counters lead it
-	bool p2p = false;
+	bool p2p = false, p2p_connected = false;
 	void * p2p_block = nullptr; size_t p2p_block_bytes = 0;
 	std::vector<void *> p2p_peer;             // mapped blocks of the other ranks (nullptr = not a neighbour)
 	double ** d_p2p_dst = nullptr;            // [2][n_ranks] where my message to rank r starts in r's ghost buffer b

@@ -68,3 +68,21 @@ def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr):
                 if ntr:
                     assert np.array_equal(d["t%d" % p][:, 1:-1, 1:-1], reft[p][:, 1:-1, 1:-1]), (r, p)
         assert seen == set(range(24))
+
+
+def test_bench_runs_as_two_rank_processes_on_one_device():
+    """bench.py under torch.distributed.run with two ranks (the driver's multi-GPU launch line), both on device 0 with the
+    peer-to-peer halo; TMX_BENCH_AUTO_SELFTEST walks the start-up comparison of `--halo auto` as well."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMX_BENCH_AUTO_SELFTEST="1")
+    env.pop("TMX_HALO", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--develop", "1", "--ne", "8", "--levels", "6", "--dt", "500", "--share-device", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=400, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert "identical bytes" in d["config"]["parallelism"], d["config"]["parallelism"]
