@@ -1471,13 +1471,139 @@ __global__ __launch_bounds__(256) void k_v_tracers_explicit(KParams p, int nt, c
 	}
 }
 
+// The same update with the shared operands of a tile staged once in LDS: a workgroup = 64 columns x 8 levels; xi_dot (and, with
+// uniform diffusion, rho) on the tile's 9 interfaces, rho on its 12 levels and per tracer the 12 column values and mixing-ratio
+// deviations (two fp64 divisions each) are evaluated by one thread each instead of by every thread whose stencil reaches them
+// (5 x for the divisions: 372 -> 264 us per launch at ne30 L40 with three tracers).  Every value is produced by the same expression as above, so the results are bit-identical.
+__global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int nt, const double * __restrict__ xin, double * xup, double dt,
+	double ks, const double * __restrict__ xref)
+{
+	constexpr int KT = 8, NL = KT + 4, NI = KT + 1;
+	__shared__ double s_xd[NI][64], s_re[NI][64], s_rh[NL][64], s_rr[NL][64], s_q[NL][64], s_mr[NL][64];
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int tx = threadIdx.x, y = WAVE_UNIFORM(threadIdx.y);
+	const int col = blockIdx.x * 64 + tx;
+	const int k0 = blockIdx.y * KT, k = k0 + y;
+	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	{
+		const MetCol mc = met_col(p, col);
+		for (int mi = y; mi < NI; mi += KT) {
+			const int m = k0 + mi;
+			double x0v = 0.0, re = 0.0;
+			if (m >= 1 && m <= L - 1) {
+				double ue = 0.0, ve = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+					ue += cc * xin[(size_t)TMX_SLAB_U(L, l) * NS + col];
+					ve += cc * xin[(size_t)TMX_SLAB_V(L, l) * NS + col];
+				}
+				double e0, e1, e2;
+				metric_edge(p, mc, m, col, e0, e1, e2);
+				x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)m * NS + col];
+			}
+			if (ks != 0.0 && m <= L) {
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					re += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * xin[(size_t)TMX_SLAB_R(L, l) * NS + col];
+				}
+			}
+			s_xd[mi][tx] = x0v; s_re[mi][tx] = re;
+		}
+		for (int li = y; li < NL; li += KT) {
+			const int l = k0 - 2 + li;
+			double a = 1.0, b = 1.0;
+			if (ks != 0.0 && l >= 0 && l < L) { a = xin[(size_t)TMX_SLAB_R(L, l) * NS + col]; b = xref[(size_t)TMX_SLAB_R(L, l) * NS + col]; }
+			s_rh[li][tx] = a; s_rr[li][tx] = b;
+		}
+	}
+	for (int c = 0; c < nt; c++) {
+		__syncthreads();           // first pass: the staging above; later passes: the previous tracer's reads of s_q / s_mr
+		for (int li = y; li < NL; li += KT) {
+			const int l = k0 - 2 + li;
+			double qv = 0.0, mr = 0.0;
+			if (l >= 0 && l < L) {
+				qv = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+				if (ks != 0.0) {
+					double a_ = qv / s_rh[li][tx];
+					a_ -= xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col] / s_rr[li][tx];
+					mr = a_;
+				}
+			}
+			s_q[li][tx] = qv; s_mr[li][tx] = mr;
+		}
+		__syncthreads();
+		if (k >= L || col >= p.ncol) continue;
+		auto qn = [&](int l) -> double { return s_q[l - k0 + 2][tx]; };
+		auto mixr = [&](int l) -> double { return s_mr[l - k0 + 2][tx]; };
+		double mf[2];
+#pragma unroll
+		for (int mo = 0; mo <= 1; mo++) {
+			const int m = k + mo;
+			double qe = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * qn(l);
+			}
+			mf[mo] = (m == 0 || m == L) ? 0.0 : je * qe * s_xd[y + mo][tx];
+			if (ks != 0.0 && m > 0 && m < L) {
+				double dq = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mixr(l);
+				}
+				mf[mo] -= ks * s_re[y + mo][tx] * dq;
+			}
+		}
+		double dmf = 0.0;
+		dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[0];
+		dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[1];
+		double F = dmf / jn;
+		double aux = 0.0;
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * qn(k);
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * qn(k + 1);
+			aux += b * fabs(s_xd[y + 1][tx]);
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * qn(k - 1);
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * qn(k);
+			aux += b * fabs(s_xd[y][tx]);
+		}
+		F -= aux;
+		const double idt = 1.0 / dt;
+		if (F != 0.0) F /= idt;
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
+		xup[so + col] = xup[so + col] - F;
+	}
+}
+
 // UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
 	if (!getenv("TMX_VT_COLUMN")) {      // level-parallel form (default); TMX_VT_COLUMN=1: the one-lane-per-column kernel, for A/B and tests
-		dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-		hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
-			e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+		const bool v1 = getenv("TMX_VT_EXPLICIT_V1") != nullptr;       // the form without LDS staging, for A/B and tests
+		if (v1) {
+			dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+			hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
+				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+		} else {
+			dim3 blk(64, 8), grd(p.NS / 64, (p.L + 7) / 8);
+			hipLaunchKernelGGL(k_v_tracers_explicit_tile, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
+				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+		}
 		return 0;
 	}
 	size_t lds; const int lw = vi_tracers_lanes(p.L, lds);

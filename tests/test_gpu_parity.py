@@ -325,11 +325,11 @@ def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_ke
     st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
     for ud in (UDIFF, None):
         out = []
-        for column in (False, True):
-            if column:
-                monkeypatch.setenv("TMX_VT_COLUMN", "1")
-            else:
-                monkeypatch.delenv("TMX_VT_COLUMN", raising=False)
+        for variant in (None, "TMX_VT_COLUMN", "TMX_VT_EXPLICIT_V1"):      # LDS-tiled (default), one lane per column, untiled
+            monkeypatch.delenv("TMX_VT_COLUMN", raising=False)
+            monkeypatch.delenv("TMX_VT_EXPLICIT_V1", raising=False)
+            if variant:
+                monkeypatch.setenv(variant, "1")
             e = Engine(g, fully_explicit=True, uniform_diffusion=ud)
             try:
                 e.upload_state(0, st); e.upload_tracers(0, tr)
@@ -339,8 +339,9 @@ def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_ke
                 out.append((e.download_state(1), e.download_tracers(1)))
             finally:
                 e.close()
-        assert max(gu.tracer_errors(out[0][1], out[1][1])) == EXACT
-        assert max(gu.prognostic_errors(out[0][0], out[1][0])) == EXACT
+        for other in out[1:]:
+            assert max(gu.tracer_errors(out[0][1], other[1])) == EXACT
+            assert max(gu.prognostic_errors(out[0][0], other[0])) == EXACT
         assert any(np.abs(a - b).max() > 0 for a, b in zip(out[0][1], tr))        # the update did something
 
 
