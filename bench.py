@@ -285,12 +285,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
+        # every leg is entered by all ranks or by none: a rank that failed in the peer-to-peer leg (e.g. a neighbour's message
+        # never became visible: TMX_ERR_COMM after the wait kernel's time-out) must not leave the others alone in the RCCL leg
+        same = True
         try:
-            a, b = dss_result(True), dss_result(False)
-            same = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+            a = dss_result(True)
         except Exception as ex:
             same, why = False, str(ex)
-        if not agree(same):
+        if agree(same):
+            b = dss_result(False)
+            same = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+            same = agree(same)
+            if not same:
+                why = "different bytes"
+        else:
+            same = False
+        if not same:
             enable(False)
             halo_note = "RCCL send/recv (auto: the peer-to-peer transport was set up but did not reproduce RCCL's bytes: %s)" % why
             if rank == 0:
@@ -302,7 +312,6 @@ def main():
             halo_note = "%s (auto: one DSS incl. exchange takes %.1f us peer-to-peer, %.1f us with RCCL send/recv; identical bytes%s)" % (
                 "peer-to-peer writes into IPC-mapped ghost buffers" if use_p2p else "RCCL send/recv", 1e6 * t_p2p, 1e6 * t_rccl,
                 "; SELF-TEST of this comparison on one device: both legs are the peer-to-peer transport" if args.share_device else "")
-        eng.upload_state(0, states)
     elif world > 1 and args.halo == "auto":
         halo_note = "RCCL send/recv (auto: peer-to-peer mapping not available: %s)" % why[:200]
     eng.upload_state(0, states)
