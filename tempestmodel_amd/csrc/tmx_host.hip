@@ -1402,12 +1402,16 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
 	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul);
 	if (e->nt > 0) {
-		// tracers: the combination is formed on the tracer slabs first, the tracer kernel then updates in place
-		const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
-		const double * tsrc[12];
-		for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
-		tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
-		tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+		// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
+		// (TMX_TRACER_LINCOMB_PASS=1: formed by a separate pass first, for A/B and tests)
+		if (getenv("TMX_TRACER_LINCOMB_PASS")) {
+			const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
+			const double * tsrc[12];
+			for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
+			tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
+			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+		} else
+			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, n, src, cf, premul);
 	}
 	int r;
 	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;

@@ -198,7 +198,8 @@ void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
 void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt);
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
-void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
+void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt,
+	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale_locally);
 int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
 void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);

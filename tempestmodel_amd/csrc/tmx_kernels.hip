@@ -671,9 +671,11 @@ void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
 // update (same contravariant velocities, recomputed here), then per element and level: clip negatives, rescale the
 // positive values so that the element mass is unchanged.
 // UD: uniform diffusion of the tracer mixing ratio q / rho in the fluxes (HorizontalDynamicsFEM.cpp:1105-1148), ks = K_scalar.
-template <bool UD>
+// NT > 0: the base is the stage's linear combination of the tracer slabs of NT instances, evaluated here as in the state
+// kernels (base_value) instead of by a k_lincomb pass over the tracer slabs in front of this kernel.
+template <bool UD, int NT>
 __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const double * __restrict__ area,
-	const double * __restrict__ xin, const double * xbase, double * xup, double dt, double ks)
+	const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, double ks)
 {
 	__shared__ double s[4][5][64];
 	__shared__ double sS[16], sD[16];
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	for (int c = 0; c < nt; c++) {
 		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
 		const double qv = act ? ldu(xin + so, cb) : 0.0;
-		const double bv = act ? ldu(xbase + so, cb) : 0.0;
+		const double bv = act ? base_value_u<NT>(xbase, so, cb) : 0.0;
 		double taf = fa * qv, tbf = fb * qv;
 		if (UD) {
 			__syncthreads();
@@ -753,12 +755,29 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	}
 }
 
-void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
+void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
+	int nterms, const double * const * src, const double * coef, int premul) {
+	LinTerms xbase;
+	xbase.n = nterms; xbase.premul = premul;
+	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	if (e->udiff)
-		hipLaunchKernelGGL(k_h_tracers<true>, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar);
-	else
-		hipLaunchKernelGGL(k_h_tracers<false>, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0);
+#define LAUNCH_HT(NT_) do { \
+		if (e->udiff) hipLaunchKernelGGL((k_h_tracers<true, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar); \
+		else hipLaunchKernelGGL((k_h_tracers<false, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0); } while (0)
+	switch (nterms) {
+		case 0: LAUNCH_HT(0); break;
+		case 2: LAUNCH_HT(2); break;
+		case 3: LAUNCH_HT(3); break;
+		case 4: LAUNCH_HT(4); break;
+		case 5: LAUNCH_HT(5); break;
+		case 6: LAUNCH_HT(6); break;
+		case 7: LAUNCH_HT(7); break;
+		case 8: LAUNCH_HT(8); break;
+		default: LAUNCH_HT(12); break;      // entries beyond n carry coefficient 0 and a valid pointer, as in tmxk_h_explicit
+	}
+#undef LAUNCH_HT
 }
 
 // ApplyScalarHyperdiffusion, tracer branch (HorizontalDynamicsFEM.cpp:1999-2035, :2076-2165) and, after the second
