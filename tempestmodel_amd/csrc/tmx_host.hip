@@ -2185,8 +2185,9 @@ static int run_program(tmx_engine * e, const Program & p) {
 					i = j; break;
 				}
 			}
-			// Copy(a->b) + StepAfterSubCycle(a,b,w): the second hyperviscosity pass writes every slab of b
-			if (n1 && n1->kind == OP_HVIS && n1->a == o.a && n1->b == o.b && hypervis_active(e)) break;
+			// Copy(a->b) + StepAfterSubCycle(a,b,w): every branch of StepAfterSubCycle rewrites all of b from a (the second
+			// hyperviscosity pass and the order-2 pass write every slab with a as their base; without viscosity it IS the copy)
+			if (n1 && n1->kind == OP_HVIS && n1->a == o.a && n1->b == o.b && o.a != o.b) break;
 			if ((r = tmx_copy_data(e, o.a, o.b))) return r;
 			break;
 		case OP_HEXP:
