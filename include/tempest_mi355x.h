@@ -366,7 +366,7 @@ int tmx_comm_init(tmx_engine * e, const unsigned char id[128]);
  *                            the reference's MPI_Allgather, torch.distributed); maps the neighbours and switches the exchange over.
  * Ranks are separate processes (a process cannot map its own export); they may share a device.  Before tmx_destroy the caller
  * lets all ranks finish (a barrier): neighbours write into this rank's block.  A neighbour whose message does not arrive within
- * 20 s makes the next tmx_sync return TMX_ERR_COMM instead of hanging the device. */
+ * 60 s (TMX_P2P_TIMEOUT_S) makes the next tmx_sync return TMX_ERR_COMM instead of hanging the device. */
 int tmx_halo_p2p_blob_bytes(tmx_engine * e);
 int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob);
 int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs);

@@ -2377,7 +2377,7 @@ extern "C" int tmx_sync(tmx_engine * e) {
 	HIPCHK(hipMemcpy(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost));
 	if (flag == 2) {
 		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
-		tmx_set_error("halo exchange: a neighbour rank's message did not arrive within 20 s (peer-to-peer transport)");
+		tmx_set_error("halo exchange: a neighbour rank's message did not arrive within the time-out (TMX_P2P_TIMEOUT_S, default 60 s) (peer-to-peer transport)");
 		return TMX_ERR_COMM;
 	}
 	if (flag) {

@@ -2004,9 +2004,9 @@ __global__ __launch_bounds__(256) void k_pack_p2p(int nslab, size_t NS, int nsen
 
 // After the messages: raise this rank's arrival counter in every neighbour's block to seq (release, system scope: the
 // preceding kernel's writes are complete at its end), then wait until every neighbour has raised its counter here.  A
-// neighbour that never arrives (a rank died) sets the engine's failure flag after 20 s instead of hanging the GPU.
+// neighbour that never arrives (a rank died) sets the engine's failure flag after 60 s (TMX_P2P_TIMEOUT_S) instead of hanging the GPU.
 __global__ __launch_bounds__(64) void k_p2p_signal_wait(int npeers, const int * __restrict__ peers, unsigned long long * const * __restrict__ flag_dst,
-	const unsigned long long * own, unsigned long long seq, int * __restrict__ fail)
+	const unsigned long long * own, unsigned long long seq, int * __restrict__ fail, unsigned long long timeout_ticks)
 {
 	for (int q = threadIdx.x; q < npeers; q += 64) {
 		__threadfence_system();
@@ -2016,7 +2016,7 @@ __global__ __launch_bounds__(64) void k_p2p_signal_wait(int npeers, const int * 
 		const unsigned long long t0 = wall_clock64();
 		while (__hip_atomic_load(own + peers[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
 			__builtin_amdgcn_s_sleep(8);
-			if (wall_clock64() - t0 > 2000000000ull) { atomicExch(fail, 2); break; }      // 100 MHz counter
+			if (wall_clock64() - t0 > timeout_ticks) { atomicExch(fail, 2); break; }      // 100 MHz counter
 		}
 	}
 	__threadfence_system();
@@ -2031,9 +2031,11 @@ void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf)
 }
 
 void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq) {
+	// how long a neighbour may lag (it may be busy on its host: output, a slower node) before the exchange gives up
+	static const unsigned long long timeout_ticks = 100000000ull * (unsigned long long)(getenv("TMX_P2P_TIMEOUT_S") ? atoi(getenv("TMX_P2P_TIMEOUT_S")) : 60);
 	hipLaunchKernelGGL(k_p2p_signal_wait, dim3(1), dim3(64), 0, s, e->p2p_npeers, (const int *)e->d_p2p_peers,
 		(unsigned long long * const *)(e->d_p2p_flag + (size_t)buf * e->cfg.n_ranks),
-		(const unsigned long long *)e->p2p_block + (size_t)buf * e->cfg.n_ranks, seq, e->d_flag);
+		(const unsigned long long *)e->p2p_block + (size_t)buf * e->cfg.n_ranks, seq, e->d_flag, timeout_ticks);
 }
 
 // ---------------------------------------------------------------------------------------------

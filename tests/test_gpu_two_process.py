@@ -22,9 +22,9 @@ def _free_port():
     return port
 
 
-def _run_ranks(world, scheme, ntr, steps, out):
+def _run_ranks(world, scheme, ntr, steps, out, **extra_env):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out, scheme, str(ntr), str(steps)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -86,3 +86,11 @@ def test_bench_runs_as_two_rank_processes_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert "identical bytes" in d["config"]["parallelism"], d["config"]["parallelism"]
+
+
+def test_absent_neighbour_is_reported_not_hung():
+    """A rank whose neighbour never sends: the wait kernel gives up after TMX_P2P_TIMEOUT_S and tmx_sync returns TMX_ERR_COMM."""
+    with tempfile.TemporaryDirectory() as out:
+        _run_ranks(2, "absent-neighbour", 0, 1, out, TMX_P2P_TIMEOUT_S="2")
+        msg = open(os.path.join(out, "rank0.txt")).read()
+        assert "did not arrive" in msg, msg
