@@ -15,6 +15,9 @@
 #include "tmx_internal.h"
 #include "tmx_refmath.h"
 
+#ifndef TMX_H_FUSE_W
+#define TMX_H_FUSE_W 1      // W of the interfaces inside a level tile updated by k_h_explicit itself (0: all of them by k_h_w_update)
+#endif
 #ifndef KT_H
 #define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads)
 #endif
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	// base of the update (a plain instance or the fused stage combination): loaded in the same burst as the state
 	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
 	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
-	double bU = 0, bV = 0, bT = 0, bR = 0;
+	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
 		const unsigned cb = (unsigned)col * 8u;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 		const double ubm = ldu(xin + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xin + TMX_SLAB_V(L, kp) * NS, cb);
 		bU = base_value_u<NT>(xbase, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_u<NT>(xbase, TMX_SLAB_V(L, k) * NS, cb);
 		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * NS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * NS, cb);
+		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * NS, cb);
 		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
 		jn = ldu(p.g2d + G2_JN * NS, cb); j2d = ldu(p.g2d + G2_J2D * NS, cb); fcor = ldu(p.g2d + G2_F * NS, cb);
 		const MetCol mc = met_col(p, col);
@@ -350,19 +354,37 @@ __global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const doubl
 	stu(xup + sV, colb, outV);
 	stu(xup + sR, colb, bR - dt * invJ * (darf + dbrf));
 	stu(xup + sT, colb, bT - dt * invJ * (dapf + dbpf));
-	stu(ucz + (size_t)k * NS, colb, uczx);
+	if (TMX_H_FUSE_W && !MF) {
+		// W on the interfaces inside the tile (part 2 below, :1612-1659): interface k takes (u x zeta)_xi of the levels k - 1 and k,
+		// which wavefront ty - 1 hands over through its own (now free) LDS row; only the tile's first interface is left to
+		// k_h_w_update, which therefore needs the hand-off array for the first and the last level of a tile only
+		s[ty][0][lane] = uczx;
+		if (ty == 0 || ty == KT_H - 1) stu(ucz + (size_t)k * NS, colb, uczx);
+		__syncthreads();       // wavefronts above the top level have left; the barrier counts the ones still running
+		if (ty > 0) {
+			double v = 0.0;
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lane];
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
+			stu(xup + TMX_SLAB_W(L, k) * NS, colb, bW + dt * v);
+		}
+	} else
+		stu(ucz + (size_t)k * NS, colb, uczx);
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
+// stride > 1: only the interfaces k = 0, stride, 2 stride, ... (the first of every level tile of k_h_explicit, which has done
+// the others) and the top one
 template <int NT>
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
-	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt)
+	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int idx = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int nfirst = (L + stride - 1) / stride;          // interfaces idx * stride < L, then the top one
+	const int k = (idx < nfirst) ? idx * stride : ((idx == nfirst) ? L : L + 1);
 	if (k > L || col >= p.ncol) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
 		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * NS + col);
@@ -401,13 +423,14 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	dim3 blk(64, KT_H), grd(ntile, (p.L + KT_H - 1) / KT_H);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
-	dim3 blk2(64, 4), grd2(ntile, (p.L + 1 + 3) / 4);
+	const int wstride = (TMX_H_FUSE_W && !(fuse_v && e->use_mfma)) ? KT_H : 1;
+	dim3 blk2(64, 4), grd2(ntile, ((p.L + wstride - 1) / wstride + 1 + 3) / 4);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
 #define LAUNCH_HV(NT_) do { \
 		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
 		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
 		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
-		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt); } while (0)
+		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HV(0); break;
 		case 2: LAUNCH_HV(2); break;
