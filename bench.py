@@ -39,9 +39,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 #                the fused combination replaces (40 B) plus the stage-combination row, 600 B/step over 4 launches
 #                (150 B); the V-explicit row (80 B) is NOT counted: fusion removes its traffic altogether
 #   v_implicit : 272 B (5 R + 3 W + 26 metric)
-#   dss        : 60 B,  hypervis: 216 B per pass (the fused pass kernel moves less than that)
+#   dss        : 60 B
+#   hypervis   : 100 B per pass.  SURVEY's row is 216 B (the reference's separate scalar and vector passes); ONE kernel does
+#                both here, and what it cannot avoid moving is 5 R + 5 W in pass 1 and 5 R (Laplacians) + 5 R (base) + 5 W in
+#                pass 2 = 12.5 doubles per pass on average.  Pricing it with the 216 B row put it above the 8 TB/s peak.
 #   lincomb    : the copies left un-fused (device copies of whole / partial instances); no SURVEY row of its own
-ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 216.0, "lincomb": 0.0}
+ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 100.0, "lincomb": 0.0}
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
 # What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
 OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
