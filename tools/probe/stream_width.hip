@@ -1,0 +1,63 @@
+// Streaming rate of this chip for the access shapes the kernels here use: 8 bytes per lane (one fp64 column value per thread,
+// 512 B per wavefront instruction) against 16 bytes per lane, out of place (y = a x), in place (x = a x) and a 5-stream
+// combination (y = sum a_m x_m), on arrays far beyond the 256 MB Infinity Cache.
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/stream_width tools/probe/stream_width.hip && /tmp/stream_width
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void k_scale8(const double * __restrict__ x, double * __restrict__ y, size_t n) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) y[i] = 1.000001 * x[i];
+}
+__global__ __launch_bounds__(256) void k_scale16(const double2 * __restrict__ x, double2 * __restrict__ y, size_t n2) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n2) { double2 v = x[i]; v.x *= 1.000001; v.y *= 1.000001; y[i] = v; }
+}
+__global__ __launch_bounds__(256) void k_inplace8(double * x, size_t n) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) x[i] = 1.000001 * x[i];
+}
+__global__ __launch_bounds__(256) void k_inplace16(double2 * x, size_t n2) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n2) { double2 v = x[i]; v.x *= 1.000001; v.y *= 1.000001; x[i] = v; }
+}
+__global__ __launch_bounds__(256) void k_comb8(const double * __restrict__ x, double * __restrict__ y, size_t n, size_t stride) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { double v = 0.0; for (int m = 0; m < 5; m++) v += 0.2 * x[i + m * stride]; y[i] = v; }
+}
+__global__ __launch_bounds__(256) void k_comb16(const double2 * __restrict__ x, double2 * __restrict__ y, size_t n2, size_t stride2) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n2) { double2 v = { 0.0, 0.0 }; for (int m = 0; m < 5; m++) { const double2 w = x[i + m * stride2]; v.x += 0.2 * w.x; v.y += 0.2 * w.y; } y[i] = v; }
+}
+
+int main() {
+	const size_t n = (size_t)96 << 20;            // 96 Mi doubles = 805 MB per array
+	double * x = nullptr, * y = nullptr;
+	CHK(hipMalloc((void **)&x, 5 * n * sizeof(double))); CHK(hipMalloc((void **)&y, n * sizeof(double)));
+	CHK(hipMemset(x, 0, 5 * n * sizeof(double))); CHK(hipMemset(y, 0, n * sizeof(double)));
+	hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+	auto timeit = [&](const char * name, double bytes, auto launch) {
+		for (int w = 0; w < 2; w++) launch();
+		hipEventRecord(a, 0);
+		for (int r = 0; r < 10; r++) launch();
+		hipEventRecord(b, 0); hipEventSynchronize(b);
+		float ms = 0; hipEventElapsedTime(&ms, a, b);
+		printf("%-34s %8.1f us  %6.2f TB/s\n", name, 1e3 * ms / 10, bytes / (ms / 10 * 1e-3) / 1e12);
+		return 0;
+	};
+	const double B = (double)n * 8;
+	timeit("y = a x      8 B per lane", 2 * B, [&] { hipLaunchKernelGGL(k_scale8, dim3((n + 255) / 256), dim3(256), 0, 0, x, y, n); });
+	timeit("y = a x     16 B per lane", 2 * B, [&] { hipLaunchKernelGGL(k_scale16, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (const double2 *)x, (double2 *)y, n / 2); });
+	timeit("x = a x      8 B per lane", 2 * B, [&] { hipLaunchKernelGGL(k_inplace8, dim3((n + 255) / 256), dim3(256), 0, 0, y, n); });
+	timeit("x = a x     16 B per lane", 2 * B, [&] { hipLaunchKernelGGL(k_inplace16, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (double2 *)y, n / 2); });
+	timeit("y = sum5 a x 8 B per lane", 6 * B, [&] { hipLaunchKernelGGL(k_comb8, dim3((n + 255) / 256), dim3(256), 0, 0, x, y, n, n); });
+	timeit("y = sum5 a x 16 B per lane", 6 * B, [&] { hipLaunchKernelGGL(k_comb16, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (const double2 *)x, (double2 *)y, n / 2, n / 2); });
+	timeit("hipMemcpyAsync D2D", 2 * B, [&] { hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, 0); });
+	// the state's size: one 104 MB instance (fits the Infinity Cache together with its copy)
+	const size_t ns = (size_t)13046400;
+	timeit("y = a x      8 B, 104 MB arrays", 2.0 * ns * 8, [&] { hipLaunchKernelGGL(k_scale8, dim3((ns + 255) / 256), dim3(256), 0, 0, x, y, ns); });
+	timeit("y = a x     16 B, 104 MB arrays", 2.0 * ns * 8, [&] { hipLaunchKernelGGL(k_scale16, dim3((ns / 2 + 255) / 256), dim3(256), 0, 0, (const double2 *)x, (double2 *)y, ns / 2); });
+	return 0;
+}
