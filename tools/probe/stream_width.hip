@@ -32,10 +32,25 @@ __global__ __launch_bounds__(256) void k_comb16(const double2 * __restrict__ x, 
 	if (i < n2) { double2 v = { 0.0, 0.0 }; for (int m = 0; m < 5; m++) { const double2 w = x[i + m * stride2]; v.x += 0.2 * w.x; v.y += 0.2 * w.y; } y[i] = v; }
 }
 
+// The access shape of the step's kernels: thread = (column, level); a field is L slabs of NS columns, an instance 5 fields; a
+// workgroup covers 64 columns x 4 levels (SHAPE 0, the kernels' tiling) or 256 columns x 1 level (SHAPE 1); every thread reads
+// NIN fields' values of its (column, level) and writes 5.
+template <int NIN, int SHAPE>
+__global__ __launch_bounds__(256) void k_slabs(const double * __restrict__ x, double * __restrict__ y, int NS, int L) {
+	const int col = SHAPE == 0 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * 256 + threadIdx.x;
+	const int k = SHAPE == 0 ? blockIdx.y * 4 + (threadIdx.x >> 6) : blockIdx.y;
+	if (k >= L || col >= NS) return;
+	double v = 0.0;
+#pragma unroll
+	for (int f = 0; f < NIN; f++) v += 0.1 * x[((size_t)f * L + k) * NS + col];
+#pragma unroll
+	for (int g = 0; g < 5; g++) y[((size_t)g * L + k) * NS + col] = v + g;
+}
+
 int main() {
 	const size_t n = (size_t)96 << 20;            // 96 Mi doubles = 805 MB per array
 	double * x = nullptr, * y = nullptr;
-	CHK(hipMalloc((void **)&x, 5 * n * sizeof(double))); CHK(hipMalloc((void **)&y, n * sizeof(double)));
+	CHK(hipMalloc((void **)&x, 5 * n * sizeof(double))); CHK(hipMalloc((void **)&y, n * sizeof(double)));      // 4 GB and 0.8 GB: also enough for the slab shapes below (35 fields of 83 MB in, 5 out)
 	CHK(hipMemset(x, 0, 5 * n * sizeof(double))); CHK(hipMemset(y, 0, n * sizeof(double)));
 	hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
 	auto timeit = [&](const char * name, double bytes, auto launch) {
@@ -59,5 +74,16 @@ int main() {
 	const size_t ns = (size_t)13046400;
 	timeit("y = a x      8 B, 104 MB arrays", 2.0 * ns * 8, [&] { hipLaunchKernelGGL(k_scale8, dim3((ns + 255) / 256), dim3(256), 0, 0, x, y, ns); });
 	timeit("y = a x     16 B, 104 MB arrays", 2.0 * ns * 8, [&] { hipLaunchKernelGGL(k_scale16, dim3((ns / 2 + 255) / 256), dim3(256), 0, 0, (const double2 *)x, (double2 *)y, ns / 2); });
+	// ne60-sized slabs so that the arrays are beyond the Infinity Cache: NS = 345 600 columns, L = 30: a field = 83 MB
+	{
+		const int NS = 345600, L = 30;
+		const double fb = (double)NS * L * 8;
+		timeit("slabs  5 in 5 out, 64 x 4 levels", 10 * fb, [&] { hipLaunchKernelGGL((k_slabs<5, 0>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("slabs  5 in 5 out, 256 x 1 level", 10 * fb, [&] { hipLaunchKernelGGL((k_slabs<5, 1>), dim3(NS / 256, L), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("slabs 10 in 5 out, 64 x 4 levels", 15 * fb, [&] { hipLaunchKernelGGL((k_slabs<10, 0>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("slabs 10 in 5 out, 256 x 1 level", 15 * fb, [&] { hipLaunchKernelGGL((k_slabs<10, 1>), dim3(NS / 256, L), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("slabs 35 in 5 out, 64 x 4 levels", 40 * fb, [&] { hipLaunchKernelGGL((k_slabs<35, 0>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("slabs 35 in 5 out, 256 x 1 level", 40 * fb, [&] { hipLaunchKernelGGL((k_slabs<35, 1>), dim3(NS / 256, L), dim3(256), 0, 0, x, y, NS, L); });
+	}
 	return 0;
 }
