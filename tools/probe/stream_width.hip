@@ -47,6 +47,23 @@ __global__ __launch_bounds__(256) void k_slabs(const double * __restrict__ x, do
 	for (int g = 0; g < 5; g++) y[((size_t)g * L + k) * NS + col] = v + g;
 }
 
+// The same work on a tile-interleaved layout: [level][64-column tile][field][64] -- the fields of a tile and level are one
+// contiguous run (NF x 512 B) instead of NF separate slab streams; instances stay separate arrays (NI of them read).
+template <int NI>
+__global__ __launch_bounds__(256) void k_tiles(const double * __restrict__ x, double * __restrict__ y, int NS, int L, size_t inst) {
+	const int tile = blockIdx.x, lane = threadIdx.x & 63;
+	const int k = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (k >= L) return;
+	const size_t base = (((size_t)k * (NS / 64) + tile) * 5) * 64 + lane;
+	double v = 0.0;
+#pragma unroll
+	for (int i = 0; i < NI; i++)
+#pragma unroll
+		for (int f = 0; f < 5; f++) v += 0.1 * x[i * inst + base + f * 64];
+#pragma unroll
+	for (int g = 0; g < 5; g++) y[base + g * 64] = v + g;
+}
+
 int main() {
 	const size_t n = (size_t)96 << 20;            // 96 Mi doubles = 805 MB per array
 	double * x = nullptr, * y = nullptr;
@@ -83,6 +100,9 @@ int main() {
 		timeit("slabs 10 in 5 out, 64 x 4 levels", 15 * fb, [&] { hipLaunchKernelGGL((k_slabs<10, 0>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L); });
 		timeit("slabs 10 in 5 out, 256 x 1 level", 15 * fb, [&] { hipLaunchKernelGGL((k_slabs<10, 1>), dim3(NS / 256, L), dim3(256), 0, 0, x, y, NS, L); });
 		timeit("slabs 35 in 5 out, 64 x 4 levels", 40 * fb, [&] { hipLaunchKernelGGL((k_slabs<35, 0>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L); });
+		timeit("tiles  5 in 5 out (interleaved)", 10 * fb, [&] { hipLaunchKernelGGL((k_tiles<1>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L, (size_t)5 * L * NS); });
+		timeit("tiles 10 in 5 out (interleaved)", 15 * fb, [&] { hipLaunchKernelGGL((k_tiles<2>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L, (size_t)5 * L * NS); });
+		timeit("tiles 35 in 5 out (interleaved)", 40 * fb, [&] { hipLaunchKernelGGL((k_tiles<7>), dim3(NS / 64, (L + 3) / 4), dim3(256), 0, 0, x, y, NS, L, (size_t)5 * L * NS); });
 		timeit("slabs 35 in 5 out, 256 x 1 level", 40 * fb, [&] { hipLaunchKernelGGL((k_slabs<35, 1>), dim3(NS / 256, L), dim3(256), 0, 0, x, y, NS, L); });
 	}
 	return 0;
