@@ -2252,7 +2252,7 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	// relaunched as one graph.  Off by default: the plain sequence is already queued asynchronously far ahead of the
 	// GPU, and the replay measured 0-1 % SLOWER (ne8: 0.419 vs 0.414 ms/step, ne16: 0.605 vs 0.601, ne30: 1.65 both).
 	// Multi-rank steps (RCCL calls on a second stream) and profiled steps always use the plain sequence.
-	if (e->use_graph && e->cfg.n_ranks == 1 && !e->prof && !e->lb) {
+	if (e->use_graph && (e->cfg.n_ranks == 1 || getenv("TMX_DEBUG_SKIP_EXCHANGE")) && !e->prof && !e->lb) {
 		StepGraphKey key = { scheme, first_step ? 1 : 0, last_step ? 1 : 0, dt };
 		for (auto & g : e->graphs)
 			if (g.key.scheme == key.scheme && g.key.first == key.first && g.key.last == key.last && g.key.dt == key.dt) {
