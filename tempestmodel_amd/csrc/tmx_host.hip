@@ -1353,7 +1353,9 @@ static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt) {
 // VerticalDynamicsFEM::StepExplicit beyond the upwind penalty of U,V (which tmxk_v_explicit / the fused explicit kernel
 // apply): in the fully explicit mode -dt F on rho*theta, W, rho (:745-790) and the explicit tracer update (:792-800),
 // and with uniform diffusion the vertical diffusion of U,V (:1059-1105).
-static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt) {
+// uv_done: the vertical diffusion of U,V has been added by tmxk_v_explicit already (TMX_UDV_SEPARATE=1 keeps the separate pass)
+static bool udv_fused(const tmx_engine * e) { return e->udiff && e->fully_explicit && !getenv("TMX_UDV_SEPARATE"); }
+static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt, bool uv_done = false) {
 	if (!e->fully_explicit) return TMX_OK;
 	int r; if ((r = check_reference_state(e))) return r;
 	const KParams p = make_params(e);
@@ -1361,7 +1363,7 @@ static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt) {
 	if (e->nt > 0)
 		REQUIRE(tmxk_vi_tracers_explicit(e, p, inst(e, iinit), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
 			"tracer column update: %d levels do not fit the LDS working set", e->L);
-	if (e->udiff)
+	if (e->udiff && !uv_done)
 		tmxk_v_uniform_diffusion_uv(e, p, inst(e, iinit), e->d_ref, inst(e, iupd), dt, e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
 	return TMX_OK;
 }
@@ -1416,8 +1418,11 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 	int r;
 	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
-	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
-	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
+	if (e->udiff) {
+		if (udv_fused(e) && (r = check_reference_state(e))) return r;
+		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
+	}
+	if ((r = v_explicit_extras(e, iinit, iupd, dt, udv_fused(e)))) return r;
 	return launch_check("hv_step_explicit(lincomb)");
 }
 
@@ -1431,8 +1436,11 @@ static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, doub
 	int r;
 	if ((r = surface_copy(e, ibase, iupd))) return r;       // the folded CopyData(base -> update)
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
-	if (e->udiff) tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
-	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
+	if (e->udiff) {
+		if (udv_fused(e) && (r = check_reference_state(e))) return r;
+		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
+	}
+	if ((r = v_explicit_extras(e, iinit, iupd, dt, udv_fused(e)))) return r;
 	return launch_check("hv_step_explicit");
 }
 
@@ -1490,8 +1498,9 @@ extern "C" int tmx_v_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	if (e->sw) return TMX_OK;      // VerticalDynamicsStub
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "V StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_V_EXPLICIT);
-	tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
-	if ((r = v_explicit_extras(e, iinit, iupd, dt))) return r;
+	if (udv_fused(e) && (r = check_reference_state(e))) return r;
+	tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
+	if ((r = v_explicit_extras(e, iinit, iupd, dt, udv_fused(e)))) return r;
 	return launch_check("v_step_explicit");
 }
 

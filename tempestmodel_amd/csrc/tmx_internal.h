@@ -182,7 +182,7 @@ void tmx_set_error(const char * fmt, ...);
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
-void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);

@@ -469,8 +469,11 @@ __device__ __forceinline__ double xidot_edge(const KParams & p, const double * _
 	return e0 * ue + e1 * ve + e2 * we;
 }
 
+// UDV: the vertical uniform diffusion of U,V of the fully explicit mode (k_v_uniform_diffusion_uv below, :1059-1105) is added
+// to the same value before it is stored -- the sum the two kernels form through memory, in the same order
+template <bool UDV>
 __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double dt)
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -498,13 +501,29 @@ __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __
 			b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * x0;
 			out += b * w_lo;
 		}
+		if (UDV) {
+			double dd = 0.0, ddr = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 2; off++) {
+				const int l = k + off;
+				if (l < 0 || l >= L) continue;
+				const double c = OPC(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+				dd += c * xin[(size_t)(sb + l) * NS + col];
+				ddr += c * xref[(size_t)(sb + l) * NS + col];
+			}
+			out += dt * cf * (dd - ddr);
+		}
 		xup[(size_t)(sb + k) * NS + col] = out;
 	}
 }
 
-void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_v_explicit, grd, blk, 0, e->stream, p, xin, xup, dt);
+	if (with_udiff_uv)
+		hipLaunchKernelGGL(k_v_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
+			e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
+	else
+		hipLaunchKernelGGL(k_v_explicit<false>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------
