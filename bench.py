@@ -397,7 +397,13 @@ def main():
             # fused passes (hypervis reads less than its row says), so "measured_GBs" is the rate to judge those by
             ms = op_time[op] / op_launches[op]
             tr = measured_traffic(op, ne, L, world, op_launches[op] / args.steps)
-            return {"launches_per_step": op_launches[op] / args.steps, "ms_per_launch": ms,
+            extra = {}
+            if op == "v_implicit":
+                # what the column solve cannot avoid moving as designed (unique columns read once, the three solved variables
+                # written to every stored column): the SURVEY row above also counts 26 metric doubles this kernel no longer
+                # reads, and the measured traffic is mostly the U-row stream of the band LU going to HBM and back
+                extra["compulsory_bytes_per_launch"] = 8.0 * ((5 * L + 1) * eng.info(1) + (3 * L + 1) * eng.info(0))
+            return {"launches_per_step": op_launches[op] / args.steps, "ms_per_launch": ms, **extra,
                     "achieved_GBs": ALG_BYTES[op] * local_points / max(ms * 1e-3, 1e-12) / 1e9,
                     "traffic": tr, "measured_GBs": (tr / max(ms * 1e-3, 1e-12) / 1e9) if tr else None,
                     "bound": OP_BOUND[op]}
