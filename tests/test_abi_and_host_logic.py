@@ -148,3 +148,25 @@ def test_refmath_is_glibc_bit_for_bit(tmp_path):
     r = subprocess.run([exe, "20000000"], stdout=subprocess.PIPE, universal_newlines=True)
     assert r.returncode == 0, r.stdout
     assert "exp mismatches 0 log mismatches 0" in r.stdout
+
+
+def test_peer_to_peer_halo_needs_a_device_engine_of_a_multi_rank_layout():
+    """tmx_halo_p2p_* argument checking on the host (plan-only engines: no device is touched): the blob size is the documented
+    handle + offsets record, and neither a plan-only nor a single-rank engine can export."""
+    from tempestmodel_amd.engine import Engine, TempestError, load_library
+    g, _ = gu.make_grid(4, 6, 24)
+    e = Engine(g, device=-2, rank=1, n_ranks=3)
+    try:
+        lib = load_library()
+        n = lib.tmx_halo_p2p_blob_bytes(e.h)
+        assert n >= 64 + 8 + 8 + 4 * 4 and n % 4 == 0
+        with pytest.raises(TempestError):
+            e.halo_p2p_export()                      # plan-only: no device memory to export
+        with pytest.raises(ValueError):
+            e.halo_p2p_connect([b"\0" * n] * 2)      # one blob per rank
+        with pytest.raises(TempestError):
+            e.halo_p2p_connect([b"\0" * n] * 3)      # nothing exported yet
+        with pytest.raises(TempestError):
+            e.halo_p2p_enable(True)                  # not connected
+    finally:
+        e.close()
