@@ -1146,12 +1146,12 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 // of interface k then k + 1, 1/dt; velocity correction of interface k then k + 1), so the results are bit-identical; only the
 // factorisation and the two substitutions stay on one lane per column (pivot row / running entries in registers, the
 // next row prefetched from LDS).  LDS: (9L + 3) x 16 doubles per workgroup, so that at L = 30 five workgroups share a CU.
-template <int NR> __global__ __launch_bounds__(NR * 16) void k_vi_tracers_rows(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
+template <int NR, int LWB> __global__ __launch_bounds__(NR << LWB) void k_vi_tracers_rows(KParams p, int nt, const double * __restrict__ xin, const double * __restrict__ w0,
 	const double * xbase, double * xup, double dt, int nunique, const int * __restrict__ ucol, const int * __restrict__ udep, int * __restrict__ flag)
 {
-	constexpr int LW = 16;
+	constexpr int LW = 1 << LWB;        // columns per workgroup (16 or 8)
 	extern __shared__ double smt[];
-	const int L = p.L, lane = threadIdx.x & 15, t = threadIdx.x >> 4;
+	const int L = p.L, lane = threadIdx.x & (LW - 1), t = threadIdx.x >> LWB;
 	const size_t NS = (size_t)p.NS;
 	double * A = smt;                                // [L][4][LW]
 	double * F = A + (size_t)L * 4 * LW;             // [L][LW]
@@ -1355,18 +1355,23 @@ template <int NR> __global__ __launch_bounds__(NR * 16) void k_vi_tracers_rows(K
 #undef AR
 }
 
-static size_t vt_rows_lds(int L) { return ((size_t)L * 4 + (size_t)L * 2 + (size_t)(L + 1) * 3) * 16 * sizeof(double); }
-// row lanes per column of k_vi_tracers_rows: 16 (four wavefronts per 16 columns) up to 48 levels, 32 above; TMX_VT_NR = 4 | 8 | 16 | 32
+static size_t vt_rows_lds(int L, int lw = 16) { return ((size_t)L * 4 + (size_t)L * 2 + (size_t)(L + 1) * 3) * lw * sizeof(double); }
+// row lanes per column of k_vi_tracers_rows: 16 (four wavefronts per 16 columns) up to 48 levels, 32 above; TMX_VT_NR = 4 | 8 | 16 | 32;
+// 8 columns per workgroup up to 48 levels (half the LDS per workgroup, twice the workgroups per CU), 16 above; TMX_VT_LW8 = 0 | 1
 static void launch_vt_rows(tmx_engine * e, const KParams & p, int ncols, const double * xin, const double * w0, const double * xbase, double * xup,
 	double dt, const int * ucol, const int * udep, size_t lds)
 {
 	static const int nr_env = getenv("TMX_VT_NR") ? atoi(getenv("TMX_VT_NR")) : 0;
+	static const int lw8_env = getenv("TMX_VT_LW8") ? atoi(getenv("TMX_VT_LW8")) : -1;
+	const bool lw8 = lw8_env >= 0 ? lw8_env == 1 : p.L <= 48;    // ne30, 2 tracers: L30 1.308 (8 columns) / 1.358 (16) ms per step, L60 3.35 / 3.21
 	const int nr = nr_env ? nr_env : (p.L > 48 ? 32 : 16);       // measured at ne30: L30 1.36 (16) / 1.49 (32) ms, L60 3.50 (16) / 3.25 (32) ms per step
-#define LAUNCH_VTR(NR_) do { \
-		hipFuncSetAttribute((const void *)k_vi_tracers_rows<NR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		hipLaunchKernelGGL(k_vi_tracers_rows<NR_>, dim3((ncols + 15) / 16), dim3(NR_ * 16), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
+#define LAUNCH_VTR(NR_, LWB_) do { \
+		const size_t lds_ = vt_rows_lds(p.L, 1 << LWB_); \
+		hipFuncSetAttribute((const void *)k_vi_tracers_rows<NR_, LWB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+		hipLaunchKernelGGL((k_vi_tracers_rows<NR_, LWB_>), dim3((ncols + (1 << LWB_) - 1) >> LWB_), dim3(NR_ << LWB_), lds_, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
 			ncols, ucol, udep, e->d_flag); } while (0)
-	if (nr == 4) LAUNCH_VTR(4); else if (nr == 8) LAUNCH_VTR(8); else if (nr == 32) LAUNCH_VTR(32); else LAUNCH_VTR(16);
+	if (lw8) { if (nr == 8) LAUNCH_VTR(8, 3); else if (nr == 32) LAUNCH_VTR(32, 3); else LAUNCH_VTR(16, 3); }
+	else if (nr == 4) LAUNCH_VTR(4, 4); else if (nr == 8) LAUNCH_VTR(8, 4); else if (nr == 32) LAUNCH_VTR(32, 4); else LAUNCH_VTR(16, 4);
 #undef LAUNCH_VTR
 }
 
