@@ -37,8 +37,11 @@ def _run_ranks(world, scheme, ntr, steps, out, **extra_env):
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
 
 
-@pytest.mark.parametrize("world,scheme,ntr", [(2, "ars343", 0), (4, "ars343", 2), (3, "strang", 0)])
-def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr):
+@pytest.mark.parametrize("world,scheme,ntr,env", [
+    (2, "ars343", 0, {}), (4, "ars343", 2, {}), (3, "strang", 0, {}),
+    # the exchange on the engine's own stream, whole-patch launches (no boundary-first split)
+    (2, "ars343", 0, {"TMX_NO_EXCHANGE_OVERLAP": "1"}), (3, "ars343", 0, {"TMX_NO_SPLIT": "1"})])
+def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr, env):
     from tempestmodel_amd.engine import Engine
     steps = 3
     g, st = gu.make_grid(4, 6, 24, ntracers=ntr)
@@ -55,7 +58,7 @@ def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr):
     finally:
         single.close()
     with tempfile.TemporaryDirectory() as out:
-        _run_ranks(world, scheme, ntr, steps, out)
+        _run_ranks(world, scheme, ntr, steps, out, **env)
         seen = set()
         for r in range(world):
             d = np.load(os.path.join(out, "rank%d.npz" % r))
