@@ -149,6 +149,20 @@ __device__ __forceinline__ double exner_from_rhotheta(const KParams & p, double 
 	// PhysicalConstants::ExnerPressureFromRhoTheta (src/atm/PhysicalConstants.h:397-399)
 	return p.cp * tmx_ref_exp(p.Rd / (p.cp - p.Rd) * tmx_ref_log(p.Rd / p.p0 * rt));      // glibc's exp / log, bit for bit (tmx_refmath.h)
 }
+// The same with the two lookup tables of exp / log in LDS (`rmtab`: 256 doubles {1/c, log c} of log, then the 256 words of
+// exp; tmx_rm_tables_to_lds fills it).  From global memory the two dependent table gathers of every evaluation are
+// vector-memory loads: in the column kernels each one cost an s_waitcnt vmcnt(0), i.e. a wait for the level prefetches
+// (and U-row stores) in flight as well.
+#define TMX_RMTAB_DOUBLES 512
+__device__ __forceinline__ void tmx_rm_tables_to_lds(double * rmtab, int tid, int nthreads) {
+	for (int t = tid; t < 256; t += nthreads) {
+		rmtab[t] = tmx_rm_log_tab[t];
+		((unsigned long long *)(rmtab + 256))[t] = tmx_rm_exp_tab[t];
+	}
+}
+__device__ __forceinline__ double exner_from_rhotheta_lds(const KParams & p, double rt, const double * rmtab) {
+	return p.cp * tmx_ref_exp_t(p.Rd / (p.cp - p.Rd) * tmx_ref_log_t(p.Rd / p.p0 * rt, rmtab), (const unsigned long long *)(rmtab + 256));
+}
 
 // ---------------------------------------------------------------------------------------------
 // H explicit, part 1: HorizontalDynamicsFEM::StepNonhydrostaticPrimitive, updates on levels
@@ -2859,11 +2873,20 @@ struct BlkCarry {
 // UD: the uniform-diffusion terms of BuildF (VerticalDynamicsFEM.cpp:2593-2635), udP = K_s / ztop^2 * second derivative
 // of (rho*theta - reference) on level k, udW = K_v / ztop^2 * the same for W on interface k, subtracted where the
 // reference subtracts them (before the upwinding terms); only the fully explicit mode evaluates them.
+// sign(x) * v as in the reference's upwinding terms ((x > 0) ? v : ((x < 0) ? -v : 0)), written as a chain of two selects: the
+// nested conditional became exec-masked branches, which cut the block row's assembly into short basic blocks
+__device__ __forceinline__ double signed_by(double x, double v) {
+	double r = 0.0;
+	r = (x < 0.0) ? -v : r;
+	r = (x > 0.0) ? v : r;
+	return r;
+}
+
 template <bool CARRY, bool UD = false>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
 	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy,
-	double udP = 0.0, double udW = 0.0)
+	double udP = 0.0, double udW = 0.0, const double * rmtab = nullptr)
 {
 	const int L = p.L;
 #pragma unroll
@@ -2935,14 +2958,14 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			rowR[DOFF(2, 2, 1)] += c0; rowP[DOFF(0, 0, 1)] += c0;
 		}
 		if (k >= 1) {
-			const double sw = (xd0 > 0.0) ? eb.ce2 : ((xd0 < 0.0) ? -eb.ce2 : 0.0);
+			const double sw = signed_by(xd0, eb.ce2);
 			rowP[DOFF(0, 1, 0)] -= sw * pr0 * pm; rowP[DOFF(0, 1, 0)] -= sw * pr1 * p0;
 			rowP[DOFF(0, 0, -1)] -= wlo * pr0;    rowP[DOFF(0, 0, 0)] -= wlo * pr1;
 			rowR[DOFF(2, 1, 0)] -= sw * pr0 * rm; rowR[DOFF(2, 1, 0)] -= sw * pr1 * r0;
 			rowR[DOFF(2, 2, -1)] -= wlo * pr0;    rowR[DOFF(2, 2, 0)] -= wlo * pr1;
 		}
 		if (k + 1 <= L - 1) {
-			const double sw = (xd1 > 0.0) ? ec.ce2 : ((xd1 < 0.0) ? -ec.ce2 : 0.0);
+			const double sw = signed_by(xd1, ec.ce2);
 			rowP[DOFF(0, 1, 1)] -= sw * pl0 * p0; rowP[DOFF(0, 1, 1)] -= sw * pl1 * pp;
 			rowP[DOFF(0, 0, 0)] -= whi * pl0;     rowP[DOFF(0, 0, 1)] -= whi * pl1;
 			rowR[DOFF(2, 1, 1)] -= sw * pl0 * r0; rowR[DOFF(2, 1, 1)] -= sw * pl1 * rp;
@@ -2953,7 +2976,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	// ---- node k quantities the W rows of this block and of the next one use ----
 	double ex0 = 0.0, wn0 = 0.0, xdn0 = 0.0, ke0 = 0.0;
 	if (k <= L - 1 && (CARRY || k >= 1)) {
-		ex0 = exner_from_rhotheta(p, B.pn);
+		ex0 = rmtab ? exner_from_rhotheta_lds(p, B.pn, rmtab) : exner_from_rhotheta(p, B.pn);
 		wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * eb.we; wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * ec.we;
 		xdn0 = B.ca2 * B.un + B.cb2 * B.vn + B.cx2 * wn0;
 		const double ca = cc.c2a0 * B.un + cc.c2a1 * B.vn + B.ca2 * wn0, cb = cc.c2a1 * B.un + cc.c2b1 * B.vn + B.cb2 * wn0;
@@ -2964,7 +2987,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		double exm, wnm, xdnm, kem;
 		if (CARRY) { exm = cy.ex; wnm = cy.wn; xdnm = cy.xdn; kem = cy.ke; }
 		else {
-			exm = exner_from_rhotheta(p, pm);
+			exm = rmtab ? exner_from_rhotheta_lds(p, pm, rmtab) : exner_from_rhotheta(p, pm);
 			wnm = 0.0; wnm += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 0) * ea.we; wnm += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * eb.we;
 			xdnm = A.ca2 * A.un + A.cb2 * A.vn + A.cx2 * wnm;
 			const double ca = cc.c2a0 * A.un + cc.c2a1 * A.vn + A.ca2 * wnm, cb = cc.c2a1 * A.un + cc.c2b1 * A.vn + A.cb2 * wnm;
@@ -3012,7 +3035,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		rowW[DOFF(1, 1, 0)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k - 1, 1) * dnm * xdnm;
 		rowW[DOFF(1, 1, 0)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * dn0 * xdn0;
 		rowW[DOFF(1, 1, 1)] += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * dn0 * xdn0;
-		const double sw = (xde > 0.0) ? cx2e : ((xde < 0.0) ? -cx2e : 0.0);
+		const double sw = signed_by(xde, cx2e);
 		rowW[DOFF(1, 1, 0)] -= cc.upc * sw * ddw;
 		rowW[DOFF(1, 1, -1)] -= cc.upc * fabs(xde) * ddm;
 		rowW[DOFF(1, 1, 0)] -= cc.upc * fabs(xde) * dd0;
@@ -3071,7 +3094,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 			mask |= 1 << c;
 		}
 	}
-	if (threadIdx.x == 0) umask[jcol] = mask;
+	if (SPARSE ? (threadIdx.x == 0) : true) umask[jcol] = mask;      // dense stores (also the lane-divergent tails, where lane 0 may be masked out): every active lane writes the same word
 	AB[((size_t)jcol * TMX_UW + TMX_BW) * 64] = pb;
 }
 
@@ -3141,6 +3164,20 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 				default: lu_pivot_tail_uniform<SPARSE, 4, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
 		}
+#ifndef TMX_VI_SELECT_PATH
+		// The lanes disagree (rare: neighbouring columns have nearly the same matrix): the same five tails, one pivot row at
+		// a time under the lanes that chose it.  A lane executes exactly the tail of its own pivot row, i.e. the statements
+		// of the per-lane select path below on the same operands; every U-row entry is stored (a fill-in entry that is zero
+		// in the lanes of one tail need not be zero in the others, so the all-lanes ballot of the sparse stores does not
+		// apply).  Unlike the select path -- whose 160 selects per step cost the kernel 30 spilled registers, reloaded in
+		// the uniform tails behind an s_waitcnt vmcnt(0) that also drained the U-row stores -- this adds no live values.
+		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		return;
+#endif
 	}
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -3395,9 +3432,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	// PAIRS producer/consumer pairs per workgroup (2 pairs = 4 wavefronts = one per SIMD of a CU)
 	const int lane = threadIdx.x, wv = WAVE_UNIFORM(threadIdx.y), role = wv & 1, pair = wv >> 1;
 	double * ring = etal + 2 * L + 1 + (size_t)pair * 2 * NQ * 64;           // [PAIRS][2][NQ][64]
-	int * umask = (int *)(etal + 2 * L + 1 + (size_t)PAIRS * 2 * NQ * 64) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
+	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * 2 * NQ * 64;        // [512] exp / log tables (exner_from_rhotheta_lds)
+	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
 	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128 * PAIRS) opsl[t] = p.ops[t];
 	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += 128 * PAIRS) etal[t] = p.eta[t];
+	tmx_rm_tables_to_lds(rmtab, wv * 64 + lane, 128 * PAIRS);
 	__syncthreads();
 	const size_t NS = (size_t)p.NS;
 	// cpw columns per wavefront (64, or fewer so that the column groups fill every SIMD of the chip evenly: tmxk_vi_fused).
@@ -3432,7 +3471,7 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 #ifdef TMX_ABL_FAST_PRODUCER      // ablation builds: the block row is evaluated once, the ring is refilled with it every time
 				if (t == 0)
 #endif
-				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
+				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
 				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
 #pragma unroll
 				for (int c = 0; c < TMX_BW; c++) { q[c * 64] = rP[c]; q[(TMX_BW + c) * 64] = rW[c]; q[(2 * TMX_BW + c) * 64] = rR[c]; }
@@ -3743,7 +3782,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const int cpw = use_pair ? e->vi_cpw : 64;
 	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
-		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double);
+		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + TMX_RMTAB_DOUBLES * sizeof(double);
 		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 #define LAUNCH_PAIR(CL_, NP_) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \

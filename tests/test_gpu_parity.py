@@ -832,6 +832,59 @@ def test_fused_column_kernels_are_bit_identical_to_split_kernels():
             assert np.array_equal(ae[3], be[3])
 
 
+def test_column_solve_with_lane_divergent_pivots():
+    """Neighbouring columns of a smooth state choose the same pivot rows, so the production column kernel normally runs its
+    wave-uniform tails only.  Here every column gets its own random scaling of rho*theta, W and rho (x 0.5 .. 2 per level,
+    W up to +-30 m/s): the 64 columns of a wavefront now pivot differently (asserted through the kernel's own statistics)
+    and the kernel takes its lane-divergent tails.  The result must still be the C oracle's dgbsv restatement bit for bit,
+    and equal to the one-wavefront kernel, whose per-lane select path is an independent implementation of the interchange."""
+    import os
+    from oracle_lib import Oracle
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step2", g)
+    rng = np.random.default_rng(7)
+    rough = []
+    for node, edge in start:
+        node = node.copy(); edge = edge.copy()
+        node[2] *= rng.uniform(0.5, 2.0, node[2].shape)
+        node[4] *= rng.uniform(0.5, 2.0, node[4].shape)
+        edge[3] = rng.uniform(-30.0, 30.0, edge[3].shape)
+        rough.append((node, edge))
+    o = Oracle(g); o.set_state(1, rough); o.set_state(2, rough)
+    assert o.v_step_implicit(1, 2, 87.0) == 0
+    want = o.get_state(2)
+    out = []
+    for env in ({"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"}):
+        os.environ.update(env)
+        try:
+            e = Engine(g)
+            e.upload_state(1, rough)
+            e.copy_data(1, 2)
+            if env["TMX_VI_PAIR"] == "1":
+                e.pivot_stats(True)
+            e.v_step_implicit(1, 2, 87.0)
+            e.sync()
+            if env["TMX_VI_PAIR"] == "1":
+                uni, tot = e.pivot_stats(False)
+                print("pivot steps on the wave-uniform path: %d of %d" % (uni, tot))
+                assert 0 < tot and uni < tot, (uni, tot)         # some steps did take the lane-divergent tails
+            out.append(e.download_state(2))
+            e.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for got in out:
+        errs = gu.prognostic_errors(got, want)
+        assert max(errs) == EXACT, errs
+        # the duplicated seam nodes inside a patch as well (the solve scatters its result to them)
+        for (an, ae), (bn, be) in zip(got, out[0]):
+            assert np.array_equal(an[[0, 1, 2, 4]], bn[[0, 1, 2, 4]])
+            assert np.array_equal(ae[3], be[3])
+
+
 def test_closed_form_metric_is_bit_identical_to_stored_arrays():
     """tmx_set_patch_metric_factors: the kernels' in-register evaluation of the terrain-following metric
     (GridPatchCSGLL.cpp:441-566) is accepted only after a bit-for-bit comparison with the stored arrays, so
