@@ -155,6 +155,9 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_GROUP")) e->vi_group = (atoi(m) != 0) ? 1 : 0;
 	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
+	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
+	if (const char * m = getenv("TMX_VI_BACK_SUB")) e->vi_back_sub = atoi(m);
+	if (const char * m = getenv("TMX_VI_STAGGER_NS")) e->vi_stagger = atoi(m) / 10;
 	if (const char * m = getenv("TMX_GRAPH")) e->use_graph = atoi(m) != 0;
 	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
 	if (!plan_only(e)) {
@@ -2603,7 +2606,31 @@ extern "C" int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long l
 		out[0] = out[1] = 0;
 		if (e->d_pivot_stats) HIPCHK(hipMemcpy(out, e->d_pivot_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	}
-	if (enable && !e->d_pivot_stats) { HIPCHK(hipMalloc((void **)&e->d_pivot_stats, 2 * sizeof(unsigned long long))); HIPCHK(hipMemset(e->d_pivot_stats, 0, 2 * sizeof(unsigned long long))); }
+#ifdef TMX_PAIR_TIMING
+	// diagnostic builds (tools/vi_timing.py): the column kernel leaves one record of cycle counts per wavefront behind the two counters
+	const size_t stat_words = 2 + 8 * 4096;
+	if (e->d_pivot_stats && !enable) {
+		std::vector<unsigned long long> rec(stat_words);
+		HIPCHK(hipMemcpy(rec.data(), e->d_pivot_stats, stat_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		for (size_t w = 0; w < 4096; w++) {
+			const unsigned long long * q = &rec[2 + 8 * w];
+			if (q[0]) fprintf(stderr, "pairtiming wave %zu role %llu hw_id %llx xcc %llu work %llu wait %llu forward %llu back %llu\n", w, q[0] - 1, q[1], q[2], q[3], q[4], q[5], q[6]);
+		}
+		if (e->vi_split_back) {      // fill-in masks of three column groups (which U-row entries exist), one line per group
+			const int n = TMX_FTOT * (e->L + 1);
+			for (int g : { 0, 100, 400 }) {
+				std::vector<int> m(n);
+				HIPCHK(hipMemcpy(m.data(), (const int *)e->d_rhs + (size_t)g * n, n * sizeof(int), hipMemcpyDeviceToHost));
+				fprintf(stderr, "umask group %d:", g);
+				for (int j = 0; j < n; j++) fprintf(stderr, " %x", m[j] >> 4);
+				fprintf(stderr, "\n");
+			}
+		}
+	}
+#else
+	const size_t stat_words = 2;
+#endif
+	if (enable && !e->d_pivot_stats) { HIPCHK(hipMalloc((void **)&e->d_pivot_stats, stat_words * sizeof(unsigned long long))); HIPCHK(hipMemset(e->d_pivot_stats, 0, stat_words * sizeof(unsigned long long))); }
 	if (!enable && e->d_pivot_stats) { (void)hipFree(e->d_pivot_stats); e->d_pivot_stats = nullptr; }
 	return TMX_OK;
 }

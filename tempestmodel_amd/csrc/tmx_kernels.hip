@@ -29,6 +29,15 @@
 // test_percall_chain).  So the fused form IS the reference's arithmetic; everything else in this file stays unfused
 // (-ffp-contract=off), as the reference's own C++ is compiled without FMA contraction.
 #define LU_UPD(a, l, u) __builtin_fma(-(l), (u), (a))
+#ifndef TMX_STORE_PRED
+#define TMX_STORE_PRED true
+#endif
+#ifndef TMX_TAIL
+#define TMX_TAIL 2
+#endif
+#ifndef TMX_SEARCH_TREE
+#define TMX_SEARCH_TREE 0      // the tree form of the pivot search costs the pair kernel 8-10 spilled registers
+#endif
 
 #define OPC(op, k, off) p.ops[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
 
@@ -2886,8 +2895,14 @@ template <bool CARRY, bool UD = false>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
 	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy,
-	double udP = 0.0, double udW = 0.0, const double * rmtab = nullptr)
+	double udP = 0.0, double udW = 0.0, const double * rmtab = nullptr, long long * tseg = nullptr)
 {
+#ifdef TMX_PAIR_TIMING
+	long long ts_ = __builtin_readcyclecounter();
+#define CBSTAMP(i) do { if (tseg) { const long long t1_ = __builtin_readcyclecounter(); tseg[i] += t1_ - ts_; ts_ = t1_; } } while (0)
+#else
+#define CBSTAMP(i)
+#endif
 	const int L = p.L;
 #pragma unroll
 	for (int d = 0; d < TMX_BW; d++) { rowP[d] = 0.0; rowW[d] = 0.0; rowR[d] = 0.0; }
@@ -2916,6 +2931,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		pe1 += ic_m * B.pn; pe1 += ic_0 * C.pn; re1 += ic_m * B.rn; re1 += ic_0 * C.rn;
 	}
 
+	CBSTAMP(0);
 	if (k < L) {
 		const double invJ = 1.0 / cc.jn;
 		const double pm = A.pn, p0 = B.pn, pp = C.pn, rm = A.rn, r0 = B.rn, rp = C.rn;
@@ -2973,6 +2989,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		}
 	}
 
+	CBSTAMP(1);
 	// ---- node k quantities the W rows of this block and of the next one use ----
 	double ex0 = 0.0, wn0 = 0.0, xdn0 = 0.0, ke0 = 0.0;
 	if (k <= L - 1 && (CARRY || k >= 1)) {
@@ -2982,6 +2999,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		const double ca = cc.c2a0 * B.un + cc.c2a1 * B.vn + B.ca2 * wn0, cb = cc.c2a1 * B.un + cc.c2b1 * B.vn + B.cb2 * wn0;
 		ke0 = 0.5 * (ca * B.un + cb * B.vn + xdn0 * wn0);
 	}
+	CBSTAMP(2);
 	if (k >= 1 && k <= L - 1) {
 		const double pm = A.pn, p0 = B.pn;
 		double exm, wnm, xdnm, kem;
@@ -3041,12 +3059,14 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		rowW[DOFF(1, 1, 0)] -= cc.upc * fabs(xde) * dd0;
 		rowW[DOFF(1, 1, 1)] -= cc.upc * fabs(xde) * ddp;
 	}
+	CBSTAMP(3);
 	rowP[4] += cc.invdt; rowW[4] += cc.invdt; rowR[4] += cc.invdt;
 	if (CARRY) {
 		cy.ex = ex0; cy.wn = wn0; cy.xdn = xdn0; cy.ke = ke0;
 		cy.ue = ue_c; cy.ve = ve_c; cy.xd = xd1; cy.pe = pe1; cy.re = re1;
 	}
 #undef DOFF
+#undef CBSTAMP
 }
 
 #undef OPCL
@@ -3076,10 +3096,31 @@ __device__ __forceinline__ double * vi_stream_base_g(double * AB, int n, int grp
 	return AB + ((size_t)grp * n * TMX_UW) * 64 + lane;
 }
 
-template <bool SPARSE>
+// PRED: the sparse stores of the fill-in entries are predicated instead of branched around: the condition "some lane holds a
+// non-zero" is wave-uniform, so the compiler would put an s_cbranch_vccz in front of every one of the five stores (a VALU
+// compare, the wait for VCC and a branch, five times per pivot step, on the elimination's critical chain).  Folding an opaque
+// per-lane `1` into the condition makes it divergent for the compiler: the store then runs under an EXEC mask that is all
+// ones or all zeros (an instruction with an empty mask issues and does nothing), no branch.
+template <bool SPARSE, bool PRED = false>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
+	if (SPARSE && PRED) {
+#pragma unroll
+		for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
+		AB[((size_t)jcol * TMX_UW + TMX_BW) * 64] = pb;
+		int one = 1;
+		asm volatile("" : "+v"(one));
+		int mask = 0;
+#pragma unroll
+		for (int c = 4; c < TMX_BW; c++) {
+			const bool any = __builtin_amdgcn_ballot_w64(piv[c] != 0.0) != 0;
+			mask |= any ? (1 << c) : 0;
+			if (any && one) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
+		}
+		if (threadIdx.x == 0) umask[jcol] = mask;
+		return;
+	}
 #ifdef TMX_ABL_NO_USTORE     // ablation builds: elimination without the U-row stream (one value kept alive)
 	if (piv[0] == 12345.678 && pb == 1.0) AB[0] = piv[1];
 	return;
@@ -3118,6 +3159,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	for (int c = 0; c < TMX_BW; c++) { piv[c] = (c == Z && PV != 4) ? 0.0 : R[PV][c]; t0[c] = (c == Z) ? 0.0 : R[0][c]; }
 	const double pb = b[PV], tb0 = b[0];
 	if (piv[0] == 0.0) singular = true;
+#if TMX_TAIL == 1
 	lu_store_urow<SPARSE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / piv[0];
 #pragma unroll
@@ -3135,27 +3177,69 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 #pragma unroll
 	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
+#else
+	// The reciprocal of the pivot and the four multipliers are started BEFORE the U-row stores: the IEEE division is a chain
+	// of a dozen dependent instructions, and the (conditional) stores -- which nothing waits for -- cover its latency.  The
+	// first entry of the incoming row is what the NEXT pivot search waits for: its LDS read is issued up front as well.
+	const double in0 = inrow[0];
+	const double rcp = 1.0 / piv[0];
+	double l[5];
+#pragma unroll
+	for (int r = 1; r < 5; r++) l[r] = ((r == PV) ? t0[0] : R[r][0]) * rcp;
+	lu_store_urow<SPARSE, TMX_STORE_PRED>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+#pragma unroll
+	for (int r = 1; r < 5; r++) {
+		// after the interchange position r holds old row r, except position PV, which holds old row 0
+#pragma unroll
+		for (int c = 1; c < TMX_BW; c++) {
+			const double src = (r == PV) ? t0[c] : ((c == Z && r != 4) ? 0.0 : R[r][c]);
+			R[r - 1][c - 1] = LU_UPD(src, l[r], piv[c]);
+		}
+		R[r - 1][TMX_BW - 1] = 0.0;
+		b[r - 1] = LU_UPD((r == PV) ? tb0 : b[r], pb, l[r]);
+	}
+	R[4][0] = in0;
+#pragma unroll
+	for (int c = 1; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
+	b[4] = inb;
+#endif
 }
 
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
 // the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
 // the per-lane select path below.
-template <bool SPARSE, bool UNI = false, int IS = 1>
+template <bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask, int * n_uniform = nullptr)
 {
 	int pv = 0;
-	double amax = fabs(R[0][0]);
+	if (UNI && TMX_SEARCH_TREE) {
+		// first maximum of |column 0| (dgbtf2's idamax) as a tree: rows 0/1 and 2/3 side by side; strict comparisons keep the
+		// lower row on ties, so the result is the sequential first maximum
+		const double a0 = fabs(R[0][0]), a1 = fabs(R[1][0]), a2 = fabs(R[2][0]), a3 = fabs(R[3][0]), a4 = fabs(R[4][0]);
+		const bool g1 = a1 > a0, g3 = a3 > a2;
+		const double m01 = g1 ? a1 : a0, m23 = g3 ? a3 : a2;
+		const int i01 = g1 ? 1 : 0, i23 = g3 ? 3 : 2;
+		const bool gh = m23 > m01;
+		const double m03 = gh ? m23 : m01;
+		const int i03 = gh ? i23 : i01;
+		pv = (a4 > m03) ? 4 : i03;
+	} else {
+		double amax = fabs(R[0][0]);
 #pragma unroll
-	for (int r = 1; r < 5; r++) {
-		const double v = fabs(R[r][0]);
-		if (v > amax) { amax = v; pv = r; }
+		for (int r = 1; r < 5; r++) {
+			const double v = fabs(R[r][0]);
+			if (v > amax) { amax = v; pv = r; }
+		}
 	}
 	if (UNI) {
 		const int pv0 = __builtin_amdgcn_readfirstlane(pv);
 		if (__builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
 			if (n_uniform) (*n_uniform)++;      // wave-uniform counter (scalar add): pivot steps that took the renaming path
+			// the usual pivot row of this kind of matrix row first (rho*theta / W / rho rows pivot 4 / 3 / 2 rows down almost
+			// everywhere): one compare and branch instead of the switch's two or three
+			if (EXPECT >= 0 && pv0 == EXPECT) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
 			switch (pv0) {
 				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
@@ -3238,8 +3322,13 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 	for (int c = 0; c < 4; c++) d.u[c] = rb[c * 64];
 #pragma unroll
 	for (int c = 4; c < TMX_BW; c++) {
+#ifdef TMX_EXP_BRANCHY_BACK
+		d.u[c] = 0.0;
+		if (mk & (1 << c)) d.u[c] = rb[c * 64];
+#else
 		const double * bp = (mk & (1 << c)) ? rb + c * 64 : zp;
 		d.u[c] = bp[0];
+#endif
 	}
 	d.y = rb[TMX_BW * 64];
 	const int k = rr / TMX_FTOT;
@@ -3412,25 +3501,53 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 #endif
 }
 
+// usual pivot rows (window row index) of the W / rho / rho*theta rows of the column Jacobian, tried first by the pair kernel
+#ifndef TMX_EXPECT_T
+#define TMX_EXPECT_T 4
+#define TMX_EXPECT_W 3
+#define TMX_EXPECT_R 2
+#endif
 // Two-wavefront variant of k_vi_fused: the block rows of a column are independent of one another, only the
 // elimination is sequential.  Wavefront 0 of the workgroup assembles block row t (compute_block, the same code)
 // into a double-buffered LDS ring while wavefront 1 runs the three pivot steps of block row t-1; one barrier
 // per block row.  The dependent chain of a column shrinks from assembly + LU to max(assembly, LU) per level
 // (cycle counts in DESIGN.md), which is what bounds the kernel on small per-GPU grids.  Same statements on the
 // same operands: bit-identical to k_vi_fused.
-template <bool SPARSE, bool CLOSED, int PAIRS>
+// BACK = false: the kernel ends with the elimination and leaves the fill-in masks of its U rows in `gmask` ([column group][3(L+1)]);
+// k_vi_back does the back substitution as a launch of its own (one wavefront per workgroup, so that the HBM-bound half of the
+// solve is spread evenly over the CUs whatever the residency of the pairs was).
+template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true>
 __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
-	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw, unsigned long long * __restrict__ stats)
+	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw, unsigned long long * __restrict__ stats, int * __restrict__ gmask = nullptr,
+	int stagger = 0)
 {
 	extern __shared__ double opsl_mem[];
 	double * opsl = opsl_mem;
 	const int L = p.L;
 	constexpr int MM = CLOSED ? 1 : 2;
 	constexpr int NQ = 3 * TMX_BW + 3;                                       // doubles per block row and column
+	// Staggered start (stagger = window in units of 10 ns, 0 = off): workgroup i begins i / gridDim.x of the window late.  All
+	// workgroups are resident at once and would otherwise run in lock-step -- every wavefront in its issue- and latency-bound
+	// elimination first, then every wavefront in its HBM-bound back substitution; spread out, the back substitutions of the
+	// early workgroups stream while the late ones still eliminate.  A sleeping wavefront issues nothing.
+	if (stagger > 0) {
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		const unsigned long long wait = (unsigned long long)stagger * blockIdx.x / gridDim.x;
+		while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+	}
 	double * etal = opsl_mem + TMX_OP_COUNT * (L + 1) * TMX_OPW;             // [2L+1]
 	// PAIRS producer/consumer pairs per workgroup (2 pairs = 4 wavefronts = one per SIMD of a CU)
-	const int lane = threadIdx.x, wv = WAVE_UNIFORM(threadIdx.y), role = wv & 1, pair = wv >> 1;
+	// Wavefronts w and w + 4 of a workgroup share a SIMD (a workgroup's wavefronts go to the SIMDs in cyclic order).  With three
+	// pairs (six wavefronts: one workgroup per CU, every CU carries the same load) the two doubly loaded SIMDs get
+	// consumer + consumer and producer + consumer, never producer + producer (the assembly is the issue-heavy role):
+	// wavefronts 0..5 = C0 P0 P1 P2 C1 C2.
+	const int lane = threadIdx.x, wv = WAVE_UNIFORM(threadIdx.y);
+#ifndef TMX_PAIR3_INTERLEAVED
+	const int role = (PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1), pair = (PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1);
+#else
+	const int role = wv & 1, pair = wv >> 1;
+#endif
 	double * ring = etal + 2 * L + 1 + (size_t)pair * 2 * NQ * 64;           // [PAIRS][2][NQ][64]
 	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * 2 * NQ * 64;        // [512] exp / log tables (exner_from_rhotheta_lds)
 	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
@@ -3458,27 +3575,88 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
 		cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
 		const MetCol mcol = met_col(p, col);
-		NodeLev nA, nB = load_node<MM>(p, mcol, xin, -1, col, etal), nC = load_node<MM>(p, mcol, xin, 0, col, etal);
-		EdgeLev eA, eB = load_edge<MM>(p, mcol, xin, -1, col, etal), eC = load_edge<MM>(p, mcol, xin, 0, col, etal);
-		NodeLev nN = load_node<MM>(p, mcol, xin, 1, col, etal);
-		EdgeLev eN = load_edge<MM>(p, mcol, xin, 1, col, etal);
+		// Level window of block row t: nodes / interfaces t-1, t, t+1 in (A, B, C).  The loads of level t+4 are issued at the top
+		// of iteration t into one of two staging sets (Y0 / Y1, alternating: the loop body is instantiated twice) and are first
+		// touched -- by a register move into N1 -- at the end of iteration t+1, two block rows later: under load the memory latency
+		// of this kernel is longer than one block row (measured: with the loads of level t+2 moved into place at the top of the
+		// next iteration the producer stalled 1 000 - 2 700 cycles per block row on its prefetch), and vmcnt retires in order,
+		// so a wait for the newest load cannot be hidden behind older ones.  The staging sets hold the five loaded values of a
+		// level only; the closed-form metric of the level is evaluated when it enters the window (stored-metric engines, whose
+		// levels carry six more loaded values, keep the one-row scheme: DEEP = false).
+		constexpr bool DEEP = CLOSED;
+		struct LevRaw { double un, vn, pn, rn, we; };
+		auto load_raw = [&](int l) {
+			LevRaw r;
+			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+			r.un = xin[TMX_SLAB_U(L, lc) * NS + col]; r.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
+			r.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; r.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
+			r.we = xin[TMX_SLAB_W(L, le) * NS + col];
+			return r;
+		};
+		auto enter = [&](const LevRaw & r, int l, NodeLev & n, EdgeLev & e) {      // level l becomes the window's C
+			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+			n.un = r.un; n.vn = r.vn; n.pn = r.pn; n.rn = r.rn; e.we = r.we;
+			metric_node3<MM>(p, mcol, lc, col, n.ca2, n.cb2, n.cx2, etal);
+			metric_edge<MM>(p, mcol, le, col, e.ce0, e.ce1, e.ce2, etal);
+		};
+		NodeLev nA = load_node<MM>(p, mcol, xin, -1, col, etal), nB = load_node<MM>(p, mcol, xin, 0, col, etal), nC = load_node<MM>(p, mcol, xin, 1, col, etal);
+		EdgeLev eA = load_edge<MM>(p, mcol, xin, -1, col, etal), eB = load_edge<MM>(p, mcol, xin, 0, col, etal), eC = load_edge<MM>(p, mcol, xin, 1, col, etal);
+		LevRaw rN1 = load_raw(2), rY0 = load_raw(3), rY1 = rY0;
+		NodeLev nN = load_node<MM>(p, mcol, xin, 2, col, etal);      // DEEP = false: level t+2, loaded one block row ahead
+		EdgeLev eN = load_edge<MM>(p, mcol, xin, 2, col, etal);
 		BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 		double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
-		for (int t = 0; t <= L + 1; t++) {
+#ifdef TMX_PAIR_TIMING
+		long long tp_work = 0, tp_wait = 0, tp_mark = __builtin_readcyclecounter();
+		long long tp_seg[6] = { 0, 0, 0, 0, 0, 0 };
+		const long long tp_start = tp_mark;
+#define PMARK(acc) do { const long long t1_ = __builtin_readcyclecounter(); acc += t1_ - tp_mark; tp_mark = t1_; } while (0)
+#else
+#define PMARK(acc)
+#endif
+		auto block_row = [&](int t, LevRaw & rYl, const LevRaw & rYm) {
 			if (t <= L) {
-				nA = nB; nB = nC; nC = nN; eA = eB; eB = eC; eC = eN;
-				nN = load_node<MM>(p, mcol, xin, t + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 2, col, etal);
+				if (DEEP) rYl = load_raw(t + 4);
+				else { /* issued below, after the shift */ }
 #ifdef TMX_ABL_FAST_PRODUCER      // ablation builds: the block row is evaluated once, the ring is refilled with it every time
 				if (t == 0)
 #endif
+#ifdef TMX_PAIR_TIMING
+				PMARK(tp_seg[4]);      // prefetch issue
+				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab, tp_seg);
+				tp_mark = __builtin_readcyclecounter();
+#else
 				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
+#endif
 				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
 #pragma unroll
 				for (int c = 0; c < TMX_BW; c++) { q[c * 64] = rP[c]; q[(TMX_BW + c) * 64] = rW[c]; q[(2 * TMX_BW + c) * 64] = rR[c]; }
 				q[(3 * TMX_BW) * 64] = fP; q[(3 * TMX_BW + 1) * 64] = fW; q[(3 * TMX_BW + 2) * 64] = fR;
 			}
+			PMARK(tp_work);
 			__syncthreads();
+			PMARK(tp_wait);
+			nA = nB; nB = nC; eA = eB; eB = eC;
+			if (DEEP) { enter(rN1, t + 2, nC, eC); rN1 = rYm; }
+			else { nC = nN; eC = eN; nN = load_node<MM>(p, mcol, xin, t + 3, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 3, col, etal); }
+#ifdef TMX_PAIR_TIMING
+			PMARK(tp_seg[5]);      // window shift (DEEP: touches loads issued two block rows earlier)
+#endif
+		};
+		for (int t = 0; t <= L + 1; t += 2) {
+			block_row(t, rY0, rY1);
+			if (t + 1 <= L + 1) block_row(t + 1, rY1, rY0);
 		}
+#ifdef TMX_PAIR_TIMING
+		if (stats && lane == 0) {
+			unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);
+			q[0] = 1 + role; q[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+			q[3] = tp_work; q[4] = tp_wait; q[5] = (unsigned long long)((long long)__builtin_readcyclecounter() - tp_start); q[6] = 0;
+			// segments of the assembly: interface interpolation | flux rows (P, R) | Exner + node quantities | W row | shift + prefetch issue
+			if (blockIdx.x % 16 == 0) printf("pairtiming producer wg %d pair %d segments: interp %lld flux %lld exner %lld wrow %lld prefetch issue %lld window shift %lld ring writes %lld\n",
+				(int)blockIdx.x, pair, tp_seg[0], tp_seg[1], tp_seg[2], tp_seg[3], tp_seg[4], tp_seg[5], tp_work);
+		}
+#endif
 		return;
 	}
 
@@ -3501,6 +3679,10 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		for (int c = 0; c < TMX_BW; c++) R[r][c] = 0.0;
 		b[r] = 0.0;
 	}
+#ifdef TMX_PAIR_TIMING
+	long long tp_work = 0, tp_wait = 0, tp_mark = __builtin_readcyclecounter();
+	const long long tp_start = tp_mark;
+#endif
 	for (int t = 0; t <= L + 1; t++) {
 		if (t >= 1) {
 			const int m = t - 1;
@@ -3528,12 +3710,15 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 			if (m < 0)
 #endif
 			{
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
+				// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
+				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_W>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
+				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_R>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
+				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_T>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
 			}
 		}
+		PMARK(tp_work);
 		__syncthreads();
+		PMARK(tp_wait);
 	}
 	{
 		double z[TMX_BW];
@@ -3541,12 +3726,45 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
 		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask, &nuni);
 	}
+#ifdef TMX_PAIR_TIMING
+	const long long tp_fwd = __builtin_readcyclecounter();
+#endif
 	if (singular) atomicExch(flag, 1);
 	// statistics for bench.py (stats = {pivot steps on the wave-uniform path, all pivot steps}, per wavefront)
 	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
 #ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
-	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
+	if (BACK) vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
+	else for (int j = lane; j < n; j += 64) gmask[(size_t)grp * n + j] = umask[j];      // this wavefront's own LDS writes: no barrier needed
 #endif
+#ifdef TMX_PAIR_TIMING
+	if (stats && lane == 0) {
+		unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);
+		q[0] = 1 + role; q[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+		q[3] = tp_work; q[4] = tp_wait; q[5] = (unsigned long long)(tp_fwd - tp_start); q[6] = (unsigned long long)((long long)__builtin_readcyclecounter() - tp_fwd);
+	}
+#endif
+#undef PMARK
+}
+
+// Back substitution of k_vi_pair<..., BACK = false>: one wavefront = one column group, same statements as the in-kernel call.
+template <int NSUB>
+__global__ __launch_bounds__(64 * NSUB) void k_vi_back(KParams p, const double * xin, double * xup, int nunique, int NUS,
+	const int * __restrict__ ucol, const int * __restrict__ udep, double * __restrict__ AB, int cpw, const int * __restrict__ gmask)
+{
+	extern __shared__ int umask_mem[];
+	// NSUB wavefronts share a column group: wavefront w serves the group's lanes [w * 64 / NSUB, (w + 1) * 64 / NSUB) with as
+	// many active lanes (more wavefronts in flight for the same bytes: the phase is bound by the memory system)
+	const int L = p.L, grp = blockIdx.x;
+	const int n = TMX_FTOT * (L + 1);
+	for (int j = threadIdx.x; j < n; j += 64 * NSUB) umask_mem[j] = gmask[(size_t)grp * n + j];
+	__syncthreads();
+	if ((int)(threadIdx.x & 63) >= 64 / NSUB) return;
+	const int lane = (threadIdx.x >> 6) * (64 / NSUB) + (threadIdx.x & 63);
+	const int ulast = min(nunique, (grp + 1) * cpw) - 1;
+	const int u = (grp * cpw < nunique) ? min(grp * cpw + min(lane, cpw - 1), ulast) : nunique - 1;
+	const int col = ucol[u];
+	const double * RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams
+	vi_back_substitute(L, (size_t)p.NS, n, u, col, NUS, vi_stream_base_g(AB, n, grp, lane), RHS, xin, xup, udep, umask_mem, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3785,11 +4003,27 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + TMX_RMTAB_DOUBLES * sizeof(double);
 		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
-#define LAUNCH_PAIR(CL_, NP_) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
-			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats)
+		// back substitution as a launch of its own (TMX_VI_SPLIT_BACK=0: inside the pair kernel); the masks go through d_rhs,
+		// which only the split cross-check kernels use otherwise
+		const bool split_back = e->vi_split_back != 0;
+		const int stagger = e->vi_stagger;
+		const int ngrp_launched = ((ngrp + pairs - 1) / pairs) * pairs;
+		const bool split = split_back && (size_t)ngrp_launched * TMX_FTOT * (p.L + 1) * sizeof(int) <= (size_t)TMX_FTOT * (p.L + 1) * e->NUS * sizeof(double);
+#define LAUNCH_PAIR(CL_, NP_) do { if (split) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, false>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
+		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
+		else if (pairs == 3) { if (p.closed) LAUNCH_PAIR(true, 3); else LAUNCH_PAIR(false, 3); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR
+		if (split) {
+			const int nsub = e->vi_back_sub;
+#define LAUNCH_BACK(NS_) hipLaunchKernelGGL(k_vi_back<NS_>, dim3(ngrp), dim3(64 * NS_), (size_t)TMX_FTOT * (p.L + 1) * sizeof(int), e->stream, p, xin, xup, e->nunique, e->vi_stream_cols, \
+				(const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, cpw, (const int *)e->d_rhs)
+			if (nsub == 2) LAUNCH_BACK(2); else if (nsub == 4) LAUNCH_BACK(4); else LAUNCH_BACK(1);
+#undef LAUNCH_BACK
+		}
 		return;
 	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \

@@ -813,7 +813,12 @@ def test_fused_column_kernels_are_bit_identical_to_split_kernels():
     for env in ({"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1"}, {"TMX_VI_GROUP": "1"},
                 {"TMX_VI_MODE": "split"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0", "TMX_VI_SPARSE": "0"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"},
-                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_CPW": "37"}):
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_CPW": "37"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "3", "TMX_VI_CPW": "50"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1", "TMX_VI_BACK_SUB": "2", "TMX_VI_CPW": "60"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1", "TMX_VI_BACK_SUB": "4", "TMX_VI_PAIR_WG": "3"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_STAGGER_NS": "5000"}):
         os.environ.update(env)
         try:
             e = Engine(g)
