@@ -45,6 +45,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 #                pass 2 = 12.5 doubles per pass on average.  Pricing it with the 216 B row put it above the 8 TB/s peak.
 #   lincomb    : the copies left un-fused (device copies of whole / partial instances); no SURVEY row of its own
 ALG_BYTES = {"h_explicit": 200.0 - 40.0 + 150.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 100.0, "lincomb": 0.0}
+# SURVEY.md 8(d)'s own per-launch rows, printed beside the figures above wherever they differ (the contract's numbers stay visible)
+SURVEY_8D_BYTES = {"h_explicit": 200.0 + 80.0, "v_implicit": 272.0, "dss": 60.0, "hypervis": 216.0, "lincomb": 0.0}
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
 # What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
 OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
@@ -55,6 +57,7 @@ OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)",
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
+PROFILE_TAG = "r03" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic_ne30_L30_n1.json")) else "r02"
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
 OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
@@ -65,7 +68,9 @@ def measured_traffic(op, ne, L, world, launches_per_step):
     separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  One table per
     workload shape, profiles/r02_pmc_traffic_ne<ne>_L<L>_n<ranks>.json (n > 1: the share of rank 0, taken with a lone
     rank-0 engine of the n-rank layout, tools/rank_share_timing.py); a shape without a table -> None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
     if not os.path.exists(path):
         return None
     try:
@@ -126,10 +131,15 @@ def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
 def cpu_baseline_allcores(ne, L, dt, nsteps_ref):
     """The reference on its 24-patch layout under mpiexec -np 24 ('N = all physical cores, stated'), when the
     host has at least 24 cores; the same routine as the 6-rank run."""
-    if (os.cpu_count() or 1) < 24:
+    n = os.cpu_count() or 1
+    if n < 24:
         return None
-    b = cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=24)
-    return b
+    # 96 ranks on the reference's 96-patch layout (6 x 4 x 4) where the host has the hardware threads, else 24 on the 24-patch one
+    if n >= 96:
+        b = cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=96)
+        if b is not None:
+            return b
+    return cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=24)
 
 
 def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
@@ -181,7 +191,7 @@ def main():
     ap.add_argument("--ppd", type=int, default=2, help="patches per panel direction (2 -> 24 patches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
-    ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "auto"), choices=["auto", "rccl", "p2p"],
+    ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "rccl"), choices=["auto", "rccl", "p2p"],
                     help="multi-rank halo transport: RCCL send/recv, peer-to-peer writes into IPC-mapped ghost buffers, or (default) "
                          "set up both, check that they deliver identical bytes, time them on this machine and keep the faster; "
                          "falls back to RCCL when the peer-to-peer mapping cannot be set up or disagrees")
@@ -367,11 +377,10 @@ def main():
     # sanity: the state must still be finite
     chk = eng.download_state(0)
     import numpy as np
-    for p in eng.local_patches:
-        if not (np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all()):
-            if os.environ.get("TMX_LIBRARY"):      # ablation builds (tools/ablate.sh) skip parts of the arithmetic on purpose
-                break
-            sys.exit("bench.py: state became non-finite")
+    state_finite = all(np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all() for p in eng.local_patches)
+    ablation_build = bool(os.environ.get("TMX_LIBRARY"))      # tools/ablate.sh builds skip parts of the arithmetic on purpose
+    if not state_finite and not ablation_build:
+        sys.exit("bench.py: state became non-finite")
 
     if rank == 0:
         n_el = 6 * ne * ne
@@ -405,6 +414,8 @@ def main():
                 extra["compulsory_bytes_per_launch"] = 8.0 * ((5 * L + 1) * eng.info(1) + (3 * L + 1) * eng.info(0))
             return {"launches_per_step": op_launches[op] / args.steps, "ms_per_launch": ms, **extra,
                     "achieved_GBs": ALG_BYTES[op] * local_points / max(ms * 1e-3, 1e-12) / 1e9,
+                    "bytes_per_point": ALG_BYTES[op], "survey_8d_bytes_per_point": SURVEY_8D_BYTES[op],
+                    "achieved_GBs_with_survey_8d_row": SURVEY_8D_BYTES[op] * local_points / max(ms * 1e-3, 1e-12) / 1e9,
                     "traffic": tr, "measured_GBs": (tr / max(ms * 1e-3, 1e-12) / 1e9) if tr else None,
                     "bound": OP_BOUND[op]}
         out = {
@@ -421,7 +432,10 @@ def main():
                            len(grid.patches), world, "processes sharing ONE GPU (multi-process path check, not a scaling number)" if args.share_device and world > 1 else "GPU(s)",
                            halo_note),
                        "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "operation": dom,
+            # `bound`: what limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64
+            # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
+            "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
+                         "kernel": kernel_name, "operation": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
@@ -432,12 +446,18 @@ def main():
                          # default path: no MFMA instruction is issued (the bit-exact contractions are LDS + VALU); with TMX_MFMA=1
                          # the fused explicit kernel issues 12 v_mfma_f64_4x4x4_4b per point: counters in profiles/r02_mfma_ab.json
                          "mfma_utilisation": mfma["active"], "mfma_ab": mfma["ab"],
+                         "offline_sources": "traffic, mfma_utilisation and mfma_ab are read from the committed rocprofv3 passes "
+                                            "(profiles/%s_*), not measured by this run; times and rates are this run's" % PROFILE_TAG,
                          },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "ms_per_step_with_event_markers": 1e3 * wall_prof / args.steps,
             "developed_steps": args.develop, "host_cpu_count": os.cpu_count(),
             "physics_after_every_step": args.physics,
+            "state_finite": bool(state_finite),
         }
+        if ablation_build:      # a library named by TMX_LIBRARY: never a result, say so in the line itself
+            out["ablation_build"] = True
+            out["library"] = os.environ["TMX_LIBRARY"]
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ne, L, dt, 6, 6)      # ~15 s of CPU work (1 warm-up + 6 timed steps)
             mpi = cpu_baseline_mpi(ne, L, dt, 6)                     # + the reference's own 6-rank MPI run, ~20 core-seconds

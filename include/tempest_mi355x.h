@@ -366,10 +366,15 @@ int tmx_comm_init(tmx_engine * e, const unsigned char id[128]);
  *                            the reference's MPI_Allgather, torch.distributed); maps the neighbours and switches the exchange over.
  * Ranks are separate processes (a process cannot map its own export); they may share a device.  Before tmx_destroy the caller
  * lets all ranks finish (a barrier): neighbours write into this rank's block.  A neighbour whose message does not arrive within
- * 60 s (TMX_P2P_TIMEOUT_S) makes the next tmx_sync return TMX_ERR_COMM instead of hanging the device. */
+ * TMX_P2P_TIMEOUT_S (default 600 s; 0 = wait for ever, like MPI_Wait) makes the next tmx_sync return TMX_ERR_COMM instead of
+ * hanging the device; the exchanges queued behind the failed one return at once.  The engine's state is then invalid.
+ *   tmx_halo_p2p_reset:      recovery after TMX_ERR_COMM.  Every rank returns from tmx_sync, barrier, every rank calls this
+ *                            (arrival counters and exchange count back to zero), barrier, upload the state again, go on with
+ *                            either transport. */
 int tmx_halo_p2p_blob_bytes(tmx_engine * e);
 int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob);
 int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs);
+int tmx_halo_p2p_reset(tmx_engine * e);
 /* With both transports set up (tmx_comm_init and tmx_halo_p2p_connect): on = 1 peer-to-peer, on = 0 RCCL.  Every rank
  * switches at the same point of its program (bench.py times one against the other at start-up and keeps the faster). */
 int tmx_halo_p2p_enable(tmx_engine * e, int on);

@@ -155,6 +155,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_GROUP")) e->vi_group = (atoi(m) != 0) ? 1 : 0;
 	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
+	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
 	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
 	if (const char * m = getenv("TMX_VI_BACK_SUB")) e->vi_back_sub = atoi(m);
 	if (const char * m = getenv("TMX_VI_STAGGER_NS")) e->vi_stagger = atoi(m) / 10;
@@ -865,7 +866,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// tiles first, the pack + grouped send/recv starts on the exchange stream, and the remaining tiles -- three quarters
 	// of a 15 x 15-element patch -- are updated while the wire is busy (hv_stage_split).  TMX_NO_SPLIT=1 switches it off.
 	e->split_stage = false;
-	if (NR > 1 && !plan.send_cols.empty() && !e->sw && !getenv("TMX_NO_SPLIT")) {
+	if (NR > 1 && !plan.send_cols.empty() && !getenv("TMX_NO_SPLIT")) {
 		std::vector<char> early(e->NS / 64, 0);
 		for (int c : plan.send_cols) early[c / 64] = 1;
 		std::vector<int> qe, ql;
@@ -899,7 +900,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	const int n = TMX_FTOT * (L + 1);
 	// column-solve scratch: per-wavefront U-row streams [NUS/64][n][9 + 1][64] plus a zero page (fused / pair kernels);
 	// the split cross-check kernels keep the band matrix [n][9][NUS] and the right-hand sides [n][NUS] in the same buffers
-	const size_t zpage = 64 * sizeof(double);
+	const size_t zpage = 128 * sizeof(double);      // one 16-byte slot per lane
 	// Columns per wavefront of the two-wavefront column kernel.  A pair (assembly + elimination wavefront) is the unit of
 	// residency: 512 pairs give every SIMD of the 256 CUs one wavefront, 1024 two.  With 64 columns per pair a grid
 	// such as ne30 (760 groups) loads 124 CUs twice and 132 once and the kernel runs as long as the doubly loaded ones;
@@ -1258,7 +1259,7 @@ static KParams make_params(const tmx_engine * e) {
 	p.g2d = e->d_g2d; p.g3n = e->d_g3n; p.g3e = e->d_g3e; p.ops = e->d_ops;
 	p.eta = e->d_eta; p.closed = e->metric_closed ? 1 : 0;
 	p.inv_da = 1.0 / e->cfg.element_delta_a;
-	p.quads = nullptr;
+	p.quads = e->stage_quads;      // tile list of a boundary-first stage in progress (hv_stage_split), else all tiles
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
 	return p;
@@ -1399,33 +1400,44 @@ static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int 
 
 // LinearCombineData(coeff -> d) + H.StepExplicit(i, d) + V.StepExplicit(i, d) in one pass: the combination is
 // evaluated inside the kernels (same accumulation order), the combined state is never written and re-read.
-static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double dt, const double * coeff, int n_coeff) {
-	const double * src[12]; double cf[12]; int premul = 0;
-	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul);
-	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
-	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul);
-	if (e->nt > 0) {
-		// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
-		// (TMX_TRACER_LINCOMB_PASS=1: formed by a separate pass first, for A/B and tests)
-		if (getenv("TMX_TRACER_LINCOMB_PASS")) {
-			const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
-			const double * tsrc[12];
-			for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
-			tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
-			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
-		} else
-			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, n, src, cf, premul);
-	}
+// the kernels of one explicit stage (H + tracers + uniform diffusion + V) over the tiles make_params() selects: all of them,
+// or the tile list of a boundary-first stage (e->stage_quads).  n > 0: the update starts from the combination src / cf.
+static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, double dt, int n, const double * const * src, const double * cf, int premul) {
 	int r;
-	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;
+	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
+	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul);
+	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1);
+	if (e->nt > 0) {
+		if (n > 0) {
+			// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
+			// (TMX_TRACER_LINCOMB_PASS=1: formed by a separate pass first, for A/B and tests; whole patches only)
+			if (getenv("TMX_TRACER_LINCOMB_PASS")) {
+				const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
+				const double * tsrc[12];
+				for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
+				tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
+				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+			} else
+				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, n, src, cf, premul);
+		} else
+			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
+	}
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
 	if (e->udiff) {
 		if (udv_fused(e) && (r = check_reference_state(e))) return r;
 		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
 	}
-	if ((r = v_explicit_extras(e, iinit, iupd, dt, udv_fused(e)))) return r;
+	return v_explicit_extras(e, iinit, iupd, dt, udv_fused(e));
+}
+
+static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double dt, const double * coeff, int n_coeff) {
+	const double * src[12]; double cf[12]; int premul = 0;
+	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul);
+	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
+	ProfScope ps(e, TMX_K_H_EXPLICIT);
+	int r;
+	if ((r = hv_stage_kernels(e, iinit, iupd, iupd, dt, n, src, cf, premul))) return r;
+	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;
 	return launch_check("hv_step_explicit(lincomb)");
 }
 
@@ -1434,26 +1446,21 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 // CopyData(initial -> update) is folded in).  Bit-identical to the separate calls.
 static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
-	tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1);
-	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
 	int r;
+	if ((r = hv_stage_kernels(e, iinit, ibase, iupd, dt, 0, nullptr, nullptr, 0))) return r;
 	if ((r = surface_copy(e, ibase, iupd))) return r;       // the folded CopyData(base -> update)
-	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
-	if (e->udiff) {
-		if (udv_fused(e) && (r = check_reference_state(e))) return r;
-		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
-	}
-	if ((r = v_explicit_extras(e, iinit, iupd, dt, udv_fused(e)))) return r;
 	return launch_check("hv_step_explicit");
 }
 
-// One explicit stage followed by its DSS on more than one rank, boundary first: the fused explicit kernels on the
-// tiles that hold columns other ranks need, pack + grouped send/recv on the exchange stream, the same kernels on the
-// remaining tiles while the wire is busy, then the averaging (local groups, wait for the wire, groups with remote
-// members).  Same kernels on disjoint tiles: bit-identical to the unsplit sequence.  Only for the plain dynamics
-// (no tracers, no uniform diffusion, implicit vertical mode), where the stage is k_h_explicit + k_h_w_update.
+// One explicit stage followed by its DSS on more than one rank, boundary first: the stage's kernels on the tiles that
+// hold columns other ranks need, pack + grouped send/recv on the exchange stream, the same kernels on the remaining tiles
+// while the wire is busy, then the averaging (local groups, wait for the wire, groups with remote members).  Same
+// kernels on disjoint tiles -- every kernel of a stage is local to a 64-column tile (whole elements, whole columns) --
+// so the result is bit-identical to the unsplit sequence.  All configurations: plain dynamics, tracers, uniform
+// diffusion, the fully explicit vertical mode (BASELINE config 4), shallow water (sw_stage_split).  The two whole-patch
+// debug variants of the tracer kernels (TMX_VT_COLUMN, TMX_TRACER_LINCOMB_PASS) switch the split off.
 static bool stage_can_split(const tmx_engine * e) {
-	return e->split_stage && e->nt == 0 && !e->udiff && !e->fully_explicit && !e->sw;
+	return e->split_stage && !getenv("TMX_VT_COLUMN") && !getenv("TMX_TRACER_LINCOMB_PASS");
 }
 static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overlapped);
 static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped);
@@ -1464,29 +1471,48 @@ static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double
 		n = lincomb_terms(e, lc, nlc, iupd, src, cf, &premul);
 		REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 	}
-	KParams p = make_params(e);
-	for (int part = 0; part < 2; part++) {
-		p.quads = part ? e->d_quads_late : e->d_quads_early;
+	int r = TMX_OK;
+	for (int part = 0; part < 2 && !r; part++) {
+		e->stage_quads = part ? e->d_quads_late : e->d_quads_early;
 		e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
 		{
 			ProfScope ps(e, TMX_K_H_EXPLICIT);
-			if (lc) tmxk_h_explicit(e, p, inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 1, n, src, cf, premul);
-			else tmxk_h_explicit(e, p, inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 1);
+			r = hv_stage_kernels(e, iinit, ibase, iupd, dt, n, src, cf, premul);
 		}
-		int r;
-		if (part == 0) {
+		e->stage_quads = nullptr;
+		if (part == 0 && !r) {
 			bool overlapped = false;
-			p.quads = nullptr;
-			if ((r = exchange(e, p, inst(e, iupd), &overlapped))) return r;
+			r = exchange(e, make_params(e), inst(e, iupd), &overlapped);
 			e->split_overlapped = overlapped;
 		}
 	}
-	int r;
+	if (r) return r;
 	if (lc) { if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r; }
 	else if ((r = surface_copy(e, ibase, iupd))) return r;
-	p.quads = nullptr;
 	if ((r = launch_check("hv_stage_split"))) return r;
-	return dss_after_exchange(e, p, iupd, e->split_overlapped);
+	return dss_after_exchange(e, make_params(e), iupd, e->split_overlapped);
+}
+
+// the same for the shallow-water set, whose stage is H.StepExplicit in place on the update instance (V is a stub)
+static int sw_stage_split(tmx_engine * e, int iinit, int iupd, double dt) {
+	int r = TMX_OK;
+	for (int part = 0; part < 2 && !r; part++) {
+		e->stage_quads = part ? e->d_quads_late : e->d_quads_early;
+		e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
+		{
+			ProfScope ps(e, TMX_K_H_EXPLICIT);
+			tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+		}
+		e->stage_quads = nullptr;
+		if (part == 0) {
+			bool overlapped = false;
+			r = exchange(e, make_params(e), inst(e, iupd), &overlapped);
+			e->split_overlapped = overlapped;
+		}
+	}
+	if (r) return r;
+	if ((r = launch_check("sw_stage_split"))) return r;
+	return dss_after_exchange(e, make_params(e), iupd, e->split_overlapped);
 }
 
 // CopyData restricted to the U,V slabs: the implicit step overwrites rho*theta, W, rho of every column
@@ -1759,7 +1785,7 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 		// second pass: coefficients scaled with the patch's (delta_alpha / reference length)^3.2, per column (G2_NUS)
 		const int scale = (c.reference_length != 0.0) ? 1 : 0;
 		if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;     // CopyData :2663, ZeroData :2693
-		if (stage_can_split(e)) {
+		if (stage_can_split(e) && !e->sw) {
 			// each pass boundary tiles first, its exchange overlapped with the interior tiles (see hv_stage_split)
 			for (int pass = 0; pass < 2; pass++) {
 				const int idst = pass ? iupd : iwork;
@@ -1769,8 +1795,13 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 					e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
 					{
 						ProfScope ps(e, TMX_K_HYPERVIS);
-						if (pass == 0) tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
-						else tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+						if (pass == 0) {
+							tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+							if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0);
+						} else {
+							tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+							if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale);
+						}
 					}
 					if (part == 0) { p.quads = nullptr; if ((r = exchange(e, p, inst(e, idst), &overlapped))) return r; }
 				}
@@ -2203,6 +2234,10 @@ static int run_program(tmx_engine * e, const Program & p) {
 			if ((r = tmx_copy_data(e, o.a, o.b))) return r;
 			break;
 		case OP_HEXP:
+			if (e->sw && stage_can_split(e) && n1 && n2 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n2->kind == OP_DSS && n2->a == o.b && o.a != o.b) {
+				if ((r = sw_stage_split(e, o.a, o.b, o.coef))) return r;
+				i += 2; break;
+			}
 			if (!e->sw && n1 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n1->coef == o.coef) {
 				if (stage_can_split(e) && n2 && n2->kind == OP_DSS && n2->a == o.b) {
 					if ((r = hv_stage_split(e, o.a, o.b, o.b, o.coef, nullptr, 0))) return r;
@@ -2387,13 +2422,14 @@ extern "C" int tmx_sync(tmx_engine * e) {
 	prof_collect(e);
 	int flag = 0;
 	HIPCHK(hipMemcpy(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost));
-	if (flag == 2) {
-		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
-		tmx_set_error("halo exchange: a neighbour rank's message did not arrive within the time-out (TMX_P2P_TIMEOUT_S, default 60 s) (peer-to-peer transport)");
+	if (flag) HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	if (flag & TMX_FLAG_COMM) {
+		// (a singular matrix reported in the same interval is a consequence: the columns were solved on stale ghost data)
+		tmx_set_error("halo exchange: a neighbour rank's message did not arrive within the time-out (TMX_P2P_TIMEOUT_S = %d s) (peer-to-peer transport); "
+			"the state of this engine is no longer valid: upload it again after tmx_halo_p2p_reset on every rank", e->p2p_timeout_s);
 		return TMX_ERR_COMM;
 	}
-	if (flag) {
-		HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	if (flag & TMX_FLAG_SINGULAR) {
 		tmx_set_error("column solve failed: exactly singular band matrix (LAPACK dgbsv info > 0)");
 		return TMX_ERR_SINGULAR;
 	}
@@ -2540,6 +2576,22 @@ extern "C" int tmx_halo_p2p_enable(tmx_engine * e, int on) {
 	if (e->xstream) HIPCHK(hipStreamSynchronize(e->xstream));
 	e->p2p = on != 0;
 	if (!e->p2p) e->d_ghost = e->d_ghost_own;
+	return TMX_OK;
+}
+
+// After a failed exchange (tmx_sync returned TMX_ERR_COMM) the ranks' exchange counters disagree.  Once EVERY rank has
+// returned from tmx_sync and the caller has put a barrier behind that (nobody is inside an exchange, nobody writes into a
+// neighbour's block), each rank calls this: its arrival counters and its own exchange count start from zero again.  A second
+// barrier, then the ranks may go on -- with either transport -- from a state they upload again.
+extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
+	int r; if ((r = check_ready(e))) return r;
+	REQUIRE(e->p2p_connected, TMX_ERR_INVALID, "tmx_halo_p2p_reset: tmx_halo_p2p_connect first");
+	HIPCHK(hipStreamSynchronize(e->stream));
+	if (e->xstream) HIPCHK(hipStreamSynchronize(e->xstream));
+	HIPCHK(hipMemset(e->p2p_block, 0, p2p_header_bytes(e->cfg.n_ranks)));
+	HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	HIPCHK(hipDeviceSynchronize());
+	e->p2p_seq = 0;
 	return TMX_OK;
 }
 

@@ -9,6 +9,9 @@
 #define TMX_NP 4            // GLL nodes per element side (horizontal order 4)
 #define TMX_NQ 16           // nodes per element
 #define TMX_TILE 64         // columns per workgroup row = 4 elements = one wavefront
+// bits of the engine's deferred-failure word (d_flag), reported by tmx_sync
+#define TMX_FLAG_SINGULAR 1    // a column solve met an exactly zero pivot
+#define TMX_FLAG_COMM 2        // a neighbour's halo message did not arrive (peer-to-peer transport)
 #define TMX_FTOT 3          // unknowns per level of the implicit column system (rho*theta, W, rho)
 #define TMX_BW 9            // band entries per row of the column Jacobian (kl = ku = 4)
 
@@ -163,6 +166,8 @@ struct tmx_engine {
 	bool use_mfma = false;                   // TMX_MFMA=1: 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
 	int vi_group = -1, vi_group_max = 6400;     // lane-group column kernel: -1 auto (nunique <= vi_group_max; column solve per step, group / pair kernel: 0.171 / 0.281 ms at 2 116 columns, 0.237 / 0.279 at 6 075, 0.349 / 0.279 at 8 100), 0 off, 1 on (TMX_VI_GROUP, TMX_VI_GROUP_MAX)
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
+	int p2p_timeout_s = 600;                 // peer-to-peer halo: how long a neighbour's message may take (TMX_P2P_TIMEOUT_S; 0 = for ever)
+	const int * stage_quads = nullptr;       // tile list of the boundary-first stage in progress (make_params -> KParams.quads)
 	int vi_split_back = 0, vi_back_sub = 1, vi_stagger = 0;   // experiments (TMX_VI_SPLIT_BACK, TMX_VI_BACK_SUB, TMX_VI_STAGGER_NS / 10): back substitution as its own launch
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)

@@ -54,6 +54,10 @@ struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 // that the level index is wave-uniform moves the operator coefficients, the 1 - eta table and all slab
 // offsets to scalar loads / SALU and frees the vector registers they occupied.
 #define WAVE_UNIFORM(v) __builtin_amdgcn_readfirstlane((int)(v))
+// 64-column tile of a workgroup: all tiles of the rank's patches, or the entries of a tile list (KParams.quads: the early /
+// late tiles of the boundary-first stages); NTILES is the matching grid size on the host
+#define TILE_X(p) ((p).quads ? (p).quads[blockIdx.x] : (int)blockIdx.x)
+#define NTILES(e, p) ((p).quads ? (e)->launch_tiles : (p).NS / 64)
 
 // Addressing: every global access here is  base pointer + (wave-uniform slab offset) + (lane's column).  Written
 // as (uniform 64-bit pointer) + (32-bit per-lane BYTE offset) it maps onto the saddr form of global_load /
@@ -168,6 +172,16 @@ __device__ __forceinline__ void tmx_rm_tables_to_lds(double * rmtab, int tid, in
 		rmtab[t] = tmx_rm_log_tab[t];
 		((unsigned long long *)(rmtab + 256))[t] = tmx_rm_exp_tab[t];
 	}
+}
+// Branch-free form for arguments in the main range of log (positive, normal, finite; the caller checks all lanes with
+// exner_arg_in_main_range first): both branches of log are evaluated and selected, exp needs none for these arguments
+// (|x| < 2^-54 gives 1.0 on its main path as well).  Same values as exner_from_rhotheta_lds there.
+__device__ __forceinline__ bool exner_arg_in_main_range(const KParams & p, double rt) {
+	const unsigned top = (unsigned)(tmx_rm_bits(p.Rd / p.p0 * rt) >> 48);
+	return top - 0x0010u < 0x7ff0u - 0x0010u;
+}
+__device__ __forceinline__ double exner_from_rhotheta_bf(const KParams & p, double rt, const double * rmtab) {
+	return p.cp * tmx_ref_exp_main(p.Rd / (p.cp - p.Rd) * tmx_ref_log_bf(p.Rd / p.p0 * rt, rmtab), (const unsigned long long *)(rmtab + 256));
 }
 __device__ __forceinline__ double exner_from_rhotheta_lds(const KParams & p, double rt, const double * rmtab) {
 	return p.cp * tmx_ref_exp_t(p.Rd / (p.cp - p.Rd) * tmx_ref_log_t(p.Rd / p.p0 * rt, rmtab), (const unsigned long long *)(rmtab + 256));
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int col = TILE_X(p) * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k >= L || col >= p.ncol) return;
 	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __
 }
 
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 	if (with_udiff_uv)
 		hipLaunchKernelGGL(k_v_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
 			e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
@@ -748,7 +762,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	if (ty * 64 + lane < 16) { sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	const int col = TILE_X(p) * 64 + lane;
 	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
 	const int k = blockIdx.y * 4 + ty;
 	const bool act = (k < L) && (col < p.ncol);
@@ -827,7 +841,7 @@ void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 #define LAUNCH_HT(NT_) do { \
 		if (e->udiff) hipLaunchKernelGGL((k_h_tracers<true, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar); \
 		else hipLaunchKernelGGL((k_h_tracers<false, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0); } while (0)
@@ -856,7 +870,7 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 	if (ty * 64 + lane < 16) { sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	const int col = TILE_X(p) * 64 + lane;
 	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
 	const double nu = nu_in * (scale ? p.g2d[G2_NUS * (size_t)p.NS + col] : 1.0);
 	const int k = blockIdx.y * 4 + ty;
@@ -916,7 +930,7 @@ __global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, con
 }
 
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 	hipLaunchKernelGGL(k_hypervis_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xsrc, xbase, xout, dt, nu, filter, scale);
 }
 
@@ -1158,7 +1172,7 @@ __global__ __launch_bounds__(64) void k_vi_tracers(KParams p, int nt, const doub
 			for (int t = 0; t < 3; t++) if (dep[t] >= 0) xup[so + dep[t]] = val;
 		}
 	}
-	if (singular) atomicExch(flag, 1);
+	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 #undef ABW
 }
 
@@ -1374,7 +1388,7 @@ template <int NR, int LWB> __global__ __launch_bounds__(NR << LWB) void k_vi_tra
 				for (int q = 0; q < 3; q++) if (dep[q] >= 0) xup[so + dep[q]] = val;
 			}
 	}
-	if (singular && valid) atomicExch(flag, 1);
+	if (singular && valid) atomicOr(flag, TMX_FLAG_SINGULAR);
 #undef AR
 }
 
@@ -1442,7 +1456,7 @@ __global__ __launch_bounds__(256) void k_v_tracers_explicit(KParams p, int nt, c
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int col = TILE_X(p) * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k >= L || col >= p.ncol) return;
 	const MetCol mc = met_col(p, col);
@@ -1572,7 +1586,7 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int tx = threadIdx.x, y = WAVE_UNIFORM(threadIdx.y);
-	const int col = blockIdx.x * 64 + tx;
+	const int col = TILE_X(p) * 64 + tx;
 	const int k0 = blockIdx.y * KT, k = k0 + y;
 	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
@@ -1685,11 +1699,11 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 	if (!getenv("TMX_VT_COLUMN")) {      // level-parallel form (default); TMX_VT_COLUMN=1: the one-lane-per-column kernel, for A/B and tests
 		const bool v1 = getenv("TMX_VT_EXPLICIT_V1") != nullptr;       // the form without LDS staging, for A/B and tests
 		if (v1) {
-			dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+			dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 			hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
 				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
 		} else {
-			dim3 blk(64, 8), grd(p.NS / 64, (p.L + 7) / 8);
+			dim3 blk(64, 8), grd(NTILES(e, p), (p.L + 7) / 8);
 			hipLaunchKernelGGL(k_v_tracers_explicit_tile, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
 				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
 		}
@@ -2074,7 +2088,8 @@ __global__ __launch_bounds__(256) void k_pack_p2p(int nslab, size_t NS, int nsen
 
 // After the messages: raise this rank's arrival counter in every neighbour's block to seq (release, system scope: the
 // preceding kernel's writes are complete at its end), then wait until every neighbour has raised its counter here.  A
-// neighbour that never arrives (a rank died) sets the engine's failure flag after 60 s (TMX_P2P_TIMEOUT_S) instead of hanging the GPU.
+// neighbour that never arrives (a rank died) sets the communication bit of the engine's failure flag after TMX_P2P_TIMEOUT_S
+// (default 600 s) instead of hanging the GPU.
 __global__ __launch_bounds__(64) void k_p2p_signal_wait(int npeers, const int * __restrict__ peers, unsigned long long * const * __restrict__ flag_dst,
 	const unsigned long long * own, unsigned long long seq, int * __restrict__ fail, unsigned long long timeout_ticks)
 {
@@ -2082,11 +2097,14 @@ __global__ __launch_bounds__(64) void k_p2p_signal_wait(int npeers, const int * 
 		__threadfence_system();
 		__hip_atomic_store(flag_dst[peers[q]], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
-	for (int q = threadIdx.x; q < npeers; q += 64) {
+	// An exchange of this engine has already timed out: its state is lost anyway (tmx_sync will say so), so the exchanges
+	// queued behind it do not wait out the time-out again, one after the other.
+	const bool failed = (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TMX_FLAG_COMM) != 0;
+	for (int q = threadIdx.x; q < npeers && !failed; q += 64) {
 		const unsigned long long t0 = wall_clock64();
 		while (__hip_atomic_load(own + peers[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
 			__builtin_amdgcn_s_sleep(8);
-			if (wall_clock64() - t0 > timeout_ticks) { atomicExch(fail, 2); break; }      // 100 MHz counter
+			if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) { atomicOr(fail, TMX_FLAG_COMM); break; }      // 100 MHz counter; 0 = wait for ever
 		}
 	}
 	__threadfence_system();
@@ -2102,7 +2120,8 @@ void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf)
 
 void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq) {
 	// how long a neighbour may lag (it may be busy on its host: output, a slower node) before the exchange gives up
-	static const unsigned long long timeout_ticks = 100000000ull * (unsigned long long)(getenv("TMX_P2P_TIMEOUT_S") ? atoi(getenv("TMX_P2P_TIMEOUT_S")) : 60);
+	// (TMX_P2P_TIMEOUT_S, default 600 s, 0 = never: under MPI a rank that writes output for minutes is slow, not dead)
+	const unsigned long long timeout_ticks = 100000000ull * (unsigned long long)e->p2p_timeout_s;
 	hipLaunchKernelGGL(k_p2p_signal_wait, dim3(1), dim3(64), 0, s, e->p2p_npeers, (const int *)e->d_p2p_peers,
 		(unsigned long long * const *)(e->d_p2p_flag + (size_t)buf * e->cfg.n_ranks),
 		(const unsigned long long *)e->p2p_block + (size_t)buf * e->cfg.n_ranks, seq, e->d_flag, timeout_ticks);
@@ -2240,7 +2259,7 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	const int col = TILE_X(p) * 64 + lane;
 	const int kk = blockIdx.y * 4 + ty;
 	const bool actw = (kk <= L) && (col < p.ncol);
 	const bool actn = (kk < L) && (col < p.ncol);
@@ -2327,7 +2346,7 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 
 void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout,
 	double dt, double ks, double kv) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 1 + 3) / 4);
 	hipLaunchKernelGGL(k_uniform_diffusion, grd, blk, 0, e->stream, p, xsrc, xref, xout, dt, ks, kv);
 }
 
@@ -2338,7 +2357,7 @@ __global__ __launch_bounds__(256) void k_v_uniform_diffusion_uv(KParams p, const
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int col = TILE_X(p) * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k >= L || col >= p.ncol) return;
 #pragma unroll
@@ -2358,7 +2377,7 @@ __global__ __launch_bounds__(256) void k_v_uniform_diffusion_uv(KParams p, const
 }
 
 void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double * xin, const double * xref, double * xup, double dt, double cf) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 	hipLaunchKernelGGL(k_v_uniform_diffusion_uv, grd, blk, 0, e->stream, p, xin, xref, xup, dt, cf);
 }
 
@@ -2791,7 +2810,7 @@ __global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, 
 			b[4] = 0.0;
 		}
 	}
-	if (singular) atomicExch(flag, 1);
+	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 
 	// back substitution in dtbsv order, scatter x0 - delta
 	const int col = ucol[u];
@@ -2891,7 +2910,12 @@ __device__ __forceinline__ double signed_by(double x, double v) {
 	return r;
 }
 
-template <bool CARRY, bool UD = false>
+// INTERIOR: the caller guarantees 1 <= k <= L - 2 and arguments of the Exner function in the main range of exp / log (positive,
+// normal, finite): every level-boundary condition below is then a compile-time `true` and exp(log()) is evaluated without
+// branches (exner_from_rhotheta_bf), so that the whole block row is ONE basic block whose dependency chains the compiler can
+// interleave -- with the dozen short blocks of the general form a lone assembly wavefront ran at a quarter of its issue rate.
+// Same statements on the same operands either way.
+template <bool CARRY, bool UD = false, bool INTERIOR = false>
 __device__ __forceinline__ void compute_block(const KParams & p, const double * opsl, const ColConst & cc, int k,
 	const NodeLev & A, const NodeLev & B, const NodeLev & C, const EdgeLev & ea, const EdgeLev & eb, const EdgeLev & ec,
 	double * rowP, double * rowW, double * rowR, double & fP, double & fW, double & fR, BlkCarry & cy,
@@ -2909,11 +2933,12 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	fP = 0.0; fW = 0.0; fR = 0.0;
 #define DOFF(cr, cc_, dk) (3 * (dk) + ((cc_) - (cr)) + 4)
 	// interior interpolation stencils (offsets -1, 0), verified by tmx_set_operators
-	const double ib_m = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, -1), ib_0 = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k < L ? k : L, 0);
+	const int kib = (INTERIOR || k < L) ? k : L;
+	const double ib_m = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, kib, -1), ib_0 = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, kib, 0);
 
 	// ---- interface k: interpolated U,V,rho*theta,rho and xi_dot (PrepareColumn :2056-2069) ----
 	double ue_b = 0.0, ve_b = 0.0, xd0 = 0.0, pe0 = 0.0, re0 = 0.0;
-	if (k >= 1 && k <= L - 1) {
+	if (INTERIOR || (k >= 1 && k <= L - 1)) {
 		if (CARRY) { ue_b = cy.ue; ve_b = cy.ve; xd0 = cy.xd; pe0 = cy.pe; re0 = cy.re; }
 		else {
 			ue_b += ib_m * A.un; ue_b += ib_0 * B.un; ve_b += ib_m * A.vn; ve_b += ib_0 * B.vn;
@@ -2924,7 +2949,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	// ---- interface k+1 ----
 	double ue_c = 0.0, ve_c = 0.0, xd1 = 0.0, pe1 = 0.0, re1 = 0.0;
 	double ic_m = 0.0, ic_0 = 0.0;
-	if (k + 1 <= L - 1) {
+	if (INTERIOR || k + 1 <= L - 1) {
 		ic_m = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1); ic_0 = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0);
 		ue_c += ic_m * B.un; ue_c += ic_0 * C.un; ve_c += ic_m * B.vn; ve_c += ic_0 * C.vn;
 		xd1 = ec.ce0 * ue_c + ec.ce1 * ve_c + ec.ce2 * ec.we;
@@ -2932,11 +2957,11 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	}
 
 	CBSTAMP(0);
-	if (k < L) {
+	if (INTERIOR || k < L) {
 		const double invJ = 1.0 / cc.jn;
 		const double pm = A.pn, p0 = B.pn, pp = C.pn, rm = A.rn, r0 = B.rn, rp = C.rn;
-		const double mf0 = (k >= 1) ? cc.je * re0 * xd0 : 0.0, mf1 = (k + 1 <= L - 1) ? cc.je * re1 * xd1 : 0.0;
-		const double pf0 = (k >= 1) ? cc.je * pe0 * xd0 : 0.0, pf1 = (k + 1 <= L - 1) ? cc.je * pe1 * xd1 : 0.0;
+		const double mf0 = (INTERIOR || k >= 1) ? cc.je * re0 * xd0 : 0.0, mf1 = (INTERIOR || k + 1 <= L - 1) ? cc.je * re1 * xd1 : 0.0;
+		const double pf0 = (INTERIOR || k >= 1) ? cc.je * pe0 * xd0 : 0.0, pf1 = (INTERIOR || k + 1 <= L - 1) ? cc.je * pe1 * xd1 : 0.0;
 		const double de0 = OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 0), de1 = OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 1);
 		double dmf = 0.0; dmf += de0 * mf0; dmf += de1 * mf1;
 		double dpf = 0.0; dpf += de0 * pf0; dpf += de1 * pf1;
@@ -2948,16 +2973,16 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 		const double pr0 = OPCL(TMX_OP_PENALTY_RIGHT, k, -1), pr1 = OPCL(TMX_OP_PENALTY_RIGHT, k, 0);
 		{
 			double a = 0.0;
-			if (k < L - 1) { double b = 0.0; b += pl0 * p0; b += pl1 * pp; a += b * whi; }
-			if (k > 0) { double b = 0.0; b += pr0 * pm; b += pr1 * p0; a += b * wlo; }
+			if (INTERIOR || k < L - 1) { double b = 0.0; b += pl0 * p0; b += pl1 * pp; a += b * whi; }
+			if (INTERIOR || k > 0) { double b = 0.0; b += pr0 * pm; b += pr1 * p0; a += b * wlo; }
 			fP -= a;
 			a = 0.0;
-			if (k < L - 1) { double b = 0.0; b += pl0 * r0; b += pl1 * rp; a += b * whi; }
-			if (k > 0) { double b = 0.0; b += pr0 * rm; b += pr1 * r0; a += b * wlo; }
+			if (INTERIOR || k < L - 1) { double b = 0.0; b += pl0 * r0; b += pl1 * rp; a += b * whi; }
+			if (INTERIOR || k > 0) { double b = 0.0; b += pr0 * rm; b += pr1 * r0; a += b * wlo; }
 			fR -= a;
 		}
 		// conservative flux terms: m = k (interface b), m = k+1 (interface c)
-		if (k >= 1) {       // m = k, neither 0 nor L
+		if (INTERIOR || k >= 1) {       // m = k, neither 0 nor L
 			const double c = de0 * cc.je * invJ * eb.ce2;
 			rowP[DOFF(0, 1, 0)] += c * pe0;
 			rowR[DOFF(2, 1, 0)] += c * re0;
@@ -2965,7 +2990,7 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			rowR[DOFF(2, 2, -1)] += cm; rowP[DOFF(0, 0, -1)] += cm;
 			rowR[DOFF(2, 2, 0)] += c0;  rowP[DOFF(0, 0, 0)] += c0;
 		}
-		if (k + 1 <= L - 1) {   // m = k+1
+		if (INTERIOR || k + 1 <= L - 1) {   // m = k+1
 			const double c = de1 * cc.je * invJ * ec.ce2;
 			rowP[DOFF(0, 1, 1)] += c * pe1;
 			rowR[DOFF(2, 1, 1)] += c * re1;
@@ -2973,14 +2998,14 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 			rowR[DOFF(2, 2, 0)] += cm; rowP[DOFF(0, 0, 0)] += cm;
 			rowR[DOFF(2, 2, 1)] += c0; rowP[DOFF(0, 0, 1)] += c0;
 		}
-		if (k >= 1) {
+		if (INTERIOR || k >= 1) {
 			const double sw = signed_by(xd0, eb.ce2);
 			rowP[DOFF(0, 1, 0)] -= sw * pr0 * pm; rowP[DOFF(0, 1, 0)] -= sw * pr1 * p0;
 			rowP[DOFF(0, 0, -1)] -= wlo * pr0;    rowP[DOFF(0, 0, 0)] -= wlo * pr1;
 			rowR[DOFF(2, 1, 0)] -= sw * pr0 * rm; rowR[DOFF(2, 1, 0)] -= sw * pr1 * r0;
 			rowR[DOFF(2, 2, -1)] -= wlo * pr0;    rowR[DOFF(2, 2, 0)] -= wlo * pr1;
 		}
-		if (k + 1 <= L - 1) {
+		if (INTERIOR || k + 1 <= L - 1) {
 			const double sw = signed_by(xd1, ec.ce2);
 			rowP[DOFF(0, 1, 1)] -= sw * pl0 * p0; rowP[DOFF(0, 1, 1)] -= sw * pl1 * pp;
 			rowP[DOFF(0, 0, 0)] -= whi * pl0;     rowP[DOFF(0, 0, 1)] -= whi * pl1;
@@ -2992,15 +3017,15 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 	CBSTAMP(1);
 	// ---- node k quantities the W rows of this block and of the next one use ----
 	double ex0 = 0.0, wn0 = 0.0, xdn0 = 0.0, ke0 = 0.0;
-	if (k <= L - 1 && (CARRY || k >= 1)) {
-		ex0 = rmtab ? exner_from_rhotheta_lds(p, B.pn, rmtab) : exner_from_rhotheta(p, B.pn);
+	if (INTERIOR || (k <= L - 1 && (CARRY || k >= 1))) {
+		ex0 = INTERIOR ? exner_from_rhotheta_bf(p, B.pn, rmtab) : (rmtab ? exner_from_rhotheta_lds(p, B.pn, rmtab) : exner_from_rhotheta(p, B.pn));
 		wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * eb.we; wn0 += OPCL(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * ec.we;
 		xdn0 = B.ca2 * B.un + B.cb2 * B.vn + B.cx2 * wn0;
 		const double ca = cc.c2a0 * B.un + cc.c2a1 * B.vn + B.ca2 * wn0, cb = cc.c2a1 * B.un + cc.c2b1 * B.vn + B.cb2 * wn0;
 		ke0 = 0.5 * (ca * B.un + cb * B.vn + xdn0 * wn0);
 	}
 	CBSTAMP(2);
-	if (k >= 1 && k <= L - 1) {
+	if (INTERIOR || (k >= 1 && k <= L - 1)) {
 		const double pm = A.pn, p0 = B.pn;
 		double exm, wnm, xdnm, kem;
 		if (CARRY) { exm = cy.ex; wnm = cy.wn; xdnm = cy.xdn; kem = cy.ke; }
@@ -3088,27 +3113,76 @@ __device__ __forceinline__ void compute_block(const KParams & p, const double * 
 // reads 5 KB rows back to back instead of ten 512-byte pieces 389 KB apart.  `AB` below is the lane's pointer into
 // its wavefront's stream (vi_stream_base), NUS / RHS / u are unused by these two helpers.
 #define TMX_UW (TMX_BW + 1)
+// Layout of a U row in the stream (TMX_USTREAM16, default): five 16-byte slots per lane, [row][slot][64 lanes][2] -- one
+// global_store_dwordx4 / global_load_dwordx4 moves two entries.  Both phases of the solve are bound by the ISSUE of vector-memory
+// instructions, not by bytes (measured: the producer's five prefetch loads per block row waited 1 000 - 2 800 cycles to
+// issue behind the elimination's ten 8-byte stores per pivot; the back substitution slowed by 30 % when the same bytes were
+// moved by twice as many instructions), so the stream is written and read in half as many, twice as wide instructions.
+// Which two entries share a slot depends on the KIND of matrix row (j mod 3: rho*theta, W, rho), chosen so that the
+// fill-in pattern of the usual pivot order packs without holes: entries 0..3 and the right-hand side (index 9) always
+// exist, of the fill-in entries 4..8 a rho*theta row normally has {4,5,7}, a W row {4,6}, a rho row {5}.  Slots 0..2 are
+// always stored; slot 3 / 4 only if one of its two entries is non-zero in some lane (mask bits 3 / 4).  Any other pivot
+// order is still exact, it merely stores a few zeros.
+#ifndef TMX_USTREAM16
+#define TMX_USTREAM16 1
+#endif
+__device__ constexpr int TMX_UPAIR[3][5][2] = {
+	{ { 0, 9 }, { 1, 2 }, { 3, 4 }, { 5, 7 }, { 6, 8 } },      // rho*theta rows
+	{ { 0, 9 }, { 1, 2 }, { 3, 4 }, { 6, 5 }, { 7, 8 } },      // W rows
+	{ { 0, 9 }, { 1, 2 }, { 3, 5 }, { 4, 6 }, { 7, 8 } } };    // rho rows
+#define TMX_USLOT (TMX_USTREAM16 ? 2 : 1)      // doubles per lane and slot
+// Order of the rows in the scratch (TMX_USTREAM_ROWMAJOR, default): [matrix row][column group][slot][lane] -- the column groups
+// advance through their rows at about the same pace, so at any time the chip writes (elimination) or reads (back substitution)
+// one contiguous run of a few megabytes instead of one 5 KB piece in each of ~800 chunks 476 KB apart.  0: [group][row]....
+// NUS below is the number of stream columns allocated (64 per column group).
+#ifndef TMX_USTREAM_ROWMAJOR
+#define TMX_USTREAM_ROWMAJOR 1
+#endif
+#define TMX_RS(NUS) (TMX_USTREAM_ROWMAJOR ? (size_t)(NUS) * TMX_UW : (size_t)TMX_UW * 64)      // doubles from one row of a group to its next
 __device__ __forceinline__ double * vi_stream_base(double * AB, int n, int u) {
-	return AB + ((size_t)(u >> 6) * n * TMX_UW) * 64 + (u & 63);
+	return AB + ((size_t)(u >> 6) * (TMX_USTREAM_ROWMAJOR ? 1 : n) * TMX_UW) * 64 + (u & 63) * TMX_USLOT;
 }
 // the same with the column group and the lane given separately (groups of fewer than 64 columns, k_vi_pair)
 __device__ __forceinline__ double * vi_stream_base_g(double * AB, int n, int grp, int lane) {
-	return AB + ((size_t)grp * n * TMX_UW) * 64 + lane;
+	return AB + ((size_t)grp * (TMX_USTREAM_ROWMAJOR ? 1 : n) * TMX_UW) * 64 + lane * TMX_USLOT;
 }
 
 // PRED: the sparse stores of the fill-in entries are predicated instead of branched around: the condition "some lane holds a
-// non-zero" is wave-uniform, so the compiler would put an s_cbranch_vccz in front of every one of the five stores (a VALU
-// compare, the wait for VCC and a branch, five times per pivot step, on the elimination's critical chain).  Folding an opaque
-// per-lane `1` into the condition makes it divergent for the compiler: the store then runs under an EXEC mask that is all
-// ones or all zeros (an instruction with an empty mask issues and does nothing), no branch.
-template <bool SPARSE, bool PRED = false>
+// non-zero" is wave-uniform, so the compiler would put an s_cbranch_vccz in front of every one of the stores (a VALU
+// compare, the wait for VCC and a branch on the elimination's critical chain).  Folding an opaque per-lane `1` into the
+// condition makes it divergent for the compiler: the store then runs under an EXEC mask that is all ones or all zeros (an
+// instruction with an empty mask issues and does nothing), no branch.
+// TYPE: kind of the matrix row jcol (jcol mod 3), a compile-time constant at every call site.
+template <bool SPARSE, bool PRED, int TYPE>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
+#ifdef TMX_ABL_NO_USTORE     // ablation builds: elimination without the U-row stream (one value kept alive)
+	if (piv[0] == 12345.678 && pb == 1.0) AB[0] = piv[1];
+	return;
+#endif
+#if TMX_USTREAM16
+	auto val = [&](int e) -> double { return e == 9 ? pb : piv[e]; };
+	double * row = AB + (size_t)jcol * TMX_RS(NUS);
+#pragma unroll
+	for (int sl = 0; sl < 3; sl++)
+		*(double2 *)(row + sl * 128) = make_double2(val(TMX_UPAIR[TYPE][sl][0]), val(TMX_UPAIR[TYPE][sl][1]));
+	int mask = 0;
+	int one = 1;
+	if (PRED) asm volatile("" : "+v"(one));
+#pragma unroll
+	for (int sl = 3; sl < 5; sl++) {
+		const double a = val(TMX_UPAIR[TYPE][sl][0]), b = val(TMX_UPAIR[TYPE][sl][1]);
+		const bool any = !SPARSE || __builtin_amdgcn_ballot_w64(a != 0.0 || b != 0.0) != 0;
+		mask |= any ? (1 << sl) : 0;
+		if (PRED ? (any && one) : any) *(double2 *)(row + sl * 128) = make_double2(a, b);
+	}
+	if (SPARSE ? (threadIdx.x == 0) : true) umask[jcol] = mask;      // dense stores (also the lane-divergent tails, where lane 0 may be masked out): every active lane writes the same word
+#else
 	if (SPARSE && PRED) {
 #pragma unroll
-		for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
-		AB[((size_t)jcol * TMX_UW + TMX_BW) * 64] = pb;
+		for (int c = 0; c < 4; c++) AB[(size_t)jcol * TMX_RS(NUS) + c * 64] = piv[c];
+		AB[(size_t)jcol * TMX_RS(NUS) + TMX_BW * 64] = pb;
 		int one = 1;
 		asm volatile("" : "+v"(one));
 		int mask = 0;
@@ -3116,27 +3190,24 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 		for (int c = 4; c < TMX_BW; c++) {
 			const bool any = __builtin_amdgcn_ballot_w64(piv[c] != 0.0) != 0;
 			mask |= any ? (1 << c) : 0;
-			if (any && one) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
+			if (any && one) AB[(size_t)jcol * TMX_RS(NUS) + c * 64] = piv[c];
 		}
 		if (threadIdx.x == 0) umask[jcol] = mask;
 		return;
 	}
-#ifdef TMX_ABL_NO_USTORE     // ablation builds: elimination without the U-row stream (one value kept alive)
-	if (piv[0] == 12345.678 && pb == 1.0) AB[0] = piv[1];
-	return;
-#endif
 #pragma unroll
-	for (int c = 0; c < 4; c++) AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
+	for (int c = 0; c < 4; c++) AB[(size_t)jcol * TMX_RS(NUS) + c * 64] = piv[c];
 	int mask = 0;
 #pragma unroll
 	for (int c = 4; c < TMX_BW; c++) {
 		if (!SPARSE || __builtin_amdgcn_ballot_w64(piv[c] != 0.0) != 0) {
-			AB[((size_t)jcol * TMX_UW + c) * 64] = piv[c];
+			AB[(size_t)jcol * TMX_RS(NUS) + c * 64] = piv[c];
 			mask |= 1 << c;
 		}
 	}
 	if (SPARSE ? (threadIdx.x == 0) : true) umask[jcol] = mask;      // dense stores (also the lane-divergent tails, where lane 0 may be masked out): every active lane writes the same word
-	AB[((size_t)jcol * TMX_UW + TMX_BW) * 64] = pb;
+	AB[(size_t)jcol * TMX_RS(NUS) + TMX_BW * 64] = pb;
+#endif
 }
 
 // Pivot step when every lane of the wavefront picked window row PV (the normal case: neighbouring columns have
@@ -3145,7 +3216,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 // so neither the 160 v_cndmask of the per-lane interchange nor the 36 moves of the slide are executed.  Only the
 // pivot row and old row 0 are copied aside, because their slots are overwritten before their last use.
 // Same multiplications and subtractions on the same operands as the generic path: bit-identical.
-template <bool SPARSE, int PV, int IS = 1>
+template <bool SPARSE, int PV, int IS, int TYPE>
 __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -3160,7 +3231,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	const double pb = b[PV], tb0 = b[0];
 	if (piv[0] == 0.0) singular = true;
 #if TMX_TAIL == 1
-	lu_store_urow<SPARSE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, false, TYPE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / piv[0];
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -3186,7 +3257,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	double l[5];
 #pragma unroll
 	for (int r = 1; r < 5; r++) l[r] = ((r == PV) ? t0[0] : R[r][0]) * rcp;
-	lu_store_urow<SPARSE, TMX_STORE_PRED>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, TMX_STORE_PRED, TYPE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
 		// after the interchange position r holds old row r, except position PV, which holds old row 0
@@ -3208,7 +3279,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
 // the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
 // the per-lane select path below.
-template <bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1>
+template <int TYPE, bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask, int * n_uniform = nullptr)
@@ -3239,13 +3310,13 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 			if (n_uniform) (*n_uniform)++;      // wave-uniform counter (scalar add): pivot steps that took the renaming path
 			// the usual pivot row of this kind of matrix row first (rho*theta / W / rho rows pivot 4 / 3 / 2 rows down almost
 			// everywhere): one compare and branch instead of the switch's two or three
-			if (EXPECT >= 0 && pv0 == EXPECT) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
+			if (EXPECT >= 0 && pv0 == EXPECT) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
 			switch (pv0) {
-				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				default: lu_pivot_tail_uniform<SPARSE, 4, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				default: lu_pivot_tail_uniform<SPARSE, 4, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
 		}
 #ifndef TMX_VI_SELECT_PATH
@@ -3255,11 +3326,11 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		// in the lanes of one tail need not be zero in the others, so the all-lanes ballot of the sparse stores does not
 		// apply).  Unlike the select path -- whose 160 selects per step cost the kernel 30 spilled registers, reloaded in
 		// the uniform tails behind an s_waitcnt vmcnt(0) that also drained the U-row stores -- this adds no live values.
-		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
 		return;
 #endif
 	}
@@ -3277,7 +3348,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		b[r] = sw ? b0 : br;
 	}
 	if (R[0][0] == 0.0) singular = true;
-	lu_store_urow<SPARSE>(R[0], b[0], AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, false, TYPE>(R[0], b[0], AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / R[0][0];
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -3317,7 +3388,24 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 {
 	const int rr = row < 0 ? 0 : row;
 	const int mk = __builtin_amdgcn_readfirstlane(umask[rr]);
-	const double * rb = AB + (size_t)rr * TMX_UW * 64;
+#if TMX_USTREAM16
+	const double * rb = AB + (size_t)rr * TMX_RS(NUS);
+	double2 v[5];
+#pragma unroll
+	for (int sl = 0; sl < 3; sl++) v[sl] = *(const double2 *)(rb + sl * 128);
+#pragma unroll
+	for (int sl = 3; sl < 5; sl++) {
+		const double * bp = (mk & (1 << sl)) ? rb + sl * 128 : zp;
+		v[sl] = *(const double2 *)bp;
+	}
+#pragma unroll
+	for (int sl = 0; sl < 5; sl++) {
+		const int ea = TMX_UPAIR[COMP][sl][0], eb = TMX_UPAIR[COMP][sl][1];
+		if (ea == 9) d.y = v[sl].x; else d.u[ea] = v[sl].x;
+		if (eb == 9) d.y = v[sl].y; else d.u[eb] = v[sl].y;
+	}
+#else
+	const double * rb = AB + (size_t)rr * TMX_RS(NUS);
 #pragma unroll
 	for (int c = 0; c < 4; c++) d.u[c] = rb[c * 64];
 #pragma unroll
@@ -3331,6 +3419,7 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 #endif
 	}
 	d.y = rb[TMX_BW * 64];
+#endif
 	const int k = rr / TMX_FTOT;
 	const int kc = (COMP == 1 || k < L) ? k : L - 1;      // level-L slots of rho*theta / rho have no slab: value unused
 	const int slab = (COMP == 0) ? TMX_SLAB_T(L, kc) : ((COMP == 1) ? TMX_SLAB_W(L, kc) : TMX_SLAB_R(L, kc));
@@ -3358,8 +3447,8 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
-	// zero page: 64 doubles behind the streams; AB is the lane's stream pointer (vi_stream_base)
-	const double * zp = RHS + ((zlane >= 0) ? zlane : (u & 63));
+	// zero page behind the streams (one slot per lane); AB is the lane's stream pointer (vi_stream_base)
+	const double * zp = RHS + ((zlane >= 0) ? zlane : (u & 63)) * TMX_USLOT;
 	// two trips (six rows) of register sets: a set is refilled for the trip after next right after it is consumed,
 	// so five rows = 55 loads are in flight (vmcnt holds 63) -- the back substitution of a full grid is HBM-bound
 	URow A, B, C, D, E, F;      // A,D: rows 3k+2 (rho); B,E: 3k+1 (W); C,F: 3k (rho*theta)
@@ -3458,7 +3547,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	}
 	b[0] = fP; b[1] = fW; b[2] = fR; b[3] = gP; b[4] = gW;
 	bool singular = false;
-	lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 0, NUS, u, sR, gR, umask);      // pivot 0 takes in row 5
+	lu_pivot_step<0, SPARSE, UNI>(R, b, singular, AB, RHS, 0, NUS, u, sR, gR, umask);      // pivot 0 takes in row 5
 	// Drain the prologue's loads here, once: otherwise the per-column constants loaded before the loop count as
 	// "possibly still in flight" at the loop header and the compiler waits vmcnt(0) -- i.e. for all U-row
 	// stores of the previous block row -- at their first use in EVERY iteration.
@@ -3477,9 +3566,9 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 		nN = load_node<MM>(p, mcol, xin, m + 2, col, etal); eN = load_edge<MM>(p, mcol, xin, m + 2, col, etal);   // used two blocks from now
 		compute_block<CARRY>(p, opsl, cc, m, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy);
 		TMARK(t_asm);
-		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
-		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
-		lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
+		lu_pivot_step<1, SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, rP, fP, umask);
+		lu_pivot_step<2, SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, rW, fW, umask);
+		lu_pivot_step<0, SPARSE, UNI>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, rR, fR, umask);
 		TMARK(t_lu);
 	}
 #ifdef TMX_VI_TIMING
@@ -3489,9 +3578,14 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, UNI>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask);
+		// the last five rows: n is a multiple of three, so their kinds are W, rho, rho*theta, W, rho
+		lu_pivot_step<1, SPARSE, UNI>(R, b, singular, AB, RHS, n - 5, NUS, u, z, 0.0, umask);
+		lu_pivot_step<2, SPARSE, UNI>(R, b, singular, AB, RHS, n - 4, NUS, u, z, 0.0, umask);
+		lu_pivot_step<0, SPARSE, UNI>(R, b, singular, AB, RHS, n - 3, NUS, u, z, 0.0, umask);
+		lu_pivot_step<1, SPARSE, UNI>(R, b, singular, AB, RHS, n - 2, NUS, u, z, 0.0, umask);
+		lu_pivot_step<2, SPARSE, UNI>(R, b, singular, AB, RHS, n - 1, NUS, u, z, 0.0, umask);
 	}
-	if (singular) atomicExch(flag, 1);
+	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 
 	vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask);
 #ifdef TMX_VI_TIMING
@@ -3587,7 +3681,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		struct LevRaw { double un, vn, pn, rn, we; };
 		auto load_raw = [&](int l) {
 			LevRaw r;
+#ifdef TMX_ABL_P_LEVEL0      // ablation builds: every level's loads hit the same five cache-resident rows
+			const int lc = (l & 1), le = (l & 1);
+#else
 			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+#endif
 			r.un = xin[TMX_SLAB_U(L, lc) * NS + col]; r.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
 			r.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; r.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
 			r.we = xin[TMX_SLAB_W(L, le) * NS + col];
@@ -3626,6 +3724,14 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab, tp_seg);
 				tp_mark = __builtin_readcyclecounter();
 #else
+				// Interior block rows whose Exner arguments are ordinary numbers in every lane can take the branch-free instantiation
+				// (one basic block of 350 vector instructions per block row).  Measured: SLOWER -- the assembly alone 118 instead of
+				// 98 us per launch, the kernel +3 % -- so it stays an experiment (-DTMX_INTERIOR_ROWS).
+#ifdef TMX_INTERIOR_ROWS
+				if (t >= 1 && t <= L - 2 && __builtin_amdgcn_ballot_w64(!exner_arg_in_main_range(p, nB.pn)) == 0)
+					compute_block<true, false, true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
+				else
+#endif
 				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
 #endif
 				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
@@ -3704,16 +3810,16 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 					R[4][c] = qW[c * 64];
 				}
 				b[3] = qf[0]; b[4] = qf[64];
-				lu_pivot_step<SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask, &nuni);      // pivot 0 takes in row 5
+				lu_pivot_step<0, SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask, &nuni);      // pivot 0 takes in row 5
 			} else
 #ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the barrier rhythm
 			if (m < 0)
 #endif
 			{
 				// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
-				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_W>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
-				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_R>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
-				lu_pivot_step<SPARSE, true, 64, TMX_EXPECT_T>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
+				lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
+				lu_pivot_step<2, SPARSE, true, 64, TMX_EXPECT_R>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
+				lu_pivot_step<0, SPARSE, true, 64, TMX_EXPECT_T>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
 			}
 		}
 		PMARK(tp_work);
@@ -3724,12 +3830,17 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 		double z[TMX_BW];
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
-		for (int j = n - 5; j < n; j++) lu_pivot_step<SPARSE, true>(R, b, singular, AB, RHS, j, NUS, u, z, 0.0, umask, &nuni);
+		// the last five rows: n is a multiple of three, so their kinds are W, rho, rho*theta, W, rho
+		lu_pivot_step<1, SPARSE, true>(R, b, singular, AB, RHS, n - 5, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<2, SPARSE, true>(R, b, singular, AB, RHS, n - 4, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<0, SPARSE, true>(R, b, singular, AB, RHS, n - 3, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<1, SPARSE, true>(R, b, singular, AB, RHS, n - 2, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<2, SPARSE, true>(R, b, singular, AB, RHS, n - 1, NUS, u, z, 0.0, umask, &nuni);
 	}
 #ifdef TMX_PAIR_TIMING
 	const long long tp_fwd = __builtin_readcyclecounter();
 #endif
-	if (singular) atomicExch(flag, 1);
+	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 	// statistics for bench.py (stats = {pivot steps on the wave-uniform path, all pivot steps}, per wavefront)
 	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
 #ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
@@ -3917,7 +4028,7 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 		w4 = (carries && rin < n) ? vin : 0.0;
 	}
 	}
-	if (singular) atomicExch(flag, 1);
+	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 #ifdef TMX_VI_TIMING
 	const long long tg2 = __builtin_readcyclecounter();
 #endif
@@ -4051,7 +4162,7 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int col = TILE_X(p) * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (col >= p.ncol || k > L) return;
 	ColConst cc;
@@ -4100,7 +4211,7 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 }
 
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 1 + 3) / 4);
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;
 		hipLaunchKernelGGL(k_vi_terms_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
@@ -4122,7 +4233,7 @@ __global__ __launch_bounds__(64) void k_sw_explicit(KParams p, const double * __
 	const int lane = threadIdx.x;
 	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
 	const size_t NS = (size_t)p.NS;
-	const int col = blockIdx.x * 64 + lane;
+	const int col = TILE_X(p) * 64 + lane;
 	const bool act = col < p.ncol;
 	double ua = 0, ub = 0, h = 0, c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, fcor = 0, zs = 0;
 	if (act) {
@@ -4171,5 +4282,5 @@ __global__ __launch_bounds__(64) void k_sw_explicit(KParams p, const double * __
 }
 
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
-	hipLaunchKernelGGL(k_sw_explicit, dim3(p.NS / 64), dim3(64), 0, e->stream, p, xin, xbase, xup, dt);
+	hipLaunchKernelGGL(k_sw_explicit, dim3(NTILES(e, p)), dim3(64), 0, e->stream, p, xin, xbase, xup, dt);
 }

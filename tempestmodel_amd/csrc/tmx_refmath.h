@@ -212,13 +212,11 @@ TMX_RM_FN double tmx_rm_dbl(unsigned long long u) {
 #define TMX_RM_ANY(c) (c)
 #endif
 
-/* exp with the table given by the caller (the global array above, or a copy in LDS: 256 words) */
-TMX_RM_FN double tmx_ref_exp_t(double x, const unsigned long long * tab) {
+/* main path of exp for |x| < 512 (also right for |x| < 2^-54, where it returns 1.0 like the special case): no branch */
+TMX_RM_FN double tmx_ref_exp_main(double x, const unsigned long long * tab) {
 	const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8000000000000p+52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
 	const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
-	const unsigned abstop = (unsigned)(tmx_rm_bits(x) >> 52) & 0x7ff;
-	/* x = k ln2/N + r;  exp(x) = 2^(k/N) exp(r) ~= scale + scale * (tail + exp(r) - 1): evaluated for every argument
-	 * (harmless garbage outside the main range, replaced below) */
+	/* x = k ln2/N + r;  exp(x) = 2^(k/N) exp(r) ~= scale + scale * (tail + exp(r) - 1) */
 	double kd = TMX_RM_FMA(x, InvLn2N, Shift);
 	const unsigned long long ki = tmx_rm_bits(kd);
 	kd -= Shift;
@@ -233,7 +231,13 @@ TMX_RM_FN double tmx_ref_exp_t(double x, const unsigned long long * tab) {
 	double tmp = TMX_RM_FMA(p23, r2, r + tail);
 	tmp = TMX_RM_FMA(r2 * r2, p45, tmp);
 	const double scale = tmx_rm_dbl(sbits);
-	double res = TMX_RM_FMA(scale, tmp, scale);
+	return TMX_RM_FMA(scale, tmp, scale);
+}
+/* exp with the table given by the caller (the global array above, or a copy in LDS: 256 words) */
+TMX_RM_FN double tmx_ref_exp_t(double x, const unsigned long long * tab) {
+	const unsigned abstop = (unsigned)(tmx_rm_bits(x) >> 52) & 0x7ff;
+	/* evaluated for every argument (harmless garbage outside the main range, replaced below) */
+	double res = tmx_ref_exp_main(x, tab);
 	const int odd = abstop - 0x3c9u >= 0x3fu;
 	if (TMX_RM_ANY(odd)) {
 		if (odd) res = (abstop < 0x3c9u) ? 1.0 + x      /* |x| < 2^-54 */
@@ -243,54 +247,62 @@ TMX_RM_FN double tmx_ref_exp_t(double x, const unsigned long long * tab) {
 }
 TMX_RM_FN double tmx_ref_exp(double x) { return tmx_ref_exp_t(x, tmx_rm_exp_tab); }
 
-/* log with the table given by the caller ({1/c, log c} pairs: 256 doubles) */
-TMX_RM_FN double tmx_ref_log_t(double x, const double * tab) {
+/* the two evaluation paths of log for positive normal finite x (selection by the caller) */
+TMX_RM_FN double tmx_ref_log_main(double x, const double * tab) {
 	const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
 	const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3, A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
+	const unsigned long long ix = tmx_rm_bits(x);
+	/* x = 2^k z, z in [0x1.6p-1, 0x1.6p0); log(x) = log1p(z/c - 1) + log(c) + k ln2 */
+	const unsigned long long tmp = ix - 0x3fe6000000000000ull;
+	const unsigned i = (unsigned)(tmp >> 45) & 127u;
+	const int k = (int)((long long)tmp >> 52);
+	const double z = tmx_rm_dbl(ix - (tmp & 0xfff0000000000000ull));
+	const double invc = tab[2 * i], logc = tab[2 * i + 1];
+	const double r = TMX_RM_FMA(z, invc, -1.0);
+	const double kd = (double)k;
+	const double w = TMX_RM_FMA(kd, Ln2hi, logc);
+	const double hi = r + w;
+	double lo = (w - hi) + r;
+	lo = TMX_RM_FMA(kd, Ln2lo, lo);
+	const double r2 = r * r;
+	const double r3 = r * r2;
+	const double p = TMX_RM_FMA(TMX_RM_FMA(r, A4, A3), r2, TMX_RM_FMA(r, A2, A1));
+	return TMX_RM_FMA(r3, p, TMX_RM_FMA(r2, A0, lo)) + hi;
+}
+TMX_RM_FN double tmx_ref_log_near1(double x) {
+	/* 1 - 2^-4 <= x < 1 + 0x1.09p-4: polynomial in r = x - 1 with the leading terms in double-double */
 	const double B0 = -0x1.0000000000000p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3, B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3,
 		B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4, B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
+	const double r = x - 1.0;
+	const double r2 = r * r;
+	const double r3 = r * r2;
+	const double q1 = TMX_RM_FMA(r2, B3, TMX_RM_FMA(r, B2, B1));
+	const double q4 = TMX_RM_FMA(r2, B6, TMX_RM_FMA(r, B5, B4));
+	double q7 = TMX_RM_FMA(r2, B9, TMX_RM_FMA(r, B8, B7));
+	q7 = TMX_RM_FMA(r3, B10, q7);
+	double P = TMX_RM_FMA(q7, r3, q4);
+	P = TMX_RM_FMA(P, r3, q1);
+	const double w27 = TMX_RM_FMA(r, 0x1p27, r);
+	const double rhi = TMX_RM_FMA(-0x1p27, r, w27);
+	const double rlo = r - rhi;
+	const double rh2 = rhi * rhi;
+	const double hi = TMX_RM_FMA(rh2, B0, r);
+	double lo = TMX_RM_FMA(rh2, B0, r - hi);
+	lo = TMX_RM_FMA(B0 * rlo, r + rhi, lo);
+	return (tmx_rm_bits(x) == 0x3ff0000000000000ull) ? 0.0 : hi + TMX_RM_FMA(P, r3, lo);
+}
+/* log for positive normal finite x without a branch: both paths, selected */
+TMX_RM_FN double tmx_ref_log_bf(double x, const double * tab) {
+	const double a = tmx_ref_log_main(x, tab), b = tmx_ref_log_near1(x);
+	return (tmx_rm_bits(x) - 0x3fee000000000000ull < 0x0003090000000000ull) ? b : a;
+}
+/* log with the table given by the caller ({1/c, log c} pairs: 256 doubles) */
+TMX_RM_FN double tmx_ref_log_t(double x, const double * tab) {
 	const unsigned long long ix = tmx_rm_bits(x);
-	double res;
-	{
-		/* main path, for every argument: x = 2^k z, z in [0x1.6p-1, 0x1.6p0); log(x) = log1p(z/c - 1) + log(c) + k ln2 */
-		const unsigned long long tmp = ix - 0x3fe6000000000000ull;
-		const unsigned i = (unsigned)(tmp >> 45) & 127u;
-		const int k = (int)((long long)tmp >> 52);
-		const double z = tmx_rm_dbl(ix - (tmp & 0xfff0000000000000ull));
-		const double invc = tab[2 * i], logc = tab[2 * i + 1];
-		const double r = TMX_RM_FMA(z, invc, -1.0);
-		const double kd = (double)k;
-		const double w = TMX_RM_FMA(kd, Ln2hi, logc);
-		const double hi = r + w;
-		double lo = (w - hi) + r;
-		lo = TMX_RM_FMA(kd, Ln2lo, lo);
-		const double r2 = r * r;
-		const double r3 = r * r2;
-		const double p = TMX_RM_FMA(TMX_RM_FMA(r, A4, A3), r2, TMX_RM_FMA(r, A2, A1));
-		res = TMX_RM_FMA(r3, p, TMX_RM_FMA(r2, A0, lo)) + hi;
-	}
+	double res = tmx_ref_log_main(x, tab);      /* for every argument; replaced below where it does not apply */
 	const int near1 = ix - 0x3fee000000000000ull < 0x0003090000000000ull;
 	if (TMX_RM_ANY(near1)) {
-		if (near1) {
-			/* 1 - 2^-4 <= x < 1 + 0x1.09p-4: polynomial in r = x - 1 with the leading terms in double-double */
-			const double r = x - 1.0;
-			const double r2 = r * r;
-			const double r3 = r * r2;
-			const double q1 = TMX_RM_FMA(r2, B3, TMX_RM_FMA(r, B2, B1));
-			const double q4 = TMX_RM_FMA(r2, B6, TMX_RM_FMA(r, B5, B4));
-			double q7 = TMX_RM_FMA(r2, B9, TMX_RM_FMA(r, B8, B7));
-			q7 = TMX_RM_FMA(r3, B10, q7);
-			double P = TMX_RM_FMA(q7, r3, q4);
-			P = TMX_RM_FMA(P, r3, q1);
-			const double w27 = TMX_RM_FMA(r, 0x1p27, r);
-			const double rhi = TMX_RM_FMA(-0x1p27, r, w27);
-			const double rlo = r - rhi;
-			const double rh2 = rhi * rhi;
-			const double hi = TMX_RM_FMA(rh2, B0, r);
-			double lo = TMX_RM_FMA(rh2, B0, r - hi);
-			lo = TMX_RM_FMA(B0 * rlo, r + rhi, lo);
-			res = (ix == 0x3ff0000000000000ull) ? 0.0 : hi + TMX_RM_FMA(P, r3, lo);
-		}
+		if (near1) res = tmx_ref_log_near1(x);
 	}
 	const unsigned top = (unsigned)(ix >> 48);
 	const int odd = !near1 && (top - 0x0010u >= 0x7ff0u - 0x0010u);

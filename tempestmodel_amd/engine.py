@@ -126,6 +126,7 @@ def load_library():
     lib.tmx_halo_p2p_export.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_halo_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
     lib.tmx_halo_p2p_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.tmx_halo_p2p_reset.argtypes = [C.c_void_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     _lib = lib
     return lib
@@ -507,6 +508,10 @@ class Engine:
         if len(blobs) != self.n_ranks or any(len(b) != n for b in blobs):
             raise ValueError("halo_p2p_connect needs one %d-byte blob per rank" % n)
         self._chk(self.lib.tmx_halo_p2p_connect(self.h, b"".join(blobs)))
+
+    def halo_p2p_reset(self):
+        """Recovery after a failed peer-to-peer exchange (tmx_halo_p2p_reset): between two barriers of all ranks."""
+        self._chk(self.lib.tmx_halo_p2p_reset(self.h))
 
     def halo_p2p_enable(self, on):
         self._chk(self.lib.tmx_halo_p2p_enable(self.h, int(bool(on))))

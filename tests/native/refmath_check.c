@@ -14,14 +14,19 @@ int main(int argc,char**argv){
 		if(m==0) x = -2.0 + 2.5*rnd();             /* exponent arguments of the Exner function */
 		else if(m==1) x = -700.0 + 1400.0*rnd();
 		else if(m==2) x = ldexp(rnd()-0.5, (int)(40*rnd())-30);
+		else if(i%8==3) x = ldexp(rnd()-0.5, -(int)(1000*rnd())-40);   /* tiny, incl. |x| < 2^-54 */
 		else x = 5.0*rnd()-2.5;
 		if(tmx_ref_exp(x)!=exp(x)){ if(bad_e<5) printf("exp mismatch %a: %a vs %a\n",x,tmx_ref_exp(x),exp(x)); bad_e++; }
+		/* the branch-free form the column kernel's assembly uses: |x| < 512 (tiny |x| included) */
+		if(fabs(x)<512.0 && tmx_ref_exp_main(x, tmx_rm_exp_tab)!=exp(x)){ if(bad_e<5) printf("exp_main mismatch %a\n",x); bad_e++; }
 		double y;
 		if(m==0) y = 0.05 + 1.1*rnd();              /* R/p0*rho*theta */
 		else if(m==1) y = 0.9375 + (1.0647-0.9375)*rnd();
 		else if(m==2) y = ldexp(0.5+rnd(), (int)(2000*rnd())-1000);
 		else y = 1e5*rnd();
 		if(tmx_ref_log(y)!=log(y)){ if(bad_l<5) printf("log mismatch %a: %a vs %a\n",y,tmx_ref_log(y),log(y)); bad_l++; }
+		/* branch-free form: positive, normal, finite arguments */
+		if(tmx_ref_log_bf(y, tmx_rm_log_tab)!=log(y)){ if(bad_l<5) printf("log_bf mismatch %a\n",y); bad_l++; }
 	}
 	long bad_p=0;
 	for(long i=0;i<n;i++){

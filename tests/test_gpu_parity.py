@@ -1058,18 +1058,29 @@ def test_multirank_device_path_loopback(n_ranks, ntr):
             e.close()
 
 
-@pytest.mark.parametrize("n_ranks,scheme", [(4, "ars343"), (8, "ars343"), (3, "strang")])
-def test_multirank_production_steps_loopback(n_ranks, scheme):
+INFO_EARLY_TILES, INFO_LATE_TILES = 7, 8
+
+
+@pytest.mark.parametrize("n_ranks,scheme,ntr", [(4, "ars343", 0), (8, "ars343", 0), (3, "strang", 0), (4, "ars343", 2), (3, "ark232", 2)])
+def test_multirank_production_steps_loopback(n_ranks, scheme, ntr):
     """The production call (tmx_step: fused program, exchanges inside) on n rank engines, one host thread each, with the
-    wire replaced by device copies (tmx_debug_loopback_group): three whole steps are bit-identical to one engine."""
+    wire replaced by device copies (tmx_debug_loopback_group): three whole steps are bit-identical to one engine.  The
+    stages run boundary tiles first (asserted: early and late tile lists exist), also with tracers, whose flux update,
+    column update and hyperviscosity then run over the two tile lists as well."""
     import threading
     from tempestmodel_amd.engine import Engine
-    d = gu.load("steps_ne4_L6_p24.npz")
-    g, _ = gu.make_grid(4, 6, 24)
-    start = gu.expand_compact(d, "step1", g)
-    single = Engine(g)
-    ranks = [Engine(g, rank=r, n_ranks=n_ranks) for r in range(n_ranks)]
+    # ne12 on 24 patches (6 x 6 elements each): the smallest layout on which every rank of a 3-, 4- or 8-rank split owns
+    # both kinds of tiles -- at ne4 / ne8 every 64-column tile touches a rank boundary and the stages are not split at all
+    g, start = gu.make_grid(12, 6, 24, ntracers=ntr)
+    tr = [g.initial_tracers[p] for p in range(24)] if ntr else None
+    ni = max(7, Engine.scheme_instances(scheme))
+    single = Engine(g, n_instances=ni)
+    ranks = [Engine(g, rank=r, n_ranks=n_ranks, n_instances=ni) for r in range(n_ranks)]
     try:
+        assert all(e.info(INFO_EARLY_TILES) > 0 and e.info(INFO_LATE_TILES) > 0 for e in ranks)
+        if ntr:
+            for e in [single] + ranks:
+                e.upload_tracers(0, tr)
         single.upload_state(0, start)
         for k in range(3):
             single.step(scheme, 200.0, first=(k == 0))
@@ -1100,6 +1111,56 @@ def test_multirank_production_steps_loopback(n_ranks, scheme):
             for p in e.local_patches:
                 assert np.array_equal(got[p][0][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), (e.rank, p)
                 assert np.array_equal(got[p][1][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), (e.rank, p)
+            if ntr:
+                gott, reft = e.download_tracers(0), single.download_tracers(0)
+                for p in e.local_patches:
+                    assert np.array_equal(gott[p][:, 1:-1, 1:-1], reft[p][:, 1:-1, 1:-1]), (e.rank, p)
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()
+
+
+def test_multirank_shallow_water_loopback():
+    """BASELINE config 1's equation set on 3 rank engines (24 patches, loopback wire): the shallow-water stage runs its
+    boundary tiles first as well; five Strang steps are bit-identical to one engine."""
+    import threading
+    from tempestmodel_amd.cubed_sphere import CubedSphereGrid, ShallowWaterTest2
+    from tempestmodel_amd.engine import Engine
+    g = CubedSphereGrid(12, 1, 1.0, shallow_water=True, ppd=2)      # ne12: every rank has early and late tiles
+    start = g.evaluate_test_case(ShallowWaterTest2())
+    single = Engine(g, n_instances=5)
+    ranks = [Engine(g, rank=r, n_ranks=3, n_instances=5) for r in range(3)]
+    try:
+        assert all(e.info(INFO_EARLY_TILES) > 0 and e.info(INFO_LATE_TILES) > 0 for e in ranks)
+        for e in [single] + ranks:
+            e.upload_state(0, start)
+        for k in range(5):
+            single.step("strang", 200.0, first=(k == 0))
+        single.sync()
+        ref = single.download_state(0)
+        Engine.loopback_group(ranks)
+        errors = []
+
+        def run(e):
+            try:
+                for k in range(5):
+                    e.step("strang", 200.0, first=(k == 0))
+                e.sync()
+            except Exception as ex:
+                errors.append(ex)
+
+        th = [threading.Thread(target=run, args=(e,)) for e in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errors and not any(t.is_alive() for t in th), errors
+        Engine.loopback_dissolve(ranks[0])
+        for e in ranks:
+            got = e.download_state(0)
+            for p in e.local_patches:
+                assert np.array_equal(got[p][0][[0, 1, 2], 1:-1, 1:-1], ref[p][0][[0, 1, 2], 1:-1, 1:-1]), (e.rank, p)
     finally:
         single.close()
         for e in ranks:
@@ -1264,12 +1325,14 @@ def test_multirank_supercell_configuration_loopback(scheme):
     mode, two tracers) on 4 rank engines through the loopback wire: three production steps bit-identical to one engine."""
     import threading
     from tempestmodel_amd.engine import Engine
-    g, start = gu.make_grid(4, 6, 24, case="smallplanet", ntracers=2)
+    g, start = gu.make_grid(12, 6, 24, case="smallplanet", ntracers=2)      # ne12: every rank has early and late tiles
     tr = [g.initial_tracers[p] for p in range(24)]
     kw = dict(fully_explicit=True, uniform_diffusion=UDIFF)
     single = Engine(g, **kw)
     ranks = [Engine(g, rank=r, n_ranks=4, **kw) for r in range(4)]
     try:
+        # boundary-first stages are on for this configuration too (tracers, uniform diffusion, explicit vertical mode)
+        assert all(e.info(INFO_EARLY_TILES) > 0 and e.info(INFO_LATE_TILES) > 0 for e in ranks)
         for e in [single] + ranks:
             e.upload_state(0, start); e.upload_tracers(0, tr)
         for k in range(3):

@@ -22,10 +22,13 @@ def _free_port():
     return port
 
 
+NE, LEV, NPATCH = 12, 6, 24      # ne12 on 24 patches: the smallest layout on which every rank owns early AND late tiles (boundary-first stages on)
+
+
 def _run_ranks(world, scheme, ntr, steps, out, **extra_env):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out, scheme, str(ntr), str(steps)],
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out, scheme, str(ntr), str(steps), str(NE), str(LEV), str(NPATCH)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:
@@ -40,18 +43,20 @@ def _run_ranks(world, scheme, ntr, steps, out, **extra_env):
 @pytest.mark.parametrize("world,scheme,ntr,env", [
     (2, "ars343", 0, {}), (4, "ars343", 2, {}), (3, "strang", 0, {}),
     # the exchange on the engine's own stream, whole-patch launches (no boundary-first split)
-    (2, "ars343", 0, {"TMX_NO_EXCHANGE_OVERLAP": "1"}), (3, "ars343", 0, {"TMX_NO_SPLIT": "1"})])
+    (2, "ars343", 0, {"TMX_NO_EXCHANGE_OVERLAP": "1"}), (3, "ars343", 0, {"TMX_NO_SPLIT": "1"}),
+    # a time-out on rank 0 (it steps alone for one step), then tmx_halo_p2p_reset on every rank and the run proper
+    (2, "recover-ars343", 0, {"TMX_P2P_TIMEOUT_S": "2"})])
 def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr, env):
     from tempestmodel_amd.engine import Engine
     steps = 3
-    g, st = gu.make_grid(4, 6, 24, ntracers=ntr)
+    g, st = gu.make_grid(NE, LEV, NPATCH, ntracers=ntr)
     single = Engine(g)
     try:
         single.upload_state(0, st)
         if ntr:
             single.upload_tracers(0, [g.initial_tracers[P.index] for P in g.patches])
         for k in range(steps):
-            single.step(scheme, 200.0, first=(k == 0))
+            single.step(scheme.replace("recover-", ""), 200.0 * 4 / NE, first=(k == 0))
         single.sync()
         ref = single.download_state(0)
         reft = single.download_tracers(0) if ntr else None
@@ -71,6 +76,9 @@ def test_ranks_in_separate_processes_match_one_engine(world, scheme, ntr, env):
                 if ntr:
                     assert np.array_equal(d["t%d" % p][:, 1:-1, 1:-1], reft[p][:, 1:-1, 1:-1]), (r, p)
         assert seen == set(range(24))
+        if scheme.startswith("recover-"):
+            msg = open(os.path.join(out, "rank0.txt")).read()
+            assert "did not arrive" in msg, msg       # the lone step did fail, and said so
 
 
 def test_bench_runs_as_two_rank_processes_on_one_device():
@@ -82,7 +90,7 @@ def test_bench_runs_as_two_rank_processes_on_one_device():
     env.pop("TMX_HALO", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--develop", "1", "--ne", "8", "--levels", "6", "--dt", "500", "--share-device", "--no-cpu-baseline"],
+                        "--develop", "1", "--ne", "8", "--levels", "6", "--dt", "500", "--share-device", "--halo", "auto", "--no-cpu-baseline"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=400, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]

@@ -42,6 +42,22 @@ def main():
                     f.write(outcome)
             dist.barrier()
             return
+        if scheme.startswith("recover-"):
+            # rank 0 steps alone and times out (TMX_P2P_TIMEOUT_S); then ALL ranks reset the transport between two barriers,
+            # upload the state again and step together: the result must be the undisturbed one
+            if rank == 0:
+                try:
+                    e.step("ars343", dt, first=True); e.sync()
+                    outcome = "no error"
+                except Exception as ex:
+                    outcome = str(ex)
+                with open(os.path.join(outdir, "rank0.txt"), "w") as f:
+                    f.write(outcome)
+            dist.barrier()
+            e.halo_p2p_reset()
+            dist.barrier()
+            e.upload_state(0, st)
+            scheme = scheme[len("recover-"):]
         e.step(scheme, dt, first=True); e.sync()
         dist.barrier()
         t0 = time.perf_counter()
