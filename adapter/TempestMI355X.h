@@ -96,13 +96,22 @@ public:
 	}
 
 	///	A plugin changed instance 0 on the device.  fStep: a time step was completed (counts towards the interval).
+	///	Model::Go runs Step, then the WorkflowProcesses (column physics), then the output managers (Model.cpp:470-509): when
+	///	the Step just taken refreshed the host copy (interval reached, last step), a physics plugin that runs after it
+	///	refreshes it again, so that output and error norms see the forcing as well.
 	void DeviceModified(bool fStep, bool fForceSync) {
 		m_fDeviceNewer = true;
 		if (fStep) m_nStepsSinceSync++;
-		if ((m_nHostSyncInterval == 1) || fForceSync || (m_nStepsSinceSync >= m_nHostSyncInterval)) {
+		const bool fFlush = (m_nHostSyncInterval == 1) || fForceSync || (m_nStepsSinceSync >= m_nHostSyncInterval)
+			|| (!fStep && m_fLastStepFlushed);
+		if (fStep) m_fLastStepFlushed = fFlush;
+		if (fFlush) {
 			Flush();
 		}
 	}
+
+	///	Called at the end of every Flush() that refreshed the host copy (KesslerPhysicsMI355X: accumulated precipitation).
+	void SetFlushHook(void (*pfnHook)(void *), void * pContext) { m_pfnFlushHook = pfnHook; m_pFlushHookContext = pContext; }
 
 	///	Bring the host copy of instance 0 up to date now (output managers, ComputeErrorNorms, end of run).
 	void Flush() {
@@ -111,6 +120,9 @@ public:
 			Check(tmx_sync(m_pEngine));
 			for (int ix = 0; ix < m_nCarried; ix++) Download(ix);
 			m_fDeviceNewer = false;
+			if (m_pfnFlushHook != NULL) {
+				m_pfnFlushHook(m_pFlushHookContext);
+			}
 		}
 		m_nStepsSinceSync = 0;
 	}
@@ -208,7 +220,8 @@ private:
 	MI355XEngine(Model & model) :
 		m_model(model), m_pEngine(NULL), m_fPeerToPeer(false),
 		m_dNuScalar(1.0e15), m_dNuDiv(1.0e15), m_dNuVort(1.0e15), m_nHypervisOrder(4), m_fFullyExplicit(false),
-		m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fHostNewer(true), m_fDeviceNewer(false), m_nCarried(1)
+		m_nHostSyncInterval(1), m_nStepsSinceSync(0), m_fLastStepFlushed(false), m_pfnFlushHook(NULL), m_pFlushHookContext(NULL),
+		m_fHostNewer(true), m_fDeviceNewer(false), m_nCarried(1)
 	{ }
 
 	GridGLL * Grid() {
@@ -486,22 +499,57 @@ private:
 			// peer-to-peer transport: every rank's blob to every rank, then map the neighbours (the ranks may share a device)
 			const int nBlob = tmx_halo_p2p_blob_bytes(m_pEngine);
 			std::vector<unsigned char> vecMine(nBlob), vecAll((size_t)nBlob * nRanks);
-			Check(tmx_halo_p2p_export(m_pEngine, &(vecMine[0])));
-			MPI_Allgather(&(vecMine[0]), nBlob, MPI_BYTE, &(vecAll[0]), nBlob, MPI_BYTE, MPI_COMM_WORLD);
-			Check(tmx_halo_p2p_connect(m_pEngine, &(vecAll[0])));
+			// Every step of the set-up is agreed on by all ranks (a rank that throws on its own leaves the others in a
+			// collective): export, gather, connect, each followed by an all-reduce of the status.  If any rank cannot map a
+			// neighbour (another node, no peer access) ALL ranks fall back to RCCL send / recv.
+			int iOk = (tmx_halo_p2p_export(m_pEngine, &(vecMine[0])) == TMX_OK) ? 1 : 0, iAll = 0;
+			std::string strWhy = iOk ? "" : tmx_last_error();
+			MPI_Allreduce(&iOk, &iAll, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+			if (iAll) {
+				MPI_Allgather(&(vecMine[0]), nBlob, MPI_BYTE, &(vecAll[0]), nBlob, MPI_BYTE, MPI_COMM_WORLD);
+				iOk = (tmx_halo_p2p_connect(m_pEngine, &(vecAll[0])) == TMX_OK) ? 1 : 0;
+				if (!iOk) strWhy = tmx_last_error();
+				MPI_Allreduce(&iOk, &iAll, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+			}
 			MPI_Barrier(MPI_COMM_WORLD);
-			m_fPeerToPeer = true;
+			if (iAll) {
+				m_fPeerToPeer = true;
+			} else {
+				if (!strWhy.empty()) {
+					fprintf(stderr, "tempest_mi355x: rank %d: peer-to-peer halo not available (%s); all ranks use RCCL send/recv\n", nRank, strWhy.c_str());
+				}
+				InitRcclComm(nRank);
+				if (iOk) {
+					Check(tmx_halo_p2p_enable(m_pEngine, 0));      // this rank did connect: switch it back
+				}
+			}
 
 		} else if (nRanks > 1) {
-			unsigned char id[128];
-			if (nRank == 0) {
-				Check(tmx_comm_unique_id(id));
-			}
-			MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
-			Check(tmx_comm_init(m_pEngine, id));
+			InitRcclComm(nRank);
 		}
 #endif
 	}
+
+#ifdef TEMPEST_MPIOMP
+	///	RCCL communicator over MPI_COMM_WORLD (collective: every rank calls it; an error here is fatal on all ranks alike).
+	void InitRcclComm(int nRank) {
+		unsigned char id[128];
+		int iOk = 1, iAll = 0;
+		if (nRank == 0) {
+			iOk = (tmx_comm_unique_id(id) == TMX_OK) ? 1 : 0;
+		}
+		MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+		if (iOk) {
+			iOk = (tmx_comm_init(m_pEngine, id) == TMX_OK) ? 1 : 0;
+		}
+		std::string strWhy = iOk ? "" : tmx_last_error();
+		MPI_Allreduce(&iOk, &iAll, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+		if (!iAll) {
+			_EXCEPTION1("tempest_mi355x: RCCL communicator could not be created on every rank (%s)",
+				strWhy.empty() ? "another rank failed" : strWhy.c_str());
+		}
+	}
+#endif
 
 private:
 	Model & m_model;
@@ -512,6 +560,9 @@ private:
 	bool m_fFullyExplicit;
 	int m_nHostSyncInterval;
 	int m_nStepsSinceSync;
+	bool m_fLastStepFlushed;
+	void (*m_pfnFlushHook)(void *);
+	void * m_pFlushHookContext;
 	bool m_fHostNewer;
 	bool m_fDeviceNewer;
 	int m_nCarried;
@@ -789,6 +840,8 @@ public:
 		}
 	}
 
+	static void FlushHook(void * pThis) { static_cast<KesslerPhysicsMI355X *>(pThis)->FlushPrecipitation(); }
+
 	virtual void Perform(const Time & time) {
 		MI355XEngine & eng = MI355XEngine::For(m_model);
 		tmx_engine * pEngine = eng.Handle();
@@ -800,12 +853,10 @@ public:
 			}
 			m_fInputsSet = true;
 		}
+		eng.SetFlushHook(&KesslerPhysicsMI355X::FlushHook, this);      // precipitation follows every refresh of the host copy
 		eng.EnsureDevice();
 		MI355XEngine::Check(tmx_physics_kessler(pEngine, 0, m_timeFrequency.GetSeconds()));
 		eng.DeviceModified(false, false);
-		if (eng.GetHostSyncInterval() == 1) {
-			FlushPrecipitation();
-		}
 		WorkflowProcess::Perform(time);
 	}
 

@@ -160,7 +160,7 @@ int main(int argc, char ** argv) {
 	double offCentering = 0.0;
 	int restartAt = -1, restartStatus = 0;
 	double msDev = -1.0;
-	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1;
+	int ne = 4, levels = 10, nsteps = 3, npatch = 6, nwarm = 1, ntracers = 0, physics = 0, hostsync = 1, modelgo = 0;
 	double dt = 200.0, ztop = 30000.0, tol = 1.0e-10, nu = 1.0e15;
 	bool fZtopGiven = false;
 	for (int i = 1; i < argc; i++) {
@@ -180,6 +180,7 @@ int main(int argc, char ** argv) {
 		else if (a == "--scheme") { scheme = v; i++; }                // parity mode: ars343 (default), ark232, ars232
 		else if (a == "--tracers") { ntracers = atoi(v); i++; }
 		else if (a == "--hostsync") { hostsync = atoi(v); i++; }    // production mode: host synchronisation interval (steps)
+		else if (a == "--modelgo") { modelgo = atoi(v); i++; }      // 1: the step loop as Model::Go runs it (last step flagged, NO manual flush before the host state is read)
 		else if (a == "--physics") { physics = atoi(v); i++; }      // 1: Held-Suarez forcing, 2: Kessler microphysics, after every step
 		else if (a == "--ztop") { ztop = atof(v); fZtopGiven = true; i++; }
 		else if (a == "--nu") { nu = atof(v); i++; }
@@ -332,15 +333,19 @@ try {
 		restore(pGrid, s0); restore(pGrid, s1, 1); restorePrect(prect0);
 		if (mode == "production") engine.MarkHostModified();
 		const auto tDev0 = std::chrono::steady_clock::now();
-		for (int s = 0; s < nsteps; s++) { pT->Step(false, false, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
-		engine.Flush();
+		// --modelgo: Model::Go's own sequence (Model.cpp:420-509): Step(fLastStep on the last one), the WorkflowProcesses, then
+		// the output managers read the host arrays -- nothing but the plugins themselves refreshes them
+		for (int s = 0; s < nsteps; s++) { pT->Step(false, modelgo && s == nsteps - 1, time, dt); if (pPhysDev) pPhysDev->Perform(time); }
+		if (!modelgo) engine.Flush();
 		MI355XEngine::Check(tmx_sync(engine.Handle()));
 		msDev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tDev0).count() / (nsteps > 0 ? nsteps : 1);
 	}
 	// deferred host synchronisation (--hostsync > 1): what a driver does at the reference's host sync points
 	// (OutputManager::ManageOutput / FinalOutput, ComputeErrorNorms: Model.cpp:484-509, :695)
-	engine.Flush();
-	if (pKesDev && hostsync > 1) pKesDev->FlushPrecipitation();
+	if (!modelgo) {
+		engine.Flush();
+		if (pKesDev && hostsync > 1) pKesDev->FlushPrecipitation();
+	}
 	save(pGrid, got);
 	savePrect(prectDev);
 

@@ -2486,7 +2486,7 @@ extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
 // reference's MPI, torch.distributed) and hands all of them to tmx_halo_p2p_connect; before tmx_destroy the caller lets every
 // rank finish (a barrier), since neighbours write into this rank's block.  The reference's exchange this replaces:
 // Connectivity.cpp:928-1120 (ExchangeBuffer pack / MPI_Isend / MPI_Irecv / unpack), Grid.cpp:627-685.
-struct p2p_blob_head { hipIpcMemHandle_t handle; unsigned long long ghost_doubles; int n_ranks, rank; };
+struct p2p_blob_head { hipIpcMemHandle_t handle; unsigned long long ghost_doubles; int n_ranks, rank; char pci[16]; };      // pci: bus id of the exporting device
 
 extern "C" int tmx_halo_p2p_blob_bytes(tmx_engine * e) {
 	if (!e || !e->finalized) return -1;
@@ -2511,6 +2511,8 @@ extern "C" int tmx_halo_p2p_export(tmx_engine * e, unsigned char * blob) {
 	memset(&h, 0, sizeof(h));
 	HIPCHK(hipIpcGetMemHandle(&h.handle, e->p2p_block));
 	h.ghost_doubles = gd; h.n_ranks = e->cfg.n_ranks; h.rank = e->cfg.rank;
+	if (hipDeviceGetPCIBusId(h.pci, (int)sizeof(h.pci), e->device) != hipSuccess) { (void)hipGetLastError(); h.pci[0] = 0; }
+	h.pci[sizeof(h.pci) - 1] = 0;
 	memcpy(blob, &h, sizeof(h));
 	memcpy(blob + sizeof(h), e->recv_rank_off.data(), sizeof(int) * (e->cfg.n_ranks + 1));
 	return TMX_OK;
@@ -2537,6 +2539,16 @@ extern "C" int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs)
 		REQUIRE(rk == me || their == ns, TMX_ERR_INVALID, "rank %d sends %d columns to rank %d which expects %d", me, ns, rk, their);
 		REQUIRE(rk == me || (ns > 0) == (nr > 0), TMX_ERR_INVALID, "halo between ranks %d and %d is one-sided (%d out, %d in)", me, rk, ns, nr);
 		if (rk == me || ns == 0) continue;
+		// a neighbour on another device of this node: the gather kernel will write into its memory, which needs peer access
+		// (where this process can see that device at all; otherwise the mapping below is the test)
+		if (h.pci[0]) {
+			int their_dev = -1;
+			if (hipDeviceGetByPCIBusId(&their_dev, h.pci) == hipSuccess && their_dev >= 0 && their_dev != e->device) {
+				int can = 0;
+				if (hipDeviceCanAccessPeer(&can, e->device, their_dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+				REQUIRE(can, TMX_ERR_COMM, "device %d (this rank) has no peer access to device %d (%s, rank %d): no peer-to-peer halo between them", e->device, their_dev, h.pci, rk);
+			} else (void)hipGetLastError();
+		}
 		void * base = nullptr;
 		const hipError_t oe = hipIpcOpenMemHandle(&base, h.handle, hipIpcMemLazyEnablePeerAccess);
 		REQUIRE(oe == hipSuccess, TMX_ERR_COMM, "hipIpcOpenMemHandle of rank %d's halo block failed: %s (ranks of one process cannot map each other; "

@@ -62,6 +62,14 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
     ("production", ["--case", "supercellreal", "--ne", "2", "--levels", "40", "--dt", "0.5", "--steps", "3", "--warm", "2", "--patches", "6"]),
     ("production", ["--case", "supercellreal", "--ne", "2", "--levels", "40", "--dt", "0.5", "--steps", "3", "--warm", "2", "--patches", "6", "--hostsync", "100"]),
     ("parity", ["--case", "supercellreal", "--ne", "2", "--levels", "40", "--dt", "0.5", "--steps", "2", "--warm", "2", "--patches", "6"]),
+    # Model::Go's own sequence (Step with fLastStep on the last step, then the WorkflowProcess, then the host state is read
+    # with NO manual flush): with a deferred host copy the physics plugin that runs after a flushing Step must flush again,
+    # the Kessler precipitation included (flush hook); intervals 1, 2 (flush in the middle and at the end) and 100 (last step only)
+    ("production", ["--modelgo", "1", "--case", "heldsuarez", "--ne", "2", "--levels", "12", "--steps", "4", "--warm", "2", "--patches", "6", "--hostsync", "100"]),
+    ("production", ["--modelgo", "1", "--case", "heldsuarez", "--ne", "2", "--levels", "12", "--steps", "4", "--warm", "2", "--patches", "6", "--hostsync", "2"]),
+    ("production", ["--modelgo", "1", "--case", "supercellreal", "--ne", "2", "--levels", "40", "--dt", "0.5", "--steps", "3", "--warm", "2", "--patches", "6", "--hostsync", "100"]),
+    ("production", ["--modelgo", "1", "--case", "supercellreal", "--ne", "2", "--levels", "40", "--dt", "0.5", "--steps", "4", "--warm", "2", "--patches", "6", "--hostsync", "2"]),
+    ("production", ["--modelgo", "1", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6", "--hostsync", "1"]),
 ])
 def test_reference_driver_with_adapter_plugins(mode, args):
     if not os.path.exists(BIN):
