@@ -359,7 +359,8 @@ try {
 	model.SetHorizontalDynamics(pH);
 	// levels == 1 -> VerticalDynamicsStub, as TempestInitialize.h:362-365
 	VerticalDynamics * pV = fSW ? (VerticalDynamics *)(new VerticalDynamicsStub(model))
-	                : (vmethod == "schur") ? (VerticalDynamics *)(new VerticalDynamicsSchur(model, 4, getenv("TMX_REF_SCHUR_VORDER") ? atoi(getenv("TMX_REF_SCHUR_VORDER")) : 2, 0, fExplicitVertical, true, false))
+	                : (vmethod == "schur") ? (VerticalDynamics *)(new VerticalDynamicsSchur(model, 4, getenv("TMX_REF_SCHUR_VORDER") ? atoi(getenv("TMX_REF_SCHUR_VORDER")) : 2, 0, fExplicitVertical,
+	                                                              getenv("TMX_REF_SCHUR_NOREF") == NULL /* --norefstate */, getenv("TMX_REF_SCHUR_MASSFLUX") != NULL /* --vmassfluxlevels */))
 	                            : (VerticalDynamics *)(new VerticalDynamicsFEM(model, 4, 1, 0, fExplicitVertical, true, false));
 	model.SetVerticalDynamics(pV);
 
@@ -367,7 +368,11 @@ try {
 	pGrid->DefineParameters();
 	pGrid->SetParameters(levels, (npatch < 6) ? 6 : npatch, ne, 4, 4, (vmethod == "schur") ? (getenv("TMX_REF_SCHUR_VORDER") ? atoi(getenv("TMX_REF_SCHUR_VORDER")) : 2) : 1,
 		(vmethod == "schur") ? Grid::VerticalDiscretization_FiniteVolume : Grid::VerticalDiscretization_FiniteElement,
-		getenv("TMX_REF_VSTAGGER_CPH") ? Grid::VerticalStaggering_CharneyPhillips : Grid::VerticalStaggering_Lorenz);
+		// probes of the Schur path only (tests/analysis/schur_reference_probe.sh): --vstagger of TempestInitialize.h:137
+		getenv("TMX_REF_VSTAGGER_CPH") ? Grid::VerticalStaggering_CharneyPhillips
+		: (getenv("TMX_REF_VSTAGGER") && std::string(getenv("TMX_REF_VSTAGGER")) == "lev") ? Grid::VerticalStaggering_Levels
+		: (getenv("TMX_REF_VSTAGGER") && std::string(getenv("TMX_REF_VSTAGGER")) == "int") ? Grid::VerticalStaggering_Interfaces
+		: Grid::VerticalStaggering_Lorenz);
 	pGrid->InitializeDataLocal();
 	model.SetGrid(pGrid, npatch);
 

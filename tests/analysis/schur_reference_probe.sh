@@ -22,4 +22,19 @@ echo "== vertical order 4 (TMX_REF_SCHUR_VORDER=4)" >> $LOG
 TMX_REF_SCHUR_VORDER=4 run --ne 4 --levels 12 --dt 200
 echo "== the same with Charney-Phillips staggering (TMX_REF_VSTAGGER_CPH=1)" >> $LOG
 TMX_REF_VSTAGGER_CPH=1 run --ne 4 --levels 10 --dt 200
+# round 3: the remaining switches of the reference's command line that reach this class
+echo "== --vstagger LEV (TMX_REF_VSTAGGER=lev)" >> $LOG
+TMX_REF_VSTAGGER=lev run --ne 4 --levels 10 --dt 200
+echo "== --vstagger INT (TMX_REF_VSTAGGER=int)" >> $LOG
+TMX_REF_VSTAGGER=int run --ne 4 --levels 10 --dt 200
+echo "== --vmassfluxlevels (TMX_REF_SCHUR_MASSFLUX=1)" >> $LOG
+TMX_REF_SCHUR_MASSFLUX=1 run --ne 4 --levels 10 --dt 200
+echo "== --vmassfluxlevels with --vstagger LEV" >> $LOG
+TMX_REF_SCHUR_MASSFLUX=1 TMX_REF_VSTAGGER=lev run --ne 4 --levels 10 --dt 200
+echo "== --norefstate (TMX_REF_SCHUR_NOREF=1)" >> $LOG
+TMX_REF_SCHUR_NOREF=1 run --ne 4 --levels 10 --dt 200
+echo "== --norefstate with --vstagger LEV, small time step" >> $LOG
+TMX_REF_SCHUR_NOREF=1 TMX_REF_VSTAGGER=lev run --ne 4 --levels 10 --dt 10
+echo "== fully explicit vertical mode (--explicitvertical): the solve is never called" >> $LOG
+run --ne 4 --levels 10 --dt 1 --explicitvertical
 cat $LOG
