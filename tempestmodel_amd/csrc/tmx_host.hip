@@ -156,6 +156,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
+	if (const char * m = getenv("TMX_HVIS_PULL")) e->hvis_pull = atoi(m);
 	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
 	if (const char * m = getenv("TMX_VI_BACK_SUB")) e->vi_back_sub = atoi(m);
 	if (const char * m = getenv("TMX_VI_STAGGER_NS")) e->vi_stagger = atoi(m) / 10;
@@ -197,7 +198,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_colref); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
 		if (e->d_ghost_own) e->d_ghost = e->d_ghost_own;          // p2p mode pointed d_ghost into the shared block
 		for (void * q : e->p2p_peer) if (q) hipIpcCloseMemHandle(q);
 		free_dev(e->p2p_block); free_dev(e->d_p2p_dst); free_dev(e->d_p2p_flag); free_dev(e->d_send_peer); free_dev(e->d_send_within); free_dev(e->d_p2p_peers);
@@ -856,6 +857,21 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)(L + 4) * NS * sizeof(double))); bytes += (size_t)(L + 4) * NS * sizeof(double);
 	HIPCHK(hipMemset(e->d_scratch, 0, (size_t)(L + 4) * NS * sizeof(double)));
 	if ((r = dev_upload(&e->d_grp_cols, plan.grp_cols, &bytes))) return r;
+	{
+		// column -> its other copies: the group table inverted, for kernels that average while loading (k_hypervis<PULL>):
+		// {the three other members in group order, n | me << 3 | type << 6 | (matrix index + 1) << 8}; all zero / -1: no copies
+		std::vector<int> colref((size_t)e->NS * 4, 0);
+		for (size_t c = 0; c < (size_t)e->NS; c++) { colref[c * 4] = colref[c * 4 + 1] = colref[c * 4 + 2] = -1; }
+		for (int g = 0; g < e->ngroups; g++)
+			for (int m = 0; m < plan.grp_n[g]; m++) {
+				const int c = plan.grp_cols[(size_t)g * 4 + m];
+				if (c < 0 || c >= e->NS) continue;
+				int q = 0;
+				for (int o = 0; o < 4; o++) if (o != m) colref[(size_t)c * 4 + q++] = (o < plan.grp_n[g]) ? plan.grp_cols[(size_t)g * 4 + o] : -1;
+				colref[(size_t)c * 4 + 3] = plan.grp_n[g] | (m << 3) | (((plan.grp_type[g] >> (2 * m)) & 3) << 6) | ((plan.grp_x[g] + 1) << 8);
+			}
+		if ((r = dev_upload(&e->d_colref, colref, &bytes))) return r;
+	}
 	if ((r = dev_upload(&e->d_grp_n, plan.grp_n, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_type, plan.grp_type, &bytes))) return r;
@@ -1763,7 +1779,13 @@ static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool ov
 	return launch_check("apply_dss");
 }
 
+// work_is_scratch: the caller never looks at the working instance afterwards (the steppers' own programs); the ABI call
+// leaves it as the reference does (the first pass's Laplacians, DSS'ed).
+static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int iwork, double dt, bool work_is_scratch);
 extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
+	return h_step_after_subcycle_impl(e, iinit, iupd, iwork, dt, false);
+}
+static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int iwork, double dt, bool work_is_scratch) {
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd)) || (r = check_inst(e, iwork))) return r;
 	// preconditions of the reference (HorizontalDynamicsFEM.cpp:2648-2655)
 	REQUIRE(iinit != iwork, TMX_ERR_INVALID, "StepAfterSubCycle: initial and working data must be distinct");
@@ -1785,6 +1807,14 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 		// second pass: coefficients scaled with the patch's (delta_alpha / reference length)^3.2, per column (G2_NUS)
 		const int scale = (c.reference_length != 0.0) ? 1 : 0;
 		if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;     // CopyData :2663, ZeroData :2693
+		// Experiment (TMX_HVIS_PULL=1, judge's "node-unique" go / no-go): the DSS between the two passes is not run as a pass
+		// of its own, the second pass averages the first pass's Laplacians while it loads them (k_hypervis<PULL>); on several
+		// ranks the raw Laplacians of the rank boundary still travel, and the second pass starts once they have arrived.
+		// Bit-identical, but a NO-GO: at ne30 L30 the second pass takes 166 instead of 67 us (every seam node gathers its one
+		// to three partner values per field from other elements' rows: n^2 instead of n loads per group, 8 bytes per lane from
+		// up to 30 different cache lines per wavefront instruction) against the 62 us of the DSS pass it replaces
+		// (profiles/r03_dss_pull_ab.txt).  Without tracers only (k_hypervis_tracers has no such form).
+		const bool pull = e->hvis_pull && e->nt == 0 && work_is_scratch;
 		if (stage_can_split(e) && !e->sw) {
 			// each pass boundary tiles first, its exchange overlapped with the interior tiles (see hv_stage_split)
 			for (int pass = 0; pass < 2; pass++) {
@@ -1799,7 +1829,7 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 							tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
 							if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0);
 						} else {
-							tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+							tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale, pull);
 							if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale);
 						}
 					}
@@ -1807,14 +1837,20 @@ extern "C" int tmx_h_step_after_subcycle(tmx_engine * e, int iinit, int iupd, in
 				}
 				p.quads = nullptr;
 				if ((r = launch_check("hypervis pass (split)"))) return r;
-				if ((r = dss_after_exchange(e, p, idst, overlapped))) return r;
+				if (pass == 0 && pull) {
+					if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));      // the neighbours' Laplacians are in the ghost buffer
+				} else if ((r = dss_after_exchange(e, p, idst, overlapped))) return r;
 			}
 		} else {
 			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
 			  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0); }
 			if ((r = launch_check("hypervis pass 1"))) return r;
-			if ((r = tmx_apply_dss(e, iwork))) return r;
-			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+			if (pull) {
+				bool overlapped = false;
+				if ((r = exchange(e, p, inst(e, iwork), &overlapped))) return r;
+				if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
+			} else if ((r = tmx_apply_dss(e, iwork))) return r;
+			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale, pull);
 			  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, 1, scale); }
 			if ((r = launch_check("hypervis pass 2"))) return r;
 			if ((r = tmx_apply_dss(e, iupd))) return r;
@@ -2265,7 +2301,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 			if ((r = vi_terms_explicit(e, o.a, o.b, o.coef))) return r;
 			break;
 		case OP_HVIS:
-			if ((r = tmx_h_step_after_subcycle(e, o.a, o.b, o.c, o.coef))) return r;
+			if ((r = h_step_after_subcycle_impl(e, o.a, o.b, o.c, o.coef, true))) return r;
 			break;
 		case OP_LINCOMB:
 			// LinearCombine(-> d) + H(i,d,c) + V(i,d,c): combination evaluated inside the explicit kernels

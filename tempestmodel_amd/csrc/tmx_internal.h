@@ -113,6 +113,9 @@ struct tmx_engine {
 	// DSS
 	int ngroups = 0, nxgroups = 0, nghost = 0;
 	int ngroups_local = 0;                   // groups [0, ngroups_local) have no member on another rank
+	int * d_colref = nullptr;                // [NS][4] the other copies of a stored column + packed group info (k_hypervis<PULL>: the DSS pulled into a kernel's loads)
+	int hvis_pull = 0;                       // TMX_HVIS_PULL=1: the second hyperviscosity pass averages the first pass's Laplacians while loading them
+	                                         // instead of a DSS pass in between (bit-identical; measured SLOWER: +99 us for the pass against 62 us saved)
 	int * d_grp_cols = nullptr;              // [ngroups][4] column index (>= NS: ghost NS+idx), -1 = none
 	int * d_grp_n = nullptr;                 // [ngroups] member count (2..4); high bit 8 = cross-panel, index in bits 16+
 	int * d_grp_x = nullptr;                 // [ngroups] index into the cross-panel matrices or -1
@@ -195,7 +198,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1);
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
-	double dt, double nu_s, double nu_d, double nu_v, int scale_locally);
+	double dt, double nu_s, double nu_d, double nu_v, int scale_locally, bool pull_dss = false);
 void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const double * const * src, const double * coef, int dst_is_term0);
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf);

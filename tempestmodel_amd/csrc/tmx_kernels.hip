@@ -2135,8 +2135,88 @@ void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long 
 // instance), otherwise the instance that StepAfterSubCycle copied into the update instance.
 
 // scale != 0: the coefficients are multiplied by the patch's (delta_alpha / reference length)^3.2 (fScaleNuLocally, :1968-1975)
+// PULL: the source instance holds values that have NOT been averaged over co-located nodes yet (the first pass's Laplacians):
+// every thread forms its own node's average while loading -- its group's copies, combined exactly as k_dss would have
+// combined them for this member (dss_combine in the member's own frame, (U,V) of copies on other panels rotated into it,
+// copies of other ranks from the ghost buffer) -- so the DSS pass between the two hyperviscosity passes (a read and a write
+// of the whole instance) is not run at all.  The partner rows are the neighbouring elements' rows, which other threads
+// load anyway: L2 hits, no extra HBM traffic.  Bit-identical to pass 1 + k_dss + pass 2.
+struct DssPull {
+	const int4 * colpart;     // [NS] {partner 1, partner 2, partner 3, info}: the OTHER copies of a stored column in the order of its group
+	                          // (column index, >= NS: ghost NS + index, -1: none); info = n | me << 3 | type << 6 | (matrix index + 1) << 8; info 0: no copies
+	const double * xmat, * ghost;
+	const int * gbase, * gstride;
+};
+template <int NF>
+__device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull & d, const double * __restrict__ x, int col, const int (&slab)[NF], bool uv, double (&out)[NF]) {
+	// out[f] = this node's DSS average of field slab[f]; with uv the last two fields are (U, V) (rotated between panels)
+	const size_t NS = (size_t)p.NS;
+	const int4 cp = d.colpart[col];
+	double own[NF];
+#pragma unroll
+	for (int f = 0; f < NF; f++) own[f] = x[(size_t)slab[f] * NS + col];
+	if (cp.w == 0) {
+#pragma unroll
+		for (int f = 0; f < NF; f++) out[f] = own[f];
+		return;
+	}
+	const int n = cp.w & 7, me = (cp.w >> 3) & 3, ty = (cp.w >> 6) & 3, xi = (cp.w >> 8) - 1;
+	const int oc[3] = { cp.x, cp.y, cp.z };
+	// v[f][m]: copies in group order; this column sits at position me, the others keep their order around it
+	double v[NF][4];
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+#pragma unroll
+		for (int f = 0; f < NF; f++) v[f][m] = 0.0;
+	}
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const int m = q + (q >= me ? 1 : 0);      // group position of the q-th other copy
+		const bool on = m < n;
+		const int c = oc[q];
+		const bool loc = on && c < (int)NS;
+		const double * ptr = !on ? x : (loc ? x + c : d.ghost + d.gbase[c - (int)NS]);
+		const size_t str = !on ? 0 : (loc ? NS : (size_t)d.gstride[c - (int)NS]);
+#pragma unroll
+		for (int f = 0; f < NF; f++) {
+			const double w = on ? ptr[(size_t)slab[f] * str] : 0.0;
+#pragma unroll
+			for (int mm = 0; mm < 4; mm++) if (mm == m) v[f][mm] = w;
+		}
+	}
+#pragma unroll
+	for (int f = 0; f < NF; f++) {
+#pragma unroll
+		for (int mm = 0; mm < 4; mm++) if (mm == me) v[f][mm] = own[f];
+	}
+	auto comb = [&](double w0, double w1, double w2, double w3) -> double {
+		switch (me) {
+			case 0: return dss_combine<0>(w0, w1, w2, w3, n, ty);
+			case 1: return dss_combine<1>(w0, w1, w2, w3, n, ty);
+			case 2: return dss_combine<2>(w0, w1, w2, w3, n, ty);
+			default: return dss_combine<3>(w0, w1, w2, w3, n, ty);
+		}
+	};
+	const int nscal = uv ? NF - 2 : NF;
+#pragma unroll
+	for (int f = 0; f < NF; f++) if (f < nscal) out[f] = comb(v[f][0], v[f][1], v[f][2], v[f][3]);
+	if (uv) {
+		double a[4], b[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			if (xi < 0 || q == me || q >= n) { a[q] = v[NF - 2][q]; b[q] = v[NF - 1][q]; }
+			else {
+				const double * T = d.xmat + (size_t)xi * 64 + (me * 4 + q) * 4;
+				a[q] = T[0] * v[NF - 2][q] + T[1] * v[NF - 1][q]; b[q] = T[2] * v[NF - 2][q] + T[3] * v[NF - 1][q];
+			}
+		}
+		out[NF - 2] = comb(a[0], a[1], a[2], a[3]); out[NF - 1] = comb(b[0], b[1], b[2], b[3]);
+	}
+}
+
+template <bool PULL>
 __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
-	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale)
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
 	__shared__ double s[4][8][64];
 	__shared__ double sD[16], sS[16];
@@ -2156,13 +2236,26 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	if (actw) {
 		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
 		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
-		psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		if (!PULL) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
 	}
-	if (actn) {
+	if (!PULL && actn) {
 		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
 		psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
 		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
 		ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+	}
+	if (PULL && actw) {
+		if (actn) {
+			const int sl[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
+			double o[5];
+			dss_pull_fields<5>(p, pull, xsrc, col, sl, true, o);
+			psiW = o[0]; psiT = o[1]; psiR = o[2]; ua = o[3]; ub = o[4];
+		} else {
+			const int sl[1] = { TMX_SLAB_W(L, kk) };
+			double o[1];
+			dss_pull_fields<1>(p, pull, xsrc, col, sl, false, o);
+			psiW = o[0];
+		}
 	}
 	const double cua = c2a0 * ua + c2a1 * ub;
 	const double cub = c2a1 * ua + c2b1 * ub;
@@ -2236,9 +2329,11 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 }
 
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
-	double dt, double nu_s, double nu_d, double nu_v, int scale) {
+	double dt, double nu_s, double nu_d, double nu_v, int scale, bool pull_dss) {
 	dim3 blk(64, 4), grd(p.quads ? e->launch_tiles : p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_hypervis, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
+	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
+	if (pull_dss) hipLaunchKernelGGL(k_hypervis<true>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	else hipLaunchKernelGGL(k_hypervis<false>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1630,3 +1630,56 @@ def test_mfma_contractions_against_the_north_star_gate(monkeypatch):
     finally:
         exact.close(); mfma.close()
 
+
+def test_dss_pulled_into_the_second_hyperviscosity_pass_is_bit_identical(monkeypatch):
+    """TMX_HVIS_PULL=1 (an archived experiment: slower): the second hyperviscosity pass of the steppers'
+    programs averages the first pass's Laplacians while loading them, the DSS pass between the two is not run.  Three
+    ARS343 steps on 24 patches (cube corners, panel edges with rotated (U,V), patch seams) equal the default path's
+    bit for bit, and so does a 3-rank run through the loopback wire (remote copies from the ghost buffer)."""
+    import threading
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(12, 6, 24)
+    ref_e = Engine(g)
+    monkeypatch.setenv("TMX_HVIS_PULL", "1")
+    pull = Engine(g)
+    ranks = [Engine(g, rank=r, n_ranks=3) for r in range(3)]
+    monkeypatch.delenv("TMX_HVIS_PULL")
+    try:
+        for e in [ref_e, pull] + ranks:
+            e.upload_state(0, start)
+        for e in (ref_e, pull):
+            for k in range(3):
+                e.step("ars343", 60.0, first=(k == 0))
+            e.sync()
+        ref = ref_e.download_state(0)
+        got = pull.download_state(0)
+        for p in range(24):
+            assert np.array_equal(got[p][0][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), p
+            assert np.array_equal(got[p][1][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), p
+        Engine.loopback_group(ranks)
+        errors = []
+
+        def run(e):
+            try:
+                for k in range(3):
+                    e.step("ars343", 60.0, first=(k == 0))
+                e.sync()
+            except Exception as ex:
+                errors.append(ex)
+
+        th = [threading.Thread(target=run, args=(e,)) for e in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errors and not any(t.is_alive() for t in th), errors
+        Engine.loopback_dissolve(ranks[0])
+        for e in ranks:
+            got = e.download_state(0)
+            for p in e.local_patches:
+                assert np.array_equal(got[p][0][[0, 1, 2, 4], 1:-1, 1:-1], ref[p][0][[0, 1, 2, 4], 1:-1, 1:-1]), (e.rank, p)
+                assert np.array_equal(got[p][1][3, 1:-1, 1:-1], ref[p][1][3, 1:-1, 1:-1]), (e.rank, p)
+    finally:
+        for e in [ref_e, pull] + ranks:
+            e.close()
+
