@@ -28,7 +28,15 @@
 // its implicit step bit for bit only with the update fused (tests/golden/lapack_spread.json,
 // test_percall_chain).  So the fused form IS the reference's arithmetic; everything else in this file stays unfused
 // (-ffp-contract=off), as the reference's own C++ is compiled without FMA contraction.
+// The band LU's updates a - l * u: fused multiply-adds, as OpenBLAS's and MKL's kernels evaluate them on x86-64-v3 hosts
+// (DESIGN.md section 2).  A reference linked to a BLAS WITHOUT fused multiply-adds (a plain netlib build, MKL on some AMD
+// hosts) is reproduced by the library's second build flavour, `make nofma` -> libtempest_mi355x_nofma.so (-DTMX_LU_NOFMA,
+// selected by TMX_LU_FMA=0 in engine.py / by linking it): multiply and subtract, rounded separately (-ffp-contract=off).
+#ifdef TMX_LU_NOFMA
+#define LU_UPD(a, l, u) ((a) - (l) * (u))
+#else
 #define LU_UPD(a, l, u) __builtin_fma(-(l), (u), (a))
+#endif
 #ifndef TMX_STORE_PRED
 #define TMX_STORE_PRED true
 #endif
@@ -4220,7 +4228,6 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
-		else if (pairs == 3) { if (p.closed) LAUNCH_PAIR(true, 3); else LAUNCH_PAIR(false, 3); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR
 		if (split) {

@@ -67,6 +67,10 @@ def load_library():
     if _lib is not None:
         return _lib
     path = os.environ.get("TMX_LIBRARY") or LIB_PATH      # TMX_LIBRARY: an experimental build of the same library (tools/ablate.sh)
+    if os.environ.get("TMX_LU_FMA") == "0" and not os.environ.get("TMX_LIBRARY"):
+        # the flavour whose band-LU updates are multiply + subtract (`make -C tempestmodel_amd/csrc nofma`): for a reference
+        # linked to a BLAS without fused multiply-adds
+        path = LIB_PATH.replace(".so", "_nofma.so")
     if not os.path.exists(path):
         raise ImportError("libtempest_mi355x.so is missing at %s -- build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "

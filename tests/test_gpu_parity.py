@@ -1,5 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
 against the C oracle on identical inputs and against the golden vectors of the real reference."""
+import os
 import numpy as np
 import pytest
 import golden_util as gu
@@ -814,10 +815,9 @@ def test_fused_column_kernels_are_bit_identical_to_split_kernels():
                 {"TMX_VI_MODE": "split"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0", "TMX_VI_SPARSE": "0"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_CPW": "37"},
-                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "3", "TMX_VI_CPW": "50"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1", "TMX_VI_BACK_SUB": "2", "TMX_VI_CPW": "60"},
-                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1", "TMX_VI_BACK_SUB": "4", "TMX_VI_PAIR_WG": "3"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_SPLIT_BACK": "1", "TMX_VI_BACK_SUB": "4", "TMX_VI_PAIR_WG": "1"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_STAGGER_NS": "5000"}):
         os.environ.update(env)
         try:
@@ -1682,4 +1682,47 @@ def test_dss_pulled_into_the_second_hyperviscosity_pass_is_bit_identical(monkeyp
     finally:
         for e in [ref_e, pull] + ranks:
             e.close()
+
+
+def test_band_lu_without_fused_multiply_add_flavour():
+    """A reference linked to a BLAS without fused multiply-adds (plain netlib, MKL on some AMD hosts) evaluates the band LU's
+    updates as multiply + subtract; the oracle restates that with orc_set_lu_fma(0) and the product with its second library
+    flavour (libtempest_mi355x_nofma.so, TMX_LU_FMA=0).  The column solve of that flavour equals the oracle's in that mode
+    bit for bit -- and differs from the default flavour, so the switch is not a no-op.  Runs in a child process (the
+    library is chosen when it is first loaded)."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tempestmodel_amd", "libtempest_mi355x_nofma.so")):
+        pytest.fail("libtempest_mi355x_nofma.so is missing: build() makes it (make -C tempestmodel_amd/csrc nofma)")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        import golden_util as gu
+        from oracle_lib import Oracle, lib
+        from tempestmodel_amd.engine import Engine
+        d = gu.load("steps_ne4_L6_p24.npz")
+        g, _ = gu.make_grid(4, 6, 24)
+        start = gu.expand_compact(d, "step2", g)
+        res = {}
+        for fma in (1, 0):
+            lib().orc_set_lu_fma(fma)
+            o = Oracle(g); o.set_state(1, start); o.set_state(2, start)
+            assert o.v_step_implicit(1, 2, 87.0) == 0
+            res[fma] = o.get_state(2)
+        lib().orc_set_lu_fma(1)
+        e = Engine(g)
+        e.upload_state(1, start); e.copy_data(1, 2); e.v_step_implicit(1, 2, 87.0); e.sync()
+        got = e.download_state(2)
+        e.close()
+        print("RESULT", max(gu.prognostic_errors(got, res[0])), max(gu.prognostic_errors(got, res[1])))
+    """ % (root, root))
+    env = dict(os.environ, TMX_LU_FMA="0")
+    env.pop("TMX_LIBRARY", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    err_nofma, err_fma = (float(v) for v in line[0].split()[1:])
+    print("multiply + subtract flavour vs oracle without / with fused multiply-adds:", err_nofma, err_fma)
+    assert err_nofma == 0.0 and err_fma > 0.0
 
