@@ -1,5 +1,6 @@
 """Helpers shared by the parity tests: fixture loading and grid construction."""
 import os
+import sys
 import numpy as np
 from tempestmodel_amd.cubed_sphere import (CubedSphereGrid, BaroclinicWaveJW, BaroclinicWaveJWSmallPlanet, ScharMountainSphere,
                                            FlatPlanetCase)
@@ -173,3 +174,33 @@ def interp_case(d):
 
 def interp_rel(x, y):
     return max(float(np.max(np.abs(x[c] - y[c])) / max(np.max(np.abs(y[c])), 1e-300)) for c in range(x.shape[0]))
+
+
+_EXACT_TOL = None
+
+
+def exact_tolerance():
+    """Tolerance of the comparisons that are bit for bit on this project's hosts: 0.0 where the host's libm is the one
+    tempestmodel_amd/csrc/tmx_refmath.h restates (glibc >= 2.28, x86-64 FMA variant: the build container and the GPU boxes),
+    checked by compiling tests/native/refmath_check.c and running it on 4e5 arguments; on any other host (no FMA units,
+    another libm, another architecture) the device, the C oracle and the golden vectors still agree to rounding error, and
+    the north-star tolerance 1e-10 is what the assertions then use."""
+    global _EXACT_TOL
+    if _EXACT_TOL is None:
+        import subprocess, tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        ok = False
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                exe = os.path.join(td, "refmath_check")
+                subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "tempestmodel_amd", "csrc"), "-o", exe,
+                                os.path.join(root, "tests", "native", "refmath_check.c"), "-lm"], check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                ok = subprocess.run([exe, "400000"], stdout=subprocess.DEVNULL).returncode == 0
+        except Exception:
+            ok = False
+        _EXACT_TOL = 0.0 if ok else 1e-10
+        if not ok:
+            sys.stderr.write("golden_util: this host's libm is not the one tmx_refmath.h restates: exact comparisons use 1e-10\n")
+    return _EXACT_TOL
+

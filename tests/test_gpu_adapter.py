@@ -6,12 +6,16 @@ The binary is built in the build container (`make -C oracle ref`) and travels wi
 the test is skipped where it is absent."""
 import os
 import subprocess
+import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "tmx_adapter_run")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_util as gu      # noqa: E402
+TOL = "1e-300" if gu.exact_tolerance() == 0.0 else "1e-10"      # identical doubles where the host's libm is the one tmx_refmath.h restates
 
 
 @pytest.mark.parametrize("mode,args", [
@@ -77,7 +81,7 @@ def test_reference_driver_with_adapter_plugins(mode, args):
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
     # the plugins see the reference's own grid objects, so the device reproduces the reference BIT FOR BIT: the tolerance
     # only has to let an exact zero through (worst < tol)
-    r = subprocess.run([BIN, "--mode", mode, "--dt", "200", "--warm", "1", "--tol", "1e-300"] + args,     # a later --dt / --warm overrides
+    r = subprocess.run([BIN, "--mode", mode, "--dt", "200", "--warm", "1", "--tol", TOL] + args,     # a later --dt / --warm overrides
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     tail = "\n".join(r.stdout.splitlines()[-6:])
     print(tail)
@@ -101,7 +105,7 @@ def test_reference_driver_under_mpi_with_peer_to_peer_halo(nranks, args):
     if not os.path.exists(BIN) or mpiexec is None:
         pytest.skip("needs oracle/_ref/tmx_adapter_run and mpiexec")
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", TMX_HALO="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([mpiexec, "-np", str(nranks), BIN, "--mode", "production", "--dt", "200", "--warm", "1", "--tol", "1e-300"] + args,
+    r = subprocess.run([mpiexec, "-np", str(nranks), BIN, "--mode", "production", "--dt", "200", "--warm", "1", "--tol", TOL] + args,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     tail = "\n".join(r.stdout.splitlines()[-24:])
     print(tail)
