@@ -516,14 +516,17 @@ __device__ __forceinline__ double xidot_edge(const KParams & p, const double * _
 
 // UDV: the vertical uniform diffusion of U,V of the fully explicit mode (k_v_uniform_diffusion_uv below, :1059-1105) is added
 // to the same value before it is stored -- the sum the two kernels form through memory, in the same order
+#ifndef KT_VE
+#define KT_VE 4       // levels per workgroup (vertical stencils: see KT_VC)
+#endif
 template <bool UDV>
-__global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __restrict__ xin,
+__global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const double * __restrict__ xin,
 	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = TILE_X(p) * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int k = blockIdx.y * KT_VE + WAVE_UNIFORM(threadIdx.y);
 	if (k >= L || col >= p.ncol) return;
 	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
 	const double w_lo = dt * fabs(xidot_edge(p, xin, k, col));       // weight of interface k
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void k_v_explicit(KParams p, const double * __
 }
 
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
-	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
+	dim3 blk(64, KT_VE), grd(NTILES(e, p), (p.L + KT_VE - 1) / KT_VE);
 	if (with_udiff_uv)
 		hipLaunchKernelGGL(k_v_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
 			e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
@@ -2155,8 +2158,8 @@ struct DssPull {
 	const double * xmat, * ghost;
 	const int * gbase, * gstride;
 };
-template <int NF>
-__device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull & d, const double * __restrict__ x, int col, const int (&slab)[NF], bool uv, double (&out)[NF]) {
+template <int NF, bool uv>
+__device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull & d, const double * __restrict__ x, int col, const int (&slab)[NF], double (&out)[NF]) {
 	// out[f] = this node's DSS average of field slab[f]; with uv the last two fields are (U, V) (rotated between panels)
 	const size_t NS = (size_t)p.NS;
 	const int4 cp = d.colpart[col];
@@ -2208,7 +2211,7 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 	const int nscal = uv ? NF - 2 : NF;
 #pragma unroll
 	for (int f = 0; f < NF; f++) if (f < nscal) out[f] = comb(v[f][0], v[f][1], v[f][2], v[f][3]);
-	if (uv) {
+	if constexpr (uv) {
 		double a[4], b[4];
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
@@ -2220,6 +2223,7 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 		}
 		out[NF - 2] = comb(a[0], a[1], a[2], a[3]); out[NF - 1] = comb(b[0], b[1], b[2], b[3]);
 	}
+	(void)xi;
 }
 
 template <bool PULL>
@@ -2256,12 +2260,12 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 		if (actn) {
 			const int sl[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
 			double o[5];
-			dss_pull_fields<5>(p, pull, xsrc, col, sl, true, o);
+			dss_pull_fields<5, true>(p, pull, xsrc, col, sl, o);
 			psiW = o[0]; psiT = o[1]; psiR = o[2]; ua = o[3]; ub = o[4];
 		} else {
 			const int sl[1] = { TMX_SLAB_W(L, kk) };
 			double o[1];
-			dss_pull_fields<1>(p, pull, xsrc, col, sl, false, o);
+			dss_pull_fields<1, false>(p, pull, xsrc, col, sl, o);
 			psiW = o[0];
 		}
 	}
@@ -4259,13 +4263,21 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 // UD (fully explicit mode with uniform diffusion): F additionally holds the vertical diffusion of rho*theta and W
 // relative to the reference column xref (cs = K_s / ztop^2, cw = K_v / ztop^2).
 template <bool UD>
-__global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const double * __restrict__ xin,
+// KT_VC levels per workgroup.  A thread reads the levels k-2 .. k+2 of its column, so the level tiles of a column overlap by
+// four levels and every value is fetched 2.7 times over at the L2's memory side (PMC, ne30 L40: 514 MB of reads per launch for
+// 190 MB of operands: the level-neighbour tiles are 1 350 workgroups apart in dispatch order, on another XCD's L2).  Taller
+// tiles make the neighbours wavefronts of one workgroup, and lose: config 4's step takes 5.12 / 5.21 / 5.34 ms with 4 / 8 / 16
+// levels per workgroup (1 024-thread workgroups leave one per CU).  4 stays.
+#ifndef KT_VC
+#define KT_VC 4
+#endif
+__global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, const double * __restrict__ xin,
 	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cs, double cw)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = TILE_X(p) * 64 + threadIdx.x;
-	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int k = blockIdx.y * KT_VC + WAVE_UNIFORM(threadIdx.y);
 	if (col >= p.ncol || k > L) return;
 	ColConst cc;
 	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
@@ -4313,7 +4325,7 @@ __global__ __launch_bounds__(256) void k_vi_terms_explicit(KParams p, const doub
 }
 
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
-	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 1 + 3) / 4);
+	dim3 blk(64, KT_VC), grd(NTILES(e, p), (p.L + 1 + KT_VC - 1) / KT_VC);
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;
 		hipLaunchKernelGGL(k_vi_terms_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,

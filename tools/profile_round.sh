@@ -3,7 +3,7 @@
 # shapes bench.py reports traffic for.  Never combines --pmc with a trace domain other than the kernel trace.
 # usage: tools/profile_round.sh <tag> [quick]        outputs under gpurun_out/<tag>_*
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -31,4 +31,18 @@ S8="$R/tools/rank_share_timing.py 8"
 one fetch_n8 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_n8 -o ${TAG} -- python3 $S8
 one write_n8 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_n8 -o ${TAG} -- python3 $S8
 one trace_n8 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_n8 -o ${TAG} -- python3 $S8
-find $OUT -name "*.csv" | head -60
+# BASELINE config 4's shape (ne30 L40, 3 tracers, uniform diffusion, explicit vertical mode, Kessler) and config 5's (ne120 L60, Held-Suarez)
+C4="$R/tools/config4_timing.py"
+one fetch_c4 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_c4 -o ${TAG} -- python3 $C4
+one write_c4 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_c4 -o ${TAG} -- python3 $C4
+one trace_c4 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_c4 -o ${TAG} -- python3 $C4
+B5="$R/bench.py --ne 120 --levels 60 --dt 37.5 --physics hs --steps 3 --warmup 1 --develop 2 --no-cpu-baseline"
+one fetch_c5 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_c5 -o ${TAG} -- python3 $B5
+one write_c5 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_c5 -o ${TAG} -- python3 $B5
+one trace_c5 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_c5 -o ${TAG} -- python3 $B5
+# the DSS pulled into the second hyperviscosity pass (archived experiment): bytes of k_hypervis / k_dss with and without
+export TMX_HVIS_PULL=1
+one fetch_pull --pmc FETCH_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/${TAG}_fetch_pull -o ${TAG} -- python3 $B
+one write_pull --pmc WRITE_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/${TAG}_write_pull -o ${TAG} -- python3 $B
+unset TMX_HVIS_PULL
+find $OUT -name "*.csv" | head -80

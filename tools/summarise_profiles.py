@@ -9,7 +9,7 @@ import collections, csv, json, os, shutil, subprocess, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(R, "gpurun_out"); P = os.path.join(R, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def counters(name):
@@ -29,7 +29,7 @@ def stats(name):
 
 
 for src, dst in (("trace", "kernel_stats"), ("trace_mfma1", "kernel_stats_mfma1"), ("trace_ne15", "kernel_stats_ne15"),
-                 ("trace_n8", "kernel_stats_rank0_of_8")):
+                 ("trace_n8", "kernel_stats_rank0_of_8"), ("trace_c4", "kernel_stats_config4_ne30_L40"), ("trace_c5", "kernel_stats_config5_ne120_L60")):
     f = os.path.join(G, "%s_%s" % (tag, src), "%s_kernel_stats.csv" % tag)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.csv" % (tag, dst)))
@@ -37,7 +37,12 @@ for src, dst in (("trace", "kernel_stats"), ("trace_mfma1", "kernel_stats_mfma1"
 for fe, wr, out, what, steps in (("fetch", "write", "ne30_L30_n1", "ne30 np4 L30, 1 GPU", 15),
                                  ("fetch_ne15", "write_ne15", "ne15_L30_n1", "ne15 np4 L30 (--ne 15 --ppd 1), 1 GPU", 15),
                                  ("fetch_n8", "write_n8", "ne30_L30_n8", "ne30 np4 L30, share of rank 0 of 8 (tools/rank_share_timing.py 8: "
-                                  "lone rank-0 engine of the 8-rank layout, wire left out)", 33)):
+                                  "lone rank-0 engine of the 8-rank layout, wire left out)", 33),
+                                 ("fetch_c4", "write_c4", "ne30_L40_n1", "BASELINE config 4's shape: tools/config4_timing.py, supercell set-up ne30 np4 L40, "
+                                  "3 tracers, uniform diffusion, explicit vertical mode, Kessler after every step, 1 GPU", 35),
+                                 ("fetch_c5", "write_c5", "ne120_L60_n1", "BASELINE config 5: bench.py --ne 120 --levels 60 --dt 37.5 --physics hs "
+                                  "--steps 3 --warmup 1 --develop 2, 1 GPU", 9),
+                                 ("fetch_pull", "write_pull", "ne30_L30_n1_hvis_pull", "ne30 np4 L30, 1 GPU, TMX_HVIS_PULL=1 (k_hypervis / k_dss only)", 15)):
     a = os.path.join(G, "%s_%s" % (tag, fe), "%s_counter_collection.csv" % tag)
     b = os.path.join(G, "%s_%s" % (tag, wr), "%s_counter_collection.csv" % tag)
     if os.path.exists(a) and os.path.exists(b):
