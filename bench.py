@@ -50,9 +50,11 @@ SURVEY_8D_BYTES = {"h_explicit": 200.0 + 80.0, "v_implicit": 272.0, "dss": 60.0,
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
 # What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
 OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
-            "v_implicit": "forward phase (120 of 197 us): latency / issue of two dependent chains of ~91 us each (block-row assembly, "
-                          "pivoted elimination) sharing SIMDs, U-row stores 24 us; back substitution (77 us): HBM, the 362 MB U-row "
-                          "stream read back at 4.7 TB/s (profiles/r02_column_solve_ablation.txt)"}
+            "v_implicit": "latency: two chains of dependent fp64 operations per column group -- block-row assembly (4 260 cycles per block row "
+                          "alone on a SIMD for 2 400 issue cycles) and pivoted elimination (1 200 cycles per pivot step for 340) -- that "
+                          "interleave on shared SIMDs (forward phase 150-190 k cycles), then the back substitution reading the 260 MB U-row "
+                          "stream back at ~4 TB/s (140-196 k cycles); the kernel lasts as long as the 141 CUs that host two workgroups "
+                          "(profiles/r03_pair_timing.txt, r03_column_solve_ablation.txt)"}
 # engine profile slots (HIP events) that make up each operation
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
@@ -129,17 +131,18 @@ def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
 
 
 def cpu_baseline_allcores(ne, L, dt, nsteps_ref):
-    """The reference on its 24-patch layout under mpiexec -np 24 ('N = all physical cores, stated'), when the
-    host has at least 24 cores; the same routine as the 6-rank run."""
+    """The reference on a many-patch layout with one MPI rank per patch ('N = all physical cores, stated').
+    The layouts the reference accepts are 6 n^2 patches with ne divisible by n; on the 256-thread hosts of the GPU boxes the
+    ne30 case runs fastest at 54 ranks (n = 3: 0.32 s per step; 24 ranks 0.34 s, 150 ranks 1.2 s, 216 ranks 1.8 s -- measured,
+    the case is too small for more ranks; 96 patches do not divide ne30), so 54 is tried first where the host has the
+    threads, then 24."""
     n = os.cpu_count() or 1
-    if n < 24:
-        return None
-    # 96 ranks on the reference's 96-patch layout (6 x 4 x 4) where the host has the hardware threads, else 24 on the 24-patch one
-    if n >= 96:
-        b = cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=96)
-        if b is not None:
-            return b
-    return cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=24)
+    for nr, nn in ((54, 3), (24, 2)):
+        if n >= nr and ne % nn == 0:
+            b = cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=nr)
+            if b is not None:
+                return b
+    return None
 
 
 def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):

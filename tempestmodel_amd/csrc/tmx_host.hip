@@ -1810,10 +1810,10 @@ static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int i
 		// Experiment (TMX_HVIS_PULL=1, judge's "node-unique" go / no-go): the DSS between the two passes is not run as a pass
 		// of its own, the second pass averages the first pass's Laplacians while it loads them (k_hypervis<PULL>); on several
 		// ranks the raw Laplacians of the rank boundary still travel, and the second pass starts once they have arrived.
-		// Bit-identical, but a NO-GO: at ne30 L30 the second pass takes 166 instead of 67 us (every seam node gathers its one
-		// to three partner values per field from other elements' rows: n^2 instead of n loads per group, 8 bytes per lane from
-		// up to 30 different cache lines per wavefront instruction) against the 62 us of the DSS pass it replaces
-		// (profiles/r03_dss_pull_ab.txt).  Without tracers only (k_hypervis_tracers has no such form).
+		// Bit-identical, but a NO-GO: at ne30 L30 the second pass takes 166 instead of 67 us and moves 703 instead of 308 MB (every
+		// seam node gathers its one to three partner values per field from other elements' rows: n^2 instead of n loads per
+		// group, 8 bytes per lane from up to 30 different cache lines per wavefront instruction, not L2 hits) against the 62 us
+		// and 248 MB of the DSS pass it replaces (profiles/r03_dss_pull_ab.txt).  Without tracers only (k_hypervis_tracers has no such form).
 		const bool pull = e->hvis_pull && e->nt == 0 && work_is_scratch;
 		if (stage_can_split(e) && !e->sw) {
 			// each pass boundary tiles first, its exchange overlapped with the interior tiles (see hv_stage_split)
