@@ -157,6 +157,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
 	if (const char * m = getenv("TMX_HVIS_PULL")) e->hvis_pull = atoi(m);
+	if (const char * m = getenv("TMX_HVIS_BLOCK")) e->hvis_block = atoi(m);
 	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
 	if (const char * m = getenv("TMX_VI_BACK_SUB")) e->vi_back_sub = atoi(m);
 	if (const char * m = getenv("TMX_VI_STAGGER_NS")) e->vi_stagger = atoi(m) / 10;
@@ -198,7 +199,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
 		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
-		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_colref); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
+		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_colref); free_dev(e->d_hvblocks); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
 		if (e->d_ghost_own) e->d_ghost = e->d_ghost_own;          // p2p mode pointed d_ghost into the shared block
 		for (void * q : e->p2p_peer) if (q) hipIpcCloseMemHandle(q);
 		free_dev(e->p2p_block); free_dev(e->d_p2p_dst); free_dev(e->d_p2p_flag); free_dev(e->d_send_peer); free_dev(e->d_send_within); free_dev(e->d_p2p_peers);
@@ -648,17 +649,27 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 			}
 			key[g] = { best, (int)g };
 		}
-		// groups with a member on another rank go last: the DSS of the others does not wait for the exchange
-		std::vector<char> remote(groups.size(), 0);
-		for (size_t g = 0; g < groups.size(); g++)
-			for (int id : groups[g].ids) if (e->patches[node_of(id).patch].owner != me) remote[g] = 1;
+		// groups with a member on another rank go last: the DSS of the others does not wait for the exchange; groups whose
+		// copies all lie in ONE patch go first: the fused hyperviscosity kernel averages those itself (k_hypervis_block)
+		std::vector<char> remote(groups.size(), 0);      // 0: one patch, 1: several patches of this rank, 2: a member on another rank
+		for (size_t g = 0; g < groups.size(); g++) {
+			const int p0 = node_of(groups[g].ids[0]).patch;
+			for (int id : groups[g].ids) {
+				if (e->patches[node_of(id).patch].owner != me) remote[g] = 2;
+				else if (node_of(id).patch != p0 && remote[g] < 1) remote[g] = 1;
+			}
+		}
 		std::sort(key.begin(), key.end(), [&](const std::pair<int, int> & a, const std::pair<int, int> & b) {
 			if (remote[a.second] != remote[b.second]) return remote[a.second] < remote[b.second];
 			return a < b;
 		});
 		std::vector<Grp> sorted(groups.size());
-		e->ngroups_local = 0;
-		for (size_t g = 0; g < groups.size(); g++) { sorted[g] = groups[key[g].second]; if (!remote[key[g].second]) e->ngroups_local++; }
+		e->ngroups_local = 0; e->ngroups_inpatch = 0;
+		for (size_t g = 0; g < groups.size(); g++) {
+			sorted[g] = groups[key[g].second];
+			if (remote[key[g].second] < 2) e->ngroups_local++;
+			if (remote[key[g].second] == 0) e->ngroups_inpatch++;
+		}
 		groups.swap(sorted);
 	}
 	e->send_rank_off.assign(NR + 1, 0); e->recv_rank_off.assign(NR + 1, 0);
@@ -871,6 +882,17 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 				colref[(size_t)c * 4 + 3] = plan.grp_n[g] | (m << 3) | (((plan.grp_type[g] >> (2 * m)) & 3) << 6) | ((plan.grp_x[g] + 1) << 8);
 			}
 		if ((r = dev_upload(&e->d_colref, colref, &bytes))) return r;
+	}
+	{
+		// element blocks of the fused hyperviscosity kernel: 5 x 5 inner elements (kernels: TMX_HB_E) per block, patch by patch
+		std::vector<int> blocks;
+		for (int pp : e->local_patches) {
+			const PatchInfo & P = e->patches[pp];
+			for (int a0 = 0; a0 < P.nea; a0 += 5) for (int b0 = 0; b0 < P.neb; b0 += 5)
+				blocks.insert(blocks.end(), { P.elem_base, P.nea, P.neb, a0, b0 });
+		}
+		e->n_hvblocks = (int)(blocks.size() / 5);
+		if (e->n_hvblocks && (r = dev_upload(&e->d_hvblocks, blocks, &bytes))) return r;
 	}
 	if ((r = dev_upload(&e->d_grp_n, plan.grp_n, &bytes))) return r;
 	if ((r = dev_upload(&e->d_grp_x, plan.grp_x, &bytes))) return r;
@@ -1480,6 +1502,7 @@ static bool stage_can_split(const tmx_engine * e) {
 }
 static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overlapped);
 static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped);
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped, int g_first);
 
 static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
 	const double * src[12]; double cf[12]; int premul = 0, n = 0;
@@ -1766,18 +1789,20 @@ extern "C" int tmx_apply_dss(tmx_engine * e, int ix) {
 	return dss_after_exchange(e, p, ix, overlapped);
 }
 
-static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped) {
+// g_first: first group to average (0: all; ngroups_inpatch: the producing kernel has averaged the in-patch groups itself)
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped, int g_first) {
 	ProfScope ps(e, TMX_K_DSS);
 	if (e->cfg.n_ranks > 1 && e->ngroups_local < e->ngroups) {
 		// groups whose members all live on this rank first (they overlap the wire), then the ones with remote members
-		tmxk_dss(e, p, inst(e, ix), 0, e->ngroups_local);
+		tmxk_dss(e, p, inst(e, ix), g_first, e->ngroups_local);
 		if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
 		tmxk_dss(e, p, inst(e, ix), e->ngroups_local, e->ngroups);
 	} else {
-		tmxk_dss(e, p, inst(e, ix), 0, e->ngroups);
+		tmxk_dss(e, p, inst(e, ix), g_first, e->ngroups);
 	}
 	return launch_check("apply_dss");
 }
+static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped) { return dss_after_exchange(e, p, ix, overlapped, 0); }
 
 // work_is_scratch: the caller never looks at the working instance afterwards (the steppers' own programs); the ABI call
 // leaves it as the reference does (the first pass's Laplacians, DSS'ed).
@@ -1840,6 +1865,20 @@ static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int i
 				if (pass == 0 && pull) {
 					if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));      // the neighbours' Laplacians are in the ghost buffer
 				} else if ((r = dss_after_exchange(e, p, idst, overlapped))) return r;
+			}
+		} else if (e->hvis_block && e->nt == 0 && !e->sw && e->n_hvblocks > 0) {
+			// both passes fused with the DSS of the seams inside a patch (k_hypervis_block); k_dss only for the groups that span patches
+			for (int pass = 0; pass < 2; pass++) {
+				const int idst = pass ? iupd : iwork;
+				{
+					ProfScope ps(e, TMX_K_HYPERVIS);
+					if (pass == 0) tmxk_hypervis_block(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
+					else tmxk_hypervis_block(e, p, inst(e, iwork), inst(e, iinit), inst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale);
+				}
+				if ((r = launch_check("hypervis pass (fused with the in-patch DSS)"))) return r;
+				bool overlapped = false;
+				if ((r = exchange(e, p, inst(e, idst), &overlapped))) return r;
+				if ((r = dss_after_exchange(e, p, idst, overlapped, e->ngroups_inpatch))) return r;
 			}
 		} else {
 			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);

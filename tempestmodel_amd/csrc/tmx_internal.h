@@ -113,6 +113,9 @@ struct tmx_engine {
 	// DSS
 	int ngroups = 0, nxgroups = 0, nghost = 0;
 	int ngroups_local = 0;                   // groups [0, ngroups_local) have no member on another rank
+	int * d_hvblocks = nullptr; int n_hvblocks = 0;   // element blocks of k_hypervis_block ({elem_base, nea, neb, a0, b0} each)
+	int ngroups_inpatch = 0;                 // DSS groups [0, ngroups_inpatch) have all their copies in ONE patch (k_hypervis_block averages those itself)
+	int hvis_block = 0;                      // TMX_HVIS_BLOCK=1: hyperviscosity passes fused with the in-patch DSS (k_hypervis_block; bit-identical, measured slower)
 	int * d_colref = nullptr;                // [NS][4] the other copies of a stored column + packed group info (k_hypervis<PULL>: the DSS pulled into a kernel's loads)
 	int hvis_pull = 0;                       // TMX_HVIS_PULL=1: the second hyperviscosity pass averages the first pass's Laplacians while loading them
 	                                         // instead of a DSS pass in between (bit-identical; measured SLOWER: +99 us for the pass against 62 us saved)
@@ -209,6 +212,8 @@ void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
+void tmxk_hypervis_block(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v, int scale_locally);
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale_locally);
 int  tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt);
 void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x);

@@ -2349,6 +2349,179 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hyperviscosity pass FUSED with the DSS of the seams inside a patch (round 3 prototype of "remove DSS passes": DESIGN.md
+// section 7).  A workgroup owns a block of up to EB x EB elements of one patch plus the ring of elements around it (where the
+// ring lies inside the patch), evaluates k_hypervis's arithmetic -- statement for statement -- for all of them with the
+// per-element contractions in LDS, leaves the five results of every node in LDS, and then averages every seam node of its
+// inner elements that is NOT on the patch's boundary from the copies in LDS, in the reference's order (alpha seams before
+// beta seams: 0.5 (x + x'), 0.5 (0.5 (x + x_alpha) + 0.5 (x_beta + x_diag)); inside a patch every copy receives the same
+// bits).  Only the inner elements are written, averaged; nodes on the patch boundary are written raw, and k_dss runs on the
+// groups that span patches only (tmx_engine::ngroups_inpatch: 91 % of the groups at ne30 on 24 patches never reach it).
+// The ring elements are evaluated redundantly by the neighbouring blocks (same operands, same statements: same bits).
+#define TMX_HB_E 5                              // inner elements per block side
+#define TMX_HB_W (TMX_HB_E + 2)                 // with the ring
+#define TMX_HB_N (TMX_HB_W * TMX_HB_W * 16)     // nodes a workgroup holds
+#define TMX_HB_T ((TMX_HB_N + 63) / 64 * 64)    // threads
+#define TMX_HB_KT 4                             // levels per workgroup (geometry stays in registers)
+struct HvBlock { int elem_base, nea, neb, a0, b0; };
+__global__ __launch_bounds__(TMX_HB_T) void k_hypervis_block(KParams p, const HvBlock * __restrict__ blocks, const double * __restrict__ xsrc,
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale)
+{
+	__shared__ double s[8][TMX_HB_N];
+	__shared__ double sD[16], sS[16];
+	const int t = threadIdx.x;
+	if (t < 16) { sD[t] = p.dx[t]; sS[t] = p.stiff[t]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const HvBlock B = blocks[blockIdx.x];
+	const int er = t >> 4, q = t & 15, i = q >> 2, j = q & 3;
+	const int ea = er / TMX_HB_W, eb_ = er - ea * TMX_HB_W;                   // position in the ringed block
+	const int a = B.a0 - 1 + ea, b = B.b0 - 1 + eb_;                          // element of the patch
+	const int na_in = min(TMX_HB_E, B.nea - B.a0), nb_in = min(TMX_HB_E, B.neb - B.b0);
+	const bool held = t < TMX_HB_N && ea <= na_in + 1 && eb_ <= nb_in + 1 && a >= 0 && a < B.nea && b >= 0 && b < B.neb;
+	const bool inner = held && ea >= 1 && ea <= na_in && eb_ >= 1 && eb_ <= nb_in;
+	const int col = held ? (B.elem_base + a * B.neb + b) * 16 + q : 0;
+	const int eb16 = er * 16;
+
+	// seam partners of an inner node, as indices into the workgroup's node arrays (-1: none; -2: the node lies on the
+	// patch boundary, its copies belong to another patch: left to k_dss)
+	int ta = -1, tb = -1, td = -1;
+	if (inner) {
+		const int ia = (i == 0) ? -1 : ((i == 3) ? 1 : 0), jb = (j == 0) ? -1 : ((j == 3) ? 1 : 0);
+		const bool oa = ia != 0 && (a + ia < 0 || a + ia >= B.nea), ob = jb != 0 && (b + jb < 0 || b + jb >= B.neb);
+		if (oa || ob) { ta = -2; }
+		else {
+			if (ia != 0) ta = ((ea + ia) * TMX_HB_W + eb_) * 16 + (3 - i) * 4 + j;
+			if (jb != 0) tb = (ea * TMX_HB_W + eb_ + jb) * 16 + i * 4 + (3 - j);
+			if (ia != 0 && jb != 0) td = ((ea + ia) * TMX_HB_W + eb_ + jb) * 16 + (3 - i) * 4 + (3 - j);
+		}
+	}
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1, ida = 0, idb = 0, nsc = 1.0;
+	if (held) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		ida = p.g2d[G2_IDA * NS + col]; idb = p.g2d[G2_IDB * NS + col];
+		nsc = scale ? p.g2d[G2_NUS * NS + col] : 1.0;
+	}
+	const double nu_s = nu_s_in * nsc, nu_d = nu_d_in * nsc, nu_v = nu_v_in * nsc;
+	__syncthreads();
+	for (int kq = 0; kq < TMX_HB_KT; kq++) {
+		const int kk = blockIdx.y * TMX_HB_KT + kq;
+		if (kk > L) break;                              // uniform
+		const bool actw = held, actn = held && kk < L;
+		double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
+		if (actw) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		if (actn) {
+			psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+			psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
+			ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
+			ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+		}
+		const double cua = c2a0 * ua + c2a1 * ub;
+		const double cub = c2a1 * ua + c2b1 * ub;
+		if (t < TMX_HB_N) {
+			s[0][t] = psiT; s[1][t] = psiR; s[2][t] = psiW;
+			s[3][t] = ua;   s[4][t] = ub;
+			s[5][t] = j2d * cua; s[6][t] = j2d * cub;
+		}
+		__syncthreads();
+		double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+		if (held) {
+#pragma unroll
+			for (int tt = 0; tt < 4; tt++) {
+				const int la = eb16 + 4 * tt + j, lb = eb16 + 4 * i + tt;
+				const double Da = sD[tt * 4 + i], Db = sD[tt * 4 + j];
+				daT += s[0][la] * Da; dbT += s[0][lb] * Db;
+				daR += s[1][la] * Da; dbR += s[1][lb] * Db;
+				daW += s[2][la] * Da; dbW += s[2][lb] * Db;
+				daub += s[4][la] * Da; dbua += s[3][lb] * Db;
+				dajua += s[5][la] * Da; dbjub += s[6][lb] * Db;
+			}
+		}
+		daT *= ida; dbT *= idb; daR *= ida; dbR *= idb; daW *= ida; dbW *= idb;
+		daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+		const double invJ2 = 1.0 / j2d;
+		const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+		__syncthreads();
+		if (t < TMX_HB_N) {
+			s[0][t] = jn * (c2a0 * daT + c2a1 * dbT); s[1][t] = jn * (c2a1 * daT + c2b1 * dbT);
+			s[2][t] = jn * (c2a0 * daR + c2a1 * dbR); s[3][t] = jn * (c2a1 * daR + c2b1 * dbR);
+			s[4][t] = je * (c2a0 * daW + c2a1 * dbW); s[5][t] = je * (c2a1 * daW + c2b1 * dbW);
+			s[6][t] = dv; s[7][t] = cl;
+		}
+		__syncthreads();
+		double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
+		if (held) {
+#pragma unroll
+			for (int tt = 0; tt < 4; tt++) {
+				const int la = eb16 + 4 * tt + j, lb = eb16 + 4 * i + tt;
+				const double Sa = sS[i * 4 + tt], Sb = sS[j * 4 + tt];
+				uaT += s[0][la] * Sa; ubT += s[1][lb] * Sb;
+				uaR += s[2][la] * Sa; ubR += s[3][lb] * Sb;
+				uaW += s[4][la] * Sa; ubW += s[5][lb] * Sb;
+				dad -= Sa * s[6][la]; dbd -= Sb * s[6][lb];
+				dac -= Sa * s[7][la]; dbc -= Sb * s[7][lb];
+			}
+		}
+		uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
+		dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
+		// the five results of this node, exactly k_hypervis's statements; the base value is only known for written nodes,
+		// so the copies in LDS hold the results with THEIR OWN base: every copy of a seam node has one (duplicated storage)
+		double rW = 0, rT = 0, rR = 0, rU = 0, rV = 0;
+		if (actw) {
+			const size_t o = TMX_SLAB_W(L, kk) * NS + col;
+			const double bs = xbase ? xbase[o] : 0.0;
+			rW = bs - dt * (1.0 / je) * nu_s * (uaW + ubW);
+		}
+		if (actn) {
+			const double invJ = 1.0 / jn;
+			size_t o = TMX_SLAB_T(L, kk) * NS + col;
+			double bs = xbase ? xbase[o] : 0.0;
+			rT = bs - dt * invJ * nu_s * (uaT + ubT);
+			o = TMX_SLAB_R(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rR = bs - dt * invJ * nu_s * (uaR + ubR);
+			const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
+			const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
+			o = TMX_SLAB_U(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rU = bs - dt * upa;
+			o = TMX_SLAB_V(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rV = bs - dt * upb;
+		}
+		__syncthreads();
+		if (t < TMX_HB_N) { s[0][t] = rW; s[1][t] = rT; s[2][t] = rR; s[3][t] = rU; s[4][t] = rV; }
+		__syncthreads();
+		if (inner) {
+			double o5[5] = { rW, rT, rR, rU, rV };
+			if (ta >= 0 || tb >= 0) {
+#pragma unroll
+				for (int f = 0; f < 5; f++) {
+					const double x = o5[f];
+					if (td >= 0) o5[f] = 0.5 * (0.5 * (x + s[f][ta]) + 0.5 * (s[f][tb] + s[f][td]));
+					else o5[f] = 0.5 * (x + s[f][ta >= 0 ? ta : tb]);
+				}
+			}
+			xout[TMX_SLAB_W(L, kk) * NS + col] = o5[0];
+			if (kk < L) {
+				xout[TMX_SLAB_T(L, kk) * NS + col] = o5[1];
+				xout[TMX_SLAB_R(L, kk) * NS + col] = o5[2];
+				xout[TMX_SLAB_U(L, kk) * NS + col] = o5[3];
+				xout[TMX_SLAB_V(L, kk) * NS + col] = o5[4];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+void tmxk_hypervis_block(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v, int scale) {
+	dim3 blk(TMX_HB_T), grd(e->n_hvblocks, (p.L + 1 + TMX_HB_KT - 1) / TMX_HB_KT);
+	hipLaunchKernelGGL(k_hypervis_block, grd, blk, 0, e->stream, p, (const HvBlock *)e->d_hvblocks, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (src/atm/HorizontalDynamicsFEM.cpp:1817-1859):
 //   ApplyVectorHyperdiffusion(initial, update, dt, -K_v, -K_v)          U,V -= dt * (-K_v) * vector Laplacian(U,V)
 //   ApplyVectorHyperdiffusion(REFERENCE, update, dt, +K_v, +K_v)        U,V -= dt * (+K_v) * vector Laplacian(U,V)_ref

@@ -1861,3 +1861,29 @@ def test_config5_full_size_properties(monkeypatch):
         for e in ranks:
             e.close()
 
+
+@pytest.mark.parametrize("ne,npatch", [(12, 24), (4, 24), (5, 6), (7, 6)])
+def test_hyperviscosity_fused_with_the_in_patch_dss_is_bit_identical(ne, npatch, monkeypatch):
+    """k_hypervis_block (TMX_HVIS_BLOCK=1: an archived experiment, slower) against k_hypervis + the full k_dss: patches of 6 x 6, 2 x 2, 5 x 5 and
+    7 x 7 elements (blocks of 5 x 5 inner elements: clipped blocks, blocks without a ring, single-element remainders), three
+    ARS343 steps, every patch, bit for bit -- the per-call ABI too (the working instance afterwards holds the DSS'ed Laplacians)."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(ne, 6, npatch)
+    res = []
+    for block in ("1", "0"):
+        monkeypatch.setenv("TMX_HVIS_BLOCK", block)
+        e = Engine(g)
+        try:
+            e.upload_state(0, start)
+            for k in range(3):
+                e.step("ars343", 720.0 / ne, first=(k == 0))
+            e.h_step_after_subcycle(0, 1, 2, 100.0)
+            e.sync()
+            res.append([e.download_state(i) for i in (0, 1, 2)])
+        finally:
+            e.close()
+    for a_inst, b_inst in zip(res[0], res[1]):
+        for (an, ae), (bn, be) in zip(a_inst, b_inst):
+            assert np.array_equal(an[[0, 1, 2, 4], 1:-1, 1:-1], bn[[0, 1, 2, 4], 1:-1, 1:-1])
+            assert np.array_equal(ae[3, 1:-1, 1:-1], be[3, 1:-1, 1:-1])
+
