@@ -147,6 +147,9 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->nslab = 5 * e->L + 1 + e->nt * e->L;
 	e->sw = (cfg->equation_set == TMX_EQN_SHALLOW_WATER);
 	e->fully_explicit = cfg->fully_explicit != 0; e->udiff = cfg->uniform_diffusion != 0;
+	e->imap.resize(cfg->n_instances);
+	for (int k = 0; k < cfg->n_instances; k++) e->imap[k] = k;
+	if (const char * v = getenv("TMX_SHARE_COPIES")) e->share_copies = atoi(v);
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
@@ -971,11 +974,12 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // state transfer
 
+static int settle_instance(tmx_engine * e, int ix);
 static int check_state_args(tmx_engine * e, int patch, int instance) {
 	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
 	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not local", patch);
 	REQUIRE(instance >= 0 && instance < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range", instance);
-	return TMX_OK;
+	return settle_instance(e, instance);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,11 +1313,24 @@ static int check_ready(tmx_engine * e) {
 	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
 	return TMX_OK;
 }
+static int settle_instance(tmx_engine * e, int ix);
 static int check_inst(tmx_engine * e, int ix) {
 	REQUIRE(ix >= 0 && ix < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range [0,%d)", ix, e->cfg.n_instances);
+	return settle_instance(e, ix);
+}
+static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)e->imap[ix] * e->inst_stride; }
+// Entry points other than tmx_step see the instances they name in slots of their own: an instance that reads another one's
+// slot, or whose slot others read (b == ix or imap[b] == ix), gets the CopyData that was left out.  b < 0: all of them.
+static int settle_instance(tmx_engine * e, int ix) {
+	if (!e->n_shared || e->in_program) return TMX_OK;
+	for (int b = 0; b < (int)e->imap.size(); b++) {
+		if (e->imap[b] == b || !(ix < 0 || b == ix || e->imap[b] == ix)) continue;
+		HIPCHK(hipMemcpyAsync(e->d_state + (size_t)b * e->inst_stride, e->d_state + (size_t)e->imap[b] * e->inst_stride,
+			e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		e->imap[b] = b; e->n_shared--;
+	}
 	return TMX_OK;
 }
-static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)ix * e->inst_stride; }
 
 // Surface slots.  HeldSuarezPhysics::Perform forms its "surface pressure" from dataREdge[RIx][i][j][0] *
 // dataREdge[TIx][i][j][0] (HeldSuarezPhysics.cpp:113-116).  With Lorenz staggering rho and rho*theta live on levels and
@@ -1370,6 +1387,7 @@ extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, dst))) return r;
 	REQUIRE(coeff && n_coeff > dst && n_coeff <= e->cfg.n_instances, TMX_ERR_INVALID,
 		"linear_combine_data: %d coefficients for destination %d and %d instances", n_coeff, dst, e->cfg.n_instances);
+	if ((r = settle_instance(e, -1))) return r;
 	const double * src[12]; double cf[12];
 	int n = 1;
 	src[0] = inst(e, dst); cf[0] = coeff[dst];
@@ -1399,11 +1417,15 @@ static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt) {
 // and with uniform diffusion the vertical diffusion of U,V (:1059-1105).
 // uv_done: the vertical diffusion of U,V has been added by tmxk_v_explicit already (TMX_UDV_SEPARATE=1 keeps the separate pass)
 static bool udv_fused(const tmx_engine * e) { return e->udiff && e->fully_explicit && !getenv("TMX_UDV_SEPARATE"); }
-static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt, bool uv_done = false) {
+// TMX_VX_FUSED=1: the U,V update of V.StepExplicit evaluated by the kernel of the explicitly treated implicit terms (one launch
+// less, shared operands).  Off by default: config 4's step measured 4.81 ms with it, 4.75 ms without -- the terms kernel is
+// bound by its dependent arithmetic, the U,V update on its own by bandwidth, and the two overlap better as two launches.
+static bool uvx_fused(const tmx_engine * e) { return udv_fused(e) && getenv("TMX_VX_FUSED"); }
+static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt, bool uv_done = false, bool with_uv = false) {
 	if (!e->fully_explicit) return TMX_OK;
 	int r; if ((r = check_reference_state(e))) return r;
 	const KParams p = make_params(e);
-	tmxk_vi_terms_explicit(e, p, inst(e, iinit), inst(e, iupd), dt);
+	tmxk_vi_terms_explicit(e, p, inst(e, iinit), inst(e, iupd), dt, with_uv);
 	if (e->nt > 0)
 		REQUIRE(tmxk_vi_tracers_explicit(e, p, inst(e, iinit), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
 			"tracer column update: %d levels do not fit the LDS working set", e->L);
@@ -1463,11 +1485,12 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
 	}
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
-	if (e->udiff) {
+	const bool uvx = uvx_fused(e);
+	if (e->udiff && !uvx) {
 		if (udv_fused(e) && (r = check_reference_state(e))) return r;
 		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
 	}
-	return v_explicit_extras(e, iinit, iupd, dt, udv_fused(e));
+	return v_explicit_extras(e, iinit, iupd, dt, udv_fused(e), uvx);
 }
 
 static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double dt, const double * coeff, int n_coeff) {
@@ -2157,7 +2180,7 @@ extern "C" int tmx_v_step_implicit_terms_explicitly(tmx_engine * e, int iinit, i
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, iinit)) || (r = check_inst(e, iupd))) return r;
 	REQUIRE(iinit != iupd && dt != 0.0, TMX_ERR_INVALID, "StepImplicitTermsExplicitly: distinct instances and non-zero dt required");
 	ProfScope ps(e, TMX_K_VI_ASSEMBLE);
-	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt);
+	tmxk_vi_terms_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, false);
 	if (e->nt > 0)      // UpdateColumnTracers(dt, initial, update, ...) of every column, :600-608
 		REQUIRE(tmxk_vi_tracers_all(e, make_params(e), inst(e, iinit), inst(e, iupd), dt) == 0, TMX_ERR_UNSUPPORTED,
 			"tracer column update: %d levels do not fit the LDS working set", e->L);
@@ -2274,13 +2297,85 @@ extern "C" int tmx_v_filter_negative_tracers(tmx_engine * e, int instance) {
 
 static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { return tmx_v_step_implicit_terms_explicitly(e, iinit, iupd, dt); }
 
+// What an operation of a stepper program reads and writes, as bit masks over the data instances.  full: instances it
+// overwrites entirely without reading them; part: instances it updates in place.
+struct OpAccess { unsigned reads, full, part; bool stencil; };
+static OpAccess op_access(const Op & o) {
+	OpAccess x = { 0u, 0u, 0u, true };
+	auto bit = [](int k) { return 1u << k; };
+	switch (o.kind) {
+	case OP_COPY: x.reads = bit(o.a); x.full = bit(o.b); break;
+	case OP_HEXP: case OP_VEXP: case OP_VITE: case OP_VIMP: x.reads = bit(o.a) | bit(o.b); x.part = bit(o.b); break;
+	case OP_DSS: case OP_VFILT: x.reads = bit(o.a); x.part = bit(o.a); break;
+	case OP_HVIS: x.reads = bit(o.a); x.full = bit(o.b) | bit(o.c); break;
+	case OP_LINCOMB:
+		x.stencil = false;      // node by node: a source may share the destination's slot
+		for (int m = 0; m < o.nlc; m++) if (o.lc[m] != 0.0) x.reads |= bit(m);
+		if (o.lc[o.a] != 0.0) x.part = bit(o.a); else x.full = bit(o.a);
+		break;
+	}
+	return x;
+}
+
+// May instance b read instance a's slot from operation `first` of the program on, in place of a copy of a made just before?
+// Yes if, until b is next overwritten entirely, nothing updates b in place, and once a has been written b is not read again
+// (b is dead from there on); a stencil operation must not write a while it reads b.  A program that ends with the two still
+// identical leaves them shared; one that ends after a was written would leave b undefined, so it is refused.
+static bool share_is_safe(const Program & p, size_t first, int a, int b) {
+	const unsigned ba = 1u << a, bb = 1u << b;
+	bool a_written = false;
+	for (size_t i = first; i < p.size(); i++) {
+		const OpAccess x = op_access(p[i]);
+		if (x.part & bb) return false;
+		if ((x.reads & bb) && a_written) return false;
+		if (((x.full | x.part) & ba) && (x.reads & bb) && x.stencil) return false;
+		if (x.full & bb) return true;
+		if ((x.full | x.part) & ba) a_written = true;
+	}
+	return !a_written;
+}
+
+// an operation is about to write instance x: give it its own slot back (with its contents unless the write is total)
+static int own_slot(tmx_engine * e, int x, bool total) {
+	if (e->imap[x] == x) return TMX_OK;
+	if (!total)
+		HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
+			e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	e->imap[x] = x; e->n_shared--;
+	return TMX_OK;
+}
+// instance x has been written: the instances that read its slot are dead by share_is_safe and go back to their own
+static void drop_readers(tmx_engine * e, int x) {
+	for (int y = 0; y < (int)e->imap.size(); y++)
+		if (y != x && e->imap[y] == x) { e->imap[y] = y; e->n_shared--; }
+}
+
+struct ProgramScope {
+	tmx_engine * e;
+	ProgramScope(tmx_engine * e_) : e(e_) { e->in_program = true; }
+	~ProgramScope() { e->in_program = false; }
+};
+struct AfterOp {      // at the end of an operation: the readers of the slots it wrote
+	tmx_engine * e; unsigned w;
+	~AfterOp() { for (int x = 0; x < (int)e->imap.size() && e->n_shared; x++) if (w >> x & 1u) drop_readers(e, x); }
+};
+
 static int run_program(tmx_engine * e, const Program & p) {
 	int r;
 	const size_t n = p.size();
+	ProgramScope scope(e);
+	// shared slots left by the previous step: kept where this program allows it, given their own copy otherwise
+	for (int b = 0; b < (int)e->imap.size() && e->n_shared; b++)
+		if (e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b) && (r = own_slot(e, b, false))) return r;
 	for (size_t i = 0; i < n; i++) {
 		const Op & o = p[i];
 		const Op * n1 = (i + 1 < n) ? &p[i + 1] : nullptr;
 		const Op * n2 = (i + 2 < n) ? &p[i + 2] : nullptr;
+		// the instances this operation (and the ones fused with it below, which write the same instance) writes
+		const OpAccess acc = op_access(o);
+		for (int x = 0; x < (int)e->imap.size() && e->n_shared; x++)
+			if (((acc.full | acc.part) >> x & 1u) && (r = own_slot(e, x, (acc.full >> x & 1u) != 0))) return r;
+		AfterOp after = { e, acc.full | acc.part };
 		switch (o.kind) {
 		case OP_COPY:
 			// Copy(a->b) + H(a,b,c) + V(a,b,c)  ==  one pass  b = a + c * rhs(a)
@@ -2302,6 +2397,20 @@ static int run_program(tmx_engine * e, const Program & p) {
 				if (!e->sw && !e->fully_explicit && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
 					if ((r = copy_uv(e, o.a, o.b))) return r;
 					if ((r = v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a))) return r;
+					i = j; break;
+				}
+			}
+			// Copy(a->b) [+ copies of the same] + V.StepImplicit(b,b,c) where the implicit step does nothing (fully explicit
+			// vertical mode :1239-1242, shallow water's stub): b stays identical to a, so it reads a's slot until it is
+			// overwritten -- no copy (config 4: three whole-state copies per ARS343 step)
+			{
+				size_t j = i + 1;
+				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
+				if ((e->sw || e->fully_explicit) && e->share_copies && !e->use_graph && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b &&
+				    o.a != o.b && e->imap[o.a] == o.a && share_is_safe(p, j + 1, o.a, o.b)) {
+					drop_readers(e, o.b);      // (dead by the same argument: b is overwritten here)
+					e->imap[o.b] = o.a; e->n_shared++;
+					after.w = 0;
 					i = j; break;
 				}
 			}

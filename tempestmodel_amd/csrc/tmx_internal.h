@@ -174,6 +174,14 @@ struct tmx_engine {
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
 	int p2p_timeout_s = 600;                 // peer-to-peer halo: how long a neighbour's message may take (TMX_P2P_TIMEOUT_S; 0 = for ever)
 	const int * stage_quads = nullptr;       // tile list of the boundary-first stage in progress (make_params -> KParams.quads)
+	// Instance map of the stepper programs (run_program): logical data instance -> slot of d_state.  A CopyData(a -> b) whose
+	// copy stays bit-identical to its source until b is next overwritten (fully explicit vertical mode, shallow water: the
+	// V.StepImplicit that follows is a stub) is not performed; b reads a's slot instead.  Identity outside tmx_step: every
+	// other entry point settles the map first (settle_instance_map).
+	std::vector<int> imap;
+	int n_shared = 0;                        // instances that currently read another instance's slot
+	bool in_program = false;
+	int share_copies = 1;                    // TMX_SHARE_COPIES=0: perform every CopyData
 	int vi_split_back = 0, vi_back_sub = 1, vi_stagger = 0;   // experiments (TMX_VI_SPLIT_BACK, TMX_VI_BACK_SUB, TMX_VI_STAGGER_NS / 10): back substitution as its own launch
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
@@ -198,7 +206,7 @@ void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, doub
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);
 void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double * xup);
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
-void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt);
+void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_uv = false);
 void tmxk_dss(tmx_engine * e, const KParams & p, double * x, int g0, int g1);
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v, int scale_locally, bool pull_dss = false);

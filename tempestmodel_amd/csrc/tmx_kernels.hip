@@ -519,15 +519,13 @@ __device__ __forceinline__ double xidot_edge(const KParams & p, const double * _
 #ifndef KT_VE
 #define KT_VE 4       // levels per workgroup (vertical stencils: see KT_VC)
 #endif
+// the update of U,V at (col, level k), k < L
 template <bool UDV>
-__global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf)
+__device__ __forceinline__ void v_explicit_point(const KParams & p, const double * __restrict__ xin, double * __restrict__ xup, double dt,
+	const double * __restrict__ xref, double cf, int col, int k)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = TILE_X(p) * 64 + threadIdx.x;
-	const int k = blockIdx.y * KT_VE + WAVE_UNIFORM(threadIdx.y);
-	if (k >= L || col >= p.ncol) return;
 	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
 	const double w_lo = dt * fabs(xidot_edge(p, xin, k, col));       // weight of interface k
 	const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
@@ -563,6 +561,16 @@ __global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const doub
 		}
 		xup[(size_t)(sb + k) * NS + col] = out;
 	}
+}
+
+template <bool UDV>
+__global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const double * __restrict__ xin,
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf)
+{
+	const int col = TILE_X(p) * 64 + threadIdx.x;
+	const int k = blockIdx.y * KT_VE + WAVE_UNIFORM(threadIdx.y);
+	if (k >= p.L || col >= p.ncol) return;
+	v_explicit_point<UDV>(p, xin, xup, dt, xref, cf, col, k);
 }
 
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
@@ -1637,21 +1645,41 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 			s_rh[li][tx] = a; s_rr[li][tx] = b;
 		}
 	}
+	// the column values a thread stages (levels y and y + KT of the tile's 12) and the value it updates are loaded one tracer
+	// ahead of their use, so that their latency overlaps the previous tracer's arithmetic instead of following a barrier
+	double pq[2] = { 0.0, 0.0 }, pr[2] = { 0.0, 0.0 }, pup = 0.0;
+	const bool mine = k < L && col < p.ncol;
+	auto prefetch = [&](int c) {
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int li = y + h * KT, l = k0 - 2 + li;
+			if (li < NL && l >= 0 && l < L) {
+				pq[h] = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+				if (ks != 0.0) pr[h] = xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+			}
+		}
+		if (mine) pup = xup[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+	};
+	if (nt > 0) prefetch(0);
 	for (int c = 0; c < nt; c++) {
 		__syncthreads();           // first pass: the staging above; later passes: the previous tracer's reads of s_q / s_mr
-		for (int li = y; li < NL; li += KT) {
-			const int l = k0 - 2 + li;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int li = y + h * KT, l = k0 - 2 + li;
+			if (li >= NL) continue;
 			double qv = 0.0, mr = 0.0;
 			if (l >= 0 && l < L) {
-				qv = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+				qv = pq[h];
 				if (ks != 0.0) {
 					double a_ = qv / s_rh[li][tx];
-					a_ -= xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col] / s_rr[li][tx];
+					a_ -= pr[h] / s_rr[li][tx];
 					mr = a_;
 				}
 			}
 			s_q[li][tx] = qv; s_mr[li][tx] = mr;
 		}
+		const double up0 = pup;
+		if (c + 1 < nt) prefetch(c + 1);
 		__syncthreads();
 		if (k >= L || col >= p.ncol) continue;
 		auto qn = [&](int l) -> double { return s_q[l - k0 + 2][tx]; };
@@ -1700,7 +1728,7 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 		const double idt = 1.0 / dt;
 		if (F != 0.0) F /= idt;
 		const size_t so = (size_t)TMX_SLAB_Q(L, c, k) * NS;
-		xup[so + col] = xup[so + col] - F;
+		xup[so + col] = up0 - F;
 	}
 }
 
@@ -4435,7 +4463,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 
 // UD (fully explicit mode with uniform diffusion): F additionally holds the vertical diffusion of rho*theta and W
 // relative to the reference column xref (cs = K_s / ztop^2, cw = K_v / ztop^2).
-template <bool UD>
+// UVX: the thread of (column, level k < L) also applies V.StepExplicit's update of U,V (v_explicit_point: penalty and, with UD,
+// the vertical diffusion), which reads the same U,V,W columns and metric rows -- one launch less per stage and the operands
+// found in the cache
+template <bool UD, bool UVX>
 // KT_VC levels per workgroup.  A thread reads the levels k-2 .. k+2 of its column, so the level tiles of a column overlap by
 // four levels and every value is fetched 2.7 times over at the L2's memory side (PMC, ne30 L40: 514 MB of reads per launch for
 // 190 MB of operands: the level-neighbour tiles are 1 350 workgroups apart in dispatch order, on another XCD's L2).  Taller
@@ -4495,16 +4526,19 @@ __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, con
 		xup[TMX_SLAB_R(L, k) * NS + col] -= dt * fR;
 	}
 	xup[TMX_SLAB_W(L, k) * NS + col] -= dt * fW;
+	if (UVX && k < L) v_explicit_point<UD>(p, xin, xup, dt, xref, cw, col, k);
 }
 
-void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
+void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_uv) {
 	dim3 blk(64, KT_VC), grd(NTILES(e, p), (p.L + 1 + KT_VC - 1) / KT_VC);
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;
-		hipLaunchKernelGGL(k_vi_terms_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
+		if (with_uv) hipLaunchKernelGGL((k_vi_terms_explicit<true, true>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
+			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2);
+		else hipLaunchKernelGGL((k_vi_terms_explicit<true, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
 			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2);
 	} else
-		hipLaunchKernelGGL(k_vi_terms_explicit<false>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0);
+		hipLaunchKernelGGL((k_vi_terms_explicit<false, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0);
 }
 
 

@@ -1887,3 +1887,65 @@ def test_hyperviscosity_fused_with_the_in_patch_dss_is_bit_identical(ne, npatch,
             assert np.array_equal(an[[0, 1, 2, 4], 1:-1, 1:-1], bn[[0, 1, 2, 4], 1:-1, 1:-1])
             assert np.array_equal(ae[3, 1:-1, 1:-1], be[3, 1:-1, 1:-1])
 
+
+
+@pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "ark232", "strang"])
+def test_stage_copies_left_out_and_fused_uv_update_are_bit_identical(monkeypatch, scheme):
+    """Fully explicit vertical mode (BASELINE config 4's): the CopyData in front of the V.StepImplicit that does nothing is not
+    performed -- the copy reads its source's slot (TMX_SHARE_COPIES=0: every copy made); TMX_VX_FUSED=1 runs V.StepExplicit's
+    U,V update inside the kernel of the explicitly treated terms instead of its own launch.  Same doubles, in instance 0
+    and in every other instance a caller can ask for between steps (the work instance of StepAfterSubCycle aside)."""
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_udiff_ars343_ne3_L6_p6.npz")
+    g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
+    st, tr = gu.expand_compact(d, "initial", g), gu.expand_compact_tracers(d, "initial", g)
+    ninst = Engine.scheme_instances(scheme)
+    runs = []
+    for variant in ({}, {"TMX_SHARE_COPIES": "0"}, {"TMX_VX_FUSED": "1"}, {"probe": True}):
+        monkeypatch.delenv("TMX_SHARE_COPIES", raising=False)
+        monkeypatch.delenv("TMX_VX_FUSED", raising=False)
+        for k, v in variant.items():
+            if k.startswith("TMX_"):
+                monkeypatch.setenv(k, v)
+        e = Engine(g, n_instances=ninst, fully_explicit=True, uniform_diffusion=UDIFF)
+        try:
+            e.upload_state(0, st); e.upload_tracers(0, tr)
+            for step in (1, 2, 3):
+                e.step(scheme, 1.0, first=(step == 1))
+                if variant.get("probe"):
+                    # a caller looks at (and so settles) stage instances between steps, and writes one back
+                    for ix in range(1, ninst):
+                        e.download_state(ix)
+                    e.upload_state(ninst - 1, e.download_state(ninst - 1))
+            e.sync()
+            runs.append([(e.download_state(ix), e.download_tracers(ix)) for ix in range(ninst)])
+        finally:
+            e.close()
+    work = {"ars343": {2}}.get(scheme, set(range(1, ninst)))      # compared beyond instance 0: ARS343's stage instances
+    for other in runs[1:]:
+        for ix in range(ninst):
+            if ix != 0 and ix in work:
+                continue
+            assert max(gu.prognostic_errors(runs[0][ix][0], other[ix][0])) <= EXACT, (scheme, ix)
+            assert max(gu.tracer_errors(runs[0][ix][1], other[ix][1])) <= EXACT, (scheme, ix)
+
+
+def test_stage_copies_left_out_in_shallow_water_are_bit_identical(monkeypatch):
+    """Shallow water (V is a stub): the same, ARS343 on Williamson test 2."""
+    from tempestmodel_amd.engine import Engine
+    from test_oracle_vs_reference import _sw_setup
+    g, states = _sw_setup()
+    out = []
+    for share in ("1", "0"):
+        monkeypatch.setenv("TMX_SHARE_COPIES", share)
+        e = Engine(g, n_instances=7)
+        try:
+            e.upload_state(0, states)
+            for n in range(4):
+                e.step("ars343", 200.0, first=(n == 0))
+            e.sync()
+            out.append([e.download_state(ix) for ix in (0, 1, 3, 4, 5, 6)])
+        finally:
+            e.close()
+    for a, b in zip(*out):
+        assert max(gu.prognostic_errors(a, b)[:3]) <= EXACT
