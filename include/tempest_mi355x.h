@@ -426,6 +426,13 @@ int tmx_debug_comm_selftest(tmx_engine * e);
  * {pivot steps in which all 64 columns of a wavefront chose the same pivot row, all pivot steps} counted so far. */
 int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long long out[2]);
 
+/* Host logic of the stepper programs, no device needed (tests/): the whole-instance copies a time scheme's program performs per
+ * step and the ones it replaces by slot sharing (a CopyData in front of a V.StepImplicit that does nothing reads its source's
+ * slot until it is overwritten: fully explicit vertical mode VerticalDynamicsFEM.cpp:1239-1242, VerticalDynamicsStub), decided
+ * exactly as tmx_step decides them.  mode 0: implicit vertical dynamics, 1: fully explicit, 2: shallow water; `steps`
+ * consecutive steps, counts of the last one; share = 0 switches the sharing off (TMX_SHARE_COPIES=0). */
+int tmx_debug_program_copies(int scheme, int mode, int steps, int share, int * copies, int * shared);
+
 /* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.
  * kernel ids: TMX_K_* below.  Profiling is off by default (no events recorded). */
 enum {

@@ -150,6 +150,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->imap.resize(cfg->n_instances);
 	for (int k = 0; k < cfg->n_instances; k++) e->imap[k] = k;
 	if (const char * v = getenv("TMX_SHARE_COPIES")) e->share_copies = atoi(v);
+	if (const char * v = getenv("TMX_XCD_VERTICAL")) e->xcd_vertical = atoi(v) ? 1 : 0;
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
 	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
@@ -2338,9 +2339,11 @@ static bool share_is_safe(const Program & p, size_t first, int a, int b) {
 // an operation is about to write instance x: give it its own slot back (with its contents unless the write is total)
 static int own_slot(tmx_engine * e, int x, bool total) {
 	if (e->imap[x] == x) return TMX_OK;
-	if (!total)
-		HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
+	if (!total) {
+		if (e->dry_run) e->dry_copies++;
+		else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
 			e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	}
 	e->imap[x] = x; e->n_shared--;
 	return TMX_OK;
 }
@@ -2360,6 +2363,9 @@ struct AfterOp {      // at the end of an operation: the readers of the slots it
 	~AfterOp() { for (int x = 0; x < (int)e->imap.size() && e->n_shared; x++) if (w >> x & 1u) drop_readers(e, x); }
 };
 
+// RUN: the launches of an operation; a dry run (tmx_debug_program_copies: the copy / sharing decisions of a program on the
+// host, no device) skips them
+#define RUN(call) (e->dry_run ? TMX_OK : (call))
 static int run_program(tmx_engine * e, const Program & p) {
 	int r;
 	const size_t n = p.size();
@@ -2383,10 +2389,10 @@ static int run_program(tmx_engine * e, const Program & p) {
 			    n2->b == o.b && n1->coef == n2->coef && n1->a != o.b) {
 				// ... + DSS(b) on several ranks: boundary tiles first, exchange overlapped with the interior tiles
 				if (stage_can_split(e) && i + 3 < n && p[i + 3].kind == OP_DSS && p[i + 3].a == o.b) {
-					if ((r = hv_stage_split(e, n1->a, o.a, o.b, n1->coef, nullptr, 0))) return r;
+					if ((r = RUN(hv_stage_split(e, n1->a, o.a, o.b, n1->coef, nullptr, 0)))) return r;
 					i += 3; break;
 				}
-				if ((r = hv_step_explicit(e, n1->a, o.a, o.b, n1->coef))) return r;
+				if ((r = RUN(hv_step_explicit(e, n1->a, o.a, o.b, n1->coef)))) return r;
 				i += 2; break;
 			}
 			// Copy(s->t) [twice in some schemes] + V.StepImplicit(t,t,c): the solve rewrites rho*theta, W, rho
@@ -2395,8 +2401,8 @@ static int run_program(tmx_engine * e, const Program & p) {
 				size_t j = i + 1;
 				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
 				if (!e->sw && !e->fully_explicit && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
-					if ((r = copy_uv(e, o.a, o.b))) return r;
-					if ((r = v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a))) return r;
+					if ((r = RUN(copy_uv(e, o.a, o.b)))) return r;
+					if ((r = RUN(v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a)))) return r;
 					i = j; break;
 				}
 			}
@@ -2409,7 +2415,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 				if ((e->sw || e->fully_explicit) && e->share_copies && !e->use_graph && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b &&
 				    o.a != o.b && e->imap[o.a] == o.a && share_is_safe(p, j + 1, o.a, o.b)) {
 					drop_readers(e, o.b);      // (dead by the same argument: b is overwritten here)
-					e->imap[o.b] = o.a; e->n_shared++;
+					e->imap[o.b] = o.a; e->n_shared++; e->dry_shared++;
 					after.w = 0;
 					i = j; break;
 				}
@@ -2417,57 +2423,83 @@ static int run_program(tmx_engine * e, const Program & p) {
 			// Copy(a->b) + StepAfterSubCycle(a,b,w): every branch of StepAfterSubCycle rewrites all of b from a (the second
 			// hyperviscosity pass and the order-2 pass write every slab with a as their base; without viscosity it IS the copy)
 			if (n1 && n1->kind == OP_HVIS && n1->a == o.a && n1->b == o.b && o.a != o.b) break;
-			if ((r = tmx_copy_data(e, o.a, o.b))) return r;
+			if (e->dry_run) e->dry_copies++;
+			else if ((r = tmx_copy_data(e, o.a, o.b))) return r;
 			break;
 		case OP_HEXP:
 			if (e->sw && stage_can_split(e) && n1 && n2 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n2->kind == OP_DSS && n2->a == o.b && o.a != o.b) {
-				if ((r = sw_stage_split(e, o.a, o.b, o.coef))) return r;
+				if ((r = RUN(sw_stage_split(e, o.a, o.b, o.coef)))) return r;
 				i += 2; break;
 			}
 			if (!e->sw && n1 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n1->coef == o.coef) {
 				if (stage_can_split(e) && n2 && n2->kind == OP_DSS && n2->a == o.b) {
-					if ((r = hv_stage_split(e, o.a, o.b, o.b, o.coef, nullptr, 0))) return r;
+					if ((r = RUN(hv_stage_split(e, o.a, o.b, o.b, o.coef, nullptr, 0)))) return r;
 					i += 2; break;
 				}
-				if ((r = hv_step_explicit(e, o.a, o.b, o.b, o.coef))) return r;
+				if ((r = RUN(hv_step_explicit(e, o.a, o.b, o.b, o.coef)))) return r;
 				i += 1; break;
 			}
-			if ((r = tmx_h_step_explicit(e, o.a, o.b, o.coef))) return r;
+			if ((r = RUN(tmx_h_step_explicit(e, o.a, o.b, o.coef)))) return r;
 			break;
 		case OP_VEXP:
-			if ((r = tmx_v_step_explicit(e, o.a, o.b, o.coef))) return r;
+			if ((r = RUN(tmx_v_step_explicit(e, o.a, o.b, o.coef)))) return r;
 			break;
 		case OP_DSS:
-			if ((r = tmx_apply_dss(e, o.a))) return r;
+			if ((r = RUN(tmx_apply_dss(e, o.a)))) return r;
 			break;
 		case OP_VIMP:
-			if ((r = tmx_v_step_implicit(e, o.a, o.b, o.coef))) return r;
+			if ((r = RUN(tmx_v_step_implicit(e, o.a, o.b, o.coef)))) return r;
 			break;
 		case OP_VFILT:
 			// VerticalDynamics::FilterNegativeTracers(instance): nothing without tracers
-			if ((r = tmx_v_filter_negative_tracers(e, o.a))) return r;
+			if ((r = RUN(tmx_v_filter_negative_tracers(e, o.a)))) return r;
 			break;
 		case OP_VITE:
-			if ((r = vi_terms_explicit(e, o.a, o.b, o.coef))) return r;
+			if ((r = RUN(vi_terms_explicit(e, o.a, o.b, o.coef)))) return r;
 			break;
 		case OP_HVIS:
-			if ((r = h_step_after_subcycle_impl(e, o.a, o.b, o.c, o.coef, true))) return r;
+			if ((r = RUN(h_step_after_subcycle_impl(e, o.a, o.b, o.c, o.coef, true)))) return r;
 			break;
 		case OP_LINCOMB:
 			// LinearCombine(-> d) + H(i,d,c) + V(i,d,c): combination evaluated inside the explicit kernels
 			if (!e->sw && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.a && n2->b == o.a &&
 			    n1->a == n2->a && n1->coef == n2->coef && n1->a != o.a) {
 				if (stage_can_split(e) && i + 3 < n && p[i + 3].kind == OP_DSS && p[i + 3].a == o.a) {
-					if ((r = hv_stage_split(e, n1->a, o.a, o.a, n1->coef, o.lc, o.nlc))) return r;
+					if ((r = RUN(hv_stage_split(e, n1->a, o.a, o.a, n1->coef, o.lc, o.nlc)))) return r;
 					i += 3; break;
 				}
-				if ((r = hv_step_explicit_lincomb(e, n1->a, o.a, n1->coef, o.lc, o.nlc))) return r;
+				if ((r = RUN(hv_step_explicit_lincomb(e, n1->a, o.a, n1->coef, o.lc, o.nlc)))) return r;
 				i += 2; break;
 			}
-			if ((r = tmx_linear_combine_data(e, o.lc, o.nlc, o.a))) return r;
+			if ((r = RUN(tmx_linear_combine_data(e, o.lc, o.nlc, o.a)))) return r;
 			break;
 		}
 	}
+	return TMX_OK;
+}
+
+#undef RUN
+
+// The whole-instance copies a stepper program performs and the ones it replaces by slot sharing, decided exactly as
+// run_program decides them, without a device: `steps` consecutive steps (the first with first_step set), counts of the last
+// one.  mode 0: implicit vertical dynamics, 1: fully explicit vertical mode, 2: shallow water.  Host logic for the CPU tests.
+extern "C" int tmx_debug_program_copies(int scheme, int mode, int steps, int share, int * copies, int * shared) {
+	REQUIRE(copies && shared && steps >= 1 && mode >= 0 && mode <= 2, TMX_ERR_INVALID, "tmx_debug_program_copies: bad argument");
+	const int need = scheme_instances(scheme);
+	REQUIRE(need > 0, TMX_ERR_INVALID, "unknown time scheme %d", scheme);
+	tmx_engine e;
+	e.cfg.n_instances = need; e.cfg.n_ranks = 1;
+	e.sw = mode == 2; e.fully_explicit = mode == 1; e.share_copies = share; e.dry_run = true;
+	e.imap.resize(need);
+	for (int k = 0; k < need; k++) e.imap[k] = k;
+	for (int n = 0; n < steps; n++) {
+		Program p;
+		int r = build_program(scheme, n == 0, 0, 1.0, p, 0.0);
+		if (r) return r;
+		e.dry_copies = e.dry_shared = 0;
+		if ((r = run_program(&e, p))) return r;
+	}
+	*copies = e.dry_copies; *shared = e.dry_shared;
 	return TMX_OK;
 }
 

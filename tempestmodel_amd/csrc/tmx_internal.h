@@ -182,6 +182,8 @@ struct tmx_engine {
 	int n_shared = 0;                        // instances that currently read another instance's slot
 	bool in_program = false;
 	int share_copies = 1;                    // TMX_SHARE_COPIES=0: perform every CopyData
+	bool dry_run = false; int dry_copies = 0, dry_shared = 0;     // tmx_debug_program_copies
+	int xcd_vertical = 1;                    // TMX_XCD_VERTICAL=0: plain 2-D order of the vertical stencil kernels' workgroups
 	int vi_split_back = 0, vi_back_sub = 1, vi_stagger = 0;   // experiments (TMX_VI_SPLIT_BACK, TMX_VI_BACK_SUB, TMX_VI_STAGGER_NS / 10): back substitution as its own launch
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
 	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)

@@ -118,6 +118,21 @@ __device__ __forceinline__ bool xcd_tile(int nx, int ny, int & x, int & y) {
 	return y < ny && x < nx;
 }
 
+// The same for the vertical stencil kernels of the fully explicit mode (explicitly treated terms, U,V penalty, tracer columns):
+// a thread of level k reads the levels k - 2 .. k + 2 of its column, so the level blocks of one 64-column tile share most of
+// their operands.  In the plain 2-D launch they are a whole row of tiles apart in dispatch order and land on different XCDs
+// (the halo levels were fetched 2.7 times over, PMC); here the 1-D launch is unfolded so that the level blocks of a column
+// tile are consecutive workgroups of ONE XCD and find the halo in its L2.  mode 0: the plain order (TMX_XCD_VERTICAL=0, A/B).
+__device__ __forceinline__ bool xcd_column_tile(int mode, int nx, int ny, int & x, int & y) {
+	const int b = blockIdx.x;
+	if (!mode) { x = b % nx; y = b / nx; return y < ny; }
+	const int xcd = b & 7, r = b >> 3;
+	y = r % ny;
+	x = (r / ny) * 8 + xcd;
+	return x < nx;
+}
+static inline int xcd_column_grid(int mode, int nx, int ny) { return mode ? ((nx + 7) / 8) * 8 * ny : nx * ny; }
+
 // 3-D terrain-following metric (GridPatchCSGLL.cpp:441-566).  Stored mode streams the reference's arrays;
 // closed mode evaluates the same expressions, operation for operation, from eight per-column factors and the
 // 1 - eta table (accepted by tmx_set_patch_metric_factors only after a bit-for-bit comparison), which removes
@@ -565,21 +580,24 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 
 template <bool UDV>
 __global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf)
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf, int ntile, int xmode)
 {
-	const int col = TILE_X(p) * 64 + threadIdx.x;
-	const int k = blockIdx.y * KT_VE + WAVE_UNIFORM(threadIdx.y);
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (p.L + KT_VE - 1) / KT_VE, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	const int k = by * KT_VE + WAVE_UNIFORM(threadIdx.y);
 	if (k >= p.L || col >= p.ncol) return;
 	v_explicit_point<UDV>(p, xin, xup, dt, xref, cf, col, k);
 }
 
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
-	dim3 blk(64, KT_VE), grd(NTILES(e, p), (p.L + KT_VE - 1) / KT_VE);
+	const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+	dim3 blk(64, KT_VE), grd(xcd_column_grid(xm, nt_, (p.L + KT_VE - 1) / KT_VE));
 	if (with_udiff_uv)
 		hipLaunchKernelGGL(k_v_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
-			e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop));
+			e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop), nt_, xm);
 	else
-		hipLaunchKernelGGL(k_v_explicit<false>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0);
+		hipLaunchKernelGGL(k_v_explicit<false>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, nt_, xm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1598,15 +1616,17 @@ __global__ __launch_bounds__(256) void k_v_tracers_explicit(KParams p, int nt, c
 // deviations (two fp64 divisions each) are evaluated by one thread each instead of by every thread whose stencil reaches them
 // (5 x for the divisions: 372 -> 264 us per launch at ne30 L40 with three tracers).  Every value is produced by the same expression as above, so the results are bit-identical.
 __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int nt, const double * __restrict__ xin, double * xup, double dt,
-	double ks, const double * __restrict__ xref)
+	double ks, const double * __restrict__ xref, int ntile, int xmode)
 {
 	constexpr int KT = 8, NL = KT + 4, NI = KT + 1;
 	__shared__ double s_xd[NI][64], s_re[NI][64], s_rh[NL][64], s_rr[NL][64], s_q[NL][64], s_mr[NL][64];
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int tx = threadIdx.x, y = WAVE_UNIFORM(threadIdx.y);
-	const int col = TILE_X(p) * 64 + tx;
-	const int k0 = blockIdx.y * KT, k = k0 + y;
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (L + KT - 1) / KT, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + tx;
+	const int k0 = by * KT, k = k0 + y;
 	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
 	{
@@ -1742,9 +1762,10 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 			hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
 				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
 		} else {
-			dim3 blk(64, 8), grd(NTILES(e, p), (p.L + 7) / 8);
+			const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+			dim3 blk(64, 8), grd(xcd_column_grid(xm, nt_, (p.L + 7) / 8));
 			hipLaunchKernelGGL(k_v_tracers_explicit_tile, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
-				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
+				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref, nt_, xm);
 		}
 		return 0;
 	}
@@ -4662,12 +4683,14 @@ template <bool UD, bool UVX>
 #define KT_VC 4
 #endif
 __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, const double * __restrict__ xin,
-	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cs, double cw)
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cs, double cw, int ntile, int xmode)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = TILE_X(p) * 64 + threadIdx.x;
-	const int k = blockIdx.y * KT_VC + WAVE_UNIFORM(threadIdx.y);
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (L + 1 + KT_VC - 1) / KT_VC, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	const int k = by * KT_VC + WAVE_UNIFORM(threadIdx.y);
 	if (col >= p.ncol || k > L) return;
 	ColConst cc;
 	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
@@ -4716,15 +4739,16 @@ __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, con
 }
 
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_uv) {
-	dim3 blk(64, KT_VC), grd(NTILES(e, p), (p.L + 1 + KT_VC - 1) / KT_VC);
+	const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+	dim3 blk(64, KT_VC), grd(xcd_column_grid(xm, nt_, (p.L + 1 + KT_VC - 1) / KT_VC));
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;
 		if (with_uv) hipLaunchKernelGGL((k_vi_terms_explicit<true, true>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
-			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2);
+			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2, nt_, xm);
 		else hipLaunchKernelGGL((k_vi_terms_explicit<true, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
-			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2);
+			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2, nt_, xm);
 	} else
-		hipLaunchKernelGGL((k_vi_terms_explicit<false, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0);
+		hipLaunchKernelGGL((k_vi_terms_explicit<false, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0, nt_, xm);
 }
 
 

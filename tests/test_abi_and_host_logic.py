@@ -170,3 +170,40 @@ def test_peer_to_peer_halo_needs_a_device_engine_of_a_multi_rank_layout():
             e.halo_p2p_enable(True)                  # not connected
     finally:
         e.close()
+
+
+def test_stepper_programs_share_the_copies_in_front_of_a_stub_implicit_step():
+    """Host logic of tmx_step, no device: which whole-instance copies a scheme's program makes per step, and which it
+    replaces by letting the copy read its source's slot (tmx_debug_program_copies runs the program's own decision code
+    without launches).  ARS343 in the fully explicit vertical mode and in shallow water: the three CopyData in front of
+    V.StepImplicit (TimestepSchemeARS343.cpp:150-236) are shared, none is made, also in steady state (the slots shared at
+    the end of a step are re-validated against the next step's program); with implicit vertical dynamics nothing is
+    shared.  Every scheme: sharing never adds copies, and copies + shared is what the program asks for."""
+    from tempestmodel_amd.engine import Engine, load_library
+    lib = load_library()
+    lib.tmx_debug_program_copies.restype = ctypes.c_int
+    lib.tmx_debug_program_copies.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int)] * 2
+
+    def run(scheme, mode, steps, share):
+        c, s = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.tmx_debug_program_copies(Engine.SCHEMES[scheme], mode, steps, share, ctypes.byref(c), ctypes.byref(s)) == 0
+        return c.value, s.value
+
+    for steps in (1, 2, 5):
+        assert run("ars343", 1, steps, 1) == (0, 3)
+        assert run("ars343", 1, steps, 0) == (3, 0)
+        # shallow water keeps the CopyData of its first stage (the H + V fusion that absorbs it is the nonhydrostatic kernel's)
+        assert run("ars343", 2, steps, 1) == (1, 3)
+        assert run("ars343", 2, steps, 0) == (4, 0)
+    assert run("ars232", 1, 3, 1) == (2, 2)
+    assert run("ars343", 0, 3, 1)[1] == 0          # the implicit solve changes the copy: nothing to share
+    for scheme in Engine.SCHEMES:
+        for mode in (0, 1, 2):
+            for steps in (1, 3):
+                made1, shared1 = run(scheme, mode, steps, 1)
+                made0, shared0 = run(scheme, mode, steps, 0)
+                assert shared0 == 0 and made1 <= made0, (scheme, mode, steps)
+                # a shared copy is either never needed or made later (when its slot is written in place): never more than asked for
+                assert made1 + shared1 >= made0 and made1 >= made0 - shared1, (scheme, mode, steps)
+    c = ctypes.c_int(); s = ctypes.c_int()
+    assert lib.tmx_debug_program_copies(99, 1, 1, 1, ctypes.byref(c), ctypes.byref(s)) != 0

@@ -1949,3 +1949,37 @@ def test_stage_copies_left_out_in_shallow_water_are_bit_identical(monkeypatch):
             e.close()
     for a, b in zip(*out):
         assert max(gu.prognostic_errors(a, b)[:3]) <= EXACT
+
+
+def test_kessler_level_parallel_kernel_with_several_rain_sub_cycles(monkeypatch):
+    """SUBROUTINE KESSLER's rain loop on the moistened supercell state with time steps long enough for the CFL limit to split it
+    (kessler.f90:117-127; the columns need different numbers of sub-cycles): the level-parallel kernel (default), the
+    one-lane-per-column kernel (TMX_KESSLER_COLUMN=1) and the oracle give the same doubles -- state, tracers, precipitation."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d, g = _supercell_case()
+    st = gu.expand_compact(d, "kessler_moist_before", g); tr = gu.expand_compact_tracers(d, "kessler_moist_before", g)
+    zl = [P.geom["z_levels"] for P in g.patches]
+    for dt in (60.0, 400.0):
+        o = Oracle(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0))
+        o.set_state(0, st); o.set_tracers(0, tr)
+        o.kessler(0, dt, zl); o.kessler(0, dt, zl)
+        out = []
+        for column in (False, True):
+            monkeypatch.delenv("TMX_KESSLER_COLUMN", raising=False)
+            if column:
+                monkeypatch.setenv("TMX_KESSLER_COLUMN", "1")
+            e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0))
+            try:
+                e.set_level_heights()
+                e.upload_state(0, st); e.upload_tracers(0, tr)
+                e.kessler(0, dt); e.kessler(0, dt); e.sync()
+                out.append((e.download_state(0), e.download_tracers(0), e.download_precipitation()))
+            finally:
+                e.close()
+        for gs, gt, pr in out:
+            assert max(gu.prognostic_errors(gs, o.get_state(0))) <= EXACT, dt
+            assert max(gu.tracer_errors(gt, o.get_tracers(0))) <= EXACT, dt
+        for P in g.patches:
+            assert np.array_equal(out[0][2][P.index][1:-1, 1:-1], out[1][2][P.index][1:-1, 1:-1])
+        assert max(float(np.max(a)) for a in out[0][2].values()) > 0.0
