@@ -541,6 +541,7 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
+	const double up0[2] = { xup[(size_t)k * NS + col], xup[(size_t)(L + k) * NS + col] };      // U, V to update: loaded with the operands
 	const double w_hi = dt * fabs(xidot_edge(p, xin, k + 1, col));   // weight of interface k+1
 	const double w_lo = dt * fabs(xidot_edge(p, xin, k, col));       // weight of interface k
 	const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
@@ -549,7 +550,7 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 		const int sb = v * L;
 		const double x0 = xin[(size_t)(sb + k) * NS + col];
 		const double xm = xin[(size_t)(sb + km) * NS + col], xp = xin[(size_t)(sb + kp) * NS + col];
-		double out = xup[(size_t)(sb + k) * NS + col];
+		double out = up0[v];
 		if (k < L - 1) {
 			double b = 0.0;
 			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * x0;
@@ -1629,6 +1630,22 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 	const int k0 = by * KT, k = k0 + y;
 	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
 	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	// the column values a thread stages (levels y and y + KT of the tile's 12) and the value it updates are loaded one tracer
+	// ahead of their use, so that their latency overlaps the previous tracer's arithmetic instead of following a barrier
+	double pq[2] = { 0.0, 0.0 }, pr[2] = { 0.0, 0.0 }, pup = 0.0;
+	const bool mine = k < L && col < p.ncol;
+	auto prefetch = [&](int c) {
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int li = y + h * KT, l = k0 - 2 + li;
+			if (li < NL && l >= 0 && l < L) {
+				pq[h] = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+				if (ks != 0.0) pr[h] = xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+			}
+		}
+		if (mine) pup = xup[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
+	};
+	if (nt > 0) prefetch(0);       // in flight while the shared operands below are staged
 	{
 		const MetCol mc = met_col(p, col);
 		for (int mi = y; mi < NI; mi += KT) {
@@ -1665,22 +1682,6 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 			s_rh[li][tx] = a; s_rr[li][tx] = b;
 		}
 	}
-	// the column values a thread stages (levels y and y + KT of the tile's 12) and the value it updates are loaded one tracer
-	// ahead of their use, so that their latency overlaps the previous tracer's arithmetic instead of following a barrier
-	double pq[2] = { 0.0, 0.0 }, pr[2] = { 0.0, 0.0 }, pup = 0.0;
-	const bool mine = k < L && col < p.ncol;
-	auto prefetch = [&](int c) {
-#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int li = y + h * KT, l = k0 - 2 + li;
-			if (li < NL && l >= 0 && l < L) {
-				pq[h] = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
-				if (ks != 0.0) pr[h] = xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
-			}
-		}
-		if (mine) pup = xup[(size_t)TMX_SLAB_Q(L, c, k) * NS + col];
-	};
-	if (nt > 0) prefetch(0);
 	for (int c = 0; c < nt; c++) {
 		__syncthreads();           // first pass: the staging above; later passes: the previous tracer's reads of s_q / s_mr
 #pragma unroll
@@ -4697,6 +4698,9 @@ __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, con
 	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
 	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
 	const MetCol mcol = met_col(p, col);
+	// the values to update, loaded with the operands (at the point of use their latency would follow the whole evaluation)
+	const double upW = xup[TMX_SLAB_W(L, k) * NS + col];
+	const double upT = (k < L) ? xup[TMX_SLAB_T(L, k) * NS + col] : 0.0, upR = (k < L) ? xup[TMX_SLAB_R(L, k) * NS + col] : 0.0;
 	const NodeLev nA = load_node(p, mcol, xin, k - 1, col), nB = load_node(p, mcol, xin, k, col), nC = load_node(p, mcol, xin, k + 1, col);
 	const EdgeLev eA = load_edge(p, mcol, xin, k - 1, col), eB = load_edge(p, mcol, xin, k, col), eC = load_edge(p, mcol, xin, k + 1, col);
 	double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
@@ -4731,10 +4735,10 @@ __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, con
 	}
 	compute_block<false, UD>(p, p.ops, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, udP, udW);
 	if (k < L) {
-		xup[TMX_SLAB_T(L, k) * NS + col] -= dt * fP;
-		xup[TMX_SLAB_R(L, k) * NS + col] -= dt * fR;
+		xup[TMX_SLAB_T(L, k) * NS + col] = upT - dt * fP;
+		xup[TMX_SLAB_R(L, k) * NS + col] = upR - dt * fR;
 	}
-	xup[TMX_SLAB_W(L, k) * NS + col] -= dt * fW;
+	xup[TMX_SLAB_W(L, k) * NS + col] = upW - dt * fW;
 	if (UVX && k < L) v_explicit_point<UD>(p, xin, xup, dt, xref, cw, col, k);
 }
 
