@@ -229,7 +229,10 @@ __device__ __forceinline__ double exner_from_rhotheta_lds(const KParams & p, dou
 // inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
 // results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
 template <bool FUSE_V, int NT, bool MF>
-__global__ __launch_bounds__(64 * KT_H) void k_h_explicit(KParams p, const double * __restrict__ xin,
+#ifndef TMX_H_MINWG
+#define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
+#endif
+__global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
 {
 	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
