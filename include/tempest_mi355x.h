@@ -428,7 +428,8 @@ int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long long out[2])
 
 /* Host logic of the stepper programs, no device needed (tests/): the whole-instance copies a time scheme's program performs per
  * step and the ones it replaces by slot sharing (a CopyData in front of a V.StepImplicit that does nothing reads its source's
- * slot until it is overwritten: fully explicit vertical mode VerticalDynamicsFEM.cpp:1239-1242, VerticalDynamicsStub), decided
+ * slot until it is overwritten: fully explicit vertical mode VerticalDynamicsFEM.cpp:1239-1242, VerticalDynamicsStub; with
+ * implicit vertical dynamics the same for the U,V slabs, which the column solve does not touch), decided
  * exactly as tmx_step decides them.  mode 0: implicit vertical dynamics, 1: fully explicit, 2: shallow water; `steps`
  * consecutive steps, counts of the last one; share = 0 switches the sharing off (TMX_SHARE_COPIES=0). */
 int tmx_debug_program_copies(int scheme, int mode, int steps, int share, int * copies, int * shared);

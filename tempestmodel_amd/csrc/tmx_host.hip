@@ -149,6 +149,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->fully_explicit = cfg->fully_explicit != 0; e->udiff = cfg->uniform_diffusion != 0;
 	e->imap.resize(cfg->n_instances);
 	for (int k = 0; k < cfg->n_instances; k++) e->imap[k] = k;
+	e->uvmap = e->imap;
 	if (const char * v = getenv("TMX_SHARE_COPIES")) e->share_copies = atoi(v);
 	if (const char * v = getenv("TMX_XCD_VERTICAL")) e->xcd_vertical = atoi(v) ? 1 : 0;
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
@@ -1320,16 +1321,27 @@ static int check_inst(tmx_engine * e, int ix) {
 	return settle_instance(e, ix);
 }
 static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)e->imap[ix] * e->inst_stride; }
+// where the U,V slabs of an instance live (the first 2 L slabs of a slot): its slot, or the slot it shares U,V with
+static const double * inst_uv(tmx_engine * e, int ix) { return e->d_state + (size_t)(e->uvmap[ix] != ix ? e->uvmap[ix] : e->imap[ix]) * e->inst_stride; }
 // Entry points other than tmx_step see the instances they name in slots of their own: an instance that reads another one's
 // slot, or whose slot others read (b == ix or imap[b] == ix), gets the CopyData that was left out.  b < 0: all of them.
+// Shared U,V slabs are settled inside a stepper program too: the operations that understand them (the fused explicit stage)
+// do not come through here.
 static int settle_instance(tmx_engine * e, int ix) {
-	if (!e->n_shared || e->in_program) return TMX_OK;
-	for (int b = 0; b < (int)e->imap.size(); b++) {
-		if (e->imap[b] == b || !(ix < 0 || b == ix || e->imap[b] == ix)) continue;
-		HIPCHK(hipMemcpyAsync(e->d_state + (size_t)b * e->inst_stride, e->d_state + (size_t)e->imap[b] * e->inst_stride,
-			e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-		e->imap[b] = b; e->n_shared--;
-	}
+	if (e->n_shared && !e->in_program)
+		for (int b = 0; b < (int)e->imap.size(); b++) {
+			if (e->imap[b] == b || !(ix < 0 || b == ix || e->imap[b] == ix)) continue;
+			HIPCHK(hipMemcpyAsync(e->d_state + (size_t)b * e->inst_stride, e->d_state + (size_t)e->imap[b] * e->inst_stride,
+				e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+			e->imap[b] = b; e->n_shared--;
+		}
+	if (e->n_uvshared)
+		for (int b = 0; b < (int)e->uvmap.size(); b++) {
+			if (e->uvmap[b] == b || !(ix < 0 || b == ix || e->uvmap[b] == ix)) continue;
+			HIPCHK(hipMemcpyAsync(e->d_state + (size_t)b * e->inst_stride, e->d_state + (size_t)e->uvmap[b] * e->inst_stride,
+				(size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+			e->uvmap[b] = b; e->n_uvshared--;
+		}
 	return TMX_OK;
 }
 
@@ -1449,12 +1461,14 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 
 // CopyData(initial -> update) followed by StepExplicit(initial, update) in one pass:
 // update = initial + dt * rhs(initial), bit-identical to the two reference calls
-static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int dst, const double ** src, double * cf, int * premul) {
+static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int dst, const double ** src, double * cf, int * premul, const double ** srcuv = nullptr) {
 	int n = 1;
 	src[0] = inst(e, dst); cf[0] = coeff[dst];
+	if (srcuv) srcuv[0] = inst_uv(e, dst);
 	for (int m = 0; m < n_coeff; m++) {
 		if (m == dst || coeff[m] == 0.0) continue;
 		if (n >= 12) return -1;
+		if (srcuv) srcuv[n] = inst_uv(e, m);
 		src[n] = inst(e, m); cf[n] = coeff[m]; n++;
 	}
 	*premul = (coeff[dst] != 0.0) ? 1 : 0;
@@ -1465,11 +1479,15 @@ static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int 
 // evaluated inside the kernels (same accumulation order), the combined state is never written and re-read.
 // the kernels of one explicit stage (H + tracers + uniform diffusion + V) over the tiles make_params() selects: all of them,
 // or the tile list of a boundary-first stage (e->stage_quads).  n > 0: the update starts from the combination src / cf.
-static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, double dt, int n, const double * const * src, const double * cf, int premul) {
+static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, double dt, int n, const double * const * src, const double * cf, int premul,
+	const double * const * srcuv) {
 	int r;
+	// U,V slabs that live in another instance's slot are understood by k_h_explicit only; the kernels of the other configurations
+	// read them through the instance pointer, and the stepper never shares U,V there
+	REQUIRE(!e->n_uvshared || (e->nt == 0 && !e->udiff && !e->fully_explicit && !e->sw), TMX_ERR_UNSUPPORTED, "internal: shared U,V slabs in a configuration whose kernels do not take them");
 	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
-	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul);
-	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1);
+	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul, inst_uv(e, iinit), inst_uv(e, iupd), srcuv);
+	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1, 0, nullptr, nullptr, 0, inst_uv(e, iinit), inst_uv(e, ibase), nullptr);
 	if (e->nt > 0) {
 		if (n > 0) {
 			// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
@@ -1495,12 +1513,12 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 }
 
 static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double dt, const double * coeff, int n_coeff) {
-	const double * src[12]; double cf[12]; int premul = 0;
-	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul);
+	const double * src[12], * srcuv[12]; double cf[12]; int premul = 0;
+	const int n = lincomb_terms(e, coeff, n_coeff, iupd, src, cf, &premul, srcuv);
 	REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
 	int r;
-	if ((r = hv_stage_kernels(e, iinit, iupd, iupd, dt, n, src, cf, premul))) return r;
+	if ((r = hv_stage_kernels(e, iinit, iupd, iupd, dt, n, src, cf, premul, srcuv))) return r;
 	if ((r = surface_lincomb(e, iupd, n, src, cf, premul))) return r;
 	return launch_check("hv_step_explicit(lincomb)");
 }
@@ -1511,7 +1529,7 @@ static int hv_step_explicit_lincomb(tmx_engine * e, int iinit, int iupd, double 
 static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
 	int r;
-	if ((r = hv_stage_kernels(e, iinit, ibase, iupd, dt, 0, nullptr, nullptr, 0))) return r;
+	if ((r = hv_stage_kernels(e, iinit, ibase, iupd, dt, 0, nullptr, nullptr, 0, nullptr))) return r;
 	if ((r = surface_copy(e, ibase, iupd))) return r;       // the folded CopyData(base -> update)
 	return launch_check("hv_step_explicit");
 }
@@ -1531,9 +1549,9 @@ static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool ov
 static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped, int g_first);
 
 static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
-	const double * src[12]; double cf[12]; int premul = 0, n = 0;
+	const double * src[12], * srcuv[12]; double cf[12]; int premul = 0, n = 0;
 	if (lc) {
-		n = lincomb_terms(e, lc, nlc, iupd, src, cf, &premul);
+		n = lincomb_terms(e, lc, nlc, iupd, src, cf, &premul, srcuv);
 		REQUIRE(n > 0, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 	}
 	int r = TMX_OK;
@@ -1542,7 +1560,7 @@ static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double
 		e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
 		{
 			ProfScope ps(e, TMX_K_H_EXPLICIT);
-			r = hv_stage_kernels(e, iinit, ibase, iupd, dt, n, src, cf, premul);
+			r = hv_stage_kernels(e, iinit, ibase, iupd, dt, n, src, cf, premul, lc ? srcuv : nullptr);
 		}
 		e->stage_quads = nullptr;
 		if (part == 0 && !r) {
@@ -2336,21 +2354,34 @@ static bool share_is_safe(const Program & p, size_t first, int a, int b) {
 	return !a_written;
 }
 
-// an operation is about to write instance x: give it its own slot back (with its contents unless the write is total)
+// an operation is about to write instance x: give it its own slot back (with its contents unless the write is total); the
+// same for U,V slabs it shares
 static int own_slot(tmx_engine * e, int x, bool total) {
-	if (e->imap[x] == x) return TMX_OK;
-	if (!total) {
-		if (e->dry_run) e->dry_copies++;
-		else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
-			e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	if (e->imap[x] != x) {
+		if (!total) {
+			if (e->dry_run) e->dry_copies++;
+			else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
+				e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		}
+		e->imap[x] = x; e->n_shared--;
 	}
-	e->imap[x] = x; e->n_shared--;
+	if (e->uvmap[x] != x) {
+		if (!total) {
+			if (e->dry_run) e->dry_copies++;
+			else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->uvmap[x] * e->inst_stride,
+				(size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		}
+		e->uvmap[x] = x; e->n_uvshared--;
+	}
 	return TMX_OK;
 }
-// instance x has been written: the instances that read its slot are dead by share_is_safe and go back to their own
+// instance x has been written: the instances that read its slot (or its U,V slabs) are dead by share_is_safe and go back to
+// their own
 static void drop_readers(tmx_engine * e, int x) {
-	for (int y = 0; y < (int)e->imap.size(); y++)
+	for (int y = 0; y < (int)e->imap.size(); y++) {
 		if (y != x && e->imap[y] == x) { e->imap[y] = y; e->n_shared--; }
+		if (y != x && e->uvmap[y] == x) { e->uvmap[y] = y; e->n_uvshared--; }
+	}
 }
 
 struct ProgramScope {
@@ -2360,7 +2391,7 @@ struct ProgramScope {
 };
 struct AfterOp {      // at the end of an operation: the readers of the slots it wrote
 	tmx_engine * e; unsigned w;
-	~AfterOp() { for (int x = 0; x < (int)e->imap.size() && e->n_shared; x++) if (w >> x & 1u) drop_readers(e, x); }
+	~AfterOp() { for (int x = 0; x < (int)e->imap.size() && (e->n_shared || e->n_uvshared); x++) if (w >> x & 1u) drop_readers(e, x); }
 };
 
 // RUN: the launches of an operation; a dry run (tmx_debug_program_copies: the copy / sharing decisions of a program on the
@@ -2371,15 +2402,16 @@ static int run_program(tmx_engine * e, const Program & p) {
 	const size_t n = p.size();
 	ProgramScope scope(e);
 	// shared slots left by the previous step: kept where this program allows it, given their own copy otherwise
-	for (int b = 0; b < (int)e->imap.size() && e->n_shared; b++)
-		if (e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b) && (r = own_slot(e, b, false))) return r;
+	for (int b = 0; b < (int)e->imap.size() && (e->n_shared || e->n_uvshared); b++)
+		if ((e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b)) || (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b)))
+			if ((r = own_slot(e, b, false))) return r;
 	for (size_t i = 0; i < n; i++) {
 		const Op & o = p[i];
 		const Op * n1 = (i + 1 < n) ? &p[i + 1] : nullptr;
 		const Op * n2 = (i + 2 < n) ? &p[i + 2] : nullptr;
 		// the instances this operation (and the ones fused with it below, which write the same instance) writes
 		const OpAccess acc = op_access(o);
-		for (int x = 0; x < (int)e->imap.size() && e->n_shared; x++)
+		for (int x = 0; x < (int)e->imap.size() && (e->n_shared || e->n_uvshared); x++)
 			if (((acc.full | acc.part) >> x & 1u) && (r = own_slot(e, x, (acc.full >> x & 1u) != 0))) return r;
 		AfterOp after = { e, acc.full | acc.part };
 		switch (o.kind) {
@@ -2401,8 +2433,20 @@ static int run_program(tmx_engine * e, const Program & p) {
 				size_t j = i + 1;
 				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
 				if (!e->sw && !e->fully_explicit && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
-					if ((r = RUN(copy_uv(e, o.a, o.b)))) return r;
+					// ... and U,V need not be copied either while the copy's U,V are only read by the fused explicit stage
+					// (k_h_explicit takes the U,V slabs of its initial instance and of the combination sources by separate
+					// pointers): the copy shares its source's U,V slabs under the rules of share_is_safe.  Not with tracers
+					// (k_h_tracers reads U,V through the instance pointer).
+					const bool share = e->share_copies && !e->use_graph && e->nt == 0 && e->imap[o.a] == o.a && e->uvmap[o.a] == o.a &&
+						share_is_safe(p, j + 1, o.a, o.b);
+					if (share) { if ((r = RUN(surface_copy(e, o.a, o.b)))) return r; }
+					else { if (e->dry_run) e->dry_copies++; if ((r = RUN(copy_uv(e, o.a, o.b)))) return r; }
 					if ((r = RUN(v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a)))) return r;
+					if (share) {
+						drop_readers(e, o.b);
+						e->uvmap[o.b] = o.a; e->n_uvshared++; e->dry_shared++;
+						after.w = 0;
+					}
 					i = j; break;
 				}
 			}
@@ -2480,7 +2524,8 @@ static int run_program(tmx_engine * e, const Program & p) {
 
 #undef RUN
 
-// The whole-instance copies a stepper program performs and the ones it replaces by slot sharing, decided exactly as
+// The instance copies a stepper program performs (whole instances; with implicit vertical dynamics the U,V slabs in front of
+// the column solve) and the ones it replaces by slot sharing, decided exactly as
 // run_program decides them, without a device: `steps` consecutive steps (the first with first_step set), counts of the last
 // one.  mode 0: implicit vertical dynamics, 1: fully explicit vertical mode, 2: shallow water.  Host logic for the CPU tests.
 extern "C" int tmx_debug_program_copies(int scheme, int mode, int steps, int share, int * copies, int * shared) {
@@ -2492,6 +2537,7 @@ extern "C" int tmx_debug_program_copies(int scheme, int mode, int steps, int sha
 	e.sw = mode == 2; e.fully_explicit = mode == 1; e.share_copies = share; e.dry_run = true;
 	e.imap.resize(need);
 	for (int k = 0; k < need; k++) e.imap[k] = k;
+	e.uvmap = e.imap;
 	for (int n = 0; n < steps; n++) {
 		Program p;
 		int r = build_program(scheme, n == 0, 0, 1.0, p, 0.0);

@@ -180,6 +180,10 @@ struct tmx_engine {
 	// other entry point settles the map first (settle_instance_map).
 	std::vector<int> imap;
 	int n_shared = 0;                        // instances that currently read another instance's slot
+	// the same for the U,V slabs alone (implicit vertical dynamics: the column solve that follows the CopyData rewrites rho*theta,
+	// W, rho of the copy, its U,V stay the source's): slot holding the U,V slabs of a logical instance
+	std::vector<int> uvmap;
+	int n_uvshared = 0;
 	bool in_program = false;
 	int share_copies = 1;                    // TMX_SHARE_COPIES=0: perform every CopyData
 	bool dry_run = false; int dry_copies = 0, dry_shared = 0;     // tmx_debug_program_copies
@@ -202,7 +206,8 @@ void tmx_set_error(const char * fmt, ...);
 
 // kernel launchers (tmx_kernels.hip)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
-	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
+	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
+	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr);
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);

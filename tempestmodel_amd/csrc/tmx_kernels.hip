@@ -52,6 +52,10 @@
 // Linear combination of state instances in the reference's accumulation order
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508): v = c_d * X_d (or 0), then += c_m * X_m.
 struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
+// Where the U,V slabs of the instances named by a LinTerms (and of the stage's initial instance) live: the instance's own slot,
+// or the slot of the instance it was copied from when the stepper left the CopyData of U,V out (tmx_host.hip: the implicit
+// column solve rewrites rho*theta, W, rho of the copy but leaves U,V identical to the source's)
+struct UvTerms { const double * src[12]; const double * xin; };
 
 // base value of the update instance at flat offset o: either a plain instance (n == 0: src[0] is the base
 // pointer) or the linear combination evaluated on the fly, so that LinearCombineData + StepExplicit is one
@@ -86,6 +90,19 @@ __device__ __forceinline__ double base_value_u(const LinTerms & t, size_t slab_o
 	double x[NT > 0 ? NT : 1];
 #pragma unroll
 	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(t.src[m] + slab_off, colb) : 0.0;
+	double v = t.premul ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
+	return v;
+}
+
+// the same for a U or V slab: sources from the UvTerms
+template <int NT>
+__device__ __forceinline__ double base_value_uv(const LinTerms & t, const UvTerms & uv, size_t slab_off, unsigned colb) {
+	if (NT == 0) return ldu(uv.src[0] + slab_off, colb);
+	double x[NT > 0 ? NT : 1];
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(uv.src[m] + slab_off, colb) : 0.0;
 	double v = t.premul ? x[0] * t.coef[0] : 0.0;
 #pragma unroll
 	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
@@ -233,7 +250,7 @@ template <bool FUSE_V, int NT, bool MF>
 #define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
 #endif
 __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
-	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt)
+	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
 {
 	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
 	__shared__ double sD[16], sS[16];
@@ -259,15 +276,16 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
 		const unsigned cb = (unsigned)col * 8u;
-		ua = ldu(xin + TMX_SLAB_U(L, k) * NS, cb);
-		ub = ldu(xin + TMX_SLAB_V(L, k) * NS, cb);
+		const double * __restrict__ xuv = uvt.xin;      // U,V of the initial instance (its own slot or the one it shares)
+		ua = ldu(xuv + TMX_SLAB_U(L, k) * NS, cb);
+		ub = ldu(xuv + TMX_SLAB_V(L, k) * NS, cb);
 		rt = ldu(xin + TMX_SLAB_T(L, k) * NS, cb);
 		rh = ldu(xin + TMX_SLAB_R(L, k) * NS, cb);
 		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * NS, cb);
 		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * NS, cb);
-		const double uam = ldu(xin + TMX_SLAB_U(L, km) * NS, cb), uap = ldu(xin + TMX_SLAB_U(L, kp) * NS, cb);
-		const double ubm = ldu(xin + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xin + TMX_SLAB_V(L, kp) * NS, cb);
-		bU = base_value_u<NT>(xbase, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_u<NT>(xbase, TMX_SLAB_V(L, k) * NS, cb);
+		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * NS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * NS, cb);
+		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * NS, cb);
+		bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * NS, cb);
 		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * NS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * NS, cb);
 		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * NS, cb);
 		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
@@ -475,14 +493,18 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	}
 }
 
+// xin_uv / xbase_uv / src_uv: where the U,V slabs of the initial instance, the base instance and the combination sources
+// live when that is not the instance's own slot (NULL: the same pointers)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
-	int nterms, const double * const * src, const double * coef, int premul) {
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv) {
 	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
 	LinTerms xbase;
+	UvTerms uvt;
 	xbase.n = nterms; xbase.premul = premul;
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
-	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
-	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
+	uvt.xin = xin_uv ? xin_uv : xin; uvt.src[0] = xbase_uv ? xbase_uv : xbase_ptr;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	dim3 blk(64, KT_H), grd(ntile, (p.L + KT_H - 1) / KT_H);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
@@ -490,9 +512,9 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	dim3 blk2(64, 4), grd2(ntile, ((p.L + wstride - 1) / wstride + 1 + 3) / 4);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
 #define LAUNCH_HV(NT_) do { \
-		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
-		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
-		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt); \
+		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
 		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HV(0); break;

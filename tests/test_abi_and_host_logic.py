@@ -177,8 +177,8 @@ def test_stepper_programs_share_the_copies_in_front_of_a_stub_implicit_step():
     replaces by letting the copy read its source's slot (tmx_debug_program_copies runs the program's own decision code
     without launches).  ARS343 in the fully explicit vertical mode and in shallow water: the three CopyData in front of
     V.StepImplicit (TimestepSchemeARS343.cpp:150-236) are shared, none is made, also in steady state (the slots shared at
-    the end of a step are re-validated against the next step's program); with implicit vertical dynamics nothing is
-    shared.  Every scheme: sharing never adds copies, and copies + shared is what the program asks for."""
+    the end of a step are re-validated against the next step's program); with implicit vertical dynamics the U,V slabs of
+    those copies are shared (the solve rewrites the rest).  Every scheme: sharing never adds copies, and copies + shared is what the program asks for."""
     from tempestmodel_amd.engine import Engine, load_library
     lib = load_library()
     lib.tmx_debug_program_copies.restype = ctypes.c_int
@@ -196,7 +196,10 @@ def test_stepper_programs_share_the_copies_in_front_of_a_stub_implicit_step():
         assert run("ars343", 2, steps, 1) == (1, 3)
         assert run("ars343", 2, steps, 0) == (4, 0)
     assert run("ars232", 1, 3, 1) == (2, 2)
-    assert run("ars343", 0, 3, 1)[1] == 0          # the implicit solve changes the copy: nothing to share
+    # implicit vertical dynamics: the column solve rewrites rho*theta, W, rho of the copy; its U,V slabs are shared instead of copied
+    for steps in (1, 2, 5):
+        assert run("ars343", 0, steps, 1) == (0, 3)
+        assert run("ars343", 0, steps, 0) == (3, 0)
     for scheme in Engine.SCHEMES:
         for mode in (0, 1, 2):
             for steps in (1, 3):

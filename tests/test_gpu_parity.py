@@ -1983,3 +1983,38 @@ def test_kessler_level_parallel_kernel_with_several_rain_sub_cycles(monkeypatch)
         for P in g.patches:
             assert np.array_equal(out[0][2][P.index][1:-1, 1:-1], out[1][2][P.index][1:-1, 1:-1])
         assert max(float(np.max(a)) for a in out[0][2].values()) > 0.0
+
+
+@pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "ark232", "strang"])
+def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypatch, scheme):
+    """Implicit vertical dynamics: the CopyData in front of V.StepImplicit is not made at all -- the solve rewrites rho*theta,
+    W, rho of the copy, and its U,V slabs are read from the source's slot by the fused explicit stage (TMX_SHARE_COPIES=0: U,V
+    copied as before).  Same doubles in instance 0 and in every stage instance a caller asks for between steps."""
+    from tempestmodel_amd.engine import Engine
+    g, states = gu.make_grid(4, 8, 6)
+    ninst = Engine.scheme_instances(scheme)
+    runs = []
+    for variant in ({}, {"TMX_SHARE_COPIES": "0"}, {"probe": True}):
+        monkeypatch.delenv("TMX_SHARE_COPIES", raising=False)
+        for k, v in variant.items():
+            if k.startswith("TMX_"):
+                monkeypatch.setenv(k, v)
+        e = Engine(g, n_instances=ninst)
+        try:
+            e.upload_state(0, states)
+            for step in (1, 2, 3):
+                e.step(scheme, 200.0, first=(step == 1))
+                if variant.get("probe"):
+                    for ix in range(1, ninst):
+                        e.download_state(ix)
+                    e.upload_state(ninst - 1, e.download_state(ninst - 1))
+            e.sync()
+            runs.append([e.download_state(ix) for ix in range(ninst)])
+        finally:
+            e.close()
+    work = {"ars343": {2}}.get(scheme, set(range(1, ninst)))
+    for other in runs[1:]:
+        for ix in range(ninst):
+            if ix != 0 and ix in work:
+                continue
+            assert max(gu.prognostic_errors(runs[0][ix], other[ix])) <= EXACT, (scheme, ix)
