@@ -1482,9 +1482,9 @@ static int lincomb_terms(tmx_engine * e, const double * coeff, int n_coeff, int 
 static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, double dt, int n, const double * const * src, const double * cf, int premul,
 	const double * const * srcuv) {
 	int r;
-	// U,V slabs that live in another instance's slot are understood by k_h_explicit only; the kernels of the other configurations
+	// U,V slabs that live in another instance's slot are understood by k_h_explicit and k_h_tracers only; the kernels of the other configurations
 	// read them through the instance pointer, and the stepper never shares U,V there
-	REQUIRE(!e->n_uvshared || (e->nt == 0 && !e->udiff && !e->fully_explicit && !e->sw), TMX_ERR_UNSUPPORTED, "internal: shared U,V slabs in a configuration whose kernels do not take them");
+	REQUIRE(!e->n_uvshared || (!e->udiff && !e->fully_explicit && !e->sw), TMX_ERR_UNSUPPORTED, "internal: shared U,V slabs in a configuration whose kernels do not take them");
 	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
 	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul, inst_uv(e, iinit), inst_uv(e, iupd), srcuv);
 	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1, 0, nullptr, nullptr, 0, inst_uv(e, iinit), inst_uv(e, ibase), nullptr);
@@ -1497,11 +1497,11 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 				const double * tsrc[12];
 				for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
 				tmxk_lincomb(e, cnt, inst(e, iupd) + off, n, tsrc, cf, premul);
-				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0, nullptr, nullptr, 0, inst_uv(e, iinit));
 			} else
-				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, n, src, cf, premul);
+				tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, n, src, cf, premul, inst_uv(e, iinit));
 		} else
-			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
+			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 0, nullptr, nullptr, 0, inst_uv(e, iinit));
 	}
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
 	const bool uvx = uvx_fused(e);
@@ -2435,9 +2435,9 @@ static int run_program(tmx_engine * e, const Program & p) {
 				if (!e->sw && !e->fully_explicit && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
 					// ... and U,V need not be copied either while the copy's U,V are only read by the fused explicit stage
 					// (k_h_explicit takes the U,V slabs of its initial instance and of the combination sources by separate
-					// pointers): the copy shares its source's U,V slabs under the rules of share_is_safe.  Not with tracers
-					// (k_h_tracers reads U,V through the instance pointer).
-					const bool share = e->share_copies && !e->use_graph && e->nt == 0 && e->imap[o.a] == o.a && e->uvmap[o.a] == o.a &&
+					// pointers, k_h_tracers those of its initial instance): the copy shares its source's U,V slabs under the rules
+					// of share_is_safe.
+					const bool share = e->share_copies && !e->use_graph && e->imap[o.a] == o.a && e->uvmap[o.a] == o.a &&
 						share_is_safe(p, j + 1, o.a, o.b);
 					if (share) { if ((r = RUN(surface_copy(e, o.a, o.b)))) return r; }
 					else { if (e->dry_run) e->dry_copies++; if ((r = RUN(copy_uv(e, o.a, o.b)))) return r; }

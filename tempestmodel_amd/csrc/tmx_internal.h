@@ -226,7 +226,7 @@ void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const doubl
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt,
-	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0);
+	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0, const double * xin_uv = nullptr);
 void tmxk_hypervis_block(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v, int scale_locally);
 void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale_locally);

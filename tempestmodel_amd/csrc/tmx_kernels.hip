@@ -817,7 +817,7 @@ void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
 // kernels (base_value) instead of by a k_lincomb pass over the tracer slabs in front of this kernel.
 template <bool UD, int NT>
 __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const double * __restrict__ area,
-	const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, double ks)
+	const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, double ks, const double * __restrict__ xuv)      // xuv: slot holding xin's U,V slabs
 {
 	__shared__ double s[4][5][64];
 	__shared__ double sS[16], sD[16];
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 	double fa = 0.0, fb = 0.0, invJ = 0.0, ar = 0.0;
 	double dc2a0 = 0.0, dc2a1 = 0.0, dc2b1 = 0.0, djn = 0.0, rho = 1.0;      // uniform diffusion only
 	if (act) {
-		const double ua = ldu(xin + TMX_SLAB_U(L, kc) * NS, cb), ub = ldu(xin + TMX_SLAB_V(L, kc) * NS, cb);
+		const double ua = ldu(xuv + TMX_SLAB_U(L, kc) * NS, cb), ub = ldu(xuv + TMX_SLAB_V(L, kc) * NS, cb);
 		const double we0 = ldu(xin + TMX_SLAB_W(L, kc) * NS, cb), we1 = ldu(xin + TMX_SLAB_W(L, kc + 1) * NS, cb);
 		const double c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb), c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb), c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
 		const double jn = ldu(p.g2d + G2_JN * NS, cb);
@@ -898,7 +898,8 @@ __global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const doub
 }
 
 void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
-	int nterms, const double * const * src, const double * coef, int premul) {
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv) {
+	if (!xin_uv) xin_uv = xin;
 	LinTerms xbase;
 	xbase.n = nterms; xbase.premul = premul;
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
@@ -906,8 +907,8 @@ void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
 	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 #define LAUNCH_HT(NT_) do { \
-		if (e->udiff) hipLaunchKernelGGL((k_h_tracers<true, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar); \
-		else hipLaunchKernelGGL((k_h_tracers<false, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0); } while (0)
+		if (e->udiff) hipLaunchKernelGGL((k_h_tracers<true, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar, xin_uv); \
+		else hipLaunchKernelGGL((k_h_tracers<false, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0, xin_uv); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HT(0); break;
 		case 2: LAUNCH_HT(2); break;

@@ -1985,13 +1985,16 @@ def test_kessler_level_parallel_kernel_with_several_rain_sub_cycles(monkeypatch)
         assert max(float(np.max(a)) for a in out[0][2].values()) > 0.0
 
 
+@pytest.mark.parametrize("ntr", [0, 2])
 @pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "ark232", "strang"])
-def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypatch, scheme):
+def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypatch, scheme, ntr):
     """Implicit vertical dynamics: the CopyData in front of V.StepImplicit is not made at all -- the solve rewrites rho*theta,
-    W, rho of the copy, and its U,V slabs are read from the source's slot by the fused explicit stage (TMX_SHARE_COPIES=0: U,V
-    copied as before).  Same doubles in instance 0 and in every stage instance a caller asks for between steps."""
+    W, rho of the copy, and its U,V slabs are read from the source's slot by the fused explicit stage and the tracer flux kernel
+    (TMX_SHARE_COPIES=0: U,V copied as before).  Same doubles in instance 0 and in every stage instance a caller asks for
+    between steps, without and with tracers."""
     from tempestmodel_amd.engine import Engine
-    g, states = gu.make_grid(4, 8, 6)
+    g, states = gu.make_grid(4, 8, 6, ntracers=ntr)
+    tracers = [np.stack([(0.01 + 0.002 * t) * n[4] * (1.0 + 0.1 * np.sin(3.0 * t + n[0] / 20.0)) for t in range(ntr)]) for n, _ in states] if ntr else None
     ninst = Engine.scheme_instances(scheme)
     runs = []
     for variant in ({}, {"TMX_SHARE_COPIES": "0"}, {"probe": True}):
@@ -2002,6 +2005,8 @@ def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypa
         e = Engine(g, n_instances=ninst)
         try:
             e.upload_state(0, states)
+            if ntr:
+                e.upload_tracers(0, tracers)
             for step in (1, 2, 3):
                 e.step(scheme, 200.0, first=(step == 1))
                 if variant.get("probe"):
@@ -2009,7 +2014,7 @@ def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypa
                         e.download_state(ix)
                     e.upload_state(ninst - 1, e.download_state(ninst - 1))
             e.sync()
-            runs.append([e.download_state(ix) for ix in range(ninst)])
+            runs.append([(e.download_state(ix), e.download_tracers(ix) if ntr else None) for ix in range(ninst)])
         finally:
             e.close()
     work = {"ars343": {2}}.get(scheme, set(range(1, ninst)))
@@ -2017,4 +2022,6 @@ def test_uv_slabs_shared_in_front_of_the_column_solve_are_bit_identical(monkeypa
         for ix in range(ninst):
             if ix != 0 and ix in work:
                 continue
-            assert max(gu.prognostic_errors(runs[0][ix], other[ix])) <= EXACT, (scheme, ix)
+            assert max(gu.prognostic_errors(runs[0][ix][0], other[ix][0])) <= EXACT, (scheme, ix)
+            if ntr:
+                assert max(gu.tracer_errors(runs[0][ix][1], other[ix][1])) <= EXACT, (scheme, ix)
