@@ -2319,12 +2319,14 @@ static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { r
 // What an operation of a stepper program reads and writes, as bit masks over the data instances.  full: instances it
 // overwrites entirely without reading them; part: instances it updates in place.
 struct OpAccess { unsigned reads, full, part; bool stencil; };
-static OpAccess op_access(const Op & o) {
+// vimp_noop: V.StepImplicit does nothing (fully explicit vertical mode, shallow water's stub)
+static OpAccess op_access(const Op & o, bool vimp_noop) {
 	OpAccess x = { 0u, 0u, 0u, true };
 	auto bit = [](int k) { return 1u << k; };
 	switch (o.kind) {
 	case OP_COPY: x.reads = bit(o.a); x.full = bit(o.b); break;
-	case OP_HEXP: case OP_VEXP: case OP_VITE: case OP_VIMP: x.reads = bit(o.a) | bit(o.b); x.part = bit(o.b); break;
+	case OP_VIMP: if (vimp_noop) break;      // fall through
+	case OP_HEXP: case OP_VEXP: case OP_VITE: x.reads = bit(o.a) | bit(o.b); x.part = bit(o.b); break;
 	case OP_DSS: case OP_VFILT: x.reads = bit(o.a); x.part = bit(o.a); break;
 	case OP_HVIS: x.reads = bit(o.a); x.full = bit(o.b) | bit(o.c); break;
 	case OP_LINCOMB:
@@ -2340,11 +2342,11 @@ static OpAccess op_access(const Op & o) {
 // Yes if, until b is next overwritten entirely, nothing updates b in place, and once a has been written b is not read again
 // (b is dead from there on); a stencil operation must not write a while it reads b.  A program that ends with the two still
 // identical leaves them shared; one that ends after a was written would leave b undefined, so it is refused.
-static bool share_is_safe(const Program & p, size_t first, int a, int b) {
+static bool share_is_safe(const Program & p, size_t first, int a, int b, bool vimp_noop) {
 	const unsigned ba = 1u << a, bb = 1u << b;
 	bool a_written = false;
 	for (size_t i = first; i < p.size(); i++) {
-		const OpAccess x = op_access(p[i]);
+		const OpAccess x = op_access(p[i], vimp_noop);
 		if (x.part & bb) return false;
 		if ((x.reads & bb) && a_written) return false;
 		if (((x.full | x.part) & ba) && (x.reads & bb) && x.stencil) return false;
@@ -2401,16 +2403,17 @@ static int run_program(tmx_engine * e, const Program & p) {
 	int r;
 	const size_t n = p.size();
 	ProgramScope scope(e);
+	const bool noop = e->sw || e->fully_explicit;      // V.StepImplicit does nothing
 	// shared slots left by the previous step: kept where this program allows it, given their own copy otherwise
 	for (int b = 0; b < (int)e->imap.size() && (e->n_shared || e->n_uvshared); b++)
-		if ((e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b)) || (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b)))
+		if ((e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b, noop)) || (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b, noop)))
 			if ((r = own_slot(e, b, false))) return r;
 	for (size_t i = 0; i < n; i++) {
 		const Op & o = p[i];
 		const Op * n1 = (i + 1 < n) ? &p[i + 1] : nullptr;
 		const Op * n2 = (i + 2 < n) ? &p[i + 2] : nullptr;
 		// the instances this operation (and the ones fused with it below, which write the same instance) writes
-		const OpAccess acc = op_access(o);
+		const OpAccess acc = op_access(o, noop);
 		for (int x = 0; x < (int)e->imap.size() && (e->n_shared || e->n_uvshared); x++)
 			if (((acc.full | acc.part) >> x & 1u) && (r = own_slot(e, x, (acc.full >> x & 1u) != 0))) return r;
 		AfterOp after = { e, acc.full | acc.part };
@@ -2438,7 +2441,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 					// pointers, k_h_tracers those of its initial instance): the copy shares its source's U,V slabs under the rules
 					// of share_is_safe.
 					const bool share = e->share_copies && !e->use_graph && e->imap[o.a] == o.a && e->uvmap[o.a] == o.a &&
-						share_is_safe(p, j + 1, o.a, o.b);
+						share_is_safe(p, j + 1, o.a, o.b, noop);
 					if (share) { if ((r = RUN(surface_copy(e, o.a, o.b)))) return r; }
 					else { if (e->dry_run) e->dry_copies++; if ((r = RUN(copy_uv(e, o.a, o.b)))) return r; }
 					if ((r = RUN(v_step_implicit_impl(e, o.a, o.b, p[j].coef, o.a)))) return r;
@@ -2450,23 +2453,19 @@ static int run_program(tmx_engine * e, const Program & p) {
 					i = j; break;
 				}
 			}
-			// Copy(a->b) [+ copies of the same] + V.StepImplicit(b,b,c) where the implicit step does nothing (fully explicit
-			// vertical mode :1239-1242, shallow water's stub): b stays identical to a, so it reads a's slot until it is
-			// overwritten -- no copy (config 4: three whole-state copies per ARS343 step)
-			{
-				size_t j = i + 1;
-				while (j < n && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
-				if ((e->sw || e->fully_explicit) && e->share_copies && !e->use_graph && j < n && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b &&
-				    o.a != o.b && e->imap[o.a] == o.a && share_is_safe(p, j + 1, o.a, o.b)) {
-					drop_readers(e, o.b);      // (dead by the same argument: b is overwritten here)
-					e->imap[o.b] = o.a; e->n_shared++; e->dry_shared++;
-					after.w = 0;
-					i = j; break;
-				}
-			}
 			// Copy(a->b) + StepAfterSubCycle(a,b,w): every branch of StepAfterSubCycle rewrites all of b from a (the second
 			// hyperviscosity pass and the order-2 pass write every slab with a as their base; without viscosity it IS the copy)
 			if (n1 && n1->kind == OP_HVIS && n1->a == o.a && n1->b == o.b && o.a != o.b) break;
+			// Any other Copy(a->b) whose copy is only read until it is next overwritten entirely (share_is_safe) is not made: b
+			// reads a's slot.  The case that matters: the copies in front of a V.StepImplicit that does nothing (fully explicit
+			// vertical mode :1239-1242, shallow water's stub) -- config 4: three whole-state copies per ARS343 step.
+			// (not into instance 0: the model state, which everything outside a step reads)
+			if (e->share_copies && !e->use_graph && o.a != o.b && o.b != 0 && e->imap[o.a] == o.a && e->uvmap[o.a] == o.a && share_is_safe(p, i + 1, o.a, o.b, noop)) {
+				drop_readers(e, o.b);      // (dead by the same argument: b is overwritten here)
+				e->imap[o.b] = o.a; e->n_shared++; e->dry_shared++;
+				after.w = 0;
+				break;
+			}
 			if (e->dry_run) e->dry_copies++;
 			else if ((r = tmx_copy_data(e, o.a, o.b))) return r;
 			break;
