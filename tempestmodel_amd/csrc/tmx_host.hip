@@ -1576,15 +1576,16 @@ static int hv_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double
 	return dss_after_exchange(e, make_params(e), iupd, e->split_overlapped);
 }
 
-// the same for the shallow-water set, whose stage is H.StepExplicit in place on the update instance (V is a stub)
-static int sw_stage_split(tmx_engine * e, int iinit, int iupd, double dt) {
+// the same for the shallow-water set, whose stage is H.StepExplicit (V is a stub); ibase: the instance the update starts from
+// (== iupd in place, == the source of a CopyData(ibase -> iupd) folded in)
+static int sw_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double dt) {
 	int r = TMX_OK;
 	for (int part = 0; part < 2 && !r; part++) {
 		e->stage_quads = part ? e->d_quads_late : e->d_quads_early;
 		e->launch_tiles = part ? e->n_quads_late : e->n_quads_early;
 		{
 			ProfScope ps(e, TMX_K_H_EXPLICIT);
-			tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
+			tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt);
 		}
 		e->stage_quads = nullptr;
 		if (part == 0) {
@@ -2430,6 +2431,19 @@ static int run_program(tmx_engine * e, const Program & p) {
 				if ((r = RUN(hv_step_explicit(e, n1->a, o.a, o.b, n1->coef)))) return r;
 				i += 2; break;
 			}
+			// shallow water: Copy(a->b) + H(a,b,c) [+ V stub]: out = a + c * rhs(a) in one pass (k_sw_explicit takes the base apart)
+			if (e->sw && e->nt == 0 && n1 && n2 && n1->kind == OP_HEXP && n2->kind == OP_VEXP && n1->b == o.b && n2->a == n1->a && n2->b == o.b && n1->a != o.b && o.a != o.b) {
+				if (stage_can_split(e) && i + 3 < n && p[i + 3].kind == OP_DSS && p[i + 3].a == o.b) {
+					if ((r = RUN(sw_stage_split(e, n1->a, o.a, o.b, n1->coef)))) return r;
+					i += 3; break;
+				}
+				if (!e->dry_run) {
+					ProfScope ps(e, TMX_K_H_EXPLICIT);
+					tmxk_sw_explicit(e, make_params(e), inst(e, n1->a), inst(e, o.a), inst(e, o.b), n1->coef);
+					if ((r = launch_check("sw copy + H"))) return r;
+				}
+				i += 2; break;
+			}
 			// Copy(s->t) [twice in some schemes] + V.StepImplicit(t,t,c): the solve rewrites rho*theta, W, rho
 			// of every stored column, so only U,V need copying and the solve reads s directly
 			{
@@ -2471,7 +2485,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 			break;
 		case OP_HEXP:
 			if (e->sw && stage_can_split(e) && n1 && n2 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n2->kind == OP_DSS && n2->a == o.b && o.a != o.b) {
-				if ((r = RUN(sw_stage_split(e, o.a, o.b, o.coef)))) return r;
+				if ((r = RUN(sw_stage_split(e, o.a, o.b, o.b, o.coef)))) return r;
 				i += 2; break;
 			}
 			if (!e->sw && n1 && n1->kind == OP_VEXP && n1->a == o.a && n1->b == o.b && n1->coef == o.coef) {
