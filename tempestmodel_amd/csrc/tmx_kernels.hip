@@ -2512,6 +2512,16 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
 		if (!PULL) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
 	}
+	// the base of the update (second pass: the instance the viscosity is applied to), loaded with the operands: at the point
+	// of use its latency would follow three barriers and both contractions
+	double bW = 0.0, bT = 0.0, bR = 0.0, bU = 0.0, bV = 0.0;
+	if (xbase && actw) {
+		bW = xbase[TMX_SLAB_W(L, kk) * NS + col];
+		if (actn) {
+			bT = xbase[TMX_SLAB_T(L, kk) * NS + col]; bR = xbase[TMX_SLAB_R(L, kk) * NS + col];
+			bU = xbase[TMX_SLAB_U(L, kk) * NS + col]; bV = xbase[TMX_SLAB_V(L, kk) * NS + col];
+		}
+	}
 	if (!PULL && actn) {
 		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
 		psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
@@ -2578,27 +2588,15 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
 	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
 
-	{
-		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
-		const double b = xbase ? xbase[o] : 0.0;
-		xout[o] = b - dt * (1.0 / je) * nu_s * (uaW + ubW);
-	}
+	xout[TMX_SLAB_W(L, kk) * NS + col] = bW - dt * (1.0 / je) * nu_s * (uaW + ubW);
 	if (actn) {
 		const double invJ = 1.0 / jn;
-		size_t o = TMX_SLAB_T(L, kk) * NS + col;
-		double b = xbase ? xbase[o] : 0.0;
-		xout[o] = b - dt * invJ * nu_s * (uaT + ubT);
-		o = TMX_SLAB_R(L, kk) * NS + col;
-		b = xbase ? xbase[o] : 0.0;
-		xout[o] = b - dt * invJ * nu_s * (uaR + ubR);
+		xout[TMX_SLAB_T(L, kk) * NS + col] = bT - dt * invJ * nu_s * (uaT + ubT);
+		xout[TMX_SLAB_R(L, kk) * NS + col] = bR - dt * invJ * nu_s * (uaR + ubR);
 		const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
 		const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
-		o = TMX_SLAB_U(L, kk) * NS + col;
-		b = xbase ? xbase[o] : 0.0;
-		xout[o] = b - dt * upa;
-		o = TMX_SLAB_V(L, kk) * NS + col;
-		b = xbase ? xbase[o] : 0.0;
-		xout[o] = b - dt * upb;
+		xout[TMX_SLAB_U(L, kk) * NS + col] = bU - dt * upa;
+		xout[TMX_SLAB_V(L, kk) * NS + col] = bV - dt * upb;
 	}
 }
 
@@ -2815,6 +2813,10 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 		psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
 		psiW -= xref[TMX_SLAB_W(L, kk) * NS + col];
 	}
+	// the values to update, loaded with the operands (at the point of use their latency would follow the barriers)
+	double oW = 0.0, oT = 0.0, oU = 0.0, oV = 0.0;
+	if (actw) oW = xout[TMX_SLAB_W(L, kk) * NS + col];
+	if (actn) { oT = xout[TMX_SLAB_T(L, kk) * NS + col]; oU = xout[TMX_SLAB_U(L, kk) * NS + col]; oV = xout[TMX_SLAB_V(L, kk) * NS + col]; }
 	if (actn) {
 		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
 		psiT -= xref[TMX_SLAB_T(L, kk) * NS + col];
@@ -2869,20 +2871,20 @@ __global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const doub
 	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb; dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
 	{
 		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
-		xout[o] = xout[o] - dt * (1.0 / je) * kv * (uaW + ubW);
+		xout[o] = oW - dt * (1.0 / je) * kv * (uaW + ubW);
 	}
 	if (actn) {
 		size_t o = TMX_SLAB_T(L, kk) * NS + col;
-		xout[o] = xout[o] - dt * (1.0 / jn) * ks * (uaT + ubT);
+		xout[o] = oT - dt * (1.0 / jn) * ks * (uaT + ubT);
 		const double nkv = -kv;
 		const double upa = nkv * dad - nkv * j2d * (c2a1 * dac + c2b1 * dbc);
 		const double upb = nkv * dbd + nkv * j2d * (c2a0 * dac + c2a1 * dbc);
 		const double upar = kv * dadr - kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
 		const double upbr = kv * dbdr + kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
 		o = TMX_SLAB_U(L, kk) * NS + col;
-		double v = xout[o]; v -= dt * upa; v -= dt * upar; xout[o] = v;
+		double v = oU; v -= dt * upa; v -= dt * upar; xout[o] = v;
 		o = TMX_SLAB_V(L, kk) * NS + col;
-		v = xout[o]; v -= dt * upb; v -= dt * upbr; xout[o] = v;
+		v = oV; v -= dt * upb; v -= dt * upbr; xout[o] = v;
 	}
 }
 
