@@ -236,7 +236,11 @@ int tmx_h_step_after_subcycle(tmx_engine * e, int i_initial, int i_update, int i
  *   STRANG  src/atm/TimestepSchemeStrang.cpp:450-674 with KinnmarkGrayUllrich35 (the default --timescheme of every
  *           reference test, TempestInitialize.h:142); STRANG_FE / _RK4 / _SSP3 / _SSPRK53 are the same step with the
  *           constructor's other ExplicitDiscretization values (TimestepSchemeStrang.h:39-45, .cpp:39-51,484-648)
- * first_step / last_step have the meaning of TimestepScheme::Step's fFirstStep / fLastStep. */
+ * first_step / last_step have the meaning of TimestepScheme::Step's fFirstStep / fLastStep.
+ * The stage CopyData calls of these sequences are mostly not performed: a copy that is only read until it is next overwritten
+ * reads its source (whole instance, or just U,V in front of the implicit column solve, which rewrites the rest).  This is
+ * invisible at this interface: every other entry point first gives the instances it names storage of their own, so after
+ * tmx_step every data instance holds what the reference's holds. */
 enum { TMX_SCHEME_ARS343 = 0, TMX_SCHEME_ARS232, TMX_SCHEME_ARS222, TMX_SCHEME_ARS443, TMX_SCHEME_ARK232, TMX_SCHEME_STRANG,
        TMX_SCHEME_STRANG_FE, TMX_SCHEME_STRANG_RK4, TMX_SCHEME_STRANG_SSP3, TMX_SCHEME_STRANG_SSPRK53 };
 /* dOffCentering of TimestepSchemeStrang's constructor (TimestepSchemeStrang.cpp:25-37,58-61,651-660), in [0, 1]; 0 by default. */
