@@ -435,7 +435,10 @@ int tmx_debug_pivot_stats(tmx_engine * e, int enable, unsigned long long out[2])
  * slot until it is overwritten: fully explicit vertical mode VerticalDynamicsFEM.cpp:1239-1242, VerticalDynamicsStub; with
  * implicit vertical dynamics the same for the U,V slabs, which the column solve does not touch), decided
  * exactly as tmx_step decides them.  mode 0: implicit vertical dynamics, 1: fully explicit, 2: shallow water; `steps`
- * consecutive steps, counts of the last one; share = 0 switches the sharing off (TMX_SHARE_COPIES=0). */
+ * consecutive steps, counts of the last one; share = 0 switches the sharing off (TMX_SHARE_COPIES=0).  The run also carries
+ * symbolic contents (value ids per instance and slot, U,V and the rest apart) through the reference's semantics and through the
+ * executed decisions, and returns -1000 - n when n reads through the instance maps would not have found the reference's value
+ * (0: sound); share = 2 is the check's negative control: every share accepted and no copy-on-write. */
 int tmx_debug_program_copies(int scheme, int mode, int steps, int share, int * copies, int * shared);
 
 /* Per-kernel device time accumulated with HIP events on the engine's stream since the last reset.

@@ -2317,6 +2317,7 @@ extern "C" int tmx_v_filter_negative_tracers(tmx_engine * e, int instance) {
 
 static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { return tmx_v_step_implicit_terms_explicitly(e, iinit, iupd, dt); }
 
+static bool g_dry_unsafe = false;      // tmx_debug_program_copies' negative control (dry runs only): every share accepted, no copy-on-write
 // What an operation of a stepper program reads and writes, as bit masks over the data instances.  full: instances it
 // overwrites entirely without reading them; part: instances it updates in place.
 struct OpAccess { unsigned reads, full, part; bool stencil; };
@@ -2344,6 +2345,7 @@ static OpAccess op_access(const Op & o, bool vimp_noop) {
 // (b is dead from there on); a stencil operation must not write a while it reads b.  A program that ends with the two still
 // identical leaves them shared; one that ends after a was written would leave b undefined, so it is refused.
 static bool share_is_safe(const Program & p, size_t first, int a, int b, bool vimp_noop) {
+	if (g_dry_unsafe) return true;
 	const unsigned ba = 1u << a, bb = 1u << b;
 	bool a_written = false;
 	for (size_t i = first; i < p.size(); i++) {
@@ -2362,7 +2364,7 @@ static bool share_is_safe(const Program & p, size_t first, int a, int b, bool vi
 static int own_slot(tmx_engine * e, int x, bool total) {
 	if (e->imap[x] != x) {
 		if (!total) {
-			if (e->dry_run) e->dry_copies++;
+			if (e->dry_run) { e->dry_copies++; if (!g_dry_unsafe) for (int c = 0; c < 2; c++) e->dry_slot[c][x] = e->dry_slot[c][e->imap[x]]; }
 			else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->imap[x] * e->inst_stride,
 				e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
 		}
@@ -2370,7 +2372,7 @@ static int own_slot(tmx_engine * e, int x, bool total) {
 	}
 	if (e->uvmap[x] != x) {
 		if (!total) {
-			if (e->dry_run) e->dry_copies++;
+			if (e->dry_run) { e->dry_copies++; if (!g_dry_unsafe) e->dry_slot[0][x] = e->dry_slot[0][e->uvmap[x]]; }
 			else HIPCHK(hipMemcpyAsync(e->d_state + (size_t)x * e->inst_stride, e->d_state + (size_t)e->uvmap[x] * e->inst_stride,
 				(size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
 		}
@@ -2397,6 +2399,53 @@ struct AfterOp {      // at the end of an operation: the readers of the slots it
 	~AfterOp() { for (int x = 0; x < (int)e->imap.size() && (e->n_shared || e->n_uvshared); x++) if (w >> x & 1u) drop_readers(e, x); }
 };
 
+// Symbolic model of the dry run.  Value ids stand for array contents: the reference's semantics of every operation is applied to
+// dry_ref (per instance, U,V and the rest apart -- the implicit column solve is the one operation that writes only the rest),
+// and an executed operation is taken to store the reference's result in the slots of the instances it writes, provided that
+// every instance it read was found, through the instance maps, in a slot holding the reference's value: that is what is checked.
+static unsigned long long dry_mix(unsigned long long h, unsigned long long v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
+static int dry_slot_of(const tmx_engine * e, int k, int c) { return (c == 0 && e->uvmap[k] != k) ? e->uvmap[k] : e->imap[k]; }
+// operations [i0, i1] of the program were executed as one unit
+static void dry_model(tmx_engine * e, const Program & p, size_t i0, size_t i1, bool noop) {
+	const int ni = (int)e->imap.size();
+	unsigned written[2] = { 0u, 0u };
+	for (size_t j = i0; j <= i1 && j < p.size(); j++) {
+		const Op & o = p[j];
+		if (o.kind == OP_VIMP && noop) continue;
+		const OpAccess x = op_access(o, noop);
+		const bool rest_only = (o.kind == OP_VIMP);            // V.StepImplicit leaves U,V alone
+		// reads from outside the unit must find the reference's value where the maps point
+		for (int k = 0; k < ni; k++)
+			for (int c = 0; c < 2; c++)
+				if ((x.reads >> k & 1u) && !(written[c] >> k & 1u) && e->dry_slot[c][dry_slot_of(e, k, c)] != e->dry_ref[c][k]) e->dry_mismatch++;
+		// the reference's result
+		std::vector<unsigned long long> nr[2] = { e->dry_ref[0], e->dry_ref[1] };
+		for (int c = (rest_only ? 1 : 0); c < 2; c++) {
+			auto in = [&](int k) { return dry_mix(e->dry_ref[0][k], e->dry_ref[1][k]); };      // a stencil operation's result depends on all of its input instance
+			switch (o.kind) {
+			case OP_COPY: nr[c][o.b] = e->dry_ref[c][o.a]; break;
+			case OP_HEXP: case OP_VEXP: case OP_VITE: case OP_VIMP: nr[c][o.b] = dry_mix(dry_mix(dry_mix(1000 + o.kind, c), in(o.a)), e->dry_ref[c][o.b]); break;
+			case OP_DSS: case OP_VFILT: nr[c][o.a] = dry_mix(dry_mix(2000 + o.kind, c), e->dry_ref[c][o.a]); break;
+			case OP_HVIS: nr[c][o.b] = dry_mix(dry_mix(3000, c), in(o.a)); nr[c][o.c] = dry_mix(dry_mix(3001, c), in(o.a)); break;
+			case OP_LINCOMB: {
+				unsigned long long h = dry_mix(4000, c);
+				for (int m = 0; m < o.nlc; m++) if (o.lc[m] != 0.0) { unsigned long long b; memcpy(&b, &o.lc[m], 8); h = dry_mix(dry_mix(h, b), e->dry_ref[c][m]); }
+				nr[c][o.a] = h; break; }
+			}
+			written[c] |= x.full | x.part;
+		}
+		e->dry_ref[0] = nr[0]; e->dry_ref[1] = nr[1];
+	}
+	// the unit's results land in the slots of the instances it wrote (or must already be there, for an instance left sharing)
+	for (int k = 0; k < ni; k++)
+		for (int c = 0; c < 2; c++)
+			if (written[c] >> k & 1u) {
+				const int sl = dry_slot_of(e, k, c);
+				if (sl == k) e->dry_slot[c][k] = e->dry_ref[c][k];
+				else if (e->dry_slot[c][sl] != e->dry_ref[c][k]) e->dry_mismatch++;
+			}
+}
+
 // RUN: the launches of an operation; a dry run (tmx_debug_program_copies: the copy / sharing decisions of a program on the
 // host, no device) skips them
 #define RUN(call) (e->dry_run ? TMX_OK : (call))
@@ -2418,6 +2467,9 @@ static int run_program(tmx_engine * e, const Program & p) {
 		for (int x = 0; x < (int)e->imap.size() && (e->n_shared || e->n_uvshared); x++)
 			if (((acc.full | acc.part) >> x & 1u) && (r = own_slot(e, x, (acc.full >> x & 1u) != 0))) return r;
 		AfterOp after = { e, acc.full | acc.part };
+		const size_t i_first = i;
+		struct DryUnit { tmx_engine * e; const Program & p; size_t i0; const size_t & i1; bool noop;
+			~DryUnit() { if (e->dry_run) dry_model(e, p, i0, i1, noop); } } dry_unit = { e, p, i_first, i, noop };      // runs before `after`
 		switch (o.kind) {
 		case OP_COPY:
 			// Copy(a->b) + H(a,b,c) + V(a,b,c)  ==  one pass  b = a + c * rhs(a)
@@ -2547,19 +2599,29 @@ extern "C" int tmx_debug_program_copies(int scheme, int mode, int steps, int sha
 	REQUIRE(need > 0, TMX_ERR_INVALID, "unknown time scheme %d", scheme);
 	tmx_engine e;
 	e.cfg.n_instances = need; e.cfg.n_ranks = 1;
-	e.sw = mode == 2; e.fully_explicit = mode == 1; e.share_copies = share; e.dry_run = true;
+	e.sw = mode == 2; e.fully_explicit = mode == 1; e.share_copies = share != 0; e.dry_run = true;
 	e.imap.resize(need);
 	for (int k = 0; k < need; k++) e.imap[k] = k;
 	e.uvmap = e.imap;
-	for (int n = 0; n < steps; n++) {
-		Program p;
-		int r = build_program(scheme, n == 0, 0, 1.0, p, 0.0);
-		if (r) return r;
-		e.dry_copies = e.dry_shared = 0;
-		if ((r = run_program(&e, p))) return r;
+	for (int c = 0; c < 2; c++) {
+		e.dry_ref[c].resize(need); e.dry_slot[c].resize(need);
+		for (int k = 0; k < need; k++) e.dry_ref[c][k] = e.dry_slot[c][k] = dry_mix(77 + c, k);
 	}
+	g_dry_unsafe = share == 2;      // negative control of the symbolic check: every share accepted
+	int r = TMX_OK;
+	for (int n = 0; n < steps && !r; n++) {
+		Program p;
+		if ((r = build_program(scheme, n == 0, 0, 1.0, p, 0.0))) break;
+		e.dry_copies = e.dry_shared = 0;
+		r = run_program(&e, p);
+		// between steps instance 0 is what everything outside looks at: it must sit in its own slot and hold the reference's value
+		for (int c = 0; c < 2; c++)
+			if (dry_slot_of(&e, 0, c) != 0 || e.dry_slot[c][0] != e.dry_ref[c][0]) e.dry_mismatch++;
+	}
+	g_dry_unsafe = false;
+	if (r) return r;
 	*copies = e.dry_copies; *shared = e.dry_shared;
-	return TMX_OK;
+	return e.dry_mismatch ? -1000 - e.dry_mismatch : TMX_OK;
 }
 
 extern "C" int tmx_scheme_instances(int scheme) { return scheme_instances(scheme); }

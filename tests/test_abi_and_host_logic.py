@@ -207,5 +207,13 @@ def test_stepper_programs_share_the_copies_in_front_of_a_stub_implicit_step():
                 assert shared0 == 0 and made1 <= made0, (scheme, mode, steps)
                 # a shared copy is either never needed or made later (when its slot is written in place): never more than asked for
                 assert made1 + shared1 >= made0 and made1 >= made0 - shared1, (scheme, mode, steps)
+    # run() above also asserted the symbolic soundness check of the dry run (return code 0: every read through the instance maps
+    # finds the value the reference's instance holds) -- for every scheme, mode, with and without sharing; over more steps:
+    for scheme in Engine.SCHEMES:
+        for mode in (0, 1, 2):
+            run(scheme, mode, 8, 1)
+    # ... and the check has teeth: with every share accepted and no copy-on-write (share = 2) it reports stale reads
     c = ctypes.c_int(); s = ctypes.c_int()
+    stale = [lib.tmx_debug_program_copies(Engine.SCHEMES[sch], 0, 4, 2, ctypes.byref(c), ctypes.byref(s)) for sch in ("ars222", "ars443", "ark232", "strang")]
+    assert all(rc <= -1000 for rc in stale), stale
     assert lib.tmx_debug_program_copies(99, 1, 1, 1, ctypes.byref(c), ctypes.byref(s)) != 0
