@@ -191,7 +191,7 @@ struct tmx_engine {
 	// as value ids, separately for the U,V slabs ([0]) and the rest ([1]); dry_mismatch counts reads through the instance maps
 	// that would not have found the reference's value
 	std::vector<unsigned long long> dry_ref[2], dry_slot[2];
-	int dry_mismatch = 0; bool dry_unsafe = false;
+	int dry_mismatch = 0;
 	int xcd_vertical = 1;                    // TMX_XCD_VERTICAL=0: plain 2-D order of the vertical stencil kernels' workgroups
 	int vi_split_back = 0, vi_back_sub = 1, vi_stagger = 0;   // experiments (TMX_VI_SPLIT_BACK, TMX_VI_BACK_SUB, TMX_VI_STAGGER_NS / 10): back substitution as its own launch
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
