@@ -661,7 +661,12 @@ __device__ __forceinline__ double dss_combine(double w0, double w1, double w2, d
 #ifndef TMX_DSS_LPT
 #define TMX_DSS_LPT 1      // slab-levels per thread of k_dss
 #endif
-__global__ __launch_bounds__(256) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
+// five workgroups (20 wavefronts) per CU: the register allocation is held to 96 (94 used; it settled at 98 = four per SIMD on its
+// own), which the gathers use (-2 % per launch; six workgroups, 80 registers, serialise the loads: +26 %)
+#ifndef TMX_DSS_MINWG
+#define TMX_DSS_MINWG 5
+#endif
+__global__ __launch_bounds__(256, TMX_DSS_MINWG) void k_dss(KParams p, double * __restrict__ x, const double * __restrict__ ghost,
 	const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gcols,
 	const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int nt, int g0)
 {
