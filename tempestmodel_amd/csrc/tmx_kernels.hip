@@ -19,7 +19,7 @@
 #define TMX_H_FUSE_W 1      // W of the interfaces inside a level tile updated by k_h_explicit itself (0: all of them by k_h_w_update)
 #endif
 #ifndef KT_H
-#define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads); 5 / 6 / 8 measured: explicit stage 0.77 / 0.75 / 0.69 against 0.56 ms per step
+#define KT_H 4      // levels per workgroup of the horizontal kernels (256 threads); 2 / 3 measure the same, 5 / 6 / 8: explicit stage 0.77 / 0.75 / 0.69 against 0.56 ms per step
                     // (three resident wavefronts per SIMD hold whole 4-wavefront workgroups only; taller tiles leave slots empty)
 #endif
 
