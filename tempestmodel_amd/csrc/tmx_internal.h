@@ -1,5 +1,5 @@
 // tmx_internal.h -- engine internals shared by the host side (tmx_host.hip) and the kernels
-// (tmx_kernels.hip).  gfx950 only.
+// (tmx_k_*.hip).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
@@ -209,7 +209,7 @@ struct tmx_engine {
 
 void tmx_set_error(const char * fmt, ...);
 
-// kernel launchers (tmx_kernels.hip)
+// kernel launchers (tmx_k_*.hip)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
 	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr);

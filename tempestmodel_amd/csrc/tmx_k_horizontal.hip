@@ -1,0 +1,1164 @@
+// tmx_k_horizontal.hip -- hand-written CDNA4 (gfx950) kernels of the spectral-element hot path (one translation unit per operator family;
+// layout, addressing and shared helpers: tmx_device.h).
+//
+// HBM layout: every field is a stack of "slabs" of NS doubles, one slab per
+// (variable, level); inside a slab the index is the column  col = element*16 + i*4 + j
+// (i = alpha node, j = beta node of the 4x4 GLL element).  One wavefront = 64 consecutive
+// columns = 4 whole elements at one level, so every global access of a wavefront is one
+// contiguous 512-byte segment and the np x np contractions stay inside a 16-lane group.
+//
+// All kernels are HBM-bound fp64 stencil work: one thread per (column, level),
+// horizontal contractions through LDS, vertical stencils through neighbouring slabs (served by
+// L2 / Infinity Cache).  Compiled with -ffp-contract=off so the arithmetic follows the operation
+// order of the reference (which is built without FMA contraction).
+//
+// Reference behaviour restated (file:line under the reference tree) is cited per kernel.
+#include "tmx_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// H explicit, part 1: HorizontalDynamicsFEM::StepNonhydrostaticPrimitive, updates on levels
+// (src/atm/HorizontalDynamicsFEM.cpp:848-1421).  The prologue interpolations (:817-831) are
+// recomputed on the fly instead of being stored.  (u x zeta)_xi is handed to part 2 via `ucz`.
+
+// FUSE_V: also apply VerticalDynamicsFEM::StepExplicit (k_v_explicit) to the freshly updated U,V in
+// registers -- same statements in the same order, so the result is bit-identical to the two calls.
+// The H-only values of levels 0,1 are kept in `uv01` for the bottom boundary condition of W, which the
+// reference evaluates before V.StepExplicit runs (HorizontalDynamicsFEM.cpp:1615-1638).
+// MF (opt-in, TMX_MFMA=1): the twelve 4x4 contractions of a wavefront's four elements as v_mfma_f64_4x4x4_4b_f64 instead
+// of LDS reads + VALU.  Lane layout of that instruction, probed on gfx950 with exact integer data (tools/probe/
+// mfma_f64_probe.hip): A[m][k] of block b at lane m + 4b + 16k, B[k][n] at lane n + 4b + 16k, D[m][n] at lane n + 4b + 16m.
+// With the lane -> node map  lane = j + 4 e + 16 i  (j beta node, e element, i alpha node) a field IS the B operand
+// of the alpha contraction (k = alpha node), the result lands on the lane of its own node, and no LDS is touched; the
+// beta contraction takes the field as A with alpha and beta exchanged, one in-register lane transpose (two
+// ds_bpermute_b32) per field.  Global accesses stay one contiguous 512-byte row per wavefront (the map permutes lanes
+// inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
+// results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
+template <bool FUSE_V, int NT, bool MF>
+#ifndef TMX_H_MINWG
+#define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
+#endif
+__global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
+	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
+{
+	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int tid = ty * 64 + lane;
+	if (!MF && tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	// column of this lane: element-major (e, i, j) in memory; MF: lane = j + 4 e + 16 i
+	const int tile = p.quads ? p.quads[blockIdx.x] : blockIdx.x;       // 64-column tile of this workgroup
+	const int col = MF ? tile * 64 + ((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3) : tile * 64 + lane;
+	const int k = blockIdx.y * KT_H + ty;
+	const bool act = (k < L) && (col < p.ncol);
+
+	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
+	double conUa = 0, conUb = 0, conUx = 0, dxua = 0, dxub = 0;
+	double v_uam = 0, v_uap = 0, v_ubm = 0, v_ubp = 0, w_hi = 0, w_lo = 0;
+	// base of the update (a plain instance or the fused stage combination): loaded in the same burst as the state
+	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
+	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
+	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
+	if (act) {
+		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
+		const unsigned cb = (unsigned)col * 8u;
+		const double * __restrict__ xuv = uvt.xin;      // U,V of the initial instance (its own slot or the one it shares)
+		ua = ldu(xuv + TMX_SLAB_U(L, k) * NS, cb);
+		ub = ldu(xuv + TMX_SLAB_V(L, k) * NS, cb);
+		rt = ldu(xin + TMX_SLAB_T(L, k) * NS, cb);
+		rh = ldu(xin + TMX_SLAB_R(L, k) * NS, cb);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * NS, cb);
+		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * NS, cb);
+		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * NS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * NS, cb);
+		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * NS, cb);
+		bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * NS, cb);
+		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * NS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * NS, cb);
+		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * NS, cb);
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		jn = ldu(p.g2d + G2_JN * NS, cb); j2d = ldu(p.g2d + G2_J2D * NS, cb); fcor = ldu(p.g2d + G2_F * NS, cb);
+		const MetCol mc = met_col(p, col);
+		metric_node(p, mc, k, col, ca2, cb2, cx2, dra, drb);
+		// W on levels (InterpolateREdgeToNode, GridPatchGLL.cpp:111-143)
+		ux = 0.0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * we0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * we1;
+		// contravariant velocities, kinetic energy (:884-930)
+		conUa = c2a0 * ua + c2a1 * ub + ca2 * ux;
+		conUb = c2a1 * ua + c2b1 * ub + cb2 * ux;
+		conUx = ca2 * ua + cb2 * ub + cx2 * ux;
+		// vertical derivatives of the covariant velocities (DifferentiateNodeToNode, :975-982)
+		const double dm = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, -1), d0 = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 0), dp = OPC(TMX_OP_DIFF_NODE_TO_NODE, k, 1);
+		dxua = 0.0; dxua += dm * uam; dxua += d0 * ua; dxua += dp * uap;
+		dxub = 0.0; dxub += dm * ubm; dxub += d0 * ub; dxub += dp * ubp;
+		if (FUSE_V) {
+			// xi_dot on the interfaces k and k+1 (VerticalDynamicsFEM.cpp:816-828), zero at the boundaries
+			v_uam = uam; v_uap = uap; v_ubm = ubm; v_ubp = ubp;
+			double xlo = 0.0, xhi = 0.0;
+			if (k >= 1) {
+				double ue = 0.0, ve = 0.0;
+				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * uam; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ua;
+				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ubm; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ub;
+				double e0, e1, e2;
+				metric_edge(p, mc, k, col, e0, e1, e2);
+				xlo = e0 * ue + e1 * ve + e2 * we0;
+			}
+			if (k + 1 <= L - 1) {
+				double ue = 0.0, ve = 0.0;
+				ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ua; ue += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * uap;
+				ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * ub; ve += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * ubp;
+				double e0, e1, e2;
+				metric_edge(p, mc, k + 1, col, e0, e1, e2);
+				xhi = e0 * ue + e1 * ve + e2 * we1;
+			}
+			w_hi = dt * fabs(xhi); w_lo = dt * fabs(xlo);
+		}
+	}
+	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
+	const double exn = act ? exner_from_rhotheta(p, rt) : 0.0;
+	const double fa = jn * conUa, fb = jn * conUb;
+	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
+	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+	if (MF) {
+		// operator entries of this lane: D[k][m] and S[m][k] with m = lane & 3, k = lane >> 4 (A of the alpha contraction
+		// d/d_alpha f (i,j) = sum_t D[t][i] f(t,j), B of the beta contraction d/d_beta f (i,j) = sum_t f(i,t) D[t][j])
+		const int m_ = lane & 3, k_ = lane >> 4;
+		const double cD = p.dx[k_ * 4 + m_], cS = p.stiff[m_ * 4 + k_];
+		// alpha <-> beta exchange inside the element: value of lane (lane >> 4) + 4 e + 16 (lane & 3)
+		const int src = (k_ + (lane & 12) + 16 * m_) * 4;
+		auto tr = [&](double v) -> double {
+			const long long b = __double_as_longlong(v);
+			const int lo = __builtin_amdgcn_ds_bpermute(src, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(src, (int)(b >> 32));
+			return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+		};
+#define MFMA4(A_, B_) __builtin_amdgcn_mfma_f64_4x4x4f64((A_), (B_), 0.0, 0, 0, 0)
+		daub = MFMA4(cD, ub); daux = MFMA4(cD, ux); dap = MFMA4(cD, exn); dake = MFMA4(cD, ke);
+		darf = -MFMA4(cS, fa * rh); dapf = -MFMA4(cS, fa * rt);
+		dbua = MFMA4(tr(ua), cD); dbux = MFMA4(tr(ux), cD); dbp = MFMA4(tr(exn), cD); dbke = MFMA4(tr(ke), cD);
+		dbrf = -MFMA4(tr(fb * rh), cS); dbpf = -MFMA4(tr(fb * rt), cS);
+#undef MFMA4
+		if (!act) return;
+	} else {
+	s[ty][0][lane] = ua;  s[ty][1][lane] = ub;  s[ty][2][lane] = ux;
+	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
+	s[ty][5][lane] = fa * rh; s[ty][6][lane] = fa * rt;
+	s[ty][7][lane] = fb * rh; s[ty][8][lane] = fb * rt;
+	__syncthreads();
+	if (!act) return;
+#ifdef TMX_H_SCHED_BARRIER
+	__builtin_amdgcn_sched_barrier(0);
+#endif
+
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j;        // node (t, j)
+		const double D = sD[t * 4 + i], S = sS[i * 4 + t];
+		daub += s[ty][1][la] * D;
+		daux += s[ty][2][la] * D;
+		dap  += s[ty][3][la] * D;
+		dake += s[ty][4][la] * D;
+		darf -= s[ty][5][la] * S;
+		dapf -= s[ty][6][la] * S;
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int lb = eb + 4 * i + t;        // node (i, t)
+		const double D = sD[t * 4 + j], S = sS[j * 4 + t];
+		dbua += s[ty][0][lb] * D;
+		dbux += s[ty][2][lb] * D;
+		dbp  += s[ty][3][lb] * D;
+		dbke += s[ty][4][lb] * D;
+		dbrf -= s[ty][7][lb] * S;
+		dbpf -= s[ty][8][lb] * S;
+	}
+	}
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];      // 1 / element spacing of the column's patch
+	daub *= ida; daux *= ida; dbua *= idb; dbux *= idb;
+	darf *= ida; dbrf *= idb; dapf *= ida; dbpf *= idb;
+	dap *= ida; dbp *= idb; dake *= ida; dbke *= idb;
+
+	// u x zeta (:1011-1037)
+	const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
+	const double ucza = conUb * jzx - conUx * jzb;
+	const double uczb = conUx * jza - conUa * jzx;
+	const double uczx = -conUa * daux - conUb * dbux;
+
+	// pointwise updates (:1321-1421)
+	const double invJ = 1.0 / jn;
+	double upa = 0.0, upb = 0.0;
+	upa += ucza; upb += uczb;
+	upa += fcor * j2d * conUb;
+	upb -= fcor * j2d * conUa;
+	const double pgfa = dap * rt / rh, pgfb = dbp * rt / rh;
+	const double daphi = p.grav * dra, dbphi = p.grav * drb;
+	upa -= (pgfa + dake + daphi);
+	upb -= (pgfb + dbke + dbphi);
+	const size_t sU = TMX_SLAB_U(L, k) * NS, sV = TMX_SLAB_V(L, k) * NS, sT = TMX_SLAB_T(L, k) * NS, sR = TMX_SLAB_R(L, k) * NS;
+	const unsigned colb = (unsigned)col * 8u;
+	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
+	// instance when the preceding CopyData(initial -> update) is fused away
+	double outU = bU + dt * upa;
+	double outV = bV + dt * upb;
+	if (FUSE_V) {
+		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
+		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ua; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_uap;
+			outU += b * w_hi;
+			b = 0.0;
+			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ub; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_ubp;
+			outV += b * w_hi;
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_uam; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ua;
+			outU += b * w_lo;
+			b = 0.0;
+			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_ubm; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ub;
+			outV += b * w_lo;
+		}
+	}
+	stu(xup + sU, colb, outU);
+	stu(xup + sV, colb, outV);
+	stu(xup + sR, colb, bR - dt * invJ * (darf + dbrf));
+	stu(xup + sT, colb, bT - dt * invJ * (dapf + dbpf));
+	if (TMX_H_FUSE_W && !MF) {
+		// W on the interfaces inside the tile (part 2 below, :1612-1659): interface k takes (u x zeta)_xi of the levels k - 1 and k,
+		// which wavefront ty - 1 hands over through its own (now free) LDS row; only the tile's first interface is left to
+		// k_h_w_update, which therefore needs the hand-off array for the first and the last level of a tile only
+		s[ty][0][lane] = uczx;
+		if (ty == 0 || ty == KT_H - 1) stu(ucz + (size_t)k * NS, colb, uczx);
+		__syncthreads();       // wavefronts above the top level have left; the barrier counts the ones still running
+		if (ty > 0) {
+			double v = 0.0;
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lane];
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
+			stu(xup + TMX_SLAB_W(L, k) * NS, colb, bW + dt * v);
+		}
+	} else
+		stu(ucz + (size_t)k * NS, colb, uczx);
+}
+
+// H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
+// boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
+// stride > 1: only the interfaces k = 0, stride, 2 stride, ... (the first of every level tile of k_h_explicit, which has done
+// the others) and the top one
+template <int NT>
+__global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
+	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + threadIdx.x;
+	const int idx = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int nfirst = (L + stride - 1) / stride;          // interfaces idx * stride < L, then the top one
+	const int k = (idx < nfirst) ? idx * stride : ((idx == nfirst) ? L : L + 1);
+	if (k > L || col >= p.ncol) return;
+	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
+		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * NS + col);
+		return;
+	}
+	if (k == 0) {
+		double u0 = 0.0, v0 = 0.0;
+		// updated U,V of levels 0,1 as the H step left them (uv01 when V.StepExplicit was fused in)
+		const double * pu0 = uv01 ? uv01 + col : xup + TMX_SLAB_U(L, 0) * NS + col;
+		const double * pu1 = uv01 ? uv01 + NS + col : xup + TMX_SLAB_U(L, 1) * NS + col;
+		const double * pv0 = uv01 ? uv01 + 2 * NS + col : xup + TMX_SLAB_V(L, 0) * NS + col;
+		const double * pv1 = uv01 ? uv01 + 3 * NS + col : xup + TMX_SLAB_V(L, 1) * NS + col;
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * (*pu0);
+		u0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pu1);
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * (*pv0);
+		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pv1);
+		double cx0, cx1, cx2;
+		metric_edge(p, met_col(p, col), 0, col, cx0, cx1, cx2);
+		xup[TMX_SLAB_W(L, 0) * NS + col] = -(cx0 * u0 + cx1 * v0) / cx2;
+	} else {
+		double v = 0.0;
+		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
+		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
+		xup[TMX_SLAB_W(L, k) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, k) * NS + col) + dt * v;
+	}
+}
+
+// xin_uv / xbase_uv / src_uv: where the U,V slabs of the initial instance, the base instance and the combination sources
+// live when that is not the instance's own slot (NULL: the same pointers)
+void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv) {
+	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
+	LinTerms xbase;
+	UvTerms uvt;
+	xbase.n = nterms; xbase.premul = premul;
+	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
+	uvt.xin = xin_uv ? xin_uv : xin; uvt.src[0] = xbase_uv ? xbase_uv : xbase_ptr;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
+	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
+	dim3 blk(64, KT_H), grd(ntile, (p.L + KT_H - 1) / KT_H);
+	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
+	const int wstride = (TMX_H_FUSE_W && !(fuse_v && e->use_mfma)) ? KT_H : 1;
+	dim3 blk2(64, 4), grd2(ntile, ((p.L + wstride - 1) / wstride + 1 + 3) / 4);
+	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
+#define LAUNCH_HV(NT_) do { \
+		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
+	switch (nterms) {
+		case 0: LAUNCH_HV(0); break;
+		case 2: LAUNCH_HV(2); break;
+		case 3: LAUNCH_HV(3); break;
+		case 4: LAUNCH_HV(4); break;
+		case 5: LAUNCH_HV(5); break;
+		case 6: LAUNCH_HV(6); break;
+		case 7: LAUNCH_HV(7); break;
+		case 8: LAUNCH_HV(8); break;
+		default: LAUNCH_HV(12); break;      // entries beyond n carry coefficient 0 and a valid pointer (see below)
+	}
+#undef LAUNCH_HV
+}
+
+// HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
+// is non-zero, ten sub-cycled backward-Euler relaxations x <- f x + (1 - f) x_ref, f = 1 / (1 + dt nu / 10), of
+// U, V, rho*theta (strength on levels) and W (strength on interfaces); rho is left alone (:2455-2461).
+__global__ __launch_bounds__(256) void k_rayleigh(int L, int NS_, int ncol, double * __restrict__ x,
+	const double * __restrict__ nu, const double * __restrict__ ref, double dt)
+{
+	const size_t NS = (size_t)NS_;
+	const int col = blockIdx.x * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k > L || col >= ncol) return;
+	const double factor = 1.0 / 10;
+	if (k < L) {
+		const double dnu = nu[(size_t)k * NS + col];
+		if (dnu != 0.0) {
+#pragma unroll
+			for (int v = 0; v < 3; v++) {
+				const size_t o = (size_t)(v * L + k) * NS + col;        // U, V, rho*theta slabs are [0, 3L)
+				double xv = x[o];
+				const double r = ref[o];
+				for (int si = 0; si < 10; si++) {
+					const double f = 1.0 / (1.0 + factor * dt * dnu);
+					xv = f * xv + (1.0 - f) * r;
+				}
+				x[o] = xv;
+			}
+		}
+	}
+	const double dnu = nu[(size_t)(L + k) * NS + col];
+	if (dnu != 0.0) {
+		const size_t o = (size_t)TMX_SLAB_W(L, k) * NS + col;
+		double xv = x[o];
+		const double r = ref[(size_t)(3 * L + k) * NS + col];
+		for (int si = 0; si < 10; si++) {
+			const double f = 1.0 / (1.0 + factor * dt * dnu);
+			xv = f * xv + (1.0 - f) * r;
+		}
+		x[o] = xv;
+	}
+}
+
+void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
+	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_rayleigh, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracer transport.  Tracer densities are node scalars stored as extra slabs
+// TMX_SLAB_Q(L, c, k) behind the state slabs, so copies, linear combinations, packing and the exchange treat
+// them like any other slab.  The kernels below are the tracer parts of the reference's state operators.
+
+// H explicit, tracer part (HorizontalDynamicsFEM.cpp:1090-1100, :1531-1553) + FilterNegativeTracers (:213-317):
+// rho q <- base - dt / J * (weak divergence of J u^a rho q, J u^b rho q) with the mass-flux base of the state
+// update (same contravariant velocities, recomputed here), then per element and level: clip negatives, rescale the
+// positive values so that the element mass is unchanged.
+// UD: uniform diffusion of the tracer mixing ratio q / rho in the fluxes (HorizontalDynamicsFEM.cpp:1105-1148), ks = K_scalar.
+// NT > 0: the base is the stage's linear combination of the tracer slabs of NT instances, evaluated here as in the state
+// kernels (base_value) instead of by a k_lincomb pass over the tracer slabs in front of this kernel.
+template <bool UD, int NT>
+__global__ __launch_bounds__(256) void k_h_tracers(KParams p, int nt, const double * __restrict__ area,
+	const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, double ks, const double * __restrict__ xuv)      // xuv: slot holding xin's U,V slabs
+{
+	__shared__ double s[4][5][64];
+	__shared__ double sS[16], sD[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	if (ty * 64 + lane < 16) { sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = TILE_X(p) * 64 + lane;
+	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
+	const int k = blockIdx.y * 4 + ty;
+	const bool act = (k < L) && (col < p.ncol);
+	const int kc = (k < L) ? k : L - 1;
+	const unsigned cb = (unsigned)col * 8u;
+	double fa = 0.0, fb = 0.0, invJ = 0.0, ar = 0.0;
+	double dc2a0 = 0.0, dc2a1 = 0.0, dc2b1 = 0.0, djn = 0.0, rho = 1.0;      // uniform diffusion only
+	if (act) {
+		const double ua = ldu(xuv + TMX_SLAB_U(L, kc) * NS, cb), ub = ldu(xuv + TMX_SLAB_V(L, kc) * NS, cb);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, kc) * NS, cb), we1 = ldu(xin + TMX_SLAB_W(L, kc + 1) * NS, cb);
+		const double c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb), c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb), c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		const double jn = ldu(p.g2d + G2_JN * NS, cb);
+		double ca2, cb2, cx2;
+		metric_node3(p, met_col(p, col), kc, col, ca2, cb2, cx2);
+		double ux = 0.0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, kc, 0) * we0; ux += OPC(TMX_OP_INTERP_REDGE_TO_NODE, kc, 1) * we1;
+		const double conUa = c2a0 * ua + c2a1 * ub + ca2 * ux;
+		const double conUb = c2a1 * ua + c2b1 * ub + cb2 * ux;
+		fa = jn * conUa; fb = jn * conUb; invJ = 1.0 / jn;
+		ar = ldu(area + (size_t)kc * NS, cb);
+		if (UD) { dc2a0 = c2a0; dc2a1 = c2a1; dc2b1 = c2b1; djn = jn; rho = ldu(xin + TMX_SLAB_R(L, kc) * NS, cb); }
+	}
+	s[ty][3][lane] = ar;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	for (int c = 0; c < nt; c++) {
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
+		const double qv = act ? ldu(xin + so, cb) : 0.0;
+		const double bv = act ? base_value_u<NT>(xbase, so, cb) : 0.0;
+		double taf = fa * qv, tbf = fb * qv;
+		if (UD) {
+			__syncthreads();
+			s[ty][4][lane] = qv / rho;
+			__syncthreads();
+			double daq = 0.0, dbq = 0.0;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				daq += s[ty][4][eb + 4 * t + j] * sD[t * 4 + i];
+				dbq += s[ty][4][eb + 4 * i + t] * sD[t * 4 + j];
+			}
+			daq *= ida; dbq *= idb;
+			const double cdaq = dc2a0 * daq + dc2a1 * dbq;
+			const double cdbq = dc2a1 * daq + dc2b1 * dbq;
+			taf -= ks * djn * rho * cdaq;
+			tbf -= ks * djn * rho * cdbq;
+		}
+		__syncthreads();
+		s[ty][0][lane] = taf; s[ty][1][lane] = tbf;
+		__syncthreads();
+		double da = 0.0, db = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			da -= s[ty][0][eb + 4 * t + j] * sS[i * 4 + t];
+			db -= s[ty][1][eb + 4 * i + t] * sS[j * 4 + t];
+		}
+		da *= ida; db *= idb;
+		double out = bv - dt * invJ * (da + db);
+		s[ty][2][lane] = out;
+		__syncthreads();
+		double total = 0.0, nonneg = 0.0;
+#pragma unroll
+		for (int n = 0; n < 16; n++) {
+			const double qq = s[ty][2][eb + n];
+			const double pm = qq * s[ty][3][eb + n];
+			total += pm;
+			if (qq >= 0.0) nonneg += pm;
+		}
+		const double r = total / nonneg;
+		out = (out > 0.0) ? out * r : 0.0;
+		if (act) stu(xup + so, cb, out);
+	}
+}
+
+void tmxk_h_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv) {
+	if (!xin_uv) xin_uv = xin;
+	LinTerms xbase;
+	xbase.n = nterms; xbase.premul = premul;
+	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; }
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
+#define LAUNCH_HT(NT_) do { \
+		if (e->udiff) hipLaunchKernelGGL((k_h_tracers<true, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, e->cfg.uniform_diffusion_scalar, xin_uv); \
+		else hipLaunchKernelGGL((k_h_tracers<false, NT_>), grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xin, xbase, xup, dt, 0.0, xin_uv); } while (0)
+	switch (nterms) {
+		case 0: LAUNCH_HT(0); break;
+		case 2: LAUNCH_HT(2); break;
+		case 3: LAUNCH_HT(3); break;
+		case 4: LAUNCH_HT(4); break;
+		case 5: LAUNCH_HT(5); break;
+		case 6: LAUNCH_HT(6); break;
+		case 7: LAUNCH_HT(7); break;
+		case 8: LAUNCH_HT(8); break;
+		default: LAUNCH_HT(12); break;      // entries beyond n carry coefficient 0 and a valid pointer, as in tmxk_h_explicit
+	}
+#undef LAUNCH_HT
+}
+
+// ApplyScalarHyperdiffusion, tracer branch (HorizontalDynamicsFEM.cpp:1999-2035, :2076-2165) and, after the second
+// pass, FilterNegativeTracers (:2707).  xbase == nullptr: base 0 (the zeroed working instance of the first pass).
+__global__ __launch_bounds__(256) void k_hypervis_tracers(KParams p, int nt, const double * __restrict__ area,
+	const double * __restrict__ xsrc, const double * xbase, double * xout, double dt, double nu_in, int filter, int scale)
+{
+	__shared__ double s[4][4][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	if (ty * 64 + lane < 16) { sD[ty * 64 + lane] = p.dx[ty * 64 + lane]; sS[ty * 64 + lane] = p.stiff[ty * 64 + lane]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = TILE_X(p) * 64 + lane;
+	const double ida = p.g2d[G2_IDA * (size_t)p.NS + col], idb = p.g2d[G2_IDB * (size_t)p.NS + col];      // 1 / element spacing of the column's patch
+	const double nu = nu_in * (scale ? p.g2d[G2_NUS * (size_t)p.NS + col] : 1.0);
+	const int k = blockIdx.y * 4 + ty;
+	const bool act = (k < L) && (col < p.ncol);
+	const int kc = (k < L) ? k : L - 1;
+	const unsigned cb = (unsigned)col * 8u;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, ar = 0;
+	if (act) {
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
+		jn = ldu(p.g2d + G2_JN * NS, cb);
+		if (filter) ar = ldu(area + (size_t)kc * NS, cb);
+	}
+	s[ty][3][lane] = ar;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	for (int c = 0; c < nt; c++) {
+		const size_t so = (size_t)TMX_SLAB_Q(L, c, kc) * NS;
+		const double psi = act ? ldu(xsrc + so, cb) : 0.0;
+		const double bv = (act && xbase) ? ldu(xbase + so, cb) : 0.0;
+		__syncthreads();
+		s[ty][0][lane] = psi;
+		__syncthreads();
+		double da = 0.0, db = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			da += s[ty][0][eb + 4 * t + j] * sD[t * 4 + i];
+			db += s[ty][0][eb + 4 * i + t] * sD[t * 4 + j];
+		}
+		da *= ida; db *= idb;
+		s[ty][1][lane] = jn * (c2a0 * da + c2a1 * db);
+		s[ty][2][lane] = jn * (c2a1 * da + c2b1 * db);
+		__syncthreads();
+		double ua = 0.0, ub = 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			ua += s[ty][1][eb + 4 * t + j] * sS[i * 4 + t];
+			ub += s[ty][2][eb + 4 * i + t] * sS[j * 4 + t];
+		}
+		ua *= ida; ub *= idb;
+		double out = bv - dt * (1.0 / jn) * nu * (ua + ub);
+		if (filter) {
+			__syncthreads();
+			s[ty][0][lane] = out;
+			__syncthreads();
+			double total = 0.0, nonneg = 0.0;
+#pragma unroll
+			for (int n = 0; n < 16; n++) {
+				const double qq = s[ty][0][eb + n];
+				const double pm = qq * s[ty][3][eb + n];
+				total += pm;
+				if (qq >= 0.0) nonneg += pm;
+			}
+			const double r = total / nonneg;
+			out = (out > 0.0) ? out * r : 0.0;
+		}
+		if (act) stu(xout + so, cb, out);
+	}
+}
+
+void tmxk_hypervis_tracers(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu, int filter, int scale) {
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_hypervis_tracers, grd, blk, 0, e->stream, p, e->nt, (const double *)e->d_area, xsrc, xbase, xout, dt, nu, filter, scale);
+}
+
+// VerticalDynamicsFEM::UpdateColumnTracers (VerticalDynamicsFEM.cpp:3783-4282), implicit mode, vertical order 1:
+// one lane per unique column.  The tridiagonal matrix (kl = ku = 1) is kept in LAPACK band storage
+// AB(i, j) = sm[(j * 4 + 2 + i - j)] and factorised / solved with the dgbtf2 / dgbtrs loops (first-maximum
+// pivoting, column-oriented back substitution) -- the restatement oracle/tmx_oracle.c:orc_dgbsv pins against
+// LAPACK -- once per tracer on a fresh copy, which is what dgbtrf + dgbtrs per tracer compute.
+// xin: initial instance (U, V, tracer densities), w0: W of the initial column [L+1][NS] (a saved copy when the step
+// runs in place and the state kernel has already overwritten it), xup: update instance (updated W; receives the tracers),
+// xbase: instance holding the tracer values the update is subtracted from (the update instance itself in the
+// reference; the initial instance when the preceding CopyData was fused away).
+// expl (fully explicit vertical mode, :3910-3912, :4047-4063, :4117-4141, :4166-4170, :4193): every stored column is
+// advanced on its own (ucol == udep == nullptr; the update instance has not been through the DSS yet), the matrix is
+// the diagonal 1/dt (dgbtrs then is one division per level), xi_dot comes from the initial W for both uses, there
+// is no velocity correction, and with ks != 0 the mass flux carries the uniform diffusion of q / rho - (q / rho)_ref.
+// LW = columns per workgroup (the lane stride of the LDS arrays): 64, or 32 when (8L + 2) x 512 bytes exceed the 160 KB of a
+// CU (L >= 40, e.g. the 40 levels of the DCMIP2016 supercell) -- half-filled wavefronts, twice the workgroups.
+// ---------------------------------------------------------------------------------------------
+// Hyperviscosity pass: scalar Laplacian of rho*theta, W, rho and vector Laplacian of (U,V)
+// (ApplyScalarHyperdiffusion / ApplyVectorHyperdiffusion / ComputeCurlAndDiv,
+//  src/atm/HorizontalDynamicsFEM.cpp:1867-2203, 2207-2414; src/atm/GridPatchCSGLL.cpp:1132-1305).
+// out = base - dt * (...)(src); base = 0 when xbase == nullptr (first pass into the zeroed work
+// instance), otherwise the instance that StepAfterSubCycle copied into the update instance.
+
+// scale != 0: the coefficients are multiplied by the patch's (delta_alpha / reference length)^3.2 (fScaleNuLocally, :1968-1975)
+// PULL: the source instance holds values that have NOT been averaged over co-located nodes yet (the first pass's Laplacians):
+// every thread forms its own node's average while loading -- its group's copies, combined exactly as k_dss would have
+// combined them for this member (dss_combine in the member's own frame, (U,V) of copies on other panels rotated into it,
+// copies of other ranks from the ghost buffer) -- so the DSS pass between the two hyperviscosity passes (a read and a write
+// of the whole instance) is not run at all.  The partner rows are the neighbouring elements' rows, which other threads
+// load anyway: L2 hits, no extra HBM traffic.  Bit-identical to pass 1 + k_dss + pass 2.
+struct DssPull {
+	const int4 * colpart;     // [NS] {partner 1, partner 2, partner 3, info}: the OTHER copies of a stored column in the order of its group
+	                          // (column index, >= NS: ghost NS + index, -1: none); info = n | me << 3 | type << 6 | (matrix index + 1) << 8; info 0: no copies
+	const double * xmat, * ghost;
+	const int * gbase, * gstride;
+};
+template <int NF, bool uv>
+__device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull & d, const double * __restrict__ x, int col, const int (&slab)[NF], double (&out)[NF]) {
+	// out[f] = this node's DSS average of field slab[f]; with uv the last two fields are (U, V) (rotated between panels)
+	const size_t NS = (size_t)p.NS;
+	const int4 cp = d.colpart[col];
+	double own[NF];
+#pragma unroll
+	for (int f = 0; f < NF; f++) own[f] = x[(size_t)slab[f] * NS + col];
+	if (cp.w == 0) {
+#pragma unroll
+		for (int f = 0; f < NF; f++) out[f] = own[f];
+		return;
+	}
+	const int n = cp.w & 7, me = (cp.w >> 3) & 3, ty = (cp.w >> 6) & 3, xi = (cp.w >> 8) - 1;
+	const int oc[3] = { cp.x, cp.y, cp.z };
+	// v[f][m]: copies in group order; this column sits at position me, the others keep their order around it
+	double v[NF][4];
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+#pragma unroll
+		for (int f = 0; f < NF; f++) v[f][m] = 0.0;
+	}
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const int m = q + (q >= me ? 1 : 0);      // group position of the q-th other copy
+		const bool on = m < n;
+		const int c = oc[q];
+		const bool loc = on && c < (int)NS;
+		const double * ptr = !on ? x : (loc ? x + c : d.ghost + d.gbase[c - (int)NS]);
+		const size_t str = !on ? 0 : (loc ? NS : (size_t)d.gstride[c - (int)NS]);
+#pragma unroll
+		for (int f = 0; f < NF; f++) {
+			const double w = on ? ptr[(size_t)slab[f] * str] : 0.0;
+#pragma unroll
+			for (int mm = 0; mm < 4; mm++) if (mm == m) v[f][mm] = w;
+		}
+	}
+#pragma unroll
+	for (int f = 0; f < NF; f++) {
+#pragma unroll
+		for (int mm = 0; mm < 4; mm++) if (mm == me) v[f][mm] = own[f];
+	}
+	auto comb = [&](double w0, double w1, double w2, double w3) -> double {
+		switch (me) {
+			case 0: return dss_combine<0>(w0, w1, w2, w3, n, ty);
+			case 1: return dss_combine<1>(w0, w1, w2, w3, n, ty);
+			case 2: return dss_combine<2>(w0, w1, w2, w3, n, ty);
+			default: return dss_combine<3>(w0, w1, w2, w3, n, ty);
+		}
+	};
+	const int nscal = uv ? NF - 2 : NF;
+#pragma unroll
+	for (int f = 0; f < NF; f++) if (f < nscal) out[f] = comb(v[f][0], v[f][1], v[f][2], v[f][3]);
+	if constexpr (uv) {
+		double a[4], b[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			if (xi < 0 || q == me || q >= n) { a[q] = v[NF - 2][q]; b[q] = v[NF - 1][q]; }
+			else {
+				const double * T = d.xmat + (size_t)xi * 64 + (me * 4 + q) * 4;
+				a[q] = T[0] * v[NF - 2][q] + T[1] * v[NF - 1][q]; b[q] = T[2] * v[NF - 2][q] + T[3] * v[NF - 1][q];
+			}
+		}
+		out[NF - 2] = comb(a[0], a[1], a[2], a[3]); out[NF - 1] = comb(b[0], b[1], b[2], b[3]);
+	}
+	(void)xi;
+}
+
+template <bool PULL>
+__global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
+{
+	__shared__ double s[4][8][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int tid = ty * 64 + lane;
+	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + lane;
+	const int kk = blockIdx.y * 4 + ty;
+	const bool actw = (kk <= L) && (col < p.ncol);     // interface level (W)
+	const bool actn = (kk < L) && (col < p.ncol);      // model level (U,V,rho*theta,rho)
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+
+	double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
+	if (actw) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		if (!PULL) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+	}
+	// the base of the update (second pass: the instance the viscosity is applied to), loaded with the operands: at the point
+	// of use its latency would follow three barriers and both contractions
+	double bW = 0.0, bT = 0.0, bR = 0.0, bU = 0.0, bV = 0.0;
+	if (xbase && actw) {
+		bW = xbase[TMX_SLAB_W(L, kk) * NS + col];
+		if (actn) {
+			bT = xbase[TMX_SLAB_T(L, kk) * NS + col]; bR = xbase[TMX_SLAB_R(L, kk) * NS + col];
+			bU = xbase[TMX_SLAB_U(L, kk) * NS + col]; bV = xbase[TMX_SLAB_V(L, kk) * NS + col];
+		}
+	}
+	if (!PULL && actn) {
+		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+		psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
+		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
+		ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+	}
+	if (PULL && actw) {
+		if (actn) {
+			const int sl[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
+			double o[5];
+			dss_pull_fields<5, true>(p, pull, xsrc, col, sl, o);
+			psiW = o[0]; psiT = o[1]; psiR = o[2]; ua = o[3]; ub = o[4];
+		} else {
+			const int sl[1] = { TMX_SLAB_W(L, kk) };
+			double o[1];
+			dss_pull_fields<1, false>(p, pull, xsrc, col, sl, o);
+			psiW = o[0];
+		}
+	}
+	const double cua = c2a0 * ua + c2a1 * ub;
+	const double cub = c2a1 * ua + c2b1 * ub;
+	s[ty][0][lane] = psiT; s[ty][1][lane] = psiR; s[ty][2][lane] = psiW;
+	s[ty][3][lane] = ua;   s[ty][4][lane] = ub;
+	s[ty][5][lane] = j2d * cua; s[ty][6][lane] = j2d * cub;
+	__syncthreads();
+
+	double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+		daT += s[ty][0][la] * Da; dbT += s[ty][0][lb] * Db;
+		daR += s[ty][1][la] * Da; dbR += s[ty][1][lb] * Db;
+		daW += s[ty][2][la] * Da; dbW += s[ty][2][lb] * Db;
+		daub += s[ty][4][la] * Da; dbua += s[ty][3][lb] * Db;
+		dajua += s[ty][5][la] * Da; dbjub += s[ty][6][lb] * Db;
+	}
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	const double nsc = scale ? p.g2d[G2_NUS * NS + col] : 1.0;
+	const double nu_s = nu_s_in * nsc, nu_d = nu_d_in * nsc, nu_v = nu_v_in * nsc;
+	daT *= ida; dbT *= idb; daR *= ida; dbR *= idb; daW *= ida; dbW *= idb;
+	daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+	const double invJ2 = 1.0 / j2d;
+	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+	__syncthreads();
+	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
+	s[ty][2][lane] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lane] = jn * (c2a1 * daR + c2b1 * dbR);
+	s[ty][4][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lane] = je * (c2a1 * daW + c2b1 * dbW);
+	s[ty][6][lane] = dv; s[ty][7][lane] = cl;
+	__syncthreads();
+	if (!actw) return;
+
+	double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+		uaT += s[ty][0][la] * Sa; ubT += s[ty][1][lb] * Sb;
+		uaR += s[ty][2][la] * Sa; ubR += s[ty][3][lb] * Sb;
+		uaW += s[ty][4][la] * Sa; ubW += s[ty][5][lb] * Sb;
+		dad -= Sa * s[ty][6][la]; dbd -= Sb * s[ty][6][lb];
+		dac -= Sa * s[ty][7][la]; dbc -= Sb * s[ty][7][lb];
+	}
+	uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
+	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
+
+	xout[TMX_SLAB_W(L, kk) * NS + col] = bW - dt * (1.0 / je) * nu_s * (uaW + ubW);
+	if (actn) {
+		const double invJ = 1.0 / jn;
+		xout[TMX_SLAB_T(L, kk) * NS + col] = bT - dt * invJ * nu_s * (uaT + ubT);
+		xout[TMX_SLAB_R(L, kk) * NS + col] = bR - dt * invJ * nu_s * (uaR + ubR);
+		const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
+		const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
+		xout[TMX_SLAB_U(L, kk) * NS + col] = bU - dt * upa;
+		xout[TMX_SLAB_V(L, kk) * NS + col] = bV - dt * upb;
+	}
+}
+
+void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v, int scale, bool pull_dss) {
+	dim3 blk(64, 4), grd(p.quads ? e->launch_tiles : p.NS / 64, (p.L + 1 + 3) / 4);
+	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
+	if (pull_dss) hipLaunchKernelGGL(k_hypervis<true>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	else hipLaunchKernelGGL(k_hypervis<false>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hyperviscosity pass FUSED with the DSS of the seams inside a patch (round 3 prototype of "remove DSS passes": DESIGN.md
+// section 7).  A workgroup owns a block of up to EB x EB elements of one patch plus the ring of elements around it (where the
+// ring lies inside the patch), evaluates k_hypervis's arithmetic -- statement for statement -- for all of them with the
+// per-element contractions in LDS, leaves the five results of every node in LDS, and then averages every seam node of its
+// inner elements that is NOT on the patch's boundary from the copies in LDS, in the reference's order (alpha seams before
+// beta seams: 0.5 (x + x'), 0.5 (0.5 (x + x_alpha) + 0.5 (x_beta + x_diag)); inside a patch every copy receives the same
+// bits).  Only the inner elements are written, averaged; nodes on the patch boundary are written raw, and k_dss runs on the
+// groups that span patches only (tmx_engine::ngroups_inpatch: 91 % of the groups at ne30 on 24 patches never reach it).
+// The ring elements are evaluated redundantly by the neighbouring blocks (same operands, same statements: same bits).
+#define TMX_HB_E 5                              // inner elements per block side
+#define TMX_HB_W (TMX_HB_E + 2)                 // with the ring
+#define TMX_HB_N (TMX_HB_W * TMX_HB_W * 16)     // nodes a workgroup holds
+#define TMX_HB_T ((TMX_HB_N + 63) / 64 * 64)    // threads
+#define TMX_HB_KT 4                             // levels per workgroup (geometry stays in registers)
+struct HvBlock { int elem_base, nea, neb, a0, b0; };
+__global__ __launch_bounds__(TMX_HB_T) void k_hypervis_block(KParams p, const HvBlock * __restrict__ blocks, const double * __restrict__ xsrc,
+	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale)
+{
+	__shared__ double s[8][TMX_HB_N];
+	__shared__ double sD[16], sS[16];
+	const int t = threadIdx.x;
+	if (t < 16) { sD[t] = p.dx[t]; sS[t] = p.stiff[t]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const HvBlock B = blocks[blockIdx.x];
+	const int er = t >> 4, q = t & 15, i = q >> 2, j = q & 3;
+	const int ea = er / TMX_HB_W, eb_ = er - ea * TMX_HB_W;                   // position in the ringed block
+	const int a = B.a0 - 1 + ea, b = B.b0 - 1 + eb_;                          // element of the patch
+	const int na_in = min(TMX_HB_E, B.nea - B.a0), nb_in = min(TMX_HB_E, B.neb - B.b0);
+	const bool held = t < TMX_HB_N && ea <= na_in + 1 && eb_ <= nb_in + 1 && a >= 0 && a < B.nea && b >= 0 && b < B.neb;
+	const bool inner = held && ea >= 1 && ea <= na_in && eb_ >= 1 && eb_ <= nb_in;
+	const int col = held ? (B.elem_base + a * B.neb + b) * 16 + q : 0;
+	const int eb16 = er * 16;
+
+	// seam partners of an inner node, as indices into the workgroup's node arrays (-1: none; -2: the node lies on the
+	// patch boundary, its copies belong to another patch: left to k_dss)
+	int ta = -1, tb = -1, td = -1;
+	if (inner) {
+		const int ia = (i == 0) ? -1 : ((i == 3) ? 1 : 0), jb = (j == 0) ? -1 : ((j == 3) ? 1 : 0);
+		const bool oa = ia != 0 && (a + ia < 0 || a + ia >= B.nea), ob = jb != 0 && (b + jb < 0 || b + jb >= B.neb);
+		if (oa || ob) { ta = -2; }
+		else {
+			if (ia != 0) ta = ((ea + ia) * TMX_HB_W + eb_) * 16 + (3 - i) * 4 + j;
+			if (jb != 0) tb = (ea * TMX_HB_W + eb_ + jb) * 16 + i * 4 + (3 - j);
+			if (ia != 0 && jb != 0) td = ((ea + ia) * TMX_HB_W + eb_ + jb) * 16 + (3 - i) * 4 + (3 - j);
+		}
+	}
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1, ida = 0, idb = 0, nsc = 1.0;
+	if (held) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		ida = p.g2d[G2_IDA * NS + col]; idb = p.g2d[G2_IDB * NS + col];
+		nsc = scale ? p.g2d[G2_NUS * NS + col] : 1.0;
+	}
+	const double nu_s = nu_s_in * nsc, nu_d = nu_d_in * nsc, nu_v = nu_v_in * nsc;
+	__syncthreads();
+	for (int kq = 0; kq < TMX_HB_KT; kq++) {
+		const int kk = blockIdx.y * TMX_HB_KT + kq;
+		if (kk > L) break;                              // uniform
+		const bool actw = held, actn = held && kk < L;
+		double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
+		if (actw) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		if (actn) {
+			psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+			psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
+			ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
+			ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+		}
+		const double cua = c2a0 * ua + c2a1 * ub;
+		const double cub = c2a1 * ua + c2b1 * ub;
+		if (t < TMX_HB_N) {
+			s[0][t] = psiT; s[1][t] = psiR; s[2][t] = psiW;
+			s[3][t] = ua;   s[4][t] = ub;
+			s[5][t] = j2d * cua; s[6][t] = j2d * cub;
+		}
+		__syncthreads();
+		double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+		if (held) {
+#pragma unroll
+			for (int tt = 0; tt < 4; tt++) {
+				const int la = eb16 + 4 * tt + j, lb = eb16 + 4 * i + tt;
+				const double Da = sD[tt * 4 + i], Db = sD[tt * 4 + j];
+				daT += s[0][la] * Da; dbT += s[0][lb] * Db;
+				daR += s[1][la] * Da; dbR += s[1][lb] * Db;
+				daW += s[2][la] * Da; dbW += s[2][lb] * Db;
+				daub += s[4][la] * Da; dbua += s[3][lb] * Db;
+				dajua += s[5][la] * Da; dbjub += s[6][lb] * Db;
+			}
+		}
+		daT *= ida; dbT *= idb; daR *= ida; dbR *= idb; daW *= ida; dbW *= idb;
+		daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+		const double invJ2 = 1.0 / j2d;
+		const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+		__syncthreads();
+		if (t < TMX_HB_N) {
+			s[0][t] = jn * (c2a0 * daT + c2a1 * dbT); s[1][t] = jn * (c2a1 * daT + c2b1 * dbT);
+			s[2][t] = jn * (c2a0 * daR + c2a1 * dbR); s[3][t] = jn * (c2a1 * daR + c2b1 * dbR);
+			s[4][t] = je * (c2a0 * daW + c2a1 * dbW); s[5][t] = je * (c2a1 * daW + c2b1 * dbW);
+			s[6][t] = dv; s[7][t] = cl;
+		}
+		__syncthreads();
+		double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
+		if (held) {
+#pragma unroll
+			for (int tt = 0; tt < 4; tt++) {
+				const int la = eb16 + 4 * tt + j, lb = eb16 + 4 * i + tt;
+				const double Sa = sS[i * 4 + tt], Sb = sS[j * 4 + tt];
+				uaT += s[0][la] * Sa; ubT += s[1][lb] * Sb;
+				uaR += s[2][la] * Sa; ubR += s[3][lb] * Sb;
+				uaW += s[4][la] * Sa; ubW += s[5][lb] * Sb;
+				dad -= Sa * s[6][la]; dbd -= Sb * s[6][lb];
+				dac -= Sa * s[7][la]; dbc -= Sb * s[7][lb];
+			}
+		}
+		uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
+		dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
+		// the five results of this node, exactly k_hypervis's statements; the base value is only known for written nodes,
+		// so the copies in LDS hold the results with THEIR OWN base: every copy of a seam node has one (duplicated storage)
+		double rW = 0, rT = 0, rR = 0, rU = 0, rV = 0;
+		if (actw) {
+			const size_t o = TMX_SLAB_W(L, kk) * NS + col;
+			const double bs = xbase ? xbase[o] : 0.0;
+			rW = bs - dt * (1.0 / je) * nu_s * (uaW + ubW);
+		}
+		if (actn) {
+			const double invJ = 1.0 / jn;
+			size_t o = TMX_SLAB_T(L, kk) * NS + col;
+			double bs = xbase ? xbase[o] : 0.0;
+			rT = bs - dt * invJ * nu_s * (uaT + ubT);
+			o = TMX_SLAB_R(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rR = bs - dt * invJ * nu_s * (uaR + ubR);
+			const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
+			const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
+			o = TMX_SLAB_U(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rU = bs - dt * upa;
+			o = TMX_SLAB_V(L, kk) * NS + col;
+			bs = xbase ? xbase[o] : 0.0;
+			rV = bs - dt * upb;
+		}
+		__syncthreads();
+		if (t < TMX_HB_N) { s[0][t] = rW; s[1][t] = rT; s[2][t] = rR; s[3][t] = rU; s[4][t] = rV; }
+		__syncthreads();
+		if (inner) {
+			double o5[5] = { rW, rT, rR, rU, rV };
+			if (ta >= 0 || tb >= 0) {
+#pragma unroll
+				for (int f = 0; f < 5; f++) {
+					const double x = o5[f];
+					if (td >= 0) o5[f] = 0.5 * (0.5 * (x + s[f][ta]) + 0.5 * (s[f][tb] + s[f][td]));
+					else o5[f] = 0.5 * (x + s[f][ta >= 0 ? ta : tb]);
+				}
+			}
+			xout[TMX_SLAB_W(L, kk) * NS + col] = o5[0];
+			if (kk < L) {
+				xout[TMX_SLAB_T(L, kk) * NS + col] = o5[1];
+				xout[TMX_SLAB_R(L, kk) * NS + col] = o5[2];
+				xout[TMX_SLAB_U(L, kk) * NS + col] = o5[3];
+				xout[TMX_SLAB_V(L, kk) * NS + col] = o5[4];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+void tmxk_hypervis_block(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
+	double dt, double nu_s, double nu_d, double nu_v, int scale) {
+	dim3 blk(TMX_HB_T), grd(e->n_hvblocks, (p.L + 1 + TMX_HB_KT - 1) / TMX_HB_KT);
+	hipLaunchKernelGGL(k_hypervis_block, grd, blk, 0, e->stream, p, (const HvBlock *)e->d_hvblocks, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (src/atm/HorizontalDynamicsFEM.cpp:1817-1859):
+//   ApplyVectorHyperdiffusion(initial, update, dt, -K_v, -K_v)          U,V -= dt * (-K_v) * vector Laplacian(U,V)
+//   ApplyVectorHyperdiffusion(REFERENCE, update, dt, +K_v, +K_v)        U,V -= dt * (+K_v) * vector Laplacian(U,V)_ref
+//   ApplyScalarHyperdiffusion(initial, update, dt, K_s, comp 2, remove ref)   rho*theta, psi = initial - reference
+//   ApplyScalarHyperdiffusion(initial, update, dt, K_v, comp 3, remove ref)   W on interfaces
+// in that order per variable, one launch; the update instance is modified in place.  Same element kernels as
+// k_hypervis (ApplyScalarHyperdiffusion :1867-2203, ApplyVectorHyperdiffusion :2207-2414).
+__global__ __launch_bounds__(256) void k_uniform_diffusion(KParams p, const double * __restrict__ xsrc,
+	const double * __restrict__ xref, double * xout, double dt, double ks, double kv)
+{
+	__shared__ double s[4][10][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int tid = ty * 64 + lane;
+	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = TILE_X(p) * 64 + lane;
+	const int kk = blockIdx.y * 4 + ty;
+	const bool actw = (kk <= L) && (col < p.ncol);
+	const bool actn = (kk < L) && (col < p.ncol);
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+
+	double psiT = 0, psiW = 0, ua = 0, ub = 0, ra = 0, rb = 0;
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
+	if (actw) {
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
+		psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		psiW -= xref[TMX_SLAB_W(L, kk) * NS + col];
+	}
+	// the values to update, loaded with the operands (at the point of use their latency would follow the barriers)
+	double oW = 0.0, oT = 0.0, oU = 0.0, oV = 0.0;
+	if (actw) oW = xout[TMX_SLAB_W(L, kk) * NS + col];
+	if (actn) { oT = xout[TMX_SLAB_T(L, kk) * NS + col]; oU = xout[TMX_SLAB_U(L, kk) * NS + col]; oV = xout[TMX_SLAB_V(L, kk) * NS + col]; }
+	if (actn) {
+		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
+		psiT -= xref[TMX_SLAB_T(L, kk) * NS + col];
+		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col]; ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+		ra = xref[TMX_SLAB_U(L, kk) * NS + col]; rb = xref[TMX_SLAB_V(L, kk) * NS + col];
+	}
+	s[ty][0][lane] = psiT; s[ty][1][lane] = psiW;
+	s[ty][2][lane] = ua; s[ty][3][lane] = ub; s[ty][4][lane] = j2d * (c2a0 * ua + c2a1 * ub); s[ty][5][lane] = j2d * (c2a1 * ua + c2b1 * ub);
+	s[ty][6][lane] = ra; s[ty][7][lane] = rb; s[ty][8][lane] = j2d * (c2a0 * ra + c2a1 * rb); s[ty][9][lane] = j2d * (c2a1 * ra + c2b1 * rb);
+	__syncthreads();
+
+	double daT = 0, dbT = 0, daW = 0, dbW = 0;
+	double daub = 0, dbua = 0, dajua = 0, dbjub = 0, daubr = 0, dbuar = 0, dajuar = 0, dbjubr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+		daT += s[ty][0][la] * Da; dbT += s[ty][0][lb] * Db;
+		daW += s[ty][1][la] * Da; dbW += s[ty][1][lb] * Db;
+		daub += s[ty][3][la] * Da; dbua += s[ty][2][lb] * Db;
+		dajua += s[ty][4][la] * Da; dbjub += s[ty][5][lb] * Db;
+		daubr += s[ty][7][la] * Da; dbuar += s[ty][6][lb] * Db;
+		dajuar += s[ty][8][la] * Da; dbjubr += s[ty][9][lb] * Db;
+	}
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	daT *= ida; dbT *= idb; daW *= ida; dbW *= idb;
+	daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+	daubr *= ida; dbuar *= idb; dajuar *= ida; dbjubr *= idb;
+	const double invJ2 = 1.0 / j2d;
+	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+	const double dvr = (dajuar + dbjubr) * invJ2, clr = (daubr - dbuar) * invJ2;
+	__syncthreads();
+	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
+	s[ty][2][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][3][lane] = je * (c2a1 * daW + c2b1 * dbW);
+	s[ty][4][lane] = dv; s[ty][5][lane] = cl; s[ty][6][lane] = dvr; s[ty][7][lane] = clr;
+	__syncthreads();
+	if (!actw) return;
+
+	double uaT = 0, ubT = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0, dadr = 0, dbdr = 0, dacr = 0, dbcr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+		uaT += s[ty][0][la] * Sa; ubT += s[ty][1][lb] * Sb;
+		uaW += s[ty][2][la] * Sa; ubW += s[ty][3][lb] * Sb;
+		dad -= Sa * s[ty][4][la]; dbd -= Sb * s[ty][4][lb];
+		dac -= Sa * s[ty][5][la]; dbc -= Sb * s[ty][5][lb];
+		dadr -= Sa * s[ty][6][la]; dbdr -= Sb * s[ty][6][lb];
+		dacr -= Sa * s[ty][7][la]; dbcr -= Sb * s[ty][7][lb];
+	}
+	uaT *= ida; ubT *= idb; uaW *= ida; ubW *= idb;
+	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb; dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
+	{
+		const size_t o = TMX_SLAB_W(L, kk) * NS + col;
+		xout[o] = oW - dt * (1.0 / je) * kv * (uaW + ubW);
+	}
+	if (actn) {
+		size_t o = TMX_SLAB_T(L, kk) * NS + col;
+		xout[o] = oT - dt * (1.0 / jn) * ks * (uaT + ubT);
+		const double nkv = -kv;
+		const double upa = nkv * dad - nkv * j2d * (c2a1 * dac + c2b1 * dbc);
+		const double upb = nkv * dbd + nkv * j2d * (c2a0 * dac + c2a1 * dbc);
+		const double upar = kv * dadr - kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
+		const double upbr = kv * dbdr + kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
+		o = TMX_SLAB_U(L, kk) * NS + col;
+		double v = oU; v -= dt * upa; v -= dt * upar; xout[o] = v;
+		o = TMX_SLAB_V(L, kk) * NS + col;
+		v = oV; v -= dt * upb; v -= dt * upbr; xout[o] = v;
+	}
+}
+
+void tmxk_uniform_diffusion(tmx_engine * e, const KParams & p, const double * xsrc, const double * xref, double * xout,
+	double dt, double ks, double kv) {
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 1 + 3) / 4);
+	hipLaunchKernelGGL(k_uniform_diffusion, grd, blk, 0, e->stream, p, xsrc, xref, xout, dt, ks, kv);
+}
+
+// Vertical uniform diffusion of U, V in VerticalDynamicsFEM::StepExplicit (src/atm/VerticalDynamicsFEM.cpp:1059-1105):
+// update += dt * K_v / ztop^2 * (DiffDiffNodeToNode(U) - DiffDiffNodeToNode(U_ref)), same for V.
+__global__ __launch_bounds__(256) void k_v_uniform_diffusion_uv(KParams p, const double * __restrict__ xin,
+	const double * __restrict__ xref, double * __restrict__ xup, double dt, double cf)
+{
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	const int col = TILE_X(p) * 64 + threadIdx.x;
+	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	if (k >= L || col >= p.ncol) return;
+#pragma unroll
+	for (int v = 0; v < 2; v++) {
+		const int sb = v * L;
+		double dd = 0.0, ddr = 0.0;
+#pragma unroll
+		for (int off = -2; off <= 2; off++) {
+			const int l = k + off;
+			if (l < 0 || l >= L) continue;
+			const double c = OPC(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+			dd += c * xin[(size_t)(sb + l) * NS + col];
+			ddr += c * xref[(size_t)(sb + l) * NS + col];
+		}
+		xup[(size_t)(sb + k) * NS + col] += dt * cf * (dd - ddr);
+	}
+}
+
+void tmxk_v_uniform_diffusion_uv(tmx_engine * e, const KParams & p, const double * xin, const double * xref, double * xup, double dt, double cf) {
+	dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
+	hipLaunchKernelGGL(k_v_uniform_diffusion_uv, grd, blk, 0, e->stream, p, xin, xref, xup, dt, cf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shallow water: HorizontalDynamicsFEM::StepShallowWater (src/atm/HorizontalDynamicsFEM.cpp:321-647).
+// One level; H is kept in the rho*theta slab.  out = base + dt * rhs(in).
+
+__global__ __launch_bounds__(64) void k_sw_explicit(KParams p, const double * __restrict__ xin,
+	const double * xbase, double * xup, double dt)
+{
+	__shared__ double s[5][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x;
+	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
+	const size_t NS = (size_t)p.NS;
+	const int col = TILE_X(p) * 64 + lane;
+	const bool act = col < p.ncol;
+	double ua = 0, ub = 0, h = 0, c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, fcor = 0, zs = 0;
+	if (act) {
+		ua = xin[0 * NS + col]; ub = xin[1 * NS + col]; h = xin[2 * NS + col];
+		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
+		j2d = p.g2d[G2_J2D * NS + col]; fcor = p.g2d[G2_F * NS + col]; zs = p.g2d[G2_ZS * NS + col];
+	}
+	const double cua = c2a0 * ua + c2a1 * ub;
+	const double cub = c2a1 * ua + c2b1 * ub;
+	double ke = 0.5 * (cua * ua + cub * ub);
+	ke += p.grav * h;
+	const double ba = j2d * cua, bb = j2d * cub;
+	s[0][lane] = ua; s[1][lane] = ub; s[2][lane] = ke;
+	s[3][lane] = ba * (h - zs); s[4][lane] = bb * (h - zs);
+	__syncthreads();
+	if (!act) return;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	double daub = 0, dbua = 0, dake = 0, dbke = 0, dafa = 0, dbfb = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j;
+		dafa -= s[3][la] * sS[i * 4 + t];
+		daub += s[1][la] * sD[t * 4 + i];
+		dake += s[2][la] * sD[t * 4 + i];
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int lb = eb + 4 * i + t;
+		dbfb -= s[4][lb] * sS[j * 4 + t];
+		dbua += s[0][lb] * sD[t * 4 + j];
+		dbke += s[2][lb] * sD[t * 4 + j];
+	}
+	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	dafa *= ida; daub *= ida; dake *= ida; dbfb *= idb; dbua *= idb; dbke *= idb;
+	double upa = 0.0, upb = 0.0;
+	const double zeta = (daub - dbua);
+	const double ucza = cub * zeta, uczb = -cua * zeta;
+	upa += fcor * j2d * cub;
+	upb -= fcor * j2d * cua;
+	upa += -dake + ucza;
+	upb += -dbke + uczb;
+	const double invJ2 = 1.0 / j2d;
+	xup[0 * NS + col] = xbase[0 * NS + col] + dt * upa;
+	xup[1 * NS + col] = xbase[1 * NS + col] + dt * upb;
+	xup[2 * NS + col] = xbase[2 * NS + col] - dt * invJ2 * (dafa + dbfb);
+}
+
+void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt) {
+	hipLaunchKernelGGL(k_sw_explicit, dim3(NTILES(e, p)), dim3(64), 0, e->stream, p, xin, xbase, xup, dt);
+}
+

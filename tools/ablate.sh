@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/abl
-make -C tempestmodel_amd/csrc EXTRA="$2" OUT="$PWD/build/abl/$1.so" > /dev/null
+make -C tempestmodel_amd/csrc -j8 EXTRA="$2" BUILD="$PWD/build/abl/obj_$1" OUT="$PWD/build/abl/$1.so" > /dev/null
 echo "built build/abl/$1.so"

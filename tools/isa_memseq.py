@@ -2,7 +2,7 @@
 """Memory-op / waitcnt sequence of one kernel's ISA (labels kept), to spot vmcnt(0) stalls.
 usage: isa_memseq.py <mangled-name-prefix> [max_chars]"""
 import re, subprocess, sys
-src = '/root/repo/tempestmodel_amd/csrc/tmx_kernels.hip'
+src = '/root/repo/tempestmodel_amd/csrc/tmx_k_column.hip'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-S',
                        '--cuda-device-only', '-o', '/tmp/k.s', src], stderr=subprocess.DEVNULL, cwd='/tmp')
 txt = open('/tmp/k.s').read()

@@ -1,6 +1,7 @@
 #!/bin/bash
-# kernel resource usage table
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -c /root/repo/tempestmodel_amd/csrc/tmx_kernels.hip -o /tmp/k.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+# kernel resource usage table of one translation unit: tools/kres.sh [horizontal|vertical|column|exchange|physics|unique] [extra flags]
+TU=${1:-column}; shift
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off "$@" -c /root/repo/tempestmodel_amd/csrc/tmx_k_$TU.hip -o /tmp/k.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None
 for l in sys.stdin:
