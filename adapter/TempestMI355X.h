@@ -505,9 +505,13 @@ private:
 			int iOk = (tmx_halo_p2p_export(m_pEngine, &(vecMine[0])) == TMX_OK) ? 1 : 0, iAll = 0;
 			std::string strWhy = iOk ? "" : tmx_last_error();
 			MPI_Allreduce(&iOk, &iAll, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+			// fConnected: THIS rank completed tmx_halo_p2p_connect (only then may it be switched back below: a rank whose export
+			// succeeded while another rank's failed never connected, and tmx_halo_p2p_enable would refuse it on that rank alone)
+			bool fConnected = false;
 			if (iAll) {
 				MPI_Allgather(&(vecMine[0]), nBlob, MPI_BYTE, &(vecAll[0]), nBlob, MPI_BYTE, MPI_COMM_WORLD);
 				iOk = (tmx_halo_p2p_connect(m_pEngine, &(vecAll[0])) == TMX_OK) ? 1 : 0;
+				fConnected = (iOk != 0);
 				if (!iOk) strWhy = tmx_last_error();
 				MPI_Allreduce(&iOk, &iAll, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
 			}
@@ -519,7 +523,7 @@ private:
 					fprintf(stderr, "tempest_mi355x: rank %d: peer-to-peer halo not available (%s); all ranks use RCCL send/recv\n", nRank, strWhy.c_str());
 				}
 				InitRcclComm(nRank);
-				if (iOk) {
+				if (fConnected) {
 					Check(tmx_halo_p2p_enable(m_pEngine, 0));      // this rank did connect: switch it back
 				}
 			}

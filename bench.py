@@ -87,13 +87,21 @@ def measured_traffic(op, ne, L, world, launches_per_step):
         return None
 
 
+def latest_profile(suffix):
+    """Newest committed profiles/rNN_<suffix> (the rounds keep their own files), or None."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return c[-1] if c else None
+
+
 def mfma_report():
-    """MFMA utilisation of the path that ran (measured offline with rocprofv3 counters, profiles/r02_mfma_ab.json) and the
-    A/B of the opt-in matrix-unit contractions against the default LDS + VALU ones."""
-    path = os.path.join(ROOT, "profiles", "r02_mfma_ab.json")
+    """MFMA utilisation of the path that ran (measured offline with rocprofv3 counters) and the A/B of the opt-in matrix-unit
+    contractions against the default LDS + VALU ones: the NEWEST committed profiles/rNN_mfma_ab.json."""
+    path = latest_profile("mfma_ab.json")
     ab = None
     try:
         ab = json.load(open(path))
+        ab["source"] = os.path.relpath(path, ROOT)
     except Exception:
         pass
     on = os.environ.get("TMX_MFMA", "0") not in ("", "0")
@@ -101,6 +109,48 @@ def mfma_report():
     if on and ab and "mfma_busy_fraction_of_explicit_kernel" in ab.get("TMX_MFMA=1", {}):
         active = ab["TMX_MFMA=1"]["mfma_busy_fraction_of_explicit_kernel"]
     return {"active": active, "ab": ab}
+
+
+def dominant_kernel_from_stats(ne, L, world):
+    """The dominant KERNEL as `rocprofv3 --kernel-trace --stats` ranks them in the committed profile of this workload shape
+    (profiles/rNN_kernel_stats*.csv): (operation, kernel name, share) or None when no profile of the shape is committed.  The
+    HIP events of this run time whole operations (an explicit stage = several instantiations of k_h_explicit + k_h_w_update),
+    so which single kernel dominates is taken from the profile, and its launch time from this run."""
+    import csv
+    tag = "" if (ne, L, world) == (30, 30, 1) else ("_ne15" if (ne, L, world) == (15, 30, 1) else None)
+    if tag is None:
+        return None
+    path = latest_profile("kernel_stats%s.csv" % tag)
+    if not path:
+        return None
+    try:
+        rows = list(csv.DictReader(open(path)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        base = top["Name"].replace("void ", "").split("<")[0].split("(")[0]
+        for op, names in OP_ROCPROF.items():
+            if base in names:
+                return op, top["Name"].split("(")[0], float(top["TotalDurationNs"]) / tot, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None
+
+
+def smi_snapshot():
+    """Clocks / power / temperature of GPU 0 as rocm-smi reports them (strings as printed), or None."""
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, universal_newlines=True, timeout=20).stdout
+        d = json.loads(out)
+        card = d.get("card0", next(iter(d.values())))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "temperature (sensor edge)")):
+                keep[k.strip()] = v
+        return keep or None
+    except Exception:
+        return None
 
 
 def cpu_baseline_mpi(ne, L, dt, nsteps_ref, nranks=6):
@@ -195,12 +245,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--develop", type=int, default=10, help="untimed steps before the warm-up (developed state)")
     ap.add_argument("--halo", default=os.environ.get("TMX_HALO", "rccl"), choices=["auto", "rccl", "p2p"],
-                    help="multi-rank halo transport: RCCL send/recv, peer-to-peer writes into IPC-mapped ghost buffers, or (default) "
-                         "set up both, check that they deliver identical bytes, time them on this machine and keep the faster; "
-                         "falls back to RCCL when the peer-to-peer mapping cannot be set up or disagrees")
+                    help="multi-rank halo transport: rccl (default) = RCCL send/recv; p2p = peer-to-peer writes into IPC-mapped ghost buffers; "
+                         "auto = set up both, check that they deliver identical bytes, time them on this machine and keep the faster "
+                         "(falls back to RCCL when the peer-to-peer mapping cannot be set up or disagrees)")
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks on HIP device 0 (1-GPU box; needs --halo p2p, host rendezvous over gloo): exercises the multi-process path, not a scaling number")
     ap.add_argument("--physics", default="none", help="hs: tmx_physics_held_suarez after every step (BASELINE config 5's shape; not the headline metric)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, the headline): the ne30 problem is fixed as --gpus grows.  weak: the grid grows with the rank count, "
+                         "ne = the multiple of 2 nearest to --ne * sqrt(gpus) (30 / 42 / 60 / 84 at 1 / 2 / 4 / 8), dt scaled with the element width")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="steps of the untimed sustained leg after the timed region (clock / power before and after are reported; 0: skip)")
+    ap.add_argument("--parity-steps", type=int, default=3,
+                    help="N > 1: after the timing, all ranks and a single-rank engine on rank 0 step this many times from the initial state and "
+                         "rank 0's patches are compared bit for bit (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -232,6 +290,9 @@ def main():
     from tempestmodel_amd.engine import Engine
 
     ne, L, dt = args.ne, args.levels, args.dt
+    if args.scaling == "weak" and world > 1:
+        ne = 2 * int(round(args.ne * (world ** 0.5) / 2.0))
+        dt = args.dt * args.ne / ne
     grid = CubedSphereGrid(ne, L, 30000.0, ppd=args.ppd)
     states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
     eng = Engine(grid, rank=rank, n_ranks=world, device=local_rank)
@@ -377,6 +438,47 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
+    # sustained leg (untimed for `value`): enough steps for clocks and power to settle, with the SMI readings on both sides
+    sustained = None
+    if args.sustained_steps > 0:
+        smi0 = smi_snapshot() if rank == 0 else None
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            eng.step_ars343(dt)
+        barrier()
+        ts = time.perf_counter() - ts0
+        if world > 1:
+            tt = torch.tensor([ts], dtype=torch.float64, device="cpu" if args.share_device else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts = float(tt.item())
+        sustained = {"steps": args.sustained_steps, "seconds": ts, "ms_per_step": 1e3 * ts / args.sustained_steps,
+                     "smi_before": smi0, "smi_after": smi_snapshot() if rank == 0 else None}
+
+    # N > 1: the line carries its own parity proof -- every rank steps again from the initial state, rank 0 also steps a
+    # single-rank engine holding all patches, and rank 0's patches must come out identical, bit for bit
+    parity = None
+    if world > 1 and args.parity_steps > 0 and not hs:
+        import numpy as np
+        eng.upload_state(0, states)
+        for _ in range(args.parity_steps):
+            _step(dt)
+        barrier()
+        got = eng.download_state(0)
+        if rank == 0:
+            one = Engine(grid, rank=0, n_ranks=1, device=local_rank)
+            one.upload_state(0, states)
+            for _ in range(args.parity_steps):
+                one.step_ars343(dt)
+            one.sync()
+            ref = one.download_state(0)
+            same = all(np.array_equal(got[p][0], ref[p][0]) and np.array_equal(got[p][1], ref[p][1]) for p in eng.local_patches)
+            worst = max(float(np.max(np.abs(got[p][0] - ref[p][0]))) for p in eng.local_patches)
+            parity = {"steps": args.parity_steps, "patches_compared": len(eng.local_patches), "identical_to_single_rank_engine": bool(same),
+                      "max_abs_difference": worst}
+            one.close()
+        barrier()
+
     # sanity: the state must still be finite
     chk = eng.download_state(0)
     import numpy as np
@@ -393,12 +495,15 @@ def main():
         value = dof_per_step * args.steps / wall
         # dominant operation of the step on this rank; a launch = one call of the operation (its kernels together)
         op_time = {op: sum(prof[k][0] for k in ks) for op, ks in OP_KERNELS.items()}
-        # The roofline object is for the dominant KERNEL, as `rocprofv3 --stats` ranks them (profiles/r03_kernel_stats.csv: k_vi_pair
-        # 32 %, k_dss 23 %, k_h_explicit<true,7> 10 %, ...).  The HIP events time whole operations, and the explicit stage is four
-        # different instantiations of k_h_explicit (0 / 4 / 6 / 7 combination terms, 78-194 us) plus k_h_w_update: its share is
-        # spread over them, so it never holds the dominant kernel even on a box where its sum passes the column solve's.
-        symbols = {"h_explicit": 4}
-        dom = max((op for op in op_time if ALG_BYTES[op] > 0), key=lambda op: op_time[op] / symbols.get(op, 1))
+        # The roofline object is for the dominant KERNEL as `rocprofv3 --stats` ranks them.  The HIP events of this run time whole
+        # operations (the explicit stage = several instantiations of k_h_explicit + k_h_w_update), so the kernel ranking is read
+        # from the committed kernel-trace profile of this workload shape; without one the top operation is taken unscaled.
+        dk = dominant_kernel_from_stats(ne, L, world)
+        if dk is not None:
+            dom, dom_note = dk[0], "dominant kernel per %s: %s (%.1f %% of kernel time there)" % (dk[3], dk[1], 100.0 * dk[2])
+        else:
+            dom = max((op for op in op_time if ALG_BYTES[op] > 0), key=lambda op: op_time[op])
+            dom_note = "no committed kernel-trace profile of this shape: the operation with the largest summed time of this run (several kernels)"
         op_launches = {op: max(sum(prof[k][1] for k in ks), 1) for op, ks in OP_KERNELS.items()}
         avg_ms = op_time[dom] / op_launches[dom]
         local_points = points / world
@@ -430,7 +535,7 @@ def main():
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
             "value": value, "unit": "element-DOF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "sypd": dt / (wall / args.steps) / 365.0,
             "config": {"workload": "Jablonowski-Williamson baroclinic wave, cubed sphere ne%d np4 L%d, ztop 30 km, "
@@ -443,7 +548,7 @@ def main():
             # `bound`: what limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64
             # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
             "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
-                         "kernel": kernel_name, "operation": dom,
+                         "kernel": kernel_name, "operation": dom, "dominant_by": dom_note,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
@@ -462,7 +567,18 @@ def main():
             "developed_steps": args.develop, "host_cpu_count": os.cpu_count(),
             "physics_after_every_step": args.physics,
             "state_finite": bool(state_finite),
+            "sustained": sustained,
         }
+        if world > 1:
+            send = eng.plan(0).reshape(-1, 4)
+            per_peer = {}
+            for r_ in send[:, 3]:
+                per_peer[int(r_)] = per_peer.get(int(r_), 0) + 1
+            nslab = 5 * L + 1
+            out["multi_rank"] = {"rccl_comm_ranks": eng.info(9), "halo_transport": {0: "none", 1: "rccl", 2: "p2p", 3: "loopback"}.get(eng.info(11), "?"),
+                                 "rank0_message_bytes_per_peer": {str(k): v * nslab * 8 for k, v in sorted(per_peer.items())},
+                                 "rank0_early_tiles": eng.info(7), "rank0_late_tiles": eng.info(8),
+                                 "parity": parity}
         if ablation_build:      # a library named by TMX_LIBRARY: never a result, say so in the line itself
             out["ablation_build"] = True
             out["library"] = os.environ["TMX_LIBRARY"]

@@ -394,7 +394,10 @@ enum {
 	TMX_INFO_HBM_BYTES,           /* device bytes allocated by the engine on this rank   */
 	TMX_INFO_METRIC_CLOSED_FORM,  /* 1: 3-D metric evaluated in registers, 0: streamed  */
 	TMX_INFO_EARLY_TILES,         /* 64-column tiles launched before the exchange starts (0: stages are not split) */
-	TMX_INFO_LATE_TILES           /* tiles updated while the exchange is in flight      */
+	TMX_INFO_LATE_TILES,          /* tiles updated while the exchange is in flight      */
+	TMX_INFO_COMM_RANKS,          /* ncclCommCount of the communicator made by tmx_comm_init (0: none)  */
+	TMX_INFO_SEND_COLUMNS,        /* columns this rank sends per exchange (all peers)     */
+	TMX_INFO_HALO_TRANSPORT       /* 0 none (one rank), 1 RCCL send/recv, 2 peer-to-peer writes, 3 in-process loopback (tests) */
 };
 long long tmx_info(tmx_engine * e, int what);
 

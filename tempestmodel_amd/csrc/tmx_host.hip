@@ -48,6 +48,7 @@ typedef int (*fn_ncclGroupEnd)(void);
 typedef int (*fn_ncclSend)(const void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_ncclRecv)(void *, size_t, int, int, void *, hipStream_t);
 typedef const char * (*fn_ncclGetErrorString)(int);
+typedef int (*fn_ncclCommCount)(void *, int *);
 
 static struct {
 	void * lib = nullptr;
@@ -59,6 +60,7 @@ static struct {
 	fn_ncclSend Send = nullptr;
 	fn_ncclRecv Recv = nullptr;
 	fn_ncclGetErrorString GetErrorString = nullptr;
+	fn_ncclCommCount CommCount = nullptr;
 } g_nccl;
 
 static int load_rccl() {
@@ -80,6 +82,7 @@ static int load_rccl() {
 	g_nccl.Send = (fn_ncclSend)dlsym(h, "ncclSend");
 	g_nccl.Recv = (fn_ncclRecv)dlsym(h, "ncclRecv");
 	g_nccl.GetErrorString = (fn_ncclGetErrorString)dlsym(h, "ncclGetErrorString");
+	g_nccl.CommCount = (fn_ncclCommCount)dlsym(h, "ncclCommCount");
 	REQUIRE(g_nccl.GetUniqueId && g_nccl.CommInitRank && g_nccl.Send && g_nccl.Recv && g_nccl.GroupStart && g_nccl.GroupEnd,
 		TMX_ERR_COMM, "RCCL symbols missing");
 	return TMX_OK;
@@ -138,6 +141,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (cfg->equation_set == TMX_EQN_SHALLOW_WATER) REQUIRE(cfg->levels == 1, TMX_ERR_INVALID, "shallow water needs levels == 1");
 	else REQUIRE(cfg->levels >= 3, TMX_ERR_INVALID, "levels must be >= 3");
 	REQUIRE(cfg->n_patches >= 1 && cfg->n_instances >= 1, TMX_ERR_INVALID, "bad patch / instance count");
+	REQUIRE(cfg->n_instances <= 32, TMX_ERR_UNSUPPORTED, "%d data instances: the stepper programs track instances in 32-bit masks", cfg->n_instances);
 	REQUIRE(cfg->n_ranks >= 1 && cfg->rank >= 0 && cfg->rank < cfg->n_ranks, TMX_ERR_INVALID, "bad rank %d of %d", cfg->rank, cfg->n_ranks);
 	tmx_engine * e = new tmx_engine();
 	e->cfg = *cfg;
@@ -1602,7 +1606,8 @@ static int sw_stage_split(tmx_engine * e, int iinit, int ibase, int iupd, double
 // CopyData restricted to the U,V slabs: the implicit step overwrites rho*theta, W, rho of every column
 static int copy_uv(tmx_engine * e, int src, int dst) {
 	ProfScope ps(e, TMX_K_LINCOMB);
-	HIPCHK(hipMemcpyAsync(inst(e, dst), inst(e, src), (size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	// (the source's U,V slabs may live in another instance's slot: inst_uv, not inst)
+	HIPCHK(hipMemcpyAsync(inst(e, dst), inst_uv(e, src), (size_t)2 * e->L * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
 	return surface_copy(e, src, dst);
 }
 
@@ -2317,6 +2322,7 @@ extern "C" int tmx_v_filter_negative_tracers(tmx_engine * e, int instance) {
 
 static int vi_terms_explicit(tmx_engine * e, int iinit, int iupd, double dt) { return tmx_v_step_implicit_terms_explicitly(e, iinit, iupd, dt); }
 
+static thread_local bool g_hvis_two_pass = true;      // set by run_program from the engine's configuration (order-4 hyperviscosity with a non-zero coefficient)
 static bool g_dry_unsafe = false;      // tmx_debug_program_copies' negative control (dry runs only): every share accepted, no copy-on-write
 // What an operation of a stepper program reads and writes, as bit masks over the data instances.  full: instances it
 // overwrites entirely without reading them; part: instances it updates in place.
@@ -2330,7 +2336,9 @@ static OpAccess op_access(const Op & o, bool vimp_noop) {
 	case OP_VIMP: if (vimp_noop) break;      // fall through
 	case OP_HEXP: case OP_VEXP: case OP_VITE: x.reads = bit(o.a) | bit(o.b); x.part = bit(o.b); break;
 	case OP_DSS: case OP_VFILT: x.reads = bit(o.a); x.part = bit(o.a); break;
-	case OP_HVIS: x.reads = bit(o.a); x.full = bit(o.b) | bit(o.c); break;
+	// StepAfterSubCycle rewrites all of b on every branch; the working instance c is written (entirely) by the two-pass
+	// branch only -- without viscosity or with one pass it is left alone, so a c that shares a slot keeps its contents
+	case OP_HVIS: x.reads = bit(o.a); x.full = bit(o.b) | (g_hvis_two_pass ? bit(o.c) : 0u); break;
 	case OP_LINCOMB:
 		x.stencil = false;      // node by node: a source may share the destination's slot
 		for (int m = 0; m < o.nlc; m++) if (o.lc[m] != 0.0) x.reads |= bit(m);
@@ -2454,6 +2462,7 @@ static int run_program(tmx_engine * e, const Program & p) {
 	const size_t n = p.size();
 	ProgramScope scope(e);
 	const bool noop = e->sw || e->fully_explicit;      // V.StepImplicit does nothing
+	g_hvis_two_pass = e->dry_run || (hypervis_active(e) && e->cfg.hypervis_order != 2);
 	// shared slots left by the previous step: kept where this program allows it, given their own copy otherwise
 	for (int b = 0; b < (int)e->imap.size() && (e->n_shared || e->n_uvshared); b++)
 		if ((e->imap[b] != b && !share_is_safe(p, 0, e->imap[b], b, noop)) || (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b, noop)))
@@ -2961,6 +2970,13 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_METRIC_CLOSED_FORM: return e->metric_closed ? 1 : 0;
 		case TMX_INFO_EARLY_TILES: return e->split_stage ? e->n_quads_early : 0;
 		case TMX_INFO_LATE_TILES: return e->split_stage ? e->n_quads_late : 0;
+		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
+			int n = 0;
+			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;
+			return 0;
+		}
+		case TMX_INFO_SEND_COLUMNS: return e->nsend;
+		case TMX_INFO_HALO_TRANSPORT: return (e->cfg.n_ranks == 1) ? 0 : (e->lb ? 3 : (e->p2p ? 2 : (e->comm ? 1 : 0)));
 	}
 	return -1;
 }

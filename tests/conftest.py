@@ -10,3 +10,23 @@ for p in (ROOT, HERE):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_report_header(config):
+    """The tolerance behind every `== exact` assertion of this run (0.0 = identical doubles) goes into the report header, so that a
+    log shows whether the suite ran bit for bit or relaxed (tests/golden_util.py: exact_tolerance)."""
+    try:
+        import golden_util
+        return "tempestmodel_amd: " + golden_util.exact_tolerance_report()
+    except Exception as ex:
+        return "tempestmodel_amd: exact-comparison tolerance UNAVAILABLE (%s)" % ex
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The same line at the end of the run: -q suppresses the header, and the driver's logs are -q runs."""
+    try:
+        import golden_util
+        if golden_util._EXACT_TOL is not None:      # only when a test of this run asked for it
+            terminalreporter.write_line("tempestmodel_amd: " + golden_util.exact_tolerance_report())
+    except Exception:
+        pass

@@ -177,30 +177,50 @@ def interp_rel(x, y):
 
 
 _EXACT_TOL = None
+_EXACT_WHY = ""
 
 
 def exact_tolerance():
     """Tolerance of the comparisons that are bit for bit on this project's hosts: 0.0 where the host's libm is the one
     tempestmodel_amd/csrc/tmx_refmath.h restates (glibc >= 2.28, x86-64 FMA variant: the build container and the GPU boxes),
-    checked by compiling tests/native/refmath_check.c and running it on 4e5 arguments; on any other host (no FMA units,
-    another libm, another architecture) the device, the C oracle and the golden vectors still agree to rounding error, and
-    the north-star tolerance 1e-10 is what the assertions then use."""
-    global _EXACT_TOL
+    checked by compiling tests/native/refmath_check.c and running it on 4e5 arguments.  Only when that probe RAN and found
+    another libm (no FMA units, another libm, another architecture) do the assertions fall back to the north-star tolerance
+    1e-10 -- the device, the C oracle and the golden vectors still agree to rounding error there.  A probe that could not run
+    (no gcc, compile error) is an error, not a reason to relax: set TMX_ALLOW_INEXACT=1 to accept 1e-10 on such a host.
+    TMX_REQUIRE_EXACT=1 fails instead of relaxing in either case.  The tolerance in use is printed in the pytest header
+    (tests/conftest.py) and by exact_tolerance_report()."""
+    global _EXACT_TOL, _EXACT_WHY
     if _EXACT_TOL is None:
         import subprocess, tempfile
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        ok = False
+        ran, ok, why = False, False, ""
         try:
             with tempfile.TemporaryDirectory() as td:
                 exe = os.path.join(td, "refmath_check")
                 subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "tempestmodel_amd", "csrc"), "-o", exe,
                                 os.path.join(root, "tests", "native", "refmath_check.c"), "-lm"], check=True,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                ok = subprocess.run([exe, "400000"], stdout=subprocess.DEVNULL).returncode == 0
-        except Exception:
-            ok = False
-        _EXACT_TOL = 0.0 if ok else 1e-10
-        if not ok:
-            sys.stderr.write("golden_util: this host's libm is not the one tmx_refmath.h restates: exact comparisons use 1e-10\n")
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                rc = subprocess.run([exe, "400000"], stdout=subprocess.DEVNULL).returncode
+                ran, ok = True, rc == 0
+                if not ok:
+                    why = "this host's libm is not the one tmx_refmath.h restates (refmath_check exit code %d)" % rc
+        except Exception as ex:      # the probe itself failed: no gcc, compile error
+            why = "the libm probe could not run (%s: %s)" % (type(ex).__name__, str(ex)[:200])
+        require = os.environ.get("TMX_REQUIRE_EXACT", "") not in ("", "0")
+        if ok:
+            _EXACT_TOL, _EXACT_WHY = 0.0, "bit for bit (host libm == tmx_refmath.h, checked on 4e5 arguments)"
+        elif require:
+            raise RuntimeError("TMX_REQUIRE_EXACT=1: exact comparisons are not possible on this host: " + why)
+        elif ran or os.environ.get("TMX_ALLOW_INEXACT", "") not in ("", "0"):
+            _EXACT_TOL, _EXACT_WHY = 1e-10, "RELAXED to 1e-10: " + why
+            sys.stderr.write("golden_util: %s: exact comparisons use 1e-10\n" % why)
+        else:
+            raise RuntimeError("golden_util.exact_tolerance: " + why + "; fix the host or set TMX_ALLOW_INEXACT=1 to compare with 1e-10")
     return _EXACT_TOL
+
+
+def exact_tolerance_report():
+    """One line for test reports: the tolerance the `exact` assertions use on this host, and why."""
+    tol = exact_tolerance()
+    return "exact-comparison tolerance = %g (%s)" % (tol, _EXACT_WHY)
 

@@ -1727,6 +1727,68 @@ def test_band_lu_without_fused_multiply_add_flavour():
     assert err_nofma <= EXACT and err_fma > EXACT
 
 
+def test_nofma_flavour_vs_live_mkl_reference():
+    """Pins the second library flavour (libtempest_mi355x_nofma.so: band-LU updates as multiply + subtract) to a REAL reference:
+    the MKL-linked oracle/_ref/tmx_ref_dump run live on this host.  MKL 2021.4 dispatches a non-FMA level-2 path on the AMD
+    hosts of the GPU boxes (tools/host_lapack_probe.sh), which is the host class the flavour exists for.  Whether THIS host is
+    one is measured, not assumed: the MKL build and the OpenBLAS-netlib build (FMA kernels on every host) of the reference
+    run the same 100 steps at ne4 L10; identical checksums mean MKL uses FMAs here, the default flavour is the matching one
+    (test_hundred_steps_ne15_L30 covers it) and this test skips, saying so.  Otherwise BASELINE config 2 (ne15 np4 L30,
+    dt 300 s) runs 100 ARS343 steps in the MKL reference, which hands over its own geometry and its state after 2 steps, and
+    the nofma flavour must reproduce the reference's final state bit for bit (child process: the library is chosen at load)."""
+    import subprocess, sys, tempfile, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mkl_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump")
+    ob_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump_lapack2")
+    if not (os.path.exists(mkl_bin) and os.path.exists(ob_bin)):
+        pytest.skip("oracle/_ref did not travel with the snapshot (built in the build container from /root/reference)")
+    if not os.path.exists(os.path.join(root, "tempestmodel_amd", "libtempest_mi355x_nofma.so")):
+        pytest.fail("libtempest_mi355x_nofma.so is missing: build() makes it (make -C tempestmodel_amd/csrc nofma)")
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    sums = []
+    for b in (mkl_bin, ob_bin):
+        out = subprocess.run([b, "--mode", "steps", "--ne", "4", "--levels", "10", "--dt", "200", "--warm", "2", "--steps", "100",
+                              "--every", "100", "--geom", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             universal_newlines=True, timeout=900).stdout
+        sums.append([l for l in out.splitlines() if "checksum step100" in l])
+    cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    print("host CPU:", cpu, "| MKL reference == OpenBLAS-netlib reference after 100 steps at ne4 L10:", sums[0] == sums[1])
+    assert sums[0] and sums[1], "the reference binaries printed no checksum"
+    if sums[0] == sums[1]:
+        pytest.skip("MKL evaluates the band LU with fused multiply-adds on this host (%s): the default flavour is the matching one "
+                    "(test_hundred_steps_ne15_L30); the multiply + subtract flavour has no live reference here" % cpu)
+    with tempfile.TemporaryDirectory() as td:
+        ref = os.path.join(td, "ref.tmxd")
+        subprocess.run([mkl_bin, "--mode", "steps", "--ne", "15", "--levels", "30", "--dt", "300", "--warm", "2", "--steps", "100",
+                        "--every", "100", "--geom", "1", "--out", ref], env=env, check=True, stdout=subprocess.DEVNULL, timeout=1500)
+        code = textwrap.dedent("""
+            import os, sys
+            sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+            import golden_util as gu, tmxd
+            from tempestmodel_amd.engine import Engine, LIB_PATH
+            rd = tmxd.read(%r)
+            g, _ = gu.grid_from_fixture(rd, override=True)
+            start = gu.full_states(rd, "warm", 6); end = gu.full_states(rd, "step100", 6)
+            e = Engine(g); e.upload_state(0, start)
+            for _ in range(100):
+                e.step_ars343(300.0)
+            e.sync()
+            got = e.download_state(0); e.close()
+            print("RESULT", " ".join("%%.3e" %% v for v in gu.prognostic_errors(got, end)))
+        """ % (root, root, ref))
+        res = {}
+        for flavour, fma in (("nofma", "0"), ("default", "1")):
+            cenv = dict(os.environ, TMX_LU_FMA=fma)
+            cenv.pop("TMX_LIBRARY", None)
+            r = subprocess.run([sys.executable, "-c", code], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+            assert r.returncode == 0 and line, r.stderr[-2000:]
+            res[flavour] = [float(v) for v in line[0].split()[1:]]
+    print("ne15 L30, 100 steps against the live MKL reference: nofma flavour", res["nofma"], "default flavour", res["default"])
+    assert max(res["default"]) < TOL_STEPS, res          # either flavour passes the north-star gate
+    assert max(res["nofma"]) <= EXACT, res               # the multiply + subtract flavour IS this host's reference, bit for bit
+
+
 def _rank_engines_step(ranks, step_fn, nsteps):
     """nsteps of step_fn(engine, k) on every rank engine, one host thread each (the loopback wire has barriers inside)."""
     import threading

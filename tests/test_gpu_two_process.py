@@ -90,13 +90,17 @@ def test_bench_runs_as_two_rank_processes_on_one_device():
     env.pop("TMX_HALO", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--develop", "1", "--ne", "8", "--levels", "6", "--dt", "500", "--share-device", "--halo", "auto", "--no-cpu-baseline"],
+                        "--develop", "1", "--ne", "8", "--levels", "6", "--dt", "500", "--share-device", "--halo", "auto", "--no-cpu-baseline", "--sustained-steps", "50"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=400, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert "identical bytes" in d["config"]["parallelism"], d["config"]["parallelism"]
+    # the line's own parity proof: rank 0's patches after three steps against a single-rank engine stepped beside it
+    par = d["multi_rank"]["parity"]
+    assert par["identical_to_single_rank_engine"] is True and par["steps"] == 3, par
+    assert d["multi_rank"]["halo_transport"] == "p2p" and d["sustained"]["steps"] > 0
 
 
 def test_absent_neighbour_is_reported_not_hung():

@@ -16,6 +16,6 @@ echo "variants: noback = no back substitution; noustore = the elimination does n
 echo "evaluated once and re-used (assembly cost removed, ring traffic kept); noelim = the consumer wavefront only keeps the barrier rhythm"
 for v in $VARIANTS; do
 	name=${v%%:*}
-	TMX_LIBRARY=$PWD/build/abl/$name.so python3 bench.py --steps 10 --warmup 2 --develop 3 --no-cpu-baseline 2>/dev/null | \
+	TMX_LIBRARY=$PWD/build/abl/$name.so python3 bench.py --steps 10 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0 2>/dev/null | \
 		python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-32s vi_solve %.3f ms/step = %.1f us/launch   (step %.3f ms)' % ('$name', d['kernel_ms_per_step']['vi_solve'], d['kernel_ms_per_step']['vi_solve']/3*1e3, d['ms_per_step']))"
 done

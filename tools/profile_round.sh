@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline"
+B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0"
 one() {   # name, rocprof args..., -- program
 	local name=$1; shift
 	rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"
@@ -23,7 +23,7 @@ one mfma1 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 one trace_mfma1 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_mfma1 -o ${TAG} -- python3 $B
 unset TMX_MFMA
 # configs[2] shape (ne15) and the 8-rank share of configs[1] (a lone rank-0 engine of the 8-rank layout, wire left out)
-B15="$R/bench.py --ne 15 --ppd 1 --steps 5 --warmup 2 --develop 3 --no-cpu-baseline"
+B15="$R/bench.py --ne 15 --ppd 1 --steps 5 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0"
 one fetch_ne15 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_ne15 -o ${TAG} -- python3 $B15
 one write_ne15 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_ne15 -o ${TAG} -- python3 $B15
 one trace_ne15 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_ne15 -o ${TAG} -- python3 $B15
@@ -36,7 +36,7 @@ C4="$R/tools/config4_timing.py"
 one fetch_c4 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_c4 -o ${TAG} -- python3 $C4
 one write_c4 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_c4 -o ${TAG} -- python3 $C4
 one trace_c4 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_c4 -o ${TAG} -- python3 $C4
-B5="$R/bench.py --ne 120 --levels 60 --dt 37.5 --physics hs --steps 3 --warmup 1 --develop 2 --no-cpu-baseline"
+B5="$R/bench.py --ne 120 --levels 60 --dt 37.5 --physics hs --steps 3 --warmup 1 --develop 2 --no-cpu-baseline --sustained-steps 0"
 one fetch_c5 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_c5 -o ${TAG} -- python3 $B5
 one write_c5 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_c5 -o ${TAG} -- python3 $B5
 one trace_c5 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_c5 -o ${TAG} -- python3 $B5

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline"
+B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0"
 one() { local name=$1; shift; rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"; }
 one trace --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- python3 $B
 one fetch --pmc FETCH_SIZE --kernel-include-regex "k_vi" --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $B
