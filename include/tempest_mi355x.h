@@ -397,9 +397,25 @@ enum {
 	TMX_INFO_LATE_TILES,          /* tiles updated while the exchange is in flight      */
 	TMX_INFO_COMM_RANKS,          /* ncclCommCount of the communicator made by tmx_comm_init (0: none)  */
 	TMX_INFO_SEND_COLUMNS,        /* columns this rank sends per exchange (all peers)     */
-	TMX_INFO_HALO_TRANSPORT       /* 0 none (one rank), 1 RCCL send/recv, 2 peer-to-peer writes, 3 in-process loopback (tests) */
+	TMX_INFO_HALO_TRANSPORT,      /* 0 none (one rank), 1 RCCL send/recv, 2 peer-to-peer writes, 3 in-process loopback (tests) */
+	TMX_INFO_UNIQUE_LAYOUT,       /* 1: the node-unique state layout is set up (tmx_step uses it where the program allows) */
+	TMX_INFO_UNIQUE_INSTANCES,    /* data instances currently held in node-unique form                              */
+	TMX_INFO_UNIQUE_CONVERSIONS,  /* conversions between the two forms so far (0 inside a run of tmx_step calls)      */
+	TMX_INFO_PARTIAL_SLOTS,       /* seam-node copies that go through the partial slots (tile and patch edges)         */
+	TMX_INFO_UNIQUE_DSS_GROUPS    /* node groups the DSS kernel of that layout finishes                               */
 };
 long long tmx_info(tmx_engine * e, int what);
+
+/* Options by name: how the engine computes, never what (results are bit-identical under every setting).
+ *   "unique_layout"      -1 default, 0 off, 1 on: hold the state once per patch node inside tmx_step (node-unique slabs: 9/16 of
+ *                        the bytes, the DSS reduced to the nodes on tile and patch edges) where every kernel of the configuration
+ *                        has that form -- nonhydrostatic set, implicit vertical dynamics, no tracers / uniform diffusion /
+ *                        Rayleigh layer; replaces nothing of the reference interface (GridPatch data stay as they are at the
+ *                        boundary).  Before tmx_finalize.
+ *   "unique_tile_shape"  elements of a wavefront: 1 = 2 x 2 blocks (default), 0 = 1 x 4 strips.  Before tmx_finalize.
+ *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize. */
+int tmx_set_option(tmx_engine * e, const char * name, double value);
+int tmx_get_option(tmx_engine * e, const char * name, double * value);
 
 /* Host-side DSS / exchange plan, for tests of the multi-rank logic (works on an engine created with
  * cfg.device = -2, "plan only": no HIP call is made and no kernel can be launched).

@@ -310,3 +310,63 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 	}
 }
 
+
+// workgroup -> (entry of the launch's tile list, level block).  Element-major kernels: the plain 2-D launch.  Node-unique kernels
+// (UQ): a 1-D launch unfolded so that every XCD sweeps a contiguous range of tiles, level block by level block -- neighbouring
+// tiles read the same rows of the unique slabs (the nodes on their common edge), which then come from that XCD's L2.
+template <bool UQ> __device__ __forceinline__ bool wg_tile(const KParams & p, int nyb, int & tile_ix, int & yb) {
+	if (!UQ) { tile_ix = blockIdx.x; yb = blockIdx.y; return true; }
+	if (p.u_xcd) return xcd_tile(p.u_ntiles, nyb, tile_ix, yb);
+	tile_ix = blockIdx.x % p.u_ntiles; yb = blockIdx.x / p.u_ntiles;
+	return yb < nyb;
+}
+static inline dim3 wg_grid(bool uq, const KParams & p, int ntiles, int nyb) {
+	if (!uq) return dim3(ntiles, nyb);
+	return dim3(p.u_xcd ? 8 * ((ntiles + 7) / 8) * nyb : ntiles * nyb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-unique state layout (UniqueLayout, tmx_internal.h): what a thread = (element, node) does with its NV results.
+//   sdst >= 0   the node belongs to this lane: store there -- after averaging with the copies other lanes of the wavefront hold,
+//               in the reference's order (GridCSGLL::ApplyDSS, GridCSGLL.cpp:560-781: 0.5 (x + x'), four copies
+//               0.5 (0.5 (x + x_alpha) + 0.5 (x_beta + x_diag)); inside a patch every copy would receive these very bits)
+//   sdst == -1  nothing: another lane of the wavefront stores this node (or a padding lane)
+//   sdst <= -2  the node's copies are not all in this wavefront (tile edge, patch edge): the per-element value goes to partial
+//               slot -2 - sdst, k_dss_u finishes the node
+// srow: NV rows of 64 doubles of LDS private to the wavefront.  LDS operations of one wavefront execute in order, so the
+// exchange needs no workgroup barrier; the wavefront-scope fence keeps the compiler from moving the reads above the writes.
+template <int NV>
+__device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[64], int lane, int sdst, int sred, const double (&v)[NV],
+	double * __restrict__ xo, const int (&slab)[NV], int nv)
+{
+#pragma unroll
+	for (int t = 0; t < NV; t++) if (t < nv) srow[t][lane] = v[t];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	if (sdst == -1) return;
+	const int n = sred & 15;
+	double o[NV];
+#pragma unroll
+	for (int t = 0; t < NV; t++) o[t] = v[t];
+	if (n == 2) {
+		const int l1 = (sred >> 4) & 63;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if (t < nv) o[t] = 0.5 * (v[t] + srow[t][l1]);
+	} else if (n == 4) {
+		const int l1 = (sred >> 4) & 63, l2 = (sred >> 10) & 63, l3 = (sred >> 16) & 63;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if (t < nv) {
+			const double p0 = v[t] + srow[t][l1], p1 = srow[t][l2] + srow[t][l3];
+			o[t] = 0.5 * (0.5 * p0 + 0.5 * p1);
+		}
+	}
+	if (sdst >= 0) {
+#pragma unroll
+		for (int t = 0; t < NV; t++) if (t < nv) xo[(size_t)slab[t] * p.NSS + sdst] = o[t];
+	} else {
+		const int q = -2 - sdst;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if (t < nv) p.part[(size_t)slab[t] * p.NP + q] = o[t];
+	}
+}

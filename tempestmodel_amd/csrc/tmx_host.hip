@@ -29,10 +29,6 @@ void tmx_set_error(const char * fmt, ...) {
 
 extern "C" const char * tmx_last_error(void) { return g_err.c_str(); }
 
-#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
-	tmx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); return TMX_ERR_DEVICE; } } while (0)
-
-#define REQUIRE(cond, code, ...) do { if (!(cond)) { tmx_set_error(__VA_ARGS__); return (code); } } while (0)
 
 static bool plan_only(const tmx_engine * e) { return e->cfg.device == -2; }
 
@@ -165,6 +161,9 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
+	if (const char * m = getenv("TMX_UNIQUE")) e->u.option = atoi(m) ? 1 : 0;
+	if (const char * m = getenv("TMX_UNIQUE_TILE")) e->u.tile_shape = atoi(m) ? 1 : 0;
+	if (const char * m = getenv("TMX_UNIQUE_XCD")) e->u.xcd_order = atoi(m) ? 1 : 0;
 	if (const char * m = getenv("TMX_HVIS_PULL")) e->hvis_pull = atoi(m);
 	if (const char * m = getenv("TMX_HVIS_BLOCK")) e->hvis_block = atoi(m);
 	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
@@ -214,6 +213,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		free_dev(e->p2p_block); free_dev(e->d_p2p_dst); free_dev(e->d_p2p_flag); free_dev(e->d_send_peer); free_dev(e->d_send_within); free_dev(e->d_p2p_peers);
 		free_dev(e->d_ghost); free_dev(e->d_sendbuf); free_dev(e->d_send_cols); free_dev(e->d_send_base); free_dev(e->d_send_stride); free_dev(e->d_ghost_base); free_dev(e->d_ghost_stride); free_dev(e->d_ucol); free_dev(e->d_udep);
 		free_dev(e->d_ab); free_dev(e->d_rhs); free_dev(e->d_flag);
+		tmxu_free(e);
 		if (e->stream) hipStreamDestroy(e->stream);
 	}
 	g_plans_erase(e);
@@ -971,6 +971,15 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); HIPCHK(hipMemset((char *)e->d_ab + abb - zpage, 0, zpage)); bytes += abb;
 	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
 	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	// Node-unique state layout (tmx_unique.hip): for the configurations all of whose step kernels have the U form -- the
+	// nonhydrostatic set with implicit vertical dynamics, no tracers, no uniform diffusion, no Rayleigh layer (its strength is
+	// stored per copy of a node), closed-form metric.  Every other configuration, and every entry point other than tmx_step,
+	// works on the element-major layout as before.
+	if (e->u.option == 1 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && !e->rayleigh && e->metric_closed &&
+	    !e->hvis_pull && !e->hvis_block && !e->use_graph && e->vi_mode == 0) {
+		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
+		if ((r = tmxu_build(e, in, &bytes))) return r;
+	}
 	e->hbm_bytes = bytes;
 	// host staging no longer needed
 	std::vector<double>().swap(e->h_g2d); std::vector<double>().swap(e->h_g3n); std::vector<double>().swap(e->h_g3e);
@@ -1310,6 +1319,8 @@ static KParams make_params(const tmx_engine * e) {
 	p.eta = e->d_eta; p.closed = e->metric_closed ? 1 : 0;
 	p.inv_da = 1.0 / e->cfg.element_delta_a;
 	p.quads = e->stage_quads;      // tile list of a boundary-first stage in progress (hv_stage_split), else all tiles
+	p.NSS = e->NS; p.t_ucol = nullptr; p.t_sdst = nullptr; p.t_sred = nullptr; p.part = nullptr; p.NP = 0;      // element-major layout (tmxu_params: node-unique)
+	p.u_ntiles = 0; p.u_xcd = e->u.xcd_order;
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
 	return p;
@@ -1332,6 +1343,9 @@ static const double * inst_uv(tmx_engine * e, int ix) { return e->d_state + (siz
 // Shared U,V slabs are settled inside a stepper program too: the operations that understand them (the fused explicit stage)
 // do not come through here.
 static int settle_instance(tmx_engine * e, int ix) {
+	// slots in node-unique form (left by tmx_step) go back to the element-major form before anything else looks at them
+	if (e->u.n_uform)
+		for (int b = 0; b < (int)e->u.form.size(); b++) if (e->u.form[b]) { int r = tmxu_to_d(e, b); if (r) return r; }
 	if (e->n_shared && !e->in_program)
 		for (int b = 0; b < (int)e->imap.size(); b++) {
 			if (e->imap[b] == b || !(ix < 0 || b == ix || e->imap[b] == ix)) continue;
@@ -1668,7 +1682,7 @@ struct LoopbackGroup {
 static int exchange_loopback(tmx_engine * e, const KParams & p, double * x) {
 	LoopbackGroup * G = e->lb;
 	const int n = (int)G->members.size(), me = e->cfg.rank;
-	tmxk_pack(e, p, x);
+	if (x) tmxk_pack(e, p, x); else tmxuk_pack(e);
 	HIPCHK(hipStreamSynchronize(e->stream));
 	pthread_barrier_wait(&G->barrier);                  // every member has packed
 	for (int s_ = 0; s_ < n; s_++) {
@@ -1716,12 +1730,14 @@ static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overla
 	// timing aid: a lone rank engine of an N-rank layout with the wire left out (results are then wrong at the rank
 	// boundary; used only by tools/rank_share_timing.py to measure the per-rank compute share of a step)
 	static const bool skip = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
-	if (skip) { tmxk_pack(e, p, x); return TMX_OK; }
+	if (skip) { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); return TMX_OK; }
 	REQUIRE(e->comm || e->p2p, TMX_ERR_COMM, "tmx_comm_init or tmx_halo_p2p_connect must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
 	const unsigned long long seq = ++e->p2p_seq;
 	const int buf = (int)(seq & 1);
-	if (e->p2p) tmxk_pack_p2p(e, p, x, buf); else tmxk_pack(e, p, x);
+	// (x == nullptr: node-unique layout, what travels are the per-element values in the partial slots)
+	if (e->p2p) { if (x) tmxk_pack_p2p(e, p, x, buf); else tmxuk_pack_p2p(e, buf); }
+	else { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); }
 	hipStream_t ws = e->stream;
 	if (overlapped && e->xstream) {
 		HIPCHK(hipEventRecord(e->ev_pack, e->stream));
@@ -2633,6 +2649,241 @@ extern "C" int tmx_debug_program_copies(int scheme, int mode, int steps, int sha
 	return e.dry_mismatch ? -1000 - e.dry_mismatch : TMX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stepper programs on the node-unique layout (UniqueLayout, tmx_internal.h; kernels instantiated with UQ = true).  The same
+// programs, interpreted with the same fusion rules: [Copy | LinearCombine]; H; V; DSS is one stage (explicit kernels writing
+// averaged nodes and partial slots, exchange of the slots other ranks need, k_dss_u), Copy; V.StepImplicit a U,V slab copy
+// plus the column solve on the unique columns, StepAfterSubCycle its one or two passes with their DSS.  An explicit update
+// that is not followed by the DSS of its instance has no node-unique form (the copies of a seam node then differ), so a program
+// is run this way only if every operation fits (program_fits_unique); otherwise, and for instances whose copies differ on entry
+// (a freshly uploaded initial state), tmx_step runs the element-major program.
+
+static double * uinst(tmx_engine * e, int ix) { return e->u.d_ustate + (size_t)e->u.uslot[ix] * e->u.ustride; }
+// where a kernel that reads instance ix while producing it must write: the spare slot; u_adopt_spare makes it the instance's afterwards
+static double * uspare(tmx_engine * e) { return e->u.d_ustate + (size_t)e->u.uspare * e->u.ustride; }
+static void u_adopt_spare(tmx_engine * e, int ix) { std::swap(e->u.uslot[ix], e->u.uspare); }
+
+// what the U interpreter does with operation i: 0 = not representable, else the number of operations it consumes
+static int unique_unit(const Program & p, size_t i) {
+	const size_t n = p.size();
+	const Op & o = p[i];
+	auto stage_at = [&](size_t j, int upd) {      // H(i,upd,c); V(i,upd,c); DSS(upd) starting at j
+		return j + 2 < n && p[j].kind == OP_HEXP && p[j + 1].kind == OP_VEXP && p[j + 2].kind == OP_DSS && p[j].b == upd && p[j + 1].b == upd &&
+			p[j + 2].a == upd && p[j].a == p[j + 1].a && p[j].coef == p[j + 1].coef && p[j].a != upd;
+	};
+	switch (o.kind) {
+	case OP_COPY:
+		if (o.a != o.b && stage_at(i + 1, o.b) && p[i + 1].a != o.b) return 4;
+		return 1;
+	case OP_LINCOMB:
+		if (stage_at(i + 1, o.a)) return 4;
+		return 1;
+	case OP_HEXP: return stage_at(i, o.b) ? 3 : 0;
+	case OP_VIMP: case OP_DSS: case OP_HVIS: case OP_VFILT: return 1;
+	}
+	return 0;      // V explicit on its own, the explicitly evaluated implicit terms (ARK232)
+}
+static bool program_fits_unique(const Program & p) {
+	for (size_t i = 0; i < p.size(); ) { const int k = unique_unit(p, i); if (!k) return false; i += k; }
+	return true;
+}
+
+static int u_dss_finish(tmx_engine * e, int ix, bool overlapped) {
+	ProfScope ps(e, TMX_K_DSS);
+	const UniqueLayout & u = e->u;
+	if (e->cfg.n_ranks > 1 && u.ngroups_local < u.ngroups) {
+		tmxuk_dss(e, uinst(e, ix), 0, u.ngroups_local);
+		if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
+		tmxuk_dss(e, uinst(e, ix), u.ngroups_local, u.ngroups);
+	} else tmxuk_dss(e, uinst(e, ix), 0, u.ngroups);
+	return launch_check("DSS of the partial slots");
+}
+
+// kernels(KParams): the launches that fill instance ix and its partial slots; run boundary tiles first where the rank has both kinds
+template <class F> static int u_produce_and_average(tmx_engine * e, int ix, int prof_slot, F kernels) {
+	const UniqueLayout & u = e->u;
+	KParams p = tmxu_params(e, make_params(e));
+	bool overlapped = false;
+	int r;
+	if (u.split) {
+		for (int part = 0; part < 2; part++) {
+			p.quads = part ? u.d_quads_late : u.d_quads_early;
+			e->launch_tiles = part ? u.n_late : u.n_early;
+			{ ProfScope ps(e, prof_slot); kernels(p); }
+			if (part == 0) { p.quads = nullptr; if ((r = exchange(e, p, nullptr, &overlapped))) return r; }
+		}
+		p.quads = nullptr;
+	} else {
+		{ ProfScope ps(e, prof_slot); kernels(p); }
+		if ((r = exchange(e, p, nullptr, &overlapped))) return r;
+	}
+	if ((r = launch_check("kernels of a stage (node-unique layout)"))) return r;
+	return u_dss_finish(e, ix, overlapped);
+}
+
+// [Copy(ibase -> iupd) | LinearCombine(lc -> iupd)]; H.StepExplicit(iinit, iupd); V.StepExplicit(iinit, iupd); DSS(iupd)
+static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
+	const double * src[12]; double cf[12]; int premul = 0, n = 0;
+	if (lc) {
+		n = 1; src[0] = uinst(e, iupd); cf[0] = lc[iupd];
+		for (int m = 0; m < nlc; m++) {
+			if (m == iupd || lc[m] == 0.0) continue;
+			REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
+			src[n] = uinst(e, m); cf[n] = lc[m]; n++;
+		}
+		premul = (lc[iupd] != 0.0) ? 1 : 0;
+	}
+	// the update instance is also read (in-place accumulation, or its own coefficient in the combination is not zero): the
+	// element-major kernels read and write a thread's own column, here other elements' threads read the node too -- write the
+	// spare slot and let it become the instance's
+	const bool aliased = lc ? (premul != 0) : (ibase == iupd);
+	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
+	double * out = aliased ? uspare(e) : uinst(e, iupd);
+	if (aliased) u_adopt_spare(e, iupd);      // (src[] and uinst(ibase) were taken before: they still name the old slot)
+	const double * base = lc ? nullptr : ((ibase == iupd && aliased) ? uspare(e) : uinst(e, ibase));
+	int r = u_produce_and_average(e, iupd, TMX_K_H_EXPLICIT, [&](const KParams & p) {
+		if (n > 0) tmxk_h_explicit(e, p, uinst(e, iinit), out, out, dt, 1, n, src, cf, premul);
+		else tmxk_h_explicit(e, p, uinst(e, iinit), base, out, dt, 1);
+	});
+	if (r) return r;
+	if (lc) {
+		const double * dsrc[12];      // the surface slots live with the element-major slots
+		int m2 = 1; dsrc[0] = inst(e, iupd);
+		for (int m = 0; m < nlc; m++) if (m != iupd && lc[m] != 0.0) dsrc[m2++] = inst(e, m);
+		return surface_lincomb(e, iupd, n, dsrc, cf, premul);
+	}
+	return surface_copy(e, ibase, iupd);
+}
+
+static int u_copy(tmx_engine * e, int a, int b, size_t doubles) {
+	if (a == b) return TMX_OK;
+	ProfScope ps(e, TMX_K_LINCOMB);
+	HIPCHK(hipMemcpyAsync(uinst(e, b), uinst(e, a), doubles * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	return surface_copy(e, a, b);
+}
+
+// [Copy(a -> b);] V.StepImplicit(b, b): the solve rewrites rho*theta, W, rho of every column, so only the U,V slabs are copied
+static int u_vimp(tmx_engine * e, int a, int b, double dt) {
+	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
+	int r;
+	if (a != b && (r = u_copy(e, a, b, (size_t)2 * e->L * e->u.NUS))) return r;
+	ProfScope ps(e, TMX_K_VI_SOLVE);
+	e->vi_unique = true;
+	tmxk_vi_fused(e, tmxu_params_columns(e, make_params(e)), uinst(e, a), uinst(e, b), dt);
+	e->vi_unique = false;
+	return launch_check("column solve (node-unique layout)");
+}
+
+// DSS of an instance whose copies already agree inside every patch (e.g. after the column solve): only the nodes on patch edges change
+static int u_dss(tmx_engine * e, int ix) {
+	bool overlapped = false;
+	int r;
+	{ ProfScope ps(e, TMX_K_DSS); tmxuk_slots_from_u(e, uinst(e, ix)); }
+	if ((r = exchange(e, tmxu_params(e, make_params(e)), nullptr, &overlapped))) return r;
+	return u_dss_finish(e, ix, overlapped);
+}
+
+// HorizontalDynamicsFEM::StepAfterSubCycle (h_step_after_subcycle_impl above, same branches)
+static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
+	const tmx_config & c = e->cfg;
+	int r;
+	REQUIRE(iinit != iwork && iupd != iwork && iinit != iupd, TMX_ERR_UNSUPPORTED, "StepAfterSubCycle on the node-unique layout needs three distinct instances");
+	if (!hypervis_active(e)) return u_copy(e, iinit, iupd, e->u.ustride);
+	if (c.hypervis_order == 2) {
+		if ((r = surface_copy(e, iinit, iupd))) return r;
+		return u_produce_and_average(e, iupd, TMX_K_HYPERVIS, [&](const KParams & p) {
+			tmxk_hypervis(e, p, uinst(e, iinit), uinst(e, iinit), uinst(e, iupd), -dt, -c.nu_scalar, c.nu_div, c.nu_vort, 0); });
+	}
+	const int scale = (c.reference_length != 0.0) ? 1 : 0;
+	if ((r = surface_copy(e, iinit, iupd)) || (r = surface_zero(e, iwork))) return r;
+	if ((r = u_produce_and_average(e, iwork, TMX_K_HYPERVIS, [&](const KParams & p) {
+		tmxk_hypervis(e, p, uinst(e, iinit), nullptr, uinst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0); }))) return r;
+	return u_produce_and_average(e, iupd, TMX_K_HYPERVIS, [&](const KParams & p) {
+		tmxk_hypervis(e, p, uinst(e, iwork), uinst(e, iinit), uinst(e, iupd), -dt, c.nu_scalar, c.nu_div, c.nu_vort, scale); });
+}
+
+static int run_program_unique(tmx_engine * e, const Program & p) {
+	int r;
+	for (size_t i = 0; i < p.size(); ) {
+		const Op & o = p[i];
+		const int k = unique_unit(p, i);
+		switch (o.kind) {
+		case OP_COPY:
+			if (k == 4) { if ((r = u_stage(e, p[i + 1].a, o.a, o.b, p[i + 1].coef, nullptr, 0))) return r; break; }
+			{
+				size_t j = i + 1;      // Copy(s -> t) [repeated] + V.StepImplicit(t, t)
+				while (j < p.size() && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
+				if (j < p.size() && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
+					if ((r = u_vimp(e, o.a, o.b, p[j].coef))) return r;
+					i = j + 1; continue;
+				}
+			}
+			// Copy(a -> b) + StepAfterSubCycle(a, b, w): every branch rewrites all of b from a
+			if (i + 1 < p.size() && p[i + 1].kind == OP_HVIS && p[i + 1].a == o.a && p[i + 1].b == o.b && o.a != o.b) break;
+			if ((r = u_copy(e, o.a, o.b, e->u.ustride))) return r;
+			break;
+		case OP_LINCOMB:
+			if (k == 4) { if ((r = u_stage(e, p[i + 1].a, o.a, o.a, p[i + 1].coef, o.lc, o.nlc))) return r; break; }
+			{
+				const double * src[12], * dsrc[12]; double cf[12];
+				int n = 1; src[0] = uinst(e, o.a); dsrc[0] = inst(e, o.a); cf[0] = o.lc[o.a];
+				for (int m = 0; m < o.nlc; m++) {
+					if (m == o.a || o.lc[m] == 0.0) continue;
+					REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear_combine_data: more than 11 source terms");
+					src[n] = uinst(e, m); dsrc[n] = inst(e, m); cf[n] = o.lc[m]; n++;
+				}
+				const int premul = o.lc[o.a] != 0.0 ? 1 : 0;
+				{ ProfScope ps(e, TMX_K_LINCOMB); tmxk_lincomb(e, e->u.ustride, uinst(e, o.a), n, src, cf, premul); }
+				if ((r = surface_lincomb(e, o.a, n, dsrc, cf, premul)) || (r = launch_check("lincomb"))) return r;
+			}
+			break;
+		case OP_HEXP: if ((r = u_stage(e, o.a, o.b, o.b, o.coef, nullptr, 0))) return r; break;
+		case OP_VIMP: if ((r = u_vimp(e, o.a, o.b, o.coef))) return r; break;
+		case OP_DSS: if ((r = u_dss(e, o.a))) return r; break;
+		case OP_HVIS: if ((r = u_hvis(e, o.a, o.b, o.c, o.coef))) return r; break;
+		case OP_VFILT: break;      // nothing without tracers
+		default: REQUIRE(false, TMX_ERR_UNSUPPORTED, "internal: operation %d has no node-unique form", o.kind);
+		}
+		i += k;
+	}
+	return TMX_OK;
+}
+
+// Entry of tmx_step: bring the instances the program reads before it overwrites them into the node-unique form (checking, for
+// those that come from the element-major form, that the copies of every node agree) and run the program there.  *done = false:
+// not possible (configuration, program, or an instance whose copies differ); the caller runs the element-major program.
+static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
+	*done = false;
+	UniqueLayout & u = e->u;
+	if (!u.built || false || !program_fits_unique(p)) return TMX_OK;
+	int r;
+	// instance maps to identity (the U interpreter does not share slots), with the slots still in their current form
+	if (e->n_shared || e->n_uvshared) { if ((r = settle_instance(e, -1))) return r; }
+	unsigned written = 0u, livein = 0u;
+	const bool noop = false;
+	g_hvis_two_pass = hypervis_active(e) && e->cfg.hypervis_order != 2;
+	for (size_t i = 0; i < p.size(); i++) {
+		const OpAccess x = op_access(p[i], noop);
+		livein |= x.reads & ~written;
+		livein |= x.part & ~written;
+		written |= x.full | x.part;
+	}
+	for (int k = 0; k < e->cfg.n_instances; k++) {
+		if (!(livein >> k & 1u) || u.form[k]) continue;
+		bool ok = true;
+		if ((r = tmxu_to_u(e, k, true, &ok))) return r;
+		if (!ok) return TMX_OK;      // copies differ: this step runs element-major (settle_instance converts what is in U form)
+	}
+	// everything the program writes is in U form afterwards; whatever else it leaves alone keeps its form
+	for (int k = 0; k < e->cfg.n_instances; k++)
+		if ((written >> k & 1u) && !u.form[k]) { u.form[k] = 1; u.n_uform++; }
+	e->in_program = true;
+	r = run_program_unique(e, p);
+	e->in_program = false;
+	*done = true;
+	return r;
+}
+
 extern "C" int tmx_scheme_instances(int scheme) { return scheme_instances(scheme); }
 
 extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_step, double dt) {
@@ -2672,6 +2923,11 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 		e->graphs.push_back(sg);
 		HIPCHK(hipGraphLaunch(sg.exec, e->stream));
 		return TMX_OK;
+	}
+	if (e->u.built) {
+		bool done = false;
+		if ((r = try_step_unique(e, p, &done)) || done) return r;
+		if ((r = settle_instance(e, -1))) return r;      // element-major step: nothing stays in U form
 	}
 	return run_program(e, p);
 }
@@ -2958,6 +3214,32 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // introspection
 
+// Options that change how (never what) the engine computes, by name; the ones that decide buffers and tables must be set before
+// tmx_finalize.  Everything here is reported back by tmx_get_option, so a run can print what it ran with.
+extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
+	REQUIRE(e && name, TMX_ERR_INVALID, "tmx_set_option: null argument");
+	const std::string n(name);
+	const int iv = (int)value;
+	if (n == "unique_layout" || n == "unique_tile_shape" || n == "unique_xcd_order") {
+		REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
+		if (n == "unique_layout") { REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1"); e->u.option = iv; }
+		else if (n == "unique_tile_shape") e->u.tile_shape = iv ? 1 : 0;
+		else e->u.xcd_order = iv ? 1 : 0;
+		return TMX_OK;
+	}
+	tmx_set_error("tmx_set_option: unknown option '%s'", name);
+	return TMX_ERR_INVALID;
+}
+extern "C" int tmx_get_option(tmx_engine * e, const char * name, double * value) {
+	REQUIRE(e && name && value, TMX_ERR_INVALID, "tmx_get_option: null argument");
+	const std::string n(name);
+	if (n == "unique_layout") *value = e->u.option;
+	else if (n == "unique_tile_shape") *value = e->u.tile_shape;
+	else if (n == "unique_xcd_order") *value = e->u.xcd_order;
+	else { tmx_set_error("tmx_get_option: unknown option '%s'", name); return TMX_ERR_INVALID; }
+	return TMX_OK;
+}
+
 extern "C" long long tmx_info(tmx_engine * e, int what) {
 	if (!e) return -1;
 	switch (what) {
@@ -2970,6 +3252,11 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_METRIC_CLOSED_FORM: return e->metric_closed ? 1 : 0;
 		case TMX_INFO_EARLY_TILES: return e->split_stage ? e->n_quads_early : 0;
 		case TMX_INFO_LATE_TILES: return e->split_stage ? e->n_quads_late : 0;
+		case TMX_INFO_UNIQUE_LAYOUT: return e->u.built ? 1 : 0;
+		case TMX_INFO_UNIQUE_INSTANCES: return e->u.n_uform;
+		case TMX_INFO_UNIQUE_CONVERSIONS: return e->u.conversions;
+		case TMX_INFO_PARTIAL_SLOTS: return e->u.built ? e->u.nslots : 0;
+		case TMX_INFO_UNIQUE_DSS_GROUPS: return e->u.built ? e->u.ngroups : 0;
 		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
 			int n = 0;
 			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;

@@ -54,6 +54,17 @@ struct KParams {
 	double inv_da;
 	double grav, Rd, cp, p0;
 	const int * quads;      // not null: blockIdx.x indexes this list of 64-column tiles (boundary-first / interior launches of a multi-rank stage)
+	// Node-unique state layout (UniqueLayout below; kernels instantiated with UQ = true).  Threads are still (tile, lane) =
+	// 4 whole elements x 16 nodes, geometry is indexed by the thread's own column (stride NS); the STATE lives in per-patch
+	// node-unique slabs of NSS doubles, t_ucol names the slab entry a thread's node reads, t_sdst / t_sred say what it does with
+	// its result (seam_store, tmx_device.h), `part` receives the per-element values of the seam nodes on tile and patch edges.
+	int u_ntiles, u_xcd;    // U kernels are launched 1-D: tiles of this launch, and whether every XCD sweeps a contiguous range of them (xcd_tile)
+	int NSS;                // state slab stride in doubles (== NS in the element-major layout)
+	const int * t_ucol;     // [NS] unique-slab index of the thread's node, -1: padding lane
+	const int * t_sdst;     // [NS] >= 0: store the (averaged) value there; -1: nothing (another lane of the tile stores this node); <= -2: partial slot -2 - t_sdst
+	const int * t_sred;     // [NS] n | lane1 << 4 | lane2 << 10 | lane3 << 16: average with the copies held by these lanes of the wavefront (n = 0, 2, 4)
+	double * part;          // [nslab][NP] partial slots
+	int NP;
 	double dx[16];          // dx[s*4+i]    = dDxBasis1D(s,i)
 	double stiff[16];       // stiff[i*4+s] = dStiffness1D(i,s)
 };
@@ -73,6 +84,44 @@ struct StepGraphKey { int scheme, first, last; double dt; };
 struct StepGraph { StepGraphKey key; hipGraphExec_t exec = nullptr; };
 
 struct ProfSlot { double ms = 0.0; long long n = 0; };
+
+// Node-unique state layout.  Inside a patch the co-located copies of a seam node carry identical bits
+// after every averaging (GridCSGLL::ApplyDSS pairs alpha seams, then beta seams: both results are symmetric in the members),
+// so a state instance can be held ONCE per patch node: (3 nea + 1) x (3 neb + 1) entries per patch and slab instead of 16 per
+// element (9/16 of the bytes).  Kernels keep their thread = (element, node) shape and gather their operands; a seam node's
+// per-element results are averaged in the reference's order inside the producing wavefront when all its copies belong to the
+// wavefront's four elements, and otherwise go to "partial slots", which a DSS kernel restricted to those nodes (tile and patch
+// edges, remote copies from the ghost buffer as before) finishes.  Three index spaces: D = element-major columns (the layout
+// of everything else, host transfers included), T = thread order (a permutation of the rank's elements: 2 x 2 element blocks
+// per wavefront), U = unique nodes.  Slots of the instance storage are in D or U form (form[]); U-form slots exist only inside
+// tmx_step of a configuration all of whose kernels have the U form, every other entry point first converts what it names.
+struct UniqueLayout {
+	bool built = false;
+	int option = -1;                         // tmx_set_option("unique_layout"): -1 auto, 0 off, 1 on where eligible
+	int tile_shape = 1;                      // T order: 0 = the element-major order (1 x 4 element strips per wavefront), 1 = 2 x 2 element blocks
+	int xcd_order = 1;                       // workgroup -> tile map of the U kernels: 1 = every XCD sweeps a contiguous range of tiles
+	int NU = 0, NUS = 0, NTS = 0, nslots = 0, NP = 0;
+	int ngroups = 0, ngroups_local = 0;      // groups left to the DSS kernel (not averaged inside a wavefront); [0, ngroups_local): no remote member
+	size_t ustride = 0;                      // doubles per U-form instance (nslab * NUS)
+	double * d_ustate = nullptr, * d_part = nullptr, * d_g2d_t = nullptr, * d_g2d_u = nullptr;
+	int * d_t_ucol = nullptr, * d_t_sdst = nullptr, * d_t_sred = nullptr;      // [NTS]
+	int * d_t_dcol = nullptr;                // [NTS] D column of a thread (-1: padding)
+	int * d_ucol_of_dcol = nullptr;          // [NS]
+	int * d_u_rep = nullptr;                 // [NUS] D column of the copy the reference's column solve works on
+	int * d_slot_ucol = nullptr;             // [NP] unique index of a slot's node
+	int * d_gsrc = nullptr, * d_gdst = nullptr, * d_gn = nullptr, * d_gx = nullptr, * d_gtype = nullptr;
+	int * d_send_slots = nullptr;
+	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_early = 0, n_late = 0; bool split = false;
+	int * d_check = nullptr;                 // consistency flag of the D -> U conversion
+	std::vector<char> form;                  // per data instance: 0 = the element-major slot is current, 1 = the node-unique one
+	// U storage holds one slot more than there are instances: a stage whose update instance is also one of its sources (in-place
+	// accumulation, a combination with a non-zero coefficient of its destination) must not overwrite nodes other threads still
+	// read -- in the unique slabs a node is read by up to four elements' threads -- so it writes the spare slot, which then
+	// becomes the instance's
+	std::vector<int> uslot; int uspare = 0;
+	int n_uform = 0;
+	long long conversions = 0;               // D <-> U conversions performed (tmx_info)
+};
 
 struct tmx_engine {
 	tmx_config cfg;
@@ -203,11 +252,31 @@ struct tmx_engine {
 	bool prof = false;
 	bool use_graph = false;                  // TMX_GRAPH=1: replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
 	std::vector<StepGraph> graphs;
+	UniqueLayout u;
+	bool vi_unique = false;                  // transient: the column solve runs on the unique slabs (tmxk_vi_fused)
 	ProfSlot prof_slots[TMX_K_COUNT];
 	std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
 };
 
 void tmx_set_error(const char * fmt, ...);
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+	tmx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); return TMX_ERR_DEVICE; } } while (0)
+#define REQUIRE(cond, code, ...) do { if (!(cond)) { tmx_set_error(__VA_ARGS__); return (code); } } while (0)
+
+// node-unique layout (tmx_unique.hip)
+struct UniquePlanInput {      // what tmx_finalize hands over: the DSS groups in the engine's order and the send list, in D columns
+	const std::vector<int> * grp_cols, * grp_n, * grp_x, * grp_type, * send_cols;
+};
+int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes);
+void tmxu_free(tmx_engine * e);
+KParams tmxu_params(const tmx_engine * e, const KParams & base);          // thread space T, state in U slabs
+KParams tmxu_params_columns(const tmx_engine * e, const KParams & base);  // one thread per unique column (column solve)
+int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent);   // D form -> U form of one slot (check: verify that the copies agree)
+int tmxu_to_d(tmx_engine * e, int slot);                                  // U form -> D form
+void tmxuk_slots_from_u(tmx_engine * e, const double * xu);               // partial slots <- the values of their nodes (DSS of an instance that is already consistent inside patches)
+void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1);              // finish the seam nodes left in the partial slots
+void tmxuk_pack(tmx_engine * e);                                          // partial slots other ranks need -> send buffer
+void tmxuk_pack_p2p(tmx_engine * e, int buf);
 
 // kernel launchers (tmx_k_*.hip)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,

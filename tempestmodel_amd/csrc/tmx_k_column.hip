@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_vi_assemble(KParams p, const double * _
 	const int u = blockIdx.x * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (u >= nunique || k > L) return;
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	const double invdt = 1.0 / dt;
 	const double upc = 0.5 * (1.0 / (double)L);             // m_dUpwindCoeff (:394-395)
 	const double cv = p.cp - p.Rd;
@@ -334,10 +334,10 @@ __global__ __launch_bounds__(64) void k_vi_solve(KParams p, const double * xin, 
 	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 
 	// back substitution in dtbsv order, scatter x0 - delta
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	int dep[3];
 #pragma unroll
-	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	for (int t = 0; t < 3; t++) dep[t] = udep ? udep[u * 3 + t] : -1;
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
@@ -964,7 +964,7 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 {
 	int dep[3];
 #pragma unroll
-	for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+	for (int t = 0; t < 3; t++) dep[t] = udep ? udep[u * 3 + t] : -1;
 	double xw[TMX_BW - 1];
 #pragma unroll
 	for (int c = 0; c < TMX_BW - 1; c++) xw[c] = 0.0;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 	const int u = blockIdx.x * 64 + threadIdx.x;
 	if (u >= nunique) return;
 	const int n = TMX_FTOT * (L + 1);
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
 	AB = vi_stream_base(AB, n, u);            // this lane's slot in its wavefront's U-row stream
 	ColConst cc;
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	const int ulast = min(nunique, (grp + 1) * cpw) - 1;
 	const int u = (grp * cpw < nunique) ? min(grp * cpw + min(lane, cpw - 1), ulast) : nunique - 1;
 	const int n = TMX_FTOT * (L + 1);
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
 	AB = vi_stream_base_g(AB, n, grp, lane);  // this lane's slot in its wavefront's U-row stream
 
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(64 * NSUB) void k_vi_back(KParams p, const double *
 	const int lane = (threadIdx.x >> 6) * (64 / NSUB) + (threadIdx.x & 63);
 	const int ulast = min(nunique, (grp + 1) * cpw) - 1;
 	const int u = (grp * cpw < nunique) ? min(grp * cpw + min(lane, cpw - 1), ulast) : nunique - 1;
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	const double * RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams
 	vi_back_substitute(L, (size_t)p.NS, n, u, col, NUS, vi_stream_base_g(AB, n, grp, lane), RHS, xin, xup, udep, umask_mem, lane);
 }
@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 	const int uraw = blockIdx.x * 4 + g;
 	const bool valid = uraw < nunique;
 	const int u = valid ? uraw : nunique - 1;       // a trailing, empty group redoes the last column (no stores)
-	const int col = ucol[u];
+	const int col = ucol ? ucol[u] : u;      // (null: node-unique layout, a unique column is its own state column)
 	double * stream = AB + (size_t)blockIdx.x * n * 64 + lane;   // [row][4 columns][16 lanes]: entry c of U row j at (j * 64 + g * 16 + c); lane 15 = rhs
 
 	ColConst cc;
@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 		if (valid) {
 			int dep[3];
 #pragma unroll
-			for (int t = 0; t < 3; t++) dep[t] = udep[u * 3 + t];
+			for (int t = 0; t < 3; t++) dep[t] = udep ? udep[u * 3 + t] : -1;
 			for (int r = c; r < n; r += 16) {
 				const int k = r / TMX_FTOT, comp = r - k * TMX_FTOT;
 				if (comp != 1 && k >= L) continue;                 // level-L slots of rho*theta / rho have no slab
@@ -1613,6 +1613,8 @@ __global__ __launch_bounds__(64) void k_vi_group(KParams p, const double * xin, 
 
 void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nunique == 0) return;
+	// node-unique layout (e->vi_unique, set by the caller together with tmxu_params_columns): unique column u IS state column u, no in-patch copies to fill
+	const int * ucolp = e->vi_unique ? nullptr : (const int *)e->d_ucol, * udepp = e->vi_unique ? nullptr : (const int *)e->d_udep;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
 	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
 	// The pair kernel shortens the per-column dependent chain to max(assembly, elimination) and is built for two
@@ -1624,8 +1626,8 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	// few columns for the chip (strong-scaling share): one column per 16-lane group
 	if (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max)) {
 		const int nwg = (e->nunique + 3) / 4;
-		if (p.closed) hipLaunchKernelGGL((k_vi_group<true>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_flag);
-		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_flag);
+		if (p.closed) hipLaunchKernelGGL((k_vi_group<true>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
+		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
 		return;
 	}
 	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
@@ -1642,16 +1644,16 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const int ngrp_launched = ((ngrp + pairs - 1) / pairs) * pairs;
 		const bool split = split_back && (size_t)ngrp_launched * TMX_FTOT * (p.L + 1) * sizeof(int) <= (size_t)TMX_FTOT * (p.L + 1) * e->NUS * sizeof(double);
 #define LAUNCH_PAIR(CL_, NP_) do { if (split) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, false>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
-			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
 		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
-			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR
 		if (split) {
 			const int nsub = e->vi_back_sub;
 #define LAUNCH_BACK(NS_) hipLaunchKernelGGL(k_vi_back<NS_>, dim3(ngrp), dim3(64 * NS_), (size_t)TMX_FTOT * (p.L + 1) * sizeof(int), e->stream, p, xin, xup, e->nunique, e->vi_stream_cols, \
-				(const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, cpw, (const int *)e->d_rhs)
+				ucolp, udepp, e->d_ab, cpw, (const int *)e->d_rhs)
 			if (nsub == 2) LAUNCH_BACK(2); else if (nsub == 4) LAUNCH_BACK(4); else LAUNCH_BACK(1);
 #undef LAUNCH_BACK
 		}
@@ -1659,10 +1661,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	}
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, true, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
-			e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); \
+			e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag); \
 	else \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, false, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
-			e->nunique, e->vi_stream_cols, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag); } while (0)
+			e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag); } while (0)
 	if (!e->vi_carry) LAUNCH_VI(false, true);
 	else if (sparse) LAUNCH_VI(true, true);
 	else LAUNCH_VI(true, false);

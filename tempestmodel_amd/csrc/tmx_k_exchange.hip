@@ -198,6 +198,21 @@ void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf)
 		(double * const *)(e->d_p2p_dst + (size_t)buf * e->cfg.n_ranks));
 }
 
+// node-unique layout: what other ranks need are per-element values of patch-edge nodes, i.e. partial slots (tmx_unique.hip)
+void tmxuk_pack(tmx_engine * e) {
+	if (e->nsend == 0) return;
+	dim3 blk(256), grd((e->nsend + 255) / 256, e->nslab);
+	hipLaunchKernelGGL(k_pack, grd, blk, 0, e->stream, e->nslab, (size_t)e->u.NP, e->nsend,
+		(const double *)e->u.d_part, (const int *)e->u.d_send_slots, (const int *)e->d_send_base, (const int *)e->d_send_stride, e->d_sendbuf);
+}
+void tmxuk_pack_p2p(tmx_engine * e, int buf) {
+	if (e->nsend == 0) return;
+	dim3 blk(256), grd((e->nsend + 255) / 256, e->nslab);
+	hipLaunchKernelGGL(k_pack_p2p, grd, blk, 0, e->stream, e->nslab, (size_t)e->u.NP, e->nsend,
+		(const double *)e->u.d_part, (const int *)e->u.d_send_slots, (const int *)e->d_send_within, (const int *)e->d_send_stride, (const int *)e->d_send_peer,
+		(double * const *)(e->d_p2p_dst + (size_t)buf * e->cfg.n_ranks));
+}
+
 void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq) {
 	// how long a neighbour may lag (it may be busy on its host: output, a slower node) before the exchange gives up
 	// (TMX_P2P_TIMEOUT_S, default 600 s, 0 = never: under MPI a rank that writes output for minutes is slow, not dead)

@@ -33,7 +33,8 @@
 // ds_bpermute_b32) per field.  Global accesses stay one contiguous 512-byte row per wavefront (the map permutes lanes
 // inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
 // results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
-template <bool FUSE_V, int NT, bool MF>
+// UQ: node-unique state layout (tmx_device.h, seam_store)
+template <bool FUSE_V, int NT, bool MF, bool UQ>
 #ifndef TMX_H_MINWG
 #define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
 #endif
@@ -48,10 +49,15 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	// column of this lane: element-major (e, i, j) in memory; MF: lane = j + 4 e + 16 i
-	const int tile = p.quads ? p.quads[blockIdx.x] : blockIdx.x;       // 64-column tile of this workgroup
+	int tix, yb;
+	if (!wg_tile<UQ>(p, (L + KT_H - 1) / KT_H, tix, yb)) return;
+	const int tile = p.quads ? p.quads[tix] : tix;       // 64-column tile of this workgroup
 	const int col = MF ? tile * 64 + ((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3) : tile * 64 + lane;
-	const int k = blockIdx.y * KT_H + ty;
-	const bool act = (k < L) && (col < p.ncol);
+	const int k = yb * KT_H + ty;
+	// UQ: geometry, LDS and the hand-over arrays keep the thread's own column; the state is gathered from the unique slabs
+	const int uc = UQ ? p.t_ucol[col] : col;
+	const size_t SS = UQ ? (size_t)p.NSS : NS;
+	const bool act = (k < L) && (UQ ? (uc >= 0) : (col < p.ncol));
 
 	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
@@ -63,21 +69,21 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
-		const unsigned cb = (unsigned)col * 8u;
+		const unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;      // byte offsets inside a state slab / a geometry slab
 		const double * __restrict__ xuv = uvt.xin;      // U,V of the initial instance (its own slot or the one it shares)
-		ua = ldu(xuv + TMX_SLAB_U(L, k) * NS, cb);
-		ub = ldu(xuv + TMX_SLAB_V(L, k) * NS, cb);
-		rt = ldu(xin + TMX_SLAB_T(L, k) * NS, cb);
-		rh = ldu(xin + TMX_SLAB_R(L, k) * NS, cb);
-		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * NS, cb);
-		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * NS, cb);
-		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * NS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * NS, cb);
-		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * NS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * NS, cb);
-		bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * NS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * NS, cb);
-		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * NS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * NS, cb);
-		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * NS, cb);
-		c2a0 = ldu(p.g2d + G2_C2A0 * NS, cb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, cb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, cb);
-		jn = ldu(p.g2d + G2_JN * NS, cb); j2d = ldu(p.g2d + G2_J2D * NS, cb); fcor = ldu(p.g2d + G2_F * NS, cb);
+		ua = ldu(xuv + TMX_SLAB_U(L, k) * SS, cb);
+		ub = ldu(xuv + TMX_SLAB_V(L, k) * SS, cb);
+		rt = ldu(xin + TMX_SLAB_T(L, k) * SS, cb);
+		rh = ldu(xin + TMX_SLAB_R(L, k) * SS, cb);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * SS, cb);
+		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * SS, cb);
+		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * SS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * SS, cb);
+		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * SS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * SS, cb);
+		bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
+		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
+		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, gb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, gb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, gb);
+		jn = ldu(p.g2d + G2_JN * NS, gb); j2d = ldu(p.g2d + G2_J2D * NS, gb); fcor = ldu(p.g2d + G2_F * NS, gb);
 		const MetCol mc = met_col(p, col);
 		metric_node(p, mc, k, col, ca2, cb2, cx2, dra, drb);
 		// W on levels (InterpolateREdgeToNode, GridPatchGLL.cpp:111-143)
@@ -219,10 +225,14 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			outV += b * w_lo;
 		}
 	}
-	stu(xup + sU, colb, outU);
-	stu(xup + sV, colb, outV);
-	stu(xup + sR, colb, bR - dt * invJ * (darf + dbrf));
-	stu(xup + sT, colb, bT - dt * invJ * (dapf + dbpf));
+	const double outR = bR - dt * invJ * (darf + dbrf), outT = bT - dt * invJ * (dapf + dbpf);
+	if (!UQ) {
+		stu(xup + sU, colb, outU);
+		stu(xup + sV, colb, outV);
+		stu(xup + sR, colb, outR);
+		stu(xup + sT, colb, outT);
+	}
+	double outW = 0.0;
 	if (TMX_H_FUSE_W && !MF) {
 		// W on the interfaces inside the tile (part 2 below, :1612-1659): interface k takes (u x zeta)_xi of the levels k - 1 and k,
 		// which wavefront ty - 1 hands over through its own (now free) LDS row; only the tile's first interface is left to
@@ -234,31 +244,46 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			double v = 0.0;
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lane];
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
-			stu(xup + TMX_SLAB_W(L, k) * NS, colb, bW + dt * v);
+			outW = bW + dt * v;
+			if (!UQ) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
 		}
 	} else
 		stu(ucz + (size_t)k * NS, colb, uczx);
+	if (UQ && !MF) {
+		// rows 1..5 of the wavefront's LDS block (row 0 is being read by the wavefront above); W only where this kernel updates it
+		const double v[5] = { outU, outV, outR, outT, outW };
+		const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
+		seam_store<5>(p, &s[ty][1], lane, p.t_sdst[col], p.t_sred[col], v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
+	}
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
 // stride > 1: only the interfaces k = 0, stride, 2 stride, ... (the first of every level tile of k_h_explicit, which has done
 // the others) and the top one
-template <int NT>
+template <int NT, bool UQ>
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
 	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride)
 {
+	__shared__ double sw[UQ ? 4 : 1][1][64];
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + threadIdx.x;
-	const int idx = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
+	const int ty = WAVE_UNIFORM(threadIdx.y);
+	int tix, yb;
 	const int nfirst = (L + stride - 1) / stride;          // interfaces idx * stride < L, then the top one
+	if (!wg_tile<UQ>(p, (nfirst + 1 + 3) / 4, tix, yb)) return;
+	const int col = (p.quads ? p.quads[tix] : tix) * 64 + threadIdx.x;
+	const int idx = yb * 4 + ty;
 	const int k = (idx < nfirst) ? idx * stride : ((idx == nfirst) ? L : L + 1);
-	if (k > L || col >= p.ncol) return;
+	const int uc = UQ ? p.t_ucol[col] : col;               // the node's entry in the state slabs (UQ: unique slabs, stride NSS)
+	const size_t SS = UQ ? (size_t)p.NSS : NS;
+	if (k > L || (UQ ? uc < 0 : col >= p.ncol)) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
-		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * NS + col);
+		// (UQ: the copies of a node all carry the base's value: every one of them may store it)
+		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * SS + uc);
 		return;
 	}
+	double wnew;
 	if (k == 0) {
 		double u0 = 0.0, v0 = 0.0;
 		// updated U,V of levels 0,1 as the H step left them (uv01 when V.StepExplicit was fused in)
@@ -272,13 +297,19 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 		v0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * (*pv1);
 		double cx0, cx1, cx2;
 		metric_edge(p, met_col(p, col), 0, col, cx0, cx1, cx2);
-		xup[TMX_SLAB_W(L, 0) * NS + col] = -(cx0 * u0 + cx1 * v0) / cx2;
+		wnew = -(cx0 * u0 + cx1 * v0) / cx2;
 	} else {
 		double v = 0.0;
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
-		xup[TMX_SLAB_W(L, k) * NS + col] = base_value<NT>(xbase, TMX_SLAB_W(L, k) * NS + col) + dt * v;
+		wnew = base_value<NT>(xbase, TMX_SLAB_W(L, k) * SS + uc) + dt * v;
 	}
+	if (UQ) {
+		const double v1[1] = { wnew };
+		const int slab[1] = { TMX_SLAB_W(L, k) };
+		seam_store<1>(p, &sw[ty][0], threadIdx.x, p.t_sdst[col], p.t_sred[col], v1, xup, slab, 1);
+	} else
+		xup[TMX_SLAB_W(L, k) * NS + col] = wnew;
 }
 
 // xin_uv / xbase_uv / src_uv: where the U,V slabs of the initial instance, the base instance and the combination sources
@@ -294,16 +325,22 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
-	dim3 blk(64, KT_H), grd(ntile, (p.L + KT_H - 1) / KT_H);
-	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
+	const bool uq = p.t_ucol != nullptr;      // node-unique layout (tmxu_params): 1-D launches, XCD-aware tile order
+	KParams q = p; q.u_ntiles = ntile;
 	const int wstride = (TMX_H_FUSE_W && !(fuse_v && e->use_mfma)) ? KT_H : 1;
-	dim3 blk2(64, 4), grd2(ntile, ((p.L + wstride - 1) / wstride + 1 + 3) / 4);
+	const int nyb = (p.L + KT_H - 1) / KT_H, nyb2 = ((p.L + wstride - 1) / wstride + 1 + 3) / 4;
+	dim3 blk(64, KT_H), grd = wg_grid(uq, q, ntile, nyb);
+	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
+	dim3 blk2(64, 4), grd2 = wg_grid(uq, q, ntile, nyb2);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
 #define LAUNCH_HV(NT_) do { \
-		if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		hipLaunchKernelGGL((k_h_w_update<NT_>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
+		if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); \
+		else hipLaunchKernelGGL((k_h_w_update<NT_, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HV(0); break;
 		case 2: LAUNCH_HV(2); break;
@@ -661,7 +698,9 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 	(void)xi;
 }
 
-template <bool PULL>
+// UQ: node-unique state layout (tmx_device.h, seam_store): operands gathered from the unique slabs, results averaged over the
+// seams inside the wavefront or handed to the partial slots
+template <bool PULL, bool UQ>
 __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
 	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
@@ -672,10 +711,15 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
-	const int col = (p.quads ? p.quads[blockIdx.x] : blockIdx.x) * 64 + lane;
-	const int kk = blockIdx.y * 4 + ty;
-	const bool actw = (kk <= L) && (col < p.ncol);     // interface level (W)
-	const bool actn = (kk < L) && (col < p.ncol);      // model level (U,V,rho*theta,rho)
+	int tix, yb;
+	if (!wg_tile<UQ>(p, (L + 1 + 3) / 4, tix, yb)) return;
+	const int col = (p.quads ? p.quads[tix] : tix) * 64 + lane;     // the thread's own column: geometry, LDS
+	const int kk = yb * 4 + ty;
+	const int uc = UQ ? p.t_ucol[col] : col;                          // where its node's state lives
+	const size_t SS = UQ ? (size_t)p.NSS : NS;                        // state slab stride
+	const bool here = UQ ? (uc >= 0) : (col < p.ncol);
+	const bool actw = (kk <= L) && here;     // interface level (W)
+	const bool actn = (kk < L) && here;      // model level (U,V,rho*theta,rho)
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
 
 	double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
@@ -683,23 +727,23 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	if (actw) {
 		c2a0 = p.g2d[G2_C2A0 * NS + col]; c2a1 = p.g2d[G2_C2A1 * NS + col]; c2b1 = p.g2d[G2_C2B1 * NS + col];
 		j2d = p.g2d[G2_J2D * NS + col]; jn = p.g2d[G2_JN * NS + col]; je = p.g2d[G2_JE * NS + col];
-		if (!PULL) psiW = xsrc[TMX_SLAB_W(L, kk) * NS + col];
+		if (!PULL) psiW = xsrc[TMX_SLAB_W(L, kk) * SS + uc];
 	}
 	// the base of the update (second pass: the instance the viscosity is applied to), loaded with the operands: at the point
 	// of use its latency would follow three barriers and both contractions
 	double bW = 0.0, bT = 0.0, bR = 0.0, bU = 0.0, bV = 0.0;
 	if (xbase && actw) {
-		bW = xbase[TMX_SLAB_W(L, kk) * NS + col];
+		bW = xbase[TMX_SLAB_W(L, kk) * SS + uc];
 		if (actn) {
-			bT = xbase[TMX_SLAB_T(L, kk) * NS + col]; bR = xbase[TMX_SLAB_R(L, kk) * NS + col];
-			bU = xbase[TMX_SLAB_U(L, kk) * NS + col]; bV = xbase[TMX_SLAB_V(L, kk) * NS + col];
+			bT = xbase[TMX_SLAB_T(L, kk) * SS + uc]; bR = xbase[TMX_SLAB_R(L, kk) * SS + uc];
+			bU = xbase[TMX_SLAB_U(L, kk) * SS + uc]; bV = xbase[TMX_SLAB_V(L, kk) * SS + uc];
 		}
 	}
 	if (!PULL && actn) {
-		psiT = xsrc[TMX_SLAB_T(L, kk) * NS + col];
-		psiR = xsrc[TMX_SLAB_R(L, kk) * NS + col];
-		ua = xsrc[TMX_SLAB_U(L, kk) * NS + col];
-		ub = xsrc[TMX_SLAB_V(L, kk) * NS + col];
+		psiT = xsrc[TMX_SLAB_T(L, kk) * SS + uc];
+		psiR = xsrc[TMX_SLAB_R(L, kk) * SS + uc];
+		ua = xsrc[TMX_SLAB_U(L, kk) * SS + uc];
+		ub = xsrc[TMX_SLAB_V(L, kk) * SS + uc];
 	}
 	if (PULL && actw) {
 		if (actn) {
@@ -761,24 +805,43 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
 	dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
 
-	xout[TMX_SLAB_W(L, kk) * NS + col] = bW - dt * (1.0 / je) * nu_s * (uaW + ubW);
+	const double oW = bW - dt * (1.0 / je) * nu_s * (uaW + ubW);
+	double oT = 0, oR = 0, oU = 0, oV = 0;
 	if (actn) {
 		const double invJ = 1.0 / jn;
-		xout[TMX_SLAB_T(L, kk) * NS + col] = bT - dt * invJ * nu_s * (uaT + ubT);
-		xout[TMX_SLAB_R(L, kk) * NS + col] = bR - dt * invJ * nu_s * (uaR + ubR);
+		oT = bT - dt * invJ * nu_s * (uaT + ubT);
+		oR = bR - dt * invJ * nu_s * (uaR + ubR);
 		const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
 		const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
-		xout[TMX_SLAB_U(L, kk) * NS + col] = bU - dt * upa;
-		xout[TMX_SLAB_V(L, kk) * NS + col] = bV - dt * upb;
+		oU = bU - dt * upa;
+		oV = bV - dt * upb;
+	}
+	if (UQ) {
+		// (level activity is wave-uniform, so all lanes of a wavefront agree on nv; the LDS rows were last read by this wavefront)
+		const double v[5] = { oW, oT, oR, oU, oV };
+		const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
+		seam_store<5>(p, &s[ty][0], lane, p.t_sdst[col], p.t_sred[col], v, xout, slab, (kk < L) ? 5 : 1);
+		return;
+	}
+	xout[TMX_SLAB_W(L, kk) * NS + col] = oW;
+	if (actn) {
+		xout[TMX_SLAB_T(L, kk) * NS + col] = oT;
+		xout[TMX_SLAB_R(L, kk) * NS + col] = oR;
+		xout[TMX_SLAB_U(L, kk) * NS + col] = oU;
+		xout[TMX_SLAB_V(L, kk) * NS + col] = oV;
 	}
 }
 
 void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout,
 	double dt, double nu_s, double nu_d, double nu_v, int scale, bool pull_dss) {
-	dim3 blk(64, 4), grd(p.quads ? e->launch_tiles : p.NS / 64, (p.L + 1 + 3) / 4);
+	const int ntiles = p.quads ? e->launch_tiles : p.NS / 64, nyb = (p.L + 1 + 3) / 4;
+	dim3 blk(64, 4);
 	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
-	if (pull_dss) hipLaunchKernelGGL(k_hypervis<true>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
-	else hipLaunchKernelGGL(k_hypervis<false>, grd, blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	if (p.t_ucol) {      // node-unique layout (tmxu_params)
+		KParams q = p; q.u_ntiles = ntiles;
+		hipLaunchKernelGGL((k_hypervis<false, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	} else if (pull_dss) hipLaunchKernelGGL((k_hypervis<true, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	else hipLaunchKernelGGL((k_hypervis<false, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -132,6 +132,8 @@ def load_library():
     lib.tmx_halo_p2p_enable.argtypes = [C.c_void_p, C.c_int]
     lib.tmx_halo_p2p_reset.argtypes = [C.c_void_p]
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
+    lib.tmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    lib.tmx_get_option.argtypes = [C.c_void_p, C.c_char_p, PD]
     _lib = lib
     return lib
 
@@ -157,9 +159,11 @@ class Engine:
     (or anything exposing the same reference-layout arrays)."""
 
     def __init__(self, grid, n_instances=7, nu=(1.0e15, 1.0e15, 1.0e15), hypervis_order=4,
-                 rank=0, n_ranks=1, owner=None, device=-1, fully_explicit=False, uniform_diffusion=None):
+                 rank=0, n_ranks=1, owner=None, device=-1, fully_explicit=False, uniform_diffusion=None, options=None):
         """``fully_explicit``: VerticalDynamicsFEM's --explicitvertical mode; ``uniform_diffusion``: (K_scalar, K_vector)
-        of Grid::HasUniformDiffusion (reference state and tracers are taken from ``grid.patches[*].geom``)."""
+        of Grid::HasUniformDiffusion (reference state and tracers are taken from ``grid.patches[*].geom``); ``options``:
+        {name: value} for tmx_set_option before tmx_finalize (e.g. {"unique_layout": 1})."""
+        self.options = dict(options or {})
         self.lib = load_library()
         self.grid = grid
         self.L = grid.L
@@ -268,6 +272,8 @@ class Engine:
                     self._chk(self.lib.tmx_set_patch_metric_factors(
                         self.h, P.index, _pd(fx[0]), _pd(fx[1]), _pd(fx[2]), float(g.phys.earth_radius),
                         _pd(fx[3]), _pd(fx[4])))
+        for k_, v_ in self.options.items():
+            self._chk(self.lib.tmx_set_option(self.h, k_.encode(), float(v_)))
         self._chk(self.lib.tmx_finalize(self.h))
         if self.uniform_diffusion is not None and not self.plan_only:
             for P in g.patches:
@@ -479,6 +485,11 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.tmx_sync(self.h))
+
+    def get_option(self, name):
+        v = np.zeros(1)
+        self._chk(self.lib.tmx_get_option(self.h, name.encode(), _pd(v)))
+        return float(v[0])
 
     def info(self, what):
         return int(self.lib.tmx_info(self.h, what))

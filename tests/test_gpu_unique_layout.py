@@ -1,0 +1,183 @@
+"""The node-unique state layout (tmx_set_option "unique_layout") against the element-major layout and the
+oracle: inside tmx_step the state is held once per patch node, the explicit / hyperviscosity kernels gather their operands and
+average seam nodes inside the producing wavefront or through partial slots, the column solve works on the unique columns
+directly.  Every result must be the element-major engine's bit for bit -- whole steps of every stepper whose program has a
+node-unique form, on one rank and on several (loopback wire), with the conversions at the boundary to every other entry point."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+INFO_GHOST, INFO_EARLY, INFO_LATE = 4, 7, 8
+INFO_UNIQUE_LAYOUT, INFO_UNIQUE_INSTANCES, INFO_UNIQUE_CONVERSIONS, INFO_PARTIAL_SLOTS, INFO_UNIQUE_GROUPS = 12, 13, 14, 15, 16
+
+
+def _same(a, b, patches):
+    """prognostic content of two download_state results, bit for bit"""
+    for p in patches:
+        if not np.array_equal(a[p][0][[0, 1, 2, 4], 1:-1, 1:-1], b[p][0][[0, 1, 2, 4], 1:-1, 1:-1]):
+            return False
+        if not np.array_equal(a[p][1][3, 1:-1, 1:-1], b[p][1][3, 1:-1, 1:-1]):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("ne,npatch,shape", [(5, 6, 1), (5, 6, 0), (6, 24, 1), (4, 24, 1), (8, 6, 1)])
+@pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "strang", "strang_rk4", "strang_ssprk53"])
+def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape):
+    """Three whole steps (the first from the pointwise initial state, whose seam copies may differ: that step then runs
+    element-major by the engine's own check) on both layouts; the node-unique path must really have run."""
+    from tempestmodel_amd.engine import Engine
+    if (ne, npatch) != (5, 6) and scheme not in ("ars343", "strang"):
+        pytest.skip("the other grids run two schemes")
+    g, start = gu.make_grid(ne, 6, npatch)
+    ni = max(7, Engine.scheme_instances(scheme))
+    d = Engine(g, n_instances=ni, options={"unique_layout": 0})
+    u = Engine(g, n_instances=ni, options={"unique_layout": 1, "unique_tile_shape": shape})
+    try:
+        assert u.info(INFO_UNIQUE_LAYOUT) == 1 and d.info(INFO_UNIQUE_LAYOUT) == 0
+        assert u.get_option("unique_tile_shape") == shape
+        d.upload_state(0, start); u.upload_state(0, start)
+        for k in range(4):
+            d.step(scheme, 150.0, first=(k == 0)); u.step(scheme, 150.0, first=(k == 0))
+            if k >= 1:
+                assert u.info(INFO_UNIQUE_INSTANCES) > 0, "step %d did not run on the node-unique layout" % k
+        d.sync(); u.sync()
+        conv = u.info(INFO_UNIQUE_CONVERSIONS)
+        for ix in range(ni):
+            assert _same(u.download_state(ix), d.download_state(ix), range(npatch)), (scheme, "instance", ix)
+        assert u.info(INFO_UNIQUE_INSTANCES) == 0 and u.info(INFO_UNIQUE_CONVERSIONS) > conv      # the download converted them back
+        # and on from the converted state: two more steps
+        for k in range(2):
+            d.step(scheme, 150.0); u.step(scheme, 150.0)
+        d.sync(); u.sync()
+        assert _same(u.download_state(0), d.download_state(0), range(npatch)), scheme
+    finally:
+        d.close(); u.close()
+
+
+def test_unique_layout_against_the_oracle_and_the_golden_vector():
+    """ARS343 steps from the reference's state after step 1 (fixture steps_ne4_L6_p24.npz): identical doubles to the C oracle,
+    reference golden vectors within the north-star tolerance -- the same assertions the element-major path has."""
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import Oracle
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step1", g)
+    o = Oracle(g); o.set_state(0, start)
+    e = Engine(g, options={"unique_layout": 1}); e.upload_state(0, start)
+    try:
+        for tag in ("step2", "step3"):
+            assert o.step_ars343(200.0) == 0
+            e.step_ars343(200.0)
+            assert e.info(INFO_UNIQUE_INSTANCES) > 0
+            e.sync()
+            got = e.download_state(0)
+            assert max(gu.prognostic_errors(got, o.get_state(0))) <= gu.exact_tolerance(), tag
+            assert max(gu.prognostic_errors(got, gu.expand_compact(d, tag, g))) < 1e-10, tag
+    finally:
+        e.close()
+
+
+def test_other_entry_points_see_the_element_major_form():
+    """tmx_step leaves instances in node-unique form; every other call converts what it names first: per-call operations after a
+    step give what the element-major engine gives, and a step after them goes back to the unique form."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(5, 6, 6)
+    d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1})
+    try:
+        for e in (d, u):
+            e.upload_state(0, start)
+            e.step_ars343(120.0); e.step_ars343(120.0)
+        assert u.info(INFO_UNIQUE_INSTANCES) > 0
+        for e in (d, u):
+            e.copy_data(0, 3)
+            e.h_step_explicit(0, 3, 40.0)       # leaves the copies of seam nodes different: no node-unique form
+            e.v_step_explicit(0, 3, 40.0)
+        assert u.info(INFO_UNIQUE_INSTANCES) == 0
+        d.sync(); u.sync()
+        assert _same(u.download_state(3), d.download_state(3), range(6))
+        for e in (d, u):
+            e.apply_dss(3)
+            e.v_step_implicit(3, 3, 40.0)
+            e.linear_combine_data([0.5, 0, 0, 0.5, 0, 0, 0], 0)
+            e.step_ars343(120.0)
+        assert u.info(INFO_UNIQUE_INSTANCES) > 0
+        d.sync(); u.sync()
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+        # an instance whose copies differ (H without DSS) as the step's input: the engine must notice and step element-major
+        for e in (d, u):
+            e.copy_data(0, 1); e.h_step_explicit(0, 1, 40.0); e.copy_data(1, 0)
+            e.step_ars343(120.0)
+        d.sync(); u.sync()
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+    finally:
+        d.close(); u.close()
+
+
+@pytest.mark.parametrize("n_ranks,scheme", [(4, "ars343"), (3, "strang"), (8, "ars343")])
+def test_multirank_steps_on_the_unique_layout_loopback(n_ranks, scheme):
+    """tmx_step on n rank engines with the node-unique layout (loopback wire): what travels are the partial slots of the
+    patch-edge nodes; boundary tiles run first.  Bit-identical to ONE element-major engine."""
+    import threading
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(12, 6, 24)
+    ni = max(7, Engine.scheme_instances(scheme))
+    single = Engine(g, n_instances=ni, options={"unique_layout": 0})
+    ranks = [Engine(g, rank=r, n_ranks=n_ranks, n_instances=ni, options={"unique_layout": 1}) for r in range(n_ranks)]
+    try:
+        assert all(e.info(INFO_UNIQUE_LAYOUT) == 1 and e.info(INFO_PARTIAL_SLOTS) > 0 for e in ranks)
+        single.upload_state(0, start)
+        for k in range(4):
+            single.step(scheme, 200.0, first=(k == 0))
+        single.sync()
+        ref = single.download_state(0)
+        for e in ranks:
+            e.upload_state(0, start)
+        Engine.loopback_group(ranks)
+        errors, used = [], []
+
+        def run(e):
+            try:
+                for k in range(4):
+                    e.step(scheme, 200.0, first=(k == 0))
+                used.append(e.info(INFO_UNIQUE_INSTANCES))
+                e.sync()
+            except Exception as ex:
+                errors.append(ex)
+
+        th = [threading.Thread(target=run, args=(e,)) for e in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        assert not errors and not any(t.is_alive() for t in th), errors
+        Engine.loopback_dissolve(ranks[0])
+        assert all(v > 0 for v in used), used
+        for e in ranks:
+            assert _same(e.download_state(0), ref, e.local_patches), e.rank
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()
+
+
+def test_unique_layout_with_held_suarez_forcing():
+    """Column physics between the steps works on the element-major form (converted there and back); the forcing may leave the
+    copies of a node different in the last bit, in which case the next step runs element-major: results are identical either way."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(4, 8, 6)
+    d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1})
+    try:
+        for e in (d, u):
+            e.set_physics_inputs(None)
+            e.upload_state(0, start)
+            for _ in range(4):
+                e.step_ars343(100.0)
+                e.held_suarez(0, 100.0)
+            e.sync()
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+    finally:
+        d.close(); u.close()
