@@ -544,7 +544,11 @@ def main():
                        "parallelism": "%d patches over %d %s, halo exchange = %s" % (
                            len(grid.patches), world, "processes sharing ONE GPU (multi-process path check, not a scaling number)" if args.share_device and world > 1 else "GPU(s)",
                            halo_note),
-                       "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30},
+                       "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30,
+                       # tmx_set_option("unique_layout") / TMX_UNIQUE: inside tmx_step the state is held once per patch node
+                       "state_layout": ("node-unique inside tmx_step (%d instances in that form at the end of the run, %d partial slots, "
+                                        "%d node groups left to the DSS kernel of %d)" % (eng.info(13), eng.info(15), eng.info(16), eng.info(2)))
+                                       if eng.info(12) == 1 else "element-major (16 nodes per element, seam nodes duplicated)"},
             # `bound`: what limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64
             # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
             "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",

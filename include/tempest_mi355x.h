@@ -407,12 +407,13 @@ enum {
 long long tmx_info(tmx_engine * e, int what);
 
 /* Options by name: how the engine computes, never what (results are bit-identical under every setting).
- *   "unique_layout"      -1 default, 0 off, 1 on: hold the state once per patch node inside tmx_step (node-unique slabs: 9/16 of
+ *   "unique_layout"      -1 default (= 1), 0 off, 1 on: hold the state once per patch node inside tmx_step (node-unique slabs: 9/16 of
  *                        the bytes, the DSS reduced to the nodes on tile and patch edges) where every kernel of the configuration
  *                        has that form -- nonhydrostatic set, implicit vertical dynamics, no tracers / uniform diffusion /
  *                        Rayleigh layer; replaces nothing of the reference interface (GridPatch data stay as they are at the
  *                        boundary).  Before tmx_finalize.
- *   "unique_tile_shape"  elements of a wavefront: 1 = 2 x 2 blocks (default), 0 = 1 x 4 strips.  Before tmx_finalize.
+ *   "unique_tile_shape"  elements of a wavefront: 0 = the element-major order, 1 x 4 strips along beta that wrap around patch rows
+ *                        (default: measured fastest), 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row.  Before tmx_finalize.
  *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize. */
 int tmx_set_option(tmx_engine * e, const char * name, double value);
 int tmx_get_option(tmx_engine * e, const char * name, double * value);

@@ -314,6 +314,34 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 // workgroup -> (entry of the launch's tile list, level block).  Element-major kernels: the plain 2-D launch.  Node-unique kernels
 // (UQ): a 1-D launch unfolded so that every XCD sweeps a contiguous range of tiles, level block by level block -- neighbouring
 // tiles read the same rows of the unique slabs (the nodes on their common edge), which then come from that XCD's L2.
+// Lane of a wavefront -> position e * 16 + i * 4 + j inside its tile of four elements.  Element-major kernels: the identity (a
+// tile is 512 contiguous bytes of every slab).  Node-unique kernels: lane = j + 4 e + 16 i, so that 16 consecutive lanes hold one
+// node row of the tile's four elements -- for elements that follow one another along beta that is ONE contiguous run of 13
+// unique nodes in the slab (one or two 128-byte lines per 16 lanes); with the identity map a 16-lane group is one element = four
+// runs of 32 bytes in four different rows, four times the L1 / L2 requests per load instruction (measured: 2.1 x the L2 requests
+// of the element-major kernel and +12 % time for 23 % fewer bytes).
+#ifndef TMX_UQ_ROWLANES
+#define TMX_UQ_ROWLANES 0      // measured with the LDS rows as they are: the permuted lanes cost the contractions two-way bank conflicts (hyperviscosity pass 149 -> 196 us)
+#endif
+template <bool UQ> __device__ __forceinline__ int tile_lane() {
+	const int h = threadIdx.x;
+	return (UQ && TMX_UQ_ROWLANES) ? ((h & 3) | (((h >> 2) & 3) << 4) | ((h >> 4) << 2)) : h;
+}
+// unique-slab index of the node at position `lane` of tile `tile` (-1: padding), from the tile's eight wave-uniform table entries:
+// no per-lane table load in front of the state loads (a dependent memory round trip at the head of every wavefront: the
+// explicit kernels ran 12 % and the hyperviscosity pass 20 % longer with t_ucol[col] there)
+__device__ __forceinline__ int tile_ucol(const KParams & p, int tile, int lane) {
+	const int * ti = p.t_tinfo + (size_t)WAVE_UNIFORM(tile) * 8;
+	const int e = lane >> 4;
+	const int b0 = ti[0], b1 = ti[1], b2 = ti[2], b3 = ti[3], n0 = ti[4], n1 = ti[5], n2 = ti[6], n3 = ti[7];
+	const int base = (e == 0) ? b0 : ((e == 1) ? b1 : ((e == 2) ? b2 : b3));
+	const int nj = (e == 0) ? n0 : ((e == 1) ? n1 : ((e == 2) ? n2 : n3));
+#ifdef TMX_ABL_UQ_DLOADS      // ablation builds (wrong results): contiguous addresses instead of the gather, everything else as it is
+	return (base < 0) ? -1 : min(tile * 64 + lane, p.NSS - 1);
+#endif
+	return (base < 0) ? -1 : base + ((lane >> 2) & 3) * nj + (lane & 3);
+}
+
 template <bool UQ> __device__ __forceinline__ bool wg_tile(const KParams & p, int nyb, int & tile_ix, int & yb) {
 	if (!UQ) { tile_ix = blockIdx.x; yb = blockIdx.y; return true; }
 	if (p.u_xcd) return xcd_tile(p.u_ntiles, nyb, tile_ix, yb);
@@ -339,6 +367,14 @@ template <int NV>
 __device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[64], int lane, int sdst, int sred, const double (&v)[NV],
 	double * __restrict__ xo, const int (&slab)[NV], int nv)
 {
+#ifdef TMX_ABL_UQ_DSTORES     // ablation builds (wrong results): every lane stores its own value to consecutive addresses, no exchange
+	{
+		const int c = min((int)(blockIdx.x & 1023) * 64 + lane, p.NSS - 1);
+#pragma unroll
+		for (int t = 0; t < NV; t++) if (t < nv) xo[(size_t)slab[t] * p.NSS + c] = v[t];
+		return;
+	}
+#endif
 #pragma unroll
 	for (int t = 0; t < NV; t++) if (t < nv) srow[t][lane] = v[t];
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

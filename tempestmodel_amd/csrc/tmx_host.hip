@@ -162,7 +162,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
 	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
 	if (const char * m = getenv("TMX_UNIQUE")) e->u.option = atoi(m) ? 1 : 0;
-	if (const char * m = getenv("TMX_UNIQUE_TILE")) e->u.tile_shape = atoi(m) ? 1 : 0;
+	if (const char * m = getenv("TMX_UNIQUE_TILE")) e->u.tile_shape = std::min(std::max(atoi(m), 0), 2);
 	if (const char * m = getenv("TMX_UNIQUE_XCD")) e->u.xcd_order = atoi(m) ? 1 : 0;
 	if (const char * m = getenv("TMX_HVIS_PULL")) e->hvis_pull = atoi(m);
 	if (const char * m = getenv("TMX_HVIS_BLOCK")) e->hvis_block = atoi(m);
@@ -975,7 +975,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// nonhydrostatic set with implicit vertical dynamics, no tracers, no uniform diffusion, no Rayleigh layer (its strength is
 	// stored per copy of a node), closed-form metric.  Every other configuration, and every entry point other than tmx_step,
 	// works on the element-major layout as before.
-	if (e->u.option == 1 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && !e->rayleigh && e->metric_closed &&
+	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && !e->rayleigh && e->metric_closed &&
 	    !e->hvis_pull && !e->hvis_block && !e->use_graph && e->vi_mode == 0) {
 		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
 		if ((r = tmxu_build(e, in, &bytes))) return r;
@@ -1319,7 +1319,7 @@ static KParams make_params(const tmx_engine * e) {
 	p.eta = e->d_eta; p.closed = e->metric_closed ? 1 : 0;
 	p.inv_da = 1.0 / e->cfg.element_delta_a;
 	p.quads = e->stage_quads;      // tile list of a boundary-first stage in progress (hv_stage_split), else all tiles
-	p.NSS = e->NS; p.t_ucol = nullptr; p.t_sdst = nullptr; p.t_sred = nullptr; p.part = nullptr; p.NP = 0;      // element-major layout (tmxu_params: node-unique)
+	p.NSS = e->NS; p.t_ucol = nullptr; p.t_tinfo = nullptr; p.t_sdst = nullptr; p.t_sred = nullptr; p.part = nullptr; p.NP = 0;      // element-major layout (tmxu_params: node-unique)
 	p.u_ntiles = 0; p.u_xcd = e->u.xcd_order;
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
@@ -3223,7 +3223,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "unique_layout" || n == "unique_tile_shape" || n == "unique_xcd_order") {
 		REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
 		if (n == "unique_layout") { REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1"); e->u.option = iv; }
-		else if (n == "unique_tile_shape") e->u.tile_shape = iv ? 1 : 0;
+		else if (n == "unique_tile_shape") { REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2"); e->u.tile_shape = iv; }
 		else e->u.xcd_order = iv ? 1 : 0;
 		return TMX_OK;
 	}

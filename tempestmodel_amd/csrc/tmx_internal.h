@@ -61,6 +61,8 @@ struct KParams {
 	int u_ntiles, u_xcd;    // U kernels are launched 1-D: tiles of this launch, and whether every XCD sweeps a contiguous range of them (xcd_tile)
 	int NSS;                // state slab stride in doubles (== NS in the element-major layout)
 	const int * t_ucol;     // [NS] unique-slab index of the thread's node, -1: padding lane
+	const int * t_tinfo;    // [NS / 64][8] per tile {unique index of node (0,0) of its four elements (-1: padding), their patches' row pitch}: t_ucol without a
+	                        //   per-lane load in front of every state load (wave-uniform: scalar loads)
 	const int * t_sdst;     // [NS] >= 0: store the (averaged) value there; -1: nothing (another lane of the tile stores this node); <= -2: partial slot -2 - t_sdst
 	const int * t_sred;     // [NS] n | lane1 << 4 | lane2 << 10 | lane3 << 16: average with the copies held by these lanes of the wavefront (n = 0, 2, 4)
 	double * part;          // [nslab][NP] partial slots
@@ -97,14 +99,15 @@ struct ProfSlot { double ms = 0.0; long long n = 0; };
 // tmx_step of a configuration all of whose kernels have the U form, every other entry point first converts what it names.
 struct UniqueLayout {
 	bool built = false;
-	int option = -1;                         // tmx_set_option("unique_layout"): -1 auto, 0 off, 1 on where eligible
-	int tile_shape = 1;                      // T order: 0 = the element-major order (1 x 4 element strips per wavefront), 1 = 2 x 2 element blocks
+	int option = -1;                         // tmx_set_option("unique_layout"): -1 default (= on where the configuration is eligible), 0 off, 1 on where eligible
+	int tile_shape = 0;                      // T order: 0 = the element-major order (1 x 4 element strips that wrap around patch rows), 1 = 2 x 2 element blocks, 2 = 1 x 4 strips inside a patch row
 	int xcd_order = 1;                       // workgroup -> tile map of the U kernels: 1 = every XCD sweeps a contiguous range of tiles
 	int NU = 0, NUS = 0, NTS = 0, nslots = 0, NP = 0;
 	int ngroups = 0, ngroups_local = 0;      // groups left to the DSS kernel (not averaged inside a wavefront); [0, ngroups_local): no remote member
 	size_t ustride = 0;                      // doubles per U-form instance (nslab * NUS)
 	double * d_ustate = nullptr, * d_part = nullptr, * d_g2d_t = nullptr, * d_g2d_u = nullptr;
 	int * d_t_ucol = nullptr, * d_t_sdst = nullptr, * d_t_sred = nullptr;      // [NTS]
+	int * d_t_tinfo = nullptr;               // [NTS / 64][8]
 	int * d_t_dcol = nullptr;                // [NTS] D column of a thread (-1: padding)
 	int * d_ucol_of_dcol = nullptr;          // [NS]
 	int * d_u_rep = nullptr;                 // [NUS] D column of the copy the reference's column solve works on

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 {
 	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
 	__shared__ double sD[16], sS[16];
-	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
 	if (!MF && tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
@@ -55,9 +55,11 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	const int col = MF ? tile * 64 + ((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3) : tile * 64 + lane;
 	const int k = yb * KT_H + ty;
 	// UQ: geometry, LDS and the hand-over arrays keep the thread's own column; the state is gathered from the unique slabs
-	const int uc = UQ ? p.t_ucol[col] : col;
+	const int uc = UQ ? tile_ucol(p, tile, lane) : col;
 	const size_t SS = UQ ? (size_t)p.NSS : NS;
 	const bool act = (k < L) && (UQ ? (uc >= 0) : (col < p.ncol));
+	// what the thread does with its results (seam_store): loaded here, with everything else, used at the end
+	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 
 	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		// rows 1..5 of the wavefront's LDS block (row 0 is being read by the wavefront above); W only where this kernel updates it
 		const double v[5] = { outU, outV, outR, outT, outW };
 		const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
-		seam_store<5>(p, &s[ty][1], lane, p.t_sdst[col], p.t_sred[col], v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
+		seam_store<5>(p, &s[ty][1], lane, sdst, sred, v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
 	}
 }
 
@@ -272,10 +274,12 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	int tix, yb;
 	const int nfirst = (L + stride - 1) / stride;          // interfaces idx * stride < L, then the top one
 	if (!wg_tile<UQ>(p, (nfirst + 1 + 3) / 4, tix, yb)) return;
-	const int col = (p.quads ? p.quads[tix] : tix) * 64 + threadIdx.x;
+	const int lane = tile_lane<UQ>();
+	const int tile = p.quads ? p.quads[tix] : tix;
+	const int col = tile * 64 + lane;
 	const int idx = yb * 4 + ty;
 	const int k = (idx < nfirst) ? idx * stride : ((idx == nfirst) ? L : L + 1);
-	const int uc = UQ ? p.t_ucol[col] : col;               // the node's entry in the state slabs (UQ: unique slabs, stride NSS)
+	const int uc = UQ ? tile_ucol(p, tile, lane) : col;    // the node's entry in the state slabs (UQ: unique slabs, stride NSS)
 	const size_t SS = UQ ? (size_t)p.NSS : NS;
 	if (k > L || (UQ ? uc < 0 : col >= p.ncol)) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	if (UQ) {
 		const double v1[1] = { wnew };
 		const int slab[1] = { TMX_SLAB_W(L, k) };
-		seam_store<1>(p, &sw[ty][0], threadIdx.x, p.t_sdst[col], p.t_sred[col], v1, xup, slab, 1);
+		seam_store<1>(p, &sw[ty][0], lane, p.t_sdst[col], p.t_sred[col], v1, xup, slab, 1);
 	} else
 		xup[TMX_SLAB_W(L, k) * NS + col] = wnew;
 }
@@ -706,16 +710,18 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 {
 	__shared__ double s[4][8][64];
 	__shared__ double sD[16], sS[16];
-	const int lane = threadIdx.x, ty = WAVE_UNIFORM(threadIdx.y);
+	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
 	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int tix, yb;
 	if (!wg_tile<UQ>(p, (L + 1 + 3) / 4, tix, yb)) return;
-	const int col = (p.quads ? p.quads[tix] : tix) * 64 + lane;     // the thread's own column: geometry, LDS
+	const int tile = p.quads ? p.quads[tix] : tix;
+	const int col = tile * 64 + lane;                                 // the thread's own column: geometry, LDS
 	const int kk = yb * 4 + ty;
-	const int uc = UQ ? p.t_ucol[col] : col;                          // where its node's state lives
+	const int uc = UQ ? tile_ucol(p, tile, lane) : col;               // where its node's state lives
+	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 	const size_t SS = UQ ? (size_t)p.NSS : NS;                        // state slab stride
 	const bool here = UQ ? (uc >= 0) : (col < p.ncol);
 	const bool actw = (kk <= L) && here;     // interface level (W)
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 		// (level activity is wave-uniform, so all lanes of a wavefront agree on nv; the LDS rows were last read by this wavefront)
 		const double v[5] = { oW, oT, oR, oU, oV };
 		const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
-		seam_store<5>(p, &s[ty][0], lane, p.t_sdst[col], p.t_sred[col], v, xout, slab, (kk < L) ? 5 : 1);
+		seam_store<5>(p, &s[ty][0], lane, sdst, sred, v, xout, slab, (kk < L) ? 5 : 1);
 		return;
 	}
 	xout[TMX_SLAB_W(L, kk) * NS + col] = oW;

@@ -22,7 +22,7 @@ template <class T> static int up(T ** d, const std::vector<T> & h, size_t * byte
 
 void tmxu_free(tmx_engine * e) {
 	UniqueLayout & u = e->u;
-	void * ptrs[] = { u.d_ustate, u.d_part, u.d_g2d_t, u.d_g2d_u, u.d_t_ucol, u.d_t_sdst, u.d_t_sred, u.d_t_dcol, u.d_ucol_of_dcol, u.d_u_rep, u.d_slot_ucol,
+	void * ptrs[] = { u.d_ustate, u.d_part, u.d_g2d_t, u.d_g2d_u, u.d_t_ucol, u.d_t_sdst, u.d_t_sred, u.d_t_tinfo, u.d_t_dcol, u.d_ucol_of_dcol, u.d_u_rep, u.d_slot_ucol,
 		u.d_gsrc, u.d_gdst, u.d_gn, u.d_gx, u.d_gtype, u.d_send_slots, u.d_quads_early, u.d_quads_late, u.d_check };
 	for (void * q : ptrs) if (q) hipFree(q);
 	u = UniqueLayout();
@@ -71,6 +71,19 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 			// what 2 x 2 blocks do not cover: the last column / row of a patch with an odd element count, as strips
 			if (P.neb & 1) for (int a = 0; a < (P.nea & ~1); a++) left.push_back(el(a, P.neb - 1));
 			if (P.nea & 1) for (int b = 0; b < P.neb; b++) left.push_back(el(P.nea - 1, b));
+		}
+		telem.insert(telem.end(), left.begin(), left.end());
+	} else if (u.tile_shape == 2) {
+		// 1 x 4 strips along beta that never wrap around a patch row (the element-major order lets them wrap where the patch width
+		// is not a multiple of four); what is left of every row goes to the end, again as runs along beta
+		std::vector<int> left;
+		for (int p : e->local_patches) {
+			const PatchInfo & P = e->patches[p];
+			for (int a = 0; a < P.nea; a++) {
+				int b = 0;
+				for (; b + 3 < P.neb; b += 4) for (int q = 0; q < 4; q++) telem.push_back(P.elem_base + a * P.neb + b + q);
+				for (; b < P.neb; b++) left.push_back(P.elem_base + a * P.neb + b);
+			}
 		}
 		telem.insert(telem.end(), left.begin(), left.end());
 	} else {
@@ -166,7 +179,16 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 			g2t[(size_t)f * u.NTS + t] = (t_dcol[t] >= 0) ? e->h_g2d[(size_t)f * NS + t_dcol[t]] : ((f == G2_J2D || f == G2_JN || f == G2_JE) ? 1.0 : 0.0);
 		for (int uu = 0; uu < u.NUS; uu++) g2u[(size_t)f * u.NUS + uu] = e->h_g2d[(size_t)f * NS + u_rep[uu]];
 	}
+	// per tile: where node (0,0) of each of its four elements lives and its patch's row pitch (ucol = base + i * pitch + j)
+	std::vector<int> tinfo((size_t)(u.NTS / 64) * 8, -1);
+	for (size_t t = 0; t < telem.size(); t++) {
+		const int p = patch_of_elem[telem[t]];
+		tinfo[(t / 4) * 8 + (t % 4)] = t_ucol[t * 16];
+		tinfo[(t / 4) * 8 + 4 + (t % 4)] = 3 * e->patches[p].neb + 1;
+		for (int q = 0; q < 16; q++) REQUIRE(t_ucol[t * 16 + q] == t_ucol[t * 16] + (q >> 2) * (3 * e->patches[p].neb + 1) + (q & 3), TMX_ERR_INVALID, "internal: tile table");
+	}
 	int r;
+	if ((r = up(&u.d_t_tinfo, tinfo, bytes))) return r;
 	if ((r = up(&u.d_g2d_t, g2t, bytes)) || (r = up(&u.d_g2d_u, g2u, bytes))) return r;
 	if ((r = up(&u.d_t_ucol, t_ucol, bytes)) || (r = up(&u.d_t_sdst, t_sdst, bytes)) || (r = up(&u.d_t_sred, t_sred, bytes)) || (r = up(&u.d_t_dcol, t_dcol, bytes))) return r;
 	if ((r = up(&u.d_ucol_of_dcol, ucol_of_dcol, bytes)) || (r = up(&u.d_u_rep, u_rep, bytes)) || (r = up(&u.d_slot_ucol, slot_ucol, bytes))) return r;
@@ -190,7 +212,7 @@ KParams tmxu_params(const tmx_engine * e, const KParams & base) {
 	KParams p = base;
 	const UniqueLayout & u = e->u;
 	p.NS = u.NTS; p.ncol = u.NTS; p.g2d = u.d_g2d_t;
-	p.NSS = u.NUS; p.t_ucol = u.d_t_ucol; p.t_sdst = u.d_t_sdst; p.t_sred = u.d_t_sred; p.part = u.d_part; p.NP = u.NP;
+	p.NSS = u.NUS; p.t_ucol = u.d_t_ucol; p.t_tinfo = u.d_t_tinfo; p.t_sdst = u.d_t_sdst; p.t_sred = u.d_t_sred; p.part = u.d_part; p.NP = u.NP;
 	return p;
 }
 

@@ -24,7 +24,7 @@ def _same(a, b, patches):
     return True
 
 
-@pytest.mark.parametrize("ne,npatch,shape", [(5, 6, 1), (5, 6, 0), (6, 24, 1), (4, 24, 1), (8, 6, 1)])
+@pytest.mark.parametrize("ne,npatch,shape", [(5, 6, 1), (5, 6, 0), (5, 6, 2), (6, 24, 2), (4, 24, 1), (8, 6, 2)])
 @pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "strang", "strang_rk4", "strang_ssprk53"])
 def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape):
     """Three whole steps (the first from the pointwise initial state, whose seam copies may differ: that step then runs
