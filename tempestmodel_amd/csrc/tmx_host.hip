@@ -976,7 +976,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// stored per copy of a node), closed-form metric.  Every other configuration, and every entry point other than tmx_step,
 	// works on the element-major layout as before.
 	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && !e->rayleigh && e->metric_closed &&
-	    !e->hvis_pull && !e->hvis_block && !e->use_graph && e->vi_mode == 0) {
+	    !e->hvis_pull && !e->hvis_block && !e->use_graph && !e->use_mfma && e->vi_mode == 0) {
 		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
 		if ((r = tmxu_build(e, in, &bytes))) return r;
 	}
