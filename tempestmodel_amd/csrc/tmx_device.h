@@ -73,6 +73,26 @@ __device__ __forceinline__ void stu(double * uniform_base, unsigned lane_byte_of
 	*(double *)((char *)uniform_base + lane_byte_off) = v;
 }
 
+// The same in two phases, for kernels that name several slabs of the combination: lin_load issues the loads of one slab's raw
+// terms (no control flow: PM = "the destination's own coefficient is not zero" is a compile-time parameter, so the loads of all
+// slabs can be issued back to back), lin_reduce combines them in the reference's order.  With base_value_u called slab after
+// slab the compiler serialised load batch -> wait -> reduce per slab behind the run-time `premul` branches: five dependent
+// memory round trips at the head of every wavefront of the explicit kernels.
+template <int NT, bool PM>
+__device__ __forceinline__ void lin_load(const double * const (&src)[12], size_t slab_off, unsigned colb, double (&x)[NT > 0 ? NT : 1]) {
+	if (NT == 0) { x[0] = ldu(src[0] + slab_off, colb); return; }
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || PM) ? ldu(src[m] + slab_off, colb) : 0.0;
+}
+template <int NT, bool PM>
+__device__ __forceinline__ double lin_reduce(const LinTerms & t, const double (&x)[NT > 0 ? NT : 1]) {
+	if (NT == 0) return x[0];
+	double v = PM ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
+	return v;
+}
+
 // base_value with the slab offset (uniform, in doubles) and the lane's byte offset kept apart
 template <int NT>
 __device__ __forceinline__ double base_value_u(const LinTerms & t, size_t slab_off, unsigned colb) {

@@ -33,8 +33,17 @@
 // ds_bpermute_b32) per field.  Global accesses stay one contiguous 512-byte row per wavefront (the map permutes lanes
 // inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
 // results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
+#ifndef TMX_H_BURST
+#define TMX_H_BURST 0      // 1: raw terms of the stage combination loaded in bursts (lin_load) instead of slab by slab (base_value_u): one memory round trip
+                           // instead of five per wavefront, but 185-190 registers (two resident wavefronts per SIMD instead of three): measured equal (element-major) or slower (node-unique)
+#endif
+#ifndef TMX_H_EXNER_LDS
+#define TMX_H_EXNER_LDS 1  // exp / log tables of the Exner function in LDS (one more barrier) instead of two dependent gathers from global memory
+#endif
 // UQ: node-unique state layout (tmx_device.h, seam_store)
-template <bool FUSE_V, int NT, bool MF, bool UQ>
+// PM: the update instance enters its own stage combination (LinTerms::premul), a compile-time parameter so that the loads of the
+// combination's raw terms carry no control flow (lin_load)
+template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM>
 #ifndef TMX_H_MINWG
 #define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
 #endif
@@ -43,9 +52,11 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 {
 	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
 	__shared__ double sD[16], sS[16];
+	__shared__ double rmtab[TMX_H_EXNER_LDS ? TMX_RMTAB_DOUBLES : 1];      // exp / log tables of the Exner function: from global memory they are two dependent gathers per wavefront
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
 	if (!MF && tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	if (TMX_H_EXNER_LDS) tmx_rm_tables_to_lds(rmtab, tid, 64 * KT_H);
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	// column of this lane: element-major (e, i, j) in memory; MF: lane = j + 4 e + 16 i
@@ -69,6 +80,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
 	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
 	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
+	constexpr int NX = NT > 0 ? NT : 1;
+	double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
+#pragma unroll
+	for (int m = 0; m < NX; m++) { xU[m] = 0; xV[m] = 0; xT[m] = 0; xR[m] = 0; xW[m] = 0; }
 	if (act) {
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
 		const unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;      // byte offsets inside a state slab / a geometry slab
@@ -81,9 +96,15 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * SS, cb);
 		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * SS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * SS, cb);
 		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * SS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * SS, cb);
-		bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
-		bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
-		if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
+		// raw terms of the base of U,V (issued with the state, before anything is waited for; reduced below); those of
+		// rho*theta, rho and W follow behind the barrier, when the registers of the prologue are free again, and arrive
+		// while the contractions run -- all of them in one burst take the kernel from three resident wavefronts per SIMD to two
+		if (TMX_H_BURST) { lin_load<NT, PM>(uvt.src, TMX_SLAB_U(L, k) * SS, cb, xU); lin_load<NT, PM>(uvt.src, TMX_SLAB_V(L, k) * SS, cb, xV); }
+		else {
+			bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
+			bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
+			if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
+		}
 		c2a0 = ldu(p.g2d + G2_C2A0 * NS, gb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, gb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, gb);
 		jn = ldu(p.g2d + G2_JN * NS, gb); j2d = ldu(p.g2d + G2_J2D * NS, gb); fcor = ldu(p.g2d + G2_F * NS, gb);
 		const MetCol mc = met_col(p, col);
@@ -121,8 +142,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			w_hi = dt * fabs(xhi); w_lo = dt * fabs(xlo);
 		}
 	}
+	if (TMX_H_BURST) { bU = lin_reduce<NT, PM>(xbase, xU); bV = lin_reduce<NT, PM>(xbase, xV); }
 	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
-	const double exn = act ? exner_from_rhotheta(p, rt) : 0.0;
+	if (TMX_H_EXNER_LDS) __syncthreads();      // the tables are in LDS (every thread's loads are in flight by now)
+	const double exn = act ? (TMX_H_EXNER_LDS ? exner_from_rhotheta_lds(p, rt, rmtab) : exner_from_rhotheta(p, rt)) : 0.0;
 	const double fa = jn * conUa, fb = jn * conUb;
 	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
 	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
@@ -145,6 +168,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		dbrf = -MFMA4(tr(fb * rh), cS); dbpf = -MFMA4(tr(fb * rt), cS);
 #undef MFMA4
 		if (!act) return;
+		if (TMX_H_BURST) {
+			const unsigned cb2 = (unsigned)uc * 8u;
+			lin_load<NT, PM>(xbase.src, TMX_SLAB_T(L, k) * SS, cb2, xT); lin_load<NT, PM>(xbase.src, TMX_SLAB_R(L, k) * SS, cb2, xR);
+		}
 	} else {
 	s[ty][0][lane] = ua;  s[ty][1][lane] = ub;  s[ty][2][lane] = ux;
 	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
@@ -155,6 +182,11 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 #ifdef TMX_H_SCHED_BARRIER
 	__builtin_amdgcn_sched_barrier(0);
 #endif
+	if (TMX_H_BURST) {
+		const unsigned cb2 = (unsigned)uc * 8u;
+		lin_load<NT, PM>(xbase.src, TMX_SLAB_T(L, k) * SS, cb2, xT); lin_load<NT, PM>(xbase.src, TMX_SLAB_R(L, k) * SS, cb2, xR);
+		if (TMX_H_FUSE_W && ty > 0) lin_load<NT, PM>(xbase.src, TMX_SLAB_W(L, k) * SS, cb2, xW);
+	}
 
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
 #pragma unroll
@@ -226,6 +258,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_ubm; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ub;
 			outV += b * w_lo;
 		}
+	}
+	if (TMX_H_BURST) {
+		bT = lin_reduce<NT, PM>(xbase, xT); bR = lin_reduce<NT, PM>(xbase, xR);
+		if (TMX_H_FUSE_W && !MF && ty > 0) bW = lin_reduce<NT, PM>(xbase, xW);
 	}
 	const double outR = bR - dt * invJ * (darf + dbrf), outT = bT - dt * invJ * (dapf + dbpf);
 	if (!UQ) {
@@ -337,12 +373,15 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off
 	dim3 blk2(64, 4), grd2 = wg_grid(uq, q, ntile, nyb2);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
+	// PM_: does the update instance enter its own combination?  (no combination: irrelevant, one instantiation)
+#define LAUNCH_HV2(NT_, PM_) do { \
+		if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true, PM_>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); } while (0)
 #define LAUNCH_HV(NT_) do { \
-		if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
+		if (NT_ == 0 || premul) LAUNCH_HV2(NT_, true); else LAUNCH_HV2(NT_, false); \
 		if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); \
 		else hipLaunchKernelGGL((k_h_w_update<NT_, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
 	switch (nterms) {
@@ -357,6 +396,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 		default: LAUNCH_HV(12); break;      // entries beyond n carry coefficient 0 and a valid pointer (see below)
 	}
 #undef LAUNCH_HV
+#undef LAUNCH_HV2
 }
 
 // HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
