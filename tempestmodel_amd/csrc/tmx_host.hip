@@ -2662,6 +2662,21 @@ static double * uinst(tmx_engine * e, int ix) { return e->u.d_ustate + (size_t)e
 // where a kernel that reads instance ix while producing it must write: the spare slot; u_adopt_spare makes it the instance's afterwards
 static double * uspare(tmx_engine * e) { return e->u.d_ustate + (size_t)e->u.uspare * e->u.ustride; }
 static void u_adopt_spare(tmx_engine * e, int ix) { std::swap(e->u.uslot[ix], e->u.uspare); }
+// U,V slabs of an instance: its own slot, or the slot of the instance it shares them with (tmx_engine::uvmap, the rules of the
+// element-major programs: the Copy in front of the column solve leaves the copy's U,V identical to the source's)
+static const double * uinst_uv(tmx_engine * e, int ix) { return uinst(e, e->uvmap[ix]); }
+// instance ix is about to be read through ONE pointer (or updated in place): give it its own U,V slabs
+static int u_own_uv(tmx_engine * e, int ix, bool total = false) {
+	if (e->uvmap[ix] == ix) return TMX_OK;
+	if (!total) {
+		ProfScope ps(e, TMX_K_LINCOMB);
+		HIPCHK(hipMemcpyAsync(uinst(e, ix), uinst_uv(e, ix), (size_t)2 * e->L * e->u.NUS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	}
+	e->uvmap[ix] = ix; e->n_uvshared--;
+	return TMX_OK;
+}
+// instance x has been rewritten: whoever read its U,V slabs is dead by share_is_safe
+static void u_written(tmx_engine * e, int x) { if (e->n_uvshared) drop_readers(e, x); }
 
 // what the U interpreter does with operation i: 0 = not representable, else the number of operations it consumes
 static int unique_unit(const Program & p, size_t i) {
@@ -2724,27 +2739,33 @@ template <class F> static int u_produce_and_average(tmx_engine * e, int ix, int 
 // [Copy(ibase -> iupd) | LinearCombine(lc -> iupd)]; H.StepExplicit(iinit, iupd); V.StepExplicit(iinit, iupd); DSS(iupd)
 static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
 	const double * src[12]; double cf[12]; int premul = 0, n = 0;
+	const double * srcuv[12];
 	if (lc) {
-		n = 1; src[0] = uinst(e, iupd); cf[0] = lc[iupd];
+		premul = (lc[iupd] != 0.0) ? 1 : 0;
+		n = 1; src[0] = uinst(e, iupd); srcuv[0] = uinst_uv(e, iupd); cf[0] = lc[iupd];
 		for (int m = 0; m < nlc; m++) {
 			if (m == iupd || lc[m] == 0.0) continue;
 			REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
-			src[n] = uinst(e, m); cf[n] = lc[m]; n++;
+			src[n] = uinst(e, m); srcuv[n] = uinst_uv(e, m); cf[n] = lc[m]; n++;
 		}
-		premul = (lc[iupd] != 0.0) ? 1 : 0;
 	}
+	const double * xin_uv = uinst_uv(e, iinit), * base_uv = uinst_uv(e, ibase);      // (taken before the update instance changes slots)
 	// the update instance is also read (in-place accumulation, or its own coefficient in the combination is not zero): the
 	// element-major kernels read and write a thread's own column, here other elements' threads read the node too -- write the
 	// spare slot and let it become the instance's
 	const bool aliased = lc ? (premul != 0) : (ibase == iupd);
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	double * out = aliased ? uspare(e) : uinst(e, iupd);
-	if (aliased) u_adopt_spare(e, iupd);      // (src[] and uinst(ibase) were taken before: they still name the old slot)
-	const double * base = lc ? nullptr : ((ibase == iupd && aliased) ? uspare(e) : uinst(e, ibase));
+	const double * base = lc ? nullptr : uinst(e, ibase), * xin = uinst(e, iinit);
+	// the stage writes every slab of the update instance: its U,V slabs are its own from here on (what it shared is read through
+	// the pointers taken above), and whoever shared ITS slabs is dead
+	if (e->uvmap[iupd] != iupd) { e->uvmap[iupd] = iupd; e->n_uvshared--; }
+	if (aliased) u_adopt_spare(e, iupd);      // (src[], base and the U,V pointers were taken before: they still name the old slots)
 	int r = u_produce_and_average(e, iupd, TMX_K_H_EXPLICIT, [&](const KParams & p) {
-		if (n > 0) tmxk_h_explicit(e, p, uinst(e, iinit), out, out, dt, 1, n, src, cf, premul);
-		else tmxk_h_explicit(e, p, uinst(e, iinit), base, out, dt, 1);
+		if (n > 0) tmxk_h_explicit(e, p, xin, out, out, dt, 1, n, src, cf, premul, xin_uv, nullptr, srcuv);
+		else tmxk_h_explicit(e, p, xin, base, out, dt, 1, 0, nullptr, nullptr, 0, xin_uv, base_uv, nullptr);
 	});
+	u_written(e, iupd);
 	if (r) return r;
 	if (lc) {
 		const double * dsrc[12];      // the surface slots live with the element-major slots
@@ -2757,20 +2778,35 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 
 static int u_copy(tmx_engine * e, int a, int b, size_t doubles) {
 	if (a == b) return TMX_OK;
-	ProfScope ps(e, TMX_K_LINCOMB);
-	HIPCHK(hipMemcpyAsync(uinst(e, b), uinst(e, a), doubles * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	int r;
+	if ((r = u_own_uv(e, a)) || (r = u_own_uv(e, b, true))) return r;
+	{
+		ProfScope ps(e, TMX_K_LINCOMB);
+		HIPCHK(hipMemcpyAsync(uinst(e, b), uinst(e, a), doubles * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	}
+	u_written(e, b);
 	return surface_copy(e, a, b);
 }
 
 // [Copy(a -> b);] V.StepImplicit(b, b): the solve rewrites rho*theta, W, rho of every column, so only the U,V slabs are copied
-static int u_vimp(tmx_engine * e, int a, int b, double dt) {
+// share: b's U,V slabs are not copied, b reads a's (decided on the program by share_is_safe, as in the element-major interpreter)
+static int u_vimp(tmx_engine * e, int a, int b, double dt, bool share) {
 	REQUIRE(dt != 0.0, TMX_ERR_INVALID, "StepImplicit: dt must be non-zero");
 	int r;
-	if (a != b && (r = u_copy(e, a, b, (size_t)2 * e->L * e->u.NUS))) return r;
-	ProfScope ps(e, TMX_K_VI_SOLVE);
-	e->vi_unique = true;
-	tmxk_vi_fused(e, tmxu_params_columns(e, make_params(e)), uinst(e, a), uinst(e, b), dt);
-	e->vi_unique = false;
+	if ((r = u_own_uv(e, a))) return r;      // the column kernel reads U,V of the initial instance through its one pointer
+	if (a != b) {
+		if (share) {
+			if ((r = u_own_uv(e, b, true)) || (r = surface_copy(e, a, b))) return r;
+		} else if ((r = u_copy(e, a, b, (size_t)2 * e->L * e->u.NUS))) return r;
+	}
+	{
+		ProfScope ps(e, TMX_K_VI_SOLVE);
+		e->vi_unique = true;
+		tmxk_vi_fused(e, tmxu_params_columns(e, make_params(e)), uinst(e, a), uinst(e, b), dt);
+		e->vi_unique = false;
+	}
+	u_written(e, b);
+	if (a != b && share) { e->uvmap[b] = a; e->n_uvshared++; }
 	return launch_check("column solve (node-unique layout)");
 }
 
@@ -2778,9 +2814,12 @@ static int u_vimp(tmx_engine * e, int a, int b, double dt) {
 static int u_dss(tmx_engine * e, int ix) {
 	bool overlapped = false;
 	int r;
+	if ((r = u_own_uv(e, ix))) return r;
 	{ ProfScope ps(e, TMX_K_DSS); tmxuk_slots_from_u(e, uinst(e, ix)); }
 	if ((r = exchange(e, tmxu_params(e, make_params(e)), nullptr, &overlapped))) return r;
-	return u_dss_finish(e, ix, overlapped);
+	r = u_dss_finish(e, ix, overlapped);
+	u_written(e, ix);
+	return r;
 }
 
 // HorizontalDynamicsFEM::StepAfterSubCycle (h_step_after_subcycle_impl above, same branches)
@@ -2789,6 +2828,10 @@ static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
 	int r;
 	REQUIRE(iinit != iwork && iupd != iwork && iinit != iupd, TMX_ERR_UNSUPPORTED, "StepAfterSubCycle on the node-unique layout needs three distinct instances");
 	if (!hypervis_active(e)) return u_copy(e, iinit, iupd, e->u.ustride);
+	// the passes read their source through one pointer and rewrite update and (two passes) working instance entirely
+	if ((r = u_own_uv(e, iinit)) || (r = u_own_uv(e, iupd, true))) return r;
+	if (c.hypervis_order != 2 && (r = u_own_uv(e, iwork, true))) return r;
+	struct Written { tmx_engine * e; int a, b; ~Written() { u_written(e, a); if (b >= 0) u_written(e, b); } } written = { e, iupd, c.hypervis_order != 2 ? iwork : -1 };
 	if (c.hypervis_order == 2) {
 		if ((r = surface_copy(e, iinit, iupd))) return r;
 		return u_produce_and_average(e, iupd, TMX_K_HYPERVIS, [&](const KParams & p) {
@@ -2804,6 +2847,9 @@ static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
 
 static int run_program_unique(tmx_engine * e, const Program & p) {
 	int r;
+	// U,V slabs still shared from the previous step: kept where this program allows it
+	for (int b = 0; b < (int)e->uvmap.size() && e->n_uvshared; b++)
+		if (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b, false) && (r = u_own_uv(e, b))) return r;
 	for (size_t i = 0; i < p.size(); ) {
 		const Op & o = p[i];
 		const int k = unique_unit(p, i);
@@ -2814,7 +2860,8 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 				size_t j = i + 1;      // Copy(s -> t) [repeated] + V.StepImplicit(t, t)
 				while (j < p.size() && p[j].kind == OP_COPY && p[j].a == o.a && p[j].b == o.b) j++;
 				if (j < p.size() && p[j].kind == OP_VIMP && p[j].a == o.b && p[j].b == o.b && o.a != o.b) {
-					if ((r = u_vimp(e, o.a, o.b, p[j].coef))) return r;
+					const bool share = e->share_copies && e->uvmap[o.a] == o.a && share_is_safe(p, j + 1, o.a, o.b, false);
+					if ((r = u_vimp(e, o.a, o.b, p[j].coef, share))) return r;
 					i = j + 1; continue;
 				}
 			}
@@ -2826,6 +2873,8 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 			if (k == 4) { if ((r = u_stage(e, p[i + 1].a, o.a, o.a, p[i + 1].coef, o.lc, o.nlc))) return r; break; }
 			{
 				const double * src[12], * dsrc[12]; double cf[12];
+				if ((r = u_own_uv(e, o.a, o.lc[o.a] == 0.0))) return r;
+				for (int m = 0; m < o.nlc; m++) if (m != o.a && o.lc[m] != 0.0 && (r = u_own_uv(e, m))) return r;      // (whole-instance pass: one pointer per source)
 				int n = 1; src[0] = uinst(e, o.a); dsrc[0] = inst(e, o.a); cf[0] = o.lc[o.a];
 				for (int m = 0; m < o.nlc; m++) {
 					if (m == o.a || o.lc[m] == 0.0) continue;
@@ -2834,11 +2883,12 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 				}
 				const int premul = o.lc[o.a] != 0.0 ? 1 : 0;
 				{ ProfScope ps(e, TMX_K_LINCOMB); tmxk_lincomb(e, e->u.ustride, uinst(e, o.a), n, src, cf, premul); }
+				u_written(e, o.a);
 				if ((r = surface_lincomb(e, o.a, n, dsrc, cf, premul)) || (r = launch_check("lincomb"))) return r;
 			}
 			break;
 		case OP_HEXP: if ((r = u_stage(e, o.a, o.b, o.b, o.coef, nullptr, 0))) return r; break;
-		case OP_VIMP: if ((r = u_vimp(e, o.a, o.b, o.coef))) return r; break;
+		case OP_VIMP: if ((r = u_vimp(e, o.a, o.b, o.coef, false))) return r; break;
 		case OP_DSS: if ((r = u_dss(e, o.a))) return r; break;
 		case OP_HVIS: if ((r = u_hvis(e, o.a, o.b, o.c, o.coef))) return r; break;
 		case OP_VFILT: break;      // nothing without tracers
@@ -2857,8 +2907,6 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	UniqueLayout & u = e->u;
 	if (!u.built || false || !program_fits_unique(p)) return TMX_OK;
 	int r;
-	// instance maps to identity (the U interpreter does not share slots), with the slots still in their current form
-	if (e->n_shared || e->n_uvshared) { if ((r = settle_instance(e, -1))) return r; }
 	unsigned written = 0u, livein = 0u;
 	const bool noop = false;
 	g_hvis_two_pass = hypervis_active(e) && e->cfg.hypervis_order != 2;
@@ -2868,12 +2916,30 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 		livein |= x.part & ~written;
 		written |= x.full | x.part;
 	}
-	for (int k = 0; k < e->cfg.n_instances; k++) {
+	bool need_check = false;
+	for (int k = 0; k < e->cfg.n_instances; k++) if ((livein >> k & 1u) && !u.form[k]) need_check = true;
+	if (need_check && u.skip_steps > 0) { u.skip_steps--; return TMX_OK; }      // the last checks failed: not every step pays for another one
+	// (timing aid TMX_DEBUG_SKIP_EXCHANGE: the state of such a run is garbage at the rank boundary, NaN payloads included; no check)
+	static const bool trust = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
+	// the check comes first and works on the slots as the element-major programs left them (shared slots included: an instance
+	// that shares is given its own first, which for the model state never happens), so that a step that stays element-major keeps them
+	for (int k = 0; k < e->cfg.n_instances && !trust; k++) {
 		if (!(livein >> k & 1u) || u.form[k]) continue;
+		if ((e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k))) return r;
 		bool ok = true;
-		if ((r = tmxu_to_u(e, k, true, &ok))) return r;
-		if (!ok) return TMX_OK;      // copies differ: this step runs element-major (settle_instance converts what is in U form)
+		if ((r = tmxu_check(e, k, &ok))) return r;
+		if (!ok) {      // copies differ: this step runs element-major
+			// (a single failure -- the pointwise initial state of a run -- costs nothing further; from the second in a row on, 4, 8, ... 1024 steps pass before the next try)
+			u.backoff++;
+			u.skip_steps = (u.backoff >= 2) ? std::min(4 << std::min(u.backoff - 2, 8), 1024) : 0;
+			return TMX_OK;
+		}
 	}
+	u.backoff = 0;
+	// instance maps to identity (shares left by an element-major program, that is: nothing is in U form; U,V slabs shared by the last node-unique step stay shared)
+	if ((e->n_shared || e->n_uvshared) && u.n_uform == 0) { if ((r = settle_instance(e, -1))) return r; }
+	for (int k = 0; k < e->cfg.n_instances; k++)
+		if ((livein >> k & 1u) && !u.form[k] && (r = tmxu_to_u(e, k, false, nullptr))) return r;
 	// everything the program writes is in U form afterwards; whatever else it leaves alone keeps its form
 	for (int k = 0; k < e->cfg.n_instances; k++)
 		if ((written >> k & 1u) && !u.form[k]) { u.form[k] = 1; u.n_uform++; }
@@ -2927,7 +2993,9 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	if (e->u.built) {
 		bool done = false;
 		if ((r = try_step_unique(e, p, &done)) || done) return r;
-		if ((r = settle_instance(e, -1))) return r;      // element-major step: nothing stays in U form
+		// element-major step: nothing stays in U form (the shared slots of the element-major programs are left as they are)
+		if (e->u.n_uform)
+			for (int b = 0; b < (int)e->u.form.size(); b++) if (e->u.form[b] && (r = tmxu_to_d(e, b))) return r;
 	}
 	return run_program(e, p);
 }

@@ -124,6 +124,10 @@ struct UniqueLayout {
 	std::vector<int> uslot; int uspare = 0;
 	int n_uform = 0;
 	long long conversions = 0;               // D <-> U conversions performed (tmx_info)
+	// an input whose copies differ makes the step run element-major; when that keeps happening (column physics between the steps
+	// that treats the copies of a node differently in the last bit, as the reference's does) the check itself -- a pass over the
+	// instance and a host synchronisation -- is not repeated every step: from the second failure in a row on, the next `skip_steps` steps do not try
+	int backoff = 0, skip_steps = 0;      // backoff: failures in a row
 };
 
 struct tmx_engine {
@@ -275,6 +279,7 @@ void tmxu_free(tmx_engine * e);
 KParams tmxu_params(const tmx_engine * e, const KParams & base);          // thread space T, state in U slabs
 KParams tmxu_params_columns(const tmx_engine * e, const KParams & base);  // one thread per unique column (column solve)
 int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent);   // D form -> U form of one slot (check: verify that the copies agree)
+int tmxu_check(tmx_engine * e, int slot, bool * consistent);              // do the copies of every node of an element-major slot agree?
 int tmxu_to_d(tmx_engine * e, int slot);                                  // U form -> D form
 void tmxuk_slots_from_u(tmx_engine * e, const double * xu);               // partial slots <- the values of their nodes (DSS of an instance that is already consistent inside patches)
 void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1);              // finish the seam nodes left in the partial slots

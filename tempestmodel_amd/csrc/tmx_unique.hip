@@ -262,6 +262,21 @@ __global__ __launch_bounds__(256) void k_u_to_d(int nslab, size_t NS, size_t NUS
 	for (int s = blockIdx.y; s < nslab; s += gridDim.y) xd[(size_t)s * NS + c] = xu[(size_t)s * NUS + uu];
 }
 
+// do the copies of every node of this element-major slot agree, bit for bit?  (one pass over the slot and a host synchronisation)
+int tmxu_check(tmx_engine * e, int slot, bool * consistent) {
+	UniqueLayout & u = e->u;
+	const double * xd = e->d_state + (size_t)slot * e->inst_stride;
+	const int ny = std::min(e->nslab, 64);
+	HIPCHK(hipMemsetAsync(u.d_check, 0, sizeof(int), e->stream));
+	hipLaunchKernelGGL(k_check_copies, dim3((e->ncol + 255) / 256, ny), dim3(256), 0, e->stream, e->nslab, (size_t)e->NS, e->ncol, xd,
+		(const int *)u.d_ucol_of_dcol, (const int *)u.d_u_rep, u.d_check);
+	int h = 0;
+	HIPCHK(hipMemcpyAsync(&h, u.d_check, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	*consistent = (h == 0);
+	return TMX_OK;
+}
+
 int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent) {
 	UniqueLayout & u = e->u;
 	if (consistent) *consistent = true;
@@ -270,13 +285,10 @@ int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent) {
 	double * xu = u.d_ustate + (size_t)u.uslot[slot] * u.ustride;
 	const int ny = std::min(e->nslab, 64);
 	if (check) {
-		HIPCHK(hipMemsetAsync(u.d_check, 0, sizeof(int), e->stream));
-		hipLaunchKernelGGL(k_check_copies, dim3((e->ncol + 255) / 256, ny), dim3(256), 0, e->stream, e->nslab, (size_t)e->NS, e->ncol, xd,
-			(const int *)u.d_ucol_of_dcol, (const int *)u.d_u_rep, u.d_check);
-		int h = 0;
-		HIPCHK(hipMemcpyAsync(&h, u.d_check, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipStreamSynchronize(e->stream));
-		if (h) { if (consistent) *consistent = false; return TMX_OK; }
+		bool ok = true;
+		int r = tmxu_check(e, slot, &ok);
+		if (r) return r;
+		if (!ok) { if (consistent) *consistent = false; return TMX_OK; }
 	}
 	hipLaunchKernelGGL(k_d_to_u, dim3((u.NU + 255) / 256, ny), dim3(256), 0, e->stream, e->nslab, (size_t)e->NS, (size_t)u.NUS, u.NU, xd, xu, (const int *)u.d_u_rep);
 	u.form[slot] = 1; u.n_uform++; u.conversions++;
