@@ -59,9 +59,9 @@ OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)",
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r03" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic_ne30_L30_n1.json")) else "r02"
+PROFILE_TAG = next((t for t in ("r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
-OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss"],
+OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss", "k_dss_u"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
 
 
@@ -70,10 +70,13 @@ def measured_traffic(op, ne, L, world, launches_per_step):
     separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  One table per
     workload shape, profiles/r02_pmc_traffic_ne<ne>_L<L>_n<ranks>.json (n > 1: the share of rank 0, taken with a lone
     rank-0 engine of the n-rank layout, tools/rank_share_timing.py); a shape without a table -> None."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_ne%d_L%d_n%d.json" % (ne, L, world))
-    if not os.path.exists(path):
+    path = None
+    for t in ("r04", "r03", "r02"):      # (the newest table of the shape; r04 on: the node-unique layout, the default)
+        c = os.path.join(ROOT, "profiles", "%s_pmc_traffic_ne%d_L%d_n%d.json" % (t, ne, L, world))
+        if os.path.exists(c):
+            path = c
+            break
+    if path is None:
         return None
     try:
         tab = json.load(open(path))
@@ -124,12 +127,14 @@ def dominant_kernel_from_stats(ne, L, world):
     if not path:
         return None
     try:
-        rows = list(csv.DictReader(open(path)))
+        def base_of(r):
+            return r["Name"].replace("void ", "").split("<")[0].split("(")[0]
+        known = {n for names in OP_ROCPROF.values() for n in names}
+        rows = [r for r in csv.DictReader(open(path)) if base_of(r) in known]      # the step's kernels (not the memsets / copies of the set-up)
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-        base = top["Name"].replace("void ", "").split("<")[0].split("(")[0]
         for op, names in OP_ROCPROF.items():
-            if base in names:
+            if base_of(top) in names:
                 return op, top["Name"].split("(")[0], float(top["TotalDurationNs"]) / tot, os.path.relpath(path, ROOT)
     except Exception:
         pass

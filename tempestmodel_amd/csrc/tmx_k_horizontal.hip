@@ -69,8 +69,6 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	const int uc = UQ ? tile_ucol(p, tile, lane) : col;
 	const size_t SS = UQ ? (size_t)p.NSS : NS;
 	const bool act = (k < L) && (UQ ? (uc >= 0) : (col < p.ncol));
-	// what the thread does with its results (seam_store): loaded here, with everything else, used at the end
-	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 
 	double ua = 0, ub = 0, rt = 1, rh = 1, ux = 0;
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, jn = 1, j2d = 0, fcor = 0, ca2 = 0, cb2 = 0, cx2 = 0, dra = 0, drb = 0;
@@ -149,6 +147,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	const double fa = jn * conUa, fb = jn * conUb;
 	double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
 	double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+	int sdst = 0, sred = 0;
 	if (MF) {
 		// operator entries of this lane: D[k][m] and S[m][k] with m = lane & 3, k = lane >> 4 (A of the alpha contraction
 		// d/d_alpha f (i,j) = sum_t D[t][i] f(t,j), B of the beta contraction d/d_beta f (i,j) = sum_t f(i,t) D[t][j])
@@ -182,6 +181,9 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 #ifdef TMX_H_SCHED_BARRIER
 	__builtin_amdgcn_sched_barrier(0);
 #endif
+	// what the thread does with its results (seam_store): loaded behind the barrier, when the registers of the prologue are free
+	// again (in front of it they cost the first stage's kernel its fourth wavefront per SIMD), used at the end
+	if (UQ) { sdst = p.t_sdst[col]; sred = p.t_sred[col]; }
 	if (TMX_H_BURST) {
 		const unsigned cb2 = (unsigned)uc * 8u;
 		lin_load<NT, PM>(xbase.src, TMX_SLAB_T(L, k) * SS, cb2, xT); lin_load<NT, PM>(xbase.src, TMX_SLAB_R(L, k) * SS, cb2, xR);
@@ -744,8 +746,13 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 
 // UQ: node-unique state layout (tmx_device.h, seam_store): operands gathered from the unique slabs, results averaged over the
 // seams inside the wavefront or handed to the partial slots
+// Registers: 131-133 left to itself (three workgroups per CU).  Held to 128 = four per CU the node-unique form gains 6 % (139 against
+// 147 us per step, 20 bytes of scratch); the element-major form loses 12 % that way (148 against 132 us) and keeps its three.
+#ifndef TMX_HV_MINWG
+#define TMX_HV_MINWG 1
+#endif
 template <bool PULL, bool UQ>
-__global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __restrict__ xsrc,
+__global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) void k_hypervis(KParams p, const double * __restrict__ xsrc,
 	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
 	__shared__ double s[4][8][64];
@@ -761,7 +768,6 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	const int col = tile * 64 + lane;                                 // the thread's own column: geometry, LDS
 	const int kk = yb * 4 + ty;
 	const int uc = UQ ? tile_ucol(p, tile, lane) : col;               // where its node's state lives
-	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 	const size_t SS = UQ ? (size_t)p.NSS : NS;                        // state slab stride
 	const bool here = UQ ? (uc >= 0) : (col < p.ncol);
 	const bool actw = (kk <= L) && here;     // interface level (W)
@@ -829,6 +835,8 @@ __global__ __launch_bounds__(256) void k_hypervis(KParams p, const double * __re
 	daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
 	const double invJ2 = 1.0 / j2d;
 	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+	// what the thread does with its results (seam_store): loaded here, behind the first contraction, used at the end
+	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 	__syncthreads();
 	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
 	s[ty][2][lane] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lane] = jn * (c2a1 * daR + c2b1 * dbR);

@@ -9,15 +9,25 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0"
+# PASSES="trace fetch write ..." restricts the run to the named passes (default: all).  Every pass runs under `timeout`: a counter
+# request the hardware cannot serve makes rocprofv3 abort and then hang on its incomplete dispatch.
 one() {   # name, rocprof args..., -- program
 	local name=$1; shift
-	rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"
+	if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi
+	timeout ${PASS_TIMEOUT:-600} rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"
 }
 one trace --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- python3 $B
 one fetch --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $B
 one write --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o ${TAG} -- python3 $B
 one valu --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/${TAG}_valu -o ${TAG} -- python3 $B
 one mfma0 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma0 -o ${TAG} -- python3 $B
+# the element-major layout (TMX_UNIQUE=0) beside the default node-unique one
+export TMX_UNIQUE=0
+one trace_d --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_d -o ${TAG} -- python3 $B
+one fetch_d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_d -o ${TAG} -- python3 $B
+one write_d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_d -o ${TAG} -- python3 $B
+unset TMX_UNIQUE
+one l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/${TAG}_l2 -o ${TAG} -- python3 $B
 export TMX_MFMA=1
 one mfma1 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma1 -o ${TAG} -- python3 $B
 one trace_mfma1 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_mfma1 -o ${TAG} -- python3 $B

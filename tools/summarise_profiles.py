@@ -28,13 +28,14 @@ def stats(name):
     return list(csv.DictReader(open(path))) if os.path.exists(path) else []
 
 
-for src, dst in (("trace", "kernel_stats"), ("trace_mfma1", "kernel_stats_mfma1"), ("trace_ne15", "kernel_stats_ne15"),
+for src, dst in (("trace", "kernel_stats"), ("trace_d", "kernel_stats_element_major"), ("trace_mfma1", "kernel_stats_mfma1"), ("trace_ne15", "kernel_stats_ne15"),
                  ("trace_n8", "kernel_stats_rank0_of_8"), ("trace_c4", "kernel_stats_config4_ne30_L40"), ("trace_c5", "kernel_stats_config5_ne120_L60")):
     f = os.path.join(G, "%s_%s" % (tag, src), "%s_kernel_stats.csv" % tag)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.csv" % (tag, dst)))
 
 for fe, wr, out, what, steps in (("fetch", "write", "ne30_L30_n1", "ne30 np4 L30, 1 GPU", 15),
+                                 ("fetch_d", "write_d", "ne30_L30_n1_element_major", "ne30 np4 L30, 1 GPU, TMX_UNIQUE=0 (element-major layout)", 15),
                                  ("fetch_ne15", "write_ne15", "ne15_L30_n1", "ne15 np4 L30 (--ne 15 --ppd 1), 1 GPU", 15),
                                  ("fetch_n8", "write_n8", "ne30_L30_n8", "ne30 np4 L30, share of rank 0 of 8 (tools/rank_share_timing.py 8: "
                                   "lone rank-0 engine of the 8-rank layout, wire left out)", 33),
