@@ -331,6 +331,15 @@ __device__ __forceinline__ void v_explicit_point(const KParams & p, const double
 }
 
 
+// Ordering point for LDS rows that only ONE wavefront touches (the contraction rows s[ty][..] of the horizontal kernels, each
+// wavefront's copy of the 4 x 4 operator tables): the LDS executes a wavefront's operations in order, so lanes see one another's
+// writes without a workgroup barrier; the fences keep the compiler from moving reads above the writes they depend on.
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // workgroup -> (entry of the launch's tile list, level block).  Element-major kernels: the plain 2-D launch.  Node-unique kernels
 // (UQ): a 1-D launch unfolded so that every XCD sweeps a contiguous range of tiles, level block by level block -- neighbouring
 // tiles read the same rows of the unique slabs (the nodes on their common edge), which then come from that XCD's L2.

@@ -51,11 +51,12 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
 {
 	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
-	__shared__ double sD[16], sS[16];
+	__shared__ double sDw[MF ? 1 : KT_H][16], sSw[MF ? 1 : KT_H][16];      // every wavefront its own copy of the operator tables (no workgroup barrier before the contractions)
 	__shared__ double rmtab[TMX_H_EXNER_LDS ? TMX_RMTAB_DOUBLES : 1];      // exp / log tables of the Exner function: from global memory they are two dependent gathers per wavefront
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
-	if (!MF && tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	if (!MF && lane < 16) { sDw[ty][lane] = p.dx[lane]; sSw[ty][lane] = p.stiff[lane]; }
+	const double * sD = sDw[MF ? 0 : ty], * sS = sSw[MF ? 0 : ty];
 	if (TMX_H_EXNER_LDS) tmx_rm_tables_to_lds(rmtab, tid, 64 * KT_H);
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
 	s[ty][5][lane] = fa * rh; s[ty][6][lane] = fa * rt;
 	s[ty][7][lane] = fb * rh; s[ty][8][lane] = fb * rt;
-	__syncthreads();
+	wave_sync();      // the rows are this wavefront's own
 	if (!act) return;
 #ifdef TMX_H_SCHED_BARRIER
 	__builtin_amdgcn_sched_barrier(0);
@@ -755,11 +756,13 @@ template <bool PULL, bool UQ>
 __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) void k_hypervis(KParams p, const double * __restrict__ xsrc,
 	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
+	// every LDS row here belongs to one wavefront (its level's fields, its own copy of the operator tables): the kernel has no
+	// workgroup barrier, the four wavefronts of a workgroup run decoupled (wave_sync)
 	__shared__ double s[4][8][64];
-	__shared__ double sD[16], sS[16];
+	__shared__ double sDw[4][16], sSw[4][16];
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
-	const int tid = ty * 64 + lane;
-	if (tid < 16) { sD[tid] = p.dx[tid]; sS[tid] = p.stiff[tid]; }
+	if (lane < 16) { sDw[ty][lane] = p.dx[lane]; sSw[ty][lane] = p.stiff[lane]; }
+	const double * sD = sDw[ty], * sS = sSw[ty];
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int tix, yb;
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	s[ty][0][lane] = psiT; s[ty][1][lane] = psiR; s[ty][2][lane] = psiW;
 	s[ty][3][lane] = ua;   s[ty][4][lane] = ub;
 	s[ty][5][lane] = j2d * cua; s[ty][6][lane] = j2d * cub;
-	__syncthreads();
+	wave_sync();
 
 	double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
 #pragma unroll
@@ -837,12 +840,12 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
 	// what the thread does with its results (seam_store): loaded here, behind the first contraction, used at the end
 	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
-	__syncthreads();
+	wave_sync();
 	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
 	s[ty][2][lane] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lane] = jn * (c2a1 * daR + c2b1 * dbR);
 	s[ty][4][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lane] = je * (c2a1 * daW + c2b1 * dbW);
 	s[ty][6][lane] = dv; s[ty][7][lane] = cl;
-	__syncthreads();
+	wave_sync();
 	if (!actw) return;
 
 	double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
