@@ -80,6 +80,16 @@ public:
 	void SetHostSyncInterval(int nSteps) { m_nHostSyncInterval = (nSteps < 1) ? 1 : nSteps; }
 	int GetHostSyncInterval() const { return m_nHostSyncInterval; }
 
+	///	Engine option by name (tmx_set_option, include/tempest_mi355x.h): recorded here, applied before tmx_finalize.  The
+	///	engine reads no environment variable on its own; what a run used can be printed with tmx_options_report.
+	void SetOption(const std::string & strName, double dValue) {
+		if (m_pEngine != NULL) {
+			Check(tmx_set_option(m_pEngine, strName.c_str(), dValue));
+		} else {
+			m_vecOptions.push_back(std::pair<std::string, double>(strName, dValue));
+		}
+	}
+
 	///	Instances whose content survives from one Step to the next: instance 0, plus instance 1 for the Strang stepper
 	///	(its carry-over, TimestepSchemeStrang.cpp:639-657).  They move together between host and device.
 	void SetCarriedInstances(int nInstances) { m_nCarried = (nInstances < 1) ? 1 : nInstances; }
@@ -480,6 +490,9 @@ private:
 					&(pGrid->GetREtaLevels()[0]), &(pGrid->GetREtaInterfaces()[0])));
 			}
 		}
+		for (size_t o = 0; o < m_vecOptions.size(); o++) {
+			Check(tmx_set_option(m_pEngine, m_vecOptions[o].first.c_str(), m_vecOptions[o].second));
+		}
 		Check(tmx_finalize(m_pEngine));
 
 		// reference state the uniform diffusion is taken relative to (Grid::HasUniformDiffusion)
@@ -559,6 +572,7 @@ private:
 	Model & m_model;
 	tmx_engine * m_pEngine;
 	bool m_fPeerToPeer;
+	std::vector< std::pair<std::string, double> > m_vecOptions;
 	double m_dNuScalar, m_dNuDiv, m_dNuVort;
 	int m_nHypervisOrder;
 	bool m_fFullyExplicit;

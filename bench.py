@@ -97,7 +97,7 @@ def latest_profile(suffix):
     return c[-1] if c else None
 
 
-def mfma_report():
+def mfma_report(on=False):
     """MFMA utilisation of the path that ran (measured offline with rocprofv3 counters) and the A/B of the opt-in matrix-unit
     contractions against the default LDS + VALU ones: the NEWEST committed profiles/rNN_mfma_ab.json."""
     path = latest_profile("mfma_ab.json")
@@ -107,7 +107,6 @@ def mfma_report():
         ab["source"] = os.path.relpath(path, ROOT)
     except Exception:
         pass
-    on = os.environ.get("TMX_MFMA", "0") not in ("", "0")
     active = 0.0
     if on and ab and "mfma_busy_fraction_of_explicit_kernel" in ab.get("TMX_MFMA=1", {}):
         active = ab["TMX_MFMA=1"]["mfma_busy_fraction_of_explicit_kernel"]
@@ -517,7 +516,7 @@ def main():
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
         if dom == "v_implicit" and eng.info(1) <= 6400:
             kernel_name = "k_vi_group (one column per 16-lane group)"
-        mfma = mfma_report()
+        mfma = mfma_report(eng.get_option("contraction_mfma") != 0)
 
         def per_op(op):
             # algorithmic figure (SURVEY 8d row x points) beside the counter-measured one: the 8d rows are not lower bounds for
@@ -577,6 +576,9 @@ def main():
             "physics_after_every_step": args.physics,
             "state_finite": bool(state_finite),
             "sustained": sustained,
+            # every engine option as this run used it (the library reads no environment variable on its own; what this script's
+            # plumbing took from TMX_* variables is listed under from_environment)
+            "engine_options": eng.options_report(),
         }
         if world > 1:
             send = eng.plan(0).reshape(-1, 4)

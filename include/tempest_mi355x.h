@@ -406,7 +406,9 @@ enum {
 };
 long long tmx_info(tmx_engine * e, int what);
 
-/* Options by name: how the engine computes, never what (results are bit-identical under every setting).
+/* Options by name (integers passed as double).  They change HOW the engine computes, never what: results are bit-identical under
+ * every setting, with the one exception "contraction_mfma", whose description says so.  The library reads NO environment variable
+ * on its own -- a stray TMX_* in a job script cannot change a run.  The list (tmx_options_report prints it with the values in use):
  *   "unique_layout"      -1 default (= 1), 0 off, 1 on: hold the state once per patch node inside tmx_step (node-unique slabs: 9/16 of
  *                        the bytes, the DSS reduced to the nodes on tile and patch edges) where every kernel of the configuration
  *                        has that form -- nonhydrostatic set, implicit vertical dynamics, no tracers / uniform diffusion /
@@ -414,9 +416,21 @@ long long tmx_info(tmx_engine * e, int what);
  *                        boundary).  Before tmx_finalize.
  *   "unique_tile_shape"  elements of a wavefront: 0 = the element-major order, 1 x 4 strips along beta that wrap around patch rows
  *                        (default: measured fastest), 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row.  Before tmx_finalize.
- *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize. */
+ *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize.
+ *   "contraction_mfma"   1: the 4 x 4 contractions of the fused explicit kernel as v_mfma_f64_4x4x4 -- NOT bit-exact (1e-15 per call,
+ *                        W 1.5e-10 after 100 steps at ne15 L30: outside the 1e-10 gate) and measured no faster.  Before tmx_finalize.
+ *   "step_graph", "share_copies", "split_stage_off", "exchange_overlap_off", "p2p_timeout_s", "metric_stored", "xcd_vertical",
+ *   "vi_*" (column solve kernel selection), "vt_*", "kessler_column", "hvis_pull", "hvis_block", "tracer_lincomb_pass", "udv_separate",
+ *   "vx_fused": kernel selection / A-B switches, each with a bit-identity test; "debug_skip_exchange": timing aid with WRONG results
+ *   at rank boundaries (tools/rank_share_timing.py only). */
 int tmx_set_option(tmx_engine * e, const char * name, double value);
 int tmx_get_option(tmx_engine * e, const char * name, double * value);
+/* "name=value" lines of every option as in use (defaults included) and, if tmx_options_from_environment applied any, the variables it
+ * took; returns the buffer length needed (buf may be NULL). */
+int tmx_options_report(tmx_engine * e, char * buf, int cap);
+/* Test / bench plumbing only: turn the historical TMX_* environment variables into options (right after tmx_create).  Says what
+ * it applied in ONE line on stderr (silenced by TMX_QUIET) and in tmx_options_report; returns how many.  The adapter does not call it. */
+int tmx_options_from_environment(tmx_engine * e);
 
 /* Host-side DSS / exchange plan, for tests of the multi-rank logic (works on an engine created with
  * cfg.device = -2, "plan only": no HIP call is made and no kernel can be launched).

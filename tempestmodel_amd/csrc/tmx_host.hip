@@ -150,27 +150,10 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	e->imap.resize(cfg->n_instances);
 	for (int k = 0; k < cfg->n_instances; k++) e->imap[k] = k;
 	e->uvmap = e->imap;
-	if (const char * v = getenv("TMX_SHARE_COPIES")) e->share_copies = atoi(v);
-	if (const char * v = getenv("TMX_XCD_VERTICAL")) e->xcd_vertical = atoi(v) ? 1 : 0;
 	if (e->sw) { e->h_ops.assign((size_t)TMX_OP_COUNT * (e->L + 1) * TMX_OPW, 0.0); e->ops_set = true;
 		for (int i = 0; i < 16; i++) { e->h_dx[i] = 0.0; e->h_stiff[i] = 0.0; } }
-	if (const char * m = getenv("TMX_VI_CARRY")) e->vi_carry = (atoi(m) != 0);
-	if (const char * m = getenv("TMX_VI_PAIR")) e->vi_pair = (atoi(m) != 0) ? 1 : 0;
-	if (const char * m = getenv("TMX_MFMA")) e->use_mfma = (atoi(m) != 0);
-	if (const char * m = getenv("TMX_VI_GROUP")) e->vi_group = (atoi(m) != 0) ? 1 : 0;
-	if (const char * m = getenv("TMX_VI_GROUP_MAX")) e->vi_group_max = atoi(m);
-	if (const char * m = getenv("TMX_VI_PAIR_WG")) e->vi_pair_wg = atoi(m);
-	if (const char * m = getenv("TMX_P2P_TIMEOUT_S")) e->p2p_timeout_s = std::max(0, atoi(m));
-	if (const char * m = getenv("TMX_UNIQUE")) e->u.option = atoi(m) ? 1 : 0;
-	if (const char * m = getenv("TMX_UNIQUE_TILE")) e->u.tile_shape = std::min(std::max(atoi(m), 0), 2);
-	if (const char * m = getenv("TMX_UNIQUE_XCD")) e->u.xcd_order = atoi(m) ? 1 : 0;
-	if (const char * m = getenv("TMX_HVIS_PULL")) e->hvis_pull = atoi(m);
-	if (const char * m = getenv("TMX_HVIS_BLOCK")) e->hvis_block = atoi(m);
-	if (const char * m = getenv("TMX_VI_SPLIT_BACK")) e->vi_split_back = atoi(m);
-	if (const char * m = getenv("TMX_VI_BACK_SUB")) e->vi_back_sub = atoi(m);
-	if (const char * m = getenv("TMX_VI_STAGGER_NS")) e->vi_stagger = atoi(m) / 10;
-	if (const char * m = getenv("TMX_GRAPH")) e->use_graph = atoi(m) != 0;
-	if (const char * m = getenv("TMX_VI_MODE")) e->vi_mode = (strcmp(m, "split") == 0) ? 1 : 0;
+	// (no environment variable is read here: options arrive through tmx_set_option, or -- for test and bench plumbing that wants the
+	// old TMX_* variables -- through an explicit tmx_options_from_environment call, which reports what it applied)
 	if (!plan_only(e)) {
 		int ndev = 0;
 		hipError_t r = hipGetDeviceCount(&ndev);
@@ -836,7 +819,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// closed-form 3-D metric only if every owned patch delivered factors that reproduce its arrays exactly
 	e->metric_closed = !e->sw && !e->h_eta.empty();
 	for (int lp : e->local_patches) e->metric_closed = e->metric_closed && e->patches[lp].metric_ok;
-	if (const char * m = getenv("TMX_METRIC")) if (strcmp(m, "stored") == 0) e->metric_closed = false;
+	if (e->opt_metric_stored) e->metric_closed = false;
 	// per-column element spacing and local hyperviscosity scale of the column's patch
 	for (int lp : e->local_patches) {
 		const PatchInfo & P = e->patches[lp];
@@ -915,7 +898,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// tiles first, the pack + grouped send/recv starts on the exchange stream, and the remaining tiles -- three quarters
 	// of a 15 x 15-element patch -- are updated while the wire is busy (hv_stage_split).  TMX_NO_SPLIT=1 switches it off.
 	e->split_stage = false;
-	if (NR > 1 && !plan.send_cols.empty() && !getenv("TMX_NO_SPLIT")) {
+	if (NR > 1 && !plan.send_cols.empty() && !e->opt_no_split) {
 		std::vector<char> early(e->NS / 64, 0);
 		for (int c : plan.send_cols) early[c / 64] = 1;
 		std::vector<int> qe, ql;
@@ -960,7 +943,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 		// (measured at ne30: 56 columns per wavefront = 64; 48 and 40, which would load every SIMD evenly, are 70 % SLOWER --
 		// the kernel is not bound by the doubly loaded CUs; the knob stays for experiments, the default is 64)
 		(void)ngrp64;
-		if (const char * m = getenv("TMX_VI_CPW")) { const int c = atoi(m); if (c >= 1 && c <= 64) e->vi_cpw = c; }
+		if (e->opt_vi_cpw >= 1 && e->opt_vi_cpw <= 64) e->vi_cpw = e->opt_vi_cpw;
 		const int ngrp = (e->nunique + e->vi_cpw - 1) / e->vi_cpw + 2;
 		e->vi_stream_cols = std::max(e->NUS, ngrp * 64);
 		// the lane-group kernel (k_vi_group) streams 16 doubles per row and column instead of 10
@@ -1447,11 +1430,11 @@ static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt) {
 // apply): in the fully explicit mode -dt F on rho*theta, W, rho (:745-790) and the explicit tracer update (:792-800),
 // and with uniform diffusion the vertical diffusion of U,V (:1059-1105).
 // uv_done: the vertical diffusion of U,V has been added by tmxk_v_explicit already (TMX_UDV_SEPARATE=1 keeps the separate pass)
-static bool udv_fused(const tmx_engine * e) { return e->udiff && e->fully_explicit && !getenv("TMX_UDV_SEPARATE"); }
+static bool udv_fused(const tmx_engine * e) { return e->udiff && e->fully_explicit && !e->opt_udv_separate; }
 // TMX_VX_FUSED=1: the U,V update of V.StepExplicit evaluated by the kernel of the explicitly treated implicit terms (one launch
 // less, shared operands).  Off by default: config 4's step measured 4.81 ms with it, 4.75 ms without -- the terms kernel is
 // bound by its dependent arithmetic, the U,V update on its own by bandwidth, and the two overlap better as two launches.
-static bool uvx_fused(const tmx_engine * e) { return udv_fused(e) && getenv("TMX_VX_FUSED"); }
+static bool uvx_fused(const tmx_engine * e) { return udv_fused(e) && e->opt_vx_fused; }
 static int v_explicit_extras(tmx_engine * e, int iinit, int iupd, double dt, bool uv_done = false, bool with_uv = false) {
 	if (!e->fully_explicit) return TMX_OK;
 	int r; if ((r = check_reference_state(e))) return r;
@@ -1510,7 +1493,7 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 		if (n > 0) {
 			// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
 			// (TMX_TRACER_LINCOMB_PASS=1: formed by a separate pass first, for A/B and tests; whole patches only)
-			if (getenv("TMX_TRACER_LINCOMB_PASS")) {
+			if (e->opt_tracer_lincomb_pass) {
 				const size_t off = (size_t)(5 * e->L + 1) * e->NS, cnt = (size_t)e->nt * e->L * e->NS;
 				const double * tsrc[12];
 				for (int m = 0; m < n; m++) tsrc[m] = src[m] + off;
@@ -1560,7 +1543,7 @@ static int hv_step_explicit(tmx_engine * e, int iinit, int ibase, int iupd, doub
 // diffusion, the fully explicit vertical mode (BASELINE config 4), shallow water (sw_stage_split).  The two whole-patch
 // debug variants of the tracer kernels (TMX_VT_COLUMN, TMX_TRACER_LINCOMB_PASS) switch the split off.
 static bool stage_can_split(const tmx_engine * e) {
-	return e->split_stage && !getenv("TMX_VT_COLUMN") && !getenv("TMX_TRACER_LINCOMB_PASS");
+	return e->split_stage && !e->opt_vt_column && !e->opt_tracer_lincomb_pass;
 }
 static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overlapped);
 static int dss_after_exchange(tmx_engine * e, const KParams & p, int ix, bool overlapped);
@@ -1729,8 +1712,7 @@ static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overla
 	if (e->lb) return exchange_loopback(e, p, x);
 	// timing aid: a lone rank engine of an N-rank layout with the wire left out (results are then wrong at the rank
 	// boundary; used only by tools/rank_share_timing.py to measure the per-rank compute share of a step)
-	static const bool skip = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
-	if (skip) { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); return TMX_OK; }
+	if (e->opt_skip_exchange) { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); return TMX_OK; }
 	REQUIRE(e->comm || e->p2p, TMX_ERR_COMM, "tmx_comm_init or tmx_halo_p2p_connect must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
 	const unsigned long long seq = ++e->p2p_seq;
@@ -2920,7 +2902,7 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	for (int k = 0; k < e->cfg.n_instances; k++) if ((livein >> k & 1u) && !u.form[k]) need_check = true;
 	if (need_check && u.skip_steps > 0) { u.skip_steps--; return TMX_OK; }      // the last checks failed: not every step pays for another one
 	// (timing aid TMX_DEBUG_SKIP_EXCHANGE: the state of such a run is garbage at the rank boundary, NaN payloads included; no check)
-	static const bool trust = getenv("TMX_DEBUG_SKIP_EXCHANGE") != nullptr;
+	const bool trust = e->opt_skip_exchange != 0;
 	// the check comes first and works on the slots as the element-major programs left them (shared slots included: an instance
 	// that shares is given its own first, which for the model state never happens), so that a step that stays element-major keeps them
 	for (int k = 0; k < e->cfg.n_instances && !trust; k++) {
@@ -2964,7 +2946,7 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	// relaunched as one graph.  Off by default: the plain sequence is already queued asynchronously far ahead of the
 	// GPU, and the replay measured 0-1 % SLOWER (ne8: 0.419 vs 0.414 ms/step, ne16: 0.605 vs 0.601, ne30: 1.65 both).
 	// Multi-rank steps (RCCL calls on a second stream) and profiled steps always use the plain sequence.
-	if (e->use_graph && (e->cfg.n_ranks == 1 || getenv("TMX_DEBUG_SKIP_EXCHANGE")) && !e->prof && !e->lb) {
+	if (e->use_graph && (e->cfg.n_ranks == 1 || e->opt_skip_exchange) && !e->prof && !e->lb) {
 		StepGraphKey key = { scheme, first_step ? 1 : 0, last_step ? 1 : 0, dt };
 		for (auto & g : e->graphs)
 			if (g.key.scheme == key.scheme && g.key.first == key.first && g.key.last == key.last && g.key.dt == key.dt) {
@@ -3127,7 +3109,7 @@ extern "C" int tmx_comm_unique_id(unsigned char id[128]) {
 }
 
 extern "C" int tmx_comm_init(tmx_engine * e, const unsigned char id[128]) {
-	if (e && !e->xstream && e->cfg.device != -2 && !getenv("TMX_NO_EXCHANGE_OVERLAP")) {
+	if (e && !e->xstream && e->cfg.device != -2 && !e->opt_no_exchange_overlap) {
 		// second stream + events for the exchange / interior-DSS overlap
 		if (hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking) != hipSuccess) e->xstream = nullptr;
 		else { hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming); hipEventCreateWithFlags(&e->ev_recv, hipEventDisableTiming); }
@@ -3240,7 +3222,7 @@ extern "C" int tmx_halo_p2p_connect(tmx_engine * e, const unsigned char * blobs)
 		|| (r = dev_upload(&e->d_send_within, sw, &bytes)) || (r = dev_upload(&e->d_p2p_peers, peers, &bytes))) return r;
 	e->hbm_bytes += bytes;
 	e->p2p_npeers = (int)peers.size();
-	if (!e->xstream && !getenv("TMX_NO_EXCHANGE_OVERLAP")) {
+	if (!e->xstream && !e->opt_no_exchange_overlap) {
 		if (hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking) != hipSuccess) e->xstream = nullptr;
 		else { hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming); hipEventCreateWithFlags(&e->ev_recv, hipEventDisableTiming); }
 	}
@@ -3282,30 +3264,123 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // introspection
 
-// Options that change how (never what) the engine computes, by name; the ones that decide buffers and tables must be set before
-// tmx_finalize.  Everything here is reported back by tmx_get_option, so a run can print what it ran with.
+// Options that change how (never what) the engine computes -- the one exception, "contraction_mfma", is named as such -- by name.
+// The library reads NO environment variable on its own: a stray TMX_* in a job script cannot change a run.  Test and bench plumbing
+// that wants the historical variables calls tmx_options_from_environment, which turns them into these options, prints ONE line
+// naming what it applied, and leaves them queryable (tmx_get_option, tmx_options_report).
+struct OptionDef { const char * name; const char * env; int kind; const char * help; };      // kind 0: any time, 1: before tmx_finalize
+static int * option_slot(tmx_engine * e, const std::string & n) {
+#define OPT(NAME_, FIELD_) if (n == NAME_) return &(FIELD_)
+	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order);
+	OPT("share_copies", e->share_copies); OPT("xcd_vertical", e->xcd_vertical);
+	OPT("vi_carry", e->vi_carry); OPT("vi_pair", e->vi_pair); OPT("vi_group", e->vi_group); OPT("vi_group_max", e->vi_group_max);
+	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
+	OPT("vi_stagger", e->vi_stagger); OPT("vi_split_kernels", e->vi_mode); OPT("vi_sparse", e->opt_vi_sparse); OPT("vi_columns_per_wavefront", e->opt_vi_cpw);
+	OPT("contraction_mfma", e->use_mfma); OPT("step_graph", e->use_graph); OPT("p2p_timeout_s", e->p2p_timeout_s);
+	OPT("hvis_pull", e->hvis_pull); OPT("hvis_block", e->hvis_block);
+	OPT("split_stage_off", e->opt_no_split); OPT("metric_stored", e->opt_metric_stored); OPT("tracer_lincomb_pass", e->opt_tracer_lincomb_pass);
+	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
+	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
+	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
+	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows);
+#undef OPT
+	return nullptr;
+}
+static const OptionDef g_options[] = {
+	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
+	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 element-major order (default), 1 2 x 2 blocks, 2 strips inside a patch row" },
+	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
+	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
+	{ "xcd_vertical", "TMX_XCD_VERTICAL", 0, "1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
+	{ "vi_carry", "TMX_VI_CARRY", 0, "column solve: carry shared sub-expressions between block rows (1)" },
+	{ "vi_pair", "TMX_VI_PAIR", 0, "column solve: two-wavefront kernel (-1 auto, 0 one-wavefront kernel, 1 on)" },
+	{ "vi_group", "TMX_VI_GROUP", 0, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
+	{ "vi_group_max", "TMX_VI_GROUP_MAX", 0, "largest rank share (unique columns) served by the lane-group kernel (6400)" },
+	{ "vi_pair_workgroup", "TMX_VI_PAIR_WG", 0, "pairs per workgroup of the two-wavefront kernel (0 auto)" },
+	{ "vi_split_back", "TMX_VI_SPLIT_BACK", 0, "back substitution as a launch of its own (0)" },
+	{ "vi_back_sub", "TMX_VI_BACK_SUB", 0, "wavefronts per column group of that launch (1)" },
+	{ "vi_stagger", "TMX_VI_STAGGER_NS", 0, "staggered workgroup starts, window in units of 10 ns (0)" },
+	{ "vi_split_kernels", "TMX_VI_MODE", 1, "1: assemble + solve as two kernels (cross-check path)" },
+	{ "vi_sparse", "TMX_VI_SPARSE", 0, "1 (default): U-row entries that are zero in all 64 columns are not stored" },
+	{ "vi_columns_per_wavefront", "TMX_VI_CPW", 1, "columns per wavefront of the two-wavefront kernel (0 = 64)" },
+	{ "contraction_mfma", "TMX_MFMA", 1, "1: the 4 x 4 contractions of the fused explicit kernel on the matrix unit -- NOT bit-exact (1e-15 per call, W 1.5e-10 after 100 steps)" },
+	{ "step_graph", "TMX_GRAPH", 1, "1: single-rank steps replayed from a captured hipGraph" },
+	{ "p2p_timeout_s", "TMX_P2P_TIMEOUT_S", 0, "peer-to-peer halo: seconds a neighbour's message may take (600; 0 = for ever)" },
+	{ "hvis_pull", "TMX_HVIS_PULL", 1, "archived experiment: DSS pulled into the second hyperviscosity pass" },
+	{ "hvis_block", "TMX_HVIS_BLOCK", 1, "archived experiment: hyperviscosity passes fused with the in-patch DSS" },
+	{ "split_stage_off", "TMX_NO_SPLIT", 1, "1: no boundary-first stages on several ranks" },
+	{ "metric_stored", "TMX_METRIC", 1, "1: stream the stored 3-D metric arrays even where the closed form is verified" },
+	{ "tracer_lincomb_pass", "TMX_TRACER_LINCOMB_PASS", 0, "1: tracer stage combination by a separate pass (A/B)" },
+	{ "udv_separate", "TMX_UDV_SEPARATE", 0, "1: vertical diffusion of U,V as a pass of its own (A/B)" },
+	{ "vx_fused", "TMX_VX_FUSED", 0, "1: V.StepExplicit's U,V update inside the explicitly-treated-terms kernel (A/B)" },
+	{ "debug_skip_exchange", "TMX_DEBUG_SKIP_EXCHANGE", 0, "TIMING AID, WRONG RESULTS at rank boundaries: a lone rank engine of an N-rank layout with the wire left out" },
+	{ "exchange_overlap_off", "TMX_NO_EXCHANGE_OVERLAP", 1, "1: the exchange runs on the engine's stream" },
+	{ "kessler_column", "TMX_KESSLER_COLUMN", 0, "1: one-lane-per-column Kessler kernel (cross-check)" },
+	{ "vt_column", "TMX_VT_COLUMN", 0, "1: one-lane-per-column explicit tracer update (cross-check)" },
+	{ "vt_explicit_v1", "TMX_VT_EXPLICIT_V1", 0, "1: level-parallel explicit tracer update without LDS staging (cross-check)" },
+	{ "vt_lanes", "TMX_VT_LANES", 0, "columns per workgroup of the one-lane tracer column kernel (16)" },
+	{ "vt_lw8", "TMX_VT_LW8", 0, "row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
+	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },
+	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
+};
 extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(e && name, TMX_ERR_INVALID, "tmx_set_option: null argument");
 	const std::string n(name);
+	int * slot = option_slot(e, n);
+	const OptionDef * def = nullptr;
+	for (const OptionDef & d : g_options) if (n == d.name) def = &d;
+	REQUIRE(slot && def, TMX_ERR_INVALID, "tmx_set_option: unknown option '%s'", name);
+	REQUIRE(!(def->kind == 1 && e->finalized), TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
 	const int iv = (int)value;
-	if (n == "unique_layout" || n == "unique_tile_shape" || n == "unique_xcd_order") {
-		REQUIRE(!e->finalized, TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
-		if (n == "unique_layout") { REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1"); e->u.option = iv; }
-		else if (n == "unique_tile_shape") { REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2"); e->u.tile_shape = iv; }
-		else e->u.xcd_order = iv ? 1 : 0;
-		return TMX_OK;
-	}
-	tmx_set_error("tmx_set_option: unknown option '%s'", name);
-	return TMX_ERR_INVALID;
+	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");
+	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2");
+	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
+	*slot = iv;
+	return TMX_OK;
 }
 extern "C" int tmx_get_option(tmx_engine * e, const char * name, double * value) {
 	REQUIRE(e && name && value, TMX_ERR_INVALID, "tmx_get_option: null argument");
-	const std::string n(name);
-	if (n == "unique_layout") *value = e->u.option;
-	else if (n == "unique_tile_shape") *value = e->u.tile_shape;
-	else if (n == "unique_xcd_order") *value = e->u.xcd_order;
-	else { tmx_set_error("tmx_get_option: unknown option '%s'", name); return TMX_ERR_INVALID; }
+	int * slot = option_slot(e, std::string(name));
+	REQUIRE(slot, TMX_ERR_INVALID, "tmx_get_option: unknown option '%s'", name);
+	*value = *slot;
 	return TMX_OK;
+}
+// "name=value" of every option, one per line, defaults included; returns the length needed (buf may be null)
+extern "C" int tmx_options_report(tmx_engine * e, char * buf, int cap) {
+	if (!e) return -1;
+	std::string out;
+	for (const OptionDef & d : g_options) { char line[160]; snprintf(line, sizeof(line), "%s=%d\n", d.name, *option_slot(e, d.name)); out += line; }
+	if (!e->env_applied.empty()) { out += "from_environment="; for (const std::string & v : e->env_applied) out += v + " "; out += "\n"; }
+	if (buf && cap > 0) { strncpy(buf, out.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+	return (int)out.size() + 1;
+}
+// The historical TMX_* variables -> options (test / bench plumbing calls this right after tmx_create; the library never does).
+// Returns the number of variables applied and says so on stderr, ONE line, unless TMX_QUIET is set.
+extern "C" int tmx_options_from_environment(tmx_engine * e) {
+	REQUIRE(e, TMX_ERR_INVALID, "tmx_options_from_environment: null engine");
+	int n = 0;
+	for (const OptionDef & d : g_options) {
+		const char * ev = getenv(d.env);
+		if (!ev) continue;
+		int v = atoi(ev);
+		const std::string nm(d.name);
+		if (nm == "metric_stored") v = (strcmp(ev, "stored") == 0) ? 1 : 0;
+		else if (nm == "vi_split_kernels") v = (strcmp(ev, "split") == 0) ? 1 : 0;
+		else if (nm == "vi_stagger") v = atoi(ev) / 10;
+		else if (nm == "debug_skip_exchange" || nm == "split_stage_off" || nm == "exchange_overlap_off" || nm == "tracer_lincomb_pass" || nm == "udv_separate" ||
+		         nm == "vx_fused" || nm == "vt_column" || nm == "vt_explicit_v1") v = 1;      // (variables whose presence alone was the switch)
+		else if (nm == "unique_layout" || nm == "vi_pair" || nm == "vi_group" || nm == "contraction_mfma" || nm == "step_graph" || nm == "vi_carry" || nm == "xcd_vertical") v = v ? 1 : 0;
+		if (d.kind == 1 && e->finalized) continue;
+		if (tmx_set_option(e, d.name, v) != TMX_OK) continue;
+		e->env_applied.push_back(std::string(d.env) + "=" + ev);
+		n++;
+	}
+	if (n && !getenv("TMX_QUIET")) {
+		std::string l = "tempest_mi355x: options taken from the environment:";
+		for (const std::string & v : e->env_applied) l += " " + v;
+		fprintf(stderr, "%s\n", l.c_str());
+	}
+	return n;
 }
 
 extern "C" long long tmx_info(tmx_engine * e, int what) {

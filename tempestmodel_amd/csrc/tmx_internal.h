@@ -225,7 +225,7 @@ struct tmx_engine {
 	double * d_image = nullptr; size_t image_n = 0;     // restart image of one patch (tmx_pack_active_state), grown on demand
 	double strang_offc = 0.0;                          // TimestepSchemeStrang off-centering (tmx_set_strang_off_centering)
 	unsigned long long * d_pivot_stats = nullptr;      // tmx_debug_pivot_stats: {uniform pivot steps, all pivot steps} of k_vi_pair, per wavefront
-	bool use_mfma = false;                   // TMX_MFMA=1: 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
+	int use_mfma = 0;                        // option "contraction_mfma" (TMX_MFMA=1): 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
 	int vi_group = -1, vi_group_max = 6400;     // lane-group column kernel: -1 auto (nunique <= vi_group_max; column solve per step, group / pair kernel: 0.171 / 0.281 ms at 2 116 columns, 0.237 / 0.279 at 6 075, 0.349 / 0.279 at 8 100), 0 off, 1 on (TMX_VI_GROUP, TMX_VI_GROUP_MAX)
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
 	int p2p_timeout_s = 600;                 // peer-to-peer halo: how long a neighbour's message may take (TMX_P2P_TIMEOUT_S; 0 = for ever)
@@ -251,14 +251,19 @@ struct tmx_engine {
 	int xcd_vertical = 1;                    // TMX_XCD_VERTICAL=0: plain 2-D order of the vertical stencil kernels' workgroups
 	int vi_split_back = 0, vi_back_sub = 1, vi_stagger = 0;   // experiments (TMX_VI_SPLIT_BACK, TMX_VI_BACK_SUB, TMX_VI_STAGGER_NS / 10): back substitution as its own launch
 	int vi_pair_wg = 0;                      // pairs per workgroup of k_vi_pair: 0 auto (1 up to 256 column groups, else 2), TMX_VI_PAIR_WG
-	bool vi_carry = true;                    // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
+	int vi_carry = 1;                        // carry shared quantities between block rows (A/B switch TMX_VI_CARRY)
 	bool fully_explicit = false, udiff = false;   // cfg.fully_explicit / cfg.uniform_diffusion
 	std::vector<double> h_ref;               // reference state in slab layout until tmx_finalize
 	double * d_ref = nullptr;                // [nslab][NS] reference state + reference tracers (uniform diffusion)
 	double * h_stage = nullptr; size_t h_stage_n = 0;   // pinned host staging buffer of tmx_upload_state / tmx_download_state
 	bool prof = false;
-	bool use_graph = false;                  // TMX_GRAPH=1: replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
+	int use_graph = 0;                       // option "step_graph" (TMX_GRAPH=1): replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
 	std::vector<StepGraph> graphs;
+	// switches that used to be read from the environment at their point of use (tmx_set_option / tmx_options_from_environment)
+	int opt_no_split = 0, opt_metric_stored = 0, opt_tracer_lincomb_pass = 0, opt_udv_separate = 0, opt_vx_fused = 0, opt_skip_exchange = 0,
+	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_lanes = 16,
+	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
+	std::vector<std::string> env_applied;    // "NAME=value" of every environment variable tmx_options_from_environment turned into an option
 	UniqueLayout u;
 	bool vi_unique = false;                  // transient: the column solve runs on the unique slabs (tmxk_vi_fused)
 	ProfSlot prof_slots[TMX_K_COUNT];

@@ -1616,7 +1616,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	// node-unique layout (e->vi_unique, set by the caller together with tmxu_params_columns): unique column u IS state column u, no in-patch copies to fill
 	const int * ucolp = e->vi_unique ? nullptr : (const int *)e->d_ucol, * udepp = e->vi_unique ? nullptr : (const int *)e->d_udep;
 	const size_t lds = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
-	const bool sparse = !(getenv("TMX_VI_SPARSE") && atoi(getenv("TMX_VI_SPARSE")) == 0);      // A/B switch, default on
+	const bool sparse = e->opt_vi_sparse != 0;      // A/B switch (option "vi_sparse"), default on
 	// The pair kernel shortens the per-column dependent chain to max(assembly, elimination) and is built for two
 	// wavefronts per SIMD (256 registers): the 1024 SIMDs hold 1024 pairs at once.  Measured per launch: ne30 on one
 	// GPU (760 column groups) 197-211 us against 229 us for the one-wavefront kernel; ne60 (3038 groups, three rounds)

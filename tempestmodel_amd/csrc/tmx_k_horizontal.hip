@@ -50,7 +50,7 @@ template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM>
 __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
 {
-	__shared__ double s[MF ? 1 : KT_H][MF ? 1 : 9][64];
+	__shared__ double s[KT_H][MF ? 1 : 9][64];
 	__shared__ double sDw[MF ? 1 : KT_H][16], sSw[MF ? 1 : KT_H][16];      // every wavefront its own copy of the operator tables (no workgroup barrier before the contractions)
 	__shared__ double rmtab[TMX_H_EXNER_LDS ? TMX_RMTAB_DOUBLES : 1];      // exp / log tables of the Exner function: from global memory they are two dependent gathers per wavefront
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		else {
 			bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
 			bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
-			if (TMX_H_FUSE_W && !MF && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
+			if (TMX_H_FUSE_W && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
 		}
 		c2a0 = ldu(p.g2d + G2_C2A0 * NS, gb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, gb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, gb);
 		jn = ldu(p.g2d + G2_JN * NS, gb); j2d = ldu(p.g2d + G2_J2D * NS, gb); fcor = ldu(p.g2d + G2_F * NS, gb);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	}
 	if (TMX_H_BURST) {
 		bT = lin_reduce<NT, PM>(xbase, xT); bR = lin_reduce<NT, PM>(xbase, xR);
-		if (TMX_H_FUSE_W && !MF && ty > 0) bW = lin_reduce<NT, PM>(xbase, xW);
+		if (TMX_H_FUSE_W && ty > 0) bW = lin_reduce<NT, PM>(xbase, xW);
 	}
 	const double outR = bR - dt * invJ * (darf + dbrf), outT = bT - dt * invJ * (dapf + dbpf);
 	if (!UQ) {
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		stu(xup + sT, colb, outT);
 	}
 	double outW = 0.0;
-	if (TMX_H_FUSE_W && !MF) {
+	if (TMX_H_FUSE_W) {
+		// (MF: the matrix-unit variant keeps one 512-byte row per wavefront for exactly this hand-over; round 3 measured it without,
+		// i.e. with every interface left to k_h_w_update)
 		// W on the interfaces inside the tile (part 2 below, :1612-1659): interface k takes (u x zeta)_xi of the levels k - 1 and k,
 		// which wavefront ty - 1 hands over through its own (now free) LDS row; only the tile's first interface is left to
 		// k_h_w_update, which therefore needs the hand-off array for the first and the last level of a tile only
@@ -370,7 +372,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	const bool uq = p.t_ucol != nullptr;      // node-unique layout (tmxu_params): 1-D launches, XCD-aware tile order
 	KParams q = p; q.u_ntiles = ntile;
-	const int wstride = (TMX_H_FUSE_W && !(fuse_v && e->use_mfma)) ? KT_H : 1;
+	const int wstride = TMX_H_FUSE_W ? KT_H : 1;
 	const int nyb = (p.L + KT_H - 1) / KT_H, nyb2 = ((p.L + wstride - 1) / wstride + 1 + 3) / 4;
 	dim3 blk(64, KT_H), grd = wg_grid(uq, q, ntile, nyb);
 	double * uv01 = e->d_scratch + (size_t)p.L * p.NS;     // 4 slabs behind the (u x zeta)_xi hand-off

@@ -366,7 +366,7 @@ void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt) {
 	// level-parallel form up to 8 x KES_NO = 40 levels (TMX_KESSLER_COLUMN=1 and taller columns: the one-lane-per-column kernel)
 	const int kt = (p.L + KES_NO - 1) / KES_NO;
 	const size_t lds = (size_t)p.L * 64 * (2 * sizeof(double) + 2 * sizeof(float)) + 64 * sizeof(double);
-	if (kt <= 8 && !getenv("TMX_KESSLER_COLUMN")) {
+	if (kt <= 8 && !e->opt_kessler_column) {
 		if (lds > 48 * 1024) hipFuncSetAttribute((const void *)k_kessler_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(k_kessler_tile<512>, dim3((p.ncol + 63) / 64), dim3(64, kt), lds, e->stream, p, x, (const double *)e->d_zlev, e->d_prect, dt, gamma, pscal);
 		return;

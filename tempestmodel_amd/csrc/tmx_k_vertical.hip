@@ -486,8 +486,7 @@ static size_t vt_rows_lds(int L, int lw = 16) { return ((size_t)L * 4 + (size_t)
 static void launch_vt_rows(tmx_engine * e, const KParams & p, int ncols, const double * xin, const double * w0, const double * xbase, double * xup,
 	double dt, const int * ucol, const int * udep, size_t lds)
 {
-	static const int nr_env = getenv("TMX_VT_NR") ? atoi(getenv("TMX_VT_NR")) : 0;
-	static const int lw8_env = getenv("TMX_VT_LW8") ? atoi(getenv("TMX_VT_LW8")) : -1;
+	const int nr_env = e->opt_vt_nr, lw8_env = e->opt_vt_lw8;      // options "vt_row_lanes", "vt_lw8"
 	const bool lw8 = lw8_env >= 0 ? lw8_env == 1 : p.L <= 48;    // ne30, 2 tracers: L30 1.308 (8 columns) / 1.358 (16) ms per step, L60 3.35 / 3.21
 	const int nr = nr_env ? nr_env : (p.L > 48 ? 32 : 16);       // measured at ne30: L30 1.36 (16) / 1.49 (32) ms, L60 3.50 (16) / 3.25 (32) ms per step
 #define LAUNCH_VTR(NR_, LWB_) do { \
@@ -511,7 +510,7 @@ static int vi_tracers_lanes(int L, size_t & lds) {
 
 int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const double * w0, const double * xbase, double * xup, double dt) {
 	if (e->nunique == 0 || e->nt == 0) return 0;
-	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {      // default: 16 columns x 4 row lanes per workgroup
+	if (e->opt_vt_rows) {      // default: 16 columns x 4 row lanes per workgroup
 		const size_t l2 = vt_rows_lds(p.L);
 		if (l2 <= 160 * 1024) {
 			launch_vt_rows(e, p, e->nunique, xin, w0, xbase, xup, dt, (const int *)e->d_ucol, (const int *)e->d_udep, l2);
@@ -524,7 +523,7 @@ int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	// ~100 cycles each) and one 64-column workgroup fills a CU's LDS, i.e. ONE wavefront per CU.  With 16 columns per
 	// workgroup five wavefronts share a CU and hide each other's LDS latency (TMX_VT_LANES: 64, 32, 16, 8 for A/B).
 	int want = 16;
-	if (const char * m = getenv("TMX_VT_LANES")) want = atoi(m);
+	want = e->opt_vt_lanes;
 	if (want < lw && (want == 32 || want == 16 || want == 8)) { lw = want; lds = ((size_t)p.L * 4 + (size_t)p.L * 2 + (size_t)(p.L + 1) * 2) * lw * sizeof(double); }
 #define LAUNCH_VT(LW_) do { hipFuncSetAttribute((const void *)k_vi_tracers<LW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 	hipLaunchKernelGGL(k_vi_tracers<LW_>, dim3((e->nunique + LW_ - 1) / LW_), dim3(64), lds, e->stream, p, e->nt, xin, w0, xbase, xup, dt, \
@@ -806,8 +805,8 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 // UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
-	if (!getenv("TMX_VT_COLUMN")) {      // level-parallel form (default); TMX_VT_COLUMN=1: the one-lane-per-column kernel, for A/B and tests
-		const bool v1 = getenv("TMX_VT_EXPLICIT_V1") != nullptr;       // the form without LDS staging, for A/B and tests
+	if (!e->opt_vt_column) {      // level-parallel form (default); option "vt_column": the one-lane-per-column kernel, for A/B and tests
+		const bool v1 = e->opt_vt_explicit_v1 != 0;       // the form without LDS staging, for A/B and tests
 		if (v1) {
 			dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 			hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
@@ -835,7 +834,7 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 // of the tracers, on every stored column (the reference loops over all nodes there, :541-542), in place on the update instance
 int tmxk_vi_tracers_all(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
-	if (!(getenv("TMX_VT_ROWS") && atoi(getenv("TMX_VT_ROWS")) == 0)) {
+	if (e->opt_vt_rows) {
 		const size_t l2 = vt_rows_lds(p.L);
 		if (l2 <= 160 * 1024) {
 			launch_vt_rows(e, p, p.ncol, xin, xin + (size_t)TMX_SLAB_W(p.L, 0) * p.NS, (const double *)xup, xup, dt, nullptr, nullptr, l2);

@@ -134,6 +134,8 @@ def load_library():
     lib.tmx_comm_unique_id.argtypes = [C.c_char_p]
     lib.tmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     lib.tmx_get_option.argtypes = [C.c_void_p, C.c_char_p, PD]
+    lib.tmx_options_from_environment.argtypes = [C.c_void_p]
+    lib.tmx_options_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     _lib = lib
     return lib
 
@@ -194,6 +196,8 @@ class Engine:
         h = C.c_void_p()
         self._chk(self.lib.tmx_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        # test / bench plumbing keeps the TMX_* variables: turned into options here, explicitly (the library itself reads none)
+        self.lib.tmx_options_from_environment(self.h)
         try:
             self._setup()
         except Exception:
@@ -485,6 +489,17 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.tmx_sync(self.h))
+
+    def options_report(self):
+        """{name: value} of every engine option as in use (tmx_options_report)."""
+        n = self.lib.tmx_options_report(self.h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.tmx_options_report(self.h, buf, n + 1)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            k, _, v = line.partition("=")
+            out[k] = v if k == "from_environment" else int(v)
+        return out
 
     def get_option(self, name):
         v = np.zeros(1)

@@ -217,3 +217,43 @@ def test_stepper_programs_share_the_copies_in_front_of_a_stub_implicit_step():
     stale = [lib.tmx_debug_program_copies(Engine.SCHEMES[sch], 0, 4, 2, ctypes.byref(c), ctypes.byref(s)) for sch in ("ars222", "ars443", "ark232", "strang")]
     assert all(rc <= -1000 for rc in stale), stale
     assert lib.tmx_debug_program_copies(99, 1, 1, 1, ctypes.byref(c), ctypes.byref(s)) != 0
+
+
+def test_options_are_explicit_and_reported():
+    """The library reads no environment variable on its own: options arrive through tmx_set_option (validated, reported by
+    tmx_options_report) or through an explicit tmx_options_from_environment call that says what it took.  Plan-only engines:
+    no device needed."""
+    from tempestmodel_amd import engine as eng
+    lib = eng.load_library()
+    cfg = eng.TmxConfig()
+    cfg.abi_version = eng.TMX_ABI_VERSION
+    cfg.horizontal_order, cfg.vertical_order, cfg.levels, cfg.n_patches, cfg.n_instances = 4, 1, 4, 6, 7
+    cfg.hypervis_order, cfg.rank, cfg.n_ranks, cfg.device = 4, 0, 1, -2
+    cfg.element_delta_a, cfg.grav, cfg.Rd, cfg.cp, cfg.p0 = 0.1, 9.8, 287.0, 1004.5, 1e5
+
+    def report(h):
+        n = lib.tmx_options_report(h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        lib.tmx_options_report(h, buf, n + 1)
+        return dict(l.split("=", 1) for l in buf.value.decode().splitlines())
+
+    old = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("TMX_")}
+    try:
+        os.environ["TMX_VI_PAIR"] = "0"; os.environ["TMX_MFMA"] = "1"; os.environ["TMX_QUIET"] = "1"
+        h = ctypes.c_void_p()
+        assert lib.tmx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+        r = report(h)
+        assert r["vi_pair"] == "-1" and r["contraction_mfma"] == "0" and "from_environment" not in r      # tmx_create looked at nothing
+        assert lib.tmx_options_from_environment(h) == 2
+        r = report(h)
+        assert r["vi_pair"] == "0" and r["contraction_mfma"] == "1" and "TMX_VI_PAIR=0" in r["from_environment"]
+        assert lib.tmx_set_option(h, b"unique_layout", ctypes.c_double(0.0)) == 0 and report(h)["unique_layout"] == "0"
+        assert lib.tmx_set_option(h, b"no_such_option", ctypes.c_double(1.0)) != 0
+        assert lib.tmx_set_option(h, b"unique_tile_shape", ctypes.c_double(7.0)) != 0
+        v = ctypes.c_double(-5.0)
+        assert lib.tmx_get_option(h, b"vi_group_max", ctypes.byref(v)) == 0 and v.value == 6400.0
+        lib.tmx_destroy(h)
+    finally:
+        for k in ("TMX_VI_PAIR", "TMX_MFMA", "TMX_QUIET"):
+            os.environ.pop(k, None)
+        os.environ.update(old)

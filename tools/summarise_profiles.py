@@ -68,11 +68,12 @@ if v:
 
 ab = {"method": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE and a separate "
                 "--kernel-trace --stats run, each with TMX_MFMA=0 and TMX_MFMA=1, of `python3 bench.py --steps 5 --warmup 2 --develop 3 "
-                "--no-cpu-baseline` (ne30 np4 L30, 1 GPU); per launch of the fused explicit kernel k_h_explicit<true,NT,MF>, summed "
+                "--no-cpu-baseline` (ne30 np4 L30, 1 GPU, element-major layout on both sides); per launch of the fused explicit kernel k_h_explicit<true,NT,MF>, summed "
                 "over its four instantiations of an ARS343 step (NT = 0, 4, 6, 7 combination terms).  mfma busy fraction = "
                 "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): the share of SIMD-cycles the matrix unit is busy."}
-for env, cn, tn in (("TMX_MFMA=0", "mfma0", "trace"), ("TMX_MFMA=1", "mfma1", "trace_mfma1")):
-    c = counters(cn); st = stats(tn)
+for env, cn, tn in (("TMX_MFMA=0", "mfma0", "trace_d"), ("TMX_MFMA=1", "mfma1", "trace_mfma1")):
+    # (both sides on the element-major layout, TMX_UNIQUE=0: the matrix-unit variant has no node-unique form)
+    c = counters(cn); st = stats(tn) or stats("trace")
     if not c:
         continue
     ex = {k: x for k, x in c.items() if "k_h_explicit" in k}
