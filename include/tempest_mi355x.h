@@ -446,6 +446,12 @@ int tmx_options_from_environment(tmx_engine * e);
 int tmx_plan_get(tmx_engine * e, int what, int * out, int cap);
 /* [n_cross][4][4][4] doubles: [member m][partner q] the 2x2 matrix rotating q's (U,V) into the frame of m's patch. */
 int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
+/* Host-side tables of the node-unique layout ("unique_layout") for a tile shape, built on the spot (plan-only engines too):
+ * what = 0 sizes (unique nodes, padded, thread columns, partial slots, groups left to the DSS kernel, of them rank-local, early tiles,
+ * late tiles); 1 element-major column of a thread; 2 its node; 3 store code; 4 averaging recipe; 5 / 6 / 7 sources, destinations and
+ * member counts of the remaining groups; 8 node of a slot; 9 slots sent to other ranks; 10 representative column of a node;
+ * 11 node of an element-major column; 12 per-tile node bases and pitches.  Returns the ints written (needed, when out == NULL), -1 on error. */
+int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out, int cap);
 
 /* Test hooks (tests/ only): n engines = ranks 0..n-1 of one grid inside ONE process on one device; the
  * RCCL transport is replaced by device-to-device copies in wire order, everything else (packing, ghost

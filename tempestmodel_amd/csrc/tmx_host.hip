@@ -3445,6 +3445,33 @@ extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 	return (int)plan.xmat.size();
 }
 
+// Host-side tables of the node-unique layout for the tile shape given, built on the spot (works on plan-only engines: no device),
+// for the CPU tests of that logic.  what = 0: (NU, NUS, NTS, slots, groups left to the DSS kernel, of them without remote member,
+// early tiles, late tiles); 1 t_dcol; 2 t_ucol; 3 t_sdst; 4 t_sred; 5 gsrc; 6 gdst; 7 gn; 8 slot_ucol; 9 send_slots; 10 u_rep;
+// 11 ucol_of_dcol; 12 per-tile info.  Returns the number of ints written (needed, when out == NULL), -1 on error.
+extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out, int cap) {
+	if (!e || !e->finalized || tile_shape < 0 || tile_shape > 2) return -1;
+	PlanHost & plan = plan_of(e);
+	UniqueLayout keep = e->u;
+	e->u = UniqueLayout(); e->u.tile_shape = tile_shape;
+	UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
+	UniqueTables T;
+	const int r = tmxu_tables(e, in, T);
+	const UniqueLayout u = e->u;
+	e->u = keep;
+	if (r) return -1;
+	std::vector<int> v;
+	switch (what) {
+		case 0: v = { u.NU, u.NUS, u.NTS, u.nslots, u.ngroups, u.ngroups_local, u.n_early, u.n_late }; break;
+		case 1: v = T.t_dcol; break; case 2: v = T.t_ucol; break; case 3: v = T.t_sdst; break; case 4: v = T.t_sred; break;
+		case 5: v = T.gsrc; break; case 6: v = T.gdst; break; case 7: v = T.gn; break; case 8: v = T.slot_ucol; break;
+		case 9: v = T.send_slots; break; case 10: v = T.u_rep; break; case 11: v = T.ucol_of_dcol; break; case 12: v = T.tinfo; break;
+		default: return -1;
+	}
+	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
+	return (int)v.size();
+}
+
 // Statistics of the two-wavefront column kernel: how many pivot steps found the same pivot row in all 64 columns of a
 // wavefront (the renaming path) out of all pivot steps.  enable = 1 starts counting (zeroed), 0 stops; out (may be NULL)
 // receives {uniform, total} accumulated so far.

@@ -279,6 +279,10 @@ void tmx_set_error(const char * fmt, ...);
 struct UniquePlanInput {      // what tmx_finalize hands over: the DSS groups in the engine's order and the send list, in D columns
 	const std::vector<int> * grp_cols, * grp_n, * grp_x, * grp_type, * send_cols;
 };
+struct UniqueTables {         // the host-side tables of the layout (tmxu_tables); thread space T = [tile][64], unique space U
+	std::vector<int> t_dcol, t_ucol, t_sdst, t_sred, tinfo, ucol_of_dcol, u_rep, slot_ucol, gsrc, gdst, gn, gx, gt, send_slots, quads_early, quads_late;
+};
+int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T);      // host only (works on plan-only engines)
 int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes);
 void tmxu_free(tmx_engine * e);
 KParams tmxu_params(const tmx_engine * e, const KParams & base);          // thread space T, state in U slabs

@@ -28,8 +28,8 @@ void tmxu_free(tmx_engine * e) {
 	u = UniqueLayout();
 }
 
-// Tables of the layout.  Called by tmx_finalize while the host copy of the 2-D geometry still exists.
-int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
+// Tables of the layout: host part (no device; also what tmx_debug_unique_tables hands to the CPU tests)
+int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 	UniqueLayout & u = e->u;
 	const int NS = e->NS;
 	const std::vector<int> & gc = *in.grp_cols, & gn = *in.grp_n, & gx = *in.grp_x, & gt = *in.grp_type;
@@ -172,28 +172,39 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 	for (int t = 0; t < (int)early.size(); t++) (early[t] ? qe : ql).push_back(t);
 	u.split = e->cfg.n_ranks > 1 && !qe.empty() && !ql.empty() && e->split_stage;
 	u.n_early = (int)qe.size(); u.n_late = (int)ql.size();
+	T.t_dcol = t_dcol; T.t_ucol = t_ucol; T.t_sdst = t_sdst; T.t_sred = t_sred; T.ucol_of_dcol = ucol_of_dcol; T.u_rep = u_rep; T.slot_ucol = slot_ucol;
+	T.gsrc = gsrc; T.gdst = gdst; T.gn = ugn; T.gx = ugx; T.gt = ugt; T.send_slots = send_slots; T.quads_early = qe; T.quads_late = ql;
+	// per tile: where node (0,0) of each of its four elements lives and its patch's row pitch (ucol = base + i * pitch + j)
+	T.tinfo.assign((size_t)(u.NTS / 64) * 8, -1);
+	for (size_t t = 0; t < telem.size(); t++) {
+		const int p = patch_of_elem[telem[t]];
+		T.tinfo[(t / 4) * 8 + (t % 4)] = t_ucol[t * 16];
+		T.tinfo[(t / 4) * 8 + 4 + (t % 4)] = 3 * e->patches[p].neb + 1;
+		for (int q = 0; q < 16; q++) REQUIRE(t_ucol[t * 16 + q] == t_ucol[t * 16] + (q >> 2) * (3 * e->patches[p].neb + 1) + (q & 3), TMX_ERR_INVALID, "internal: tile table");
+	}
+	return TMX_OK;
+}
+
+// Tables + device buffers.  Called by tmx_finalize while the host copy of the 2-D geometry still exists.
+int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
+	UniqueLayout & u = e->u;
+	UniqueTables T;
+	int r = tmxu_tables(e, in, T);
+	if (r) return r;
+	const int NS = e->NS;
 	// geometry in thread order and per unique column (the representative copy's)
 	std::vector<double> g2t((size_t)G2_COUNT * u.NTS, 0.0), g2u((size_t)G2_COUNT * u.NUS, 0.0);
 	for (int f = 0; f < G2_COUNT; f++) {
 		for (int t = 0; t < u.NTS; t++)
-			g2t[(size_t)f * u.NTS + t] = (t_dcol[t] >= 0) ? e->h_g2d[(size_t)f * NS + t_dcol[t]] : ((f == G2_J2D || f == G2_JN || f == G2_JE) ? 1.0 : 0.0);
-		for (int uu = 0; uu < u.NUS; uu++) g2u[(size_t)f * u.NUS + uu] = e->h_g2d[(size_t)f * NS + u_rep[uu]];
+			g2t[(size_t)f * u.NTS + t] = (T.t_dcol[t] >= 0) ? e->h_g2d[(size_t)f * NS + T.t_dcol[t]] : ((f == G2_J2D || f == G2_JN || f == G2_JE) ? 1.0 : 0.0);
+		for (int uu = 0; uu < u.NUS; uu++) g2u[(size_t)f * u.NUS + uu] = e->h_g2d[(size_t)f * NS + T.u_rep[uu]];
 	}
-	// per tile: where node (0,0) of each of its four elements lives and its patch's row pitch (ucol = base + i * pitch + j)
-	std::vector<int> tinfo((size_t)(u.NTS / 64) * 8, -1);
-	for (size_t t = 0; t < telem.size(); t++) {
-		const int p = patch_of_elem[telem[t]];
-		tinfo[(t / 4) * 8 + (t % 4)] = t_ucol[t * 16];
-		tinfo[(t / 4) * 8 + 4 + (t % 4)] = 3 * e->patches[p].neb + 1;
-		for (int q = 0; q < 16; q++) REQUIRE(t_ucol[t * 16 + q] == t_ucol[t * 16] + (q >> 2) * (3 * e->patches[p].neb + 1) + (q & 3), TMX_ERR_INVALID, "internal: tile table");
-	}
-	int r;
-	if ((r = up(&u.d_t_tinfo, tinfo, bytes))) return r;
+	if ((r = up(&u.d_t_tinfo, T.tinfo, bytes))) return r;
 	if ((r = up(&u.d_g2d_t, g2t, bytes)) || (r = up(&u.d_g2d_u, g2u, bytes))) return r;
-	if ((r = up(&u.d_t_ucol, t_ucol, bytes)) || (r = up(&u.d_t_sdst, t_sdst, bytes)) || (r = up(&u.d_t_sred, t_sred, bytes)) || (r = up(&u.d_t_dcol, t_dcol, bytes))) return r;
-	if ((r = up(&u.d_ucol_of_dcol, ucol_of_dcol, bytes)) || (r = up(&u.d_u_rep, u_rep, bytes)) || (r = up(&u.d_slot_ucol, slot_ucol, bytes))) return r;
-	if ((r = up(&u.d_gsrc, gsrc, bytes)) || (r = up(&u.d_gdst, gdst, bytes)) || (r = up(&u.d_gn, ugn, bytes)) || (r = up(&u.d_gx, ugx, bytes)) || (r = up(&u.d_gtype, ugt, bytes))) return r;
-	if ((r = up(&u.d_send_slots, send_slots, bytes)) || (r = up(&u.d_quads_early, qe, bytes)) || (r = up(&u.d_quads_late, ql, bytes))) return r;
+	if ((r = up(&u.d_t_ucol, T.t_ucol, bytes)) || (r = up(&u.d_t_sdst, T.t_sdst, bytes)) || (r = up(&u.d_t_sred, T.t_sred, bytes)) || (r = up(&u.d_t_dcol, T.t_dcol, bytes))) return r;
+	if ((r = up(&u.d_ucol_of_dcol, T.ucol_of_dcol, bytes)) || (r = up(&u.d_u_rep, T.u_rep, bytes)) || (r = up(&u.d_slot_ucol, T.slot_ucol, bytes))) return r;
+	if ((r = up(&u.d_gsrc, T.gsrc, bytes)) || (r = up(&u.d_gdst, T.gdst, bytes)) || (r = up(&u.d_gn, T.gn, bytes)) || (r = up(&u.d_gx, T.gx, bytes)) || (r = up(&u.d_gtype, T.gt, bytes))) return r;
+	if ((r = up(&u.d_send_slots, T.send_slots, bytes)) || (r = up(&u.d_quads_early, T.quads_early, bytes)) || (r = up(&u.d_quads_late, T.quads_late, bytes))) return r;
 	u.ustride = (size_t)e->nslab * u.NUS;
 	const size_t ub = (size_t)(e->cfg.n_instances + 1) * u.ustride * sizeof(double), pb = (size_t)e->nslab * u.NP * sizeof(double);
 	HIPCHK(hipMalloc((void **)&u.d_ustate, ub)); HIPCHK(hipMemset(u.d_ustate, 0, ub)); *bytes += ub;

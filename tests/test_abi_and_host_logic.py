@@ -257,3 +257,82 @@ def test_options_are_explicit_and_reported():
         for k in ("TMX_VI_PAIR", "TMX_MFMA", "TMX_QUIET"):
             os.environ.pop(k, None)
         os.environ.update(old)
+
+
+def _unique_tables(e, shape):
+    lib = e.lib
+    lib.tmx_debug_unique_tables.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    out = {}
+    for what, name in enumerate(("sizes", "t_dcol", "t_ucol", "t_sdst", "t_sred", "gsrc", "gdst", "gn", "slot_ucol", "send_slots", "u_rep", "ucol_of_dcol", "tinfo")):
+        n = lib.tmx_debug_unique_tables(e.h, shape, what, None, 0)
+        assert n >= 0, name
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        assert lib.tmx_debug_unique_tables(e.h, shape, what, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n) == n
+        out[name] = a[:n]
+    return out
+
+
+@pytest.mark.parametrize("ne,npatch,n_ranks", [(5, 6, 1), (6, 24, 1), (12, 24, 3), (7, 6, 1)])
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_unique_layout_tables(ne, npatch, n_ranks, shape):
+    """Host logic of the node-unique layout (tmxu_tables), on plan-only engines: every unique node is stored by exactly one place
+    -- one lane of one tile (alone, or averaging the copies its wavefront holds), or the DSS kernel through the partial slots of all
+    its copies; averaging recipes name lanes of the same tile that hold copies of the same node; the per-tile node arithmetic
+    reproduces the per-thread table; what other ranks need are slots."""
+    from tempestmodel_amd.engine import Engine
+    g, _ = gu.make_grid(ne, 4, npatch)
+    for rank in range(n_ranks):
+        e = Engine(g, device=-2, rank=rank, n_ranks=n_ranks)
+        T = _unique_tables(e, shape)
+        NU, NUS, NTS, nslots, ngroups, nlocal, nearly, nlate = (int(v) for v in T["sizes"])
+        el = len([p for p in range(npatch) if e.owner[p] == rank]) * (ne * ne * 6 // npatch)
+        per_patch = ne * ne * 6 // npatch
+        side = int(round(per_patch ** 0.5))
+        assert NU == len(e.local_patches) * (3 * side + 1) ** 2 and NTS == (el * 16 + 63) // 64 * 64
+        tu, sd, sr, td = T["t_ucol"], T["t_sdst"], T["t_sred"], T["t_dcol"]
+        valid = td >= 0
+        assert valid.sum() == el * 16 and sorted(td[valid]) == list(range(el * 16))          # thread order = a permutation of the elements' nodes
+        assert (tu[valid] == T["ucol_of_dcol"][td[valid]]).all() and (tu[~valid] == -1).all() and (sd[~valid] == -1).all()
+        # who stores each unique node
+        stores = np.zeros(NU, dtype=np.int64)
+        np.add.at(stores, sd[sd >= 0], 1)
+        slot_nodes = T["slot_ucol"][:nslots]
+        slots = -2 - sd[sd <= -2]
+        assert sorted(slots) == list(range(nslots)) and (slot_nodes[slots] == tu[sd <= -2]).all()
+        via_dss = np.zeros(NU, dtype=np.int64)
+        gd = T["gdst"].reshape(-1, 4); gs = T["gsrc"].reshape(-1, 4); gn = T["gn"]
+        assert len(gn) == ngroups
+        for k in range(ngroups):
+            d = gd[k][gd[k] >= 0]
+            assert len(set(d)) == len(d) and len(d) >= 1
+            via_dss[d] += 1
+            loc = gs[k][:gn[k]]
+            loc = loc[(loc >= 0) & (loc < max(nslots, 1) + 63)]      # (ghosts are numbered from the padded slot count on)
+            assert set(slot_nodes[loc[loc < nslots]]) <= set(d)        # a group's local copies are copies of the nodes it stores
+        assert ((stores + via_dss) == 1).all(), "a unique node is stored twice or never"
+        # copies handed to the DSS kernel never coincide with nodes a lane stores
+        assert not (set(slot_nodes) & set(sd[sd >= 0]))
+        # averaging recipes
+        for t in np.nonzero(sr)[0]:
+            n = sr[t] & 15
+            assert n in (2, 4) and sd[t] == tu[t]
+            lanes = [(sr[t] >> s) & 63 for s in (4, 10, 16)][:n - 1]
+            base = (t // 64) * 64
+            for l in lanes:
+                assert tu[base + l] == tu[t] and sd[base + l] == -1 and base + l != t
+            assert len(set(lanes)) == n - 1
+        # lanes that store nothing are exactly the partners of some recipe
+        partners = set()
+        for t in np.nonzero(sr)[0]:
+            partners |= {(t // 64) * 64 + ((sr[t] >> s) & 63) for s in (4, 10, 16)[:(sr[t] & 15) - 1]}
+        assert partners == set(np.nonzero(valid & (sd == -1))[0])
+        # per-tile arithmetic == per-thread table
+        ti = T["tinfo"].reshape(-1, 8)
+        for t in range(NTS):
+            b, nj = ti[t // 64][(t % 64) // 16], ti[t // 64][4 + (t % 64) // 16]
+            assert (tu[t] == -1 and b < 0) or tu[t] == b + ((t >> 2) & 3) * nj + (t & 3)
+        # what other ranks need
+        send = e.plan(0).reshape(-1, 4) if n_ranks > 1 else np.zeros((0, 4), dtype=np.int32)
+        assert len(T["send_slots"]) == len(send) and (nearly > 0) == (len(send) > 0)
+        assert nlocal <= ngroups
+        e.close()
