@@ -181,3 +181,22 @@ def test_unique_layout_with_held_suarez_forcing():
         assert _same(u.download_state(0), d.download_state(0), range(6))
     finally:
         d.close(); u.close()
+
+
+@pytest.mark.parametrize("order,nu", [(2, (1.0e5, 1.0e5, 1.0e5)), (4, (0.0, 0.0, 0.0)), (0, (1.0e15, 1.0e15, 1.0e15))])
+def test_other_viscosity_branches_on_the_unique_layout(order, nu):
+    """StepAfterSubCycle's other branches (one viscosity pass, no viscosity at all) in the node-unique interpreter."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(5, 6, 6)
+    d = Engine(g, nu=nu, hypervis_order=order, options={"unique_layout": 0})
+    u = Engine(g, nu=nu, hypervis_order=order, options={"unique_layout": 1})
+    try:
+        for e in (d, u):
+            e.upload_state(0, start)
+            for _ in range(3):
+                e.step_ars343(100.0)
+            e.sync()
+        assert u.info(INFO_UNIQUE_INSTANCES) > 0
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+    finally:
+        d.close(); u.close()
