@@ -972,12 +972,12 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // state transfer
 
-static int settle_instance(tmx_engine * e, int ix);
-static int check_state_args(tmx_engine * e, int patch, int instance) {
+static int settle_instance(tmx_engine * e, int ix, bool read_only);
+static int check_state_args(tmx_engine * e, int patch, int instance, bool read_only = false) {
 	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
 	REQUIRE(patch >= 0 && patch < e->cfg.n_patches && e->patches[patch].owner == e->cfg.rank, TMX_ERR_INVALID, "patch %d is not local", patch);
 	REQUIRE(instance >= 0 && instance < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range", instance);
-	return settle_instance(e, instance);
+	return settle_instance(e, instance, read_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1136,7 +1136,7 @@ extern "C" int tmx_upload_tracers(tmx_engine * e, int patch, int instance, const
 }
 
 extern "C" int tmx_download_tracers(tmx_engine * e, int patch, int instance, double * tracers) {
-	int r = check_state_args(e, patch, instance);
+	int r = check_state_args(e, patch, instance, true);
 	if (r) return r;
 	REQUIRE(e->nt > 0 && tracers, TMX_ERR_INVALID, "tmx_download_tracers: engine has no tracers / null array");
 	const PatchInfo & P = e->patches[patch];
@@ -1155,7 +1155,7 @@ extern "C" int tmx_download_tracers(tmx_engine * e, int patch, int instance, dou
 }
 
 extern "C" int tmx_download_state(tmx_engine * e, int patch, int instance, double * node, double * redge) {
-	int r = check_state_args(e, patch, instance);
+	int r = check_state_args(e, patch, instance, true);
 	if (r) return r;
 	REQUIRE(node && (redge || e->sw), TMX_ERR_INVALID, "tmx_download_state: null array");
 	const PatchInfo & P = e->patches[patch];
@@ -1252,7 +1252,7 @@ static int image_buffer(tmx_engine * e, size_t n) {
 }
 
 extern "C" int tmx_pack_active_state(tmx_engine * e, int patch, int instance, void * dst, size_t dst_bytes) {
-	int r = check_state_args(e, patch, instance);
+	int r = check_state_args(e, patch, instance, true);
 	if (r) return r;
 	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "restart image with the shallow-water equation set is not supported");
 	const PatchInfo & P = e->patches[patch];
@@ -1313,10 +1313,10 @@ static int check_ready(tmx_engine * e) {
 	REQUIRE(e && e->finalized && !plan_only(e), TMX_ERR_INVALID, "engine not finalized");
 	return TMX_OK;
 }
-static int settle_instance(tmx_engine * e, int ix);
-static int check_inst(tmx_engine * e, int ix) {
+static int settle_instance(tmx_engine * e, int ix, bool read_only);
+static int check_inst(tmx_engine * e, int ix, bool read_only = false) {
 	REQUIRE(ix >= 0 && ix < e->cfg.n_instances, TMX_ERR_INVALID, "instance %d out of range [0,%d)", ix, e->cfg.n_instances);
-	return settle_instance(e, ix);
+	return settle_instance(e, ix, read_only);
 }
 static double * inst(tmx_engine * e, int ix) { return e->d_state + (size_t)e->imap[ix] * e->inst_stride; }
 // where the U,V slabs of an instance live (the first 2 L slabs of a slot): its slot, or the slot it shares U,V with
@@ -1325,10 +1325,18 @@ static const double * inst_uv(tmx_engine * e, int ix) { return e->d_state + (siz
 // slot, or whose slot others read (b == ix or imap[b] == ix), gets the CopyData that was left out.  b < 0: all of them.
 // Shared U,V slabs are settled inside a stepper program too: the operations that understand them (the fused explicit stage)
 // do not come through here.
-static int settle_instance(tmx_engine * e, int ix) {
-	// slots in node-unique form (left by tmx_step) go back to the element-major form before anything else looks at them
-	if (e->u.n_uform)
-		for (int b = 0; b < (int)e->u.form.size(); b++) if (e->u.form[b]) { int r = tmxu_to_d(e, b); if (r) return r; }
+// read_only: the caller only reads instance ix (downloads, output interpolation, the restart image).  The node-unique form of an
+// instance converted for a reader stays valid beside the element-major one (form 2), so a download between two steps costs one
+// conversion of the instance read and the next tmx_step neither checks nor converts anything.
+static int settle_instance(tmx_engine * e, int ix, bool read_only = false) {
+	// slots in node-unique form (left by tmx_step) go back to the element-major form before anything else looks at them: the one
+	// named (where nothing shares slots), else all of them; a writer invalidates the node-unique copy
+	if (e->u.n_uform) {
+		bool one = ix >= 0 && e->imap[ix] == ix && e->uvmap[ix] == ix;
+		for (int b = 0; b < (int)e->imap.size() && one; b++) if (b != ix && (e->imap[b] == ix || e->uvmap[b] == ix)) one = false;
+		for (int b = 0; b < (int)e->u.form.size(); b++)
+			if (e->u.form[b] && (!one || b == ix)) { int r = tmxu_to_d(e, b, one && read_only); if (r) return r; }
+	}
 	if (e->n_shared && !e->in_program)
 		for (int b = 0; b < (int)e->imap.size(); b++) {
 			if (e->imap[b] == b || !(ix < 0 || b == ix || e->imap[b] == ix)) continue;
@@ -1401,7 +1409,7 @@ extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int
 	int r; if ((r = check_ready(e)) || (r = check_inst(e, dst))) return r;
 	REQUIRE(coeff && n_coeff > dst && n_coeff <= e->cfg.n_instances, TMX_ERR_INVALID,
 		"linear_combine_data: %d coefficients for destination %d and %d instances", n_coeff, dst, e->cfg.n_instances);
-	if ((r = settle_instance(e, -1))) return r;
+	if ((r = settle_instance(e, -1, false))) return r;
 	const double * src[12]; double cf[12];
 	int n = 1;
 	src[0] = inst(e, dst); cf[0] = coeff[dst];
@@ -2281,7 +2289,7 @@ static InterpArgs interp_args(const tmx_interp * q) {
 
 extern "C" int tmx_interp_state(tmx_engine * e, tmx_interp * q, int instance, int only_at, int include_ref, int primitive,
 	double earth_radius, double * out) {
-	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance, true))) return r;
 	REQUIRE(q && q->owner == e && out, TMX_ERR_INVALID, "tmx_interp_state: bad plan / null output");
 	REQUIRE(only_at >= 0 && only_at <= 2, TMX_ERR_INVALID, "tmx_interp_state: only_variables_at must be 0, 1 or 2");
 	REQUIRE(!primitive || q->has_rll, TMX_ERR_INVALID, "tmx_interp_state: convert_to_primitive needs rll_from_abp in the plan");
@@ -2300,7 +2308,7 @@ extern "C" int tmx_interp_state(tmx_engine * e, tmx_interp * q, int instance, in
 }
 
 extern "C" int tmx_interp_tracers(tmx_engine * e, tmx_interp * q, int instance, double * out) {
-	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance, true))) return r;
 	REQUIRE(q && q->owner == e && out, TMX_ERR_INVALID, "tmx_interp_tracers: bad plan / null output");
 	REQUIRE(e->nt > 0, TMX_ERR_INVALID, "Unable to Interpolate with no tracers.");
 	tmxk_interp_tracers(e, make_params(e), interp_args(q), inst(e, instance), q->d_out);
@@ -2907,7 +2915,7 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	// that shares is given its own first, which for the model state never happens), so that a step that stays element-major keeps them
 	for (int k = 0; k < e->cfg.n_instances && !trust; k++) {
 		if (!(livein >> k & 1u) || u.form[k]) continue;
-		if ((e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k))) return r;
+		if ((e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k, false))) return r;
 		bool ok = true;
 		if ((r = tmxu_check(e, k, &ok))) return r;
 		if (!ok) {      // copies differ: this step runs element-major
@@ -2919,12 +2927,12 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	}
 	u.backoff = 0;
 	// instance maps to identity (shares left by an element-major program, that is: nothing is in U form; U,V slabs shared by the last node-unique step stay shared)
-	if ((e->n_shared || e->n_uvshared) && u.n_uform == 0) { if ((r = settle_instance(e, -1))) return r; }
+	if ((e->n_shared || e->n_uvshared) && u.n_uform == 0) { if ((r = settle_instance(e, -1, false))) return r; }
 	for (int k = 0; k < e->cfg.n_instances; k++)
 		if ((livein >> k & 1u) && !u.form[k] && (r = tmxu_to_u(e, k, false, nullptr))) return r;
 	// everything the program writes is in U form afterwards; whatever else it leaves alone keeps its form
 	for (int k = 0; k < e->cfg.n_instances; k++)
-		if ((written >> k & 1u) && !u.form[k]) { u.form[k] = 1; u.n_uform++; }
+		if (written >> k & 1u) { if (!u.form[k]) u.n_uform++; u.form[k] = 1; }      // (form 2 -> 1: the element-major copy goes stale)
 	e->in_program = true;
 	r = run_program_unique(e, p);
 	e->in_program = false;

@@ -116,7 +116,7 @@ struct UniqueLayout {
 	int * d_send_slots = nullptr;
 	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_early = 0, n_late = 0; bool split = false;
 	int * d_check = nullptr;                 // consistency flag of the D -> U conversion
-	std::vector<char> form;                  // per data instance: 0 = the element-major slot is current, 1 = the node-unique one
+	std::vector<char> form;                  // per data instance: 0 = the element-major slot is current, 1 = the node-unique one, 2 = both (converted for a reader)
 	// U storage holds one slot more than there are instances: a stage whose update instance is also one of its sources (in-place
 	// accumulation, a combination with a non-zero coefficient of its destination) must not overwrite nodes other threads still
 	// read -- in the unique slabs a node is read by up to four elements' threads -- so it writes the spare slot, which then
@@ -289,7 +289,7 @@ KParams tmxu_params(const tmx_engine * e, const KParams & base);          // thr
 KParams tmxu_params_columns(const tmx_engine * e, const KParams & base);  // one thread per unique column (column solve)
 int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent);   // D form -> U form of one slot (check: verify that the copies agree)
 int tmxu_check(tmx_engine * e, int slot, bool * consistent);              // do the copies of every node of an element-major slot agree?
-int tmxu_to_d(tmx_engine * e, int slot);                                  // U form -> D form
+int tmxu_to_d(tmx_engine * e, int slot, bool keep_u = false);                                  // U form -> D form
 void tmxuk_slots_from_u(tmx_engine * e, const double * xu);               // partial slots <- the values of their nodes (DSS of an instance that is already consistent inside patches)
 void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1);              // finish the seam nodes left in the partial slots
 void tmxuk_pack(tmx_engine * e);                                          // partial slots other ranks need -> send buffer

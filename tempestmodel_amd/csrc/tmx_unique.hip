@@ -291,7 +291,7 @@ int tmxu_check(tmx_engine * e, int slot, bool * consistent) {
 int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent) {
 	UniqueLayout & u = e->u;
 	if (consistent) *consistent = true;
-	if (u.form[slot] == 1) return TMX_OK;
+	if (u.form[slot] != 0) { u.form[slot] = 1; return TMX_OK; }      // (form 2: both copies were current; the caller is about to write the node-unique one)
 	const double * xd = e->d_state + (size_t)slot * e->inst_stride;
 	double * xu = u.d_ustate + (size_t)u.uslot[slot] * u.ustride;
 	const int ny = std::min(e->nslab, 64);
@@ -306,14 +306,21 @@ int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent) {
 	return TMX_OK;
 }
 
-int tmxu_to_d(tmx_engine * e, int slot) {
+// keep_u: the caller only reads -- the node-unique copy stays valid beside the element-major one (form 2)
+int tmxu_to_d(tmx_engine * e, int slot, bool keep_u) {
 	UniqueLayout & u = e->u;
 	if (u.form[slot] == 0) return TMX_OK;
+	if (u.form[slot] == 2) {      // the element-major copy is current already
+		if (!keep_u) { u.form[slot] = 0; u.n_uform--; }
+		return TMX_OK;
+	}
 	double * xd = e->d_state + (size_t)slot * e->inst_stride;
 	const double * xu = u.d_ustate + (size_t)u.uslot[slot] * u.ustride;
 	const int ny = std::min(e->nslab, 64);
 	hipLaunchKernelGGL(k_u_to_d, dim3((e->ncol + 255) / 256, ny), dim3(256), 0, e->stream, e->nslab, (size_t)e->NS, (size_t)u.NUS, e->ncol, xu, xd, (const int *)u.d_ucol_of_dcol);
-	u.form[slot] = 0; u.n_uform--; u.conversions++;
+	u.conversions++;
+	if (keep_u) u.form[slot] = 2;
+	else { u.form[slot] = 0; u.n_uform--; }
 	return TMX_OK;
 }
 

@@ -48,7 +48,7 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
         conv = u.info(INFO_UNIQUE_CONVERSIONS)
         for ix in range(ni):
             assert _same(u.download_state(ix), d.download_state(ix), range(npatch)), (scheme, "instance", ix)
-        assert u.info(INFO_UNIQUE_INSTANCES) == 0 and u.info(INFO_UNIQUE_CONVERSIONS) > conv      # the download converted them back
+        assert u.info(INFO_UNIQUE_CONVERSIONS) > conv      # the downloads converted what they read (a reader leaves the node-unique copy valid beside it)
         # and on from the converted state: two more steps
         for k in range(2):
             d.step(scheme, 150.0); u.step(scheme, 150.0)
@@ -197,6 +197,37 @@ def test_other_viscosity_branches_on_the_unique_layout(order, nu):
                 e.step_ars343(100.0)
             e.sync()
         assert u.info(INFO_UNIQUE_INSTANCES) > 0
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+    finally:
+        d.close(); u.close()
+
+
+def test_download_between_steps_keeps_the_unique_form():
+    """A read-only entry point converts the instance it names and leaves its node-unique copy valid: the next step neither checks
+    nor converts (conversion count), other instances are not touched, and the result is the element-major engine's."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(5, 6, 6)
+    d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1})
+    try:
+        for e in (d, u):
+            e.upload_state(0, start)
+            e.step_ars343(120.0); e.step_ars343(120.0)
+        n_u = u.info(INFO_UNIQUE_INSTANCES)
+        c0 = u.info(INFO_UNIQUE_CONVERSIONS)
+        a = u.download_state(0)
+        assert u.info(INFO_UNIQUE_CONVERSIONS) == c0 + 1 and u.info(INFO_UNIQUE_INSTANCES) == n_u      # one conversion, nothing left the unique form
+        assert _same(a, d.download_state(0), range(6))
+        u.download_state(0)
+        assert u.info(INFO_UNIQUE_CONVERSIONS) == c0 + 1                                                  # the element-major copy is current
+        for e in (d, u):
+            e.step_ars343(120.0)
+        assert u.info(INFO_UNIQUE_CONVERSIONS) == c0 + 1                                                  # the step neither checked nor converted
+        d.sync(); u.sync()
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+        # a writer of the same instance invalidates the node-unique copy
+        for e in (d, u):
+            e.apply_dss(0); e.step_ars343(120.0)
+        d.sync(); u.sync()
         assert _same(u.download_state(0), d.download_state(0), range(6))
     finally:
         d.close(); u.close()
