@@ -490,6 +490,7 @@ extern "C" int tmx_set_patch_physics_inputs(tmx_engine * e, int patch, const dou
 	}
 	if (!P.physics_set) e->patches_with_physics++;
 	P.physics_set = true;
+	e->u.physics_dirty = true;
 	return TMX_OK;
 }
 
@@ -3004,14 +3005,39 @@ extern "C" int tmx_set_strang_off_centering(tmx_engine * e, double off_centering
 
 extern "C" int tmx_step_ars343(tmx_engine * e, double dt) { return tmx_step(e, TMX_SCHEME_ARS343, 0, 0, dt); }
 
+static int held_suarez_unique(tmx_engine * e, int instance, double dt, bool * done);
 extern "C" int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt) {
-	int r; if ((r = check_ready(e)) || (r = check_inst(e, instance))) return r;
+	int r; if ((r = check_ready(e))) return r;
+	if (e->u.built && !e->sw) { bool done = false; if ((r = held_suarez_unique(e, instance, dt, &done)) || done) return r; }
+	if ((r = check_inst(e, instance))) return r;
 	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "Held-Suarez physics with the shallow-water equation set is not supported");
 	for (int lp : e->local_patches)
 		REQUIRE(e->patches[lp].physics_set, TMX_ERR_INVALID, "tmx_set_patch_physics_inputs was not called for patch %d", lp);
 	ProfScope ps(e, TMX_K_LINCOMB);
 	tmxk_held_suarez(e, make_params(e), inst(e, instance), e->track_surface ? surface_slots(e, instance) : nullptr, dt);
 	return launch_check("physics_held_suarez");
+}
+// the same on the unique columns of an instance that tmx_step left in node-unique form (no conversion there and back): the forcing is
+// column by column, so with inputs that agree on all copies of a node (checked) one evaluation per node is every copy's result.
+// *done = false: not applicable, the caller takes the element-major route.
+static int held_suarez_unique(tmx_engine * e, int instance, double dt, bool * done) {
+	*done = false;
+	UniqueLayout & u = e->u;
+	if (!u.built || instance < 0 || instance >= e->cfg.n_instances || u.form[instance] == 0 || e->imap[instance] != instance) return TMX_OK;
+	for (int lp : e->local_patches) if (!e->patches[lp].physics_set) return TMX_OK;      // (the element-major route reports it)
+	bool ok = false;
+	int r = tmxu_physics_inputs(e, &ok);
+	if (r || !ok) return r;
+	if ((r = u_own_uv(e, instance))) return r;
+	ProfScope ps(e, TMX_K_LINCOMB);
+	// the tracked surface slots live with the element-major slot (the stage algebra of tmx_step keeps them there); their copies agree
+	// whenever the instance's do (they are covered by the check that admitted the instance to the node-unique form)
+	if (e->track_surface) tmxuk_gather_rows(e, 2, surface_slots(e, instance), u.d_surf_u);
+	tmxk_held_suarez(e, tmxu_params_columns(e, make_params(e)), uinst(e, instance), e->track_surface ? u.d_surf_u : nullptr, dt);
+	u.form[instance] = 1;      // (an element-major copy kept for a reader is stale now)
+	u_written(e, instance);
+	*done = true;
+	return launch_check("physics_held_suarez (node-unique)");
 }
 
 // ---- Kessler microphysics (BASELINE config 4) ----

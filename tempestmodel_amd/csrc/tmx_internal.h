@@ -128,6 +128,10 @@ struct UniqueLayout {
 	// that treats the copies of a node differently in the last bit, as the reference's does) the check itself -- a pass over the
 	// instance and a host synchronisation -- is not repeated every step: from the second failure in a row on, the next `skip_steps` steps do not try
 	int backoff = 0, skip_steps = 0;      // backoff: failures in a row
+	// column physics on the unique columns (Held-Suarez forcing): its per-column inputs (latitude, sin / cos of it, pinned surface
+	// pressure) per unique node, valid only if every copy of a node carries the same bits (checked on the device when they change)
+	bool physics_dirty = true, physics_ok = false;
+	double * d_surf_u = nullptr;             // [2][NUS] the tracked surface slots of the instance being forced, per unique column
 };
 
 struct tmx_engine {
@@ -294,6 +298,8 @@ void tmxuk_slots_from_u(tmx_engine * e, const double * xu);               // par
 void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1);              // finish the seam nodes left in the partial slots
 void tmxuk_pack(tmx_engine * e);                                          // partial slots other ranks need -> send buffer
 void tmxuk_pack_p2p(tmx_engine * e, int buf);
+int tmxu_physics_inputs(tmx_engine * e, bool * ok);                       // refresh the per-unique-column physics inputs; *ok: the copies of every node agree
+void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu);   // xu[r][u] = xd[r][representative column of u]
 
 // kernel launchers (tmx_k_*.hip)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,

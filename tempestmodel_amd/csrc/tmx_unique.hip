@@ -23,7 +23,7 @@ template <class T> static int up(T ** d, const std::vector<T> & h, size_t * byte
 void tmxu_free(tmx_engine * e) {
 	UniqueLayout & u = e->u;
 	void * ptrs[] = { u.d_ustate, u.d_part, u.d_g2d_t, u.d_g2d_u, u.d_t_ucol, u.d_t_sdst, u.d_t_sred, u.d_t_tinfo, u.d_t_dcol, u.d_ucol_of_dcol, u.d_u_rep, u.d_slot_ucol,
-		u.d_gsrc, u.d_gdst, u.d_gn, u.d_gx, u.d_gtype, u.d_send_slots, u.d_quads_early, u.d_quads_late, u.d_check };
+		u.d_gsrc, u.d_gdst, u.d_gn, u.d_gx, u.d_gtype, u.d_send_slots, u.d_quads_early, u.d_quads_late, u.d_check, u.d_surf_u };
 	for (void * q : ptrs) if (q) hipFree(q);
 	u = UniqueLayout();
 }
@@ -210,6 +210,8 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 	HIPCHK(hipMalloc((void **)&u.d_ustate, ub)); HIPCHK(hipMemset(u.d_ustate, 0, ub)); *bytes += ub;
 	HIPCHK(hipMalloc((void **)&u.d_part, pb)); HIPCHK(hipMemset(u.d_part, 0, pb)); *bytes += pb;
 	HIPCHK(hipMalloc((void **)&u.d_check, sizeof(int))); HIPCHK(hipMemset(u.d_check, 0, sizeof(int)));
+	HIPCHK(hipMalloc((void **)&u.d_surf_u, (size_t)2 * u.NUS * sizeof(double))); HIPCHK(hipMemset(u.d_surf_u, 0, (size_t)2 * u.NUS * sizeof(double)));
+	*bytes += (size_t)2 * u.NUS * sizeof(double);
 	u.form.assign(e->cfg.n_instances, 0);
 	u.uslot.resize(e->cfg.n_instances);
 	for (int k = 0; k < e->cfg.n_instances; k++) u.uslot[k] = k;
@@ -278,8 +280,11 @@ int tmxu_check(tmx_engine * e, int slot, bool * consistent) {
 	UniqueLayout & u = e->u;
 	const double * xd = e->d_state + (size_t)slot * e->inst_stride;
 	const int ny = std::min(e->nslab, 64);
+	// (with tracked surface slots -- the two rows behind the slabs that the Held-Suarez forcing reads -- those are checked too: the
+	// forcing on the unique columns relies on it)
+	const int nrows = e->nslab + (e->track_surface ? 2 : 0);
 	HIPCHK(hipMemsetAsync(u.d_check, 0, sizeof(int), e->stream));
-	hipLaunchKernelGGL(k_check_copies, dim3((e->ncol + 255) / 256, ny), dim3(256), 0, e->stream, e->nslab, (size_t)e->NS, e->ncol, xd,
+	hipLaunchKernelGGL(k_check_copies, dim3((e->ncol + 255) / 256, ny), dim3(256), 0, e->stream, nrows, (size_t)e->NS, e->ncol, xd,
 		(const int *)u.d_ucol_of_dcol, (const int *)u.d_u_rep, u.d_check);
 	int h = 0;
 	HIPCHK(hipMemcpyAsync(&h, u.d_check, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -418,4 +423,34 @@ void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1) {
 	hipLaunchKernelGGL(k_dss_u, dim3(8 * ((nx + 7) / 8) * ny), dim3(64, 4), 0, e->stream, e->L, e->nt, (size_t)u.NUS, (size_t)u.NP, xu, (const double *)u.d_part,
 		(const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride, g1, (const int *)u.d_gsrc, (const int *)u.d_gdst,
 		(const int *)u.d_gn, (const int *)u.d_gx, (const int *)u.d_gtype, (const double *)e->d_xmat, g0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// column physics on the unique columns
+
+void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu) {
+	const UniqueLayout & u = e->u;
+	hipLaunchKernelGGL(k_d_to_u, dim3((u.NU + 255) / 256, std::min(nrows, 64)), dim3(256), 0, e->stream, nrows, (size_t)e->NS, (size_t)u.NUS, u.NU, xd, xu, (const int *)u.d_u_rep);
+}
+
+// The per-column inputs of the Held-Suarez forcing (rows G2_LAT .. G2_COSLAT of the 2-D geometry: latitude, pinned surface
+// pressure, sin and cos of the latitude) per unique column, and whether the forcing may run there at all: only if every copy
+// of a node carries the same input bits -- then every copy would receive the same result, which is what one unique column holds.
+int tmxu_physics_inputs(tmx_engine * e, bool * ok) {
+	UniqueLayout & u = e->u;
+	if (u.physics_dirty) {
+		static_assert(G2_PS == G2_LAT + 1 && G2_SINLAT == G2_LAT + 2 && G2_COSLAT == G2_LAT + 3, "physics input rows are contiguous");
+		const double * xd = e->d_g2d + (size_t)G2_LAT * e->NS;
+		HIPCHK(hipMemsetAsync(u.d_check, 0, sizeof(int), e->stream));
+		hipLaunchKernelGGL(k_check_copies, dim3((e->ncol + 255) / 256, 4), dim3(256), 0, e->stream, 4, (size_t)e->NS, e->ncol, xd,
+			(const int *)u.d_ucol_of_dcol, (const int *)u.d_u_rep, u.d_check);
+		tmxuk_gather_rows(e, 4, xd, u.d_g2d_u + (size_t)G2_LAT * u.NUS);
+		int h = 0;
+		HIPCHK(hipMemcpyAsync(&h, u.d_check, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipStreamSynchronize(e->stream));
+		u.physics_ok = (h == 0);
+		u.physics_dirty = false;
+	}
+	*ok = u.physics_ok;
+	return TMX_OK;
 }

@@ -164,20 +164,42 @@ def test_multirank_steps_on_the_unique_layout_loopback(n_ranks, scheme):
             e.close()
 
 
-def test_unique_layout_with_held_suarez_forcing():
-    """Column physics between the steps works on the element-major form (converted there and back); the forcing may leave the
-    copies of a node different in the last bit, in which case the next step runs element-major: results are identical either way."""
+@pytest.mark.parametrize("pinned_ps", [False, True])
+def test_unique_layout_with_held_suarez_forcing(pinned_ps):
+    """The Held-Suarez forcing between the steps runs on the unique columns of the instance tmx_step left in node-unique form -- no
+    conversion there and back (conversion count) -- when its per-column inputs agree on all copies of a node (checked on the device);
+    with the tracked surface slots of the reference (HeldSuarezPhysics.cpp:113-116) and with a pinned surface pressure.  Identical to
+    the element-major engine; inputs that differ between copies send the forcing back to the element-major form, again identical."""
     from tempestmodel_amd.engine import Engine
     g, start = gu.make_grid(4, 8, 6)
+    sp = [np.full_like(np.asarray(g.patches[p].lat), 1.0e5) + 50.0 * np.cos(np.asarray(g.patches[p].lat)) for p in range(6)] if pinned_ps else None
     d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1})
     try:
         for e in (d, u):
-            e.set_physics_inputs(None)
+            e.set_physics_inputs(sp)
             e.upload_state(0, start)
-            for _ in range(4):
+            for _ in range(2):
+                e.step_ars343(100.0)
+                e.held_suarez(0, 100.0)
+        c0 = u.info(INFO_UNIQUE_CONVERSIONS)
+        for e in (d, u):
+            for _ in range(3):
                 e.step_ars343(100.0)
                 e.held_suarez(0, 100.0)
             e.sync()
+        assert u.info(INFO_UNIQUE_CONVERSIONS) == c0 and u.info(INFO_UNIQUE_INSTANCES) > 0      # nothing went back and forth
+        assert _same(u.download_state(0), d.download_state(0), range(6))
+        # inputs that differ between the copies of a node (last bit of the latitude of one element's nodes): element-major forcing
+        lat0 = np.array(g.patches[0].lat, copy=True)
+        g.patches[0].lat = lat0.copy(); g.patches[0].lat[1:5, 1:5] = np.nextafter(lat0[1:5, 1:5], 10.0)
+        for e in (d, u):
+            e.set_physics_inputs(sp)
+            for _ in range(2):
+                e.step_ars343(100.0)
+                e.held_suarez(0, 100.0)
+            e.sync()
+        g.patches[0].lat = lat0
+        assert u.info(INFO_UNIQUE_CONVERSIONS) > c0
         assert _same(u.download_state(0), d.download_state(0), range(6))
     finally:
         d.close(); u.close()
