@@ -424,6 +424,7 @@ def main():
         eng.step_ars343(dt)
     barrier()
     wall = time.perf_counter() - t0
+    unique_after_timed = eng.info(13)      # data instances in node-unique form when the timed region ended
     # per-kernel device time: the same K steps again with HIP events around every launch on the
     # engine's stream (kept out of the timed region: the event markers cost a few % of wall time)
     eng.profile_enable(True)
@@ -550,8 +551,8 @@ def main():
                            halo_note),
                        "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30,
                        # tmx_set_option("unique_layout") / TMX_UNIQUE: inside tmx_step the state is held once per patch node
-                       "state_layout": ("node-unique inside tmx_step (%d instances in that form at the end of the run, %d partial slots, "
-                                        "%d node groups left to the DSS kernel of %d)" % (eng.info(13), eng.info(15), eng.info(16), eng.info(2)))
+                       "state_layout": ("node-unique inside tmx_step (%d instances in that form at the end of the timed region, %d partial slots, "
+                                        "%d node groups left to the DSS kernel of %d)" % (unique_after_timed, eng.info(15), eng.info(16), eng.info(2)))
                                        if eng.info(12) == 1 else "element-major (16 nodes per element, seam nodes duplicated)"},
             # `bound`: what limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64
             # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
