@@ -350,8 +350,15 @@ __device__ __forceinline__ void wave_sync() {
 // runs of 32 bytes in four different rows, four times the L1 / L2 requests per load instruction (measured: 2.1 x the L2 requests
 // of the element-major kernel and +12 % time for 23 % fewer bytes).
 #ifndef TMX_UQ_ROWLANES
-#define TMX_UQ_ROWLANES 0      // measured with the LDS rows as they are: the permuted lanes cost the contractions two-way bank conflicts (hyperviscosity pass 149 -> 196 us)
+#define TMX_UQ_ROWLANES 0      // measured: with the LDS rows as they were the permuted lanes cost the contractions two-way bank conflicts (hyperviscosity pass 149 ->
+                               // 196 us); with padded rows (lds_pos) the explicit stage is level (0.577 against 0.576 ms per step) and the hyperviscosity pass 4 % slower:
+                               // halving the L2 requests buys nothing, so the identity map stays
 #endif
+// LDS position of tile position l in a contraction row.  With the row-major lane map a half-wavefront holds node rows i = 0, 1 of all
+// four elements, whose 128-byte blocks would fall on the same banks two by two; eight doubles of padding in front of elements 2, 3
+// (rows of 80 instead of 64 doubles) separate them.
+#define TMX_UQ_ROWLEN(UQ_) (((UQ_) && TMX_UQ_ROWLANES) ? 80 : 64)
+template <bool UQ> __device__ __forceinline__ int lds_pos(int l) { return (UQ && TMX_UQ_ROWLANES) ? l + ((l >> 5) << 3) : l; }
 template <bool UQ> __device__ __forceinline__ int tile_lane() {
 	const int h = threadIdx.x;
 	return (UQ && TMX_UQ_ROWLANES) ? ((h & 3) | (((h >> 2) & 3) << 4) | ((h >> 4) << 2)) : h;
@@ -392,10 +399,11 @@ static inline dim3 wg_grid(bool uq, const KParams & p, int ntiles, int nyb) {
 //               slot -2 - sdst, k_dss_u finishes the node
 // srow: NV rows of 64 doubles of LDS private to the wavefront.  LDS operations of one wavefront execute in order, so the
 // exchange needs no workgroup barrier; the wavefront-scope fence keeps the compiler from moving the reads above the writes.
-template <int NV>
-__device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[64], int lane, int sdst, int sred, const double (&v)[NV],
+template <int NV, int RL>
+__device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[RL], int lane_, int sdst, int sred, const double (&v)[NV],
 	double * __restrict__ xo, const int (&slab)[NV], int nv)
 {
+	const int lane = lds_pos<RL != 64>(lane_);
 #ifdef TMX_ABL_UQ_DSTORES     // ablation builds (wrong results): every lane stores its own value to consecutive addresses, no exchange
 	{
 		const int c = min((int)(blockIdx.x & 1023) * 64 + lane, p.NSS - 1);
@@ -415,11 +423,11 @@ __device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[64]
 #pragma unroll
 	for (int t = 0; t < NV; t++) o[t] = v[t];
 	if (n == 2) {
-		const int l1 = (sred >> 4) & 63;
+		const int l1 = lds_pos<RL != 64>((sred >> 4) & 63);
 #pragma unroll
 		for (int t = 0; t < NV; t++) if (t < nv) o[t] = 0.5 * (v[t] + srow[t][l1]);
 	} else if (n == 4) {
-		const int l1 = (sred >> 4) & 63, l2 = (sred >> 10) & 63, l3 = (sred >> 16) & 63;
+		const int l1 = lds_pos<RL != 64>((sred >> 4) & 63), l2 = lds_pos<RL != 64>((sred >> 10) & 63), l3 = lds_pos<RL != 64>((sred >> 16) & 63);
 #pragma unroll
 		for (int t = 0; t < NV; t++) if (t < nv) {
 			const double p0 = v[t] + srow[t][l1], p1 = srow[t][l2] + srow[t][l3];

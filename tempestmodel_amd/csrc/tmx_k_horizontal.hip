@@ -50,11 +50,12 @@ template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM>
 __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
 	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
 {
-	__shared__ double s[KT_H][MF ? 1 : 9][64];
+	__shared__ double s[KT_H][MF ? 1 : 9][TMX_UQ_ROWLEN(UQ)];
 	__shared__ double sDw[MF ? 1 : KT_H][16], sSw[MF ? 1 : KT_H][16];      // every wavefront its own copy of the operator tables (no workgroup barrier before the contractions)
 	__shared__ double rmtab[TMX_H_EXNER_LDS ? TMX_RMTAB_DOUBLES : 1];      // exp / log tables of the Exner function: from global memory they are two dependent gathers per wavefront
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	const int tid = ty * 64 + lane;
+	const int lp = lds_pos<UQ>(lane);      // where this lane's values sit in an LDS row
 	if (!MF && lane < 16) { sDw[ty][lane] = p.dx[lane]; sSw[ty][lane] = p.stiff[lane]; }
 	const double * sD = sDw[MF ? 0 : ty], * sS = sSw[MF ? 0 : ty];
 	if (TMX_H_EXNER_LDS) tmx_rm_tables_to_lds(rmtab, tid, 64 * KT_H);
@@ -173,10 +174,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			lin_load<NT, PM>(xbase.src, TMX_SLAB_T(L, k) * SS, cb2, xT); lin_load<NT, PM>(xbase.src, TMX_SLAB_R(L, k) * SS, cb2, xR);
 		}
 	} else {
-	s[ty][0][lane] = ua;  s[ty][1][lane] = ub;  s[ty][2][lane] = ux;
-	s[ty][3][lane] = exn; s[ty][4][lane] = ke;
-	s[ty][5][lane] = fa * rh; s[ty][6][lane] = fa * rt;
-	s[ty][7][lane] = fb * rh; s[ty][8][lane] = fb * rt;
+	s[ty][0][lp] = ua;  s[ty][1][lp] = ub;  s[ty][2][lp] = ux;
+	s[ty][3][lp] = exn; s[ty][4][lp] = ke;
+	s[ty][5][lp] = fa * rh; s[ty][6][lp] = fa * rt;
+	s[ty][7][lp] = fb * rh; s[ty][8][lp] = fb * rt;
 	wave_sync();      // the rows are this wavefront's own
 	if (!act) return;
 #ifdef TMX_H_SCHED_BARRIER
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		if (TMX_H_FUSE_W && ty > 0) lin_load<NT, PM>(xbase.src, TMX_SLAB_W(L, k) * SS, cb2, xW);
 	}
 
-	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<UQ>(lane & 48);
 #pragma unroll
 	for (int t = 0; t < 4; t++) {
 		const int la = eb + 4 * t + j;        // node (t, j)
@@ -280,12 +281,12 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		// W on the interfaces inside the tile (part 2 below, :1612-1659): interface k takes (u x zeta)_xi of the levels k - 1 and k,
 		// which wavefront ty - 1 hands over through its own (now free) LDS row; only the tile's first interface is left to
 		// k_h_w_update, which therefore needs the hand-off array for the first and the last level of a tile only
-		s[ty][0][lane] = uczx;
+		s[ty][0][lp] = uczx;
 		if (ty == 0 || ty == KT_H - 1) stu(ucz + (size_t)k * NS, colb, uczx);
 		__syncthreads();       // wavefronts above the top level have left; the barrier counts the ones still running
 		if (ty > 0) {
 			double v = 0.0;
-			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lane];
+			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lp];
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
 			outW = bW + dt * v;
 			if (!UQ) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		// rows 1..5 of the wavefront's LDS block (row 0 is being read by the wavefront above); W only where this kernel updates it
 		const double v[5] = { outU, outV, outR, outT, outW };
 		const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
-		seam_store<5>(p, &s[ty][1], lane, sdst, sred, v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
+		seam_store<5, TMX_UQ_ROWLEN(UQ)>(p, &s[ty][1], lane, sdst, sred, v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
 	}
 }
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	if (UQ) {
 		const double v1[1] = { wnew };
 		const int slab[1] = { TMX_SLAB_W(L, k) };
-		seam_store<1>(p, &sw[ty][0], lane, p.t_sdst[col], p.t_sred[col], v1, xup, slab, 1);
+		seam_store<1, 64>(p, &sw[ty][0], lane, p.t_sdst[col], p.t_sred[col], v1, xup, slab, 1);
 	} else
 		xup[TMX_SLAB_W(L, k) * NS + col] = wnew;
 }
@@ -760,11 +761,12 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 {
 	// every LDS row here belongs to one wavefront (its level's fields, its own copy of the operator tables): the kernel has no
 	// workgroup barrier, the four wavefronts of a workgroup run decoupled (wave_sync)
-	__shared__ double s[4][8][64];
+	__shared__ double s[4][8][TMX_UQ_ROWLEN(UQ)];
 	__shared__ double sDw[4][16], sSw[4][16];
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	if (lane < 16) { sDw[ty][lane] = p.dx[lane]; sSw[ty][lane] = p.stiff[lane]; }
 	const double * sD = sDw[ty], * sS = sSw[ty];
+	const int lp = lds_pos<UQ>(lane);
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int tix, yb;
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	const bool here = UQ ? (uc >= 0) : (col < p.ncol);
 	const bool actw = (kk <= L) && here;     // interface level (W)
 	const bool actn = (kk < L) && here;      // model level (U,V,rho*theta,rho)
-	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<UQ>(lane & 48);
 
 	double psiT = 0, psiR = 0, psiW = 0, ua = 0, ub = 0;
 	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
@@ -817,9 +819,9 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	}
 	const double cua = c2a0 * ua + c2a1 * ub;
 	const double cub = c2a1 * ua + c2b1 * ub;
-	s[ty][0][lane] = psiT; s[ty][1][lane] = psiR; s[ty][2][lane] = psiW;
-	s[ty][3][lane] = ua;   s[ty][4][lane] = ub;
-	s[ty][5][lane] = j2d * cua; s[ty][6][lane] = j2d * cub;
+	s[ty][0][lp] = psiT; s[ty][1][lp] = psiR; s[ty][2][lp] = psiW;
+	s[ty][3][lp] = ua;   s[ty][4][lp] = ub;
+	s[ty][5][lp] = j2d * cua; s[ty][6][lp] = j2d * cub;
 	wave_sync();
 
 	double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
@@ -843,10 +845,10 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	// what the thread does with its results (seam_store): loaded here, behind the first contraction, used at the end
 	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
 	wave_sync();
-	s[ty][0][lane] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lane] = jn * (c2a1 * daT + c2b1 * dbT);
-	s[ty][2][lane] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lane] = jn * (c2a1 * daR + c2b1 * dbR);
-	s[ty][4][lane] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lane] = je * (c2a1 * daW + c2b1 * dbW);
-	s[ty][6][lane] = dv; s[ty][7][lane] = cl;
+	s[ty][0][lp] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lp] = jn * (c2a1 * daT + c2b1 * dbT);
+	s[ty][2][lp] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lp] = jn * (c2a1 * daR + c2b1 * dbR);
+	s[ty][4][lp] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lp] = je * (c2a1 * daW + c2b1 * dbW);
+	s[ty][6][lp] = dv; s[ty][7][lp] = cl;
 	wave_sync();
 	if (!actw) return;
 
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 		// (level activity is wave-uniform, so all lanes of a wavefront agree on nv; the LDS rows were last read by this wavefront)
 		const double v[5] = { oW, oT, oR, oU, oV };
 		const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
-		seam_store<5>(p, &s[ty][0], lane, sdst, sred, v, xout, slab, (kk < L) ? 5 : 1);
+		seam_store<5, TMX_UQ_ROWLEN(UQ)>(p, &s[ty][0], lane, sdst, sred, v, xout, slab, (kk < L) ? 5 : 1);
 		return;
 	}
 	xout[TMX_SLAB_W(L, kk) * NS + col] = oW;
