@@ -2685,9 +2685,9 @@ static int unique_unit(const Program & p, size_t i) {
 		if (stage_at(i + 1, o.a)) return 4;
 		return 1;
 	case OP_HEXP: return stage_at(i, o.b) ? 3 : 0;
-	case OP_VIMP: case OP_DSS: case OP_HVIS: case OP_VFILT: return 1;
+	case OP_VIMP: case OP_DSS: case OP_HVIS: case OP_VFILT: case OP_VITE: return 1;
 	}
-	return 0;      // V explicit on its own, the explicitly evaluated implicit terms (ARK232)
+	return 0;      // V explicit on its own
 }
 static bool program_fits_unique(const Program & p) {
 	for (size_t i = 0; i < p.size(); ) { const int k = unique_unit(p, i); if (!k) return false; i += k; }
@@ -2801,6 +2801,20 @@ static int u_vimp(tmx_engine * e, int a, int b, double dt, bool share) {
 	return launch_check("column solve (node-unique layout)");
 }
 
+// VerticalDynamicsFEM::StepImplicitTermsExplicitly (ARK232): update -= dt F(initial) for rho*theta, W, rho, column by column -- on the
+// unique columns (every copy of a node would receive the same increment of the same value)
+static int u_vite(tmx_engine * e, int a, int b, double dt) {
+	REQUIRE(a != b && dt != 0.0, TMX_ERR_INVALID, "StepImplicitTermsExplicitly: distinct instances and non-zero dt required");
+	int r;
+	if ((r = u_own_uv(e, a))) return r;      // (the kernel reads U,V of the initial instance through its one pointer)
+	{
+		ProfScope ps(e, TMX_K_VI_ASSEMBLE);
+		tmxk_vi_terms_explicit(e, tmxu_params_columns(e, make_params(e)), uinst(e, a), uinst(e, b), dt, false);
+	}
+	u_written(e, b);
+	return launch_check("explicitly evaluated implicit terms (node-unique layout)");
+}
+
 // DSS of an instance whose copies already agree inside every patch (e.g. after the column solve): only the nodes on patch edges change
 static int u_dss(tmx_engine * e, int ix) {
 	bool overlapped = false;
@@ -2882,6 +2896,7 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 		case OP_VIMP: if ((r = u_vimp(e, o.a, o.b, o.coef, false))) return r; break;
 		case OP_DSS: if ((r = u_dss(e, o.a))) return r; break;
 		case OP_HVIS: if ((r = u_hvis(e, o.a, o.b, o.c, o.coef))) return r; break;
+		case OP_VITE: if ((r = u_vite(e, o.a, o.b, o.coef))) return r; break;
 		case OP_VFILT: break;      // nothing without tracers
 		default: REQUIRE(false, TMX_ERR_UNSUPPORTED, "internal: operation %d has no node-unique form", o.kind);
 		}

@@ -25,7 +25,7 @@ def _same(a, b, patches):
 
 
 @pytest.mark.parametrize("ne,npatch,shape", [(5, 6, 1), (5, 6, 0), (5, 6, 2), (6, 24, 2), (4, 24, 1), (8, 6, 2)])
-@pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "strang", "strang_rk4", "strang_ssprk53"])
+@pytest.mark.parametrize("scheme", ["ars343", "ars232", "ars222", "ars443", "ark232", "strang", "strang_fe", "strang_rk4", "strang_ssp3", "strang_ssprk53"])
 def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape):
     """Three whole steps (the first from the pointwise initial state, whose seam copies may differ: that step then runs
     element-major by the engine's own check) on both layouts; the node-unique path must really have run."""
