@@ -3521,6 +3521,14 @@ extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what,
 	return (int)v.size();
 }
 
+// Diagnostic builds (-DTMX_H_TIMING): shader cycles per wavefront of the fused explicit kernel by phase, [16][8] (tmx_k_horizontal.hip)
+extern "C" int tmx_debug_h_timing(tmx_engine * e, unsigned long long * out) {
+	int r; if ((r = check_ready(e))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));
+	tmxk_h_timing_read(out);
+	return TMX_OK;
+}
+
 // Statistics of the two-wavefront column kernel: how many pivot steps found the same pivot row in all 64 columns of a
 // wavefront (the renaming path) out of all pivot steps.  enable = 1 starts counting (zeroed), 0 stops; out (may be NULL)
 // receives {uniform, total} accumulated so far.

@@ -305,6 +305,7 @@ void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
 	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr);
+void tmxk_h_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [16 instantiations][7 phases + count], cleared by the read
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);
 void tmxk_vi_assemble(tmx_engine * e, const KParams & p, const double * xin, double dt);

@@ -33,6 +33,33 @@
 // ds_bpermute_b32) per field.  Global accesses stay one contiguous 512-byte row per wavefront (the map permutes lanes
 // inside it).  The matrix unit accumulates with fused multiply-adds, the reference with separate multiplies and adds:
 // results agree to rounding (1e-15), not bit for bit -- which is why this path is not the default.
+// Diagnostic builds (-DTMX_H_TIMING, tools/h_timing.py): shader cycles per wavefront of k_h_explicit by phase, accumulated per
+// instantiation (index = number of combination terms): [0] prologue up to the last load issued, [1] until the loaded values are
+// there and the pointwise arithmetic in front of the Exner function is done, [2] Exner function + LDS writes, [3] contractions,
+// [4] pointwise updates up to the W hand-over barrier, [5] barrier + W, [6] stores / seam exchange, [7] wavefronts counted.
+#ifdef TMX_H_TIMING
+// (one record per wavefront, plain stores: atomics on a handful of addresses serialise chip-wide and stall the very phases measured)
+#define HT_WAVES 65536
+__device__ unsigned long long g_h_rec[8][HT_WAVES][8];
+#define HT_DECL long long ht_ = __builtin_readcyclecounter(); long long hts_[7] = { 0, 0, 0, 0, 0, 0, 0 }
+#define HT_MARK(i) do { const long long t1_ = __builtin_readcyclecounter(); hts_[i] += t1_ - ht_; ht_ = t1_; } while (0)
+#define HT_END(NT_) do { if (threadIdx.x == 0) { const unsigned w_ = ((blockIdx.x * gridDim.y + blockIdx.y) * KT_H + threadIdx.y) % HT_WAVES; \
+	for (int q_ = 0; q_ < 7; q_++) g_h_rec[(NT_) & 7][w_][q_] = (unsigned long long)hts_[q_]; g_h_rec[(NT_) & 7][w_][7] = 1ull; } } while (0)
+void tmxk_h_timing_read(unsigned long long * out) {
+	static std::vector<unsigned long long> h((size_t)8 * HT_WAVES * 8);
+	hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_h_rec), h.size() * sizeof(unsigned long long));
+	for (int i = 0; i < 128; i++) out[i] = 0;
+	for (int nt = 0; nt < 8; nt++) for (int w = 0; w < HT_WAVES; w++) if (h[((size_t)nt * HT_WAVES + w) * 8 + 7])
+		for (int q = 0; q < 8; q++) out[nt * 8 + q] += h[((size_t)nt * HT_WAVES + w) * 8 + q];
+	std::fill(h.begin(), h.end(), 0ull);
+	hipMemcpyToSymbol(HIP_SYMBOL(g_h_rec), h.data(), h.size() * sizeof(unsigned long long));
+}
+#else
+#define HT_DECL
+#define HT_MARK(i)
+#define HT_END(NT_)
+void tmxk_h_timing_read(unsigned long long * out) { for (int i = 0; i < 128; i++) out[i] = 0; }
+#endif
 #ifndef TMX_H_BURST
 #define TMX_H_BURST 0      // 1: raw terms of the stage combination loaded in bursts (lin_load) instead of slab by slab (base_value_u): one memory round trip
                            // instead of five per wavefront, but 185-190 registers (two resident wavefronts per SIMD instead of three): measured equal (element-major) or slower (node-unique)
@@ -79,6 +106,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	// base of the update (a plain instance or the fused stage combination): loaded in the same burst as the state
 	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
 	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
+	HT_DECL;
 	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
 	constexpr int NX = NT > 0 ? NT : 1;
 	double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
@@ -142,8 +170,13 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			w_hi = dt * fabs(xhi); w_lo = dt * fabs(xlo);
 		}
 	}
+	HT_MARK(0);
 	if (TMX_H_BURST) { bU = lin_reduce<NT, PM>(xbase, xU); bV = lin_reduce<NT, PM>(xbase, xV); }
 	const double ke = 0.5 * (conUa * ua + conUb * ub + conUx * ux);
+#ifdef TMX_H_TIMING
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	HT_MARK(1);
 	if (TMX_H_EXNER_LDS) __syncthreads();      // the tables are in LDS (every thread's loads are in flight by now)
 	const double exn = act ? (TMX_H_EXNER_LDS ? exner_from_rhotheta_lds(p, rt, rmtab) : exner_from_rhotheta(p, rt)) : 0.0;
 	const double fa = jn * conUa, fb = jn * conUb;
@@ -179,6 +212,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	s[ty][5][lp] = fa * rh; s[ty][6][lp] = fa * rt;
 	s[ty][7][lp] = fb * rh; s[ty][8][lp] = fb * rt;
 	wave_sync();      // the rows are this wavefront's own
+	HT_MARK(2);
 	if (!act) return;
 #ifdef TMX_H_SCHED_BARRIER
 	__builtin_amdgcn_sched_barrier(0);
@@ -216,6 +250,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		dbpf -= s[ty][8][lb] * S;
 	}
 	}
+	HT_MARK(3);
 	const double ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];      // 1 / element spacing of the column's patch
 	daub *= ida; daux *= ida; dbua *= idb; dbux *= idb;
 	darf *= ida; dbrf *= idb; dapf *= ida; dbpf *= idb;
@@ -283,7 +318,9 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		// k_h_w_update, which therefore needs the hand-off array for the first and the last level of a tile only
 		s[ty][0][lp] = uczx;
 		if (ty == 0 || ty == KT_H - 1) stu(ucz + (size_t)k * NS, colb, uczx);
+		HT_MARK(4);
 		__syncthreads();       // wavefronts above the top level have left; the barrier counts the ones still running
+		HT_MARK(5);
 		if (ty > 0) {
 			double v = 0.0;
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lp];
@@ -299,6 +336,11 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
 		seam_store<5, TMX_UQ_ROWLEN(UQ)>(p, &s[ty][1], lane, sdst, sred, v, xup, slab, (TMX_H_FUSE_W && ty > 0) ? 5 : 4);
 	}
+#ifdef TMX_H_TIMING
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	HT_MARK(6);
+	HT_END(NT);
 }
 
 // H explicit, part 2: W on interfaces (src/atm/HorizontalDynamicsFEM.cpp:1612-1659): bottom
