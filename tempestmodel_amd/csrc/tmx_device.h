@@ -43,7 +43,7 @@
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508): v = c_d * X_d (or 0), then += c_m * X_m.
 struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
 // Where the U,V slabs of the instances named by a LinTerms (and of the stage's initial instance) live: the instance's own slot,
-// or the slot of the instance it was copied from when the stepper left the CopyData of U,V out (tmx_host.hip: the implicit
+// or the slot of the instance it was copied from when the stepper left the CopyData of U,V out (tmx_step.hip: the implicit
 // column solve rewrites rho*theta, W, rho of the copy but leaves U,V identical to the source's)
 struct UvTerms { const double * src[12]; const double * xin; };
 

@@ -1,4 +1,4 @@
-// tmx_internal.h -- engine internals shared by the host side (tmx_host.hip) and the kernels
+// tmx_internal.h -- engine internals shared by the host side (tmx_host.hip, tmx_step.hip, tmx_unique.hip) and the kernels
 // (tmx_k_*.hip).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -208,7 +208,7 @@ struct tmx_engine {
 	double * d_ab = nullptr;                 // [3(L+1)*9][NUS] band rows, overwritten by U rows
 	double * d_rhs = nullptr;                // [3(L+1)][NUS]
 	int * d_flag = nullptr;                  // singular-pivot flag
-	bool track_surface = false; int patches_with_physics = 0;     // surface slots carried through the stage algebra (tmx_host.hip: surface_copy)
+	bool track_surface = false; int patches_with_physics = 0;     // surface slots carried through the stage algebra (tmx_step.hip: surface_copy)
 	// Kessler microphysics (tmx_physics_kessler): level heights [L][NS], accumulated precipitation [NS], column work arrays [8][L][NS]
 	std::vector<double> h_zlev; bool zlev_dirty = false;
 	double * d_zlev = nullptr, * d_prect = nullptr, * d_kes = nullptr;
