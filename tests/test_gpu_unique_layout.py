@@ -253,3 +253,25 @@ def test_download_between_steps_keeps_the_unique_form():
         assert _same(u.download_state(0), d.download_state(0), range(6))
     finally:
         d.close(); u.close()
+
+
+@pytest.mark.parametrize("ne,npatch,L,shape", [(2, 6, 3, 0), (3, 6, 5, 1), (7, 6, 4, 2), (6, 54, 3, 0), (9, 54, 4, 1), (10, 24, 5, 0), (2, 24, 3, 2)])
+def test_odd_grids_on_the_unique_layout(ne, npatch, L, shape):
+    """Grids whose patches are one element wide, have odd element counts, or number 54 (three patches per panel side), at few levels
+    (level tiles partly empty): five ARS343 steps and three Strang steps on both layouts."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(ne, L, npatch)
+    d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1, "unique_tile_shape": shape})
+    try:
+        assert u.info(INFO_UNIQUE_LAYOUT) == 1
+        for e in (d, u):
+            e.upload_state(0, start)
+            for _ in range(5):
+                e.step_ars343(100.0)
+            for k in range(3):
+                e.step("strang", 100.0, first=(k == 0))
+            e.sync()
+        assert u.info(INFO_UNIQUE_INSTANCES) > 0
+        assert _same(u.download_state(0), d.download_state(0), range(npatch))
+    finally:
+        d.close(); u.close()
