@@ -275,3 +275,27 @@ def test_odd_grids_on_the_unique_layout(ne, npatch, L, shape):
         assert _same(u.download_state(0), d.download_state(0), range(npatch))
     finally:
         d.close(); u.close()
+
+
+def test_full_size_hundred_steps_both_layouts():
+    """The bench workload at its full size (ne30 np4 L30, 24 patches, dt 150 s): 100 ARS343 steps on the node-unique and on the
+    element-major layout end in identical doubles, every instance of the stepper included (the element-major path is the one the
+    live-reference tests pin: test_bench_workload_vs_live_reference, test_hundred_steps_ne15_L30)."""
+    from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
+    from tempestmodel_amd.engine import Engine
+    grid = CubedSphereGrid(30, 30, 30000.0, ppd=2)
+    states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
+    d = Engine(grid, options={"unique_layout": 0}); u = Engine(grid, options={"unique_layout": 1})
+    try:
+        for e in (d, u):
+            e.upload_state(0, states)
+            for _ in range(100):
+                e.step_ars343(150.0)
+            e.sync()
+        assert u.info(INFO_UNIQUE_INSTANCES) == 7
+        for ix in range(7):
+            assert _same(u.download_state(ix), d.download_state(ix), range(24)), ix
+        a = u.download_state(0)
+        assert all(np.isfinite(a[p][0]).all() for p in range(24))
+    finally:
+        d.close(); u.close()
