@@ -452,6 +452,9 @@ int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap);
  * member counts of the remaining groups; 8 node of a slot; 9 slots sent to other ranks; 10 representative column of a node;
  * 11 node of an element-major column; 12 per-tile node bases and pitches.  Returns the ints written (needed, when out == NULL), -1 on error. */
 int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out, int cap);
+/* Does the stepper program of a scheme have a node-unique form?  Returns the number of units the node-unique interpreter runs it in
+ * (a unit = the operations it fuses into one stage / solve / pass), 0 if some operation has none, -1 for an unknown scheme.  No device. */
+int tmx_debug_program_unique(int scheme, int first_step, int last_step);
 /* Diagnostic builds of the library (-DTMX_H_TIMING) only, zeros otherwise: shader cycles per wavefront of the fused explicit kernel by
  * phase, out[16 instantiations (combination terms)][7 phases + wavefront count] (tools/h_timing.py); the read clears the counters. */
 int tmx_debug_h_timing(tmx_engine * e, unsigned long long * out);

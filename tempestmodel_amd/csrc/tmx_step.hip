@@ -1402,6 +1402,16 @@ static bool program_fits_unique(const Program & p) {
 	return true;
 }
 
+// Host logic for the CPU tests: does the program of a scheme have a node-unique form, and in how many units does the interpreter run it?
+// Returns the number of units (fused groups of operations), 0 if some operation has no node-unique form, -1 for an unknown scheme.
+extern "C" int tmx_debug_program_unique(int scheme, int first_step, int last_step) {
+	Program p;
+	if (build_program(scheme, first_step, last_step, 1.0, p, 0.0)) return -1;
+	int units = 0;
+	for (size_t i = 0; i < p.size(); ) { const int k = unique_unit(p, i); if (!k) return 0; i += k; units++; }
+	return units;
+}
+
 static int u_dss_finish(tmx_engine * e, int ix, bool overlapped) {
 	ProfScope ps(e, TMX_K_DSS);
 	const UniqueLayout & u = e->u;

@@ -336,3 +336,18 @@ def test_unique_layout_tables(ne, npatch, n_ranks, shape):
         assert len(T["send_slots"]) == len(send) and (nearly > 0) == (len(send) > 0)
         assert nlocal <= ngroups
         e.close()
+
+
+def test_every_stepper_program_has_a_node_unique_form():
+    """Host logic of the node-unique interpreter (no device): all ten stepper programs decompose into its units -- fused
+    [Copy | LinearCombine]; H; V; DSS stages, column solves, hyperviscosity steps, DSS, copies and combinations -- also on
+    the first and the last step of a run (Strang's programs differ there)."""
+    from tempestmodel_amd import engine as eng
+    lib = eng.load_library()
+    expect_stages = {"ars343": 4, "ars232": 3, "ars222": 2, "ars443": 4, "ark232": 4, "strang": 5, "strang_fe": 1, "strang_rk4": 4, "strang_ssp3": 3, "strang_ssprk53": 5}
+    for name, sid in eng.Engine.SCHEMES.items():
+        for first in (0, 1):
+            for last in (0, 1):
+                units = lib.tmx_debug_program_unique(sid, first, last)
+                assert units >= expect_stages[name] + 1, (name, first, last, units)      # at least its explicit stages and the step after the sub-cycle
+    assert lib.tmx_debug_program_unique(99, 0, 0) == -1
