@@ -18,6 +18,15 @@ devnull = os.open(os.devnull, os.O_WRONLY); keep = os.dup(1); os.dup2(devnull, 1
 for _ in range(3):
     e.step_ars343(150.0)
 e.sync()
+if "--step" in sys.argv:      # the column solves of a whole step (on the node-unique layout where that is the default): records of the last one
+    os.dup2(keep, 1)
+    print("---- the last column solve of one ARS343 step, ne30 L30, developed state, %d instances in node-unique form ----" % e.info(13), flush=True)
+    e.pivot_stats(True)
+    e.step_ars343(150.0)
+    e.sync()
+    e.pivot_stats(False)
+    e.close()
+    sys.exit(0)
 e.copy_data(0, 1)
 for _ in range(3):
     e.v_step_implicit(1, 1, 65.0)      # warm
