@@ -402,7 +402,8 @@ enum {
 	TMX_INFO_UNIQUE_INSTANCES,    /* data instances currently held in node-unique form                              */
 	TMX_INFO_UNIQUE_CONVERSIONS,  /* conversions between the two forms so far (0 inside a run of tmx_step calls)      */
 	TMX_INFO_PARTIAL_SLOTS,       /* seam-node copies that go through the partial slots (tile and patch edges)         */
-	TMX_INFO_UNIQUE_DSS_GROUPS    /* node groups the DSS kernel of that layout finishes                               */
+	TMX_INFO_UNIQUE_DSS_GROUPS,   /* node groups the DSS kernel of that layout finishes                               */
+	TMX_INFO_PREFIX_STAGES        /* explicit stages so far whose combination started from a partial sum an earlier stage stored */
 };
 long long tmx_info(tmx_engine * e, int what);
 
@@ -455,6 +456,10 @@ int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out,
 /* Does the stepper program of a scheme have a node-unique form?  Returns the number of units the node-unique interpreter runs it in
  * (a unit = the operations it fuses into one stage / solve / pass), 0 if some operation has none, -1 for an unknown scheme.  No device. */
 int tmx_debug_program_unique(int scheme, int first_step, int last_step);
+/* Host logic for the CPU tests: the explicit stages of a scheme's program that can start from a partial sum an earlier stage
+ * stores (node-unique layout, option "unique_prefix").  Returns their number; pairs[2 k], pairs[2 k + 1] (k < cap): operation
+ * index of the producing and of the consuming stage; terms[k]: source instances the consuming stage no longer reads. */
+int tmx_debug_program_prefix(int scheme, int first_step, int last_step, int * pairs, int * terms, int cap);
 /* Diagnostic builds of the library (-DTMX_H_TIMING) only, zeros otherwise: shader cycles per wavefront of the fused explicit kernel by
  * phase, out[16 instantiations (combination terms)][7 phases + wavefront count] (tools/h_timing.py); the read clears the counters. */
 int tmx_debug_h_timing(tmx_engine * e, unsigned long long * out);

@@ -93,6 +93,36 @@ __device__ __forceinline__ double lin_reduce(const LinTerms & t, const double (&
 	return v;
 }
 
+// Prefix of a LATER stage's combination, formed from the terms this stage has loaded anyway.  The reference accumulates a
+// combination in a fixed order -- the destination's own term first, then the other instances in ascending order
+// (GridPatch::LinearCombineData) -- so the value after the first k terms is a well-defined intermediate; when the instances of
+// those k terms are exactly the instances this stage combines, it can be formed here (same operands, same order, the later
+// stage's coefficients) and stored, and the later stage starts from it (coefficient 1: exact) and reads k - 1 instances less.
+// ARS343: the third stage combines instances 0..4, the fourth 1, 0, 2, 3, 4, 5, 6: seven source instances become three.
+// coef[m] belongs to this stage's term m >= 1; first = this stage's term index of the later stage's destination (-1: it has none).
+template <int NT>
+__device__ __forceinline__ double emit_value(const EmitTerms & em, const double (&x)[NT > 0 ? NT : 1]) {
+	double p = 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) if (em.first == m) p = x[m] * em.coef[m];
+#pragma unroll
+	for (int m = 1; m < NT; m++) { const double q = p + em.coef[m] * x[m]; p = (em.first == m) ? p : q; }
+	return p;
+}
+// base_value_u / base_value_uv that also return that prefix (EM: compile-time switch)
+template <int NT, bool EM>
+__device__ __forceinline__ double base_value_u2(const LinTerms & t, const double * const (&src)[12], const EmitTerms & em, size_t slab_off, unsigned colb, double & pfx) {
+	if (NT == 0) return ldu(src[0] + slab_off, colb);
+	double x[NT > 0 ? NT : 1];
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(src[m] + slab_off, colb) : 0.0;
+	double v = t.premul ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
+	if (EM) pfx = emit_value<NT>(em, x);
+	return v;
+}
+
 // base_value with the slab offset (uniform, in doubles) and the lane's byte offset kept apart
 template <int NT>
 __device__ __forceinline__ double base_value_u(const LinTerms & t, size_t slab_off, unsigned colb) {

@@ -1406,7 +1406,7 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 struct OptionDef { const char * name; const char * env; int kind; const char * help; };      // kind 0: any time, 1: before tmx_finalize
 static int * option_slot(tmx_engine * e, const std::string & n) {
 #define OPT(NAME_, FIELD_) if (n == NAME_) return &(FIELD_)
-	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order);
+	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_prefix", e->u.prefix_option);
 	OPT("share_copies", e->share_copies); OPT("xcd_vertical", e->xcd_vertical);
 	OPT("vi_carry", e->vi_carry); OPT("vi_pair", e->vi_pair); OPT("vi_group", e->vi_group); OPT("vi_group_max", e->vi_group_max);
 	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
@@ -1425,6 +1425,7 @@ static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
 	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 element-major order (default), 1 2 x 2 blocks, 2 strips inside a patch row" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
+	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 0, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
 	{ "xcd_vertical", "TMX_XCD_VERTICAL", 0, "1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
 	{ "vi_carry", "TMX_VI_CARRY", 0, "column solve: carry shared sub-expressions between block rows (1)" },
@@ -1535,6 +1536,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_UNIQUE_CONVERSIONS: return e->u.conversions;
 		case TMX_INFO_PARTIAL_SLOTS: return e->u.built ? e->u.nslots : 0;
 		case TMX_INFO_UNIQUE_DSS_GROUPS: return e->u.built ? e->u.ngroups : 0;
+		case TMX_INFO_PREFIX_STAGES: return e->u.prefix_stages;
 		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
 			int n = 0;
 			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;

@@ -122,6 +122,11 @@ struct UniqueLayout {
 	// read -- in the unique slabs a node is read by up to four elements' threads -- so it writes the spare slot, which then
 	// becomes the instance's
 	std::vector<int> uslot; int uspare = 0;
+	// and one more for the prefix of a later stage's combination that an explicit stage forms from the instances it reads anyway
+	// (EmitTerms below, prefix_plan in tmx_step.hip); prefix_option: tmx_set_option("unique_prefix"), 0 = default -- measured: the
+	// store of the prefix costs the producing stage what the consuming stage saves (ARS343, ne30 L30: 186.8 + 122.2 us against 144.1 + 166.7 us)
+	int uprefix = 0, prefix_option = 0;
+	long long prefix_stages = 0;             // stages that started from a stored prefix (tmx_info)
 	int n_uform = 0;
 	long long conversions = 0;               // D <-> U conversions performed (tmx_info)
 	// an input whose copies differ makes the step run element-major; when that keeps happening (column physics between the steps
@@ -302,9 +307,11 @@ int tmxu_physics_inputs(tmx_engine * e, bool * ok);                       // ref
 void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu);   // xu[r][u] = xd[r][representative column of u]
 
 // kernel launchers (tmx_k_*.hip)
+// the prefix of a later stage's combination that an explicit stage also forms and stores (emit_value in tmx_device.h)
+struct EmitTerms { double * xp; double coef[12]; int first; };
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
-	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr);
+	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr, const EmitTerms * emit = nullptr);
 void tmxk_h_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [16 instantiations][7 phases + count], cleared by the read
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);

@@ -67,15 +67,24 @@ void tmxk_h_timing_read(unsigned long long * out) { for (int i = 0; i < 128; i++
 #ifndef TMX_H_EXNER_LDS
 #define TMX_H_EXNER_LDS 1  // exp / log tables of the Exner function in LDS (one more barrier) instead of two dependent gathers from global memory
 #endif
+#ifndef TMX_H_EM_GROUPS
+#define TMX_H_EM_GROUPS 2
+#endif
+#ifndef TMX_H_LATE_BASE
+#define TMX_H_LATE_BASE 1  // node-unique layout, stage combinations of three and more terms: the combination's raw terms are loaded and reduced at the end of
+                           // the kernel, next to the stores, where almost nothing else is live -- in the prologue's burst they take the kernel over 128 registers
+                           // (three resident wavefronts per SIMD instead of four)
+#endif
 // UQ: node-unique state layout (tmx_device.h, seam_store)
 // PM: the update instance enters its own stage combination (LinTerms::premul), a compile-time parameter so that the loads of the
 // combination's raw terms carry no control flow (lin_load)
-template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM>
+// EM: also form and store the prefix of a later stage's combination from the loaded terms (EmitTerms, tmx_device.h)
+template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM, bool EM>
 #ifndef TMX_H_MINWG
 #define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
 #endif
 __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p, const double * __restrict__ xin,
-	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt)
+	LinTerms xbase, double * xup, double * __restrict__ ucz, double * __restrict__ uv01, double dt, UvTerms uvt, EmitTerms em)
 {
 	__shared__ double s[KT_H][MF ? 1 : 9][TMX_UQ_ROWLEN(UQ)];
 	__shared__ double sDw[MF ? 1 : KT_H][16], sSw[MF ? 1 : KT_H][16];      // every wavefront its own copy of the operator tables (no workgroup barrier before the contractions)
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
 	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
 	HT_DECL;
+	constexpr bool LB = TMX_H_LATE_BASE && UQ && FUSE_V && !MF && NT >= 3 && !TMX_H_BURST;
 	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
 	constexpr int NX = NT > 0 ? NT : 1;
 	double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
@@ -128,7 +138,16 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		// rho*theta, rho and W follow behind the barrier, when the registers of the prologue are free again, and arrive
 		// while the contractions run -- all of them in one burst take the kernel from three resident wavefronts per SIMD to two
 		if (TMX_H_BURST) { lin_load<NT, PM>(uvt.src, TMX_SLAB_U(L, k) * SS, cb, xU); lin_load<NT, PM>(uvt.src, TMX_SLAB_V(L, k) * SS, cb, xV); }
-		else {
+		else if (LB) { }
+		else if (EM) {
+			// every copy of a node forms the same prefix (the sources are consistent): each stores it, to the same entry
+			double pf = 0.0;
+			bU = base_value_u2<NT, true>(xbase, uvt.src, em, TMX_SLAB_U(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, pf);
+			bV = base_value_u2<NT, true>(xbase, uvt.src, em, TMX_SLAB_V(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, pf);
+			bT = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_T(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, pf);
+			bR = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_R(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, pf);
+			if (TMX_H_FUSE_W && ty > 0) { bW = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, pf); }
+		} else {
 			bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
 			bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
 			if (TMX_H_FUSE_W && ty > 0) bW = base_value_u<NT>(xbase, TMX_SLAB_W(L, k) * SS, cb);
@@ -276,40 +295,44 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	const unsigned colb = (unsigned)col * 8u;
 	// out = base + dt * rhs; base == out for the reference's in-place accumulation, base == initial
 	// instance when the preceding CopyData(initial -> update) is fused away
-	double outU = bU + dt * upa;
-	double outV = bV + dt * upb;
+	// (LB: the increments are kept apart and added to the base, in this order, at the end of the kernel)
+	const double tU = dt * upa, tV = dt * upb;
+	double outU = bU + tU;
+	double outV = bV + tV;
+	double tUhi = 0, tVhi = 0, tUlo = 0, tVlo = 0;
 	if (FUSE_V) {
-		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
+		if (!LB && k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
 		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
 		if (k < L - 1) {
 			double b = 0.0;
 			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ua; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_uap;
-			outU += b * w_hi;
+			tUhi = b * w_hi; outU += tUhi;
 			b = 0.0;
 			b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * ub; b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * v_ubp;
-			outV += b * w_hi;
+			tVhi = b * w_hi; outV += tVhi;
 		}
 		if (k > 0) {
 			double b = 0.0;
 			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_uam; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ua;
-			outU += b * w_lo;
+			tUlo = b * w_lo; outU += tUlo;
 			b = 0.0;
 			b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * v_ubm; b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * ub;
-			outV += b * w_lo;
+			tVlo = b * w_lo; outV += tVlo;
 		}
 	}
 	if (TMX_H_BURST) {
 		bT = lin_reduce<NT, PM>(xbase, xT); bR = lin_reduce<NT, PM>(xbase, xR);
 		if (TMX_H_FUSE_W && ty > 0) bW = lin_reduce<NT, PM>(xbase, xW);
 	}
-	const double outR = bR - dt * invJ * (darf + dbrf), outT = bT - dt * invJ * (dapf + dbpf);
+	const double tR = dt * invJ * (darf + dbrf), tT = dt * invJ * (dapf + dbpf);
+	double outR = bR - tR, outT = bT - tT;
 	if (!UQ) {
 		stu(xup + sU, colb, outU);
 		stu(xup + sV, colb, outV);
 		stu(xup + sR, colb, outR);
 		stu(xup + sT, colb, outT);
 	}
-	double outW = 0.0;
+	double outW = 0.0, tW = 0.0;
 	if (TMX_H_FUSE_W) {
 		// (MF: the matrix-unit variant keeps one 512-byte row per wavefront for exactly this hand-over; round 3 measured it without,
 		// i.e. with every interface left to k_h_w_update)
@@ -325,11 +348,48 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			double v = 0.0;
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * s[ty - 1][0][lp];
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
-			outW = bW + dt * v;
+			tW = dt * v;
+			outW = bW + tW;
 			if (!UQ) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
 		}
 	} else
 		stu(ucz + (size_t)k * NS, colb, uczx);
+	if (LB) {
+		// the stage combination, now: NT loads per slab in flight beside five increments (and, EM, the prefix of a later stage's
+		// combination formed from the same terms: every copy of a node forms the same one and stores it, to the same entry)
+#if TMX_H_LATE_BASE == 2
+		__builtin_amdgcn_sched_barrier(0);
+#endif
+		unsigned cb = (unsigned)uc * 8u;
+#if TMX_H_LATE_BASE == 1
+		asm volatile("" : "+v"(cb) : "v"(tR), "v"(tT), "v"(outU), "v"(outV));      // (the addresses exist only now: the loads cannot be moved up into the contractions)
+#endif
+		const bool withW = TMX_H_FUSE_W && ty > 0;
+		double pU = 0, pV = 0, pT = 0, pR = 0, pW = 0;
+		bU = base_value_u2<NT, EM>(xbase, uvt.src, em, TMX_SLAB_U(L, k) * SS, cb, pU);
+		bV = base_value_u2<NT, EM>(xbase, uvt.src, em, TMX_SLAB_V(L, k) * SS, cb, pV);
+#if TMX_H_EM_GROUPS >= 2
+		// EM: both sums need a slab's terms, and all five slabs' terms in flight at once cost the fourth resident wavefront again: two (three) rounds
+		if (EM) asm volatile("" : "+v"(cb) : "v"(bU), "v"(bV), "v"(pU), "v"(pV));
+#endif
+		bT = base_value_u2<NT, EM>(xbase, xbase.src, em, TMX_SLAB_T(L, k) * SS, cb, pT);
+#if TMX_H_EM_GROUPS >= 3
+		if (EM) asm volatile("" : "+v"(cb) : "v"(bT), "v"(pT));
+#endif
+		bR = base_value_u2<NT, EM>(xbase, xbase.src, em, TMX_SLAB_R(L, k) * SS, cb, pR);
+		if (withW) bW = base_value_u2<NT, EM>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, cb, pW);
+		if (EM) {
+			stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, pU); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, pV);
+			stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, pT); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, pR);
+			if (withW) stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, pW);
+		}
+		outU = bU + tU; outV = bV + tV;
+		if (k < 2) { uv01[(size_t)k * NS + col] = outU; uv01[(size_t)(2 + k) * NS + col] = outV; }
+		if (k < L - 1) { outU += tUhi; outV += tVhi; }
+		if (k > 0) { outU += tUlo; outV += tVlo; }
+		outR = bR - tR; outT = bT - tT;
+		if (withW) outW = bW + tW;
+	}
 	if (UQ && !MF) {
 		// rows 1..5 of the wavefront's LDS block (row 0 is being read by the wavefront above); W only where this kernel updates it
 		const double v[5] = { outU, outV, outR, outT, outW };
@@ -347,9 +407,9 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
 // stride > 1: only the interfaces k = 0, stride, 2 stride, ... (the first of every level tile of k_h_explicit, which has done
 // the others) and the top one
-template <int NT, bool UQ>
+template <int NT, bool UQ, bool EM>
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
-	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride)
+	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride, EmitTerms em)
 {
 	__shared__ double sw[UQ ? 4 : 1][1][64];
 	const int L = p.L;
@@ -368,6 +428,11 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	if (k > L || (UQ ? uc < 0 : col >= p.ncol)) return;
 	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
 		// (UQ: the copies of a node all carry the base's value: every one of them may store it)
+		if (EM) {
+			double pf = 0.0;
+			xup[TMX_SLAB_W(L, L) * SS + uc] = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, L) * SS, (unsigned)uc * 8u, pf);
+			em.xp[TMX_SLAB_W(L, L) * SS + uc] = pf;
+		} else
 		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * SS + uc);
 		return;
 	}
@@ -390,6 +455,11 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 		double v = 0.0;
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz[(size_t)(k - 1) * NS + col];
 		v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * ucz[(size_t)k * NS + col];
+		if (EM) {
+			double pf = 0.0;
+			wnew = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, (unsigned)uc * 8u, pf) + dt * v;
+			em.xp[TMX_SLAB_W(L, k) * SS + uc] = pf;
+		} else
 		wnew = base_value<NT>(xbase, TMX_SLAB_W(L, k) * SS + uc) + dt * v;
 	}
 	if (UQ) {
@@ -403,7 +473,8 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 // xin_uv / xbase_uv / src_uv: where the U,V slabs of the initial instance, the base instance and the combination sources
 // live when that is not the instance's own slot (NULL: the same pointers)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
-	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv) {
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv,
+	const EmitTerms * emit) {
 	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
 	LinTerms xbase;
 	UvTerms uvt;
@@ -422,16 +493,22 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	dim3 blk2(64, 4), grd2 = wg_grid(uq, q, ntile, nyb2);
 	const double * uvp = fuse_v ? (const double *)uv01 : (const double *)nullptr;
 	// PM_: does the update instance enter its own combination?  (no combination: irrelevant, one instantiation)
+	EmitTerms em0; em0.xp = nullptr; em0.first = -1; for (int m = 0; m < 12; m++) em0.coef[m] = 0.0;
+	// (the prefix of a later stage's combination: node-unique layout with the vertical part fused in, no own coefficient, at least two terms)
+	const bool emit_ok = emit && emit->xp && uq && fuse_v && !premul && nterms >= 3 && nterms <= 8;
+	const EmitTerms em = emit_ok ? *emit : em0;
 #define LAUNCH_HV2(NT_, PM_) do { \
-		if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true, PM_>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); \
-		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false, PM_>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt); } while (0)
+		if (uq && fuse_v && emit_ok && NT_ >= 3 && NT_ <= 8 && !PM_) hipLaunchKernelGGL((k_h_explicit<true, (NT_ >= 3 && NT_ <= 8) ? NT_ : 3, false, true, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em); \
+		else if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
+		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
+		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
+		else if (fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
+		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); } while (0)
 #define LAUNCH_HV(NT_) do { \
 		if (NT_ == 0 || premul) LAUNCH_HV2(NT_, true); else LAUNCH_HV2(NT_, false); \
-		if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); \
-		else hipLaunchKernelGGL((k_h_w_update<NT_, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride); } while (0)
+		if (uq && emit_ok && NT_ >= 3 && NT_ <= 8) hipLaunchKernelGGL((k_h_w_update<(NT_ >= 3 && NT_ <= 8) ? NT_ : 3, true, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em); \
+		else if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true, false>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); \
+		else hipLaunchKernelGGL((k_h_w_update<NT_, false, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_HV(0); break;
 		case 2: LAUNCH_HV(2); break;

@@ -1445,15 +1445,100 @@ template <class F> static int u_produce_and_average(tmx_engine * e, int ix, int 
 	return u_dss_finish(e, ix, overlapped);
 }
 
+// A stage "LinearCombine(lc -> d); H; V; DSS(d)" at operation i whose sources are exactly the LEADING terms of a later such
+// stage's combination (in the reference's accumulation order: the destination's own term, then ascending instance index), none of
+// them written in between: it also stores that leading partial sum (EmitTerms), and the later stage starts from it.
+// ARS343 (the bench): stage 3 reads instances 0..4, stage 4 combines 1, 0, 2, 3, 4, 5, 6 -- it reads the prefix, 5 and 6.
+struct PrefixPlan {
+	size_t producer = 0, consumer = 0;      // operation index of the two stages' LinearCombine
+	unsigned members = 0u;    // instances the prefix holds
+	int first = -1;           // producer's term index of the consumer's destination (-1: the consumer's own coefficient is zero)
+	double coef[12];          // consumer's coefficient of the producer's term m
+};
+static bool prefix_plan(const tmx_engine * e, const Program & p, size_t i, PrefixPlan * plan) {
+	const Op & R = p[i];
+	if (!e->u.prefix_option || R.kind != OP_LINCOMB || unique_unit(p, i) != 4 || R.lc[R.a] != 0.0) return false;
+	int term_of[32]; unsigned A = 0u; int nA = 0;
+	for (int m = 0; m < 32; m++) term_of[m] = -1;
+	for (int m = 0; m < R.nlc && m < 32; m++) if (m != R.a && R.lc[m] != 0.0) { term_of[m] = 1 + nA++; A |= 1u << m; }
+	if (nA < 2 || nA > 7) return false;      // (the kernels that store a prefix: 3 to 8 terms, the destination's unread one included)
+	for (size_t j = i + 4; j < p.size(); j++) {
+		const Op & S = p[j];
+		if (S.kind == OP_LINCOMB && unique_unit(p, j) == 4) {
+			unsigned B = 0u;
+			for (int m = 0; m < S.nlc && m < 32; m++) if (S.lc[m] != 0.0) B |= 1u << m;
+			if ((B & A) == A && (B & ~A) != 0u) {
+				// order: [S.a if its coefficient is not zero], then ascending -- the members first
+				int top = -1, low = 32;      // last member and first other term of the ascending part
+				for (int q = 0; q < 32; q++) if ((A >> q & 1u) && q != S.a) top = q;
+				for (int q = 31; q >= 0; q--) if ((B & ~A) >> q & 1u) low = q;
+				if ((!(B >> S.a & 1u) || (A >> S.a & 1u)) && low > top) {
+					plan->producer = i; plan->consumer = j; plan->members = A; plan->first = (A >> S.a & 1u) ? term_of[S.a] : -1;
+					for (int m = 0; m < 12; m++) plan->coef[m] = 0.0;
+					for (int m = 0; m < 32; m++) if (term_of[m] >= 0) plan->coef[term_of[m]] = S.lc[m];
+					return true;
+				}
+			}
+		}
+		const OpAccess x = op_access(S, false);
+		if ((x.full | x.part) & A) return false;      // a member is rewritten: no later stage sees these values
+	}
+	return false;
+}
+
+// the producer / consumer pairs of a program that are used: there is one prefix slot, so their spans must not touch; the pairs that
+// save the most source instances first (ARS343: the third stage's five sources serve the fourth -- four instances less to read --
+// rather than the second stage's three serving the third)
+static std::vector<PrefixPlan> prefix_schedule(const tmx_engine * e, const Program & p) {
+	std::vector<PrefixPlan> all, use;
+	for (size_t i = 0; i < p.size(); ) {
+		const int k = unique_unit(p, i);
+		if (!k) return use;
+		PrefixPlan plan;
+		if (prefix_plan(e, p, i, &plan)) all.push_back(plan);
+		i += k;
+	}
+	auto saved = [](const PrefixPlan & a) { int c = 0; for (int m = 0; m < 32; m++) c += a.members >> m & 1u; return c - 1; };
+	std::stable_sort(all.begin(), all.end(), [&](const PrefixPlan & a, const PrefixPlan & b) { return saved(a) > saved(b); });
+	for (const PrefixPlan & a : all) {
+		bool clash = false;
+		for (const PrefixPlan & b : use) clash = clash || !(a.consumer < b.producer || b.consumer < a.producer);
+		if (!clash) use.push_back(a);
+	}
+	std::sort(use.begin(), use.end(), [](const PrefixPlan & a, const PrefixPlan & b) { return a.producer < b.producer; });
+	return use;
+}
+
+extern "C" int tmx_debug_program_prefix(int scheme, int first_step, int last_step, int * pairs, int * terms, int cap) {
+	Program p;
+	if (build_program(scheme, first_step, last_step, 1.0, p, 0.0)) return -1;
+	tmx_engine e;      // (only the option is read)
+	e.u.prefix_option = 1;
+	if (!program_fits_unique(p)) return 0;
+	const std::vector<PrefixPlan> use = prefix_schedule(&e, p);
+	int n = 0;
+	for (const PrefixPlan & plan : use) {
+		if (n < cap) {
+			if (pairs) { pairs[2 * n] = (int)plan.producer; pairs[2 * n + 1] = (int)plan.consumer; }
+			if (terms) { int c = 0; for (int m = 0; m < 32; m++) c += plan.members >> m & 1u; terms[n] = c - 1; }
+		}
+		n++;
+	}
+	return n;
+}
+
 // [Copy(ibase -> iupd) | LinearCombine(lc -> iupd)]; H.StepExplicit(iinit, iupd); V.StepExplicit(iinit, iupd); DSS(iupd)
-static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc) {
+// emit: also store the prefix of a later stage's combination; held: members of the stored prefix this stage's combination starts from
+static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, const double * lc, int nlc, const PrefixPlan * emit = nullptr, unsigned held = 0u) {
 	const double * src[12]; double cf[12]; int premul = 0, n = 0;
 	const double * srcuv[12];
+	double * const prefix = e->u.d_ustate + (size_t)e->u.uprefix * e->u.ustride;
 	if (lc) {
 		premul = (lc[iupd] != 0.0) ? 1 : 0;
 		n = 1; src[0] = uinst(e, iupd); srcuv[0] = uinst_uv(e, iupd); cf[0] = lc[iupd];
+		if (held) { src[0] = srcuv[0] = prefix; cf[0] = 1.0; premul = 1; e->u.prefix_stages++; }      // (times one: exact)
 		for (int m = 0; m < nlc; m++) {
-			if (m == iupd || lc[m] == 0.0) continue;
+			if (m == iupd || lc[m] == 0.0 || (held >> m & 1u)) continue;
 			REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
 			src[n] = uinst(e, m); srcuv[n] = uinst_uv(e, m); cf[n] = lc[m]; n++;
 		}
@@ -1462,25 +1547,32 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	// the update instance is also read (in-place accumulation, or its own coefficient in the combination is not zero): the
 	// element-major kernels read and write a thread's own column, here other elements' threads read the node too -- write the
 	// spare slot and let it become the instance's
-	const bool aliased = lc ? (premul != 0) : (ibase == iupd);
+	bool aliased = lc ? (premul != 0) : (ibase == iupd);
+	if (held) {      // the destination's own term is inside the prefix: its slot is read only if something else lives there
+		const double * mine = uinst(e, iupd);
+		aliased = xin_uv == mine;
+		for (int m = 1; m < n; m++) aliased = aliased || src[m] == mine || srcuv[m] == mine;
+	}
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	double * out = aliased ? uspare(e) : uinst(e, iupd);
 	const double * base = lc ? nullptr : uinst(e, ibase), * xin = uinst(e, iinit);
+	EmitTerms em; em.xp = nullptr; em.first = -1;
+	if (emit && lc && !premul && n >= 3 && n <= 8) { em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m]; }
 	// the stage writes every slab of the update instance: its U,V slabs are its own from here on (what it shared is read through
 	// the pointers taken above), and whoever shared ITS slabs is dead
 	if (e->uvmap[iupd] != iupd) { e->uvmap[iupd] = iupd; e->n_uvshared--; }
 	if (aliased) u_adopt_spare(e, iupd);      // (src[], base and the U,V pointers were taken before: they still name the old slots)
 	int r = u_produce_and_average(e, iupd, TMX_K_H_EXPLICIT, [&](const KParams & p) {
-		if (n > 0) tmxk_h_explicit(e, p, xin, out, out, dt, 1, n, src, cf, premul, xin_uv, nullptr, srcuv);
+		if (n > 0) tmxk_h_explicit(e, p, xin, out, out, dt, 1, n, src, cf, premul, xin_uv, nullptr, srcuv, em.xp ? &em : nullptr);
 		else tmxk_h_explicit(e, p, xin, base, out, dt, 1, 0, nullptr, nullptr, 0, xin_uv, base_uv, nullptr);
 	});
 	u_written(e, iupd);
 	if (r) return r;
 	if (lc) {
-		const double * dsrc[12];      // the surface slots live with the element-major slots
-		int m2 = 1; dsrc[0] = inst(e, iupd);
-		for (int m = 0; m < nlc; m++) if (m != iupd && lc[m] != 0.0) dsrc[m2++] = inst(e, m);
-		return surface_lincomb(e, iupd, n, dsrc, cf, premul);
+		const double * dsrc[12]; double dcf[12];      // the surface slots live with the element-major slots (all terms: no prefix there)
+		int m2 = 1; dsrc[0] = inst(e, iupd); dcf[0] = lc[iupd];
+		for (int m = 0; m < nlc; m++) if (m != iupd && lc[m] != 0.0) { dsrc[m2] = inst(e, m); dcf[m2++] = lc[m]; }
+		return surface_lincomb(e, iupd, m2, dsrc, dcf, lc[iupd] != 0.0 ? 1 : 0);
 	}
 	return surface_copy(e, ibase, iupd);
 }
@@ -1570,6 +1662,11 @@ static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
 
 static int run_program_unique(tmx_engine * e, const Program & p) {
 	int r;
+	const std::vector<PrefixPlan> plans = prefix_schedule(e, p);
+	auto plan_at = [&](size_t i, bool consumer) -> const PrefixPlan * {
+		for (const PrefixPlan & a : plans) if ((consumer ? a.consumer : a.producer) == i) return &a;
+		return nullptr;
+	};
 	// U,V slabs still shared from the previous step: kept where this program allows it
 	for (int b = 0; b < (int)e->uvmap.size() && e->n_uvshared; b++)
 		if (e->uvmap[b] != b && !share_is_safe(p, 0, e->uvmap[b], b, false) && (r = u_own_uv(e, b))) return r;
@@ -1593,7 +1690,11 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 			if ((r = u_copy(e, o.a, o.b, e->u.ustride))) return r;
 			break;
 		case OP_LINCOMB:
-			if (k == 4) { if ((r = u_stage(e, p[i + 1].a, o.a, o.a, p[i + 1].coef, o.lc, o.nlc))) return r; break; }
+			if (k == 4) {
+				const PrefixPlan * held = plan_at(i, true);      // an earlier stage has stored the leading partial sum of this combination
+				if ((r = u_stage(e, p[i + 1].a, o.a, o.a, p[i + 1].coef, o.lc, o.nlc, plan_at(i, false), held ? held->members : 0u))) return r;
+				break;
+			}
 			{
 				const double * src[12], * dsrc[12]; double cf[12];
 				if ((r = u_own_uv(e, o.a, o.lc[o.a] == 0.0))) return r;

@@ -206,7 +206,7 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 	if ((r = up(&u.d_gsrc, T.gsrc, bytes)) || (r = up(&u.d_gdst, T.gdst, bytes)) || (r = up(&u.d_gn, T.gn, bytes)) || (r = up(&u.d_gx, T.gx, bytes)) || (r = up(&u.d_gtype, T.gt, bytes))) return r;
 	if ((r = up(&u.d_send_slots, T.send_slots, bytes)) || (r = up(&u.d_quads_early, T.quads_early, bytes)) || (r = up(&u.d_quads_late, T.quads_late, bytes))) return r;
 	u.ustride = (size_t)e->nslab * u.NUS;
-	const size_t ub = (size_t)(e->cfg.n_instances + 1) * u.ustride * sizeof(double), pb = (size_t)e->nslab * u.NP * sizeof(double);
+	const size_t ub = (size_t)(e->cfg.n_instances + 2) * u.ustride * sizeof(double), pb = (size_t)e->nslab * u.NP * sizeof(double);
 	HIPCHK(hipMalloc((void **)&u.d_ustate, ub)); HIPCHK(hipMemset(u.d_ustate, 0, ub)); *bytes += ub;
 	HIPCHK(hipMalloc((void **)&u.d_part, pb)); HIPCHK(hipMemset(u.d_part, 0, pb)); *bytes += pb;
 	HIPCHK(hipMalloc((void **)&u.d_check, sizeof(int))); HIPCHK(hipMemset(u.d_check, 0, sizeof(int)));
@@ -215,7 +215,7 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 	u.form.assign(e->cfg.n_instances, 0);
 	u.uslot.resize(e->cfg.n_instances);
 	for (int k = 0; k < e->cfg.n_instances; k++) u.uslot[k] = k;
-	u.uspare = e->cfg.n_instances;
+	u.uspare = e->cfg.n_instances; u.uprefix = e->cfg.n_instances + 1;
 	u.n_uform = 0;
 	u.built = true;
 	return TMX_OK;

@@ -351,3 +351,22 @@ def test_every_stepper_program_has_a_node_unique_form():
                 units = lib.tmx_debug_program_unique(sid, first, last)
                 assert units >= expect_stages[name] + 1, (name, first, last, units)      # at least its explicit stages and the step after the sub-cycle
     assert lib.tmx_debug_program_unique(99, 0, 0) == -1
+
+
+def test_stage_combinations_that_start_from_a_stored_partial_sum():
+    """Host logic (no device): which explicit stages of a program can start from the leading partial sum of their combination,
+    stored by an earlier stage that reads the same instances.  ARS343: operation 12 (third stage, LinearCombine of instances 0..4)
+    serves operation 18 (fourth stage: 1, 0, 2, 3, 4, 5, 6 in accumulation order), which then reads four instances less; the
+    second stage's three sources would serve the third stage too, but there is one slot and the larger saving wins."""
+    import ctypes
+    from tempestmodel_amd import engine as eng
+    lib = eng.load_library()
+    pairs = (ctypes.c_int * 16)(); terms = (ctypes.c_int * 8)()
+    for first in (0, 1):
+        assert lib.tmx_debug_program_prefix(eng.Engine.SCHEMES["ars343"], first, 0, pairs, terms, 8) == 1
+        assert list(pairs[:2]) == [12, 18] and terms[0] == 4
+    for name, sid in eng.Engine.SCHEMES.items():
+        n = lib.tmx_debug_program_prefix(sid, 0, 0, pairs, terms, 8)
+        assert n >= 0 and all(pairs[2 * k] < pairs[2 * k + 1] and terms[k] >= 1 for k in range(n)), name
+        assert all(pairs[2 * k + 1] < pairs[2 * k + 2] for k in range(n - 1)), name      # one slot: the spans do not touch
+    assert lib.tmx_debug_program_prefix(99, 0, 0, pairs, terms, 8) == -1

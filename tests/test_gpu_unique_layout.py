@@ -11,7 +11,7 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 INFO_GHOST, INFO_EARLY, INFO_LATE = 4, 7, 8
-INFO_UNIQUE_LAYOUT, INFO_UNIQUE_INSTANCES, INFO_UNIQUE_CONVERSIONS, INFO_PARTIAL_SLOTS, INFO_UNIQUE_GROUPS = 12, 13, 14, 15, 16
+INFO_UNIQUE_LAYOUT, INFO_UNIQUE_INSTANCES, INFO_UNIQUE_CONVERSIONS, INFO_PARTIAL_SLOTS, INFO_UNIQUE_GROUPS, INFO_PREFIX_STAGES = 12, 13, 14, 15, 16, 17
 
 
 def _same(a, b, patches):
@@ -56,6 +56,28 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
         assert _same(u.download_state(0), d.download_state(0), range(npatch)), scheme
     finally:
         d.close(); u.close()
+
+
+def test_stored_prefix_of_a_stage_combination_changes_no_bit():
+    """ARS343's third stage reads instances 0..4, the leading terms of the fourth stage's combination (1, 0, 2, 3, 4, 5, 6 in the
+    reference's accumulation order): with "unique_prefix" it also stores that partial sum, and the fourth stage reads it and instances 5, 6.  With the
+    option off (the default: the extra store costs what the four reads save) every stage reads all its
+    sources; same bits, with shared U,V slabs (the default) and with every copy made."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(6, 8, 6)
+    for share in (1, 0):
+        a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1, "share_copies": share})
+        b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0, "share_copies": share})
+        try:
+            a.upload_state(0, start); b.upload_state(0, start)
+            for k in range(5):
+                a.step("ars343", 120.0, first=(k == 0)); b.step("ars343", 120.0, first=(k == 0))
+            a.sync(); b.sync()
+            assert a.info(INFO_PREFIX_STAGES) >= 4 and b.info(INFO_PREFIX_STAGES) == 0      # (one per step that ran node-unique)
+            for ix in range(7):
+                assert _same(a.download_state(ix), b.download_state(ix), range(6)), ("instance", ix, "share_copies", share)
+        finally:
+            a.close(); b.close()
 
 
 def test_unique_layout_against_the_oracle_and_the_golden_vector():
