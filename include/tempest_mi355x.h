@@ -403,7 +403,8 @@ enum {
 	TMX_INFO_UNIQUE_CONVERSIONS,  /* conversions between the two forms so far (0 inside a run of tmx_step calls)      */
 	TMX_INFO_PARTIAL_SLOTS,       /* seam-node copies that go through the partial slots (tile and patch edges)         */
 	TMX_INFO_UNIQUE_DSS_GROUPS,   /* node groups the DSS kernel of that layout finishes                               */
-	TMX_INFO_PREFIX_STAGES        /* explicit stages so far whose combination started from a partial sum an earlier stage stored */
+	TMX_INFO_PREFIX_STAGES,       /* explicit stages so far whose combination started from a partial sum an earlier stage stored */
+	TMX_INFO_EXPERIMENTS_BUILD    /* 1: the experiments flavour of the library (archived experiments and cross-check kernels compiled in) */
 };
 long long tmx_info(tmx_engine * e, int what);
 
@@ -423,14 +424,20 @@ long long tmx_info(tmx_engine * e, int what);
  *   "step_graph", "share_copies", "split_stage_off", "exchange_overlap_off", "p2p_timeout_s", "metric_stored", "xcd_vertical",
  *   "vi_*" (column solve kernel selection), "vt_*", "kessler_column", "hvis_pull", "hvis_block", "tracer_lincomb_pass", "udv_separate",
  *   "vx_fused": kernel selection / A-B switches, each with a bit-identity test; "debug_skip_exchange": timing aid with WRONG results
- *   at rank boundaries (tools/rank_share_timing.py only). */
+ *   at rank boundaries (tools/rank_share_timing.py only).
+ * Archived experiments and cross-check kernels -- "unique_prefix", "hvis_pull", "hvis_block", "vi_split_kernels", "vi_pair" = 0,
+ * "vi_carry", "vi_sparse", "vi_split_back", "vi_back_sub", "vx_fused", "vt_explicit_v1", "debug_skip_exchange" -- are compiled into the
+ * experiments flavour of the library only (libtempest_mi355x_exp.so, `make -C tempestmodel_amd/csrc exp`; tmx_info(TMX_INFO_EXPERIMENTS_BUILD)):
+ * the production library holds neither the kernels nor the switch, and answers TMX_ERR_UNSUPPORTED to any value but the default. */
 int tmx_set_option(tmx_engine * e, const char * name, double value);
 int tmx_get_option(tmx_engine * e, const char * name, double * value);
 /* "name=value" lines of every option as in use (defaults included) and, if tmx_options_from_environment applied any, the variables it
  * took; returns the buffer length needed (buf may be NULL). */
 int tmx_options_report(tmx_engine * e, char * buf, int cap);
 /* Test / bench plumbing only: turn the historical TMX_* environment variables into options (right after tmx_create).  Says what
- * it applied in ONE line on stderr (silenced by TMX_QUIET) and in tmx_options_report; returns how many.  The adapter does not call it. */
+ * it applied in ONE line on stderr (silenced by TMX_QUIET) and in tmx_options_report; returns how many, or TMX_ERR_UNSUPPORTED (< 0) if a
+ * variable names a value this build refuses -- a variable that would have changed the run and cannot is an error, not a silent default.
+ * The adapter does not call it. */
 int tmx_options_from_environment(tmx_engine * e);
 
 /* Host-side DSS / exchange plan, for tests of the multi-rank logic (works on an engine created with

@@ -1403,7 +1403,9 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 // The library reads NO environment variable on its own: a stray TMX_* in a job script cannot change a run.  Test and bench plumbing
 // that wants the historical variables calls tmx_options_from_environment, which turns them into these options, prints ONE line
 // naming what it applied, and leaves them queryable (tmx_get_option, tmx_options_report).
-struct OptionDef { const char * name; const char * env; int kind; const char * help; };      // kind 0: any time, 1: before tmx_finalize
+// kind 0: any time, 1: before tmx_finalize; +2: selects an archived experiment or a cross-check kernel that only the experiments flavour of the
+// library holds (-DTMX_EXPERIMENTS, libtempest_mi355x_exp.so): the production library refuses every value but the default
+struct OptionDef { const char * name; const char * env; int kind; const char * help; };
 static int * option_slot(tmx_engine * e, const std::string & n) {
 #define OPT(NAME_, FIELD_) if (n == NAME_) return &(FIELD_)
 	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_prefix", e->u.prefix_option);
@@ -1425,35 +1427,35 @@ static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
 	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 element-major order (default), 1 2 x 2 blocks, 2 strips inside a patch row" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
-	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 0, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
+	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
 	{ "xcd_vertical", "TMX_XCD_VERTICAL", 0, "1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
-	{ "vi_carry", "TMX_VI_CARRY", 0, "column solve: carry shared sub-expressions between block rows (1)" },
-	{ "vi_pair", "TMX_VI_PAIR", 0, "column solve: two-wavefront kernel (-1 auto, 0 one-wavefront kernel, 1 on)" },
+	{ "vi_carry", "TMX_VI_CARRY", 2, "column solve: carry shared sub-expressions between block rows (1)" },
+	{ "vi_pair", "TMX_VI_PAIR", 2, "column solve: two-wavefront kernel (-1 auto, 0 one-wavefront kernel, 1 on)" },
 	{ "vi_group", "TMX_VI_GROUP", 0, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
 	{ "vi_group_max", "TMX_VI_GROUP_MAX", 0, "largest rank share (unique columns) served by the lane-group kernel (6400)" },
 	{ "vi_pair_workgroup", "TMX_VI_PAIR_WG", 0, "pairs per workgroup of the two-wavefront kernel (0 auto)" },
-	{ "vi_split_back", "TMX_VI_SPLIT_BACK", 0, "back substitution as a launch of its own (0)" },
-	{ "vi_back_sub", "TMX_VI_BACK_SUB", 0, "wavefronts per column group of that launch (1)" },
+	{ "vi_split_back", "TMX_VI_SPLIT_BACK", 2, "back substitution as a launch of its own (0)" },
+	{ "vi_back_sub", "TMX_VI_BACK_SUB", 2, "wavefronts per column group of that launch (1)" },
 	{ "vi_stagger", "TMX_VI_STAGGER_NS", 0, "staggered workgroup starts, window in units of 10 ns (0)" },
-	{ "vi_split_kernels", "TMX_VI_MODE", 1, "1: assemble + solve as two kernels (cross-check path)" },
-	{ "vi_sparse", "TMX_VI_SPARSE", 0, "1 (default): U-row entries that are zero in all 64 columns are not stored" },
+	{ "vi_split_kernels", "TMX_VI_MODE", 3, "1: assemble + solve as two kernels (cross-check path)" },
+	{ "vi_sparse", "TMX_VI_SPARSE", 2, "1 (default): U-row entries that are zero in all 64 columns are not stored" },
 	{ "vi_columns_per_wavefront", "TMX_VI_CPW", 1, "columns per wavefront of the two-wavefront kernel (0 = 64)" },
 	{ "contraction_mfma", "TMX_MFMA", 1, "1: the 4 x 4 contractions of the fused explicit kernel on the matrix unit -- NOT bit-exact (1e-15 per call, W 1.5e-10 after 100 steps)" },
 	{ "step_graph", "TMX_GRAPH", 1, "1: single-rank steps replayed from a captured hipGraph" },
 	{ "p2p_timeout_s", "TMX_P2P_TIMEOUT_S", 0, "peer-to-peer halo: seconds a neighbour's message may take (600; 0 = for ever)" },
-	{ "hvis_pull", "TMX_HVIS_PULL", 1, "archived experiment: DSS pulled into the second hyperviscosity pass" },
-	{ "hvis_block", "TMX_HVIS_BLOCK", 1, "archived experiment: hyperviscosity passes fused with the in-patch DSS" },
+	{ "hvis_pull", "TMX_HVIS_PULL", 3, "archived experiment: DSS pulled into the second hyperviscosity pass" },
+	{ "hvis_block", "TMX_HVIS_BLOCK", 3, "archived experiment: hyperviscosity passes fused with the in-patch DSS" },
 	{ "split_stage_off", "TMX_NO_SPLIT", 1, "1: no boundary-first stages on several ranks" },
 	{ "metric_stored", "TMX_METRIC", 1, "1: stream the stored 3-D metric arrays even where the closed form is verified" },
 	{ "tracer_lincomb_pass", "TMX_TRACER_LINCOMB_PASS", 0, "1: tracer stage combination by a separate pass (A/B)" },
 	{ "udv_separate", "TMX_UDV_SEPARATE", 0, "1: vertical diffusion of U,V as a pass of its own (A/B)" },
-	{ "vx_fused", "TMX_VX_FUSED", 0, "1: V.StepExplicit's U,V update inside the explicitly-treated-terms kernel (A/B)" },
-	{ "debug_skip_exchange", "TMX_DEBUG_SKIP_EXCHANGE", 0, "TIMING AID, WRONG RESULTS at rank boundaries: a lone rank engine of an N-rank layout with the wire left out" },
+	{ "vx_fused", "TMX_VX_FUSED", 2, "1: V.StepExplicit's U,V update inside the explicitly-treated-terms kernel (A/B)" },
+	{ "debug_skip_exchange", "TMX_DEBUG_SKIP_EXCHANGE", 2, "TIMING AID, WRONG RESULTS at rank boundaries: a lone rank engine of an N-rank layout with the wire left out" },
 	{ "exchange_overlap_off", "TMX_NO_EXCHANGE_OVERLAP", 1, "1: the exchange runs on the engine's stream" },
 	{ "kessler_column", "TMX_KESSLER_COLUMN", 0, "1: one-lane-per-column Kessler kernel (cross-check)" },
 	{ "vt_column", "TMX_VT_COLUMN", 0, "1: one-lane-per-column explicit tracer update (cross-check)" },
-	{ "vt_explicit_v1", "TMX_VT_EXPLICIT_V1", 0, "1: level-parallel explicit tracer update without LDS staging (cross-check)" },
+	{ "vt_explicit_v1", "TMX_VT_EXPLICIT_V1", 2, "1: level-parallel explicit tracer update without LDS staging (cross-check)" },
 	{ "vt_lanes", "TMX_VT_LANES", 0, "columns per workgroup of the one-lane tracer column kernel (16)" },
 	{ "vt_lw8", "TMX_VT_LW8", 0, "row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
 	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },
@@ -1466,8 +1468,10 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	const OptionDef * def = nullptr;
 	for (const OptionDef & d : g_options) if (n == d.name) def = &d;
 	REQUIRE(slot && def, TMX_ERR_INVALID, "tmx_set_option: unknown option '%s'", name);
-	REQUIRE(!(def->kind == 1 && e->finalized), TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
+	REQUIRE(!((def->kind & 1) && e->finalized), TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
 	const int iv = (int)value;
+	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == *slot || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
+		"tmx_set_option(%s = %d): an archived experiment / cross-check kernel, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", name, iv);
 	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");
 	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2");
 	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
@@ -1495,6 +1499,7 @@ extern "C" int tmx_options_report(tmx_engine * e, char * buf, int cap) {
 extern "C" int tmx_options_from_environment(tmx_engine * e) {
 	REQUIRE(e, TMX_ERR_INVALID, "tmx_options_from_environment: null engine");
 	int n = 0;
+	std::string refused;
 	for (const OptionDef & d : g_options) {
 		const char * ev = getenv(d.env);
 		if (!ev) continue;
@@ -1506,8 +1511,8 @@ extern "C" int tmx_options_from_environment(tmx_engine * e) {
 		else if (nm == "debug_skip_exchange" || nm == "split_stage_off" || nm == "exchange_overlap_off" || nm == "tracer_lincomb_pass" || nm == "udv_separate" ||
 		         nm == "vx_fused" || nm == "vt_column" || nm == "vt_explicit_v1") v = 1;      // (variables whose presence alone was the switch)
 		else if (nm == "unique_layout" || nm == "vi_pair" || nm == "vi_group" || nm == "contraction_mfma" || nm == "step_graph" || nm == "vi_carry" || nm == "xcd_vertical") v = v ? 1 : 0;
-		if (d.kind == 1 && e->finalized) continue;
-		if (tmx_set_option(e, d.name, v) != TMX_OK) continue;
+		if ((d.kind & 1) && e->finalized) continue;
+		if (tmx_set_option(e, d.name, v) != TMX_OK) { refused += std::string(" ") + d.env + "=" + ev; continue; }
 		e->env_applied.push_back(std::string(d.env) + "=" + ev);
 		n++;
 	}
@@ -1516,6 +1521,8 @@ extern "C" int tmx_options_from_environment(tmx_engine * e) {
 		for (const std::string & v : e->env_applied) l += " " + v;
 		fprintf(stderr, "%s\n", l.c_str());
 	}
+	// a variable that would have changed the run and cannot: an error, not a silent default
+	REQUIRE(refused.empty(), TMX_ERR_UNSUPPORTED, "tmx_options_from_environment: refused by this build of the library (out of range, or an experiments-only option):%s", refused.c_str());
 	return n;
 }
 
@@ -1537,6 +1544,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_PARTIAL_SLOTS: return e->u.built ? e->u.nslots : 0;
 		case TMX_INFO_UNIQUE_DSS_GROUPS: return e->u.built ? e->u.ngroups : 0;
 		case TMX_INFO_PREFIX_STAGES: return e->u.prefix_stages;
+		case TMX_INFO_EXPERIMENTS_BUILD: return TMX_EXP;
 		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
 			int n = 0;
 			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;

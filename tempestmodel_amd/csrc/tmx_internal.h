@@ -306,6 +306,15 @@ void tmxuk_pack_p2p(tmx_engine * e, int buf);
 int tmxu_physics_inputs(tmx_engine * e, bool * ok);                       // refresh the per-unique-column physics inputs; *ok: the copies of every node agree
 void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu);   // xu[r][u] = xd[r][representative column of u]
 
+// Archived experiments and cross-check kernels (slower or not bit-exact paths kept for A/B runs and tests, and the timing aid that
+// leaves the wire out) are compiled into the experiments flavour of the library only (`make exp`: libtempest_mi355x_exp.so,
+// -DTMX_EXPERIMENTS); the options that select them are refused by the production library (tmx_set_option).
+#ifdef TMX_EXPERIMENTS
+#define TMX_EXP 1
+#else
+#define TMX_EXP 0
+#endif
+
 // kernel launchers (tmx_k_*.hip)
 // the prefix of a later stage's combination that an explicit stage also forms and stores (emit_value in tmx_device.h)
 struct EmitTerms { double * xp; double coef[12]; int first; };

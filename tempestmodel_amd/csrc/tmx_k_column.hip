@@ -15,6 +15,7 @@
 // Reference behaviour restated (file:line under the reference tree) is cited per kernel.
 #include "tmx_device.h"
 
+#if TMX_EXP      // the two-kernel cross-check path (option "vi_split_kernels"): in the experiments flavour of the library only
 // ---------------------------------------------------------------------------------------------
 // V implicit, part 1: residual F and analytic band Jacobian of one block row (level) of one column
 // (VerticalDynamicsFEM::SetupReferenceColumn / PrepareColumn / BuildF / BuildJacobianF_LOR_RhoTheta_Pi /
@@ -367,6 +368,7 @@ void tmxk_vi_solve(tmx_engine * e, const KParams & p, const double * xin, double
 	hipLaunchKernelGGL(k_vi_solve, dim3((e->nunique + 63) / 64), dim3(64), 0, e->stream, p, xin, xup,
 		e->nunique, e->NUS, (const int *)e->d_ucol, (const int *)e->d_udep, e->d_ab, e->d_rhs, e->d_flag);
 }
+#endif      // TMX_EXP
 
 // ---------------------------------------------------------------------------------------------
 // V implicit, fused: the same residual / Jacobian / pivoted band LU as k_vi_assemble + k_vi_solve,
@@ -1630,7 +1632,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
 		return;
 	}
-	const bool use_pair = (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
+	const bool use_pair = !TMX_EXP || (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
 	const int cpw = use_pair ? e->vi_cpw : 64;
 	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
@@ -1639,17 +1641,18 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 		// back substitution as a launch of its own (TMX_VI_SPLIT_BACK=0: inside the pair kernel); the masks go through d_rhs,
 		// which only the split cross-check kernels use otherwise
-		const bool split_back = e->vi_split_back != 0;
+		const bool split_back = TMX_EXP && e->vi_split_back != 0;      // (experiments flavour only)
 		const int stagger = e->vi_stagger;
 		const int ngrp_launched = ((ngrp + pairs - 1) / pairs) * pairs;
 		const bool split = split_back && (size_t)ngrp_launched * TMX_FTOT * (p.L + 1) * sizeof(int) <= (size_t)TMX_FTOT * (p.L + 1) * e->NUS * sizeof(double);
-#define LAUNCH_PAIR(CL_, NP_) do { if (split) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, false>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+#define LAUNCH_PAIR(CL_, NP_) do { if (TMX_EXP && split) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, TMX_EXP == 0>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
 		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR
+#if TMX_EXP
 		if (split) {
 			const int nsub = e->vi_back_sub;
 #define LAUNCH_BACK(NS_) hipLaunchKernelGGL(k_vi_back<NS_>, dim3(ngrp), dim3(64 * NS_), (size_t)TMX_FTOT * (p.L + 1) * sizeof(int), e->stream, p, xin, xup, e->nunique, e->vi_stream_cols, \
@@ -1657,8 +1660,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 			if (nsub == 2) LAUNCH_BACK(2); else if (nsub == 4) LAUNCH_BACK(4); else LAUNCH_BACK(1);
 #undef LAUNCH_BACK
 		}
+#endif
 		return;
 	}
+#if TMX_EXP      // the one-wavefront kernel (options "vi_pair" = 0, "vi_carry" = 0, "vi_sparse" = 0)
 #define LAUNCH_VI(C_, S_) do { if (p.closed) \
 		hipLaunchKernelGGL((k_vi_fused<C_, S_, true, false>), dim3((e->nunique + 63) / 64), dim3(64), lds, e->stream, p, xin, xup, dt, \
 			e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag); \
@@ -1669,6 +1674,9 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	else if (sparse) LAUNCH_VI(true, true);
 	else LAUNCH_VI(true, false);
 #undef LAUNCH_VI
+#else
+	(void)lds; (void)sparse;
+#endif
 }
 
 
@@ -1754,9 +1762,12 @@ void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xi
 	dim3 blk(64, KT_VC), grd(xcd_column_grid(xm, nt_, (p.L + 1 + KT_VC - 1) / KT_VC));
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;
+#if TMX_EXP      // (option "vx_fused", measured slower: experiments flavour only)
 		if (with_uv) hipLaunchKernelGGL((k_vi_terms_explicit<true, true>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
 			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2, nt_, xm);
-		else hipLaunchKernelGGL((k_vi_terms_explicit<true, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
+		else
+#endif
+		hipLaunchKernelGGL((k_vi_terms_explicit<true, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
 			e->cfg.uniform_diffusion_scalar / z2, e->cfg.uniform_diffusion_vector / z2, nt_, xm);
 	} else
 		hipLaunchKernelGGL((k_vi_terms_explicit<false, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0, nt_, xm);

@@ -495,10 +495,10 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	// PM_: does the update instance enter its own combination?  (no combination: irrelevant, one instantiation)
 	EmitTerms em0; em0.xp = nullptr; em0.first = -1; for (int m = 0; m < 12; m++) em0.coef[m] = 0.0;
 	// (the prefix of a later stage's combination: node-unique layout with the vertical part fused in, no own coefficient, at least two terms)
-	const bool emit_ok = emit && emit->xp && uq && fuse_v && !premul && nterms >= 3 && nterms <= 8;
+	const bool emit_ok = TMX_EXP && emit && emit->xp && uq && fuse_v && !premul && nterms >= 3 && nterms <= 8;
 	const EmitTerms em = emit_ok ? *emit : em0;
 #define LAUNCH_HV2(NT_, PM_) do { \
-		if (uq && fuse_v && emit_ok && NT_ >= 3 && NT_ <= 8 && !PM_) hipLaunchKernelGGL((k_h_explicit<true, (NT_ >= 3 && NT_ <= 8) ? NT_ : 3, false, true, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em); \
+		if (TMX_EXP && uq && fuse_v && emit_ok && NT_ >= 3 && NT_ <= 8 && !PM_) hipLaunchKernelGGL((k_h_explicit<true, (NT_ >= 3 && NT_ <= 8) ? NT_ : 3, false, true, false, TMX_EXP != 0>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em); \
 		else if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
 		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
 		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
@@ -506,7 +506,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 		else hipLaunchKernelGGL((k_h_explicit<false, NT_, false, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); } while (0)
 #define LAUNCH_HV(NT_) do { \
 		if (NT_ == 0 || premul) LAUNCH_HV2(NT_, true); else LAUNCH_HV2(NT_, false); \
-		if (uq && emit_ok && NT_ >= 3 && NT_ <= 8) hipLaunchKernelGGL((k_h_w_update<(NT_ >= 3 && NT_ <= 8) ? NT_ : 3, true, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em); \
+		if (TMX_EXP && uq && emit_ok && NT_ >= 3 && NT_ <= 8) hipLaunchKernelGGL((k_h_w_update<(NT_ >= 3 && NT_ <= 8) ? NT_ : 3, true, TMX_EXP != 0>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em); \
 		else if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true, false>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); \
 		else hipLaunchKernelGGL((k_h_w_update<NT_, false, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); } while (0)
 	switch (nterms) {
@@ -1020,10 +1020,14 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	if (p.t_ucol) {      // node-unique layout (tmxu_params)
 		KParams q = p; q.u_ntiles = ntiles;
 		hipLaunchKernelGGL((k_hypervis<false, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
-	} else if (pull_dss) hipLaunchKernelGGL((k_hypervis<true, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+	}
+#if TMX_EXP
+	else if (pull_dss) hipLaunchKernelGGL((k_hypervis<true, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+#endif
 	else hipLaunchKernelGGL((k_hypervis<false, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 }
 
+#if TMX_EXP      // archived experiment (option "hvis_block"): in the experiments flavour of the library only
 // ---------------------------------------------------------------------------------------------
 // Hyperviscosity pass FUSED with the DSS of the seams inside a patch (round 3 prototype of "remove DSS passes": DESIGN.md
 // section 7).  A workgroup owns a block of up to EB x EB elements of one patch plus the ring of elements around it (where the
@@ -1196,6 +1200,7 @@ void tmxk_hypervis_block(tmx_engine * e, const KParams & p, const double * xsrc,
 	dim3 blk(TMX_HB_T), grd(e->n_hvblocks, (p.L + 1 + TMX_HB_KT - 1) / TMX_HB_KT);
 	hipLaunchKernelGGL(k_hypervis_block, grd, blk, 0, e->stream, p, (const HvBlock *)e->d_hvblocks, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale);
 }
+#endif      // TMX_EXP
 
 // ---------------------------------------------------------------------------------------------
 // Uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (src/atm/HorizontalDynamicsFEM.cpp:1817-1859):

@@ -533,6 +533,7 @@ int tmxk_vi_tracers(tmx_engine * e, const KParams & p, const double * xin, const
 	return 0;
 }
 
+#if TMX_EXP      // the form without LDS staging (option "vt_explicit_v1"), superseded by k_v_tracers_explicit_tile: experiments flavour only
 // UpdateColumnTracers in the fully explicit vertical mode, level-parallel.  There the matrix is the diagonal 1/dt, so the
 // update of (column, level, tracer) only needs the column within two levels: one thread per (column, level) evaluates
 // exactly the statements of k_vi_tracers' explicit branch (same operands, same order: bit-identical, tested) instead of one
@@ -660,8 +661,9 @@ __global__ __launch_bounds__(256) void k_v_tracers_explicit(KParams p, int nt, c
 		xup[so + col] = xup[so + col] - F;
 	}
 }
+#endif      // TMX_EXP
 
-// The same update with the shared operands of a tile staged once in LDS: a workgroup = 64 columns x 8 levels; xi_dot (and, with
+// The same update (k_v_tracers_explicit, experiments flavour: one thread per (column, level) with every operand from memory) with the shared operands of a tile staged once in LDS: a workgroup = 64 columns x 8 levels; xi_dot (and, with
 // uniform diffusion, rho) on the tile's 9 interfaces, rho on its 12 levels and per tracer the 12 column values and mixing-ratio
 // deviations (two fp64 divisions each) are evaluated by one thread each instead of by every thread whose stencil reaches them
 // (5 x for the divisions: 372 -> 264 us per launch at ne30 L40 with three tracers).  Every value is produced by the same expression as above, so the results are bit-identical.
@@ -806,12 +808,14 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
 	if (!e->opt_vt_column) {      // level-parallel form (default); option "vt_column": the one-lane-per-column kernel, for A/B and tests
-		const bool v1 = e->opt_vt_explicit_v1 != 0;       // the form without LDS staging, for A/B and tests
-		if (v1) {
+#if TMX_EXP
+		if (e->opt_vt_explicit_v1) {      // the form without LDS staging, for A/B and tests
 			dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
 			hipLaunchKernelGGL(k_v_tracers_explicit, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,
 				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
-		} else {
+		} else
+#endif
+		{
 			const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
 			dim3 blk(64, 8), grd(xcd_column_grid(xm, nt_, (p.L + 7) / 8));
 			hipLaunchKernelGGL(k_v_tracers_explicit_tile, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,

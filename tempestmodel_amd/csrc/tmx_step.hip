@@ -350,10 +350,13 @@ static int v_step_implicit_impl(tmx_engine * e, int iinit, int iupd, double dt, 
 		HIPCHK(hipMemcpyAsync(e->d_w0, w0, (size_t)(e->L + 1) * e->NS * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
 		w0 = e->d_w0;
 	}
+#if TMX_EXP
 	if (e->vi_mode == 1) {
 		{ ProfScope ps(e, TMX_K_VI_ASSEMBLE); tmxk_vi_assemble(e, p, inst(e, iinit), dt); }
 		{ ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_solve(e, p, inst(e, iinit), inst(e, iupd)); }
-	} else {
+	} else
+#endif
+	{
 		ProfScope ps(e, TMX_K_VI_SOLVE); tmxk_vi_fused(e, p, inst(e, iinit), inst(e, iupd), dt);
 	}
 	if (e->nt > 0) {
@@ -429,7 +432,7 @@ static int exchange(tmx_engine * e, const KParams & p, double * x, bool * overla
 	if (e->lb) return exchange_loopback(e, p, x);
 	// timing aid: a lone rank engine of an N-rank layout with the wire left out (results are then wrong at the rank
 	// boundary; used only by tools/rank_share_timing.py to measure the per-rank compute share of a step)
-	if (e->opt_skip_exchange) { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); return TMX_OK; }
+	if (TMX_EXP && e->opt_skip_exchange) { if (x) tmxk_pack(e, p, x); else tmxuk_pack(e); return TMX_OK; }      // (experiments flavour only)
 	REQUIRE(e->comm || e->p2p, TMX_ERR_COMM, "tmx_comm_init or tmx_halo_p2p_connect must be called before a multi-rank exchange");
 	ProfScope ps(e, TMX_K_EXCHANGE);
 	const unsigned long long seq = ++e->p2p_seq;
@@ -604,7 +607,7 @@ static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int i
 		// seam node gathers its one to three partner values per field from other elements' rows: n^2 instead of n loads per
 		// group, 8 bytes per lane from up to 30 different cache lines per wavefront instruction, not L2 hits) against the 62 us
 		// and 248 MB of the DSS pass it replaces (profiles/r03_dss_pull_ab.txt).  Without tracers only (k_hypervis_tracers has no such form).
-		const bool pull = e->hvis_pull && e->nt == 0 && work_is_scratch;
+		const bool pull = TMX_EXP && e->hvis_pull && e->nt == 0 && work_is_scratch;      // (experiments flavour only)
 		if (stage_can_split(e) && !e->sw) {
 			// each pass boundary tiles first, its exchange overlapped with the interior tiles (see hv_stage_split)
 			for (int pass = 0; pass < 2; pass++) {
@@ -631,7 +634,9 @@ static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int i
 					if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));      // the neighbours' Laplacians are in the ghost buffer
 				} else if ((r = dss_after_exchange(e, p, idst, overlapped))) return r;
 			}
-		} else if (e->hvis_block && e->nt == 0 && !e->sw && e->n_hvblocks > 0) {
+		}
+#if TMX_EXP
+		else if (e->hvis_block && e->nt == 0 && !e->sw && e->n_hvblocks > 0) {
 			// both passes fused with the DSS of the seams inside a patch (k_hypervis_block); k_dss only for the groups that span patches
 			for (int pass = 0; pass < 2; pass++) {
 				const int idst = pass ? iupd : iwork;
@@ -645,7 +650,9 @@ static int h_step_after_subcycle_impl(tmx_engine * e, int iinit, int iupd, int i
 				if ((r = exchange(e, p, inst(e, idst), &overlapped))) return r;
 				if ((r = dss_after_exchange(e, p, idst, overlapped, e->ngroups_inpatch))) return r;
 			}
-		} else {
+		}
+#endif
+		else {
 			{ ProfScope ps(e, TMX_K_HYPERVIS); tmxk_hypervis(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 1.0, 1.0, 0);
 			  if (e->nt > 0) tmxk_hypervis_tracers(e, p, inst(e, iinit), nullptr, inst(e, iwork), 1.0, 1.0, 0, 0); }
 			if ((r = launch_check("hypervis pass 1"))) return r;
@@ -1745,7 +1752,7 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	for (int k = 0; k < e->cfg.n_instances; k++) if ((livein >> k & 1u) && !u.form[k]) need_check = true;
 	if (need_check && u.skip_steps > 0) { u.skip_steps--; return TMX_OK; }      // the last checks failed: not every step pays for another one
 	// (timing aid TMX_DEBUG_SKIP_EXCHANGE: the state of such a run is garbage at the rank boundary, NaN payloads included; no check)
-	const bool trust = e->opt_skip_exchange != 0;
+	const bool trust = TMX_EXP && e->opt_skip_exchange != 0;
 	// the check comes first and works on the slots as the element-major programs left them (shared slots included: an instance
 	// that shares is given its own first, which for the model state never happens), so that a step that stays element-major keeps them
 	for (int k = 0; k < e->cfg.n_instances && !trust; k++) {
@@ -1789,7 +1796,7 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	// relaunched as one graph.  Off by default: the plain sequence is already queued asynchronously far ahead of the
 	// GPU, and the replay measured 0-1 % SLOWER (ne8: 0.419 vs 0.414 ms/step, ne16: 0.605 vs 0.601, ne30: 1.65 both).
 	// Multi-rank steps (RCCL calls on a second stream) and profiled steps always use the plain sequence.
-	if (e->use_graph && (e->cfg.n_ranks == 1 || e->opt_skip_exchange) && !e->prof && !e->lb) {
+	if (e->use_graph && (e->cfg.n_ranks == 1 || (TMX_EXP && e->opt_skip_exchange)) && !e->prof && !e->lb) {
 		StepGraphKey key = { scheme, first_step ? 1 : 0, last_step ? 1 : 0, dt };
 		for (auto & g : e->graphs)
 			if (g.key.scheme == key.scheme && g.key.first == key.first && g.key.last == key.last && g.key.dt == key.dt) {

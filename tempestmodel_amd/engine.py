@@ -58,19 +58,27 @@ class TmxPatchGeometry(C.Structure):
     _fields_ = [(n, PD) for n in GEOM_FIELDS]
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load the HIP library.  Fails loudly when it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(flavour=None):
+    """Load the HIP library.  Fails loudly when it has not been built (no fallback).
+
+    ``flavour``: None = the production library; "experiments" = libtempest_mi355x_exp.so (`make -C tempestmodel_amd/csrc exp`),
+    the same library plus the archived experiments and cross-check kernels whose options the production library refuses
+    (TMX_FLAVOUR=experiments in the environment selects it for test plumbing that cannot pass the argument)."""
+    flavour = flavour or os.environ.get("TMX_FLAVOUR") or None
+    if flavour not in (None, "production", "experiments"):
+        raise ValueError("unknown library flavour %r" % (flavour,))
     path = os.environ.get("TMX_LIBRARY") or LIB_PATH      # TMX_LIBRARY: an experimental build of the same library (tools/ablate.sh)
     if os.environ.get("TMX_LU_FMA") == "0" and not os.environ.get("TMX_LIBRARY"):
         # the flavour whose band-LU updates are multiply + subtract (`make -C tempestmodel_amd/csrc nofma`): for a reference
         # linked to a BLAS without fused multiply-adds
         path = LIB_PATH.replace(".so", "_nofma.so")
+    elif flavour == "experiments" and not os.environ.get("TMX_LIBRARY"):
+        path = LIB_PATH.replace(".so", "_exp.so")
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise ImportError("libtempest_mi355x.so is missing at %s -- build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
@@ -136,7 +144,7 @@ def load_library():
     lib.tmx_get_option.argtypes = [C.c_void_p, C.c_char_p, PD]
     lib.tmx_options_from_environment.argtypes = [C.c_void_p]
     lib.tmx_options_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -161,12 +169,12 @@ class Engine:
     (or anything exposing the same reference-layout arrays)."""
 
     def __init__(self, grid, n_instances=7, nu=(1.0e15, 1.0e15, 1.0e15), hypervis_order=4,
-                 rank=0, n_ranks=1, owner=None, device=-1, fully_explicit=False, uniform_diffusion=None, options=None):
+                 rank=0, n_ranks=1, owner=None, device=-1, fully_explicit=False, uniform_diffusion=None, options=None, flavour=None):
         """``fully_explicit``: VerticalDynamicsFEM's --explicitvertical mode; ``uniform_diffusion``: (K_scalar, K_vector)
         of Grid::HasUniformDiffusion (reference state and tracers are taken from ``grid.patches[*].geom``); ``options``:
-        {name: value} for tmx_set_option before tmx_finalize (e.g. {"unique_layout": 1})."""
+        {name: value} for tmx_set_option before tmx_finalize (e.g. {"unique_layout": 1}); ``flavour``: see load_library."""
         self.options = dict(options or {})
-        self.lib = load_library()
+        self.lib = load_library(flavour)
         self.grid = grid
         self.L = grid.L
         self.npatch = len(grid.patches)
@@ -197,7 +205,11 @@ class Engine:
         self._chk(self.lib.tmx_create(C.byref(cfg), C.byref(h)))
         self.h = h
         # test / bench plumbing keeps the TMX_* variables: turned into options here, explicitly (the library itself reads none)
-        self.lib.tmx_options_from_environment(self.h)
+        if self.lib.tmx_options_from_environment(self.h) < 0:      # a variable this flavour of the library refuses
+            msg = self.lib.tmx_last_error().decode()
+            self.lib.tmx_destroy(self.h)
+            self.h = None
+            raise TempestError(-1, msg)
         try:
             self._setup()
         except Exception:

@@ -19,11 +19,12 @@ def _declared_symbols():
 
 def test_library_exports_every_declared_symbol():
     from tempestmodel_amd.engine import load_library
-    lib = load_library()
     syms = _declared_symbols()
     assert len(syms) >= 25
-    for s in syms:
-        assert hasattr(lib, s), "libtempest_mi355x.so does not export %s" % s
+    for flavour in (None, "experiments"):      # the production library and the one with the archived experiments compiled in: one ABI
+        lib = load_library(flavour)
+        for s in syms:
+            assert hasattr(lib, s), "libtempest_mi355x%s.so does not export %s" % ("_exp" if flavour else "", s)
 
 
 def test_no_cpu_fallback():
@@ -239,22 +240,38 @@ def test_options_are_explicit_and_reported():
 
     old = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("TMX_")}
     try:
-        os.environ["TMX_VI_PAIR"] = "0"; os.environ["TMX_MFMA"] = "1"; os.environ["TMX_QUIET"] = "1"
+        os.environ["TMX_VI_GROUP"] = "1"; os.environ["TMX_MFMA"] = "1"; os.environ["TMX_QUIET"] = "1"
         h = ctypes.c_void_p()
         assert lib.tmx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
         r = report(h)
-        assert r["vi_pair"] == "-1" and r["contraction_mfma"] == "0" and "from_environment" not in r      # tmx_create looked at nothing
+        assert r["vi_group"] == "-1" and r["contraction_mfma"] == "0" and "from_environment" not in r      # tmx_create looked at nothing
         assert lib.tmx_options_from_environment(h) == 2
         r = report(h)
-        assert r["vi_pair"] == "0" and r["contraction_mfma"] == "1" and "TMX_VI_PAIR=0" in r["from_environment"]
+        assert r["vi_group"] == "1" and r["contraction_mfma"] == "1" and "TMX_VI_GROUP=1" in r["from_environment"]
         assert lib.tmx_set_option(h, b"unique_layout", ctypes.c_double(0.0)) == 0 and report(h)["unique_layout"] == "0"
         assert lib.tmx_set_option(h, b"no_such_option", ctypes.c_double(1.0)) != 0
         assert lib.tmx_set_option(h, b"unique_tile_shape", ctypes.c_double(7.0)) != 0
         v = ctypes.c_double(-5.0)
         assert lib.tmx_get_option(h, b"vi_group_max", ctypes.byref(v)) == 0 and v.value == 6400.0
+        # archived experiments and cross-check kernels: the production library holds neither the kernels nor the switch
+        lib.tmx_info.restype = ctypes.c_longlong
+        assert lib.tmx_info(h, 18) == 0      # TMX_INFO_EXPERIMENTS_BUILD
+        for name, value in ((b"hvis_pull", 1.0), (b"hvis_block", 1.0), (b"vi_pair", 0.0), (b"vi_split_kernels", 1.0), (b"unique_prefix", 1.0),
+                            (b"debug_skip_exchange", 1.0), (b"vx_fused", 1.0), (b"vt_explicit_v1", 1.0), (b"vi_split_back", 1.0)):
+            assert lib.tmx_set_option(h, name, ctypes.c_double(value)) == -2, name      # TMX_ERR_UNSUPPORTED
+            assert b"experiments flavour" in lib.tmx_last_error()
+        assert lib.tmx_set_option(h, b"vi_pair", ctypes.c_double(1.0)) == 0 and lib.tmx_set_option(h, b"hvis_pull", ctypes.c_double(0.0)) == 0
+        os.environ["TMX_HVIS_PULL"] = "1"      # and a variable that cannot be honoured is an error, not a silent default
+        assert lib.tmx_options_from_environment(h) == -2 and b"TMX_HVIS_PULL=1" in lib.tmx_last_error()
+        os.environ.pop("TMX_HVIS_PULL")
         lib.tmx_destroy(h)
+        xl = eng.load_library("experiments")
+        h = ctypes.c_void_p()
+        assert xl.tmx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+        assert xl.tmx_info(h, 18) == 1 and xl.tmx_set_option(h, b"hvis_pull", ctypes.c_double(1.0)) == 0
+        xl.tmx_destroy(h)
     finally:
-        for k in ("TMX_VI_PAIR", "TMX_MFMA", "TMX_QUIET"):
+        for k in ("TMX_VI_GROUP", "TMX_MFMA", "TMX_QUIET", "TMX_HVIS_PULL"):
             os.environ.pop(k, None)
         os.environ.update(old)
 

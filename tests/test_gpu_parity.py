@@ -331,7 +331,8 @@ def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_ke
             monkeypatch.delenv("TMX_VT_EXPLICIT_V1", raising=False)
             if variant:
                 monkeypatch.setenv(variant, "1")
-            e = Engine(g, fully_explicit=True, uniform_diffusion=ud)
+            # (the untiled form is an archived kernel: experiments flavour of the library)
+            e = Engine(g, fully_explicit=True, uniform_diffusion=ud, flavour="experiments" if variant == "TMX_VT_EXPLICIT_V1" else None)
             try:
                 e.upload_state(0, st); e.upload_tracers(0, tr)
                 e.copy_data(0, 1)
@@ -821,7 +822,7 @@ def test_fused_column_kernels_are_bit_identical_to_split_kernels():
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_STAGGER_NS": "5000"}):
         os.environ.update(env)
         try:
-            e = Engine(g)
+            e = Engine(g, flavour="experiments")      # (the one-wavefront, split and separate-back-substitution kernels live there)
             e.upload_state(1, start)
             e.copy_data(1, 2)
             e.v_step_implicit(1, 2, 87.0)
@@ -865,7 +866,7 @@ def test_column_solve_with_lane_divergent_pivots():
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"}):
         os.environ.update(env)
         try:
-            e = Engine(g)
+            e = Engine(g, flavour="experiments" if env["TMX_VI_PAIR"] == "0" else None)
             e.upload_state(1, rough)
             e.copy_data(1, 2)
             if env["TMX_VI_PAIR"] == "1":
@@ -1640,9 +1641,9 @@ def test_dss_pulled_into_the_second_hyperviscosity_pass_is_bit_identical(monkeyp
     from tempestmodel_amd.engine import Engine
     g, start = gu.make_grid(12, 6, 24)
     ref_e = Engine(g)
-    monkeypatch.setenv("TMX_HVIS_PULL", "1")
-    pull = Engine(g)
-    ranks = [Engine(g, rank=r, n_ranks=3) for r in range(3)]
+    monkeypatch.setenv("TMX_HVIS_PULL", "1")      # (an archived kernel: experiments flavour of the library)
+    pull = Engine(g, flavour="experiments")
+    ranks = [Engine(g, rank=r, n_ranks=3, flavour="experiments") for r in range(3)]
     monkeypatch.delenv("TMX_HVIS_PULL")
     try:
         for e in [ref_e, pull] + ranks:
@@ -1936,7 +1937,7 @@ def test_hyperviscosity_fused_with_the_in_patch_dss_is_bit_identical(ne, npatch,
     res = []
     for block in ("1", "0"):
         monkeypatch.setenv("TMX_HVIS_BLOCK", block)
-        e = Engine(g)
+        e = Engine(g, flavour="experiments")      # (an archived kernel: experiments flavour of the library)
         try:
             e.upload_state(0, start)
             for k in range(3):
@@ -1971,7 +1972,7 @@ def test_stage_copies_left_out_and_fused_uv_update_are_bit_identical(monkeypatch
         for k, v in variant.items():
             if k.startswith("TMX_"):
                 monkeypatch.setenv(k, v)
-        e = Engine(g, n_instances=ninst, fully_explicit=True, uniform_diffusion=UDIFF)
+        e = Engine(g, n_instances=ninst, fully_explicit=True, uniform_diffusion=UDIFF, flavour="experiments" if "TMX_VX_FUSED" in variant else None)
         try:
             e.upload_state(0, st); e.upload_tracers(0, tr)
             for step in (1, 2, 3):

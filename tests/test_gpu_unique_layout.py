@@ -61,13 +61,13 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
 def test_stored_prefix_of_a_stage_combination_changes_no_bit():
     """ARS343's third stage reads instances 0..4, the leading terms of the fourth stage's combination (1, 0, 2, 3, 4, 5, 6 in the
     reference's accumulation order): with "unique_prefix" it also stores that partial sum, and the fourth stage reads it and instances 5, 6.  With the
-    option off (the default: the extra store costs what the four reads save) every stage reads all its
-    sources; same bits, with shared U,V slabs (the default) and with every copy made."""
+    option off (the default, and all the production library has: the extra store costs what the four reads save, DESIGN.md
+    section 3a; the storing kernels are in the experiments flavour of the library) every stage reads all its sources; same bits, with shared U,V slabs (the default) and with every copy made."""
     from tempestmodel_amd.engine import Engine
     g, start = gu.make_grid(6, 8, 6)
     for share in (1, 0):
-        a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1, "share_copies": share})
-        b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0, "share_copies": share})
+        a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1, "share_copies": share}, flavour="experiments")
+        b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0, "share_copies": share})      # (the production library)
         try:
             a.upload_state(0, start); b.upload_state(0, start)
             for k in range(5):

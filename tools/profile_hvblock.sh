@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --steps 5 --warmup 2 --develop 3 --no-cpu-baseline --sustained-steps 0"
 for blk in 1 0; do
-	export TMX_HVIS_BLOCK=$blk
+	export TMX_HVIS_BLOCK=$blk TMX_FLAVOUR=experiments
 	rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/hvb${blk}_fetch -o hvb -- python3 $B > /dev/null 2>&1
 	rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/hvb${blk}_write -o hvb -- python3 $B > /dev/null 2>&1
 	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hvb${blk}_trace -o hvb -- python3 $B > /dev/null 2>&1

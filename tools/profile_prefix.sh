@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 P="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sustained-steps 0 --parity-steps 0"
 for m in 0 1; do
-	export TMX_UNIQUE_PREFIX=$m
+	export TMX_UNIQUE_PREFIX=$m TMX_FLAVOUR=experiments
 	timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefix_trace_$m -o pfx -- python3 $P > $OUT/prefix_trace_$m.log 2>&1
 	f=$(find $OUT/prefix_trace_$m -name "pfx_kernel_stats.csv" | head -1)
 	echo "== unique_prefix=$m"

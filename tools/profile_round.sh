@@ -51,8 +51,8 @@ one fetch_c5 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_c5 -o ${T
 one write_c5 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_c5 -o ${TAG} -- python3 $B5
 one trace_c5 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_c5 -o ${TAG} -- python3 $B5
 # the DSS pulled into the second hyperviscosity pass (archived experiment): bytes of k_hypervis / k_dss with and without
-export TMX_HVIS_PULL=1
+export TMX_HVIS_PULL=1 TMX_FLAVOUR=experiments
 one fetch_pull --pmc FETCH_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/${TAG}_fetch_pull -o ${TAG} -- python3 $B
 one write_pull --pmc WRITE_SIZE --kernel-include-regex "k_hypervis|k_dss" --output-format csv -d $OUT/${TAG}_write_pull -o ${TAG} -- python3 $B
-unset TMX_HVIS_PULL
+unset TMX_HVIS_PULL TMX_FLAVOUR
 find $OUT -name "*.csv" | head -80

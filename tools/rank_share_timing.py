@@ -6,6 +6,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["TMX_DEBUG_SKIP_EXCHANGE"] = "1"
+os.environ["TMX_FLAVOUR"] = "experiments"      # the timing aid is compiled into that flavour of the library only
 from tempestmodel_amd.cubed_sphere import CubedSphereGrid, BaroclinicWaveJW
 from tempestmodel_amd.engine import Engine
 
