@@ -70,6 +70,9 @@ void tmxk_h_timing_read(unsigned long long * out) { for (int i = 0; i < 128; i++
 #ifndef TMX_H_EM_GROUPS
 #define TMX_H_EM_GROUPS 2
 #endif
+#ifndef TMX_H_LATE_BASE_D
+#define TMX_H_LATE_BASE_D 1      // the same on the element-major layout
+#endif
 #ifndef TMX_H_LATE_BASE
 #define TMX_H_LATE_BASE 1  // node-unique layout, stage combinations of three and more terms: the combination's raw terms are loaded and reduced at the end of
                            // the kernel, next to the stores, where almost nothing else is live -- in the prologue's burst they take the kernel over 128 registers
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	// and reduced to four values at once -- loading it at the point of use made the compiler keep all 48 LDS reads
 	// and the 4 x NT combination sources live together (180-200 VGPRs, occupancy 2)
 	HT_DECL;
-	constexpr bool LB = TMX_H_LATE_BASE && UQ && FUSE_V && !MF && NT >= 3 && !TMX_H_BURST;
+	constexpr bool LB = TMX_H_LATE_BASE && (UQ || TMX_H_LATE_BASE_D) && FUSE_V && !MF && NT >= 3 && !TMX_H_BURST;
 	double bU = 0, bV = 0, bT = 0, bR = 0, bW = 0;
 	constexpr int NX = NT > 0 ? NT : 1;
 	double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 	}
 	const double tR = dt * invJ * (darf + dbrf), tT = dt * invJ * (dapf + dbpf);
 	double outR = bR - tR, outT = bT - tT;
-	if (!UQ) {
+	if (!UQ && !LB) {
 		stu(xup + sU, colb, outU);
 		stu(xup + sV, colb, outV);
 		stu(xup + sR, colb, outR);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			v += OPC(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
 			tW = dt * v;
 			outW = bW + tW;
-			if (!UQ) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
+			if (!UQ && !LB) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
 		}
 	} else
 		stu(ucz + (size_t)k * NS, colb, uczx);
@@ -389,6 +392,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		if (k > 0) { outU += tUlo; outV += tVlo; }
 		outR = bR - tR; outT = bT - tT;
 		if (withW) outW = bW + tW;
+		if (!UQ) {
+			stu(xup + sU, colb, outU); stu(xup + sV, colb, outV); stu(xup + sR, colb, outR); stu(xup + sT, colb, outT);
+			if (withW) stu(xup + TMX_SLAB_W(L, k) * NS, colb, outW);
+		}
 	}
 	if (UQ && !MF) {
 		// rows 1..5 of the wavefront's LDS block (row 0 is being read by the wavefront above); W only where this kernel updates it
