@@ -1418,7 +1418,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("split_stage_off", e->opt_no_split); OPT("metric_stored", e->opt_metric_stored); OPT("tracer_lincomb_pass", e->opt_tracer_lincomb_pass);
 	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
 	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
-	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
+	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
 	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows);
 #undef OPT
 	return nullptr;
@@ -1456,6 +1456,7 @@ static const OptionDef g_options[] = {
 	{ "kessler_column", "TMX_KESSLER_COLUMN", 0, "1: one-lane-per-column Kessler kernel (cross-check)" },
 	{ "vt_column", "TMX_VT_COLUMN", 0, "1: one-lane-per-column explicit tracer update (cross-check)" },
 	{ "vt_explicit_v1", "TMX_VT_EXPLICIT_V1", 2, "1: level-parallel explicit tracer update without LDS staging (cross-check)" },
+	{ "vt_explicit_walk", "TMX_VT_WALK", 0, "explicit tracer update: -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the LDS-tiled level-parallel kernel; 4, 5, 6, 8, 10 = that many levels per thread held in registers (experiments build)" },
 	{ "vt_lanes", "TMX_VT_LANES", 0, "columns per workgroup of the one-lane tracer column kernel (16)" },
 	{ "vt_lw8", "TMX_VT_LW8", 0, "row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
 	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },
@@ -1470,6 +1471,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(slot && def, TMX_ERR_INVALID, "tmx_set_option: unknown option '%s'", name);
 	REQUIRE(!((def->kind & 1) && e->finalized), TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
 	const int iv = (int)value;
+	REQUIRE(TMX_EXP || n != "vt_explicit_walk" || iv <= 0, TMX_ERR_UNSUPPORTED, "tmx_set_option(vt_explicit_walk = %d): the register-held segments are compiled into the experiments flavour of the library only", iv);
 	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == *slot || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
 		"tmx_set_option(%s = %d): an archived experiment / cross-check kernel, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", name, iv);
 	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");

@@ -804,10 +804,313 @@ __global__ __launch_bounds__(512) void k_v_tracers_explicit_tile(KParams p, int 
 	}
 }
 
+#if TMX_EXP      // superseded by the sliding-window form below (measured: -2 % against the tiled kernel at 4 levels per thread, slower at 8 and 10): experiments flavour only
+// The same update by column segments: a thread = (column, KC consecutive levels), no LDS and no barrier.  The operands a segment's
+// stencils reach -- U, V, rho on KC + 3 / KC + 4 levels, per tracer the KC + 4 column values and mixing-ratio deviations -- are loaded
+// once into registers and every interface flux is formed once (the level-parallel forms evaluate the flux of interface k + 1 for level
+// k and again for level k + 1: the same expression on the same operands, so once is the same value).  Statement for statement the
+// arithmetic of k_v_tracers_explicit_tile: bit-identical (tested).
+template <int KC>
+__global__ __launch_bounds__(64) void k_v_tracers_explicit_walk(KParams p, int nt, const double * __restrict__ xin, double * xup, double dt,
+	double ks, const double * __restrict__ xref, int ntile, int xmode)
+{
+	constexpr int NL = KC + 4, NI = KC + 1;
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (L + KC - 1) / KC, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	if (col >= p.ncol) return;
+	const int k0 = WAVE_UNIFORM(by * KC);
+	const int nk = min(KC, L - k0);
+	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	double xd[NI], re[NI], rh[NL], rr[NL];
+	{
+		// xi_dot of the initial column on the segment's interfaces (zero at the boundaries), rho there (uniform diffusion only)
+		const MetCol mc = met_col(p, col);
+		double uw[KC + 3], vw[KC + 3];
+#pragma unroll
+		for (int t = 0; t < KC + 3; t++) {
+			const int l = k0 - 2 + t;
+			uw[t] = 0.0; vw[t] = 0.0;
+			if (l >= 0 && l < L) { uw[t] = xin[(size_t)TMX_SLAB_U(L, l) * NS + col]; vw[t] = xin[(size_t)TMX_SLAB_V(L, l) * NS + col]; }
+		}
+#pragma unroll
+		for (int li = 0; li < NL; li++) {
+			const int l = k0 - 2 + li;
+			rh[li] = 1.0; rr[li] = 1.0;
+			if (ks != 0.0 && l >= 0 && l < L) { rh[li] = xin[(size_t)TMX_SLAB_R(L, l) * NS + col]; rr[li] = xref[(size_t)TMX_SLAB_R(L, l) * NS + col]; }
+		}
+#pragma unroll
+		for (int mi = 0; mi < NI; mi++) {
+			const int m = k0 + mi;
+			double x0v = 0.0, r0 = 0.0;
+			if (mi <= nk && m >= 1 && m <= L - 1) {
+				double ue = 0.0, ve = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					const double cc = OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+					ue += cc * uw[mi + off + 2];
+					ve += cc * vw[mi + off + 2];
+				}
+				double e0, e1, e2;
+				metric_edge(p, mc, m, col, e0, e1, e2);
+				x0v = e0 * ue + e1 * ve + e2 * w0[(size_t)m * NS + col];
+			}
+			if (ks != 0.0 && mi <= nk && m <= L) {
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					r0 += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * rh[mi + off + 2];
+				}
+			}
+			xd[mi] = x0v; re[mi] = r0;
+		}
+	}
+	const double idt = 1.0 / dt;
+	for (int c = 0; c < nt; c++) {
+		double q[NL], mr[NL], up0[KC];
+#pragma unroll
+		for (int li = 0; li < NL; li++) {
+			const int l = k0 - 2 + li;
+			double qv = 0.0, a_ = 0.0;
+			if (l >= 0 && l < L) {
+				qv = xin[(size_t)TMX_SLAB_Q(L, c, l) * NS + col];
+				if (ks != 0.0) {
+					a_ = qv / rh[li];
+					a_ -= xref[(size_t)TMX_SLAB_Q(L, c, l) * NS + col] / rr[li];
+				}
+			}
+			q[li] = qv; mr[li] = a_;
+		}
+#pragma unroll
+		for (int i = 0; i < KC; i++) up0[i] = (i < nk) ? xup[(size_t)TMX_SLAB_Q(L, c, k0 + i) * NS + col] : 0.0;
+		double mf[NI];
+#pragma unroll
+		for (int mi = 0; mi < NI; mi++) {
+			const int m = k0 + mi;
+			double v = 0.0;
+			if (mi <= nk) {
+				double qe = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					qe += OPC(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * q[mi + off + 2];
+				}
+				v = (m == 0 || m == L) ? 0.0 : je * qe * xd[mi];
+				if (ks != 0.0 && m > 0 && m < L) {
+					double dq = 0.0;
+#pragma unroll
+					for (int off = -2; off <= 1; off++) {
+						const int l = m + off;
+						if (l < 0 || l >= L) continue;
+						dq += OPC(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mr[mi + off + 2];
+					}
+					v -= ks * re[mi] * dq;
+				}
+			}
+			mf[mi] = v;
+		}
+#pragma unroll
+		for (int i = 0; i < KC; i++) {
+			if (i >= nk) continue;
+			const int k = k0 + i;
+			double dmf = 0.0;
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf[i];
+			dmf += OPC(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf[i + 1];
+			double F = dmf / jn;
+			double aux = 0.0;
+			if (k < L - 1) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 0) * q[i + 2];
+				b += OPC(TMX_OP_PENALTY_LEFT, k, 1) * q[i + 3];
+				aux += b * fabs(xd[i + 1]);
+			}
+			if (k > 0) {
+				double b = 0.0;
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, -1) * q[i + 1];
+				b += OPC(TMX_OP_PENALTY_RIGHT, k, 0) * q[i + 2];
+				aux += b * fabs(xd[i]);
+			}
+			F -= aux;
+			if (F != 0.0) F /= idt;
+			xup[(size_t)TMX_SLAB_Q(L, c, k) * NS + col] = up0[i] - F;
+		}
+	}
+}
+
+#endif      // TMX_EXP
+
+// The same update by a thread that walks a column (or one of `nseg` segments of it) level by level with the stencils' operands in a
+// sliding register window -- the four levels k - 1 .. k + 2 of U, V, rho and, for NTR tracers at once, of the column values and
+// mixing-ratio deviations -- so that every operand is loaded once (a segment re-reads the four levels around its ends), the two
+// divisions of a deviation and every interface flux are evaluated once, and the level entering the window is loaded an iteration
+// ahead of its first use.  No LDS, no barrier.  Statement for statement the arithmetic of k_v_tracers_explicit_tile: bit-identical (tested).
+#define OPCL(op, k, off) opsl[(((op) * (L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+// The operator coefficients and the 1 - eta table come from LDS: the kernel stores to the update instance inside the loop, after which
+// the compiler may not read them through the scalar cache any more (the stores might alias them) -- as vector loads each one waits
+// for every load in flight (s_waitcnt vmcnt(0)), the prefetched level included.
+template <int NTR, bool CLOSED>
+__global__ __launch_bounds__(128) void k_v_tracers_explicit_slide(KParams p, int c0, const double * __restrict__ xin, double * xup, double dt,
+	double ks, const double * __restrict__ xref, int ntile, int xmode, int nseg)
+{
+	extern __shared__ double opsl[];      // [TMX_OP_COUNT][L + 1][TMX_OPW], then 1 - eta [2 L + 1]
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	double * etal = opsl + TMX_OP_COUNT * (L + 1) * TMX_OPW;
+	{
+		const int tid = threadIdx.y * 64 + threadIdx.x;
+		for (int t = tid; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128) opsl[t] = p.ops[t];
+		if (CLOSED) for (int t = tid; t < 2 * L + 1; t += 128) etal[t] = p.eta[t];
+		__syncthreads();
+	}
+	constexpr int MM = CLOSED ? 1 : 2;
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (nseg + 1) / 2, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	if (col >= p.ncol) return;
+	const int sg = WAVE_UNIFORM(by * 2 + (int)threadIdx.y);      // the two wavefronts of a workgroup: two segments of the same columns
+	const int seg = (L + nseg - 1) / nseg, k0 = sg * seg, k1 = min(L, k0 + seg);
+	if (sg >= nseg || k0 >= k1) return;
+	const double * w0 = xin + (size_t)TMX_SLAB_W(L, 0) * NS;
+	const double jn = p.g2d[G2_JN * NS + col], je = p.g2d[G2_JE * NS + col];
+	const MetCol mc = met_col(p, col);
+	const bool ud = ks != 0.0;
+	const double idt = 1.0 / dt;
+	auto in = [&](int l) { return l >= 0 && l < L; };
+	// deviation of the mixing ratio from the reference's (uniform diffusion only), as the staging of the tiled kernel forms it
+	auto deviation = [&](bool ok, double qv, double rhv, double qrv, double rrv) -> double {
+		double a_ = 0.0;
+		if (ok && ud) { a_ = qv / rhv; a_ -= qrv / rrv; }
+		return a_;
+	};
+	// window: levels k - 1 .. k + 2, at the (virtual) level k = k0 - 1 the walk starts from
+	double uw[4], vw[4], rh[4], q[NTR][4], mr[NTR][4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int l = k0 - 2 + j;
+		const bool ok = in(l);
+		uw[j] = ok ? xin[(size_t)TMX_SLAB_U(L, l) * NS + col] : 0.0;
+		vw[j] = ok ? xin[(size_t)TMX_SLAB_V(L, l) * NS + col] : 0.0;
+		const double rhv = (ok && ud) ? xin[(size_t)TMX_SLAB_R(L, l) * NS + col] : 1.0, rrv = (ok && ud) ? xref[(size_t)TMX_SLAB_R(L, l) * NS + col] : 1.0;
+		rh[j] = rhv;
+#pragma unroll
+		for (int t = 0; t < NTR; t++) {
+			const double qv = ok ? xin[(size_t)TMX_SLAB_Q(L, c0 + t, l) * NS + col] : 0.0;
+			const double qrv = (ok && ud) ? xref[(size_t)TMX_SLAB_Q(L, c0 + t, l) * NS + col] : 0.0;
+			q[t][j] = qv; mr[t][j] = deviation(ok, qv, rhv, qrv, rrv);
+		}
+	}
+	double xd_lo = 0.0, mf_lo[NTR], up[NTR];
+#pragma unroll
+	for (int t = 0; t < NTR; t++) { mf_lo[t] = 0.0; up[t] = 0.0; }
+	double wm = (k0 >= 1 && k0 <= L - 1) ? w0[(size_t)k0 * NS + col] : 0.0;      // W on the interface of the current iteration
+	for (int k = k0 - 1; k < k1; k++) {
+		const int m = k + 1;
+		// the level that enters the window after this iteration, W of the next interface, the values the next level updates
+		const int ln = k + 3;
+		const bool okn = in(ln) && ln <= k1 + 1;
+		const double eU = okn ? xin[(size_t)TMX_SLAB_U(L, ln) * NS + col] : 0.0, eV = okn ? xin[(size_t)TMX_SLAB_V(L, ln) * NS + col] : 0.0;
+		const double eR = (okn && ud) ? xin[(size_t)TMX_SLAB_R(L, ln) * NS + col] : 1.0, eRR = (okn && ud) ? xref[(size_t)TMX_SLAB_R(L, ln) * NS + col] : 1.0;
+		const double wn = (m + 1 >= 1 && m + 1 <= L - 1 && m + 1 <= k1) ? w0[(size_t)(m + 1) * NS + col] : 0.0;
+		double eQ[NTR], eQR[NTR], upn[NTR];
+#pragma unroll
+		for (int t = 0; t < NTR; t++) {
+			eQ[t] = okn ? xin[(size_t)TMX_SLAB_Q(L, c0 + t, ln) * NS + col] : 0.0;
+			eQR[t] = (okn && ud) ? xref[(size_t)TMX_SLAB_Q(L, c0 + t, ln) * NS + col] : 0.0;
+			upn[t] = (k + 1 < k1) ? xup[(size_t)TMX_SLAB_Q(L, c0 + t, k + 1) * NS + col] : 0.0;
+		}
+		// xi_dot (zero at the boundaries) and, with uniform diffusion, rho on interface m
+		double xd_hi = 0.0, re_hi = 0.0;
+		if (m >= 1 && m <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				const double cc = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+				ue += cc * uw[off + 2];
+				ve += cc * vw[off + 2];
+			}
+			double e0, e1, e2;
+			metric_edge<MM>(p, mc, m, col, e0, e1, e2, etal);
+			xd_hi = e0 * ue + e1 * ve + e2 * wm;
+		}
+		if (ud && m <= L) {
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				re_hi += OPCL(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * rh[off + 2];
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < NTR; t++) {
+			double qe = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				qe += OPCL(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * q[t][off + 2];
+			}
+			double mf_hi = (m == 0 || m == L) ? 0.0 : je * qe * xd_hi;
+			if (ud && m > 0 && m < L) {
+				double dq = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 1; off++) {
+					const int l = m + off;
+					if (l < 0 || l >= L) continue;
+					dq += OPCL(TMX_OP_DIFF_NODE_TO_REDGE, m, off) * mr[t][off + 2];
+				}
+				mf_hi -= ks * re_hi * dq;
+			}
+			if (k >= k0) {      // level k: window entries 0, 1, 2 are the levels k - 1, k, k + 1
+				double dmf = 0.0;
+				dmf += OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 0) * mf_lo[t];
+				dmf += OPCL(TMX_OP_DIFF_REDGE_TO_NODE, k, 1) * mf_hi;
+				double F = dmf / jn;
+				double aux = 0.0;
+				if (k < L - 1) {
+					double b = 0.0;
+					b += OPCL(TMX_OP_PENALTY_LEFT, k, 0) * q[t][1];
+					b += OPCL(TMX_OP_PENALTY_LEFT, k, 1) * q[t][2];
+					aux += b * fabs(xd_hi);
+				}
+				if (k > 0) {
+					double b = 0.0;
+					b += OPCL(TMX_OP_PENALTY_RIGHT, k, -1) * q[t][0];
+					b += OPCL(TMX_OP_PENALTY_RIGHT, k, 0) * q[t][1];
+					aux += b * fabs(xd_lo);
+				}
+				F -= aux;
+				if (F != 0.0) F /= idt;
+				xup[(size_t)TMX_SLAB_Q(L, c0 + t, k) * NS + col] = up[t] - F;
+			}
+			mf_lo[t] = mf_hi;
+			// the window moves up one level
+			q[t][0] = q[t][1]; q[t][1] = q[t][2]; q[t][2] = q[t][3]; q[t][3] = eQ[t];
+			mr[t][0] = mr[t][1]; mr[t][1] = mr[t][2]; mr[t][2] = mr[t][3]; mr[t][3] = deviation(okn, eQ[t], eR, eQR[t], eRR);
+			up[t] = upn[t];
+		}
+		xd_lo = xd_hi; wm = wn;
+		uw[0] = uw[1]; uw[1] = uw[2]; uw[2] = uw[3]; uw[3] = eU;
+		vw[0] = vw[1]; vw[1] = vw[2]; vw[2] = vw[3]; vw[3] = eV;
+		rh[0] = rh[1]; rh[1] = rh[2]; rh[2] = rh[3]; rh[3] = eR;
+	}
+}
+
+#undef OPCL
+
 // UpdateColumnTracers in the fully explicit vertical mode: every stored column, in place on the update instance
 int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt) {
 	if (e->nt == 0 || p.ncol == 0) return 0;
-	if (!e->opt_vt_column) {      // level-parallel form (default); option "vt_column": the one-lane-per-column kernel, for A/B and tests
+	if (!e->opt_vt_column) {      // level-parallel / column-walking forms; option "vt_column": the one-lane-per-column LDS kernel, for A/B and tests
+		const size_t lds_slide = ((size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW + 2 * p.L + 1) * sizeof(double);
 #if TMX_EXP
 		if (e->opt_vt_explicit_v1) {      // the form without LDS staging, for A/B and tests
 			dim3 blk(64, 4), grd(NTILES(e, p), (p.L + 3) / 4);
@@ -815,7 +1118,36 @@ int tmxk_vi_tracers_explicit(tmx_engine * e, const KParams & p, const double * x
 				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref);
 		} else
 #endif
-		{
+		if (e->opt_vt_walk < 0 && lds_slide <= 64 * 1024) {      // a thread walks (a segment of) its column: -n = n segments per column
+			const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+			// default (-1000): segments in pairs (the two wavefronts of a workgroup) until the chip has two wavefronts per SIMD, at least five
+			// levels each -- ne30 L40 on one GPU: 1 350 tiles x 2 (measured: 1 / 2 / 3 / 4 segments 4.27 / 4.08 / 4.28 / 4.20 ms per step of BASELINE
+			// config 4's shape, the LDS-tiled kernel 4.67)
+			int nseg = -e->opt_vt_walk;
+			if (e->opt_vt_walk == -1000) for (nseg = 2; nt_ * nseg < 2048 && p.L / (nseg + 2) >= 5; nseg += 2) { }
+			nseg = std::max(1, std::min(nseg, p.L));
+			dim3 blk(64, 2), grd(xcd_column_grid(xm, nt_, (nseg + 1) / 2));
+			const double ks_ = e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0;
+			const size_t lds = lds_slide;
+			for (int c0 = 0; c0 < e->nt; c0 += 3) {
+				const int ntr = std::min(3, e->nt - c0);
+#define LAUNCH_SLIDE(N_) do { if (p.closed) hipLaunchKernelGGL((k_v_tracers_explicit_slide<N_, true>), grd, blk, lds, e->stream, p, c0, xin, xup, dt, ks_, (const double *)e->d_ref, nt_, xm, nseg); \
+				else hipLaunchKernelGGL((k_v_tracers_explicit_slide<N_, false>), grd, blk, lds, e->stream, p, c0, xin, xup, dt, ks_, (const double *)e->d_ref, nt_, xm, nseg); } while (0)
+				if (ntr == 3) LAUNCH_SLIDE(3); else if (ntr == 2) LAUNCH_SLIDE(2); else LAUNCH_SLIDE(1);
+#undef LAUNCH_SLIDE
+			}
+		}
+#if TMX_EXP
+		else if (e->opt_vt_walk == 4 || e->opt_vt_walk == 5 || e->opt_vt_walk == 6 || e->opt_vt_walk == 8 || e->opt_vt_walk == 10) {      // by column segments of that many levels
+			const int nt_ = NTILES(e, p), xm = e->xcd_vertical, kc = e->opt_vt_walk;
+			dim3 blk(64), grd(xcd_column_grid(xm, nt_, (p.L + kc - 1) / kc));
+#define LAUNCH_WALK(KC_) hipLaunchKernelGGL(k_v_tracers_explicit_walk<KC_>, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt, \
+				e->udiff ? e->cfg.uniform_diffusion_scalar : 0.0, (const double *)e->d_ref, nt_, xm)
+			if (kc == 4) LAUNCH_WALK(4); else if (kc == 5) LAUNCH_WALK(5); else if (kc == 6) LAUNCH_WALK(6); else if (kc == 8) LAUNCH_WALK(8); else LAUNCH_WALK(10);
+#undef LAUNCH_WALK
+		}
+#endif
+		else {
 			const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
 			dim3 blk(64, 8), grd(xcd_column_grid(xm, nt_, (p.L + 7) / 8));
 			hipLaunchKernelGGL(k_v_tracers_explicit_tile, grd, blk, 0, e->stream, p, e->nt, xin, xup, dt,

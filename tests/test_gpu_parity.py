@@ -319,20 +319,24 @@ def test_uniform_diffusion_explicit_vertical_steps(scheme):
 
 def test_level_parallel_explicit_tracer_update_is_bit_identical_to_the_column_kernel(monkeypatch):
     """UpdateColumnTracers in the fully explicit mode: the level-parallel kernel (default) and the one-lane-per-column kernel
-    (TMX_VT_COLUMN=1) give identical doubles, with and without uniform diffusion."""
+    (TMX_VT_COLUMN=1) give identical doubles, with and without uniform diffusion -- and so do the sliding-window form (the default:
+    a thread walks a segment of its column) at every segment count, the LDS-tiled form it superseded and the archived ones."""
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps_udiff_ars343_ne3_L6_p6.npz")
     g, _ = gu.make_grid(3, 6, 6, case="smallplanet", ntracers=2)
     st, tr = gu.expand_compact(d, "step1", g), gu.expand_compact_tracers(d, "step1", g)
     for ud in (UDIFF, None):
         out = []
-        for variant in (None, "TMX_VT_COLUMN", "TMX_VT_EXPLICIT_V1"):      # LDS-tiled (default), one lane per column, untiled
-            monkeypatch.delenv("TMX_VT_COLUMN", raising=False)
-            monkeypatch.delenv("TMX_VT_EXPLICIT_V1", raising=False)
+        # LDS-tiled, one lane per column, untiled, by column segments of 4 / 8 / 10 levels (six levels here: a ragged last segment, a lone ragged one)
+        for variant in (None, "TMX_VT_COLUMN", "TMX_VT_EXPLICIT_V1", "TMX_VT_WALK=0", "TMX_VT_WALK=4", "TMX_VT_WALK=5", "TMX_VT_WALK=8", "TMX_VT_WALK=10",
+                        "TMX_VT_WALK=-1", "TMX_VT_WALK=-2", "TMX_VT_WALK=-3", "TMX_VT_WALK=-6"):      # (negative: a sliding window over each of n column segments)
+            for name in ("TMX_VT_COLUMN", "TMX_VT_EXPLICIT_V1", "TMX_VT_WALK"):
+                monkeypatch.delenv(name, raising=False)
             if variant:
-                monkeypatch.setenv(variant, "1")
-            # (the untiled form is an archived kernel: experiments flavour of the library)
-            e = Engine(g, fully_explicit=True, uniform_diffusion=ud, flavour="experiments" if variant == "TMX_VT_EXPLICIT_V1" else None)
+                monkeypatch.setenv(variant.split("=")[0], variant.split("=")[1] if "=" in variant else "1")
+            # (the untiled form and the register-held segments are archived kernels: experiments flavour of the library)
+            archived = variant == "TMX_VT_EXPLICIT_V1" or (variant or "").startswith("TMX_VT_WALK=") and int(variant.split("=")[1]) > 0
+            e = Engine(g, fully_explicit=True, uniform_diffusion=ud, flavour="experiments" if archived else None)
             try:
                 e.upload_state(0, st); e.upload_tracers(0, tr)
                 e.copy_data(0, 1)
@@ -1415,18 +1419,23 @@ def test_kessler_physics_on_the_supercell_state():
         e.close()
 
 
-def test_supercell_steps_with_kessler():
+@pytest.mark.parametrize("walk", [None, 0, 4, 6, 10, -1, -2, -3, -8])
+def test_supercell_steps_with_kessler(walk, monkeypatch):
     """BASELINE config 4 end to end at ne2 L40: SupercellTest's own state (reference dump after 2 steps), 3 ARS343 steps
     with uniform diffusion, fully explicit vertical dynamics, three tracers, nu = 0, KesslerPhysics::Perform after every
-    step (Model.cpp:470-481) -- against the oracle on identical inputs and against the reference's state."""
+    step (Model.cpp:470-481) -- against the oracle on identical inputs and against the reference's state.  walk: the explicit
+    tracer update by column segments of that many levels, negative: by a sliding window over each of that many segments of a column
+    (option "vt_explicit_walk"; 0 = the LDS-tiled kernel; None = the default)."""
     from tempestmodel_amd.engine import Engine
     from oracle_lib import Oracle
+    if walk is not None:
+        monkeypatch.setenv("TMX_VT_WALK", str(walk))
     d, g = _supercell_case()
     dt = float(d["cfg/dt"][0])
     st = gu.expand_compact(d, "warm", g); tr = gu.expand_compact_tracers(d, "warm", g)
     o = Oracle(g, nu=(0.0, 0.0, 0.0), fully_explicit=True, uniform_diffusion=(1500.0, 500.0))
     o.set_state(0, st); o.set_tracers(0, tr)
-    e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0))
+    e = Engine(g, fully_explicit=True, uniform_diffusion=(1500.0, 500.0), nu=(0.0, 0.0, 0.0), flavour="experiments" if (walk or 0) > 0 else None)
     try:
         e.set_level_heights()
         e.upload_state(0, st); e.upload_tracers(0, tr)
