@@ -1418,7 +1418,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("split_stage_off", e->opt_no_split); OPT("metric_stored", e->opt_metric_stored); OPT("tracer_lincomb_pass", e->opt_tracer_lincomb_pass);
 	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
 	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
-	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
+	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vite_walk", e->opt_vite_walk); OPT("vx_walk", e->opt_vx_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
 	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows);
 #undef OPT
 	return nullptr;
@@ -1457,6 +1457,8 @@ static const OptionDef g_options[] = {
 	{ "vt_column", "TMX_VT_COLUMN", 0, "1: one-lane-per-column explicit tracer update (cross-check)" },
 	{ "vt_explicit_v1", "TMX_VT_EXPLICIT_V1", 2, "1: level-parallel explicit tracer update without LDS staging (cross-check)" },
 	{ "vt_explicit_walk", "TMX_VT_WALK", 0, "explicit tracer update: -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the LDS-tiled level-parallel kernel; 4, 5, 6, 8, 10 = that many levels per thread held in registers (experiments build)" },
+	{ "vite_walk", "TMX_VITE_WALK", 0, "explicitly evaluated implicit terms (StepImplicitTermsExplicitly): -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the level-parallel kernel" },
+	{ "vx_walk", "TMX_VX_WALK", 0, "V.StepExplicit's U,V update: -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the level-parallel kernel" },
 	{ "vt_lanes", "TMX_VT_LANES", 0, "columns per workgroup of the one-lane tracer column kernel (16)" },
 	{ "vt_lw8", "TMX_VT_LW8", 0, "row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
 	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },

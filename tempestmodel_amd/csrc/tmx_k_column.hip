@@ -1757,8 +1757,167 @@ __global__ __launch_bounds__(64 * KT_VC) void k_vi_terms_explicit(KParams p, con
 	if (UVX && k < L) v_explicit_point<UD>(p, xin, xup, dt, xref, cw, col, k);
 }
 
+// The same update by a thread that walks a column (or one of `nseg` segments of it) block row by block row, as the column solve's
+// assembly does: the three node levels and three interfaces a block row touches in a sliding register window, the quantities a
+// block row shares with the next carried over (compute_block<CARRY>: one evaluation of the Exner function per level instead of
+// two, every state value loaded once instead of three to five times), the next levels loaded two iterations ahead, operator
+// coefficients and the 1 - eta table in LDS.  The uniform-diffusion stencils take the state's five levels from the window (the
+// value that has just left it, the three in it, the one about to enter) and keep sliding windows of the reference's.  A segment that
+// does not start at the bottom evaluates the block row below it first, only to fill the carry.  Same statements on the same
+// operands as k_vi_terms_explicit: bit-identical (tested).
+#define OPCL(op, k, off) opsl[(((op) * (p.L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+template <bool UD, bool CLOSED>
+__global__ __launch_bounds__(128) void k_vi_terms_explicit_slide(KParams p, const double * __restrict__ xin,
+	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cs, double cw, int ntile, int xmode, int nseg)
+{
+	extern __shared__ double opsl_mem[];
+	double * opsl = opsl_mem;
+	const int L = p.L;
+	constexpr int MM = CLOSED ? 1 : 2;
+	double * etal = opsl_mem + TMX_OP_COUNT * (L + 1) * TMX_OPW;
+	{
+		const int tid = threadIdx.y * 64 + threadIdx.x;
+		for (int t = tid; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128) opsl[t] = p.ops[t];
+		if (CLOSED) for (int t = tid; t < 2 * L + 1; t += 128) etal[t] = p.eta[t];
+		__syncthreads();
+	}
+	const size_t NS = (size_t)p.NS;
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (nseg + 1) / 2, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	if (col >= p.ncol) return;
+	const int sg = WAVE_UNIFORM(by * 2 + (int)threadIdx.y);
+	const int seg = (L + 1 + nseg - 1) / nseg, k0 = sg * seg, k1 = min(L + 1, k0 + seg);      // block rows k0 .. k1 - 1 of 0 .. L
+	if (sg >= nseg || k0 >= k1) return;
+	ColConst cc;
+	cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+	cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+	cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+	const MetCol mcol = met_col(p, col);
+	const int kw = (k0 > 0) ? k0 - 1 : 0;      // first block row evaluated (k0 - 1: for the carry only)
+	// The window: block row k reads U, V, rho*theta, rho of the levels k - 1, k, k + 1 and W of the interfaces k - 1, k, k + 1; with the
+	// carry, the metric terms of level k and of the interfaces k, k + 1 only.  Levels k + 2 and k + 3 are in flight as raw values
+	// (their metric terms are arithmetic on per-column factors and the LDS table: evaluated when a level becomes the window's top).
+	struct Raw { double un, vn, pn, rn, we; };
+	auto raw = [&](int l) {      // (out-of-range levels carry the values of the nearest one, as load_node / load_edge)
+		Raw r;
+		const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+		r.un = xin[TMX_SLAB_U(L, lc) * NS + col]; r.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
+		r.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; r.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
+		r.we = xin[TMX_SLAB_W(L, le) * NS + col];
+		return r;
+	};
+	auto node_of = [&](const Raw & r, int l) {
+		NodeLev n; n.un = r.un; n.vn = r.vn; n.pn = r.pn; n.rn = r.rn;
+		const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
+		metric_node3<MM>(p, mcol, lc, col, n.ca2, n.cb2, n.cx2, etal);
+		return n;
+	};
+	auto edge_of = [&](const Raw & r, int l) {
+		EdgeLev e; e.we = r.we;
+		const int le = l < 0 ? 0 : (l > L ? L : l);
+		metric_edge<MM>(p, mcol, le, col, e.ce0, e.ce1, e.ce2, etal);
+		return e;
+	};
+	Raw rA = raw(kw - 1), rN = raw(kw + 2);
+	NodeLev nB = load_node<MM>(p, mcol, xin, kw, col, etal), nC = load_node<MM>(p, mcol, xin, kw + 1, col, etal);
+	EdgeLev eB = load_edge<MM>(p, mcol, xin, kw, col, etal), eC = load_edge<MM>(p, mcol, xin, kw + 1, col, etal);
+	double pm2 = 0.0, wm2 = 0.0;      // rho*theta of level k - 2, W of interface k - 2 (what has left the window)
+	double tr[5] = { 0, 0, 0, 0, 0 }, wr[5] = { 0, 0, 0, 0, 0 };      // reference rho*theta on the levels, W on the interfaces k - 2 .. k + 2
+	auto ref_T = [&](int l) { return (UD && l >= 0 && l < L) ? xref[(size_t)TMX_SLAB_T(L, l) * NS + col] : 0.0; };
+	auto ref_W = [&](int l) { return (UD && l >= 0 && l <= L) ? xref[(size_t)TMX_SLAB_W(L, l) * NS + col] : 0.0; };
+	if (UD) {
+		if (kw - 2 >= 0) { pm2 = xin[(size_t)TMX_SLAB_T(L, kw - 2) * NS + col]; wm2 = xin[(size_t)TMX_SLAB_W(L, kw - 2) * NS + col]; }
+#pragma unroll
+		for (int t = 0; t < 5; t++) { tr[t] = ref_T(kw - 2 + t); wr[t] = ref_W(kw - 2 + t); }
+	}
+	double upT = 0.0, upR = 0.0, upW = 0.0;
+	if (kw == k0) {
+		upW = xup[TMX_SLAB_W(L, kw) * NS + col];
+		if (kw < L) { upT = xup[TMX_SLAB_T(L, kw) * NS + col]; upR = xup[TMX_SLAB_R(L, kw) * NS + col]; }
+	}
+	BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+	for (int k = kw; k < k1; k++) {
+		// two levels ahead: the level that enters the window after the next block row; the reference's entering values and the
+		// values the next block row updates
+		const Raw rNN = raw(k + 3);
+		const double trn = ref_T(k + 3), wrn = ref_W(k + 3);
+		double upTn = 0.0, upRn = 0.0, upWn = 0.0;
+		if (k + 1 < k1) {
+			upWn = xup[TMX_SLAB_W(L, k + 1) * NS + col];
+			if (k + 1 < L) { upTn = xup[TMX_SLAB_T(L, k + 1) * NS + col]; upRn = xup[TMX_SLAB_R(L, k + 1) * NS + col]; }
+		}
+		double udP = 0.0, udW = 0.0;
+		if (UD) {
+			const double tw[5] = { pm2, rA.pn, nB.pn, nC.pn, rN.pn }, ww[5] = { wm2, rA.we, eB.we, eC.we, rN.we };
+			if (k < L) {
+				double dd = 0.0, ddr = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 2; off++) {
+					const int l = k + off;
+					if (l < 0 || l >= L) continue;
+					const double c = OPCL(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+					dd += c * tw[off + 2];
+					ddr += c * tr[off + 2];
+				}
+				udP = cs * (dd - ddr);
+			}
+			if (k > 0 && k < L) {
+				double dd = 0.0, ddr = 0.0;
+#pragma unroll
+				for (int off = -2; off <= 2; off++) {
+					const int l = k + off;
+					if (l < 0 || l > L) continue;
+					const double c = OPCL(TMX_OP_DIFFDIFF_REDGE_TO_REDGE, k, off);
+					dd += c * ww[off + 2];
+					ddr += c * wr[off + 2];
+				}
+				udW = cw * (dd - ddr);
+			}
+		}
+		double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+		{
+			NodeLev nA; nA.un = rA.un; nA.vn = rA.vn; nA.pn = rA.pn; nA.rn = rA.rn; nA.ca2 = 0.0; nA.cb2 = 0.0; nA.cx2 = 0.0;      // (with the carry a block row reads no metric term of level k - 1)
+			EdgeLev eA; eA.we = rA.we; eA.ce0 = 0.0; eA.ce1 = 0.0; eA.ce2 = 0.0;
+			compute_block<true, UD>(p, opsl, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, udP, udW);
+		}
+		if (k >= k0) {
+			if (k < L) {
+				xup[TMX_SLAB_T(L, k) * NS + col] = upT - dt * fP;
+				xup[TMX_SLAB_R(L, k) * NS + col] = upR - dt * fR;
+			}
+			xup[TMX_SLAB_W(L, k) * NS + col] = upW - dt * fW;
+		}
+		pm2 = rA.pn; wm2 = rA.we;
+		rA.un = nB.un; rA.vn = nB.vn; rA.pn = nB.pn; rA.rn = nB.rn; rA.we = eB.we;
+		nB = nC; eB = eC;
+		nC = node_of(rN, k + 2); eC = edge_of(rN, k + 2);
+		rN = rNN;
+		tr[0] = tr[1]; tr[1] = tr[2]; tr[2] = tr[3]; tr[3] = tr[4]; tr[4] = trn;
+		wr[0] = wr[1]; wr[1] = wr[2]; wr[2] = wr[3]; wr[3] = wr[4]; wr[4] = wrn;
+		upT = upTn; upR = upRn; upW = upWn;
+	}
+}
+#undef OPCL
+
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_uv) {
 	const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+	const size_t lds_slide = ((size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW + 2 * p.L + 1) * sizeof(double);
+	if (e->opt_vite_walk < 0 && !with_uv && lds_slide <= 64 * 1024) {      // a thread walks (a segment of) its column; -n = n segments, -1000 = chosen from the grid size
+		int nseg = -e->opt_vite_walk;
+		if (e->opt_vite_walk == -1000) for (nseg = 2; nt_ * nseg < 2048 && (p.L + 1) / (nseg + 2) >= 5; nseg += 2) { }
+		nseg = std::max(1, std::min(nseg, p.L + 1));
+		dim3 blk(64, 2), grd(xcd_column_grid(xm, nt_, (nseg + 1) / 2));
+		const bool ud = e->udiff && e->fully_explicit;
+		const double z2 = e->cfg.ztop * e->cfg.ztop;
+		const double cs = ud ? e->cfg.uniform_diffusion_scalar / z2 : 0.0, cw = ud ? e->cfg.uniform_diffusion_vector / z2 : 0.0;
+#define LAUNCH_VS(UD_, CL_) hipLaunchKernelGGL((k_vi_terms_explicit_slide<UD_, CL_>), grd, blk, lds_slide, e->stream, p, xin, xup, dt, (const double *)(ud ? e->d_ref : nullptr), cs, cw, nt_, xm, nseg)
+		if (ud) { if (p.closed) LAUNCH_VS(true, true); else LAUNCH_VS(true, false); }
+		else { if (p.closed) LAUNCH_VS(false, true); else LAUNCH_VS(false, false); }
+#undef LAUNCH_VS
+		return;
+	}
 	dim3 blk(64, KT_VC), grd(xcd_column_grid(xm, nt_, (p.L + 1 + KT_VC - 1) / KT_VC));
 	if (e->udiff && e->fully_explicit) {
 		const double z2 = e->cfg.ztop * e->cfg.ztop;

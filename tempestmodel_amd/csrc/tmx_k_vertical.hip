@@ -27,8 +27,133 @@ __global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const doub
 	v_explicit_point<UDV>(p, xin, xup, dt, xref, cf, col, k);
 }
 
+// The same update by a thread that walks a column (or one of `nseg` segments of it) level by level: U, V of the levels k - 2 .. k + 2
+// (and, UDV, the reference's) in a sliding register window, xi_dot of every interface evaluated once (the level-parallel form evaluates
+// it for the level below and again for the level above), the entering level loaded an iteration ahead, operator coefficients and
+// the 1 - eta table in LDS (see k_v_tracers_explicit_slide).  Same statements on the same operands as v_explicit_point: bit-identical (tested).
+#define OPCL(op, k, off) opsl[(((op) * (L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+template <bool UDV, bool CLOSED>
+__global__ __launch_bounds__(128) void k_v_explicit_slide(KParams p, const double * __restrict__ xin, double * __restrict__ xup, double dt,
+	const double * __restrict__ xref, double cf, int ntile, int xmode, int nseg)
+{
+	extern __shared__ double opsl[];      // [TMX_OP_COUNT][L + 1][TMX_OPW], then 1 - eta [2 L + 1]
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS;
+	double * etal = opsl + TMX_OP_COUNT * (L + 1) * TMX_OPW;
+	{
+		const int tid = threadIdx.y * 64 + threadIdx.x;
+		for (int t = tid; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128) opsl[t] = p.ops[t];
+		if (CLOSED) for (int t = tid; t < 2 * L + 1; t += 128) etal[t] = p.eta[t];
+		__syncthreads();
+	}
+	constexpr int MM = CLOSED ? 1 : 2;
+	int bx, by;
+	if (!xcd_column_tile(xmode, ntile, (nseg + 1) / 2, bx, by)) return;
+	const int col = (p.quads ? p.quads[bx] : bx) * 64 + threadIdx.x;
+	if (col >= p.ncol) return;
+	const int sg = WAVE_UNIFORM(by * 2 + (int)threadIdx.y);
+	const int seg = (L + nseg - 1) / nseg, k0 = sg * seg, k1 = min(L, k0 + seg);
+	if (sg >= nseg || k0 >= k1) return;
+	const MetCol mc = met_col(p, col);
+	auto in = [&](int l) { return l >= 0 && l < L; };
+	// window: levels k - 2 .. k + 2, at the (virtual) level k = k0 - 1 the walk starts from
+	double uw[5], vw[5], ur[5], vr[5];
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const int l = k0 - 3 + j;
+		const bool ok = in(l);
+		uw[j] = ok ? xin[(size_t)TMX_SLAB_U(L, l) * NS + col] : 0.0;
+		vw[j] = ok ? xin[(size_t)TMX_SLAB_V(L, l) * NS + col] : 0.0;
+		ur[j] = (UDV && ok) ? xref[(size_t)TMX_SLAB_U(L, l) * NS + col] : 0.0;
+		vr[j] = (UDV && ok) ? xref[(size_t)TMX_SLAB_V(L, l) * NS + col] : 0.0;
+	}
+	double xd_lo = 0.0, upU = 0.0, upV = 0.0;
+	double wm = (k0 >= 1 && k0 <= L - 1) ? xin[(size_t)TMX_SLAB_W(L, k0) * NS + col] : 0.0;      // W on the interface of the current iteration
+#pragma unroll 1
+	for (int k = k0 - 1; k < k1; k++) {
+		const int m = k + 1;
+		// the level that enters the window after this iteration, W of the next interface, the values the next level updates
+		const int ln = k + 3;
+		const bool okn = in(ln) && ln <= k1 + 1;
+		const double eU = okn ? xin[(size_t)TMX_SLAB_U(L, ln) * NS + col] : 0.0, eV = okn ? xin[(size_t)TMX_SLAB_V(L, ln) * NS + col] : 0.0;
+		const double eUR = (UDV && okn) ? xref[(size_t)TMX_SLAB_U(L, ln) * NS + col] : 0.0, eVR = (UDV && okn) ? xref[(size_t)TMX_SLAB_V(L, ln) * NS + col] : 0.0;
+		const double wn = (m + 1 >= 1 && m + 1 <= L - 1 && m + 1 <= k1) ? xin[(size_t)TMX_SLAB_W(L, m + 1) * NS + col] : 0.0;
+		const double upUn = (k + 1 < k1) ? xup[(size_t)TMX_SLAB_U(L, k + 1) * NS + col] : 0.0, upVn = (k + 1 < k1) ? xup[(size_t)TMX_SLAB_V(L, k + 1) * NS + col] : 0.0;
+		// xi_dot on interface m (xidot_edge): window entries 1 .. 4 are the levels m - 2 .. m + 1
+		double xd_hi = 0.0;
+		if (m >= 1 && m <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+#pragma unroll
+			for (int off = -2; off <= 1; off++) {
+				const int l = m + off;
+				if (l < 0 || l >= L) continue;
+				const double c = OPCL(TMX_OP_INTERP_NODE_TO_REDGE, m, off);
+				ue += c * uw[off + 3];
+				ve += c * vw[off + 3];
+			}
+			double e0, e1, e2;
+			metric_edge<MM>(p, mc, m, col, e0, e1, e2, etal);
+			xd_hi = e0 * ue + e1 * ve + e2 * wm;
+		}
+		if (k >= k0) {      // level k: window entry 2
+			const double w_hi = dt * fabs(xd_hi), w_lo = dt * fabs(xd_lo);
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				const double * x = v ? vw : uw, * xr = v ? vr : ur;
+				const double x0 = x[2], xm = x[1], xp = x[3];
+				double out = v ? upV : upU;
+				if (k < L - 1) {
+					double b = 0.0;
+					b += OPCL(TMX_OP_PENALTY_LEFT, k, 0) * x0;
+					b += OPCL(TMX_OP_PENALTY_LEFT, k, 1) * xp;
+					out += b * w_hi;
+				}
+				if (k > 0) {
+					double b = 0.0;
+					b += OPCL(TMX_OP_PENALTY_RIGHT, k, -1) * xm;
+					b += OPCL(TMX_OP_PENALTY_RIGHT, k, 0) * x0;
+					out += b * w_lo;
+				}
+				if (UDV) {
+					double dd = 0.0, ddr = 0.0;
+#pragma unroll
+					for (int off = -2; off <= 2; off++) {
+						const int l = k + off;
+						if (l < 0 || l >= L) continue;
+						const double c = OPCL(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, off);
+						dd += c * x[off + 2];
+						ddr += c * xr[off + 2];
+					}
+					out += dt * cf * (dd - ddr);
+				}
+				xup[(size_t)(v * L + k) * NS + col] = out;
+			}
+		}
+		xd_lo = xd_hi; wm = wn; upU = upUn; upV = upVn;
+#pragma unroll
+		for (int j = 0; j < 4; j++) { uw[j] = uw[j + 1]; vw[j] = vw[j + 1]; ur[j] = ur[j + 1]; vr[j] = vr[j + 1]; }
+		uw[4] = eU; vw[4] = eV; ur[4] = eUR; vr[4] = eVR;
+	}
+}
+#undef OPCL
+
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv) {
 	const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
+	const size_t lds_slide = ((size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW + 2 * p.L + 1) * sizeof(double);
+	if (e->opt_vx_walk < 0 && lds_slide <= 64 * 1024) {      // a thread walks (a segment of) its column; -n = n segments, -1000 = chosen from the grid size
+		int nseg = -e->opt_vx_walk;
+		// (a light kernel, four resident wavefronts per SIMD: ne30 L40 on one GPU 1 / 2 / 4 segments 3.84 / 3.76 / 3.75 ms per step of BASELINE config 4's
+		// shape, the level-parallel kernel 3.98)
+		if (e->opt_vx_walk == -1000) for (nseg = 2; nt_ * nseg < 4096 && p.L / (nseg + 2) >= 5; nseg += 2) { }
+		nseg = std::max(1, std::min(nseg, p.L));
+		dim3 blk(64, 2), grd(xcd_column_grid(xm, nt_, (nseg + 1) / 2));
+		const double cf = with_udiff_uv ? e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop) : 0.0;
+#define LAUNCH_VXS(UD_, CL_) hipLaunchKernelGGL((k_v_explicit_slide<UD_, CL_>), grd, blk, lds_slide, e->stream, p, xin, xup, dt, (const double *)(with_udiff_uv ? e->d_ref : nullptr), cf, nt_, xm, nseg)
+		if (with_udiff_uv) { if (p.closed) LAUNCH_VXS(true, true); else LAUNCH_VXS(true, false); }
+		else { if (p.closed) LAUNCH_VXS(false, true); else LAUNCH_VXS(false, false); }
+#undef LAUNCH_VXS
+		return;
+	}
 	dim3 blk(64, KT_VE), grd(xcd_column_grid(xm, nt_, (p.L + KT_VE - 1) / KT_VE));
 	if (with_udiff_uv)
 		hipLaunchKernelGGL(k_v_explicit<true>, grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)e->d_ref,
