@@ -379,6 +379,46 @@ def test_row_parallel_implicit_tracer_update_is_bit_identical_to_the_column_kern
         assert any(np.abs(a - b).max() > 0 for a, b in zip(out[0][1], tr))
 
 
+@pytest.mark.parametrize("L,ud", [(6, True), (6, False), (23, True)])
+def test_column_walking_vertical_kernels_are_bit_identical_to_the_level_parallel_ones(L, ud):
+    """V.StepExplicit's U,V update, the explicitly evaluated implicit terms and the explicit tracer column update as level-parallel
+    kernels (option value 0) and as column walks with sliding register windows (the default; -n: n segments per column, here also
+    more segments than fit, ragged last segments and single-level segments): per call and over whole ARS343 / ARK232 steps in the
+    fully explicit vertical mode, with and without uniform diffusion -- identical doubles."""
+    from tempestmodel_amd.engine import Engine
+    g, st = gu.make_grid(3, L, 6, case="smallplanet", ntracers=2)
+    rng = np.random.default_rng(5)
+    tr = [np.abs(1e-3 * P_node[4][None] * (1.0 + 0.1 * rng.standard_normal((2,) + P_node[4].shape))) for P_node, _ in st]
+    for P, (n, e_), t in zip(g.patches, st, tr):
+        P.geom["ref_node"] = n.copy(); P.geom["ref_redge"] = e_.copy(); P.geom["ref_tracers"] = 0.9 * t
+    # a rough state: the penalty terms and the diffusion stencils see sign changes and large gradients
+    rough = []
+    for n, e_ in st:
+        n = n.copy(); e_ = e_.copy()
+        n[0] += rng.uniform(-20.0, 20.0, n[0].shape); n[1] += rng.uniform(-20.0, 20.0, n[1].shape)
+        n[2] *= 1.0 + 0.01 * rng.standard_normal(n[2].shape); n[4] *= 1.0 + 0.01 * rng.standard_normal(n[4].shape)
+        e_[3] = rng.uniform(-3.0, 3.0, e_[3].shape)
+        rough.append((n, e_))
+    res = []
+    for seg in (0, -1000, -1, -2, -3, -5, -64):
+        e = Engine(g, n_instances=8, fully_explicit=True, uniform_diffusion=UDIFF if ud else None,
+                   options={"vx_walk": seg, "vite_walk": seg, "vt_explicit_walk": seg})
+        try:
+            e.upload_state(0, rough); e.upload_tracers(0, tr)
+            e.copy_data(0, 1); e.v_step_explicit(0, 1, 0.7)
+            e.copy_data(0, 2); e.v_step_implicit_terms_explicitly(0, 2, 0.7)
+            for k in range(2):
+                e.step("ars343", 0.5, first=(k == 0))
+            e.step("ark232", 0.5)
+            e.sync()
+            res.append([(e.download_state(ix), e.download_tracers(ix)) for ix in (0, 1, 2)])
+        finally:
+            e.close()
+    for other in res[1:]:
+        for (sa, ta), (sb, tb) in zip(res[0], other):
+            assert max(gu.prognostic_errors(sa, sb)) == 0.0 and max(gu.tracer_errors(ta, tb)) == 0.0
+
+
 def test_explicit_vertical_without_diffusion_matches_oracle():
     """--explicitvertical alone (no uniform diffusion, no tracers): ARS343 and Strang steps against the C oracle."""
     from tempestmodel_amd.engine import Engine
