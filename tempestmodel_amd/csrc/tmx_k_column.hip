@@ -1160,6 +1160,9 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	// consumer + consumer and producer + consumer, never producer + producer (the assembly is the issue-heavy role):
 	// wavefronts 0..5 = C0 P0 P1 P2 C1 C2.
 	const int lane = threadIdx.x, wv = WAVE_UNIFORM(threadIdx.y);
+	// (Measured and not kept, round 4: the roles in the other order -- consumer first -- for the workgroups of the second dispatch round, or
+	// for every other workgroup, so that two workgroups sharing a CU would put a producer and a consumer on every SIMD: column solve
+	// 0.500 / 0.486 against 0.480 ms per step.)
 #ifndef TMX_PAIR3_INTERLEAVED
 	const int role = (PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1), pair = (PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1);
 #else
