@@ -421,6 +421,9 @@ long long tmx_info(tmx_engine * e, int what);
  *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize.
  *   "contraction_mfma"   1: the 4 x 4 contractions of the fused explicit kernel as v_mfma_f64_4x4x4 -- NOT bit-exact (1e-15 per call,
  *                        W 1.5e-10 after 100 steps at ne15 L30: outside the 1e-10 gate) and measured no faster.  Before tmx_finalize.
+ *   "vt_explicit_walk", "vx_walk", "vite_walk"   fully explicit vertical mode: the tracer column update, V.StepExplicit's U,V update and the explicitly
+ *                        evaluated implicit terms as column walks with sliding register windows: -1000 (default) the number of segments per column chosen
+ *                        from the grid size, -n = n segments, 0 = the level-parallel kernels they superseded (bit-identical, tested).
  *   "step_graph", "share_copies", "split_stage_off", "exchange_overlap_off", "p2p_timeout_s", "metric_stored", "xcd_vertical",
  *   "vi_*" (column solve kernel selection), "vt_*", "kessler_column", "hvis_pull", "hvis_block", "tracer_lincomb_pass", "udv_separate",
  *   "vx_fused": kernel selection / A-B switches, each with a bit-identity test; "debug_skip_exchange": timing aid with WRONG results
