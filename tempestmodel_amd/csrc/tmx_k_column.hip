@@ -654,6 +654,26 @@ __device__ constexpr int TMX_UPAIR[3][5][2] = {
 	{ { 0, 9 }, { 1, 2 }, { 3, 4 }, { 6, 5 }, { 7, 8 } },      // W rows
 	{ { 0, 9 }, { 1, 2 }, { 3, 5 }, { 4, 6 }, { 7, 8 } } };    // rho rows
 #define TMX_USLOT (TMX_USTREAM16 ? 2 : 1)      // doubles per lane and slot
+// TMX_USTREAM_NT: the U-row stream is written once and read once, 5 KB per column and direction -- bit 0: the elimination's stores,
+// bit 1: the back substitution's loads carry the non-temporal hint.  Measured (round 5, ne30 L30, same box, two alternations): the
+// column solve itself does not move (0.476-0.492 ms per step with any of 0..3), but the stream no longer evicts the state from the
+// L2 / Infinity Cache: the explicit kernels that follow go from 0.578 to 0.552 (stores), 0.549 (loads), 0.535 ms per step (both),
+// the step from 1.394 to 1.350 ms.  Default: both.
+#ifndef TMX_USTREAM_NT
+#define TMX_USTREAM_NT 3
+#endif
+typedef double tmx_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ustream_store2(double * q, double a, double b) {
+	tmx_dbl2 v; v.x = a; v.y = b;
+	if (TMX_USTREAM_NT & 1) __builtin_nontemporal_store(v, (tmx_dbl2 *)q);
+	else *(tmx_dbl2 *)q = v;
+}
+__device__ __forceinline__ double2 ustream_load2(const double * q) {
+	tmx_dbl2 v;
+	if (TMX_USTREAM_NT & 2) v = __builtin_nontemporal_load((const tmx_dbl2 *)q);
+	else v = *(const tmx_dbl2 *)q;
+	return make_double2(v.x, v.y);
+}
 // Order of the rows in the scratch (TMX_USTREAM_ROWMAJOR, default): [matrix row][column group][slot][lane] -- the column groups
 // advance through their rows at about the same pace, so at any time the chip writes (elimination) or reads (back substitution)
 // one contiguous run of a few megabytes instead of one 5 KB piece in each of ~800 chunks 476 KB apart.  0: [group][row]....
@@ -689,7 +709,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 	double * row = AB + (size_t)jcol * TMX_RS(NUS);
 #pragma unroll
 	for (int sl = 0; sl < 3; sl++)
-		*(double2 *)(row + sl * 128) = make_double2(val(TMX_UPAIR[TYPE][sl][0]), val(TMX_UPAIR[TYPE][sl][1]));
+		ustream_store2(row + sl * 128, val(TMX_UPAIR[TYPE][sl][0]), val(TMX_UPAIR[TYPE][sl][1]));
 	int mask = 0;
 	int one = 1;
 	if (PRED) asm volatile("" : "+v"(one));
@@ -698,7 +718,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 		const double a = val(TMX_UPAIR[TYPE][sl][0]), b = val(TMX_UPAIR[TYPE][sl][1]);
 		const bool any = !SPARSE || __builtin_amdgcn_ballot_w64(a != 0.0 || b != 0.0) != 0;
 		mask |= any ? (1 << sl) : 0;
-		if (PRED ? (any && one) : any) *(double2 *)(row + sl * 128) = make_double2(a, b);
+		if (PRED ? (any && one) : any) ustream_store2(row + sl * 128, a, b);
 	}
 	if (SPARSE ? (threadIdx.x == 0) : true) umask[jcol] = mask;      // dense stores (also the lane-divergent tails, where lane 0 may be masked out): every active lane writes the same word
 #else
@@ -733,13 +753,38 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 #endif
 }
 
+// The LDS ring between the two wavefronts of k_vi_pair holds a block row of the column Jacobian WITHOUT its structural zeros:
+// compute_block only ever touches the band entries d = 1,4,5,7,8 of a rho*theta row, d = 0,1,2,3,4,5,7 of a W row and
+// d = 1,3,4,6,7 of a rho row (DOFF of its statements; every other entry keeps the +0.0 it was initialised with), i.e. 17 of the
+// 27 entries, plus the three residuals: 20 doubles per column instead of 30.  A third fewer LDS writes and reads per block row,
+// and room for a THREE-deep ring in the LDS that held two dense block rows (TMX_RING_DEPTH).  TMX_RSLOT[kind][d] = slot of band
+// entry d of the row of that kind, -1 = structural zero (the consumer takes the literal 0.0 the dense ring carried).
+#ifndef TMX_RING_DENSE
+#define TMX_RING_NQ 20
+__device__ constexpr int TMX_RSLOT[3][TMX_BW] = {
+	{ -1, 0, -1, -1, 1, 2, -1, 3, 4 },          // rho*theta row
+	{ 5, 6, 7, 8, 9, 10, -1, 11, -1 },          // W row
+	{ -1, 12, -1, 13, 14, -1, 15, 16, -1 } };   // rho row
+#define TMX_RSLOT_RHS 17                        // + kind
+#else      // A/B builds: every entry travels
+#define TMX_RING_NQ 30
+__device__ constexpr int TMX_RSLOT[3][TMX_BW] = { { 0, 1, 2, 3, 4, 5, 6, 7, 8 }, { 9, 10, 11, 12, 13, 14, 15, 16, 17 }, { 18, 19, 20, 21, 22, 23, 24, 25, 26 } };
+#define TMX_RSLOT_RHS 27
+#endif
+// entry c of the incoming matrix row: INK < 0: a dense row of stride IS (registers, zeros); INK = kind: the ring's block row at `in`
+template <int INK, int IS>
+__device__ __forceinline__ double lu_in_entry(const double * in, int c) {
+	if (INK < 0) return in[c * IS];
+	return (TMX_RSLOT[INK < 0 ? 0 : INK][c] >= 0) ? in[TMX_RSLOT[INK < 0 ? 0 : INK][c] * 64] : 0.0;
+}
+
 // Pivot step when every lane of the wavefront picked window row PV (the normal case: neighbouring columns have
 // nearly identical matrices).  The interchange is a compile-time renaming and the rank-1 update writes straight
 // into the slid position -- new row r-1, column c-1  <-  (row that sits at r after the swap)[c] - l_r * pivot[c] --
 // so neither the 160 v_cndmask of the per-lane interchange nor the 36 moves of the slide are executed.  Only the
 // pivot row and old row 0 are copied aside, because their slots are overwritten before their last use.
 // Same multiplications and subtractions on the same operands as the generic path: bit-identical.
-template <bool SPARSE, int PV, int IS, int TYPE>
+template <bool SPARSE, int PV, int IS, int TYPE, int INK = -1>
 __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -769,13 +814,13 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 		b[r - 1] = LU_UPD((r == PV) ? tb0 : b[r], pb, l);
 	}
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = lu_in_entry<INK, IS>(inrow, c);      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
 #else
 	// The reciprocal of the pivot and the four multipliers are started BEFORE the U-row stores: the IEEE division is a chain
 	// of a dozen dependent instructions, and the (conditional) stores -- which nothing waits for -- cover its latency.  The
 	// first entry of the incoming row is what the NEXT pivot search waits for: its LDS read is issued up front as well.
-	const double in0 = inrow[0];
+	const double in0 = lu_in_entry<INK, IS>(inrow, 0);
 	const double rcp = 1.0 / piv[0];
 	double l[5];
 #pragma unroll
@@ -794,7 +839,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	}
 	R[4][0] = in0;
 #pragma unroll
-	for (int c = 1; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
+	for (int c = 1; c < TMX_BW; c++) R[4][c] = lu_in_entry<INK, IS>(inrow, c);      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
 #endif
 }
@@ -802,7 +847,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
 // the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
 // the per-lane select path below.
-template <int TYPE, bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1>
+template <int TYPE, bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1, int INK = -1>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask, int * n_uniform = nullptr)
@@ -829,17 +874,17 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 	}
 	if (UNI) {
 		const int pv0 = __builtin_amdgcn_readfirstlane(pv);
-		if (__builtin_amdgcn_ballot_w64(pv != pv0) == 0) {
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(pv != pv0) == 0, 1)) {      // (the hint keeps the register allocator's split points out of this path)
 			if (n_uniform) (*n_uniform)++;      // wave-uniform counter (scalar add): pivot steps that took the renaming path
 			// the usual pivot row of this kind of matrix row first (rho*theta / W / rho rows pivot 4 / 3 / 2 rows down almost
 			// everywhere): one compare and branch instead of the switch's two or three
-			if (EXPECT >= 0 && pv0 == EXPECT) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
+			if (EXPECT >= 0 && __builtin_expect(pv0 == EXPECT, 1)) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
 			switch (pv0) {
-				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				default: lu_pivot_tail_uniform<SPARSE, 4, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				default: lu_pivot_tail_uniform<SPARSE, 4, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
 		}
 #ifndef TMX_VI_SELECT_PATH
@@ -849,11 +894,11 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		// in the lanes of one tail need not be zero in the others, so the all-lanes ballot of the sparse stores does not
 		// apply).  Unlike the select path -- whose 160 selects per step cost the kernel 30 spilled registers, reloaded in
 		// the uniform tails behind an s_waitcnt vmcnt(0) that also drained the U-row stores -- this adds no live values.
-		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS, TYPE>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
 		return;
 #endif
 	}
@@ -888,7 +933,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		b[r] = b[r + 1];
 	}
 #pragma unroll
-	for (int c = 0; c < TMX_BW; c++) R[4][c] = inrow[c * IS];      // IS: stride of the incoming row (1 registers, 64 LDS ring)
+	for (int c = 0; c < TMX_BW; c++) R[4][c] = lu_in_entry<INK, IS>(inrow, c);      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
 }
 
@@ -915,11 +960,11 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 	const double * rb = AB + (size_t)rr * TMX_RS(NUS);
 	double2 v[5];
 #pragma unroll
-	for (int sl = 0; sl < 3; sl++) v[sl] = *(const double2 *)(rb + sl * 128);
+	for (int sl = 0; sl < 3; sl++) v[sl] = ustream_load2(rb + sl * 128);
 #pragma unroll
 	for (int sl = 3; sl < 5; sl++) {
 		const double * bp = (mk & (1 << sl)) ? rb + sl * 128 : zp;
-		v[sl] = *(const double2 *)bp;
+		v[sl] = ustream_load2(bp);
 	}
 #pragma unroll
 	for (int sl = 0; sl < 5; sl++) {
@@ -1125,14 +1170,39 @@ __global__ __launch_bounds__(64) void k_vi_fused(KParams p, const double * xin, 
 #define TMX_EXPECT_R 2
 #endif
 // Two-wavefront variant of k_vi_fused: the block rows of a column are independent of one another, only the
-// elimination is sequential.  Wavefront 0 of the workgroup assembles block row t (compute_block, the same code)
-// into a double-buffered LDS ring while wavefront 1 runs the three pivot steps of block row t-1; one barrier
-// per block row.  The dependent chain of a column shrinks from assembly + LU to max(assembly, LU) per level
-// (cycle counts in DESIGN.md), which is what bounds the kernel on small per-GPU grids.  Same statements on the
-// same operands: bit-identical to k_vi_fused.
+// elimination is sequential.  Wavefront 0 of a pair assembles block rows (compute_block, the same code) into an LDS ring,
+// wavefront 1 runs the three pivot steps of each block row out of it.  The dependent chain of a column shrinks from
+// assembly + LU to max(assembly, LU) (cycle counts in DESIGN.md), which is what bounds the kernel on small per-GPU grids.
+// Same statements on the same operands: bit-identical to k_vi_fused.
+// Round 5: the two roles no longer meet at a workgroup barrier after every block row.  The ring is TMX_RING_DEPTH block rows deep
+// (sparse block rows, TMX_RSLOT above: three fit where two dense ones did) and the roles hand over through two LDS counters per
+// pair -- `produced` (block rows published) and `consumed` -- so the assembly runs up to TMX_RING_DEPTH block rows ahead and a pair
+// pays max(sum assembly, sum elimination) instead of the sum over block rows of max(assembly, elimination); with the barrier both
+// roles spent 28 % of the forward phase waiting for each other (profiles/r04_pair_timing.txt).  Ordering: LDS executes a
+// wavefront's instructions in order; the writer still drains lgkmcnt before it raises its counter, the reader polls the counter
+// with a volatile read (s_sleep between polls) and a compiler barrier keeps the ring accesses behind it.  No vmcnt wait anywhere.
 // BACK = false: the kernel ends with the elimination and leaves the fill-in masks of its U rows in `gmask` ([column group][3(L+1)]);
 // k_vi_back does the back substitution as a launch of its own (one wavefront per workgroup, so that the HBM-bound half of the
 // solve is spread evenly over the CUs whatever the residency of the pairs was).
+#ifndef TMX_RING_DEPTH
+#define TMX_RING_DEPTH 3
+#endif
+// (the counters are accessed through explicit LDS pointers: a volatile access through a generic pointer compiles to a FLAT load followed
+// by s_waitcnt vmcnt(0), i.e. a wait for every U-row store in flight)
+typedef __attribute__((address_space(3))) int tmx_lds_int;
+// The poll loop is ONE asm statement: as a loop in the source it sat inside the block-row loop, and the register allocator answered the
+// nested loop with 34 spilled registers in the elimination (reloaded behind s_waitcnt vmcnt, i.e. behind the U-row stores).
+__device__ __forceinline__ void ring_wait(const int * counter, int need) {
+	const unsigned addr = (unsigned)(size_t)(const tmx_lds_int *)counter;
+	int v, sv;
+	asm volatile("Lring_poll_%=:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_ge_i32 %1, %3\n\t"
+		"s_cbranch_scc1 Lring_go_%=\n\ts_sleep 1\n\ts_branch Lring_poll_%=\nLring_go_%=:"
+		: "=&v"(v), "=&s"(sv) : "v"(addr), "s"(need) : "memory", "scc");
+}
+__device__ __forceinline__ void ring_post(int * counter, int value, int lane) {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wavefront's ring writes (producer) / ring reads (consumer) are done
+	if (lane == 0) *(volatile tmx_lds_int *)counter = value;
+}
 template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true>
 __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
@@ -1143,7 +1213,8 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	double * opsl = opsl_mem;
 	const int L = p.L;
 	constexpr int MM = CLOSED ? 1 : 2;
-	constexpr int NQ = 3 * TMX_BW + 3;                                       // doubles per block row and column
+	constexpr int NQ = TMX_RING_NQ;                                          // doubles per block row and column in the ring (sparse: TMX_RSLOT)
+	constexpr int RD = TMX_RING_DEPTH;
 	// Staggered start (stagger = window in units of 10 ns, 0 = off): workgroup i begins i / gridDim.x of the window late.  All
 	// workgroups are resident at once and would otherwise run in lock-step -- every wavefront in its issue- and latency-bound
 	// elimination first, then every wavefront in its HBM-bound back substitution; spread out, the back substitutions of the
@@ -1168,9 +1239,11 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 #else
 	const int role = wv & 1, pair = wv >> 1;
 #endif
-	double * ring = etal + 2 * L + 1 + (size_t)pair * 2 * NQ * 64;           // [PAIRS][2][NQ][64]
-	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * 2 * NQ * 64;        // [512] exp / log tables (exner_from_rhotheta_lds)
+	double * ring = etal + 2 * L + 1 + (size_t)pair * RD * NQ * 64;          // [PAIRS][RD][NQ][64]
+	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * RD * NQ * 64;       // [512] exp / log tables (exner_from_rhotheta_lds)
 	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
+	int * rcount = (int *)(rmtab + TMX_RMTAB_DOUBLES) + PAIRS * TMX_FTOT * (L + 1) + 2 * pair;   // [PAIRS]{produced, consumed}
+	if (role == 0 && lane == 0) { rcount[0] = 0; rcount[1] = 0; }
 	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128 * PAIRS) opsl[t] = p.ops[t];
 	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += 128 * PAIRS) etal[t] = p.eta[t];
 	tmx_rm_tables_to_lds(rmtab, wv * 64 + lane, 128 * PAIRS);
@@ -1239,45 +1312,51 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 #define PMARK(acc)
 #endif
 		auto block_row = [&](int t, LevRaw & rYl, const LevRaw & rYm) {
-			if (t <= L) {
-				if (DEEP) rYl = load_raw(t + 4);
-				else { /* issued below, after the shift */ }
+			if (DEEP) rYl = load_raw(t + 4);
+			else { /* issued below, after the shift */ }
 #ifdef TMX_ABL_FAST_PRODUCER      // ablation builds: the block row is evaluated once, the ring is refilled with it every time
-				if (t == 0)
+			if (t == 0)
 #endif
 #ifdef TMX_PAIR_TIMING
-				PMARK(tp_seg[4]);      // prefetch issue
-				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab, tp_seg);
-				tp_mark = __builtin_readcyclecounter();
-#else
-				// Interior block rows whose Exner arguments are ordinary numbers in every lane can take the branch-free instantiation
-				// (one basic block of 350 vector instructions per block row).  Measured: SLOWER -- the assembly alone 118 instead of
-				// 98 us per launch, the kernel +3 % -- so it stays an experiment (-DTMX_INTERIOR_ROWS).
-#ifdef TMX_INTERIOR_ROWS
-				if (t >= 1 && t <= L - 2 && __builtin_amdgcn_ballot_w64(!exner_arg_in_main_range(p, nB.pn)) == 0)
-					compute_block<true, false, true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
-				else
-#endif
-				compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
-#endif
-				double * q = ring + (size_t)(t & 1) * NQ * 64 + lane;
-#pragma unroll
-				for (int c = 0; c < TMX_BW; c++) { q[c * 64] = rP[c]; q[(TMX_BW + c) * 64] = rW[c]; q[(2 * TMX_BW + c) * 64] = rR[c]; }
-				q[(3 * TMX_BW) * 64] = fP; q[(3 * TMX_BW + 1) * 64] = fW; q[(3 * TMX_BW + 2) * 64] = fR;
+			{
+			PMARK(tp_seg[4]);      // prefetch issue
+			compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab, tp_seg);
+			tp_mark = __builtin_readcyclecounter();
 			}
+#else
+			// Interior block rows whose Exner arguments are ordinary numbers in every lane can take the branch-free instantiation
+			// (one basic block of 350 vector instructions per block row).  Measured: SLOWER -- the assembly alone 118 instead of
+			// 98 us per launch, the kernel +3 % -- so it stays an experiment (-DTMX_INTERIOR_ROWS).
+#ifdef TMX_INTERIOR_ROWS
+			if (t >= 1 && t <= L - 2 && __builtin_amdgcn_ballot_w64(!exner_arg_in_main_range(p, nB.pn)) == 0)
+				compute_block<true, false, true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
+			else
+#endif
+			compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
+#endif
 			PMARK(tp_work);
-			__syncthreads();
+			// the slot of block row t held block row t - RD: free once the consumer has taken that one in (evaluated first, waited for here)
+			if (t >= RD) ring_wait(rcount + 1, t - RD + 1);
 			PMARK(tp_wait);
+			double * q = ring + (size_t)(t % RD) * NQ * 64 + lane;
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				if (TMX_RSLOT[0][c] >= 0) q[TMX_RSLOT[0][c] * 64] = rP[c];
+				if (TMX_RSLOT[1][c] >= 0) q[TMX_RSLOT[1][c] * 64] = rW[c];
+				if (TMX_RSLOT[2][c] >= 0) q[TMX_RSLOT[2][c] * 64] = rR[c];
+			}
+			q[(TMX_RSLOT_RHS + 0) * 64] = fP; q[(TMX_RSLOT_RHS + 1) * 64] = fW; q[(TMX_RSLOT_RHS + 2) * 64] = fR;
+			ring_post(rcount, t + 1, lane);
 			nA = nB; nB = nC; eA = eB; eB = eC;
 			if (DEEP) { enter(rN1, t + 2, nC, eC); rN1 = rYm; }
 			else { nC = nN; eC = eN; nN = load_node<MM>(p, mcol, xin, t + 3, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 3, col, etal); }
 #ifdef TMX_PAIR_TIMING
-			PMARK(tp_seg[5]);      // window shift (DEEP: touches loads issued two block rows earlier)
+			PMARK(tp_seg[5]);      // ring writes + window shift (DEEP: touches loads issued two block rows earlier)
 #endif
 		};
-		for (int t = 0; t <= L + 1; t += 2) {
+		for (int t = 0; t <= L; t += 2) {
 			block_row(t, rY0, rY1);
-			if (t + 1 <= L + 1) block_row(t + 1, rY1, rY0);
+			if (t + 1 <= L) block_row(t + 1, rY1, rY0);
 		}
 #ifdef TMX_PAIR_TIMING
 		if (stats && lane == 0) {
@@ -1315,43 +1394,46 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	long long tp_work = 0, tp_wait = 0, tp_mark = __builtin_readcyclecounter();
 	const long long tp_start = tp_mark;
 #endif
-	for (int t = 0; t <= L + 1; t++) {
-		if (t >= 1) {
-			const int m = t - 1;
-			const double * q = ring + (size_t)(m & 1) * NQ * 64 + lane;
-			const double * qP = q, * qW = q + TMX_BW * 64, * qR = q + 2 * TMX_BW * 64, * qf = q + 3 * TMX_BW * 64;
-			if (m == 0) {
-				// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
-#pragma unroll
-				for (int c = 0; c < TMX_BW; c++) {
-					R[0][c] = (c + 4 < TMX_BW) ? qP[(c + 4) * 64] : 0.0;
-					R[1][c] = (c + 3 < TMX_BW) ? qW[(c + 3) * 64] : 0.0;
-					R[2][c] = (c + 2 < TMX_BW) ? qR[(c + 2) * 64] : 0.0;
-				}
-				b[0] = qf[0]; b[1] = qf[64]; b[2] = qf[128];
-			} else if (m == 1) {
-#pragma unroll
-				for (int c = 0; c < TMX_BW; c++) {
-					R[3][c] = (c + 1 < TMX_BW) ? qP[(c + 1) * 64] : 0.0;
-					R[4][c] = qW[c * 64];
-				}
-				b[3] = qf[0]; b[4] = qf[64];
-				lu_pivot_step<0, SPARSE, true, 64>(R, b, singular, AB, RHS, 0, NUS, u, qR, qf[128], umask, &nuni);      // pivot 0 takes in row 5
-			} else
-#ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the barrier rhythm
-			if (m < 0)
-#endif
-			{
-				// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
-				lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, qP, qf[0], umask, &nuni);
-				lu_pivot_step<2, SPARSE, true, 64, TMX_EXPECT_R>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, qW, qf[64], umask, &nuni);
-				lu_pivot_step<0, SPARSE, true, 64, TMX_EXPECT_T>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, qR, qf[128], umask, &nuni);
-			}
-		}
+	for (int m = 0; m <= L; m++) {
 		PMARK(tp_work);
-		__syncthreads();
+		ring_wait(rcount, m + 1);      // block row m is in the ring
 		PMARK(tp_wait);
+		const double * q = ring + (size_t)(m % RD) * NQ * 64 + lane;
+		// band entry d of the block row's rho*theta / W / rho row (structural zeros are literals), and the three residuals
+#define QE(kind, d) lu_in_entry<kind, 64>(q, d)
+#define QF(kind) q[(TMX_RSLOT_RHS + (kind)) * 64]
+		if (m == 0) {
+			// window row r holds matrix columns 0..8; band entry d of row r sits at column r - 4 + d
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				R[0][c] = (c + 4 < TMX_BW) ? QE(0, c + 4 < TMX_BW ? c + 4 : 0) : 0.0;
+				R[1][c] = (c + 3 < TMX_BW) ? QE(1, c + 3 < TMX_BW ? c + 3 : 0) : 0.0;
+				R[2][c] = (c + 2 < TMX_BW) ? QE(2, c + 2 < TMX_BW ? c + 2 : 0) : 0.0;
+			}
+			b[0] = QF(0); b[1] = QF(1); b[2] = QF(2);
+		} else if (m == 1) {
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				R[3][c] = (c + 1 < TMX_BW) ? QE(0, c + 1 < TMX_BW ? c + 1 : 0) : 0.0;
+				R[4][c] = QE(1, c);
+			}
+			b[3] = QF(0); b[4] = QF(1);
+			lu_pivot_step<0, SPARSE, true, 64, -1, 2>(R, b, singular, AB, RHS, 0, NUS, u, q, QF(2), umask, &nuni);      // pivot 0 takes in row 5
+		} else
+#ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the hand-over rhythm
+		if (m < 0)
+#endif
+		{
+			// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
+			lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W, 0>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, q, QF(0), umask, &nuni);
+			lu_pivot_step<2, SPARSE, true, 64, TMX_EXPECT_R, 1>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, q, QF(1), umask, &nuni);
+			lu_pivot_step<0, SPARSE, true, 64, TMX_EXPECT_T, 2>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, q, QF(2), umask, &nuni);
+		}
+#undef QE
+#undef QF
+		ring_post(rcount + 1, m + 1, lane);      // the slot may be refilled
 	}
+	PMARK(tp_work);
 	{
 		double z[TMX_BW];
 #pragma unroll
@@ -1640,7 +1722,7 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
 		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + TMX_RMTAB_DOUBLES * sizeof(double);
-		const size_t lds_pair = (size_t)2 * (3 * TMX_BW + 3) * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int);
+		const size_t lds_pair = (size_t)TMX_RING_DEPTH * TMX_RING_NQ * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int) + 2 * sizeof(int);      // ring, fill-in masks, hand-over counters
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 		// back substitution as a launch of its own (TMX_VI_SPLIT_BACK=0: inside the pair kernel); the masks go through d_rhs,
 		// which only the split cross-check kernels use otherwise
