@@ -59,10 +59,97 @@ OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)",
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = next((t for t in ("r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
+PROFILE_TAG = next((t for t in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
 OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss", "k_dss_u"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the loaded library was built from (tempestmodel_amd/csrc/*.hip, *.h,
+    include/*.h, in name order).  tools/summarise_profiles.py stamps the committed counter tables with the same figure, so the line
+    can say whether the offline numbers belong to the code that ran."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tempestmodel_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "tempestmodel_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_LIB_KERNELS = None
+
+
+def library_kernels():
+    """Base names of the __global__ kernels the loaded product library holds (mangled host-stub names in its symbol strings)."""
+    global _LIB_KERNELS
+    if _LIB_KERNELS is None:
+        import re
+        from tempestmodel_amd import engine as _eng
+        path = os.environ.get("TMX_LIBRARY") or getattr(_eng, "LIB_PATH", None) or os.path.join(ROOT, "tempestmodel_amd", "libtempest_mi355x.so")
+        names = set()
+        try:
+            blob = open(path, "rb").read()
+            for m in re.finditer(rb"_Z(\d+)(k_[a-z0-9_]+)", blob):
+                n = int(m.group(1))
+                names.add(m.group(2)[:n].decode())
+        except Exception:
+            pass
+        _LIB_KERNELS = names
+    return _LIB_KERNELS
+
+
+def profile_kernels_known(names):
+    """(ok, unknown): every kernel base name of a committed profile must exist in the loaded library, else its numbers are refused."""
+    lib = library_kernels()
+    if not lib:
+        return True, []      # symbol strings not readable: nothing to check against
+    unknown = sorted({n for n in names if n.startswith("k_") and n not in lib})
+    return (not unknown), unknown
+
+
+def traffic_table(ne, L, world):
+    """The newest committed PMC table of the shape (path, parsed json) or (None, None); refused (None) when it names kernels the loaded library does not hold."""
+    for t in ("r05", "r04", "r03", "r02"):      # (the newest table of the shape; r04 on: the node-unique layout, the default)
+        c = os.path.join(ROOT, "profiles", "%s_pmc_traffic_ne%d_L%d_n%d.json" % (t, ne, L, world))
+        if os.path.exists(c):
+            try:
+                tab = json.load(open(c))
+            except Exception:
+                return None, None
+            ok, unknown = profile_kernels_known([k.replace("void ", "").split("<")[0].split("(")[0] for k in tab["kernels"]])
+            if not ok:
+                sys.stderr.write("bench: %s names kernels the loaded library does not hold (%s): its traffic figures are not used\n" % (os.path.relpath(c, ROOT), ", ".join(unknown)))
+                return None, None
+            return c, tab
+    return None, None
+
+
+def layout_model(eng, L, unique):
+    """Bytes per launch each operation cannot avoid moving IN THE LAYOUT THAT RUNS (SURVEY 8(d)'s rule -- every needed array read or
+    written once -- applied to the arrays that exist): with the node-unique layout a state / update / combination-source array has one
+    entry per patch node (NU columns), the geometry is the 2-D per-(element, node) slabs the closed-form metric needs (NS columns, no
+    level factor; the 26 three-dimensional metric doubles of the 8(d) row are not stored at all), the DSS reads the partial slots and
+    writes the nodes on tile and patch edges.  Element-major: state arrays have NS columns.  ARS343's four explicit launches read
+    1 + 4 + 6 + 7 source instances (the stage combinations are evaluated inside them)."""
+    NS, NU, NPs, NG = eng.info(0), eng.info(1), eng.info(15), eng.info(16)
+    closed = eng.info(6) == 1
+    nslab = 5 * L + 1
+    cols = NU if unique else NS
+    inst = 8.0 * cols * nslab                      # one state instance
+    slots = 8.0 * NPs * nslab if unique else 0.0   # per-element values of the seam nodes on tile / patch edges
+    geo2d_h = 8.0 * NS * 20                        # 2-D slabs of the horizontal kernels (metric, Coriolis, spacing, closed-form factors)
+    geo3d_h = 0.0 if closed else 8.0 * NS * L * 10
+    geo_v = 8.0 * cols * 14 + (0.0 if closed else 8.0 * cols * L * 26)
+    h_reads = (1 + 4 + 6 + 7) / 4.0                # source instances per explicit launch, ARS343 average
+    out = {
+        "h_explicit": h_reads * inst + geo2d_h + geo3d_h + inst + slots,
+        "v_implicit": inst + 8.0 * cols * (3 * L + 1) + geo_v,
+        "dss": (slots + 8.0 * NG * nslab) if unique else 0.75 * 2 * inst,
+        "hypervis": 1.25 * inst + inst + slots,    # pass 1: state in, Laplacians out; pass 2: Laplacians + base in, state out
+        "lincomb": 0.0,
+    }
+    return out
 
 
 def measured_traffic(op, ne, L, world, launches_per_step):
@@ -70,16 +157,10 @@ def measured_traffic(op, ne, L, world, launches_per_step):
     separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_table.py).  One table per
     workload shape, profiles/r02_pmc_traffic_ne<ne>_L<L>_n<ranks>.json (n > 1: the share of rank 0, taken with a lone
     rank-0 engine of the n-rank layout, tools/rank_share_timing.py); a shape without a table -> None."""
-    path = None
-    for t in ("r04", "r03", "r02"):      # (the newest table of the shape; r04 on: the node-unique layout, the default)
-        c = os.path.join(ROOT, "profiles", "%s_pmc_traffic_ne%d_L%d_n%d.json" % (t, ne, L, world))
-        if os.path.exists(c):
-            path = c
-            break
+    path, tab = traffic_table(ne, L, world)
     if path is None:
         return None
     try:
-        tab = json.load(open(path))
         per_step = 0.0
         for name, row in tab["kernels"].items():
             base = name.replace("void ", "").split("<")[0].split("(")[0]
@@ -130,6 +211,10 @@ def dominant_kernel_from_stats(ne, L, world):
             return r["Name"].replace("void ", "").split("<")[0].split("(")[0]
         known = {n for names in OP_ROCPROF.values() for n in names}
         rows = [r for r in csv.DictReader(open(path)) if base_of(r) in known]      # the step's kernels (not the memsets / copies of the set-up)
+        ok, unknown = profile_kernels_known([base_of(r) for r in rows])
+        if not ok:      # a profile of kernels this library no longer holds says nothing about this run
+            sys.stderr.write("bench: %s names kernels the loaded library does not hold (%s): not used\n" % (os.path.relpath(path, ROOT), ", ".join(unknown)))
+            return None
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         for op, names in OP_ROCPROF.items():
@@ -460,11 +545,16 @@ def main():
         sustained = {"steps": args.sustained_steps, "seconds": ts, "ms_per_step": 1e3 * ts / args.sustained_steps,
                      "smi_before": smi0, "smi_after": smi_snapshot() if rank == 0 else None}
 
+    # sanity: the state the timed and sustained legs produced must still be finite (checked BEFORE the parity leg re-uploads the initial state)
+    import numpy as np
+    chk = eng.download_state(0)
+    state_finite = all(np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all() for p in eng.local_patches)
+    del chk
+
     # N > 1: the line carries its own parity proof -- every rank steps again from the initial state, rank 0 also steps a
     # single-rank engine holding all patches, and rank 0's patches must come out identical, bit for bit
     parity = None
     if world > 1 and args.parity_steps > 0 and not hs:
-        import numpy as np
         eng.upload_state(0, states)
         for _ in range(args.parity_steps):
             _step(dt)
@@ -484,10 +574,9 @@ def main():
             one.close()
         barrier()
 
-    # sanity: the state must still be finite
-    chk = eng.download_state(0)
-    import numpy as np
-    state_finite = all(np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all() for p in eng.local_patches)
+    if parity is not None or (world > 1 and args.parity_steps > 0 and not hs):      # ... and the state behind the parity leg as well
+        chk = eng.download_state(0)
+        state_finite = state_finite and all(np.isfinite(chk[p][0]).all() and np.isfinite(chk[p][1][3]).all() for p in eng.local_patches)
     ablation_build = bool(os.environ.get("TMX_LIBRARY"))      # tools/ablate.sh builds skip parts of the arithmetic on purpose
     if not state_finite and not ablation_build:
         sys.exit("bench.py: state became non-finite")
@@ -518,6 +607,19 @@ def main():
         if dom == "v_implicit" and eng.info(1) <= 6400:
             kernel_name = "k_vi_group (one column per 16-lane group)"
         mfma = mfma_report(eng.get_option("contraction_mfma") != 0)
+        # second accounting, for the layout that ran (layout_model above) and the measured HBM rate = counter traffic / this run's time
+        unique_ran = eng.info(12) == 1 and unique_after_timed > 0
+        lay = layout_model(eng, L, unique_ran)
+        lay_dom = lay[dom]
+        dom_traffic = measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps)
+        tpath, ttab = traffic_table(ne, L, world)
+        step_traffic = None
+        if ttab is not None:
+            known = {n for names in OP_ROCPROF.values() for n in names}
+            step_traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] / ttab["steps"] for k, r in ttab["kernels"].items()
+                               if k.replace("void ", "").split("<")[0].split("(")[0] in known)
+        sha_now = csrc_sha16()
+        sha_prof = (ttab or {}).get("csrc_sha16")
 
         def per_op(op):
             # algorithmic figure (SURVEY 8d row x points) beside the counter-measured one: the 8d rows are not lower bounds for
@@ -535,6 +637,7 @@ def main():
                     "bytes_per_point": ALG_BYTES[op], "survey_8d_bytes_per_point": SURVEY_8D_BYTES[op],
                     "achieved_GBs_with_survey_8d_row": SURVEY_8D_BYTES[op] * local_points / max(ms * 1e-3, 1e-12) / 1e9,
                     "traffic": tr, "measured_GBs": (tr / max(ms * 1e-3, 1e-12) / 1e9) if tr else None,
+                    "layout_aware_bytes_per_launch": lay[op], "layout_aware_GBs": lay[op] / max(ms * 1e-3, 1e-12) / 1e9,
                     "bound": OP_BOUND[op]}
         out = {
             "metric": "element-DOF-updates/s (JW baroclinic wave ne%d np4 L%d, ARS343 IMEX)" % (ne, L),
@@ -550,6 +653,10 @@ def main():
                            len(grid.patches), world, "processes sharing ONE GPU (multi-process path check, not a scaling number)" if args.share_device and world > 1 else "GPU(s)",
                            halo_note),
                        "hbm_allocated_GiB_per_gpu": eng.info(5) / 2.0 ** 30,
+                       # the sustained leg beside the K timed steps (full record: top-level "sustained")
+                       "sustained_steps": sustained["steps"] if sustained else 0,
+                       "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
+                       "sustained_value": (dof_per_step / (sustained["ms_per_step"] * 1e-3)) if sustained else None,
                        # tmx_set_option("unique_layout") / TMX_UNIQUE: inside tmx_step the state is held once per patch node
                        "state_layout": ("node-unique inside tmx_step (%d instances in that form at the end of the timed region, %d partial slots, "
                                         "%d node groups left to the DSS kernel of %d)" % (unique_after_timed, eng.info(15), eng.info(16), eng.info(2)))
@@ -559,8 +666,25 @@ def main():
             "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
                          "kernel": kernel_name, "operation": dom, "dominant_by": dom_note,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom, ne, L, world, op_launches[dom] / args.steps), "avg_launch_ms": avg_ms,
+                         "traffic": dom_traffic, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
+                         # (1) the same 8(d) row on the points this layout holds (the column solve works on the unique columns, not the stored ones)
+                         "achieved_8d_row_on_layout_points": (ALG_BYTES[dom] * (eng.info(1) if (unique_ran or dom == "v_implicit") else eng.info(0)) * L) / (avg_ms * 1e-3) / 1e9,
+                         "frac_8d_row_on_layout_points": (ALG_BYTES[dom] * (eng.info(1) if (unique_ran or dom == "v_implicit") else eng.info(0)) * L) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # (2) layout-aware algorithmic bytes: what the operation cannot avoid moving in the layout that runs (layout_model)
+                         "layout_aware_bytes_per_launch": lay_dom, "achieved_layout_aware": lay_dom / (avg_ms * 1e-3) / 1e9,
+                         "frac_layout_aware": lay_dom / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # (3) the HBM rate itself: counter traffic of the committed PMC table / this run's launch time
+                         "hbm_rate_GBs": (dom_traffic / (avg_ms * 1e-3) / 1e9) if dom_traffic else None,
+                         "hbm_rate_frac": (dom_traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_traffic else None,
+                         "traffic_over_layout_aware_bytes": (dom_traffic / lay_dom) if (dom_traffic and lay_dom) else None,
+                         "whole_step_traffic_bytes": step_traffic,
+                         "whole_step_hbm_rate_GBs": (step_traffic / (ms_per_step * 1e-3) / 1e9) if step_traffic else None,
+                         "whole_step_hbm_rate_frac": (step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+                         "whole_step_layout_aware_GBs": sum(lay[op] * op_launches[op] / args.steps for op in lay) / (ms_per_step * 1e-3) / 1e9,
+                         "traffic_source": os.path.relpath(tpath, ROOT) if tpath else None,
+                         "traffic_source_csrc_sha16": sha_prof, "library_csrc_sha16": sha_now,
+                         "traffic_source_matches_library_sources": (sha_prof == sha_now) if sha_prof else None,
                          "per_operation": {op: per_op(op) for op in OP_KERNELS},
                          "limited_by": OP_BOUND[dom],
                          "uniform_pivot_fraction": (pivot[0] / pivot[1]) if pivot[1] else None,

@@ -66,6 +66,7 @@ void prof_collect(tmx_engine * e) {
 // ---------------------------------------------------------------------------------------------
 // life cycle
 
+static void tmx_record_option_defaults(tmx_engine * e);
 extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg && out, TMX_ERR_INVALID, "tmx_create: null argument");
 	REQUIRE(cfg->abi_version == TMX_ABI_VERSION, TMX_ERR_INVALID, "tmx_create: ABI version %d, library is %d", cfg->abi_version, TMX_ABI_VERSION);
@@ -90,6 +91,7 @@ extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg->n_instances <= 32, TMX_ERR_UNSUPPORTED, "%d data instances: the stepper programs track instances in 32-bit masks", cfg->n_instances);
 	REQUIRE(cfg->n_ranks >= 1 && cfg->rank >= 0 && cfg->rank < cfg->n_ranks, TMX_ERR_INVALID, "bad rank %d of %d", cfg->rank, cfg->n_ranks);
 	tmx_engine * e = new tmx_engine();
+	tmx_record_option_defaults(e);      // what "the default" of every option is (the production flavour refuses any other value of an experiments option)
 	e->cfg = *cfg;
 	e->L = cfg->levels;
 	e->patches.resize(cfg->n_patches);
@@ -1425,7 +1427,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 }
 static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
-	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 element-major order (default), 1 2 x 2 blocks, 2 strips inside a patch row" },
+	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
 	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
@@ -1464,6 +1466,10 @@ static const OptionDef g_options[] = {
 	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
 };
+static void tmx_record_option_defaults(tmx_engine * e) {
+	e->opt_default.clear();
+	for (const OptionDef & d : g_options) e->opt_default.push_back(*option_slot(e, d.name));
+}
 extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(e && name, TMX_ERR_INVALID, "tmx_set_option: null argument");
 	const std::string n(name);
@@ -1474,11 +1480,25 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(!((def->kind & 1) && e->finalized), TMX_ERR_INVALID, "tmx_set_option(%s) after tmx_finalize", name);
 	const int iv = (int)value;
 	REQUIRE(TMX_EXP || n != "vt_explicit_walk" || iv <= 0, TMX_ERR_UNSUPPORTED, "tmx_set_option(vt_explicit_walk = %d): the register-held segments are compiled into the experiments flavour of the library only", iv);
-	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == *slot || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
+	int dflt = *slot;
+	for (size_t k = 0; k < e->opt_default.size() && k < sizeof(g_options) / sizeof(g_options[0]); k++) if (n == g_options[k].name) dflt = e->opt_default[k];
+	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == dflt || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
 		"tmx_set_option(%s = %d): an archived experiment / cross-check kernel, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", name, iv);
 	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");
 	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2");
 	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
+	// integer options that select a kernel shape: only the values a launch knows (everything else used to fall through to a default silently)
+	if (n == "vi_group") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vi_group: -1 (auto), 0 or 1");
+	if (n == "vi_group_max") REQUIRE(iv >= 0, TMX_ERR_INVALID, "vi_group_max must not be negative");
+	if (n == "vi_pair_workgroup") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "vi_pair_workgroup: 0 (auto), 1 or 2");
+	if (n == "vi_stagger") REQUIRE(iv >= 0, TMX_ERR_INVALID, "vi_stagger must not be negative");
+	if (n == "vi_columns_per_wavefront") REQUIRE(iv >= 0 && iv <= 64, TMX_ERR_INVALID, "vi_columns_per_wavefront: 0 (= 64) .. 64");
+	if (n == "vi_back_sub") REQUIRE(iv == 1 || iv == 2 || iv == 4, TMX_ERR_INVALID, "vi_back_sub: 1, 2 or 4");
+	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
+	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
+	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
+	if (n == "unique_xcd_order" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;
 }

@@ -272,6 +272,7 @@ struct tmx_engine {
 	int opt_no_split = 0, opt_metric_stored = 0, opt_tracer_lincomb_pass = 0, opt_udv_separate = 0, opt_vx_fused = 0, opt_skip_exchange = 0,
 	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_walk = -1000, opt_vite_walk = -1000, opt_vx_walk = -1000, opt_vt_lanes = 16,
 	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
+	std::vector<int> opt_default;            // default of every option, in g_options order (tmx_record_option_defaults)
 	std::vector<std::string> env_applied;    // "NAME=value" of every environment variable tmx_options_from_environment turned into an option
 	UniqueLayout u;
 	bool vi_unique = false;                  // transient: the column solve runs on the unique slabs (tmxk_vi_fused)

@@ -1711,7 +1711,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	// two; 380 groups 125 us with two pairs per workgroup, 131 us with one.  So it is the production kernel at every
 	// size; the one-wavefront kernel stays as TMX_VI_PAIR=0 (bit-identical, tested).
 	// few columns for the chip (strong-scaling share): one column per 16-lane group
-	if (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max)) {
+	// (the options that select it may be set after tmx_finalize sized the scratch for the pair kernel's 10 doubles per row and column: the
+	// lane-group kernel streams 16, and is only launched where its stream fits -- otherwise the pair kernel serves the share)
+	const bool group_fits = (size_t)((e->nunique + 3) / 4) * 64 <= (size_t)TMX_UW * e->vi_stream_cols;
+	if (group_fits && (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max))) {
 		const int nwg = (e->nunique + 3) / 4;
 		if (p.closed) hipLaunchKernelGGL((k_vi_group<true>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
 		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);

@@ -224,3 +224,31 @@ def exact_tolerance_report():
     tol = exact_tolerance()
     return "exact-comparison tolerance = %g (%s)" % (tol, _EXACT_WHY)
 
+
+
+def live_reference_required():
+    """Whether a missing oracle/_ref binary fails a test instead of skipping it.  TMX_REQUIRE_LIVE_REF=1 / 0 decides; unset, the live
+    reference is REQUIRED wherever a GPU is present -- the strongest parity tests (the device against the real reference run on the same
+    host) are `-m gpu` tests, oracle/_ref travels to the GPU box with the snapshot, and a run there that silently skipped them would
+    stay green without its proof.  Set TMX_REQUIRE_LIVE_REF=0 on a GPU host that has no /root/reference to build oracle/_ref from."""
+    v = os.environ.get("TMX_REQUIRE_LIVE_REF", "")
+    if v != "":
+        return v != "0"
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def need_live_reference(*paths, what=None):
+    """Fail (where the live reference is required) or skip when one of the oracle/_ref binaries is missing."""
+    import pytest
+    missing = [p for p in paths if not os.path.exists(p)]
+    if not missing:
+        return
+    msg = "%s not built / did not travel with the snapshot (oracle/_ref is built from /root/reference in the build container%s)" % (
+        ", ".join(os.path.relpath(m, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) for m in missing), "; " + what if what else "")
+    if live_reference_required():
+        pytest.fail(msg + " -- required on a GPU host (TMX_REQUIRE_LIVE_REF=0 turns this into a skip)")
+    pytest.skip(msg)

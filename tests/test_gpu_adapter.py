@@ -76,8 +76,7 @@ TOL = "1e-300" if gu.exact_tolerance() == 0.0 else "1e-10"      # identical doub
     ("production", ["--modelgo", "1", "--ne", "3", "--levels", "6", "--steps", "3", "--patches", "6", "--hostsync", "1"]),
 ])
 def test_reference_driver_with_adapter_plugins(mode, args):
-    if not os.path.exists(BIN):
-        pytest.skip("oracle/_ref/tmx_adapter_run not built (needs /root/reference)")
+    gu.need_live_reference(BIN)
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
     # the plugins see the reference's own grid objects, so the device reproduces the reference BIT FOR BIT: the tolerance
     # only has to let an exact zero through (worst < tol)
@@ -102,8 +101,9 @@ def test_reference_driver_under_mpi_with_peer_to_peer_halo(nranks, args):
     exchange through IPC-mapped ghost buffers): every rank reports a zero difference on the patches it owns."""
     import shutil
     mpiexec = next((c for c in ("/opt/conda/bin/mpiexec", "mpiexec") if shutil.which(c)), None)
-    if not os.path.exists(BIN) or mpiexec is None:
-        pytest.skip("needs oracle/_ref/tmx_adapter_run and mpiexec")
+    gu.need_live_reference(BIN)
+    if mpiexec is None:
+        pytest.skip("needs mpiexec")
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", TMX_HALO="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([mpiexec, "-np", str(nranks), BIN, "--mode", "production", "--dt", "200", "--warm", "1", "--tol", TOL] + args,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)

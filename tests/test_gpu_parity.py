@@ -756,8 +756,7 @@ def test_bench_workload_vs_live_reference():
     import tmxd
     from tempestmodel_amd.engine import Engine
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    gu.need_live_reference(ref_bin)
     ne, L, dt, npatch = 30, 30, 150.0, 24
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "ref.tmxd")
@@ -812,8 +811,7 @@ def test_live_reference_sweep(name, args, case, ntr, opts, scheme, dt, nsteps):
     import tmxd
     from tempestmodel_amd.engine import Engine
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    gu.need_live_reference(ref_bin)
     npatch = int(args[args.index("--patches") + 1]) if "--patches" in args else 24
     full = list(args) + ([] if "--patches" in args else ["--patches", "24"])
     with tempfile.TemporaryDirectory() as td:
@@ -1322,8 +1320,7 @@ def test_shallow_water_24_patches_vs_live_reference():
     from tempestmodel_amd.cubed_sphere import CubedSphereGrid
     from tempestmodel_amd.engine import Engine
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    gu.need_live_reference(ref_bin)
     ne, npatch, dt, nsteps = 8, 24, 200.0, 4
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "ref.tmxd")
@@ -1506,8 +1503,7 @@ def test_supercell_kessler_24_patches_vs_live_reference():
     import tmxd
     from tempestmodel_amd.engine import Engine
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    gu.need_live_reference(ref_bin)
     ne, L, npatch, dt, nsteps = 4, 40, 24, 0.5, 3
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "ref.tmxd")
@@ -1589,8 +1585,7 @@ def test_held_suarez_L60_24_patches_vs_live_reference():
     import tmxd
     from tempestmodel_amd.engine import Engine
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/tmx_ref_dump_lapack2 not built (needs /root/reference)")
+    gu.need_live_reference(ref_bin)
     ne, L, dt, npatch = 16, 60, 200.0, 24
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "ref.tmxd")
@@ -1790,8 +1785,7 @@ def test_nofma_flavour_vs_live_mkl_reference():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mkl_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump")
     ob_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump_lapack2")
-    if not (os.path.exists(mkl_bin) and os.path.exists(ob_bin)):
-        pytest.skip("oracle/_ref did not travel with the snapshot (built in the build container from /root/reference)")
+    gu.need_live_reference(mkl_bin, ob_bin)
     if not os.path.exists(os.path.join(root, "tempestmodel_amd", "libtempest_mi355x_nofma.so")):
         pytest.fail("libtempest_mi355x_nofma.so is missing: build() makes it (make -C tempestmodel_amd/csrc nofma)")
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")

@@ -8,6 +8,7 @@
 # patches, and rank 0's patches must be identical, bit for bit.
 set -u
 cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 NMAX=${1:-8}
 PORT=${PORT:-29541}
@@ -15,7 +16,15 @@ run() {   # ranks, extra bench flags...
 	local n=$1; shift
 	python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $n "$@"
 }
-field() { python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print($1)"; }
+field() {   # prints the expression of the run's JSON line, or says that the run left none (failed / refused) instead of a traceback
+	python3 -c "
+import sys, json
+ls = [l for l in sys.stdin if l.startswith('{')]
+if not ls:
+    print('   (no JSON line: the run failed or was refused -- see its .err file)')
+else:
+    d = json.loads(ls[-1]); print($1)"
+}
 
 echo "== 0. device count (expect >= 2)"
 python3 -c "import torch; print(torch.cuda.device_count())"

@@ -47,8 +47,14 @@ for fe, wr, out, what, steps in (("fetch", "write", "ne30_L30_n1", "ne30 np4 L30
     a = os.path.join(G, "%s_%s" % (tag, fe), "%s_counter_collection.csv" % tag)
     b = os.path.join(G, "%s_%s" % (tag, wr), "%s_counter_collection.csv" % tag)
     if os.path.exists(a) and os.path.exists(b):
-        subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_table.py"), a, b, str(steps),
-                        os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, out)), what], check=True, stdout=subprocess.DEVNULL)
+        dstj = os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, out))
+        subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_table.py"), a, b, str(steps), dstj, what], check=True, stdout=subprocess.DEVNULL)
+        # stamp the table with the hash of the kernel sources it was taken with (bench.py compares it with the tree it runs from);
+        # summarise right after the gpurun call, before the sources are edited again
+        sys.path.insert(0, R)
+        import bench as _bench
+        tabj = json.load(open(dstj)); tabj["csrc_sha16"] = os.environ.get("TMX_PROFILE_SHA") or _bench.csrc_sha16()
+        json.dump(tabj, open(dstj, "w"), indent=1)
 
 v = counters("valu")
 if v:
