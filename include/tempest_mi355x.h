@@ -404,7 +404,8 @@ enum {
 	TMX_INFO_PARTIAL_SLOTS,       /* seam-node copies that go through the partial slots (tile and patch edges)         */
 	TMX_INFO_UNIQUE_DSS_GROUPS,   /* node groups the DSS kernel of that layout finishes                               */
 	TMX_INFO_PREFIX_STAGES,       /* explicit stages so far whose combination started from a partial sum an earlier stage stored */
-	TMX_INFO_EXPERIMENTS_BUILD    /* 1: the experiments flavour of the library (archived experiments and cross-check kernels compiled in) */
+	TMX_INFO_EXPERIMENTS_BUILD,   /* 1: the experiments flavour of the library (archived experiments and cross-check kernels compiled in) */
+	TMX_INFO_MIXED_STEPS          /* steps so far whose explicit stages read an element-major instance copy by copy beside node-unique ones ("unique_mixed") */
 };
 long long tmx_info(tmx_engine * e, int what);
 
@@ -419,6 +420,12 @@ long long tmx_info(tmx_engine * e, int what);
  *   "unique_tile_shape"  elements of a wavefront: 0 = the element-major order, 1 x 4 strips along beta that wrap around patch rows
  *                        (default: measured fastest), 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row.  Before tmx_finalize.
  *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize.
+ *   "unique_mixed"       1 (default): an element-major instance a step reads before overwriting it -- a freshly uploaded state, or the model state
+ *                        behind an operation the reference applies per copy with per-copy inputs (Held-Suarez forcing: HeldSuarezPhysics.cpp:60-301
+ *                        evaluates every copy of a seam node with that copy's own latitude, which differs in the last bit) -- is read that
+ *                        way, copy by copy, by the explicit stages, and the step still runs on the node-unique layout (bit-identical: the
+ *                        stages compute per copy and average as before).  0: the round-4 rule (check that the copies agree, convert, or run
+ *                        the whole step element-major).
  *   "contraction_mfma"   1: the 4 x 4 contractions of the fused explicit kernel as v_mfma_f64_4x4x4 -- NOT bit-exact (1e-15 per call,
  *                        W 1.5e-10 after 100 steps at ne15 L30: outside the 1e-10 gate) and measured no faster.  Before tmx_finalize.
  *   "vt_explicit_walk", "vx_walk", "vite_walk"   fully explicit vertical mode: the tracer column update, V.StepExplicit's U,V update and the explicitly
@@ -466,6 +473,9 @@ int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out,
 /* Does the stepper program of a scheme have a node-unique form?  Returns the number of units the node-unique interpreter runs it in
  * (a unit = the operations it fuses into one stage / solve / pass), 0 if some operation has none, -1 for an unknown scheme.  No device. */
 int tmx_debug_program_unique(int scheme, int first_step, int last_step);
+/* Host logic of "unique_mixed": 1 if only the explicit stages of the scheme's program read data instance `instance` before the program overwrites
+ * it (so that it may stay element-major, read copy by copy, while the step runs on the node-unique layout), 0 if not, -1 unknown scheme. */
+int tmx_debug_program_mixed(int scheme, int first_step, int last_step, int instance);
 /* Host logic for the CPU tests: the explicit stages of a scheme's program that can start from a partial sum an earlier stage
  * stores (node-unique layout, option "unique_prefix").  Returns their number; pairs[2 k], pairs[2 k + 1] (k < cap): operation
  * index of the producing and of the consuming stage; terms[k]: source instances the consuming stage no longer reads. */

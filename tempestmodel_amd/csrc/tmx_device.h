@@ -41,7 +41,10 @@
 
 // Linear combination of state instances in the reference's accumulation order
 // (GridPatch::LinearCombineData, src/atm/GridPatch.cpp:1436-1508): v = c_d * X_d (or 0), then += c_m * X_m.
-struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; };
+// dmask (node-unique kernels instantiated with DM only): bit m set = term m is an ELEMENT-MAJOR instance whose copies of a node may differ
+// (the model state behind a per-copy operation such as the Held-Suarez forcing): the thread reads its own copy, slab stride NS, the
+// thread's own column; bit 31: the same for the stage's initial instance.  The kernels' results are node-unique either way.
+struct LinTerms { const double * src[12]; double coef[12]; int n; int premul; unsigned dmask; };
 // Where the U,V slabs of the instances named by a LinTerms (and of the stage's initial instance) live: the instance's own slot,
 // or the slot of the instance it was copied from when the stepper left the CopyData of U,V out (tmx_step.hip: the implicit
 // column solve rewrites rho*theta, W, rho of the copy but leaves U,V identical to the source's)
@@ -143,6 +146,20 @@ __device__ __forceinline__ double base_value_uv(const LinTerms & t, const UvTerm
 	double x[NT > 0 ? NT : 1];
 #pragma unroll
 	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(uv.src[m] + slab_off, colb) : 0.0;
+	double v = t.premul ? x[0] * t.coef[0] : 0.0;
+#pragma unroll
+	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
+	return v;
+}
+
+// base_value_u / base_value_uv where some terms are element-major instances (LinTerms::dmask): slab index given, stride and lane offset per term
+template <int NT>
+__device__ __forceinline__ double base_value_dm(const LinTerms & t, const double * const (&src)[12], int slab, size_t SS, size_t NS, unsigned cb, unsigned gb) {
+	auto ld = [&](int m) -> double { const bool d = (t.dmask >> m) & 1u; return ldu(src[m] + (size_t)slab * (d ? NS : SS), d ? gb : cb); };
+	if (NT == 0) return ld(0);
+	double x[NT > 0 ? NT : 1];
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ld(m) : 0.0;
 	double v = t.premul ? x[0] * t.coef[0] : 0.0;
 #pragma unroll
 	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];

@@ -1410,7 +1410,7 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 struct OptionDef { const char * name; const char * env; int kind; const char * help; };
 static int * option_slot(tmx_engine * e, const std::string & n) {
 #define OPT(NAME_, FIELD_) if (n == NAME_) return &(FIELD_)
-	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_prefix", e->u.prefix_option);
+	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_mixed", e->u.mixed_option); OPT("unique_prefix", e->u.prefix_option);
 	OPT("share_copies", e->share_copies); OPT("xcd_vertical", e->xcd_vertical);
 	OPT("vi_carry", e->vi_carry); OPT("vi_pair", e->vi_pair); OPT("vi_group", e->vi_group); OPT("vi_group_max", e->vi_group_max);
 	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
@@ -1429,6 +1429,7 @@ static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
 	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
+	{ "unique_mixed", "TMX_UNIQUE_MIXED", 0, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
 	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
 	{ "xcd_vertical", "TMX_XCD_VERTICAL", 0, "1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
@@ -1497,7 +1498,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;
@@ -1569,6 +1570,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_UNIQUE_DSS_GROUPS: return e->u.built ? e->u.ngroups : 0;
 		case TMX_INFO_PREFIX_STAGES: return e->u.prefix_stages;
 		case TMX_INFO_EXPERIMENTS_BUILD: return TMX_EXP;
+		case TMX_INFO_MIXED_STEPS: return e->u.mixed_steps;
 		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
 			int n = 0;
 			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;

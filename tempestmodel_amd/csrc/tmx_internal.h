@@ -133,6 +133,13 @@ struct UniqueLayout {
 	// that treats the copies of a node differently in the last bit, as the reference's does) the check itself -- a pass over the
 	// instance and a host synchronisation -- is not repeated every step: from the second failure in a row on, the next `skip_steps` steps do not try
 	int backoff = 0, skip_steps = 0;      // backoff: failures in a row
+	// Instances the running program reads in ELEMENT-MAJOR form, copy by copy, although everything it writes is node-unique: the model state
+	// behind an operation the reference applies per copy with per-copy inputs (Held-Suarez forcing: the copies of a seam node differ in the
+	// last bit afterwards), or a freshly uploaded state.  Only the explicit stages read such an instance (dlive_program_ok); the bit goes
+	// when the program overwrites the instance.  No consistency check, no host synchronisation, no conversion.
+	unsigned dlive = 0u;
+	int mixed_option = 1;                 // tmx_set_option("unique_mixed"): 0 = the old rule (check the copies, convert or run the step element-major)
+	long long mixed_steps = 0;            // steps that ran that way (tmx_info)
 	// column physics on the unique columns (Held-Suarez forcing): its per-column inputs (latitude, sin / cos of it, pinned surface
 	// pressure) per unique node, valid only if every copy of a node carries the same bits (checked on the device when they change)
 	bool physics_dirty = true, physics_ok = false;
@@ -321,7 +328,8 @@ void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu
 struct EmitTerms { double * xp; double coef[12]; int first; };
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
-	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr, const EmitTerms * emit = nullptr);
+	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr, const EmitTerms * emit = nullptr,
+	unsigned dmask = 0u);      // dmask: LinTerms::dmask (node-unique kernels: which sources are element-major instances read per copy)
 void tmxk_h_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [16 instantiations][7 phases + count], cleared by the read
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);

@@ -82,7 +82,9 @@ void tmxk_h_timing_read(unsigned long long * out) { for (int i = 0; i < 128; i++
 // PM: the update instance enters its own stage combination (LinTerms::premul), a compile-time parameter so that the loads of the
 // combination's raw terms carry no control flow (lin_load)
 // EM: also form and store the prefix of a later stage's combination from the loaded terms (EmitTerms, tmx_device.h)
-template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM, bool EM>
+// DM (with UQ): some sources are element-major instances whose copies of a node may differ (LinTerms::dmask) -- the stage reads them per
+// copy, as the element-major kernel does, and still averages and stores node-unique results
+template <bool FUSE_V, int NT, bool MF, bool UQ, bool PM, bool EM, bool DM = false>
 #ifndef TMX_H_MINWG
 #define TMX_H_MINWG 1      // ablation: minimum workgroups per CU the register allocation must allow (4 caps at 128 registers: slower, spills)
 #endif
@@ -129,14 +131,18 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 		const int km = (k > 0) ? k - 1 : 0, kp = (k < L - 1) ? k + 1 : L - 1;
 		const unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;      // byte offsets inside a state slab / a geometry slab
 		const double * __restrict__ xuv = uvt.xin;      // U,V of the initial instance (its own slot or the one it shares)
-		ua = ldu(xuv + TMX_SLAB_U(L, k) * SS, cb);
-		ub = ldu(xuv + TMX_SLAB_V(L, k) * SS, cb);
-		rt = ldu(xin + TMX_SLAB_T(L, k) * SS, cb);
-		rh = ldu(xin + TMX_SLAB_R(L, k) * SS, cb);
-		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * SS, cb);
-		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * SS, cb);
-		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * SS, cb), uap = ldu(xuv + TMX_SLAB_U(L, kp) * SS, cb);
-		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * SS, cb), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * SS, cb);
+		// (DM: the initial instance may be element-major -- the thread's own copy, slab stride NS)
+		const bool xd = DM && (xbase.dmask >> 31) != 0u;
+		const size_t SX = xd ? NS : SS;
+		const unsigned cx = xd ? gb : cb;
+		ua = ldu(xuv + TMX_SLAB_U(L, k) * SX, cx);
+		ub = ldu(xuv + TMX_SLAB_V(L, k) * SX, cx);
+		rt = ldu(xin + TMX_SLAB_T(L, k) * SX, cx);
+		rh = ldu(xin + TMX_SLAB_R(L, k) * SX, cx);
+		const double we0 = ldu(xin + TMX_SLAB_W(L, k) * SX, cx);
+		const double we1 = ldu(xin + TMX_SLAB_W(L, k + 1) * SX, cx);
+		const double uam = ldu(xuv + TMX_SLAB_U(L, km) * SX, cx), uap = ldu(xuv + TMX_SLAB_U(L, kp) * SX, cx);
+		const double ubm = ldu(xuv + TMX_SLAB_V(L, km) * SX, cx), ubp = ldu(xuv + TMX_SLAB_V(L, kp) * SX, cx);
 		// raw terms of the base of U,V (issued with the state, before anything is waited for; reduced below); those of
 		// rho*theta, rho and W follow behind the barrier, when the registers of the prologue are free again, and arrive
 		// while the contractions run -- all of them in one burst take the kernel from three resident wavefronts per SIMD to two
@@ -150,6 +156,10 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 			bT = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_T(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, pf);
 			bR = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_R(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, pf);
 			if (TMX_H_FUSE_W && ty > 0) { bW = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, cb, pf); stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, pf); }
+		} else if (DM) {
+			bU = base_value_dm<NT>(xbase, uvt.src, TMX_SLAB_U(L, k), SS, NS, cb, gb); bV = base_value_dm<NT>(xbase, uvt.src, TMX_SLAB_V(L, k), SS, NS, cb, gb);
+			bT = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_T(L, k), SS, NS, cb, gb); bR = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_R(L, k), SS, NS, cb, gb);
+			if (TMX_H_FUSE_W && ty > 0) bW = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, k), SS, NS, cb, gb);
 		} else {
 			bU = base_value_uv<NT>(xbase, uvt, TMX_SLAB_U(L, k) * SS, cb); bV = base_value_uv<NT>(xbase, uvt, TMX_SLAB_V(L, k) * SS, cb);
 			bT = base_value_u<NT>(xbase, TMX_SLAB_T(L, k) * SS, cb); bR = base_value_u<NT>(xbase, TMX_SLAB_R(L, k) * SS, cb);
@@ -369,6 +379,13 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 #endif
 		const bool withW = TMX_H_FUSE_W && ty > 0;
 		double pU = 0, pV = 0, pT = 0, pR = 0, pW = 0;
+		if (DM) {
+			unsigned gbl = (unsigned)col * 8u;
+			asm volatile("" : "+v"(gbl) : "v"(cb));
+			bU = base_value_dm<NT>(xbase, uvt.src, TMX_SLAB_U(L, k), SS, NS, cb, gbl); bV = base_value_dm<NT>(xbase, uvt.src, TMX_SLAB_V(L, k), SS, NS, cb, gbl);
+			bT = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_T(L, k), SS, NS, cb, gbl); bR = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_R(L, k), SS, NS, cb, gbl);
+			if (withW) bW = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, k), SS, NS, cb, gbl);
+		} else {
 		bU = base_value_u2<NT, EM>(xbase, uvt.src, em, TMX_SLAB_U(L, k) * SS, cb, pU);
 		bV = base_value_u2<NT, EM>(xbase, uvt.src, em, TMX_SLAB_V(L, k) * SS, cb, pV);
 #if TMX_H_EM_GROUPS >= 2
@@ -381,6 +398,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 #endif
 		bR = base_value_u2<NT, EM>(xbase, xbase.src, em, TMX_SLAB_R(L, k) * SS, cb, pR);
 		if (withW) bW = base_value_u2<NT, EM>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, cb, pW);
+		}
 		if (EM) {
 			stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, pU); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, pV);
 			stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, pT); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, pR);
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(64 * KT_H, TMX_H_MINWG) void k_h_explicit(KParams p
 // boundary from the UPDATED U,V extrapolated to the surface, interior += dt * interp((u x zeta)_xi).
 // stride > 1: only the interfaces k = 0, stride, 2 stride, ... (the first of every level tile of k_h_explicit, which has done
 // the others) and the top one
-template <int NT, bool UQ, bool EM>
+template <int NT, bool UQ, bool EM, bool DM = false>
 __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, double * xup,
 	const double * __restrict__ ucz, const double * __restrict__ uv01, double dt, int stride, EmitTerms em)
 {
@@ -440,6 +458,8 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 			xup[TMX_SLAB_W(L, L) * SS + uc] = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, L) * SS, (unsigned)uc * 8u, pf);
 			em.xp[TMX_SLAB_W(L, L) * SS + uc] = pf;
 		} else
+		if (DM) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, L), SS, NS, (unsigned)uc * 8u, (unsigned)col * 8u);
+		else
 		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * SS + uc);
 		return;
 	}
@@ -466,7 +486,9 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 			double pf = 0.0;
 			wnew = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, k) * SS, (unsigned)uc * 8u, pf) + dt * v;
 			em.xp[TMX_SLAB_W(L, k) * SS + uc] = pf;
-		} else
+		} else if (DM)
+			wnew = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, k), SS, NS, (unsigned)uc * 8u, (unsigned)col * 8u) + dt * v;
+		else
 		wnew = base_value<NT>(xbase, TMX_SLAB_W(L, k) * SS + uc) + dt * v;
 	}
 	if (UQ) {
@@ -481,11 +503,11 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 // live when that is not the instance's own slot (NULL: the same pointers)
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv,
-	const EmitTerms * emit) {
+	const EmitTerms * emit, unsigned dmask) {
 	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
 	LinTerms xbase;
 	UvTerms uvt;
-	xbase.n = nterms; xbase.premul = premul;
+	xbase.n = nterms; xbase.premul = premul; xbase.dmask = dmask;
 	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
 	uvt.xin = xin_uv ? xin_uv : xin; uvt.src[0] = xbase_uv ? xbase_uv : xbase_ptr;
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
@@ -506,6 +528,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	const EmitTerms em = emit_ok ? *emit : em0;
 #define LAUNCH_HV2(NT_, PM_) do { \
 		if (TMX_EXP && uq && fuse_v && emit_ok && NT_ >= 3 && NT_ <= 8 && !PM_) hipLaunchKernelGGL((k_h_explicit<true, (NT_ >= 3 && NT_ <= 8) ? NT_ : 3, false, true, false, TMX_EXP != 0>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em); \
+		else if (uq && fuse_v && dmask) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
 		else if (uq && fuse_v) hipLaunchKernelGGL((k_h_explicit<true, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
 		else if (uq) hipLaunchKernelGGL((k_h_explicit<false, NT_, false, true, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
 		else if (fuse_v && e->use_mfma) hipLaunchKernelGGL((k_h_explicit<true, NT_, true, false, PM_, false>), grd, blk, 0, e->stream, p, xin, xbase, xup, e->d_scratch, uv01, dt, uvt, em0); \
@@ -514,6 +537,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 #define LAUNCH_HV(NT_) do { \
 		if (NT_ == 0 || premul) LAUNCH_HV2(NT_, true); else LAUNCH_HV2(NT_, false); \
 		if (TMX_EXP && uq && emit_ok && NT_ >= 3 && NT_ <= 8) hipLaunchKernelGGL((k_h_w_update<(NT_ >= 3 && NT_ <= 8) ? NT_ : 3, true, TMX_EXP != 0>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em); \
+		else if (uq && dmask) hipLaunchKernelGGL((k_h_w_update<NT_, true, false, true>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); \
 		else if (uq) hipLaunchKernelGGL((k_h_w_update<NT_, true, false>), grd2, blk2, 0, e->stream, q, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); \
 		else hipLaunchKernelGGL((k_h_w_update<NT_, false, false>), grd2, blk2, 0, e->stream, p, xbase, xup, (const double *)e->d_scratch, uvp, dt, wstride, em0); } while (0)
 	switch (nterms) {

@@ -1540,17 +1540,25 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	const double * src[12]; double cf[12]; int premul = 0, n = 0;
 	const double * srcuv[12];
 	double * const prefix = e->u.d_ustate + (size_t)e->u.uprefix * e->u.ustride;
+	// instances read in element-major form, copy by copy (UniqueLayout::dlive): their pointers are the element-major slots', the kernels get a mask
+	auto dl = [&](int k) -> bool { return (e->u.dlive >> k & 1u) != 0u; };
+	unsigned dmask = 0u;
 	if (lc) {
 		premul = (lc[iupd] != 0.0) ? 1 : 0;
-		n = 1; src[0] = uinst(e, iupd); srcuv[0] = uinst_uv(e, iupd); cf[0] = lc[iupd];
+		n = 1; src[0] = dl(iupd) ? inst(e, iupd) : uinst(e, iupd); srcuv[0] = dl(iupd) ? inst_uv(e, iupd) : uinst_uv(e, iupd); cf[0] = lc[iupd];
+		if (dl(iupd)) dmask |= 1u;
 		if (held) { src[0] = srcuv[0] = prefix; cf[0] = 1.0; premul = 1; e->u.prefix_stages++; }      // (times one: exact)
 		for (int m = 0; m < nlc; m++) {
 			if (m == iupd || lc[m] == 0.0 || (held >> m & 1u)) continue;
 			REQUIRE(n < 12, TMX_ERR_UNSUPPORTED, "linear combination with more than 11 source terms");
-			src[n] = uinst(e, m); srcuv[n] = uinst_uv(e, m); cf[n] = lc[m]; n++;
+			src[n] = dl(m) ? inst(e, m) : uinst(e, m); srcuv[n] = dl(m) ? inst_uv(e, m) : uinst_uv(e, m); cf[n] = lc[m];
+			if (dl(m)) dmask |= 1u << n;
+			n++;
 		}
-	}
-	const double * xin_uv = uinst_uv(e, iinit), * base_uv = uinst_uv(e, ibase);      // (taken before the update instance changes slots)
+	} else if (dl(ibase)) dmask |= 1u;
+	if (dl(iinit)) dmask |= 1u << 31;
+	REQUIRE(!(held && dmask), TMX_ERR_UNSUPPORTED, "internal: stored prefix with element-major sources");
+	const double * xin_uv = dl(iinit) ? inst_uv(e, iinit) : uinst_uv(e, iinit), * base_uv = dl(ibase) ? inst_uv(e, ibase) : uinst_uv(e, ibase);      // (taken before the update instance changes slots)
 	// the update instance is also read (in-place accumulation, or its own coefficient in the combination is not zero): the
 	// element-major kernels read and write a thread's own column, here other elements' threads read the node too -- write the
 	// spare slot and let it become the instance's
@@ -1562,17 +1570,18 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	}
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	double * out = aliased ? uspare(e) : uinst(e, iupd);
-	const double * base = lc ? nullptr : uinst(e, ibase), * xin = uinst(e, iinit);
+	const double * base = lc ? nullptr : (dl(ibase) ? inst(e, ibase) : uinst(e, ibase)), * xin = dl(iinit) ? inst(e, iinit) : uinst(e, iinit);
 	EmitTerms em; em.xp = nullptr; em.first = -1;
-	if (emit && lc && !premul && n >= 3 && n <= 8) { em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m]; }
+	if (emit && lc && !premul && n >= 3 && n <= 8 && !dmask) { em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m]; }
 	// the stage writes every slab of the update instance: its U,V slabs are its own from here on (what it shared is read through
 	// the pointers taken above), and whoever shared ITS slabs is dead
 	if (e->uvmap[iupd] != iupd) { e->uvmap[iupd] = iupd; e->n_uvshared--; }
 	if (aliased) u_adopt_spare(e, iupd);      // (src[], base and the U,V pointers were taken before: they still name the old slots)
 	int r = u_produce_and_average(e, iupd, TMX_K_H_EXPLICIT, [&](const KParams & p) {
-		if (n > 0) tmxk_h_explicit(e, p, xin, out, out, dt, 1, n, src, cf, premul, xin_uv, nullptr, srcuv, em.xp ? &em : nullptr);
-		else tmxk_h_explicit(e, p, xin, base, out, dt, 1, 0, nullptr, nullptr, 0, xin_uv, base_uv, nullptr);
+		if (n > 0) tmxk_h_explicit(e, p, xin, out, out, dt, 1, n, src, cf, premul, xin_uv, nullptr, srcuv, em.xp ? &em : nullptr, dmask);
+		else tmxk_h_explicit(e, p, xin, base, out, dt, 1, 0, nullptr, nullptr, 0, xin_uv, base_uv, nullptr, nullptr, dmask);
 	});
+	e->u.dlive &= ~(1u << iupd);      // the instance is node-unique from here on
 	u_written(e, iupd);
 	if (r) return r;
 	if (lc) {
@@ -1592,6 +1601,7 @@ static int u_copy(tmx_engine * e, int a, int b, size_t doubles) {
 		ProfScope ps(e, TMX_K_LINCOMB);
 		HIPCHK(hipMemcpyAsync(uinst(e, b), uinst(e, a), doubles * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
 	}
+	if (doubles == e->u.ustride) e->u.dlive &= ~(1u << b);
 	u_written(e, b);
 	return surface_copy(e, a, b);
 }
@@ -1653,7 +1663,7 @@ static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
 	// the passes read their source through one pointer and rewrite update and (two passes) working instance entirely
 	if ((r = u_own_uv(e, iinit)) || (r = u_own_uv(e, iupd, true))) return r;
 	if (c.hypervis_order != 2 && (r = u_own_uv(e, iwork, true))) return r;
-	struct Written { tmx_engine * e; int a, b; ~Written() { u_written(e, a); if (b >= 0) u_written(e, b); } } written = { e, iupd, c.hypervis_order != 2 ? iwork : -1 };
+	struct Written { tmx_engine * e; int a, b; ~Written() { e->u.dlive &= ~(1u << a); u_written(e, a); if (b >= 0) { e->u.dlive &= ~(1u << b); u_written(e, b); } } } written = { e, iupd, c.hypervis_order != 2 ? iwork : -1 };
 	if (c.hypervis_order == 2) {
 		if ((r = surface_copy(e, iinit, iupd))) return r;
 		return u_produce_and_average(e, iupd, TMX_K_HYPERVIS, [&](const KParams & p) {
@@ -1714,6 +1724,7 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 				}
 				const int premul = o.lc[o.a] != 0.0 ? 1 : 0;
 				{ ProfScope ps(e, TMX_K_LINCOMB); tmxk_lincomb(e, e->u.ustride, uinst(e, o.a), n, src, cf, premul); }
+				e->u.dlive &= ~(1u << o.a);
 				u_written(e, o.a);
 				if ((r = surface_lincomb(e, o.a, n, dsrc, cf, premul)) || (r = launch_check("lincomb"))) return r;
 			}
@@ -1729,6 +1740,33 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 		i += k;
 	}
 	return TMX_OK;
+}
+
+// May the program read the instances of `dlive` in element-major form, copy by copy?  Only the explicit stages can (their kernels take a
+// source mask); every other operation must find the instance overwritten -- node-unique -- by the time it reads it.
+static bool dlive_program_ok(const Program & p, unsigned dlive) {
+	for (size_t i = 0; i < p.size() && dlive; ) {
+		const int k = unique_unit(p, i);
+		if (!k) return false;
+		const Op & o = p[i];
+		const bool stage = ((o.kind == OP_COPY || o.kind == OP_LINCOMB) && k == 4) || (o.kind == OP_HEXP && k == 3);
+		unsigned wr = 0u;
+		for (int j = 0; j < k; j++) {
+			const OpAccess x = op_access(p[i + j], false);
+			if (!stage && ((x.reads | x.part) & dlive)) return false;
+			wr |= x.full | x.part;
+		}
+		dlive &= ~wr;
+		i += k;
+	}
+	return true;
+}
+// Host logic for the CPU tests: can the scheme's program read instance `instance` copy by copy (1), or not (0)?  -1: unknown scheme
+extern "C" int tmx_debug_program_mixed(int scheme, int first_step, int last_step, int instance) {
+	Program p;
+	if (build_program(scheme, first_step, last_step, 1.0, p, 0.0)) return -1;
+	g_hvis_two_pass = true;
+	return (program_fits_unique(p) && dlive_program_ok(p, 1u << instance)) ? 1 : 0;
 }
 
 // Entry of tmx_step: bring the instances the program reads before it overwrites them into the node-unique form (checking, for
@@ -1749,13 +1787,22 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 		written |= x.full | x.part;
 	}
 	bool need_check = false;
-	for (int k = 0; k < e->cfg.n_instances; k++) if ((livein >> k & 1u) && !u.form[k]) need_check = true;
+	unsigned dform = 0u;
+	for (int k = 0; k < e->cfg.n_instances; k++) if ((livein >> k & 1u) && !u.form[k]) { need_check = true; dform |= 1u << k; }
+	// Round 5: live-in instances in element-major form are READ that way, copy by copy, by the explicit stages (no check of the copies, no
+	// host synchronisation, no conversion; exact whether the copies agree or not) wherever the program lets only its stages read them
+	u.dlive = 0u;
+	if (dform && u.mixed_option && u.tile_shape == 0 && !(TMX_EXP && u.prefix_option) && dlive_program_ok(p, dform)) {
+		for (int k = 0; k < e->cfg.n_instances; k++)
+			if ((dform >> k & 1u) && (e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k, false))) return r;
+		u.dlive = dform; need_check = false; u.mixed_steps++;
+	}
 	if (need_check && u.skip_steps > 0) { u.skip_steps--; return TMX_OK; }      // the last checks failed: not every step pays for another one
 	// (timing aid TMX_DEBUG_SKIP_EXCHANGE: the state of such a run is garbage at the rank boundary, NaN payloads included; no check)
 	const bool trust = TMX_EXP && e->opt_skip_exchange != 0;
 	// the check comes first and works on the slots as the element-major programs left them (shared slots included: an instance
 	// that shares is given its own first, which for the model state never happens), so that a step that stays element-major keeps them
-	for (int k = 0; k < e->cfg.n_instances && !trust; k++) {
+	for (int k = 0; k < e->cfg.n_instances && !trust && !u.dlive; k++) {
 		if (!(livein >> k & 1u) || u.form[k]) continue;
 		if ((e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k, false))) return r;
 		bool ok = true;
@@ -1771,13 +1818,14 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	// instance maps to identity (shares left by an element-major program, that is: nothing is in U form; U,V slabs shared by the last node-unique step stay shared)
 	if ((e->n_shared || e->n_uvshared) && u.n_uform == 0) { if ((r = settle_instance(e, -1, false))) return r; }
 	for (int k = 0; k < e->cfg.n_instances; k++)
-		if ((livein >> k & 1u) && !u.form[k] && (r = tmxu_to_u(e, k, false, nullptr))) return r;
+		if ((livein >> k & 1u) && !u.form[k] && !(u.dlive >> k & 1u) && (r = tmxu_to_u(e, k, false, nullptr))) return r;
 	// everything the program writes is in U form afterwards; whatever else it leaves alone keeps its form
 	for (int k = 0; k < e->cfg.n_instances; k++)
 		if (written >> k & 1u) { if (!u.form[k]) u.n_uform++; u.form[k] = 1; }      // (form 2 -> 1: the element-major copy goes stale)
 	e->in_program = true;
 	r = run_program_unique(e, p);
 	e->in_program = false;
+	u.dlive = 0u;
 	*done = true;
 	return r;
 }

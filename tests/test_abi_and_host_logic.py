@@ -370,6 +370,21 @@ def test_every_stepper_program_has_a_node_unique_form():
     assert lib.tmx_debug_program_unique(99, 0, 0) == -1
 
 
+def test_which_programs_may_read_the_model_state_copy_by_copy():
+    """Host logic of "unique_mixed" (no device): a live-in element-major instance may be read copy by copy while the step runs on the
+    node-unique layout iff only explicit stages read it before the program overwrites it.  ARS343 / ARS222 / ARK232 start with an explicit
+    stage of the model state and combine it into the later ones; ARS232 / ARS443 and the Strang family start with a column solve or a
+    whole-instance pass of instance 0 and keep the round-4 rule (check, convert or run element-major)."""
+    from tempestmodel_amd import engine as eng
+    lib = eng.load_library()
+    can = {"ars343": 1, "ars232": 0, "ars222": 1, "ars443": 0, "ark232": 1, "strang": 0, "strang_fe": 0, "strang_rk4": 0, "strang_ssp3": 0, "strang_ssprk53": 0}
+    for name, sid in eng.Engine.SCHEMES.items():
+        for first in (0, 1):
+            for last in (0, 1):
+                assert lib.tmx_debug_program_mixed(sid, first, last, 0) == can[name], (name, first, last)
+    assert lib.tmx_debug_program_mixed(99, 0, 0, 0) == -1
+
+
 def test_stage_combinations_that_start_from_a_stored_partial_sum():
     """Host logic (no device): which explicit stages of a program can start from the leading partial sum of their combination,
     stored by an earlier stage that reads the same instances.  ARS343: operation 12 (third stage, LinearCombine of instances 0..4)

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 INFO_GHOST, INFO_EARLY, INFO_LATE = 4, 7, 8
 INFO_UNIQUE_LAYOUT, INFO_UNIQUE_INSTANCES, INFO_UNIQUE_CONVERSIONS, INFO_PARTIAL_SLOTS, INFO_UNIQUE_GROUPS, INFO_PREFIX_STAGES = 12, 13, 14, 15, 16, 17
+INFO_MIXED_STEPS = 19
 
 
 def _same(a, b, patches):
@@ -224,6 +225,86 @@ def test_unique_layout_with_held_suarez_forcing(pinned_ps):
         assert u.info(INFO_UNIQUE_CONVERSIONS) > c0
         assert _same(u.download_state(0), d.download_state(0), range(6))
     finally:
+        d.close(); u.close()
+
+
+def _perturb_copies(arrs, rng):
+    """every stored value moved by -1, 0 or +1 ulp, independently: the copies of a seam node no longer agree"""
+    out = []
+    for a in arrs:
+        a = np.array(a, copy=True)
+        k = rng.integers(-1, 2, size=a.shape)
+        up, dn = np.nextafter(a, np.inf), np.nextafter(a, -np.inf)
+        out.append(np.where(k > 0, up, np.where(k < 0, dn, a)))
+    return tuple(out)
+
+
+@pytest.mark.parametrize("scheme,npatch", [("ars343", 6), ("ars343", 24), ("ars232", 6), ("ark232", 6), ("strang", 6)])
+def test_steps_from_a_state_whose_copies_differ_read_it_copy_by_copy(scheme, npatch):
+    """"unique_mixed": a live-in element-major instance whose copies of a seam node differ (here: every stored value moved by up to an ulp)
+    is read copy by copy by the explicit stages while everything the step writes is node-unique -- no check, no conversion.  Identical to the
+    element-major engine and to the round-4 rule (check, then the whole step element-major); schemes whose programs let another
+    operation read the instance (host logic: tmx_debug_program_mixed) fall back to that rule by themselves."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(5, 6, npatch)
+    rng = np.random.default_rng(5)
+    ni = max(7, Engine.scheme_instances(scheme))
+    d = Engine(g, n_instances=ni, options={"unique_layout": 0})
+    u = Engine(g, n_instances=ni, options={"unique_layout": 1})
+    o = Engine(g, n_instances=ni, options={"unique_layout": 1, "unique_mixed": 0})
+    try:
+        can = u.lib.tmx_debug_program_mixed(Engine.SCHEMES[scheme], 0, 0, 0) == 1
+        for e in (d, u, o):
+            e.upload_state(0, start)
+            e.step(scheme, 150.0, first=True); e.step(scheme, 150.0)
+        nsteps = 0
+        for k in range(3):
+            for e in (d, u, o):
+                e.sync()
+            cur = d.download_state(0)
+            bad = {p: _perturb_copies(cur[p], rng) for p in range(npatch)}
+            for e in (d, u, o):
+                e.upload_state(0, bad)
+                e.step(scheme, 150.0)
+            nsteps += 1
+            assert o.info(INFO_MIXED_STEPS) == 0
+            if can:
+                assert u.info(INFO_MIXED_STEPS) >= nsteps and u.info(INFO_UNIQUE_INSTANCES) > 0, "step %d did not run on the node-unique layout" % k
+        for e in (d, u, o):
+            e.sync()
+        for ix in range(ni):
+            a = d.download_state(ix)
+            assert _same(u.download_state(ix), a, range(npatch)), (scheme, "mixed", ix)
+            assert _same(o.download_state(ix), a, range(npatch)), (scheme, "old rule", ix)
+    finally:
+        d.close(); u.close(); o.close()
+
+
+def test_held_suarez_forcing_with_per_copy_latitudes_keeps_the_unique_layout():
+    """The reference evaluates the Held-Suarez forcing per stored copy with that copy's own latitude (HeldSuarezPhysics.cpp:60-301), and
+    its latitude array differs in the last bit between the copies of a third of the seam nodes: the forced state has no node-unique form.
+    Round 4 then ran every step element-major; now the next step's explicit stages read the forced instance copy by copy and the step stays
+    on the node-unique layout.  Five steps with forcing after each, per-copy latitudes everywhere: identical to the element-major engine."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(4, 8, 24)
+    rng = np.random.default_rng(11)
+    lat0 = [np.array(g.patches[p].lat, copy=True) for p in range(24)]
+    d = Engine(g, options={"unique_layout": 0}); u = Engine(g, options={"unique_layout": 1})
+    try:
+        for p in range(24):
+            g.patches[p].lat = _perturb_copies((lat0[p],), rng)[0]
+        for e in (d, u):
+            e.set_physics_inputs(None)
+            e.upload_state(0, start)
+            for _ in range(5):
+                e.step_ars343(100.0)
+                e.held_suarez(0, 100.0)
+            e.sync()
+        assert u.info(INFO_MIXED_STEPS) == 5
+        assert _same(u.download_state(0), d.download_state(0), range(24))
+    finally:
+        for p in range(24):
+            g.patches[p].lat = lat0[p]
         d.close(); u.close()
 
 
