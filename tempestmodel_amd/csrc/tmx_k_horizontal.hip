@@ -451,20 +451,23 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 	const int uc = UQ ? tile_ucol(p, tile, lane) : col;    // the node's entry in the state slabs (UQ: unique slabs, stride NSS)
 	const size_t SS = UQ ? (size_t)p.NSS : NS;
 	if (k > L || (UQ ? uc < 0 : col >= p.ncol)) return;
-	if (k == L) {      // the top interface is not touched by the H step; carry it over when base != out
-		// (UQ: the copies of a node all carry the base's value: every one of them may store it)
-		if (EM) {
-			double pf = 0.0;
-			xup[TMX_SLAB_W(L, L) * SS + uc] = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, L) * SS, (unsigned)uc * 8u, pf);
-			em.xp[TMX_SLAB_W(L, L) * SS + uc] = pf;
-		} else
-		if (DM) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, L), SS, NS, (unsigned)uc * 8u, (unsigned)col * 8u);
-		else
+	double wnew;
+	if (k == L && !UQ) {      // the top interface is not touched by the H step; carry it over when base != out
 		if (NT != 0 || xbase.src[0] != xup) xup[TMX_SLAB_W(L, L) * SS + uc] = base_value<NT>(xbase, TMX_SLAB_W(L, L) * SS + uc);
 		return;
 	}
-	double wnew;
-	if (k == 0) {
+	if (k == L) {
+		// UQ: the base's value goes through seam_store like every other result of the stage, so that the partial slots of the nodes on tile
+		// and patch edges hold it when the DSS kernel averages them (round 5: it used to be stored to the node directly, and the DSS then
+		// averaged whatever the slots of this slab held -- zeros, which is what W on the rigid lid always is; a state with W != 0 there
+		// would have been changed).  DM: the copies may carry different base values (element-major sources): the node gets their average.
+		if (DM) wnew = base_value_dm<NT>(xbase, xbase.src, TMX_SLAB_W(L, L), SS, NS, (unsigned)uc * 8u, (unsigned)col * 8u);
+		else if (EM) {
+			double pf = 0.0;
+			wnew = base_value_u2<NT, true>(xbase, xbase.src, em, TMX_SLAB_W(L, L) * SS, (unsigned)uc * 8u, pf);
+			em.xp[TMX_SLAB_W(L, L) * SS + uc] = pf;
+		} else wnew = base_value<NT>(xbase, TMX_SLAB_W(L, L) * SS + uc);
+	} else if (k == 0) {
 		double u0 = 0.0, v0 = 0.0;
 		// updated U,V of levels 0,1 as the H step left them (uv01 when V.StepExplicit was fused in)
 		const double * pu0 = uv01 ? uv01 + col : xup + TMX_SLAB_U(L, 0) * NS + col;

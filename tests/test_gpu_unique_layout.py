@@ -239,14 +239,14 @@ def _perturb_copies(arrs, rng):
     return tuple(out)
 
 
-@pytest.mark.parametrize("scheme,npatch", [("ars343", 6), ("ars343", 24), ("ars232", 6), ("ark232", 6), ("strang", 6)])
-def test_steps_from_a_state_whose_copies_differ_read_it_copy_by_copy(scheme, npatch):
+@pytest.mark.parametrize("scheme,ne,npatch", [("ars343", 5, 6), ("ars343", 6, 24), ("ars222", 5, 6), ("ars232", 5, 6), ("ark232", 5, 6), ("strang", 5, 6)])
+def test_steps_from_a_state_whose_copies_differ_read_it_copy_by_copy(scheme, ne, npatch):
     """"unique_mixed": a live-in element-major instance whose copies of a seam node differ (here: every stored value moved by up to an ulp)
     is read copy by copy by the explicit stages while everything the step writes is node-unique -- no check, no conversion.  Identical to the
     element-major engine and to the round-4 rule (check, then the whole step element-major); schemes whose programs let another
     operation read the instance (host logic: tmx_debug_program_mixed) fall back to that rule by themselves."""
     from tempestmodel_amd.engine import Engine
-    g, start = gu.make_grid(5, 6, npatch)
+    g, start = gu.make_grid(ne, 6, npatch)
     rng = np.random.default_rng(5)
     ni = max(7, Engine.scheme_instances(scheme))
     d = Engine(g, n_instances=ni, options={"unique_layout": 0})
