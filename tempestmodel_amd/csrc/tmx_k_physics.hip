@@ -15,24 +15,37 @@
 // Reference behaviour restated (file:line under the reference tree) is cited per kernel.
 #include "tmx_device.h"
 
-__global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restrict__ x, const double * __restrict__ surf, double dt, double gamma, double kappa, double pscal)
+// FROM_U: the instance comes in node-unique form (xs, slab stride NSS, node of a stored column = ucd[col]) and leaves element-major (x): every
+// stored copy is forced with its own inputs, rho and W -- which the forcing does not touch -- are copied across, so the conversion the
+// element-major route would need first is this kernel's own load
+template <bool FROM_U>
+__global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restrict__ x, const double * __restrict__ surf, double dt, double gamma, double kappa, double pscal,
+	const double * __restrict__ xs, size_t NSS, const int * __restrict__ ucd)
 {
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	const int col = blockIdx.x * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
-	if (k >= L || col >= p.ncol) return;
+	if (k > (FROM_U ? L : L - 1) || col >= p.ncol) return;
 	const unsigned cb = (unsigned)col * 8u;
+	const unsigned sb = FROM_U ? (unsigned)ucd[col] * 8u : cb;      // where this copy's values come from
+	const double * __restrict__ xr = FROM_U ? xs : x;
+	const size_t SR = FROM_U ? NSS : NS;
+	if (FROM_U) {
+		stu(x + TMX_SLAB_W(L, k) * NS, cb, ldu(xr + TMX_SLAB_W(L, k) * SR, sb));
+		if (k == L) return;
+	}
 	const double bsig = 0.7, kf = 1.0 / 86400.0, ka = (1.0 / 40.0) / 86400.0, ks = (1.0 / 4.0) / 86400.0;
 	const double dty = 60.0, dthz = 10.0, tmin = 200.0, tmax = 315.0;
 	const double ps = surf ? pscal * tmx_ref_exp(tmx_ref_log(ldu(surf, cb) * ldu(surf + NS, cb)) * gamma) : ldu(p.g2d + G2_PS * NS, cb);
-	const double rho = ldu(x + TMX_SLAB_R(L, k) * NS, cb), rt = ldu(x + TMX_SLAB_T(L, k) * NS, cb);
+	const double rho = ldu(xr + TMX_SLAB_R(L, k) * SR, sb), rt = ldu(xr + TMX_SLAB_T(L, k) * SR, sb);
+	if (FROM_U) stu(x + TMX_SLAB_R(L, k) * NS, cb, rho);
 	{
 		const double pr = pscal * tmx_ref_exp(tmx_ref_log(rho * rt) * gamma);
 		const double sigma = pr / ps;
 		double bs = (sigma - bsig) / (1.0 - bsig);
 		if (bs < 0.0) bs = 0.0;
-		const double u = ldu(x + TMX_SLAB_U(L, k) * NS, cb), v = ldu(x + TMX_SLAB_V(L, k) * NS, cb);
+		const double u = ldu(xr + TMX_SLAB_U(L, k) * SR, sb), v = ldu(xr + TMX_SLAB_V(L, k) * SR, sb);
 		stu(x + TMX_SLAB_U(L, k) * NS, cb, u / (1.0 + kf * bs * dt));
 		stu(x + TMX_SLAB_V(L, k) * NS, cb, v / (1.0 + kf * bs * dt));
 	}
@@ -52,12 +65,14 @@ __global__ __launch_bounds__(256) void k_held_suarez(KParams p, double * __restr
 	stu(x + TMX_SLAB_T(L, k) * NS, cb, rt * (1.0 + dt / (1.0 - dt * ddh) * dh));
 }
 
-void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt) {
+// xs != null: the instance is read from its node-unique form (stride NSS, ucd = node of every stored column) and written element-major to x
+void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt, const double * xs, size_t NSS, const int * ucd) {
 	// PhysicalConstants::GetGamma / GetKappa / pressure scaling (src/atm/PhysicalConstants.h:355-376), host libm as in the reference
 	const double gamma = p.cp / (p.cp - p.Rd), kappa = p.Rd / p.cp;
 	const double pscal = p.p0 * pow(p.Rd / p.p0, gamma);
-	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 3) / 4);
-	hipLaunchKernelGGL(k_held_suarez, grd, blk, 0, e->stream, p, x, surf, dt, gamma, kappa, pscal);
+	dim3 blk(64, 4);
+	if (xs) hipLaunchKernelGGL(k_held_suarez<true>, dim3(p.NS / 64, (p.L + 1 + 3) / 4), blk, 0, e->stream, p, x, surf, dt, gamma, kappa, pscal, xs, NSS, ucd);
+	else hipLaunchKernelGGL(k_held_suarez<false>, dim3(p.NS / 64, (p.L + 3) / 4), blk, 0, e->stream, p, x, surf, dt, gamma, kappa, pscal, (const double *)nullptr, (size_t)0, (const int *)nullptr);
 }
 
 // Column physics: KesslerPhysics::Perform (test/dcmip2016/KesslerPhysics.cpp:83-285) around SUBROUTINE KESSLER

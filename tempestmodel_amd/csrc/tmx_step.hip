@@ -1898,6 +1898,26 @@ static int held_suarez_unique(tmx_engine * e, int instance, double dt, bool * do
 extern "C" int tmx_physics_held_suarez(tmx_engine * e, int instance, double dt) {
 	int r; if ((r = check_ready(e))) return r;
 	if (e->u.built && !e->sw) { bool done = false; if ((r = held_suarez_unique(e, instance, dt, &done)) || done) return r; }
+	// The instance is node-unique but the forcing's inputs differ between the copies of a node (the reference's own latitude array does):
+	// every stored copy is forced with its own inputs straight from the node-unique slabs -- the kernel's load is the conversion -- and the
+	// instance is element-major afterwards; the next step's explicit stages read it copy by copy ("unique_mixed")
+	{
+		UniqueLayout & u = e->u;
+		bool all_set = true;
+		for (int lp : e->local_patches) all_set = all_set && e->patches[lp].physics_set;
+		if (u.built && !e->sw && all_set && instance >= 0 && instance < e->cfg.n_instances && u.form[instance] == 1 && e->imap[instance] == instance && u.mixed_option) {
+			bool shared = false;
+			for (int b = 0; b < (int)e->imap.size(); b++) if (b != instance && (e->imap[b] == instance || e->uvmap[b] == instance)) shared = true;
+			if (!shared) {
+				if ((r = u_own_uv(e, instance))) return r;
+				ProfScope ps(e, TMX_K_LINCOMB);
+				tmxk_held_suarez(e, make_params(e), inst(e, instance), e->track_surface ? surface_slots(e, instance) : nullptr, dt,
+					uinst(e, instance), (size_t)u.NUS, (const int *)u.d_ucol_of_dcol);
+				u.form[instance] = 0; u.n_uform--; u.conversions++;
+				return launch_check("physics_held_suarez (node-unique in, element-major out)");
+			}
+		}
+	}
 	if ((r = check_inst(e, instance))) return r;
 	REQUIRE(!e->sw, TMX_ERR_UNSUPPORTED, "Held-Suarez physics with the shallow-water equation set is not supported");
 	for (int lp : e->local_patches)

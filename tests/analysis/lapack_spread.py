@@ -8,7 +8,7 @@ spread two *valid builds of the reference itself* show, which is the floor of an
 
 Writes tests/golden/lapack_spread.json (end-state checksums of both binaries + the spread + the C oracle's distance
 to both, the oracle running on the reference's own geometry and operators: `--geom 1`), which tests/test_oracle_vs_reference.py::test_w_gate_tolerance_follows_reference_spread and
-tests/test_gpu_parity.py read to set the W tolerance.
+the tests/test_gpu_*.py parity files read to set the W tolerance.
 
 usage: python tests/analysis/lapack_spread.py [--cases ne4,ne15]
 """

@@ -228,6 +228,46 @@ def test_unique_layout_with_held_suarez_forcing(pinned_ps):
         d.close(); u.close()
 
 
+@pytest.mark.parametrize("scheme,mixed", [("strang", 1), ("ars343", 0), ("ars343", 1)])
+def test_ranks_may_run_one_step_through_different_interpreters(scheme, mixed):
+    """Every rank decides by itself whether a step runs node-unique or element-major (the check of its own live-in instances; with
+    "unique_mixed" the decision is structural for the schemes that allow it, data-dependent for the others).  Here only ONE rank's patches carry
+    seam copies that differ, so that rank takes another route through the step than its neighbours: both interpreters issue the same
+    exchanges with the same wire content, and the ranks' results are those of one element-major engine."""
+    from tempestmodel_amd.engine import Engine
+    from parity_common import _rank_engines_step
+    n_ranks = 3
+    g, start = gu.make_grid(12, 6, 24)
+    rng = np.random.default_rng(3)
+    ni = max(7, Engine.scheme_instances(scheme))
+    single = Engine(g, n_instances=ni, options={"unique_layout": 0})
+    ranks = [Engine(g, rank=r, n_ranks=n_ranks, n_instances=ni, options={"unique_layout": 1, "unique_mixed": mixed}) for r in range(n_ranks)]
+    try:
+        single.upload_state(0, start)
+        for k in range(2):
+            single.step(scheme, 200.0, first=(k == 0))
+        single.sync()
+        cur = single.download_state(0)
+        odd = {p: (_perturb_copies(cur[p], rng) if p in ranks[1].local_patches else cur[p]) for p in range(24)}
+        single.upload_state(0, odd)
+        for k in range(2):
+            single.step(scheme, 200.0)
+        single.sync()
+        ref = single.download_state(0)
+        for e in ranks:
+            e.upload_state(0, odd)
+        Engine.loopback_group(ranks)
+        _rank_engines_step(ranks, lambda e, k: e.step(scheme, 200.0), 2)
+        Engine.loopback_dissolve(ranks[0])
+        assert all(e.info(INFO_UNIQUE_INSTANCES) > 0 for e in ranks)      # the second step ran node-unique everywhere
+        for e in ranks:
+            assert _same(e.download_state(0), ref, e.local_patches), e.rank
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()
+
+
 def _perturb_copies(arrs, rng):
     """every stored value moved by -1, 0 or +1 ulp, independently: the copies of a seam node no longer agree"""
     out = []

@@ -408,7 +408,7 @@ def test_lapack_spread_of_the_reference_is_zero():
     prognostic state), so 'which LAPACK' is not a source of spread -- both evaluate dgbtf2 / dgbtrs with fused
     multiply-adds, as the oracle and the device do.  The oracle's remaining distance to those runs is input synthesis
     (cubed_sphere.py vs the reference's grid objects), within the 1e-10 gate for every variable but W at ne15 L30,
-    which tests/test_gpu_parity.py::test_hundred_steps_ne15_L30 therefore runs on the reference's own inputs."""
+    which tests/test_gpu_live_reference.py::test_hundred_steps_ne15_L30 therefore runs on the reference's own inputs."""
     import json, os
     sp = json.load(open(os.path.join(gu.GOLDEN, "lapack_spread.json")))
     for case in ("ne4_L10_dt200", "ne15_L30_dt300"):
