@@ -72,6 +72,14 @@ struct UvTerms { const double * src[12]; const double * xin; };
 __device__ __forceinline__ double ldu(const double * uniform_base, unsigned lane_byte_off) {
 	return *(const double *)((const char *)uniform_base + lane_byte_off);
 }
+// the same with the non-temporal hint (TMX_H_TERMS_NT: the raw terms of a stage combination -- up to seven whole instances read once per stage)
+#ifndef TMX_H_TERMS_NT
+#define TMX_H_TERMS_NT 0
+#endif
+__device__ __forceinline__ double ldu_term(const double * uniform_base, unsigned lane_byte_off) {
+	if (TMX_H_TERMS_NT) return __builtin_nontemporal_load((const double *)((const char *)uniform_base + lane_byte_off));
+	return *(const double *)((const char *)uniform_base + lane_byte_off);
+}
 __device__ __forceinline__ void stu(double * uniform_base, unsigned lane_byte_off, double v) {
 	*(double *)((char *)uniform_base + lane_byte_off) = v;
 }
@@ -118,7 +126,7 @@ __device__ __forceinline__ double base_value_u2(const LinTerms & t, const double
 	if (NT == 0) return ldu(src[0] + slab_off, colb);
 	double x[NT > 0 ? NT : 1];
 #pragma unroll
-	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(src[m] + slab_off, colb) : 0.0;
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu_term(src[m] + slab_off, colb) : 0.0;
 	double v = t.premul ? x[0] * t.coef[0] : 0.0;
 #pragma unroll
 	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
@@ -132,7 +140,7 @@ __device__ __forceinline__ double base_value_u(const LinTerms & t, size_t slab_o
 	if (NT == 0) return ldu(t.src[0] + slab_off, colb);
 	double x[NT > 0 ? NT : 1];
 #pragma unroll
-	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(t.src[m] + slab_off, colb) : 0.0;
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu_term(t.src[m] + slab_off, colb) : 0.0;
 	double v = t.premul ? x[0] * t.coef[0] : 0.0;
 #pragma unroll
 	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];
@@ -145,7 +153,7 @@ __device__ __forceinline__ double base_value_uv(const LinTerms & t, const UvTerm
 	if (NT == 0) return ldu(uv.src[0] + slab_off, colb);
 	double x[NT > 0 ? NT : 1];
 #pragma unroll
-	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu(uv.src[m] + slab_off, colb) : 0.0;
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || t.premul) ? ldu_term(uv.src[m] + slab_off, colb) : 0.0;
 	double v = t.premul ? x[0] * t.coef[0] : 0.0;
 #pragma unroll
 	for (int m = 1; m < NT; m++) v += t.coef[m] * x[m];

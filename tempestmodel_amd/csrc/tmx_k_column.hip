@@ -1203,8 +1203,13 @@ __device__ __forceinline__ void ring_post(int * counter, int value, int lane) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wavefront's ring writes (producer) / ring reads (consumer) are done
 	if (lane == 0) *(volatile tmx_lds_int *)counter = value;
 }
-template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true>
-__global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
+// NPROD = 2 (with PAIRS = 1, closed-form metric; grids that leave SIMDs idle): TWO assembly wavefronts per elimination wavefront.  The block
+// rows of a column are independent of one another, so wavefront q in {0, 1} assembles the block rows t = q (mod 2) -- without the carry
+// between consecutive rows (compute_block<false>: the same statements on the same operands, one more Exner evaluation per row) -- into the
+// same ring, and the elimination wavefront takes the rows in order from whichever producer made them (one `produced` counter each).  The
+// forward phase of a column group then costs the elimination chain, not the longer assembly chain.
+template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true, int NPROD = 1>
+__global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw, unsigned long long * __restrict__ stats, int * __restrict__ gmask = nullptr,
 	int stagger = 0)
@@ -1214,7 +1219,9 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	const int L = p.L;
 	constexpr int MM = CLOSED ? 1 : 2;
 	constexpr int NQ = TMX_RING_NQ;                                          // doubles per block row and column in the ring (sparse: TMX_RSLOT)
-	constexpr int RD = TMX_RING_DEPTH;
+	constexpr int RD = (NPROD == 2) ? TMX_RING_DEPTH + 1 : TMX_RING_DEPTH;      // (two rows are being written at a time)
+	constexpr int NTHR = PAIRS * 64 * (1 + NPROD);
+	static_assert(NPROD == 1 || (NPROD == 2 && PAIRS == 1 && CLOSED), "two producers: one column group per workgroup, closed-form metric");
 	// Staggered start (stagger = window in units of 10 ns, 0 = off): workgroup i begins i / gridDim.x of the window late.  All
 	// workgroups are resident at once and would otherwise run in lock-step -- every wavefront in its issue- and latency-bound
 	// elimination first, then every wavefront in its HBM-bound back substitution; spread out, the back substitutions of the
@@ -1235,18 +1242,18 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	// for every other workgroup, so that two workgroups sharing a CU would put a producer and a consumer on every SIMD: column solve
 	// 0.500 / 0.486 against 0.480 ms per step.)
 #ifndef TMX_PAIR3_INTERLEAVED
-	const int role = (PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1), pair = (PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1);
+	const int role = (NPROD == 2) ? (wv == 2 ? 1 : 0) : ((PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1)), pair = (NPROD == 2) ? 0 : ((PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1));
 #else
 	const int role = wv & 1, pair = wv >> 1;
 #endif
 	double * ring = etal + 2 * L + 1 + (size_t)pair * RD * NQ * 64;          // [PAIRS][RD][NQ][64]
 	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * RD * NQ * 64;       // [512] exp / log tables (exner_from_rhotheta_lds)
 	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
-	int * rcount = (int *)(rmtab + TMX_RMTAB_DOUBLES) + PAIRS * TMX_FTOT * (L + 1) + 2 * pair;   // [PAIRS]{produced, consumed}
-	if (role == 0 && lane == 0) { rcount[0] = 0; rcount[1] = 0; }
-	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128 * PAIRS) opsl[t] = p.ops[t];
-	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += 128 * PAIRS) etal[t] = p.eta[t];
-	tmx_rm_tables_to_lds(rmtab, wv * 64 + lane, 128 * PAIRS);
+	int * rcount = (int *)(rmtab + TMX_RMTAB_DOUBLES) + PAIRS * TMX_FTOT * (L + 1) + 4 * pair;   // [PAIRS]{produced, consumed, produced by the second producer, -}
+	if (role == 1 && lane == 0) { rcount[0] = 0; rcount[1] = 0; rcount[2] = 0; }
+	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += NTHR) opsl[t] = p.ops[t];
+	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += NTHR) etal[t] = p.eta[t];
+	tmx_rm_tables_to_lds(rmtab, wv * 64 + lane, NTHR);
 	__syncthreads();
 	const size_t NS = (size_t)p.NS;
 	// cpw columns per wavefront (64, or fewer so that the column groups fill every SIMD of the chip evenly: tmxk_vi_fused).
@@ -1261,6 +1268,53 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 	RHS = AB + (size_t)n * TMX_UW * NUS;      // zero page behind the streams (vi_back_substitute)
 	AB = vi_stream_base_g(AB, n, grp, lane);  // this lane's slot in its wavefront's U-row stream
 
+	if (role == 0 && NPROD == 2) {
+		// ---- one of two producers: block rows q, q + 2, ... without the carry; the two levels that enter the window per row are loaded two rows ahead ----
+		const int q = wv;
+		ColConst cc;
+		cc.c2a0 = p.g2d[G2_C2A0 * NS + col]; cc.c2a1 = p.g2d[G2_C2A1 * NS + col]; cc.c2b1 = p.g2d[G2_C2B1 * NS + col];
+		cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
+		cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
+		const MetCol mcol = met_col(p, col);
+		struct LevRaw2 { double un, vn, pn, rn, we; };
+		auto load_raw2 = [&](int l) {
+			LevRaw2 r;
+			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+			r.un = xin[TMX_SLAB_U(L, lc) * NS + col]; r.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
+			r.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; r.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
+			r.we = xin[TMX_SLAB_W(L, le) * NS + col];
+			return r;
+		};
+		auto enter2 = [&](const LevRaw2 & r, int l, NodeLev & n, EdgeLev & e) {
+			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
+			n.un = r.un; n.vn = r.vn; n.pn = r.pn; n.rn = r.rn; e.we = r.we;
+			metric_node3<MM>(p, mcol, lc, col, n.ca2, n.cb2, n.cx2, etal);
+			metric_edge<MM>(p, mcol, le, col, e.ce0, e.ce1, e.ce2, etal);
+		};
+		NodeLev nA = load_node<MM>(p, mcol, xin, q - 1, col, etal), nB = load_node<MM>(p, mcol, xin, q, col, etal), nC = load_node<MM>(p, mcol, xin, q + 1, col, etal);
+		EdgeLev eA = load_edge<MM>(p, mcol, xin, q - 1, col, etal), eB = load_edge<MM>(p, mcol, xin, q, col, etal), eC = load_edge<MM>(p, mcol, xin, q + 1, col, etal);
+		LevRaw2 r1 = load_raw2(q + 2), r2 = load_raw2(q + 3);
+		double rP[TMX_BW], rW[TMX_BW], rR[TMX_BW], fP, fW, fR;
+		BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		for (int t = q; t <= L; t += 2) {
+			const LevRaw2 n1 = load_raw2(t + 4), n2 = load_raw2(t + 5);
+			compute_block<false>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
+			if (t >= RD) ring_wait(rcount + 1, t - RD + 1);
+			double * qd = ring + (size_t)(t % RD) * NQ * 64 + lane;
+#pragma unroll
+			for (int c = 0; c < TMX_BW; c++) {
+				if (TMX_RSLOT[0][c] >= 0) qd[TMX_RSLOT[0][c] * 64] = rP[c];
+				if (TMX_RSLOT[1][c] >= 0) qd[TMX_RSLOT[1][c] * 64] = rW[c];
+				if (TMX_RSLOT[2][c] >= 0) qd[TMX_RSLOT[2][c] * 64] = rR[c];
+			}
+			qd[(TMX_RSLOT_RHS + 0) * 64] = fP; qd[(TMX_RSLOT_RHS + 1) * 64] = fW; qd[(TMX_RSLOT_RHS + 2) * 64] = fR;
+			ring_post(rcount + 2 * q, (t >> 1) + 1, lane);
+			nA = nC; eA = eC;
+			enter2(r1, t + 2, nB, eB); enter2(r2, t + 3, nC, eC);
+			r1 = n1; r2 = n2;
+		}
+		return;
+	}
 	if (role == 0) {
 		// ---- producer: assemble block rows 0..L ----
 		ColConst cc;
@@ -1396,7 +1450,8 @@ __global__ __launch_bounds__(128 * PAIRS) __attribute__((amdgpu_waves_per_eu(2, 
 #endif
 	for (int m = 0; m <= L; m++) {
 		PMARK(tp_work);
-		ring_wait(rcount, m + 1);      // block row m is in the ring
+		if (NPROD == 2) ring_wait(rcount + 2 * (m & 1), (m >> 1) + 1);      // block row m is in the ring: made by producer m mod 2 as its (m / 2)-th
+		else ring_wait(rcount, m + 1);      // block row m is in the ring
 		PMARK(tp_wait);
 		const double * q = ring + (size_t)(m % RD) * NQ * 64 + lane;
 		// band entry d of the block row's rho*theta / W / rho row (structural zeros are literals), and the three residuals
@@ -1725,8 +1780,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
 		const size_t lds_common = (size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW * sizeof(double) + (size_t)(2 * p.L + 1) * sizeof(double) + TMX_RMTAB_DOUBLES * sizeof(double);
-		const size_t lds_pair = (size_t)TMX_RING_DEPTH * TMX_RING_NQ * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int) + 2 * sizeof(int);      // ring, fill-in masks, hand-over counters
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
+		// two assembly wavefronts per column group where every wavefront still has a SIMD to itself (option "vi_producers": 0 auto, 1, 2)
+		const bool two_prod = p.closed && pairs == 1 && cpw == 64 && (e->vi_producers == 2 || (e->vi_producers == 0 && ngrp * 3 <= 1024));
+		const size_t lds_pair = (size_t)(TMX_RING_DEPTH + (two_prod ? 1 : 0)) * TMX_RING_NQ * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int) + 4 * sizeof(int);      // ring, fill-in masks, hand-over counters
 		// back substitution as a launch of its own (TMX_VI_SPLIT_BACK=0: inside the pair kernel); the masks go through d_rhs,
 		// which only the split cross-check kernels use otherwise
 		const bool split_back = TMX_EXP && e->vi_split_back != 0;      // (experiments flavour only)
@@ -1737,6 +1794,10 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
 		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
+		if (two_prod && !(TMX_EXP && split))
+			hipLaunchKernelGGL((k_vi_pair<true, true, 1, true, 2>), dim3(ngrp), dim3(64, 3), lds_common + lds_pair, e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols,
+				ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger);
+		else
 		if (pairs == 1) { if (p.closed) LAUNCH_PAIR(true, 1); else LAUNCH_PAIR(false, 1); }
 		else { if (p.closed) LAUNCH_PAIR(true, 2); else LAUNCH_PAIR(false, 2); }
 #undef LAUNCH_PAIR

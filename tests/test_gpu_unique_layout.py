@@ -254,9 +254,13 @@ def test_ranks_may_run_one_step_through_different_interpreters(scheme, mixed):
             single.step(scheme, 200.0)
         single.sync()
         ref = single.download_state(0)
+        # the ranks live through the same history (Strang carries an instance from step to step): two steps, the new state, two steps
+        for e in ranks:
+            e.upload_state(0, start)
+        Engine.loopback_group(ranks)
+        _rank_engines_step(ranks, lambda e, k: e.step(scheme, 200.0, first=(k == 0)), 2)
         for e in ranks:
             e.upload_state(0, odd)
-        Engine.loopback_group(ranks)
         _rank_engines_step(ranks, lambda e, k: e.step(scheme, 200.0), 2)
         Engine.loopback_dissolve(ranks[0])
         assert all(e.info(INFO_UNIQUE_INSTANCES) > 0 for e in ranks)      # the second step ran node-unique everywhere
