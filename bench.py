@@ -50,11 +50,11 @@ SURVEY_8D_BYTES = {"h_explicit": 200.0 + 80.0, "v_implicit": 272.0, "dss": 60.0,
 ALG_BYTES_PER_STEP = 3328.0          # SURVEY.md 8(d) total: 416 doubles per point per step
 # What limits each operation (the roofline that bounds the PATH is HBM bandwidth):
 OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)", "hypervis": "hbm", "lincomb": "hbm",
-            "v_implicit": "latency: two chains of dependent fp64 operations per column group -- block-row assembly (4 260 cycles per block row "
-                          "alone on a SIMD for 2 400 issue cycles) and pivoted elimination (1 200 cycles per pivot step for 340) -- that "
-                          "interleave on shared SIMDs (forward phase 150-190 k cycles), then the back substitution reading the 260 MB U-row "
-                          "stream back at ~4 TB/s (140-196 k cycles); the kernel lasts as long as the 141 CUs that host two workgroups "
-                          "(profiles/r03_pair_timing.txt, r03_column_solve_ablation.txt)"}
+            "v_implicit": "stream + two chains: the pivoted band LU must write its U rows (277 MB per launch at ne30) and read them back -- 5.6 x the "
+                          "kernel's compulsory bytes -- while two dependent fp64 chains per column group run beside it: forward phase ~113 us = "
+                          "max(assembly ~104 us alone, elimination ~96 us alone with its stores, 63 without) now that the roles hand over through a "
+                          "three-deep LDS ring instead of a barrier per block row; back substitution ~50 us = the stream read back at ~6 TB/s "
+                          "(profiles/r05_column_solve_ablation.txt, r05_pair_timing_raw.txt)"}
 # engine profile slots (HIP events) that make up each operation
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
