@@ -414,9 +414,10 @@ long long tmx_info(tmx_engine * e, int what);
  * on its own -- a stray TMX_* in a job script cannot change a run.  The list (tmx_options_report prints it with the values in use):
  *   "unique_layout"      -1 default (= 1), 0 off, 1 on: hold the state once per patch node inside tmx_step (node-unique slabs: 9/16 of
  *                        the bytes, the DSS reduced to the nodes on tile and patch edges) where every kernel of the configuration
- *                        has that form -- nonhydrostatic set, implicit vertical dynamics, no tracers / uniform diffusion /
- *                        Rayleigh layer; replaces nothing of the reference interface (GridPatch data stay as they are at the
- *                        boundary).  Before tmx_finalize.
+ *                        has that form -- nonhydrostatic set, implicit vertical dynamics, no tracers / uniform diffusion (a Rayleigh
+ *                        layer, applied per stored copy, leaves the state element-major at the end of a step and the next step reads it
+ *                        copy by copy: "unique_mixed"); replaces nothing of the reference interface (GridPatch data stay as they are at
+ *                        the boundary).  Before tmx_finalize.
  *   "unique_tile_shape"  elements of a wavefront: 0 = the element-major order, 1 x 4 strips along beta that wrap around patch rows
  *                        (default: measured fastest), 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row.  Before tmx_finalize.
  *   "unique_xcd_order"   1 (default): every XCD sweeps a contiguous range of tiles.  Before tmx_finalize.

@@ -893,10 +893,11 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
 	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
 	// Node-unique state layout (tmx_unique.hip): for the configurations all of whose step kernels have the U form -- the
-	// nonhydrostatic set with implicit vertical dynamics, no tracers, no uniform diffusion, no Rayleigh layer (its strength is
-	// stored per copy of a node), closed-form metric.  Every other configuration, and every entry point other than tmx_step,
-	// works on the element-major layout as before.
-	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && !e->rayleigh && e->metric_closed &&
+	// nonhydrostatic set with implicit vertical dynamics, no tracers, no uniform diffusion, closed-form metric; a Rayleigh layer (its
+	// strength is stored per copy of a node) since round 5: the relaxation at the end of StepAfterSubCycle reads node-unique and writes
+	// element-major, and the next step reads that copy by copy ("unique_mixed").  Every other configuration, and every entry point other
+	// than tmx_step, works on the element-major layout as before.
+	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && (!e->rayleigh || e->u.mixed_option) && e->metric_closed &&
 	    !e->hvis_pull && !e->hvis_block && !e->use_graph && !e->use_mfma && e->vi_mode == 0) {
 		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
 		if ((r = tmxu_build(e, in, &bytes))) return r;

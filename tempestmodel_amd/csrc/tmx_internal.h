@@ -345,7 +345,7 @@ void tmxk_lincomb(tmx_engine * e, size_t n, double * dst, int nterms, const doub
 void tmxk_pack(tmx_engine * e, const KParams & p, const double * x);
 void tmxk_pack_p2p(tmx_engine * e, const KParams & p, const double * x, int buf);
 void tmxk_p2p_signal_wait(tmx_engine * e, hipStream_t s, int buf, unsigned long long seq);
-void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt);
+void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt, const double * xs = nullptr, size_t NSS = 0, const int * ucd = nullptr);
 void tmxk_held_suarez(tmx_engine * e, const KParams & p, double * x, const double * surf, double dt, const double * xs = nullptr, size_t NSS = 0, const int * ucd = nullptr);
 void tmxk_kessler(tmx_engine * e, const KParams & p, double * x, double dt);
 // tracers (rows H8 / V8)

@@ -561,46 +561,60 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 // HorizontalDynamicsFEM::ApplyRayleighFriction (src/atm/HorizontalDynamicsFEM.cpp:2420-2570): where the strength
 // is non-zero, ten sub-cycled backward-Euler relaxations x <- f x + (1 - f) x_ref, f = 1 / (1 + dt nu / 10), of
 // U, V, rho*theta (strength on levels) and W (strength on interfaces); rho is left alone (:2455-2461).
+// FROM_U: the instance comes in node-unique form (xs, slab stride NSS, node of a stored column = ucd[col]) and leaves element-major (x): the
+// strength and the reference state are per stored copy, so the copies of a seam node may end different (the reference applies the relaxation
+// per copy); slabs and points the relaxation leaves alone are copied across -- the kernel's load is the conversion (cf. k_held_suarez<FROM_U>)
+template <bool FROM_U>
 __global__ __launch_bounds__(256) void k_rayleigh(int L, int NS_, int ncol, double * __restrict__ x,
-	const double * __restrict__ nu, const double * __restrict__ ref, double dt)
+	const double * __restrict__ nu, const double * __restrict__ ref, double dt, const double * __restrict__ xs, size_t NSS, const int * __restrict__ ucd)
 {
 	const size_t NS = (size_t)NS_;
 	const int col = blockIdx.x * 64 + threadIdx.x;
 	const int k = blockIdx.y * 4 + WAVE_UNIFORM(threadIdx.y);
 	if (k > L || col >= ncol) return;
+	const double * __restrict__ xr = FROM_U ? xs : x;
+	const size_t SR = FROM_U ? NSS : NS;
+	const size_t sc = FROM_U ? (size_t)ucd[col] : (size_t)col;
 	const double factor = 1.0 / 10;
 	if (k < L) {
 		const double dnu = nu[(size_t)k * NS + col];
-		if (dnu != 0.0) {
+		if (FROM_U) x[(size_t)TMX_SLAB_R(L, k) * NS + col] = xr[(size_t)TMX_SLAB_R(L, k) * SR + sc];      // rho is left alone (:2455-2461)
+		if (dnu != 0.0 || FROM_U) {
 #pragma unroll
 			for (int v = 0; v < 3; v++) {
 				const size_t o = (size_t)(v * L + k) * NS + col;        // U, V, rho*theta slabs are [0, 3L)
-				double xv = x[o];
-				const double r = ref[o];
-				for (int si = 0; si < 10; si++) {
-					const double f = 1.0 / (1.0 + factor * dt * dnu);
-					xv = f * xv + (1.0 - f) * r;
+				double xv = xr[(size_t)(v * L + k) * SR + sc];
+				if (dnu != 0.0) {
+					const double r = ref[o];
+					for (int si = 0; si < 10; si++) {
+						const double f = 1.0 / (1.0 + factor * dt * dnu);
+						xv = f * xv + (1.0 - f) * r;
+					}
 				}
 				x[o] = xv;
 			}
 		}
 	}
 	const double dnu = nu[(size_t)(L + k) * NS + col];
-	if (dnu != 0.0) {
+	if (dnu != 0.0 || FROM_U) {
 		const size_t o = (size_t)TMX_SLAB_W(L, k) * NS + col;
-		double xv = x[o];
-		const double r = ref[(size_t)(3 * L + k) * NS + col];
-		for (int si = 0; si < 10; si++) {
-			const double f = 1.0 / (1.0 + factor * dt * dnu);
-			xv = f * xv + (1.0 - f) * r;
+		double xv = xr[(size_t)TMX_SLAB_W(L, k) * SR + sc];
+		if (dnu != 0.0) {
+			const double r = ref[(size_t)(3 * L + k) * NS + col];
+			for (int si = 0; si < 10; si++) {
+				const double f = 1.0 / (1.0 + factor * dt * dnu);
+				xv = f * xv + (1.0 - f) * r;
+			}
 		}
 		x[o] = xv;
 	}
 }
 
-void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt) {
+// xs != null: read node-unique (stride NSS, ucd = node of every stored column), write element-major to x
+void tmxk_rayleigh(tmx_engine * e, const KParams & p, double * x, double dt, const double * xs, size_t NSS, const int * ucd) {
 	dim3 blk(64, 4), grd(p.NS / 64, (p.L + 1 + 3) / 4);
-	hipLaunchKernelGGL(k_rayleigh, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt);
+	if (xs) hipLaunchKernelGGL(k_rayleigh<true>, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt, xs, NSS, ucd);
+	else hipLaunchKernelGGL(k_rayleigh<false>, grd, blk, 0, e->stream, p.L, p.NS, p.ncol, x, (const double *)e->d_ray_nu, (const double *)e->d_ray_ref, dt, (const double *)nullptr, (size_t)0, (const int *)nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1655,7 +1655,25 @@ static int u_dss(tmx_engine * e, int ix) {
 }
 
 // HorizontalDynamicsFEM::StepAfterSubCycle (h_step_after_subcycle_impl above, same branches)
+static int u_hvis_core(tmx_engine * e, int iinit, int iupd, int iwork, double dt);
+// ... and its Rayleigh friction (APPLY_RAYLEIGH_WITH_HYPERVIS, HorizontalDynamicsFEM.cpp:2719-2724, ApplyRayleighFriction :2420-2570): the
+// reference relaxes every stored copy with the copy's own strength and reference state, so the result has no node-unique form -- the kernel
+// reads the node-unique instance and writes the element-major one, and the next step's explicit stages read that copy by copy ("unique_mixed")
 static int u_hvis(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
+	int r = u_hvis_core(e, iinit, iupd, iwork, dt);
+	if (r || !e->rayleigh) return r;
+	UniqueLayout & u = e->u;
+	REQUIRE(e->imap[iupd] == iupd, TMX_ERR_INVALID, "internal: Rayleigh friction on a shared slot");
+	if ((r = u_own_uv(e, iupd))) return r;
+	{
+		ProfScope ps(e, TMX_K_HYPERVIS);
+		tmxk_rayleigh(e, make_params(e), inst(e, iupd), dt, uinst(e, iupd), (size_t)u.NUS, (const int *)u.d_ucol_of_dcol);
+	}
+	if (u.form[iupd]) { u.form[iupd] = 0; u.n_uform--; }
+	u.conversions++;
+	return launch_check("rayleigh friction (node-unique in, element-major out)");
+}
+static int u_hvis_core(tmx_engine * e, int iinit, int iupd, int iwork, double dt) {
 	const tmx_config & c = e->cfg;
 	int r;
 	REQUIRE(iinit != iwork && iupd != iwork && iinit != iupd, TMX_ERR_UNSUPPORTED, "StepAfterSubCycle on the node-unique layout needs three distinct instances");

@@ -272,6 +272,33 @@ def test_ranks_may_run_one_step_through_different_interpreters(scheme, mixed):
             e.close()
 
 
+@pytest.mark.parametrize("scheme,npatch,ne", [("ars343", 6, 4), ("ars343", 24, 6), ("ars222", 6, 4), ("strang", 6, 4)])
+def test_rayleigh_layer_on_the_unique_layout(scheme, npatch, ne):
+    """Schar mountain (topography, Rayleigh layer near the top and the lateral boundaries of the reduced-radius sphere): the reference
+    relaxes every stored copy with the copy's own strength and reference state (HorizontalDynamicsFEM.cpp:2420-2570), so the state behind
+    StepAfterSubCycle has no node-unique form.  Round 5: the relaxation reads the node-unique instance and writes the element-major one
+    (k_rayleigh<FROM_U>), the next step's explicit stages read that copy by copy; schemes that cannot ("strang") check the copies and fall
+    back by themselves.  Identical to the element-major engine, step after step."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(ne, 8, npatch, case="schar")
+    ni = max(7, Engine.scheme_instances(scheme))
+    d = Engine(g, n_instances=ni, options={"unique_layout": 0}); u = Engine(g, n_instances=ni, options={"unique_layout": 1})
+    try:
+        assert u.info(INFO_UNIQUE_LAYOUT) == 1
+        for e in (d, u):
+            e.upload_state(0, start)
+        for k in range(5):
+            for e in (d, u):
+                e.step(scheme, 0.5, first=(k == 0))
+            d.sync(); u.sync()
+            if k in (0, 2, 4):
+                assert _same(u.download_state(0), d.download_state(0), range(npatch)), (scheme, "step", k)
+        if scheme != "strang":
+            assert u.info(INFO_MIXED_STEPS) >= 4
+    finally:
+        d.close(); u.close()
+
+
 def _perturb_copies(arrs, rng):
     """every stored value moved by -1, 0 or +1 ulp, independently: the copies of a seam node no longer agree"""
     out = []

@@ -15,7 +15,9 @@ one() {   # name, rocprof args..., -- program
 	local name=$1; shift
 	if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi
 	timeout ${PASS_TIMEOUT:-600} rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1 || echo "$name failed"
+	echo $SHA > $OUT/${TAG}_${name}.sha      # hash of the kernel sources this pass ran (bench.csrc_sha16; tools/summarise_profiles.py stamps the tables with it)
 }
+SHA=$(cd $R && python3 -c "import bench; print(bench.csrc_sha16())" 2>/dev/null)
 one trace --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- python3 $B
 one fetch --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $B
 one write --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o ${TAG} -- python3 $B

@@ -53,7 +53,9 @@ for fe, wr, out, what, steps in (("fetch", "write", "ne30_L30_n1", "ne30 np4 L30
         # summarise right after the gpurun call, before the sources are edited again
         sys.path.insert(0, R)
         import bench as _bench
-        tabj = json.load(open(dstj)); tabj["csrc_sha16"] = os.environ.get("TMX_PROFILE_SHA") or _bench.csrc_sha16()
+        shaf = os.path.join(G, "%s_%s.sha" % (tag, fe))      # written on the GPU box by tools/profile_round.sh; older passes: TMX_PROFILE_SHA or the current tree
+        sha = open(shaf).read().strip() if os.path.exists(shaf) and open(shaf).read().strip() else (os.environ.get("TMX_PROFILE_SHA") or _bench.csrc_sha16())
+        tabj = json.load(open(dstj)); tabj["csrc_sha16"] = sha
         json.dump(tabj, open(dstj, "w"), indent=1)
 
 v = counters("valu")
