@@ -1722,6 +1722,20 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 			}
 			// Copy(a -> b) + StepAfterSubCycle(a, b, w): every branch rewrites all of b from a
 			if (i + 1 < p.size() && p[i + 1].kind == OP_HVIS && p[i + 1].a == o.a && p[i + 1].b == o.b && o.a != o.b) break;
+			if (!e->u.form[o.a] && o.a != o.b) {
+				// the source is element-major: the Rayleigh relaxation at the end of StepAfterSubCycle left it so (u_hvis); the copy is
+				// a whole-slot copy as in the element-major program (surface slots included), and the destination is element-major too
+				REQUIRE(e->rayleigh && e->imap[o.a] == o.a && e->imap[o.b] == o.b, TMX_ERR_INVALID, "internal: element-major source of a copy inside a node-unique program");
+				if ((r = u_own_uv(e, o.b, true))) return r;
+				{
+					ProfScope ps(e, TMX_K_LINCOMB);
+					HIPCHK(hipMemcpyAsync(inst(e, o.b), inst(e, o.a), e->inst_stride * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+				}
+				if (e->u.form[o.b]) { e->u.form[o.b] = 0; e->u.n_uform--; }
+				e->u.dlive &= ~(1u << o.b);
+				u_written(e, o.b);
+				break;
+			}
 			if ((r = u_copy(e, o.a, o.b, e->u.ustride))) return r;
 			break;
 		case OP_LINCOMB:
@@ -1790,10 +1804,20 @@ extern "C" int tmx_debug_program_mixed(int scheme, int first_step, int last_step
 // Entry of tmx_step: bring the instances the program reads before it overwrites them into the node-unique form (checking, for
 // those that come from the element-major form, that the copies of every node agree) and run the program there.  *done = false:
 // not possible (configuration, program, or an instance whose copies differ); the caller runs the element-major program.
+// With a Rayleigh layer the result of StepAfterSubCycle is element-major (u_hvis): the node-unique interpreter serves the programs in which
+// only copies of that result follow (ARS343: nothing follows; ARS222 / 232 / 443 / ARK232: Copy(result -> 0)); Strang's closing column solve
+// of the relaxed state has no node-unique form, its programs stay element-major
+static bool rayleigh_program_ok(const Program & p) {
+	size_t h = p.size();
+	for (size_t i = 0; i < p.size(); i++) if (p[i].kind == OP_HVIS) { if (h != p.size()) return false; h = i; }
+	for (size_t i = h + 1; i < p.size(); i++) if (!(p[i].kind == OP_COPY && p[i].a == p[h].b)) return false;
+	return true;
+}
 static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	*done = false;
 	UniqueLayout & u = e->u;
 	if (!u.built || false || !program_fits_unique(p)) return TMX_OK;
+	if (e->rayleigh && !rayleigh_program_ok(p)) return TMX_OK;
 	int r;
 	unsigned written = 0u, livein = 0u;
 	const bool noop = false;
