@@ -54,7 +54,7 @@ OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)",
                           "kernel's compulsory bytes -- while two dependent fp64 chains per column group run beside it: forward phase ~113 us = "
                           "max(assembly ~104 us alone, elimination ~96 us alone with its stores, 63 without) now that the roles hand over through a "
                           "three-deep LDS ring instead of a barrier per block row; back substitution ~50 us = the stream read back at ~6 TB/s "
-                          "(profiles/r05_column_solve_ablation.txt, r05_pair_timing_raw.txt)"}
+                          "(profiles/r05_column_solve_ablation.txt, r05_pair_timing.txt)"}
 # engine profile slots (HIP events) that make up each operation
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}

@@ -1416,7 +1416,8 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 		if (stats && lane == 0) {
 			unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);
 			q[0] = 1 + role; q[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-			q[3] = tp_work; q[4] = tp_wait; q[5] = (unsigned long long)((long long)__builtin_readcyclecounter() - tp_start); q[6] = 0;
+			q[5] = (unsigned long long)((long long)__builtin_readcyclecounter() - tp_start); q[4] = tp_wait; q[3] = q[5] - q[4]; q[6] = 0;      // work = everything but the waits for a free ring slot
+			(void)tp_work;
 			// segments of the assembly: interface interpolation | flux rows (P, R) | Exner + node quantities | W row | shift + prefetch issue
 			if (blockIdx.x % 16 == 0) printf("pairtiming producer wg %d pair %d segments: interp %lld flux %lld exner %lld wrow %lld prefetch issue %lld window shift %lld ring writes %lld\n",
 				(int)blockIdx.x, pair, tp_seg[0], tp_seg[1], tp_seg[2], tp_seg[3], tp_seg[4], tp_seg[5], tp_work);
