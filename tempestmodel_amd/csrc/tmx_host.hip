@@ -1414,7 +1414,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_mixed", e->u.mixed_option); OPT("unique_prefix", e->u.prefix_option);
 	OPT("share_copies", e->share_copies); OPT("xcd_vertical", e->xcd_vertical);
 	OPT("vi_carry", e->vi_carry); OPT("vi_pair", e->vi_pair); OPT("vi_group", e->vi_group); OPT("vi_group_max", e->vi_group_max);
-	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_producers", e->vi_producers); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
+	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_producers", e->vi_producers); OPT("vi_ring_depth", e->vi_ring_depth); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
 	OPT("vi_stagger", e->vi_stagger); OPT("vi_split_kernels", e->vi_mode); OPT("vi_sparse", e->opt_vi_sparse); OPT("vi_columns_per_wavefront", e->opt_vi_cpw);
 	OPT("contraction_mfma", e->use_mfma); OPT("step_graph", e->use_graph); OPT("p2p_timeout_s", e->p2p_timeout_s);
 	OPT("hvis_pull", e->hvis_pull); OPT("hvis_block", e->hvis_block);
@@ -1439,6 +1439,7 @@ static const OptionDef g_options[] = {
 	{ "vi_group", "TMX_VI_GROUP", 0, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
 	{ "vi_group_max", "TMX_VI_GROUP_MAX", 0, "largest rank share (unique columns) served by the lane-group kernel (6400)" },
 	{ "vi_pair_workgroup", "TMX_VI_PAIR_WG", 0, "pairs per workgroup of the two-wavefront kernel (0 auto)" },
+	{ "vi_ring_depth", "TMX_VI_RING_DEPTH", 0, "block rows in the LDS ring between assembly and elimination: 0 auto (3, or 2 where only that fits two workgroups per CU: more than ~38 levels), 2, 3" },
 	{ "vi_producers", "TMX_VI_PRODUCERS", 0, "assembly wavefronts per column group of that kernel: 0 auto (2 on grids that leave every wavefront a SIMD of its own), 1, 2" },
 	{ "vi_split_back", "TMX_VI_SPLIT_BACK", 2, "back substitution as a launch of its own (0)" },
 	{ "vi_back_sub", "TMX_VI_BACK_SUB", 2, "wavefronts per column group of that launch (1)" },
@@ -1494,6 +1495,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vi_group") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vi_group: -1 (auto), 0 or 1");
 	if (n == "vi_group_max") REQUIRE(iv >= 0, TMX_ERR_INVALID, "vi_group_max must not be negative");
 	if (n == "vi_pair_workgroup") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "vi_pair_workgroup: 0 (auto), 1 or 2");
+	if (n == "vi_ring_depth") REQUIRE(iv == 0 || iv == 2 || iv == 3, TMX_ERR_INVALID, "vi_ring_depth: 0 (auto), 2 or 3");
 	if (n == "vi_producers") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "vi_producers: 0 (auto), 1 or 2");
 	if (n == "vi_stagger") REQUIRE(iv >= 0, TMX_ERR_INVALID, "vi_stagger must not be negative");
 	if (n == "vi_columns_per_wavefront") REQUIRE(iv >= 0 && iv <= 64, TMX_ERR_INVALID, "vi_columns_per_wavefront: 0 (= 64) .. 64");

@@ -234,6 +234,7 @@ struct tmx_engine {
 	// profiling
 	bool sw = false;                         // shallow-water equation set (no vertical dynamics)
 	int vi_mode = 0;                         // 0 = fused column kernel, 1 = assemble + solve (two kernels)
+	int vi_ring_depth = 0;                   // block rows in the LDS ring of the two-role column kernel: 0 auto (3, or 2 where that lets two workgroups onto a CU), 2, 3
 	int vi_producers = 0;                    // assembly wavefronts per column group of the two-role column kernel: 0 auto (2 where every wavefront has a SIMD to itself), 1, 2
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
 	// boundary-first launches (ranks > 1): 64-column tiles holding a column another rank needs, and the others

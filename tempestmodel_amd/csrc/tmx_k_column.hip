@@ -1208,7 +1208,10 @@ __device__ __forceinline__ void ring_post(int * counter, int value, int lane) {
 // between consecutive rows (compute_block<false>: the same statements on the same operands, one more Exner evaluation per row) -- into the
 // same ring, and the elimination wavefront takes the rows in order from whichever producer made them (one `produced` counter each).  The
 // forward phase of a column group then costs the elimination chain, not the longer assembly chain.
-template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true, int NPROD = 1>
+// RDT: block rows the ring holds (three where the LDS leaves room for two workgroups per CU with them, else two: from about 38 levels on the
+// operator tables and three-deep rings of two pairs pass 80 KB per workgroup -- rounds 1-4 ran such grids, BASELINE config 5's 60 levels among
+// them, with ONE workgroup per CU)
+template <bool SPARSE, bool CLOSED, int PAIRS, bool BACK = true, int NPROD = 1, int RDT = TMX_RING_DEPTH>
 __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vi_pair(KParams p, const double * xin, double * xup, double dt,
 	int nunique, int NUS, const int * __restrict__ ucol, const int * __restrict__ udep,
 	double * __restrict__ AB, double * __restrict__ RHS, int * __restrict__ flag, int cpw, unsigned long long * __restrict__ stats, int * __restrict__ gmask = nullptr,
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	const int L = p.L;
 	constexpr int MM = CLOSED ? 1 : 2;
 	constexpr int NQ = TMX_RING_NQ;                                          // doubles per block row and column in the ring (sparse: TMX_RSLOT)
-	constexpr int RD = (NPROD == 2) ? TMX_RING_DEPTH + 1 : TMX_RING_DEPTH;      // (two rows are being written at a time)
+	constexpr int RD = (NPROD == 2) ? RDT + 1 : RDT;      // (two rows are being written at a time)
 	constexpr int NTHR = PAIRS * 64 * (1 + NPROD);
 	static_assert(NPROD == 1 || (NPROD == 2 && PAIRS == 1 && CLOSED), "two producers: one column group per workgroup, closed-form metric");
 	// Staggered start (stagger = window in units of 10 ns, 0 = off): workgroup i begins i / gridDim.x of the window late.  All
@@ -1784,7 +1787,14 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const int pairs = (e->vi_pair_wg > 0) ? e->vi_pair_wg : ((ngrp <= 256) ? 1 : 2);
 		// two assembly wavefronts per column group where every wavefront still has a SIMD to itself (option "vi_producers": 0 auto, 1, 2)
 		const bool two_prod = p.closed && pairs == 1 && cpw == 64 && (e->vi_producers == 2 || (e->vi_producers == 0 && ngrp * 3 <= 1024));
-		const size_t lds_pair = (size_t)(TMX_RING_DEPTH + (two_prod ? 1 : 0)) * TMX_RING_NQ * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int) + 4 * sizeof(int);      // ring, fill-in masks, hand-over counters
+		auto lds_pair_of = [&](int depth) { return (size_t)depth * TMX_RING_NQ * 64 * sizeof(double) + (size_t)TMX_FTOT * (p.L + 1) * sizeof(int) + 4 * sizeof(int); };      // ring, fill-in masks, hand-over counters
+		// ring depth: three block rows, or two where only that lets a second workgroup onto every CU (160 KB of LDS; option "vi_ring_depth": 0 auto, 2, 3)
+		const size_t cu_lds = 160 * 1024;
+		int rdt = TMX_RING_DEPTH;
+		if (e->vi_ring_depth == 2 || e->vi_ring_depth == 3) rdt = e->vi_ring_depth;
+		else if (!two_prod && 2 * (lds_common + pairs * lds_pair_of(3)) > cu_lds && 2 * (lds_common + pairs * lds_pair_of(2)) <= cu_lds) rdt = 2;
+		if (TMX_EXP && e->vi_split_back != 0) rdt = TMX_RING_DEPTH;      // (the separate-back-substitution cross-check is instantiated with the default depth)
+		const size_t lds_pair = lds_pair_of(two_prod ? TMX_RING_DEPTH + 1 : rdt);
 		// back substitution as a launch of its own (TMX_VI_SPLIT_BACK=0: inside the pair kernel); the masks go through d_rhs,
 		// which only the split cross-check kernels use otherwise
 		const bool split_back = TMX_EXP && e->vi_split_back != 0;      // (experiments flavour only)
@@ -1793,7 +1803,9 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 		const bool split = split_back && (size_t)ngrp_launched * TMX_FTOT * (p.L + 1) * sizeof(int) <= (size_t)TMX_FTOT * (p.L + 1) * e->NUS * sizeof(double);
 #define LAUNCH_PAIR(CL_, NP_) do { if (TMX_EXP && split) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, TMX_EXP == 0>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)e->d_rhs, 0); \
-		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+		else if (rdt == 2) hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true, 1, 2>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
+			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); \
+		else hipLaunchKernelGGL((k_vi_pair<true, CL_, NP_, true, 1, 3>), dim3((ngrp + NP_ - 1) / NP_), dim3(64, 2 * NP_), lds_common + NP_ * lds_pair, \
 			e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols, ucolp, udepp, e->d_ab, e->d_rhs, e->d_flag, cpw, e->d_pivot_stats, (int *)nullptr, stagger); } while (0)
 		if (two_prod && !(TMX_EXP && split))
 			hipLaunchKernelGGL((k_vi_pair<true, true, 1, true, 2>), dim3(ngrp), dim3(64, 3), lds_common + lds_pair, e->stream, p, xin, xup, dt, e->nunique, e->vi_stream_cols,

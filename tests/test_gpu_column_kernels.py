@@ -132,7 +132,11 @@ def test_fused_column_kernels_are_bit_identical_to_split_kernels():
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_STAGGER_NS": "5000"},
                 # one / two assembly wavefronts per column group (round 5: the second producer evaluates every other block row without the carry)
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_PRODUCERS": "1"},
-                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_PRODUCERS": "2"}):
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_PRODUCERS": "2"},
+                # ring of two / three block rows (two is what grids of more than ~38 levels get: the LDS then holds two workgroups per CU)
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_RING_DEPTH": "2"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "1", "TMX_VI_PRODUCERS": "1", "TMX_VI_RING_DEPTH": "2"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_RING_DEPTH": "3"}):
         os.environ.update(env)
         try:
             e = Engine(g, flavour="experiments")      # (the one-wavefront, split and separate-back-substitution kernels live there)
@@ -177,6 +181,7 @@ def test_column_solve_with_lane_divergent_pivots():
     out = []
     for env in ({"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "0"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PRODUCERS": "1"}, {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PRODUCERS": "2"},
+                {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_RING_DEPTH": "2"},
                 {"TMX_VI_GROUP": "0", "TMX_VI_PAIR": "1", "TMX_VI_PAIR_WG": "2", "TMX_VI_CPW": "60"}):
         os.environ.update(env)
         try:
