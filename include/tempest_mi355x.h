@@ -477,6 +477,9 @@ int tmx_debug_program_unique(int scheme, int first_step, int last_step);
 /* Host logic of "unique_mixed": 1 if only the explicit stages of the scheme's program read data instance `instance` before the program overwrites
  * it (so that it may stay element-major, read copy by copy, while the step runs on the node-unique layout), 0 if not, -1 unknown scheme. */
 int tmx_debug_program_mixed(int scheme, int first_step, int last_step, int instance);
+/* Host logic of the Rayleigh layer on the node-unique layout: 1 if only copies of StepAfterSubCycle's result follow it in the scheme's program
+ * (the relaxed, element-major result is never read by a node-unique operation), 0 if the program stays element-major, -1 unknown scheme. */
+int tmx_debug_program_rayleigh(int scheme, int first_step, int last_step);
 /* Host logic for the CPU tests: the explicit stages of a scheme's program that can start from a partial sum an earlier stage
  * stores (node-unique layout, option "unique_prefix").  Returns their number; pairs[2 k], pairs[2 k + 1] (k < cap): operation
  * index of the producing and of the consuming stage; terms[k]: source instances the consuming stage no longer reads. */

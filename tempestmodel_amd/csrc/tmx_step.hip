@@ -1813,6 +1813,12 @@ static bool rayleigh_program_ok(const Program & p) {
 	for (size_t i = h + 1; i < p.size(); i++) if (!(p[i].kind == OP_COPY && p[i].a == p[h].b)) return false;
 	return true;
 }
+// Host logic for the CPU tests: with a Rayleigh layer, does the scheme's program run on the node-unique layout (1) or element-major (0)?  -1: unknown scheme
+extern "C" int tmx_debug_program_rayleigh(int scheme, int first_step, int last_step) {
+	Program p;
+	if (build_program(scheme, first_step, last_step, 1.0, p, 0.0)) return -1;
+	return (program_fits_unique(p) && rayleigh_program_ok(p)) ? 1 : 0;
+}
 static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	*done = false;
 	UniqueLayout & u = e->u;

@@ -385,6 +385,18 @@ def test_which_programs_may_read_the_model_state_copy_by_copy():
     assert lib.tmx_debug_program_mixed(99, 0, 0, 0) == -1
 
 
+def test_which_programs_keep_the_unique_layout_with_a_rayleigh_layer():
+    """Host logic (no device): the Rayleigh relaxation at the end of StepAfterSubCycle leaves its result element-major; the node-unique
+    interpreter serves the programs in which only copies of that result follow (the ARS / ARK family), Strang's -- which close with a
+    column solve of the relaxed state -- stay element-major."""
+    from tempestmodel_amd import engine as eng
+    lib = eng.load_library()
+    for name, sid in eng.Engine.SCHEMES.items():
+        for first in (0, 1):
+            assert lib.tmx_debug_program_rayleigh(sid, first, 0) == (0 if name.startswith("strang") else 1), (name, first)
+    assert lib.tmx_debug_program_rayleigh(99, 0, 0) == -1
+
+
 def test_stage_combinations_that_start_from_a_stored_partial_sum():
     """Host logic (no device): which explicit stages of a program can start from the leading partial sum of their combination,
     stored by an earlier stage that reads the same instances.  ARS343: operation 12 (third stage, LinearCombine of instances 0..4)
