@@ -658,19 +658,24 @@ __device__ constexpr int TMX_UPAIR[3][5][2] = {
 // bit 1: the back substitution's loads carry the non-temporal hint.  Measured (round 5, ne30 L30, same box, two alternations): the
 // column solve itself does not move (0.476-0.492 ms per step with any of 0..3), but the stream no longer evicts the state from the
 // L2 / Infinity Cache: the explicit kernels that follow go from 0.578 to 0.552 (stores), 0.549 (loads), 0.535 ms per step (both),
-// the step from 1.394 to 1.350 ms.  Default: both.
+// the step from 1.394 to 1.350 ms.  Default: both -- except in the small-grid variant of the pair kernel (NTS below; profiles/r05_stream_hint_small_grids.txt).
 #ifndef TMX_USTREAM_NT
 #define TMX_USTREAM_NT 3
 #endif
 typedef double tmx_dbl2 __attribute__((ext_vector_type(2)));
+// NTS: this instantiation's stream carries the hint at all (the small-grid variant of the pair kernel does not: at ne15 the whole stream, 66 MB,
+// stays in the Infinity Cache between the phases and the hint costs 2 % of the step; at ne20, 125 MB, it already pays)
+#define TMX_NTS_DEFAULT (TMX_USTREAM_NT != 0)
+template <bool NTS>
 __device__ __forceinline__ void ustream_store2(double * q, double a, double b) {
 	tmx_dbl2 v; v.x = a; v.y = b;
-	if (TMX_USTREAM_NT & 1) __builtin_nontemporal_store(v, (tmx_dbl2 *)q);
+	if (NTS && (TMX_USTREAM_NT & 1)) __builtin_nontemporal_store(v, (tmx_dbl2 *)q);
 	else *(tmx_dbl2 *)q = v;
 }
+template <bool NTS>
 __device__ __forceinline__ double2 ustream_load2(const double * q) {
 	tmx_dbl2 v;
-	if (TMX_USTREAM_NT & 2) v = __builtin_nontemporal_load((const tmx_dbl2 *)q);
+	if (NTS && (TMX_USTREAM_NT & 2)) v = __builtin_nontemporal_load((const tmx_dbl2 *)q);
 	else v = *(const tmx_dbl2 *)q;
 	return make_double2(v.x, v.y);
 }
@@ -696,7 +701,7 @@ __device__ __forceinline__ double * vi_stream_base_g(double * AB, int n, int grp
 // condition makes it divergent for the compiler: the store then runs under an EXEC mask that is all ones or all zeros (an
 // instruction with an empty mask issues and does nothing), no branch.
 // TYPE: kind of the matrix row jcol (jcol mod 3), a compile-time constant at every call site.
-template <bool SPARSE, bool PRED, int TYPE>
+template <bool SPARSE, bool PRED, int TYPE, bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
@@ -709,7 +714,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 	double * row = AB + (size_t)jcol * TMX_RS(NUS);
 #pragma unroll
 	for (int sl = 0; sl < 3; sl++)
-		ustream_store2(row + sl * 128, val(TMX_UPAIR[TYPE][sl][0]), val(TMX_UPAIR[TYPE][sl][1]));
+		ustream_store2<NTS>(row + sl * 128, val(TMX_UPAIR[TYPE][sl][0]), val(TMX_UPAIR[TYPE][sl][1]));
 	int mask = 0;
 	int one = 1;
 	if (PRED) asm volatile("" : "+v"(one));
@@ -718,7 +723,7 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 		const double a = val(TMX_UPAIR[TYPE][sl][0]), b = val(TMX_UPAIR[TYPE][sl][1]);
 		const bool any = !SPARSE || __builtin_amdgcn_ballot_w64(a != 0.0 || b != 0.0) != 0;
 		mask |= any ? (1 << sl) : 0;
-		if (PRED ? (any && one) : any) ustream_store2(row + sl * 128, a, b);
+		if (PRED ? (any && one) : any) ustream_store2<NTS>(row + sl * 128, a, b);
 	}
 	if (SPARSE ? (threadIdx.x == 0) : true) umask[jcol] = mask;      // dense stores (also the lane-divergent tails, where lane 0 may be masked out): every active lane writes the same word
 #else
@@ -784,7 +789,7 @@ __device__ __forceinline__ double lu_in_entry(const double * in, int c) {
 // so neither the 160 v_cndmask of the per-lane interchange nor the 36 moves of the slide are executed.  Only the
 // pivot row and old row 0 are copied aside, because their slots are overwritten before their last use.
 // Same multiplications and subtractions on the same operands as the generic path: bit-identical.
-template <bool SPARSE, int PV, int IS, int TYPE, int INK = -1>
+template <bool SPARSE, int PV, int IS, int TYPE, int INK = -1, bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask)
@@ -799,7 +804,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	const double pb = b[PV], tb0 = b[0];
 	if (piv[0] == 0.0) singular = true;
 #if TMX_TAIL == 1
-	lu_store_urow<SPARSE, false, TYPE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, false, TYPE, NTS>(piv, pb, AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / piv[0];
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -825,7 +830,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	double l[5];
 #pragma unroll
 	for (int r = 1; r < 5; r++) l[r] = ((r == PV) ? t0[0] : R[r][0]) * rcp;
-	lu_store_urow<SPARSE, TMX_STORE_PRED, TYPE>(piv, pb, AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, TMX_STORE_PRED, TYPE, NTS>(piv, pb, AB, RHS, jcol, NUS, u, umask);
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
 		// after the interchange position r holds old row r, except position PV, which holds old row 0
@@ -847,7 +852,7 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
 // the pivot row); lanes that disagree -- and kernels without the register budget for five specialised tails -- take
 // the per-lane select path below.
-template <int TYPE, bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1, int INK = -1>
+template <int TYPE, bool SPARSE, bool UNI = false, int IS = 1, int EXPECT = -1, int INK = -1, bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b)[5], bool & singular,
 	double * __restrict__ AB, double * __restrict__ RHS, int jcol, int NUS, int u,
 	const double * inrow, double inb, int * umask, int * n_uniform = nullptr)
@@ -878,13 +883,13 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 			if (n_uniform) (*n_uniform)++;      // wave-uniform counter (scalar add): pivot steps that took the renaming path
 			// the usual pivot row of this kind of matrix row first (rho*theta / W / rho rows pivot 4 / 3 / 2 rows down almost
 			// everywhere): one compare and branch instead of the switch's two or three
-			if (EXPECT >= 0 && __builtin_expect(pv0 == EXPECT, 1)) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
+			if (EXPECT >= 0 && __builtin_expect(pv0 == EXPECT, 1)) { lu_pivot_tail_uniform<SPARSE, (EXPECT >= 0 ? EXPECT : 0), IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return; }
 			switch (pv0) {
-				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
-				default: lu_pivot_tail_uniform<SPARSE, 4, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 0: lu_pivot_tail_uniform<SPARSE, 0, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 1: lu_pivot_tail_uniform<SPARSE, 1, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 2: lu_pivot_tail_uniform<SPARSE, 2, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				case 3: lu_pivot_tail_uniform<SPARSE, 3, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
+				default: lu_pivot_tail_uniform<SPARSE, 4, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask); return;
 			}
 		}
 #ifndef TMX_VI_SELECT_PATH
@@ -894,11 +899,11 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		// in the lanes of one tail need not be zero in the others, so the all-lanes ballot of the sparse stores does not
 		// apply).  Unlike the select path -- whose 160 selects per step cost the kernel 30 spilled registers, reloaded in
 		// the uniform tails behind an s_waitcnt vmcnt(0) that also drained the U-row stores -- this adds no live values.
-		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
-		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS, TYPE, INK>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 0) lu_pivot_tail_uniform<false, 0, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 1) lu_pivot_tail_uniform<false, 1, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 2) lu_pivot_tail_uniform<false, 2, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 3) lu_pivot_tail_uniform<false, 3, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
+		if (pv == 4) lu_pivot_tail_uniform<false, 4, IS, TYPE, INK, NTS>(R, b, singular, AB, RHS, jcol, NUS, u, inrow, inb, umask);
 		return;
 #endif
 	}
@@ -916,7 +921,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 		b[r] = sw ? b0 : br;
 	}
 	if (R[0][0] == 0.0) singular = true;
-	lu_store_urow<SPARSE, false, TYPE>(R[0], b[0], AB, RHS, jcol, NUS, u, umask);
+	lu_store_urow<SPARSE, false, TYPE, NTS>(R[0], b[0], AB, RHS, jcol, NUS, u, umask);
 	const double rcp = 1.0 / R[0][0];
 #pragma unroll
 	for (int r = 1; r < 5; r++) {
@@ -950,7 +955,7 @@ __device__ __forceinline__ void lu_pivot_step(double (&R)[5][TMX_BW], double (&b
 // n = 3(L+1).
 struct URow { double u[TMX_BW]; double y, x0; };
 
-template <int COMP>
+template <int COMP, bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS, int u, int col, int NUS,
 	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, const int * umask, const double * zp)
 {
@@ -960,11 +965,11 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 	const double * rb = AB + (size_t)rr * TMX_RS(NUS);
 	double2 v[5];
 #pragma unroll
-	for (int sl = 0; sl < 3; sl++) v[sl] = ustream_load2(rb + sl * 128);
+	for (int sl = 0; sl < 3; sl++) v[sl] = ustream_load2<NTS>(rb + sl * 128);
 #pragma unroll
 	for (int sl = 3; sl < 5; sl++) {
 		const double * bp = (mk & (1 << sl)) ? rb + sl * 128 : zp;
-		v[sl] = ustream_load2(bp);
+		v[sl] = ustream_load2<NTS>(bp);
 	}
 #pragma unroll
 	for (int sl = 0; sl < 5; sl++) {
@@ -1005,6 +1010,7 @@ __device__ __forceinline__ double vi_back_row(const URow & s, double (&xw)[TMX_B
 	return xr;
 }
 
+template <bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int u, int col, int NUS,
 	const double * __restrict__ AB, const double * __restrict__ RHS, const double * xin, double * xup,
 	const int * __restrict__ udep, const int * umask, int zlane = -1)
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ void vi_back_substitute(int L, size_t NS, int n, int 
 	// two trips (six rows) of register sets: a set is refilled for the trip after next right after it is consumed,
 	// so five rows = 55 loads are in flight (vmcnt holds 63) -- the back substitution of a full grid is HBM-bound
 	URow A, B, C, D, E, F;      // A,D: rows 3k+2 (rho); B,E: 3k+1 (W); C,F: 3k (rho*theta)
-#define LOADROW(S, COMP, row) vi_load_urow<COMP>(S, row, L, NS, u, col, NUS, AB, RHS, xin, umask, zp)
+#define LOADROW(S, COMP, row) vi_load_urow<COMP, NTS>(S, row, L, NS, u, col, NUS, AB, RHS, xin, umask, zp)
 	LOADROW(A, 2, n - 1); LOADROW(B, 1, n - 2); LOADROW(C, 0, n - 3);
 	LOADROW(D, 2, n - 4); LOADROW(E, 1, n - 5); LOADROW(F, 0, n - 6);
 	{
@@ -1225,6 +1231,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	constexpr int RD = (NPROD == 2) ? RDT + 1 : RDT;      // (two rows are being written at a time)
 	constexpr int NTHR = PAIRS * 64 * (1 + NPROD);
 	static_assert(NPROD == 1 || (NPROD == 2 && PAIRS == 1 && CLOSED), "two producers: one column group per workgroup, closed-form metric");
+	constexpr bool NTSK = TMX_NTS_DEFAULT && NPROD != 2;      // the small-grid variant's stream stays in the caches (ustream_store2)
 	// Staggered start (stagger = window in units of 10 ns, 0 = off): workgroup i begins i / gridDim.x of the window late.  All
 	// workgroups are resident at once and would otherwise run in lock-step -- every wavefront in its issue- and latency-bound
 	// elimination first, then every wavefront in its HBM-bound back substitution; spread out, the back substitutions of the
@@ -1479,16 +1486,16 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 				R[4][c] = QE(1, c);
 			}
 			b[3] = QF(0); b[4] = QF(1);
-			lu_pivot_step<0, SPARSE, true, 64, -1, 2>(R, b, singular, AB, RHS, 0, NUS, u, q, QF(2), umask, &nuni);      // pivot 0 takes in row 5
+			lu_pivot_step<0, SPARSE, true, 64, -1, 2, NTSK>(R, b, singular, AB, RHS, 0, NUS, u, q, QF(2), umask, &nuni);      // pivot 0 takes in row 5
 		} else
 #ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the hand-over rhythm
 		if (m < 0)
 #endif
 		{
 			// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
-			lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W, 0>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, q, QF(0), umask, &nuni);
-			lu_pivot_step<2, SPARSE, true, 64, TMX_EXPECT_R, 1>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, q, QF(1), umask, &nuni);
-			lu_pivot_step<0, SPARSE, true, 64, TMX_EXPECT_T, 2>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, q, QF(2), umask, &nuni);
+			lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W, 0, NTSK>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, q, QF(0), umask, &nuni);
+			lu_pivot_step<2, SPARSE, true, 64, TMX_EXPECT_R, 1, NTSK>(R, b, singular, AB, RHS, 3 * m - 4, NUS, u, q, QF(1), umask, &nuni);
+			lu_pivot_step<0, SPARSE, true, 64, TMX_EXPECT_T, 2, NTSK>(R, b, singular, AB, RHS, 3 * m - 3, NUS, u, q, QF(2), umask, &nuni);
 		}
 #undef QE
 #undef QF
@@ -1500,11 +1507,11 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 #pragma unroll
 		for (int c = 0; c < TMX_BW; c++) z[c] = 0.0;
 		// the last five rows: n is a multiple of three, so their kinds are W, rho, rho*theta, W, rho
-		lu_pivot_step<1, SPARSE, true>(R, b, singular, AB, RHS, n - 5, NUS, u, z, 0.0, umask, &nuni);
-		lu_pivot_step<2, SPARSE, true>(R, b, singular, AB, RHS, n - 4, NUS, u, z, 0.0, umask, &nuni);
-		lu_pivot_step<0, SPARSE, true>(R, b, singular, AB, RHS, n - 3, NUS, u, z, 0.0, umask, &nuni);
-		lu_pivot_step<1, SPARSE, true>(R, b, singular, AB, RHS, n - 2, NUS, u, z, 0.0, umask, &nuni);
-		lu_pivot_step<2, SPARSE, true>(R, b, singular, AB, RHS, n - 1, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<1, SPARSE, true, 1, -1, -1, NTSK>(R, b, singular, AB, RHS, n - 5, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<2, SPARSE, true, 1, -1, -1, NTSK>(R, b, singular, AB, RHS, n - 4, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<0, SPARSE, true, 1, -1, -1, NTSK>(R, b, singular, AB, RHS, n - 3, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<1, SPARSE, true, 1, -1, -1, NTSK>(R, b, singular, AB, RHS, n - 2, NUS, u, z, 0.0, umask, &nuni);
+		lu_pivot_step<2, SPARSE, true, 1, -1, -1, NTSK>(R, b, singular, AB, RHS, n - 1, NUS, u, z, 0.0, umask, &nuni);
 	}
 #ifdef TMX_PAIR_TIMING
 	const long long tp_fwd = __builtin_readcyclecounter();
@@ -1513,7 +1520,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	// statistics for bench.py (stats = {pivot steps on the wave-uniform path, all pivot steps}, per wavefront)
 	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
 #ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
-	if (BACK) vi_back_substitute(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
+	if (BACK) vi_back_substitute<NTSK>(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
 	else for (int j = lane; j < n; j += 64) gmask[(size_t)grp * n + j] = umask[j];      // this wavefront's own LDS writes: no barrier needed
 #endif
 #ifdef TMX_PAIR_TIMING
