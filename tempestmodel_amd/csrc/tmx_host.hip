@@ -1429,11 +1429,11 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
 	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row" },
-	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 1, "1 (default): every XCD sweeps a contiguous range of tiles" },
+	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 3, "A/B switch, experiments flavour only: 1 (default): every XCD sweeps a contiguous range of tiles" },
 	{ "unique_mixed", "TMX_UNIQUE_MIXED", 0, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
 	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
-	{ "xcd_vertical", "TMX_XCD_VERTICAL", 0, "1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
+	{ "xcd_vertical", "TMX_XCD_VERTICAL", 2, "A/B switch, experiments flavour only: 1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
 	{ "vi_carry", "TMX_VI_CARRY", 2, "column solve: carry shared sub-expressions between block rows (1)" },
 	{ "vi_pair", "TMX_VI_PAIR", 2, "column solve: two-wavefront kernel (-1 auto, 0 one-wavefront kernel, 1 on)" },
 	{ "vi_group", "TMX_VI_GROUP", 0, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
@@ -1443,7 +1443,7 @@ static const OptionDef g_options[] = {
 	{ "vi_producers", "TMX_VI_PRODUCERS", 0, "assembly wavefronts per column group of that kernel: 0 auto (2 on grids that leave every wavefront a SIMD of its own), 1, 2" },
 	{ "vi_split_back", "TMX_VI_SPLIT_BACK", 2, "back substitution as a launch of its own (0)" },
 	{ "vi_back_sub", "TMX_VI_BACK_SUB", 2, "wavefronts per column group of that launch (1)" },
-	{ "vi_stagger", "TMX_VI_STAGGER_NS", 0, "staggered workgroup starts, window in units of 10 ns (0)" },
+	{ "vi_stagger", "TMX_VI_STAGGER_NS", 2, "A/B switch, experiments flavour only: staggered workgroup starts, window in units of 10 ns (0)" },
 	{ "vi_split_kernels", "TMX_VI_MODE", 3, "1: assemble + solve as two kernels (cross-check path)" },
 	{ "vi_sparse", "TMX_VI_SPARSE", 2, "1 (default): U-row entries that are zero in all 64 columns are not stored" },
 	{ "vi_columns_per_wavefront", "TMX_VI_CPW", 1, "columns per wavefront of the two-wavefront kernel (0 = 64)" },
@@ -1454,8 +1454,8 @@ static const OptionDef g_options[] = {
 	{ "hvis_block", "TMX_HVIS_BLOCK", 3, "archived experiment: hyperviscosity passes fused with the in-patch DSS" },
 	{ "split_stage_off", "TMX_NO_SPLIT", 1, "1: no boundary-first stages on several ranks" },
 	{ "metric_stored", "TMX_METRIC", 1, "1: stream the stored 3-D metric arrays even where the closed form is verified" },
-	{ "tracer_lincomb_pass", "TMX_TRACER_LINCOMB_PASS", 0, "1: tracer stage combination by a separate pass (A/B)" },
-	{ "udv_separate", "TMX_UDV_SEPARATE", 0, "1: vertical diffusion of U,V as a pass of its own (A/B)" },
+	{ "tracer_lincomb_pass", "TMX_TRACER_LINCOMB_PASS", 2, "A/B switch, experiments flavour only: 1: tracer stage combination by a separate pass (A/B)" },
+	{ "udv_separate", "TMX_UDV_SEPARATE", 2, "A/B switch, experiments flavour only: 1: vertical diffusion of U,V as a pass of its own (A/B)" },
 	{ "vx_fused", "TMX_VX_FUSED", 2, "1: V.StepExplicit's U,V update inside the explicitly-treated-terms kernel (A/B)" },
 	{ "debug_skip_exchange", "TMX_DEBUG_SKIP_EXCHANGE", 2, "TIMING AID, WRONG RESULTS at rank boundaries: a lone rank engine of an N-rank layout with the wire left out" },
 	{ "exchange_overlap_off", "TMX_NO_EXCHANGE_OVERLAP", 1, "1: the exchange runs on the engine's stream" },
@@ -1465,9 +1465,9 @@ static const OptionDef g_options[] = {
 	{ "vt_explicit_walk", "TMX_VT_WALK", 0, "explicit tracer update: -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the LDS-tiled level-parallel kernel; 4, 5, 6, 8, 10 = that many levels per thread held in registers (experiments build)" },
 	{ "vite_walk", "TMX_VITE_WALK", 0, "explicitly evaluated implicit terms (StepImplicitTermsExplicitly): -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the level-parallel kernel" },
 	{ "vx_walk", "TMX_VX_WALK", 0, "V.StepExplicit's U,V update: -1000 (default) a sliding register window over column segments, their number chosen from the grid size; -n = n segments; 0 = the level-parallel kernel" },
-	{ "vt_lanes", "TMX_VT_LANES", 0, "columns per workgroup of the one-lane tracer column kernel (16)" },
-	{ "vt_lw8", "TMX_VT_LW8", 0, "row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
-	{ "vt_row_lanes", "TMX_VT_NR", 0, "row lanes of that kernel (0 auto)" },
+	{ "vt_lanes", "TMX_VT_LANES", 2, "A/B switch, experiments flavour only: columns per workgroup of the one-lane tracer column kernel (16)" },
+	{ "vt_lw8", "TMX_VT_LW8", 2, "A/B switch, experiments flavour only: row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
+	{ "vt_row_lanes", "TMX_VT_NR", 2, "A/B switch, experiments flavour only: row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
 };
 static void tmx_record_option_defaults(tmx_engine * e) {

@@ -257,7 +257,10 @@ def test_options_are_explicit_and_reported():
         lib.tmx_info.restype = ctypes.c_longlong
         assert lib.tmx_info(h, 18) == 0      # TMX_INFO_EXPERIMENTS_BUILD
         for name, value in ((b"hvis_pull", 1.0), (b"hvis_block", 1.0), (b"vi_pair", 0.0), (b"vi_split_kernels", 1.0), (b"unique_prefix", 1.0),
-                            (b"debug_skip_exchange", 1.0), (b"vx_fused", 1.0), (b"vt_explicit_v1", 1.0), (b"vi_split_back", 1.0)):
+                            (b"debug_skip_exchange", 1.0), (b"vx_fused", 1.0), (b"vt_explicit_v1", 1.0), (b"vi_split_back", 1.0),
+                            # round 5: A/B switches no test of the production library uses went the same way
+                            (b"vi_stagger", 500.0), (b"xcd_vertical", 0.0), (b"unique_xcd_order", 0.0), (b"tracer_lincomb_pass", 1.0),
+                            (b"udv_separate", 1.0), (b"vt_lanes", 32.0), (b"vt_lw8", 1.0), (b"vt_row_lanes", 8.0)):
             assert lib.tmx_set_option(h, name, ctypes.c_double(value)) == -2, name      # TMX_ERR_UNSUPPORTED
             assert b"experiments flavour" in lib.tmx_last_error()
         assert lib.tmx_set_option(h, b"vi_pair", ctypes.c_double(1.0)) == 0 and lib.tmx_set_option(h, b"hvis_pull", ctypes.c_double(0.0)) == 0
