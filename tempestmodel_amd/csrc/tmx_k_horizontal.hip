@@ -922,7 +922,10 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 #ifndef TMX_HV_MINWG
 #define TMX_HV_MINWG 1
 #endif
-template <bool PULL, bool UQ>
+// HB: the launch has a base instance (second pass, or the one-pass order-2 form); without one (first pass: plain Laplacians) the five base
+// values are compile-time zeros instead of registers -- that instantiation then fits its 128 registers without the 20 bytes of scratch
+// (the second pass keeps its 20 bytes: loading two or four of the base values at their point of use instead leaves it at 20 / 44 bytes)
+template <bool PULL, bool UQ, bool HB = true>
 __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) void k_hypervis(KParams p, const double * __restrict__ xsrc,
 	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	// the base of the update (second pass: the instance the viscosity is applied to), loaded with the operands: at the point
 	// of use its latency would follow three barriers and both contractions
 	double bW = 0.0, bT = 0.0, bR = 0.0, bU = 0.0, bV = 0.0;
-	if (xbase && actw) {
+	if (HB && xbase && actw) {
 		bW = xbase[TMX_SLAB_W(L, kk) * SS + uc];
 		if (actn) {
 			bT = xbase[TMX_SLAB_T(L, kk) * SS + uc]; bR = xbase[TMX_SLAB_R(L, kk) * SS + uc];
@@ -1067,7 +1070,8 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
 	if (p.t_ucol) {      // node-unique layout (tmxu_params)
 		KParams q = p; q.u_ntiles = ntiles;
-		hipLaunchKernelGGL((k_hypervis<false, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+		if (xbase) hipLaunchKernelGGL((k_hypervis<false, true, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+		else hipLaunchKernelGGL((k_hypervis<false, true, false>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 	}
 #if TMX_EXP
 	else if (pull_dss) hipLaunchKernelGGL((k_hypervis<true, false>), dim3(ntiles, nyb), blk, 0, e->stream, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
