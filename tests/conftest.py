@@ -15,11 +15,20 @@ def pytest_configure(config):
 def pytest_report_header(config):
     """The tolerance behind every `== exact` assertion of this run (0.0 = identical doubles) goes into the report header, so that a
     log shows whether the suite ran bit for bit or relaxed (tests/golden_util.py: exact_tolerance)."""
+    lines = []
     try:
         import golden_util
-        return "tempestmodel_amd: " + golden_util.exact_tolerance_report()
+        lines.append("tempestmodel_amd: " + golden_util.exact_tolerance_report())
     except Exception as ex:
-        return "tempestmodel_amd: exact-comparison tolerance UNAVAILABLE (%s)" % ex
+        lines.append("tempestmodel_amd: exact-comparison tolerance UNAVAILABLE (%s)" % ex)
+    try:      # the live reference (oracle/_ref, built from /root/reference in the build container): required on a GPU host (TMX_REQUIRE_LIVE_REF)
+        import golden_util
+        ref = os.path.join(ROOT, "oracle", "_ref", "tmx_ref_dump_lapack2")
+        lines.append("tempestmodel_amd: live reference %s, %s" % ("present" if os.path.exists(ref) else "MISSING",
+                     "required (a missing binary fails its tests)" if golden_util.live_reference_required() else "optional (its tests skip without it)"))
+    except Exception:
+        pass
+    return lines
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
