@@ -37,5 +37,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         import golden_util
         if golden_util._EXACT_TOL is not None:      # only when a test of this run asked for it
             terminalreporter.write_line("tempestmodel_amd: " + golden_util.exact_tolerance_report())
+        if golden_util.live_reference_required():      # (a GPU host: say so in -q logs too)
+            ref = os.path.join(ROOT, "oracle", "_ref", "tmx_ref_dump_lapack2")
+            terminalreporter.write_line("tempestmodel_amd: live reference %s and required (TMX_REQUIRE_LIVE_REF)" % ("present" if os.path.exists(ref) else "MISSING"))
     except Exception:
         pass
