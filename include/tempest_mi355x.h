@@ -487,6 +487,10 @@ int tmx_debug_program_prefix(int scheme, int first_step, int last_step, int * pa
 /* Diagnostic builds of the library (-DTMX_H_TIMING) only, zeros otherwise: shader cycles per wavefront of the fused explicit kernel by
  * phase, out[16 instantiations (combination terms)][7 phases + wavefront count] (tools/h_timing.py); the read clears the counters. */
 int tmx_debug_h_timing(tmx_engine * e, unsigned long long * out);
+/* The same for the column-segment walk that runs the explicit stage on the node-unique layout (option "h_walk"; tmx_k_hwalk.hip):
+ * out[16][8], rows = combination terms, columns = prologue, loads issued, pointwise + Exner, contractions, updates, wait for the
+ * combination's terms, seam exchange + stores, wavefront count. */
+int tmx_debug_h_walk_timing(tmx_engine * e, unsigned long long * out);
 
 /* Test hooks (tests/ only): n engines = ranks 0..n-1 of one grid inside ONE process on one device; the
  * RCCL transport is replaced by device-to-device copies in wire order, everything else (packing, ghost

@@ -1422,7 +1422,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
 	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
 	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vite_walk", e->opt_vite_walk); OPT("vx_walk", e->opt_vx_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
-	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows);
+	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows); OPT("h_walk", e->opt_h_walk);
 #undef OPT
 	return nullptr;
 }
@@ -1469,6 +1469,7 @@ static const OptionDef g_options[] = {
 	{ "vt_lw8", "TMX_VT_LW8", 2, "A/B switch, experiments flavour only: row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
 	{ "vt_row_lanes", "TMX_VT_NR", 2, "A/B switch, experiments flavour only: row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
+	{ "h_walk", "TMX_H_WALK", 0, "explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register window, segments per column from the grid size; -n = n segments; 0 = the level-parallel kernel + k_h_w_update" },
 };
 static void tmx_record_option_defaults(tmx_engine * e) {
 	e->opt_default.clear();
@@ -1653,6 +1654,13 @@ extern "C" int tmx_debug_h_timing(tmx_engine * e, unsigned long long * out) {
 	int r; if ((r = check_ready(e))) return r;
 	HIPCHK(hipStreamSynchronize(e->stream));
 	tmxk_h_timing_read(out);
+	return TMX_OK;
+}
+// the same for the column-segment walk (tmx_k_hwalk.hip), [8][8]; padded to [16][8] like the above
+extern "C" int tmx_debug_h_walk_timing(tmx_engine * e, unsigned long long * out) {
+	int r; if ((r = check_ready(e))) return r;
+	HIPCHK(hipStreamSynchronize(e->stream));
+	tmxk_h_walk_timing_read(out);
 	return TMX_OK;
 }
 

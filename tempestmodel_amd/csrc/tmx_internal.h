@@ -281,6 +281,7 @@ struct tmx_engine {
 	int opt_no_split = 0, opt_metric_stored = 0, opt_tracer_lincomb_pass = 0, opt_udv_separate = 0, opt_vx_fused = 0, opt_skip_exchange = 0,
 	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_walk = -1000, opt_vite_walk = -1000, opt_vx_walk = -1000, opt_vt_lanes = 16,
 	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
+	int opt_h_walk = -1000;                  // explicit stage on the node-unique layout: -1000 auto (column-segment walk, segments from the grid size), -n = n segments, 0 = the level-parallel kernel
 	std::vector<int> opt_default;            // default of every option, in g_options order (tmx_record_option_defaults)
 	std::vector<std::string> env_applied;    // "NAME=value" of every environment variable tmx_options_from_environment turned into an option
 	UniqueLayout u;
@@ -332,6 +333,12 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	int nterms = 0, const double * const * src = nullptr, const double * coef = nullptr, int premul = 0,
 	const double * xin_uv = nullptr, const double * xbase_uv = nullptr, const double * const * src_uv = nullptr, const EmitTerms * emit = nullptr,
 	unsigned dmask = 0u);      // dmask: LinTerms::dmask (node-unique kernels: which sources are element-major instances read per copy)
+// the same stage as a column-segment walk (tmx_k_hwalk.hip): node-unique layout, vertical part fused in
+bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit);
+int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles);
+void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt,
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask);
+void tmxk_h_walk_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [8 instantiations][7 phases + count], cleared by the read
 void tmxk_h_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [16 instantiations][7 phases + count], cleared by the read
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);
 void tmxk_v_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_udiff_uv = false);

@@ -1,0 +1,386 @@
+// tmx_k_hwalk.hip -- the explicit stage of the node-unique layout as a COLUMN-SEGMENT WALK (round 6).
+//
+// Same arithmetic, statement for statement, as k_h_explicit<FUSE_V, NT, .., UQ> + k_h_w_update (tmx_k_horizontal.hip):
+// HorizontalDynamicsFEM::StepNonhydrostaticPrimitive (src/atm/HorizontalDynamicsFEM.cpp:848-1421, W on interfaces :1612-1659),
+// VerticalDynamicsFEM::StepExplicit in the implicit mode (src/atm/VerticalDynamicsFEM.cpp:816-828, 984-1023) and the stage's
+// LinearCombineData (src/atm/GridPatch.cpp:1436-1508) -- but a wavefront no longer owns ONE level of its four elements: it walks a
+// segment of levels k0 .. k1-1 upwards.
+//   * the 17 per-column geometry values, the seam tables and the operator rows are loaded once per segment instead of once per level
+//     (16 of the level-parallel kernel's 26 + 5 NT loads per thread and level);
+//   * U, V of the levels k-1, k, k+1, W of the interfaces k, k+1 live in a sliding register window: 5 state loads per level instead of 10;
+//   * the loads of level k+1 and the stage combination's raw terms of level k are issued BEFORE level k's arithmetic (Exner function,
+//     twelve contractions, pointwise updates), so a wavefront waits for memory once per level, behind ~3 000 cycles of its own work;
+//   * xi_dot of interface k+1 is evaluated once (the level-parallel kernel forms it in the wavefronts of both adjacent levels);
+//   * (u x zeta)_xi of the level below stays in a register, so W of EVERY interface is updated here: the segment's first interface from a
+//     recomputed (u x zeta)_xi of level k0-1 (one contraction row: U, V, W of that level are in the window anyway), the bottom boundary
+//     condition from the H-only U, V of levels 0, 1 kept in registers, the rigid lid by the last segment.  k_h_w_update and its hand-over
+//     arrays (ucz, uv01) are not used on this path.
+// One workgroup = one wavefront (no workgroup barrier anywhere); LDS: nine contraction rows (reused by the seam exchange), the
+// operator tables, the exp / log tables of the Exner function.
+#include "tmx_device.h"
+
+#ifdef TMX_H_TIMING
+// shader cycles per wavefront by phase, accumulated over the levels of a segment; one record per wavefront (tools/h_timing.py)
+// [0] prologue (geometry, window, halo level), [1] loads of the next level + combination terms issued, [2] pointwise + Exner + LDS writes,
+// [3] contractions, [4] pointwise updates, [5] wait for the combination's terms + reduce, [6] seam exchange + stores, [7] wavefronts
+#define HW_WAVES 32768
+__device__ unsigned long long g_hw_rec[8][HW_WAVES][8];
+#define HW_DECL long long hw_ = __builtin_readcyclecounter(); long long hws_[7] = { 0, 0, 0, 0, 0, 0, 0 }
+#define HW_MARK(i) do { const long long t1_ = __builtin_readcyclecounter(); hws_[i] += t1_ - hw_; hw_ = t1_; } while (0)
+#define HW_END(NT_) do { if (threadIdx.x == 0) { const unsigned w_ = blockIdx.x % HW_WAVES; \
+	for (int q_ = 0; q_ < 7; q_++) g_hw_rec[(NT_) & 7][w_][q_] = (unsigned long long)hws_[q_]; g_hw_rec[(NT_) & 7][w_][7] = 1ull; } } while (0)
+void tmxk_h_walk_timing_read(unsigned long long * out) {
+	static std::vector<unsigned long long> h((size_t)8 * HW_WAVES * 8);
+	hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_hw_rec), h.size() * sizeof(unsigned long long));
+	for (int i = 0; i < 128; i++) out[i] = 0;
+	for (int nt = 0; nt < 8; nt++) for (int w = 0; w < HW_WAVES; w++) if (h[((size_t)nt * HW_WAVES + w) * 8 + 7])
+		for (int q = 0; q < 8; q++) out[nt * 8 + q] += h[((size_t)nt * HW_WAVES + w) * 8 + q];
+	std::fill(h.begin(), h.end(), 0ull);
+	hipMemcpyToSymbol(HIP_SYMBOL(g_hw_rec), h.data(), h.size() * sizeof(unsigned long long));
+}
+#else
+#define HW_DECL
+#define HW_MARK(i)
+#define HW_END(NT_)
+void tmxk_h_walk_timing_read(unsigned long long * out) { for (int i = 0; i < 128; i++) out[i] = 0; }
+#endif
+
+// where term m of the stage combination reads slab `slab`: node-unique (stride SS, the node's entry) or, DM and bit m of the mask set,
+// the thread's own stored copy of an element-major instance (stride NS, the thread's column)
+template <bool DM>
+__device__ __forceinline__ double term_load(const double * src, unsigned dmask, int m, int slab, size_t SS, size_t NS, unsigned cb, unsigned gb) {
+	const bool d = DM && ((dmask >> m) & 1u);
+	return ldu_term(src + (size_t)slab * (d ? NS : SS), d ? gb : cb);
+}
+template <int NT, bool PM, bool DM>
+__device__ __forceinline__ void terms_load(const double * const (&src)[12], unsigned dmask, int slab, size_t SS, size_t NS, unsigned cb, unsigned gb, double (&x)[NT > 0 ? NT : 1]) {
+	if (NT == 0) { x[0] = term_load<DM>(src[0], dmask, 0, slab, SS, NS, cb, gb); return; }
+#pragma unroll
+	for (int m = 0; m < NT; m++) x[m] = (m > 0 || PM) ? term_load<DM>(src[m], dmask, m, slab, SS, NS, cb, gb) : 0.0;
+}
+
+// Operator rows and the 1 - eta table through the CONSTANT address space: the walk stores results before it loads the next level's
+// coefficients, and a load behind a store that may alias is not a scalar load any more (the compiler fetched every coefficient with a
+// vector load of one address: ~15 vector-memory instructions and 30 registers per level).  The tables are written by tmx_finalize only.
+typedef const double __attribute__((address_space(4))) * tmx_cdp;
+#define OPK(op, k, off) opsc[(((op) * (L + 1)) + (k)) * TMX_OPW + ((off) + 2)]
+
+#ifndef TMX_HW_WAVES_PER_EU
+#define TMX_HW_WAVES_PER_EU 2      // register budget: 256 per lane (the raw terms of a seven-term combination alone are 70 registers in flight)
+#endif
+
+template <int NT, bool PM, bool DM>
+__global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg)
+{
+	__shared__ double s[9][64];
+	__shared__ double sD[16], sS[16];
+	__shared__ double rmtab[TMX_RMTAB_DOUBLES];
+	const int lane = threadIdx.x;
+	HW_DECL;
+	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
+	tmx_rm_tables_to_lds(rmtab, lane, 64);
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS;
+	int tix, seg;
+	if (!wg_tile<true>(p, nseg, tix, seg)) return;
+	const int tile = p.quads ? p.quads[tix] : tix;
+	const int k0 = WAVE_UNIFORM((seg * L) / nseg), k1 = WAVE_UNIFORM(((seg + 1) * L) / nseg);
+	const int col = tile * 64 + lane;
+	const int uc = max(tile_ucol(p, tile, lane), 0);      // padding lanes (a whole element of the last tile): node 0, nothing stored (t_sdst = -1)
+	unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;
+	// the initial instance may be element-major (DM, bit 31): the thread's own copy
+	const bool xd = DM && (xbase.dmask >> 31) != 0u;
+	const size_t SX = xd ? NS : SS;
+	unsigned cx = xd ? gb : cb;
+	const double * __restrict__ xuv = uvt.xin;
+	const unsigned dmask = xbase.dmask;
+	const tmx_cdp opsc = (tmx_cdp)(unsigned long long)p.ops, etac = (tmx_cdp)(unsigned long long)p.eta;
+
+	// ---- per-column constants (once per segment)
+	const double c2a0 = ldu(p.g2d + G2_C2A0 * NS, gb), c2a1 = ldu(p.g2d + G2_C2A1 * NS, gb), c2b1 = ldu(p.g2d + G2_C2B1 * NS, gb);
+	const double jn = ldu(p.g2d + G2_JN * NS, gb), j2d = ldu(p.g2d + G2_J2D * NS, gb), fcor = ldu(p.g2d + G2_F * NS, gb);
+	const MetCol mc = met_col(p, col);
+	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
+	const int sdst = p.t_sdst[col], sred = p.t_sred[col];
+	// ---- window of the first level
+	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
+	{
+		const int km = (k0 > 0) ? k0 - 1 : 0, kp = (k0 < L - 1) ? k0 + 1 : L - 1;
+		uM = ldu(xuv + TMX_SLAB_U(L, km) * SX, cx); u0 = ldu(xuv + TMX_SLAB_U(L, k0) * SX, cx); uP = ldu(xuv + TMX_SLAB_U(L, kp) * SX, cx);
+		vM = ldu(xuv + TMX_SLAB_V(L, km) * SX, cx); v0 = ldu(xuv + TMX_SLAB_V(L, k0) * SX, cx); vP = ldu(xuv + TMX_SLAB_V(L, kp) * SX, cx);
+		w0 = ldu(xin + TMX_SLAB_W(L, k0) * SX, cx); w1 = ldu(xin + TMX_SLAB_W(L, k0 + 1) * SX, cx);
+		t0 = ldu(xin + TMX_SLAB_T(L, k0) * SX, cx); r0 = ldu(xin + TMX_SLAB_R(L, k0) * SX, cx);
+	}
+	const double wH = (k0 > 0) ? ldu(xin + TMX_SLAB_W(L, k0 - 1) * SX, cx) : 0.0;
+	const double invJ = 1.0 / jn;
+	const double fj = fcor * j2d;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	wave_sync();      // operator and exp / log tables are this wavefront's own
+	// ---- (u x zeta)_xi of the level below the segment (:1011-1037, the xi component alone) and xi_dot of the segment's first interface
+	double ucz_prev = 0.0, xlo = 0.0;
+	if (k0 > 0) {
+		const int kh = k0 - 1;
+		double ca2, cb2, cx2, dra, drb;
+		met_eval(mc, etac[kh], ca2, cb2, cx2, dra, drb);
+		double ux = 0.0; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, kh, 0) * wH; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, kh, 1) * w0;
+		const double conUa = c2a0 * uM + c2a1 * vM + ca2 * ux;
+		const double conUb = c2a1 * uM + c2b1 * vM + cb2 * ux;
+		s[2][lane] = ux;
+		wave_sync();
+		double daux = 0, dbux = 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			daux += s[2][eb + 4 * t + j] * sD[t * 4 + i];
+			dbux += s[2][eb + 4 * i + t] * sD[t * 4 + j];
+		}
+		daux *= ida; dbux *= idb;
+		ucz_prev = -conUa * daux - conUb * dbux;
+		double ue = 0.0, ve = 0.0;
+		ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k0, -1) * uM; ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k0, 0) * u0;
+		ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k0, -1) * vM; ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k0, 0) * v0;
+		double e0, e1, e2, ea, eb_;
+		met_eval(mc, etac[L + k0], e0, e1, e2, ea, eb_);
+		xlo = e0 * ue + e1 * ve + e2 * w0;
+		wave_sync();
+	}
+	double uh0 = 0.0, vh0 = 0.0;      // H-only U, V of level 0 (bottom boundary condition of W, :1615-1638)
+	HW_MARK(0);
+
+	constexpr int NX = NT > 0 ? NT : 1;
+	for (int kl = k0; kl < k1; kl++) {
+		// (the level index through readfirstlane: opaque to the loop optimiser, which would otherwise turn every  base + k * stride + lane  into a
+		// per-lane 64-bit induction pointer -- two registers per stream, 10 + 10 NT of them -- instead of scalar base + 32-bit lane offset)
+		const int k = WAVE_UNIFORM(kl);
+		// (and the lane offsets redefined per level: hoisted out of the loop, base + lane becomes one 64-bit register pair per source instance)
+		asm volatile("" : "+v"(cb), "+v"(gb), "+v"(cx));
+		// ---- loads of the next level's window and of this level's combination terms: in flight during this level's arithmetic
+		double uN = uP, vN = vP, wN = 0.0, tN = 0.0, rN = 0.0;
+		if (k + 1 < k1) {
+			const int kpp = (k + 2 < L) ? k + 2 : L - 1;
+			uN = ldu(xuv + TMX_SLAB_U(L, kpp) * SX, cx); vN = ldu(xuv + TMX_SLAB_V(L, kpp) * SX, cx);
+			wN = ldu(xin + TMX_SLAB_W(L, k + 2) * SX, cx);
+			tN = ldu(xin + TMX_SLAB_T(L, k + 1) * SX, cx); rN = ldu(xin + TMX_SLAB_R(L, k + 1) * SX, cx);
+		}
+		double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
+		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_U(L, k), SS, NS, cb, gb, xU);
+		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_V(L, k), SS, NS, cb, gb, xV);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_T(L, k), SS, NS, cb, gb, xT);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_R(L, k), SS, NS, cb, gb, xR);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, (k > 0) ? k : 1), SS, NS, cb, gb, xW);      // (interface 0 has no base: boundary condition)
+		__builtin_amdgcn_sched_barrier(0);
+		HW_MARK(1);
+
+		// ---- level k, pointwise (:884-982)
+		double ca2, cb2, cx2, dra, drb;
+		met_eval(mc, etac[k], ca2, cb2, cx2, dra, drb);
+		double ux = 0.0; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, k, 0) * w0; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, k, 1) * w1;
+		const double conUa = c2a0 * u0 + c2a1 * v0 + ca2 * ux;
+		const double conUb = c2a1 * u0 + c2b1 * v0 + cb2 * ux;
+		const double conUx = ca2 * u0 + cb2 * v0 + cx2 * ux;
+		const double dm = OPK(TMX_OP_DIFF_NODE_TO_NODE, k, -1), d0 = OPK(TMX_OP_DIFF_NODE_TO_NODE, k, 0), dp = OPK(TMX_OP_DIFF_NODE_TO_NODE, k, 1);
+		double dxua = 0.0; dxua += dm * uM; dxua += d0 * u0; dxua += dp * uP;
+		double dxub = 0.0; dxub += dm * vM; dxub += d0 * v0; dxub += dp * vP;
+		// xi_dot on interface k+1 (VerticalDynamicsFEM.cpp:816-828), zero at the lid; interface k's is carried from the level below
+		double xhi = 0.0;
+		if (k + 1 <= L - 1) {
+			double ue = 0.0, ve = 0.0;
+			ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * u0; ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * uP;
+			ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * v0; ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * vP;
+			double e0, e1, e2, ea, eb_;
+			met_eval(mc, etac[L + k + 1], e0, e1, e2, ea, eb_);
+			xhi = e0 * ue + e1 * ve + e2 * w1;
+		}
+		const double w_hi = dt * fabs(xhi), w_lo = dt * fabs(xlo);
+		const double ke = 0.5 * (conUa * u0 + conUb * v0 + conUx * ux);
+		const double exn = exner_from_rhotheta_lds(p, t0, rmtab);
+		const double fa = jn * conUa, fb = jn * conUb;
+		s[0][lane] = u0;  s[1][lane] = v0;  s[2][lane] = ux;
+		s[3][lane] = exn; s[4][lane] = ke;
+		s[5][lane] = fa * r0; s[6][lane] = fa * t0;
+		s[7][lane] = fb * r0; s[8][lane] = fb * t0;
+		wave_sync();
+		HW_MARK(2);
+		// the twelve 4 x 4 contractions in four groups of three (each sum in the level-parallel kernel's order, t = 0 .. 3); the empty asm
+		// statements keep the compiler from issuing all 80 LDS reads at once (160 registers, measured: the loop's pressure peak)
+		double daub = 0, daux = 0, dbua = 0, dbux = 0, dap = 0, dbp = 0, dake = 0, dbke = 0;
+		double darf = 0, dapf = 0, dbrf = 0, dbpf = 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int la = eb + 4 * t + j;        // node (t, j)
+			const double D = sD[t * 4 + i];
+			daub += s[1][la] * D;
+			daux += s[2][la] * D;
+			dap  += s[3][la] * D;
+		}
+		asm volatile("" : "+v"(daub), "+v"(daux), "+v"(dap) : : "memory");      // this group's sums exist before the next group's LDS reads are issued
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int la = eb + 4 * t + j;
+			const double D = sD[t * 4 + i], S = sS[i * 4 + t];
+			dake += s[4][la] * D;
+			darf -= s[5][la] * S;
+			dapf -= s[6][la] * S;
+		}
+		asm volatile("" : "+v"(dake), "+v"(darf), "+v"(dapf) : : "memory");      // this group's sums exist before the next group's LDS reads are issued
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int lb = eb + 4 * i + t;        // node (i, t)
+			const double D = sD[t * 4 + j];
+			dbua += s[0][lb] * D;
+			dbux += s[2][lb] * D;
+			dbp  += s[3][lb] * D;
+		}
+		asm volatile("" : "+v"(dbua), "+v"(dbux), "+v"(dbp) : : "memory");      // this group's sums exist before the next group's LDS reads are issued
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int lb = eb + 4 * i + t;
+			const double D = sD[t * 4 + j], S = sS[j * 4 + t];
+			dbke += s[4][lb] * D;
+			dbrf -= s[7][lb] * S;
+			dbpf -= s[8][lb] * S;
+		}
+		asm volatile("" : "+v"(dbke), "+v"(dbrf), "+v"(dbpf) : : "memory");      // this group's sums exist before the next group's LDS reads are issued
+		HW_MARK(3);
+		daub *= ida; daux *= ida; dbua *= idb; dbux *= idb;
+		darf *= ida; dbrf *= idb; dapf *= ida; dbpf *= idb;
+		dap *= ida; dbp *= idb; dake *= ida; dbke *= idb;
+		// u x zeta (:1011-1037)
+		const double jza = dbux - dxub, jzb = dxua - daux, jzx = daub - dbua;
+		const double ucza = conUb * jzx - conUx * jzb;
+		const double uczb = conUx * jza - conUa * jzx;
+		const double uczx = -conUa * daux - conUb * dbux;
+		// pointwise updates (:1321-1421)
+		double upa = 0.0, upb = 0.0;
+		upa += ucza; upb += uczb;
+		upa += fj * conUb;
+		upb -= fj * conUa;
+		const double pgfa = dap * t0 / r0, pgfb = dbp * t0 / r0;
+		const double daphi = p.grav * dra, dbphi = p.grav * drb;
+		upa -= (pgfa + dake + daphi);
+		upb -= (pgfb + dbke + dbphi);
+		const double tU = dt * upa, tV = dt * upb;
+		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
+		double tUhi = 0, tVhi = 0, tUlo = 0, tVlo = 0;
+		if (k < L - 1) {
+			double b = 0.0;
+			b += OPK(TMX_OP_PENALTY_LEFT, k, 0) * u0; b += OPK(TMX_OP_PENALTY_LEFT, k, 1) * uP;
+			tUhi = b * w_hi;
+			b = 0.0;
+			b += OPK(TMX_OP_PENALTY_LEFT, k, 0) * v0; b += OPK(TMX_OP_PENALTY_LEFT, k, 1) * vP;
+			tVhi = b * w_hi;
+		}
+		if (k > 0) {
+			double b = 0.0;
+			b += OPK(TMX_OP_PENALTY_RIGHT, k, -1) * uM; b += OPK(TMX_OP_PENALTY_RIGHT, k, 0) * u0;
+			tUlo = b * w_lo;
+			b = 0.0;
+			b += OPK(TMX_OP_PENALTY_RIGHT, k, -1) * vM; b += OPK(TMX_OP_PENALTY_RIGHT, k, 0) * v0;
+			tVlo = b * w_lo;
+		}
+		const double tR = dt * invJ * (darf + dbrf), tT = dt * invJ * (dapf + dbpf);
+		// W on interface k (:1612-1659): (u x zeta)_xi of the levels k - 1 and k
+		double tW = 0.0;
+		if (k > 0) {
+			double v = 0.0;
+			v += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k, -1) * ucz_prev;
+			v += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k, 0) * uczx;
+			tW = dt * v;
+		}
+		HW_MARK(4);
+		// ---- the stage combination (reference order), then base + increments in the level-parallel kernel's order
+		const double bU = lin_reduce<NT, PM>(xbase, xU), bV = lin_reduce<NT, PM>(xbase, xV);
+		const double bT = lin_reduce<NT, PM>(xbase, xT), bR = lin_reduce<NT, PM>(xbase, xR), bW = lin_reduce<NT, PM>(xbase, xW);
+		HW_MARK(5);
+		double outU = bU + tU, outV = bV + tV;
+		const double uh = outU, vh = outV;      // H-only values (levels 0, 1: the bottom boundary condition below)
+		if (k < L - 1) { outU += tUhi; outV += tVhi; }
+		if (k > 0) { outU += tUlo; outV += tVlo; }
+		const double outR = bR - tR, outT = bT - tT;
+		const double outW = bW + tW;
+		{
+			const double v[5] = { outU, outV, outR, outT, outW };
+			const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
+			seam_store<5, 64>(p, &s[0], lane, sdst, sred, v, xup, slab, (k > 0) ? 5 : 4);
+		}
+		if (k == 0) { uh0 = uh; vh0 = vh; }
+		if (k == 1) {
+			// bottom boundary: W of interface 0 from the H-only U, V of levels 0 and 1 extrapolated to the surface (:1615-1638)
+			wave_sync();
+			double ub0 = 0.0, vb0 = 0.0;
+			ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * uh0; ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * uh;
+			vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
+			double e0, e1, e2, ea, eb_;
+			met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
+			const double v1[1] = { -(e0 * ub0 + e1 * vb0) / e2 };
+			const int slab1[1] = { TMX_SLAB_W(L, 0) };
+			seam_store<1, 64>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+		}
+		wave_sync();
+		HW_MARK(6);
+		// ---- slide the window
+		uM = u0; u0 = uP; uP = uN; vM = v0; v0 = vP; vP = vN;
+		w0 = w1; w1 = wN; t0 = tN; r0 = rN;
+		ucz_prev = uczx; xlo = xhi;
+	}
+	if (k1 == L) {
+		// the rigid lid: the H step leaves W there alone; the base's value goes through the seam exchange like every other result
+		double xW[NX];
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NS, cb, gb, xW);
+		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
+		const int slab1[1] = { TMX_SLAB_W(L, L) };
+		seam_store<1, 64>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+	}
+	HW_MARK(6);
+	HW_END(NT);
+}
+
+// Does this launch have a walk form?  (node-unique layout with the vertical part fused in, closed-form metric, no stored prefix, up to
+// eight terms; segments of at least two levels so that levels 0 and 1 -- the bottom boundary condition -- belong to one wavefront)
+bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit) {
+	const bool uq = p.t_ucol != nullptr;
+	return uq && fuse_v && !emit && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
+}
+
+// segments per column: enough wavefronts to fill the chip's 2 048 slots at two per SIMD about twice over, at least two levels each
+int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles) {
+	int nseg;
+	if (e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
+	else {
+		nseg = (2 * 2048 + ntiles - 1) / (ntiles > 0 ? ntiles : 1);
+		if (nseg > p.L / 5) nseg = p.L / 5;      // at least five levels per segment: the halo level and the per-segment loads stay below a fifth
+	}
+	if (nseg > p.L / 2) nseg = p.L / 2;
+	if (nseg < 1) nseg = 1;
+	return nseg;
+}
+
+void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask) {
+	LinTerms xbase;
+	UvTerms uvt;
+	xbase.n = nterms; xbase.premul = premul; xbase.dmask = dmask;
+	xbase.src[0] = xbase_ptr; xbase.coef[0] = 0.0;
+	uvt.xin = xin_uv ? xin_uv : xin; uvt.src[0] = xbase_uv ? xbase_uv : xbase_ptr;
+	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
+	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
+	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
+	const int nseg = tmxk_h_walk_segments(e, p, ntile);
+	KParams q = p; q.u_ntiles = ntile;
+	const dim3 blk(64), grd = wg_grid(true, q, ntile, nseg);
+#define LAUNCH_W2(NT_, PM_) do { \
+		if (dmask) hipLaunchKernelGGL((k_h_walk<NT_, PM_, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg); \
+		else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg); } while (0)
+#define LAUNCH_W(NT_) do { if (NT_ == 0 || premul) LAUNCH_W2(NT_, true); else LAUNCH_W2(NT_, false); } while (0)
+	switch (nterms) {
+		case 0: LAUNCH_W(0); break;
+		case 2: LAUNCH_W(2); break;
+		case 3: LAUNCH_W(3); break;
+		case 4: LAUNCH_W(4); break;
+		case 5: LAUNCH_W(5); break;
+		case 6: LAUNCH_W(6); break;
+		case 7: LAUNCH_W(7); break;
+		default: LAUNCH_W(8); break;
+	}
+#undef LAUNCH_W
+#undef LAUNCH_W2
+}
