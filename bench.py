@@ -59,9 +59,9 @@ OP_BOUND = {"h_explicit": "hbm", "dss": "hbm (gathers: partially used sectors)",
 OP_KERNELS = {"h_explicit": ["h_explicit", "v_explicit"], "v_implicit": ["vi_assemble", "vi_solve"],
               "dss": ["dss"], "hypervis": ["hypervis"], "lincomb": ["lincomb"]}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = next((t for t in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
+PROFILE_TAG = next((t for t in ("r06", "r05", "r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
-OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss", "k_dss_u"],
+OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update", "k_h_walk"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss", "k_dss_u"],
               "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
 
 
@@ -322,6 +322,23 @@ def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
             "sypd": dt / tmin / 365.0}
 
 
+def self_launch(n):
+    """Run this script as n ranks under torch.distributed.run (127.0.0.1 rendezvous on a free port) and return the launcher's exit code.
+    stdout of the ranks passes through (rank 0 prints the one JSON line), stderr too.  Nothing in this process has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL / IPC-mapped ghost buffers)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (n, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,8 +371,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` without a launcher: start the ranks ourselves, as a CHILD process, before anything here has
+            # touched the GPU (no exec of a process that initialised HIP), and relay rank 0's JSON line and the launcher's exit code
+            sys.exit(self_launch(args.gpus))
+        sys.exit("bench.py --gpus %d inside a world of %d ranks: --gpus must equal WORLD_SIZE (one rank per GPU)" % (args.gpus, world))
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
@@ -601,8 +621,16 @@ def main():
         op_launches = {op: max(sum(prof[k][1] for k in ks), 1) for op, ks in OP_KERNELS.items()}
         avg_ms = op_time[dom] / op_launches[dom]
         local_points = points / world
-        achieved = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
-        kernel_name = {"h_explicit": "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
+        # headline `achieved` / `frac`: SURVEY 8(d)'s row x the points the kernel really PROCESSES -- unique (node, level) points where the
+        # node-unique layout ran or the operation is the column solve, stored points otherwise; the same row on the stored points (rounds
+        # 1-5's headline) stays beside it as frac_8d_row_on_stored_points
+        proc_points = (eng.info(1) * L) if (eng.info(12) == 1 and unique_after_timed > 0) or dom == "v_implicit" else local_points
+        achieved = ALG_BYTES[dom] * proc_points / (avg_ms * 1e-3) / 1e9
+        achieved_stored = ALG_BYTES[dom] * local_points / (avg_ms * 1e-3) / 1e9
+        op_share = {op: op_time[op] / max(sum(op_time.values()), 1e-12) for op in op_time}
+        dom_op = max(op_share, key=lambda op: op_share[op])
+        walk = eng.get_option("h_walk") != 0 and eng.info(12) == 1 and unique_after_timed > 0
+        kernel_name = {"h_explicit": "k_h_walk<NT> (column-segment walk)" if walk else "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
         if dom == "v_implicit" and eng.info(1) <= 6400:
             kernel_name = "k_vi_group (one column per 16-lane group)"
@@ -665,9 +693,12 @@ def main():
             # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
             "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
                          "kernel": kernel_name, "operation": dom, "dominant_by": dom_note,
+                         "dominant_operation": dom_op, "operation_share_of_kernel_time": {op: round(v, 4) for op, v in op_share.items()},
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "points_processed_per_launch": proc_points, "points_stored": local_points,
+                         "achieved_8d_row_on_stored_points": achieved_stored, "frac_8d_row_on_stored_points": achieved_stored / HBM_PEAK_GBS,
                          "traffic": dom_traffic, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES[dom] * local_points,
+                         "algorithmic_bytes_per_launch": ALG_BYTES[dom] * proc_points,
                          # (1) the same 8(d) row on the points this layout holds (the column solve works on the unique columns, not the stored ones)
                          "achieved_8d_row_on_layout_points": (ALG_BYTES[dom] * (eng.info(1) if (unique_ran or dom == "v_implicit") else eng.info(0)) * L) / (avg_ms * 1e-3) / 1e9,
                          "frac_8d_row_on_layout_points": (ALG_BYTES[dom] * (eng.info(1) if (unique_ran or dom == "v_implicit") else eng.info(0)) * L) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -726,6 +757,10 @@ def main():
             allc = cpu_baseline_allcores(ne, L, dt, 4)              # + 24 ranks on the 24-patch layout where the host has them
             if allc is not None:
                 out["cpu_baseline_allcores"] = allc
+                # the fairest host figure travels INSIDE the cpu_baseline object as well (its headline fields stay the one-core run)
+                out["cpu_baseline"]["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "kind", "sample") if k in allc}
+            if mpi is not None:
+                out["cpu_baseline"]["mpi_6_ranks"] = {k: mpi[k] for k in ("value", "unit", "cores", "kind", "sample") if k in mpi}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()        # peer-to-peer transport: neighbours write into this rank's block until they are done

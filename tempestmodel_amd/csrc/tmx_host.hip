@@ -1428,7 +1428,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 }
 static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
-	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row" },
+	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row, 3 = a generalised Hilbert curve through every patch (4 consecutive elements edge-connected, 16 consecutive ones compact)" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 3, "A/B switch, experiments flavour only: 1 (default): every XCD sweeps a contiguous range of tiles" },
 	{ "unique_mixed", "TMX_UNIQUE_MIXED", 0, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
 	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
@@ -1490,7 +1490,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == dflt || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
 		"tmx_set_option(%s = %d): an archived experiment / cross-check kernel, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", name, iv);
 	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");
-	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2");
+	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 3, TMX_ERR_INVALID, "unique_tile_shape: 0, 1, 2 or 3");
 	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
 	// integer options that select a kernel shape: only the values a launch knows (everything else used to fall through to a default silently)
 	if (n == "vi_group") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vi_group: -1 (auto), 0 or 1");
@@ -1627,7 +1627,7 @@ extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 // early tiles, late tiles); 1 t_dcol; 2 t_ucol; 3 t_sdst; 4 t_sred; 5 gsrc; 6 gdst; 7 gn; 8 slot_ucol; 9 send_slots; 10 u_rep;
 // 11 ucol_of_dcol; 12 per-tile info.  Returns the number of ints written (needed, when out == NULL), -1 on error.
 extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out, int cap) {
-	if (!e || !e->finalized || tile_shape < 0 || tile_shape > 2) return -1;
+	if (!e || !e->finalized || tile_shape < 0 || tile_shape > 3) return -1;
 	PlanHost & plan = plan_of(e);
 	UniqueLayout keep = e->u;
 	e->u = UniqueLayout(); e->u.tile_shape = tile_shape;

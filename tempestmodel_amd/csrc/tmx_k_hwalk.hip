@@ -72,13 +72,17 @@ typedef const double __attribute__((address_space(4))) * tmx_cdp;
 template <int NT, bool PM, bool DM>
 __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg)
 {
-	__shared__ double s[9][64];
+	constexpr int RL = TMX_UQ_ROWLEN(true);
+	__shared__ double s[9][RL];
 	__shared__ double sD[16], sS[16];
 	__shared__ double rmtab[TMX_RMTAB_DOUBLES];
-	const int lane = threadIdx.x;
+	const int lane = tile_lane<true>();      // position e * 16 + i * 4 + j of this thread inside its tile (tmx_device.h: the identity unless TMX_UQ_ROWLANES)
+	const int lp = lds_pos<true>(lane);      // where its values sit in an LDS row
 	HW_DECL;
-	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
-	tmx_rm_tables_to_lds(rmtab, lane, 64);
+	// the exp / log tables (256 + 256 words) on their way to LDS: all eight loads of a lane in flight with the geometry and the first window
+	double tlog[4]; unsigned long long texp[4];
+#pragma unroll
+	for (int t = 0; t < 4; t++) { tlog[t] = tmx_rm_log_tab[t * 64 + threadIdx.x]; texp[t] = tmx_rm_exp_tab[t * 64 + threadIdx.x]; }
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS;
 	int tix, seg;
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 	const double wH = (k0 > 0) ? ldu(xin + TMX_SLAB_W(L, k0 - 1) * SX, cx) : 0.0;
 	const double invJ = 1.0 / jn;
 	const double fj = fcor * j2d;
-	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<true>(lane & 48);
+	if (threadIdx.x < 16) { sD[threadIdx.x] = p.dx[threadIdx.x]; sS[threadIdx.x] = p.stiff[threadIdx.x]; }
+#pragma unroll
+	for (int t = 0; t < 4; t++) { rmtab[t * 64 + threadIdx.x] = tlog[t]; ((unsigned long long *)(rmtab + 256))[t * 64 + threadIdx.x] = texp[t]; }
 	wave_sync();      // operator and exp / log tables are this wavefront's own
 	// ---- (u x zeta)_xi of the level below the segment (:1011-1037, the xi component alone) and xi_dot of the segment's first interface
 	double ucz_prev = 0.0, xlo = 0.0;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		double ux = 0.0; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, kh, 0) * wH; ux += OPK(TMX_OP_INTERP_REDGE_TO_NODE, kh, 1) * w0;
 		const double conUa = c2a0 * uM + c2a1 * vM + ca2 * ux;
 		const double conUb = c2a1 * uM + c2b1 * vM + cb2 * ux;
-		s[2][lane] = ux;
+		s[2][lp] = ux;
 		wave_sync();
 		double daux = 0, dbux = 0;
 #pragma unroll
@@ -194,10 +201,10 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		const double ke = 0.5 * (conUa * u0 + conUb * v0 + conUx * ux);
 		const double exn = exner_from_rhotheta_lds(p, t0, rmtab);
 		const double fa = jn * conUa, fb = jn * conUb;
-		s[0][lane] = u0;  s[1][lane] = v0;  s[2][lane] = ux;
-		s[3][lane] = exn; s[4][lane] = ke;
-		s[5][lane] = fa * r0; s[6][lane] = fa * t0;
-		s[7][lane] = fb * r0; s[8][lane] = fb * t0;
+		s[0][lp] = u0;  s[1][lp] = v0;  s[2][lp] = ux;
+		s[3][lp] = exn; s[4][lp] = ke;
+		s[5][lp] = fa * r0; s[6][lp] = fa * t0;
+		s[7][lp] = fb * r0; s[8][lp] = fb * t0;
 		wave_sync();
 		HW_MARK(2);
 		// the twelve 4 x 4 contractions in four groups of three (each sum in the level-parallel kernel's order, t = 0 .. 3); the empty asm
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		{
 			const double v[5] = { outU, outV, outR, outT, outW };
 			const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
-			seam_store<5, 64>(p, &s[0], lane, sdst, sred, v, xup, slab, (k > 0) ? 5 : 4);
+			seam_store<5, RL>(p, &s[0], lane, sdst, sred, v, xup, slab, (k > 0) ? 5 : 4);
 		}
 		if (k == 0) { uh0 = uh; vh0 = vh; }
 		if (k == 1) {
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 			met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
 			const double v1[1] = { -(e0 * ub0 + e1 * vb0) / e2 };
 			const int slab1[1] = { TMX_SLAB_W(L, 0) };
-			seam_store<1, 64>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+			seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
 		}
 		wave_sync();
 		HW_MARK(6);
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NS, cb, gb, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
-		seam_store<1, 64>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
 	}
 	HW_MARK(6);
 	HW_END(NT);
@@ -341,13 +348,24 @@ bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nte
 	return uq && fuse_v && !emit && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
 }
 
-// segments per column: enough wavefronts to fill the chip's 2 048 slots at two per SIMD about twice over, at least two levels each
-int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles) {
-	int nseg;
+// Segments per column.  One wavefront per segment, two resident per SIMD (256 registers), three for the plain stage and the two-term
+// combination (168): the count whose wavefronts fill the chip's slots most evenly -- whole rounds, or many of them -- with at least five
+// levels each; every segment costs a halo level and its own loads (geometry, tables, first window), priced at 2 % of the launch per segment
+// (measured: ne30 3 / 4 / 6 segments 0.404 / 0.430 / 0.415 ms per step; the 8-rank share of ne30, 169 tiles, 6 / 10 / 15 segments 0.178 /
+// 0.148 / 0.129 against 0.151 of the level-parallel kernel: a small grid wants short segments, i.e. wavefronts on every SIMD).
+int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms) {
+	int nseg = 1;
 	if (e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
 	else {
-		nseg = (2 * 2048 + ntiles - 1) / (ntiles > 0 ? ntiles : 1);
-		if (nseg > p.L / 5) nseg = p.L / 5;      // at least five levels per segment: the halo level and the per-segment loads stay below a fifth
+		static int cus = 0;      // (one device kind per process)
+		if (!cus) { int dev = 0, n = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+		const double slots = (double)cus * 4 * (nterms <= 2 ? 3 : 2);
+		double best = -1.0;
+		for (int n = 1; n <= p.L / 2 || n == 1; n++) {
+			const double rounds = (double)ntiles * n / slots;
+			const double eff = rounds / (double)(long long)(rounds + 0.999999) - 0.02 * n - (rounds < 1.0 ? 0.25 * (1.0 - rounds) : 0.0);      // fill of the last round; a per-segment cost; idle SIMDs
+			if (eff > best) { best = eff; nseg = n; }
+		}
 	}
 	if (nseg > p.L / 2) nseg = p.L / 2;
 	if (nseg < 1) nseg = 1;
@@ -364,7 +382,7 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
-	const int nseg = tmxk_h_walk_segments(e, p, ntile);
+	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms);
 	KParams q = p; q.u_ntiles = ntile;
 	const dim3 blk(64), grd = wg_grid(true, q, ntile, nseg);
 #define LAUNCH_W2(NT_, PM_) do { \

@@ -12,6 +12,36 @@
 #include <cstring>
 #include <map>
 
+// Generalised Hilbert curve over a w x h rectangle (the construction published as "gilbert": recursive halving along the longer
+// side, odd halves rounded so that the curve stays continuous; a diagonal step can occur only on odd x odd rectangles).  Any run of
+// consecutive cells is a compact region at ANY offset -- which is what the thread order needs: 4 consecutive elements (a wavefront)
+// are edge-connected, 16 consecutive ones (a workgroup's block) have the perimeter of a 4 x 4 block give or take a cell.
+static int floor_half(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
+static int sign_of(int v) { return (v > 0) - (v < 0); }
+static void gilbert_rec(int x, int y, int ax, int ay, int bx, int by, std::vector<std::pair<int, int>> & out) {
+	const int w = std::abs(ax + ay), h = std::abs(bx + by);
+	const int dax = sign_of(ax), day = sign_of(ay), dbx = sign_of(bx), dby = sign_of(by);
+	if (h == 1) { for (int q = 0; q < w; q++) { out.push_back({ x, y }); x += dax; y += day; } return; }
+	if (w == 1) { for (int q = 0; q < h; q++) { out.push_back({ x, y }); x += dbx; y += dby; } return; }
+	int ax2 = floor_half(ax), ay2 = floor_half(ay), bx2 = floor_half(bx), by2 = floor_half(by);
+	const int w2 = std::abs(ax2 + ay2), h2 = std::abs(bx2 + by2);
+	if (2 * w > 3 * h) {
+		if ((w2 % 2) && w > 2) { ax2 += dax; ay2 += day; }
+		gilbert_rec(x, y, ax2, ay2, bx, by, out);
+		gilbert_rec(x + ax2, y + ay2, ax - ax2, ay - ay2, bx, by, out);
+	} else {
+		if ((h2 % 2) && h > 2) { bx2 += dbx; by2 += dby; }
+		gilbert_rec(x, y, bx2, by2, ax2, ay2, out);
+		gilbert_rec(x + bx2, y + by2, ax, ay, bx - bx2, by - by2, out);
+		gilbert_rec(x + (ax - dax) + (bx2 - dbx), y + (ay - day) + (by2 - dby), -bx2, -by2, -(ax - ax2), -(ay - ay2), out);
+	}
+}
+static std::vector<std::pair<int, int>> gilbert_order(int w, int h) {
+	std::vector<std::pair<int, int>> out;
+	if (w >= h) gilbert_rec(0, 0, w, 0, 0, h, out); else gilbert_rec(0, 0, 0, h, w, 0, out);
+	return out;
+}
+
 template <class T> static int up(T ** d, const std::vector<T> & h, size_t * bytes) {
 	const size_t n = h.size() ? h.size() : 1;
 	HIPCHK(hipMalloc((void **)d, n * sizeof(T)));
@@ -86,6 +116,12 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 			}
 		}
 		telem.insert(telem.end(), left.begin(), left.end());
+	} else if (u.tile_shape == 3) {
+		// a space-filling curve through every patch (x = beta element, y = alpha element)
+		for (int p : e->local_patches) {
+			const PatchInfo & P = e->patches[p];
+			for (const std::pair<int, int> & c : gilbert_order(P.neb, P.nea)) telem.push_back(P.elem_base + c.second * P.neb + c.first);
+		}
 	} else {
 		for (int q = 0; q < e->ne_local; q++) telem.push_back(q);
 	}

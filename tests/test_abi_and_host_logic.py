@@ -293,7 +293,7 @@ def _unique_tables(e, shape):
 
 
 @pytest.mark.parametrize("ne,npatch,n_ranks", [(5, 6, 1), (6, 24, 1), (12, 24, 3), (7, 6, 1)])
-@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
 def test_unique_layout_tables(ne, npatch, n_ranks, shape):
     """Host logic of the node-unique layout (tmxu_tables), on plan-only engines: every unique node is stored by exactly one place
     -- one lane of one tile (alone, or averaging the copies its wavefront holds), or the DSS kernel through the partial slots of all

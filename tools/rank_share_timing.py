@@ -13,6 +13,7 @@ from tempestmodel_amd.engine import Engine
 grid = CubedSphereGrid(30, 30, 30000.0, ppd=2)
 states = grid.evaluate_test_case(BaroclinicWaveJW(0.0, 30000.0, "exp"))
 shares = {}
+kernels = {}
 RANKS = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]      # e.g. `rank_share_timing.py 8` under rocprofv3
 for n in RANKS:
     e = Engine(grid, rank=0, n_ranks=n)
@@ -33,6 +34,7 @@ for n in RANKS:
     print("ranks %d: rank-0 share %d patches, %.3f ms/step without the wire" % (n, len(e.local_patches), 1e3 * wall),
           {k: round(v[0] / 10, 3) for k, v in prof.items() if v[1]})
     shares[n] = 1e3 * wall
+    kernels[n] = {k: round(v[0] / 10, 4) for k, v in prof.items() if v[1]}
     e.close()
 # Critical-path estimate of an N-rank step: the per-rank compute share measured above + the part of the six exchanges per
 # ARS343 step that the boundary-first launch order does not hide.  The wire itself cannot be measured on a one-GPU box; the
@@ -43,3 +45,10 @@ if 1 in shares:
         print("exposed exchange latency %2.0f us x 6 per step:" % tx,
               "  ".join("N=%d %.3f ms -> speed-up %.2f" % (n, shares[n] + (6 * tx * 1e-3 if n > 1 else 0.0),
                                                           shares[1] / (shares[n] + (6 * tx * 1e-3 if n > 1 else 0.0))) for n in sorted(shares)))
+
+# machine-readable copy (bench.py's N > 1 lines quote it as multi_rank.projected_from_rank_share): TMX_RANK_SHARE_JSON=<path>
+if os.environ.get("TMX_RANK_SHARE_JSON"):
+    import json
+    json.dump({"what": "compute share of rank 0 of an N-rank ne30 np4 L30 ARS343 step on ONE MI355X, wire left out (tools/rank_share_timing.py)",
+               "ms_per_step": {str(n): shares[n] for n in sorted(shares)}, "kernel_ms_per_step": {str(n): kernels[n] for n in sorted(kernels)}},
+              open(os.environ["TMX_RANK_SHARE_JSON"], "w"), indent=1)
