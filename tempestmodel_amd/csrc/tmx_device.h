@@ -498,3 +498,44 @@ __device__ __forceinline__ void seam_store(const KParams & p, double (*srow)[RL]
 		for (int t = 0; t < NV; t++) if (t < nv) p.part[(size_t)slab[t] * p.NP + q] = o[t];
 	}
 }
+
+// Seam exchange of a BLOCK: the workgroup's (up to) four wavefronts hold a block of the thread order; a node whose copies all sit in the
+// block is averaged here (reference order, as seam_store), whichever wavefronts hold them.  xrow: [6][256] doubles of LDS shared by the
+// workgroup, one of two buffers alternating by level, so that ONE barrier per level orders everything: a wavefront that writes buffer b
+// for level k + 2 has passed the barrier of level k + 1, which every wavefront reaches only after its reads of level k (buffer b).
+// The barrier waits for LDS traffic only (s_waitcnt lgkmcnt(0)): __syncthreads() would also drain vmcnt, i.e. wait for the prefetched
+// next level and the combination's terms in flight -- the very loads the walk issues early.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int NV>
+__device__ __forceinline__ void block_seam_store(const KParams & p, double (*xrow)[256], int pos, int sdst, int sred, const double (&v)[NV],
+	double * __restrict__ xo, const int (&slab)[NV], unsigned vmask)
+{
+#pragma unroll
+	for (int t = 0; t < NV; t++) if ((vmask >> t) & 1u) xrow[t][pos] = v[t];
+	lds_barrier();
+	if (sdst == -1) return;
+	const int n = sred & 15;
+	double o[NV];
+#pragma unroll
+	for (int t = 0; t < NV; t++) o[t] = v[t];
+	if (n == 2) {
+		const int l1 = (sred >> 4) & 255;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if ((vmask >> t) & 1u) o[t] = 0.5 * (v[t] + xrow[t][l1]);
+	} else if (n == 4) {
+		const int l1 = (sred >> 4) & 255, l2 = (sred >> 12) & 255, l3 = (sred >> 20) & 255;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if ((vmask >> t) & 1u) {
+			const double p0 = v[t] + xrow[t][l1], p1 = xrow[t][l2] + xrow[t][l3];
+			o[t] = 0.5 * (0.5 * p0 + 0.5 * p1);
+		}
+	}
+	if (sdst >= 0) {
+#pragma unroll
+		for (int t = 0; t < NV; t++) if ((vmask >> t) & 1u) xo[(size_t)slab[t] * p.NSS + sdst] = o[t];
+	} else {
+		const int q = -2 - sdst;
+#pragma unroll
+		for (int t = 0; t < NV; t++) if ((vmask >> t) & 1u) p.part[(size_t)slab[t] * p.NP + q] = o[t];
+	}
+}

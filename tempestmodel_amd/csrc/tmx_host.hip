@@ -901,6 +901,11 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	    !e->hvis_pull && !e->hvis_block && !e->use_graph && !e->use_mfma && e->vi_mode == 0) {
 		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
 		if ((r = tmxu_build(e, in, &bytes))) return r;
+		if (e->u.NTS > NS) {      // the block thread order pads: the level-parallel kernels' hand-over arrays are indexed by thread
+			hipFree(e->d_scratch); e->d_scratch = nullptr;
+			HIPCHK(hipMalloc((void **)&e->d_scratch, (size_t)(L + 4) * e->u.NTS * sizeof(double))); bytes += (size_t)(L + 4) * (e->u.NTS - NS) * sizeof(double);
+			HIPCHK(hipMemset(e->d_scratch, 0, (size_t)(L + 4) * e->u.NTS * sizeof(double)));
+		}
 	}
 	e->hbm_bytes = bytes;
 	// host staging no longer needed
@@ -1411,7 +1416,7 @@ extern "C" int tmx_halo_p2p_reset(tmx_engine * e) {
 struct OptionDef { const char * name; const char * env; int kind; const char * help; };
 static int * option_slot(tmx_engine * e, const std::string & n) {
 #define OPT(NAME_, FIELD_) if (n == NAME_) return &(FIELD_)
-	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_mixed", e->u.mixed_option); OPT("unique_prefix", e->u.prefix_option);
+	OPT("unique_layout", e->u.option); OPT("unique_tile_shape", e->u.tile_shape); OPT("unique_blocks", e->u.block_option); OPT("unique_xcd_order", e->u.xcd_order); OPT("unique_mixed", e->u.mixed_option); OPT("unique_prefix", e->u.prefix_option);
 	OPT("share_copies", e->share_copies); OPT("xcd_vertical", e->xcd_vertical);
 	OPT("vi_carry", e->vi_carry); OPT("vi_pair", e->vi_pair); OPT("vi_group", e->vi_group); OPT("vi_group_max", e->vi_group_max);
 	OPT("vi_pair_workgroup", e->vi_pair_wg); OPT("vi_producers", e->vi_producers); OPT("vi_ring_depth", e->vi_ring_depth); OPT("vi_split_back", e->vi_split_back); OPT("vi_back_sub", e->vi_back_sub);
@@ -1428,10 +1433,11 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 }
 static const OptionDef g_options[] = {
 	{ "unique_layout", "TMX_UNIQUE", 1, "node-unique state layout inside tmx_step: -1 default (= 1), 0 off, 1 on where eligible" },
-	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row, 3 = a generalised Hilbert curve through every patch (4 consecutive elements edge-connected, 16 consecutive ones compact)" },
+	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row; experiments flavour only: 3 = a generalised Hilbert curve through every patch, 4 = 4 x 4 element blocks of 1 x 4 strips" },
+	{ "unique_blocks", "TMX_UNIQUE_BLOCKS", 2, "archived experiment (round 6: the DSS loses 0.05 ms per step, the producers pay 0.10): block kernels on that layout -- a workgroup of four wavefronts averages the seams between them through LDS, the DSS kernel finishes fewer nodes: -1 (default) on with unique_tile_shape 4, 0 off, 1 on with any thread order" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 3, "A/B switch, experiments flavour only: 1 (default): every XCD sweeps a contiguous range of tiles" },
 	{ "unique_mixed", "TMX_UNIQUE_MIXED", 0, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
-	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 2, "1: an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (0 = default: measured neutral)" },
+	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 0, "1 (default): an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (ARS343: the fourth stage reads 3 instances instead of 7); 0: every stage reads all its terms" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
 	{ "xcd_vertical", "TMX_XCD_VERTICAL", 2, "A/B switch, experiments flavour only: 1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
 	{ "vi_carry", "TMX_VI_CARRY", 2, "column solve: carry shared sub-expressions between block rows (1)" },
@@ -1490,7 +1496,11 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(TMX_EXP || !(def->kind & 2) || iv == dflt || (n == "vi_pair" && iv != 0), TMX_ERR_UNSUPPORTED,      // (vi_pair: -1 and 1 both mean the production kernel)
 		"tmx_set_option(%s = %d): an archived experiment / cross-check kernel, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", name, iv);
 	if (n == "unique_layout") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_layout: -1 (default), 0 or 1");
-	if (n == "unique_tile_shape") REQUIRE(iv >= 0 && iv <= 3, TMX_ERR_INVALID, "unique_tile_shape: 0, 1, 2 or 3");
+	if (n == "unique_tile_shape") {
+		REQUIRE(iv >= 0 && iv <= 4, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2 (3, 4: experiments flavour of the library)");
+		REQUIRE(TMX_EXP || iv <= 2, TMX_ERR_UNSUPPORTED, "tmx_set_option(unique_tile_shape = %d): an archived experiment, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", iv);
+	}
+	if (n == "unique_blocks") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_blocks: -1 (auto), 0 or 1");
 	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
 	// integer options that select a kernel shape: only the values a launch knows (everything else used to fall through to a default silently)
 	if (n == "vi_group") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vi_group: -1 (auto), 0 or 1");
@@ -1504,7 +1514,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;
@@ -1627,7 +1637,7 @@ extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 // early tiles, late tiles); 1 t_dcol; 2 t_ucol; 3 t_sdst; 4 t_sred; 5 gsrc; 6 gdst; 7 gn; 8 slot_ucol; 9 send_slots; 10 u_rep;
 // 11 ucol_of_dcol; 12 per-tile info.  Returns the number of ints written (needed, when out == NULL), -1 on error.
 extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what, int * out, int cap) {
-	if (!e || !e->finalized || tile_shape < 0 || tile_shape > 3) return -1;
+	if (!e || !e->finalized || tile_shape < 0 || tile_shape > 4) return -1;
 	PlanHost & plan = plan_of(e);
 	UniqueLayout keep = e->u;
 	e->u = UniqueLayout(); e->u.tile_shape = tile_shape;
@@ -1639,7 +1649,9 @@ extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what,
 	if (r) return -1;
 	std::vector<int> v;
 	switch (what) {
-		case 0: v = { u.NU, u.NUS, u.NTS, u.nslots, u.ngroups, u.ngroups_local, u.n_early, u.n_late }; break;
+		case 0: v = { u.NU, u.NUS, u.NTS, u.nslots, u.ngroups, u.ngroups_local, u.n_early, u.n_late, u.b_ngroups, u.b_ngroups_local, u.nblocks, u.nb_early, u.nb_late }; break;
+		case 13: v = T.b_sdst; break; case 14: v = T.b_sred; break; case 15: v = T.blk_info; break; case 16: v = T.b_gsrc; break; case 17: v = T.b_gdst; break; case 18: v = T.b_gn; break;
+		case 19: v = T.blks_early; break; case 20: v = T.blks_late; break;
 		case 1: v = T.t_dcol; break; case 2: v = T.t_ucol; break; case 3: v = T.t_sdst; break; case 4: v = T.t_sred; break;
 		case 5: v = T.gsrc; break; case 6: v = T.gdst; break; case 7: v = T.gn; break; case 8: v = T.slot_ucol; break;
 		case 9: v = T.send_slots; break; case 10: v = T.u_rep; break; case 11: v = T.ucol_of_dcol; break; case 12: v = T.tinfo; break;

@@ -67,6 +67,13 @@ struct KParams {
 	const int * t_sred;     // [NS] n | lane1 << 4 | lane2 << 10 | lane3 << 16: average with the copies held by these lanes of the wavefront (n = 0, 2, 4)
 	double * part;          // [nslab][NP] partial slots
 	int NP;
+	// block kernels (a workgroup = up to four wavefronts = one block of the thread order averages the seams between its wavefronts through LDS):
+	int NSD;                // slab stride of ELEMENT-MAJOR instances (mixed reads): the thread space may be padded beyond it
+	const int * t_dcol;     // [NS] stored (element-major) column of a thread, -1: padding -- where a mixed read finds the thread's own copy
+	const int * b_sdst;     // [NS] as t_sdst with the block's averaging done: fewer partial slots
+	const int * b_sred;     // [NS] n | pos1 << 4 | pos2 << 12 | pos3 << 20, positions 64 * wavefront + lane inside the block
+	const int * blk_info;   // [blocks] first wavefront (tile) * 8 + wavefronts
+	const int * bquads;     // not null: blockIdx.x indexes this list of blocks (boundary-first launches)
 	double dx[16];          // dx[s*4+i]    = dDxBasis1D(s,i)
 	double stiff[16];       // stiff[i*4+s] = dStiffness1D(i,s)
 };
@@ -100,10 +107,17 @@ struct ProfSlot { double ms = 0.0; long long n = 0; };
 struct UniqueLayout {
 	bool built = false;
 	int option = -1;                         // tmx_set_option("unique_layout"): -1 default (= on where the configuration is eligible), 0 off, 1 on where eligible
-	int tile_shape = 0;                      // T order: 0 = the element-major order (1 x 4 element strips that wrap around patch rows), 1 = 2 x 2 element blocks, 2 = 1 x 4 strips inside a patch row
+	int tile_shape = 0;                      // T order: 0 = the element-major order (1 x 4 element strips that wrap around patch rows), 1 = 2 x 2 element blocks, 2 = 1 x 4 strips inside a patch row,
+	                                         // 3 = a generalised Hilbert curve, 4 = 4 x 4 element blocks of 1 x 4 strips (padded at ragged patch edges)
 	int xcd_order = 1;                       // workgroup -> tile map of the U kernels: 1 = every XCD sweeps a contiguous range of tiles
 	int NU = 0, NUS = 0, NTS = 0, nslots = 0, NP = 0;
 	int ngroups = 0, ngroups_local = 0;      // groups left to the DSS kernel (not averaged inside a wavefront); [0, ngroups_local): no remote member
+	// the same behind a block kernel (groups no workgroup averaged), the blocks themselves, and which kind of kernel filled the partial slots last
+	int b_ngroups = 0, b_ngroups_local = 0, nblocks = 0, nb_early = 0, nb_late = 0;
+	int * d_b_sdst = nullptr, * d_b_sred = nullptr, * d_blk_info = nullptr, * d_b_gsrc = nullptr, * d_b_gdst = nullptr, * d_b_gn = nullptr, * d_b_gx = nullptr, * d_b_gtype = nullptr;
+	int * d_blks_early = nullptr, * d_blks_late = nullptr;
+	bool slots_by_blocks = false;            // the partial slots in memory were written by block kernels: the DSS runs the shorter list
+	int block_option = -1;                   // tmx_set_option("unique_blocks"): -1 auto (on with the block thread order), 0 off, 1 on
 	size_t ustride = 0;                      // doubles per U-form instance (nslab * NUS)
 	double * d_ustate = nullptr, * d_part = nullptr, * d_g2d_t = nullptr, * d_g2d_u = nullptr;
 	int * d_t_ucol = nullptr, * d_t_sdst = nullptr, * d_t_sred = nullptr;      // [NTS]
@@ -123,9 +137,11 @@ struct UniqueLayout {
 	// becomes the instance's
 	std::vector<int> uslot; int uspare = 0;
 	// and one more for the prefix of a later stage's combination that an explicit stage forms from the instances it reads anyway
-	// (EmitTerms below, prefix_plan in tmx_step.hip); prefix_option: tmx_set_option("unique_prefix"), 0 = default -- measured: the
-	// store of the prefix costs the producing stage what the consuming stage saves (ARS343, ne30 L30: 186.8 + 122.2 us against 144.1 + 166.7 us)
-	int uprefix = 0, prefix_option = 0;
+	// (EmitTerms below, prefix_plan in tmx_step.hip); prefix_option: tmx_set_option("unique_prefix"), 1 = default since round 6 -- with the
+	// level-parallel kernel the store of the prefix cost the producing stage what the consuming stage saved (ARS343, ne30 L30: 186.8 + 122.2 us
+	// against 144.1 + 166.7 us); the column-segment walk is bound by its streams, and 4 source instances less are 0.02-0.03 ms per step
+	int uprefix = 0, prefix_option = 1;
+	long long prefix_for = -1;               // operation index of the stage the stored prefix belongs to (-1: none stored)
 	long long prefix_stages = 0;             // stages that started from a stored prefix (tmx_info)
 	int n_uform = 0;
 	long long conversions = 0;               // D <-> U conversions performed (tmx_info)
@@ -239,6 +255,7 @@ struct tmx_engine {
 	int vi_pair = -1;                        // two-wavefront column kernel (assembly || elimination): -1 auto (small grids), 0 off, 1 on (TMX_VI_PAIR)
 	// boundary-first launches (ranks > 1): 64-column tiles holding a column another rank needs, and the others
 	int * d_quads_early = nullptr, * d_quads_late = nullptr; int n_quads_early = 0, n_quads_late = 0, launch_tiles = 0; bool split_stage = false, split_overlapped = false;
+	int launch_blocks = 0;                   // blocks of the launch in progress (KParams::bquads), node-unique layout
 	std::vector<struct tmx_interp *> interps;          // output-interpolation plans created on this engine and not yet destroyed
 	double * d_image = nullptr; size_t image_n = 0;     // restart image of one patch (tmx_pack_active_state), grown on demand
 	double strang_offc = 0.0;                          // TimestepSchemeStrang off-centering (tmx_set_strang_off_centering)
@@ -301,17 +318,19 @@ struct UniquePlanInput {      // what tmx_finalize hands over: the DSS groups in
 };
 struct UniqueTables {         // the host-side tables of the layout (tmxu_tables); thread space T = [tile][64], unique space U
 	std::vector<int> t_dcol, t_ucol, t_sdst, t_sred, tinfo, ucol_of_dcol, u_rep, slot_ucol, gsrc, gdst, gn, gx, gt, send_slots, quads_early, quads_late;
+	std::vector<int> blk_first, blk_nt, blk_info, b_sdst, b_sred, b_gsrc, b_gdst, b_gn, b_gx, b_gt, blks_early, blks_late;      // block level
 };
 int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T);      // host only (works on plan-only engines)
 int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes);
 void tmxu_free(tmx_engine * e);
 KParams tmxu_params(const tmx_engine * e, const KParams & base);          // thread space T, state in U slabs
+// block kernels (archived experiment, round 6): compiled into the experiments flavour of the library only
 KParams tmxu_params_columns(const tmx_engine * e, const KParams & base);  // one thread per unique column (column solve)
 int tmxu_to_u(tmx_engine * e, int slot, bool check, bool * consistent);   // D form -> U form of one slot (check: verify that the copies agree)
 int tmxu_check(tmx_engine * e, int slot, bool * consistent);              // do the copies of every node of an element-major slot agree?
 int tmxu_to_d(tmx_engine * e, int slot, bool keep_u = false);                                  // U form -> D form
 void tmxuk_slots_from_u(tmx_engine * e, const double * xu);               // partial slots <- the values of their nodes (DSS of an instance that is already consistent inside patches)
-void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1);              // finish the seam nodes left in the partial slots
+void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1, bool blocks = false);   // finish the seam nodes left in the partial slots (blocks: the list behind block kernels)
 void tmxuk_pack(tmx_engine * e);                                          // partial slots other ranks need -> send buffer
 void tmxuk_pack_p2p(tmx_engine * e, int buf);
 int tmxu_physics_inputs(tmx_engine * e, bool * ok);                       // refresh the per-unique-column physics inputs; *ok: the copies of every node agree
@@ -325,6 +344,7 @@ void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu
 #else
 #define TMX_EXP 0
 #endif
+static inline bool tmxu_blocks_on(const tmx_engine * e) { return TMX_EXP && e->u.built && (e->u.block_option == 1 || (e->u.block_option < 0 && e->u.tile_shape == 4)); }
 
 // kernel launchers (tmx_k_*.hip)
 // the prefix of a later stage's combination that an explicit stage also forms and stores (emit_value in tmx_device.h)
@@ -337,7 +357,8 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit);
 int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms);
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt,
-	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask);
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
+	const EmitTerms * emit = nullptr);
 void tmxk_h_walk_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [8 instantiations][7 phases + count], cleared by the read
 void tmxk_h_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [16 instantiations][7 phases + count], cleared by the read
 void tmxk_sw_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt);

@@ -508,8 +508,8 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv,
 	const EmitTerms * emit, unsigned dmask) {
 	// node-unique layout, vertical part fused in: the column-segment walk (tmx_k_hwalk.hip) does the whole stage, W of every interface included
-	if (tmxk_h_walk_ok(e, p, fuse_v, nterms, TMX_EXP && emit && emit->xp)) {
-		tmxk_h_walk(e, p, xin, xbase_ptr, xup, dt, nterms, src, coef, premul, xin_uv, xbase_uv, src_uv, dmask);
+	if (tmxk_h_walk_ok(e, p, fuse_v, nterms, emit && emit->xp)) {
+		tmxk_h_walk(e, p, xin, xbase_ptr, xup, dt, nterms, src, coef, premul, xin_uv, xbase_uv, src_uv, dmask, emit);
 		return;
 	}
 	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels
@@ -522,6 +522,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	const bool uq = p.t_ucol != nullptr;      // node-unique layout (tmxu_params): 1-D launches, XCD-aware tile order
+	if (uq) e->u.slots_by_blocks = false;      // (wavefront-level seam exchange: the DSS kernel runs its full list)
 	KParams q = p; q.u_ntiles = ntile;
 	const int wstride = TMX_H_FUSE_W ? KT_H : 1;
 	const int nyb = (p.L + KT_H - 1) / KT_H, nyb2 = ((p.L + wstride - 1) / wstride + 1 + 3) / 4;
@@ -930,14 +931,17 @@ __device__ __forceinline__ void dss_pull_fields(const KParams & p, const DssPull
 // HB: the launch has a base instance (second pass, or the one-pass order-2 form); without one (first pass: plain Laplacians) the five base
 // values are compile-time zeros instead of registers -- that instantiation then fits its 128 registers without the 20 bytes of scratch
 // (the second pass keeps its 20 bytes: loading two or four of the base values at their point of use instead leaves it at 20 / 44 bytes)
-template <bool PULL, bool UQ, bool HB = true>
+// BLK (with UQ): the workgroup's four wavefronts are the wavefronts of ONE BLOCK of the thread order at ONE level (instead of one wavefront's
+// tile at four levels); the seams between them are averaged through LDS (block_seam_store, tmx_device.h), one barrier per workgroup
+template <bool PULL, bool UQ, bool HB = true, bool BLK = false>
 __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) void k_hypervis(KParams p, const double * __restrict__ xsrc,
 	const double * __restrict__ xbase, double * __restrict__ xout, double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, DssPull pull)
 {
 	// every LDS row here belongs to one wavefront (its level's fields, its own copy of the operator tables): the kernel has no
-	// workgroup barrier, the four wavefronts of a workgroup run decoupled (wave_sync)
+	// workgroup barrier, the four wavefronts of a workgroup run decoupled (wave_sync) -- up to the one exchange of the block form
 	__shared__ double s[4][8][TMX_UQ_ROWLEN(UQ)];
 	__shared__ double sDw[4][16], sSw[4][16];
+	__shared__ double xs[BLK ? 5 : 1][BLK ? 256 : 1];
 	const int lane = tile_lane<UQ>(), ty = WAVE_UNIFORM(threadIdx.y);
 	if (lane < 16) { sDw[ty][lane] = p.dx[lane]; sSw[ty][lane] = p.stiff[lane]; }
 	const double * sD = sDw[ty], * sS = sSw[ty];
@@ -945,10 +949,15 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	const int L = p.L;
 	const size_t NS = (size_t)p.NS;
 	int tix, yb;
-	if (!wg_tile<UQ>(p, (L + 1 + 3) / 4, tix, yb)) return;
-	const int tile = p.quads ? p.quads[tix] : tix;
+	if (!wg_tile<UQ>(p, BLK ? L + 1 : (L + 1 + 3) / 4, tix, yb)) return;
+	int tile;
+	if (BLK) {
+		const int info = p.blk_info[p.bquads ? p.bquads[tix] : tix];
+		if (ty >= (info & 7)) return;      // (a wavefront that has ended no longer counts at the workgroup's barrier)
+		tile = (info >> 3) + ty;
+	} else tile = p.quads ? p.quads[tix] : tix;
 	const int col = tile * 64 + lane;                                 // the thread's own column: geometry, LDS
-	const int kk = yb * 4 + ty;
+	const int kk = BLK ? yb : yb * 4 + ty;
 	const int uc = UQ ? tile_ucol(p, tile, lane) : col;               // where its node's state lives
 	const size_t SS = UQ ? (size_t)p.NSS : NS;                        // state slab stride
 	const bool here = UQ ? (uc >= 0) : (col < p.ncol);
@@ -1018,14 +1027,14 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 	const double invJ2 = 1.0 / j2d;
 	const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
 	// what the thread does with its results (seam_store): loaded here, behind the first contraction, used at the end
-	const int sdst = UQ ? p.t_sdst[col] : 0, sred = UQ ? p.t_sred[col] : 0;
+	const int sdst = UQ ? (BLK ? p.b_sdst[col] : p.t_sdst[col]) : 0, sred = UQ ? (BLK ? p.b_sred[col] : p.t_sred[col]) : 0;
 	wave_sync();
 	s[ty][0][lp] = jn * (c2a0 * daT + c2a1 * dbT); s[ty][1][lp] = jn * (c2a1 * daT + c2b1 * dbT);
 	s[ty][2][lp] = jn * (c2a0 * daR + c2a1 * dbR); s[ty][3][lp] = jn * (c2a1 * daR + c2b1 * dbR);
 	s[ty][4][lp] = je * (c2a0 * daW + c2a1 * dbW); s[ty][5][lp] = je * (c2a1 * daW + c2b1 * dbW);
 	s[ty][6][lp] = dv; s[ty][7][lp] = cl;
 	wave_sync();
-	if (!actw) return;
+	if (!BLK && !actw) return;      // (BLK: padding lanes stay for the exchange below -- a whole padding wavefront must reach the barrier its block's others wait at)
 
 	double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
 #pragma unroll
@@ -1056,7 +1065,8 @@ __global__ __launch_bounds__(256, (UQ && TMX_HV_MINWG < 4) ? 4 : TMX_HV_MINWG) v
 		// (level activity is wave-uniform, so all lanes of a wavefront agree on nv; the LDS rows were last read by this wavefront)
 		const double v[5] = { oW, oT, oR, oU, oV };
 		const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
-		seam_store<5, TMX_UQ_ROWLEN(UQ)>(p, &s[ty][0], lane, sdst, sred, v, xout, slab, (kk < L) ? 5 : 1);
+		if constexpr (BLK) block_seam_store<5>(p, xs, ty * 64 + lane, sdst, sred, v, xout, slab, (kk < L) ? 31u : 1u);
+		else seam_store<5, TMX_UQ_ROWLEN(UQ)>(p, &s[ty][0], lane, sdst, sred, v, xout, slab, (kk < L) ? 5 : 1);
 		return;
 	}
 	xout[TMX_SLAB_W(L, kk) * NS + col] = oW;
@@ -1075,7 +1085,15 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
 	if (p.t_ucol) {      // node-unique layout (tmxu_params)
 		KParams q = p; q.u_ntiles = ntiles;
-		if (xbase) hipLaunchKernelGGL((k_hypervis<false, true, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+		const bool blocks = tmxu_blocks_on(e);      // a workgroup = a block of the thread order at one level: its seams are averaged in the kernel
+		e->u.slots_by_blocks = blocks;
+		if (blocks) {
+			const int nblk = p.bquads ? e->launch_blocks : e->u.nblocks;
+			q.u_ntiles = nblk;
+			if (xbase) hipLaunchKernelGGL((k_hypervis<false, true, true, TMX_EXP != 0>), wg_grid(true, q, nblk, p.L + 1), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+			else hipLaunchKernelGGL((k_hypervis<false, true, false, TMX_EXP != 0>), wg_grid(true, q, nblk, p.L + 1), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
+		}
+		else if (xbase) hipLaunchKernelGGL((k_hypervis<false, true, true>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 		else hipLaunchKernelGGL((k_hypervis<false, true, false>), wg_grid(true, q, ntiles, nyb), blk, 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, d);
 	}
 #if TMX_EXP

@@ -47,11 +47,13 @@ void tmxk_h_walk_timing_read(unsigned long long * out) { for (int i = 0; i < 128
 
 // where term m of the stage combination reads slab `slab`: node-unique (stride SS, the node's entry) or, DM and bit m of the mask set,
 // the thread's own stored copy of an element-major instance (stride NS, the thread's column)
+// (NS / gb here: stride and byte offset of the thread's stored column in the ELEMENT-MAJOR layout -- KParams::NSD, t_dcol)
 template <bool DM>
 __device__ __forceinline__ double term_load(const double * src, unsigned dmask, int m, int slab, size_t SS, size_t NS, unsigned cb, unsigned gb) {
 	const bool d = DM && ((dmask >> m) & 1u);
 	return ldu_term(src + (size_t)slab * (d ? NS : SS), d ? gb : cb);
 }
+
 template <int NT, bool PM, bool DM>
 __device__ __forceinline__ void terms_load(const double * const (&src)[12], unsigned dmask, int slab, size_t SS, size_t NS, unsigned cb, unsigned gb, double (&x)[NT > 0 ? NT : 1]) {
 	if (NT == 0) { x[0] = term_load<DM>(src[0], dmask, 0, slab, SS, NS, cb, gb); return; }
@@ -69,33 +71,51 @@ typedef const double __attribute__((address_space(4))) * tmx_cdp;
 #define TMX_HW_WAVES_PER_EU 2      // register budget: 256 per lane (the raw terms of a seven-term combination alone are 70 registers in flight)
 #endif
 
-template <int NT, bool PM, bool DM>
-__global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg)
+// BLK: a workgroup = the (up to four) wavefronts of a block of the thread order, walking the same segment in step; the seams between them
+// are averaged through LDS (block_seam_store, tables KParams::b_sdst / b_sred), W of the surface and of the lid travel with levels 1 and L-1
+// EM: the stage also forms and stores the leading partial sum of a LATER stage's combination from the terms it has loaded anyway (EmitTerms,
+// emit_value in tmx_device.h; prefix_plan in tmx_step.hip): the later stage then reads that one instance instead of the members
+template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false>
+__global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg, EmitTerms em)
 {
 	constexpr int RL = TMX_UQ_ROWLEN(true);
-	__shared__ double s[9][RL];
+	constexpr int NW = BLK ? 4 : 1;
+	__shared__ double sw[NW][9][RL];
+	__shared__ double xs[BLK ? 2 : 1][BLK ? 6 : 1][BLK ? 256 : 1];
 	__shared__ double sD[16], sS[16];
 	__shared__ double rmtab[TMX_RMTAB_DOUBLES];
+	const int wv = BLK ? WAVE_UNIFORM(threadIdx.y) : 0;
+	double (*s)[RL] = sw[wv];
 	const int lane = tile_lane<true>();      // position e * 16 + i * 4 + j of this thread inside its tile (tmx_device.h: the identity unless TMX_UQ_ROWLANES)
 	const int lp = lds_pos<true>(lane);      // where its values sit in an LDS row
 	HW_DECL;
-	// the exp / log tables (256 + 256 words) on their way to LDS: all eight loads of a lane in flight with the geometry and the first window
-	double tlog[4]; unsigned long long texp[4];
+	// the exp / log tables (256 + 256 words) on their way to LDS: a lane's loads in flight with the geometry and the first window
+	constexpr int NTL = BLK ? 1 : 4;
+	double tlog[NTL]; unsigned long long texp[NTL];
+	const int tidw = wv * 64 + (int)threadIdx.x;
 #pragma unroll
-	for (int t = 0; t < 4; t++) { tlog[t] = tmx_rm_log_tab[t * 64 + threadIdx.x]; texp[t] = tmx_rm_exp_tab[t * 64 + threadIdx.x]; }
+	for (int t = 0; t < NTL; t++) { tlog[t] = tmx_rm_log_tab[t * 64 + tidw]; texp[t] = tmx_rm_exp_tab[t * 64 + tidw]; }
 	const int L = p.L;
-	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS;
+	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS, NSD = (size_t)p.NSD;
 	int tix, seg;
 	if (!wg_tile<true>(p, nseg, tix, seg)) return;
-	const int tile = p.quads ? p.quads[tix] : tix;
+	int tile;
+	bool idle = false;      // BLK: a wavefront beyond the block's last one only keeps the barriers company
+	if (BLK) {
+		const int info = p.blk_info[p.bquads ? p.bquads[tix] : tix];
+		tile = (info >> 3) + wv; idle = wv >= (info & 7);
+		if (idle) tile = info >> 3;
+	} else tile = p.quads ? p.quads[tix] : tix;
 	const int k0 = WAVE_UNIFORM((seg * L) / nseg), k1 = WAVE_UNIFORM(((seg + 1) * L) / nseg);
 	const int col = tile * 64 + lane;
 	const int uc = max(tile_ucol(p, tile, lane), 0);      // padding lanes (a whole element of the last tile): node 0, nothing stored (t_sdst = -1)
 	unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;
+	// where the thread's own stored copy sits in an element-major instance (mixed reads, DM): its stored column, that layout's stride
+	unsigned gd = DM ? (unsigned)max(p.t_dcol[col], 0) * 8u : gb;
 	// the initial instance may be element-major (DM, bit 31): the thread's own copy
 	const bool xd = DM && (xbase.dmask >> 31) != 0u;
-	const size_t SX = xd ? NS : SS;
-	unsigned cx = xd ? gb : cb;
+	const size_t SX = xd ? NSD : SS;
+	unsigned cx = xd ? gd : cb;
 	const double * __restrict__ xuv = uvt.xin;
 	const unsigned dmask = xbase.dmask;
 	const tmx_cdp opsc = (tmx_cdp)(unsigned long long)p.ops, etac = (tmx_cdp)(unsigned long long)p.eta;
@@ -105,7 +125,8 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 	const double jn = ldu(p.g2d + G2_JN * NS, gb), j2d = ldu(p.g2d + G2_J2D * NS, gb), fcor = ldu(p.g2d + G2_F * NS, gb);
 	const MetCol mc = met_col(p, col);
 	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
-	const int sdst = p.t_sdst[col], sred = p.t_sred[col];
+	const int sdst = BLK ? p.b_sdst[col] : p.t_sdst[col], sred = BLK ? p.b_sred[col] : p.t_sred[col];
+	const int pos = wv * 64 + lane;      // BLK: position in the block
 	// ---- window of the first level
 	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
 	{
@@ -119,10 +140,13 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 	const double invJ = 1.0 / jn;
 	const double fj = fcor * j2d;
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<true>(lane & 48);
-	if (threadIdx.x < 16) { sD[threadIdx.x] = p.dx[threadIdx.x]; sS[threadIdx.x] = p.stiff[threadIdx.x]; }
+	if (tidw < 16) { sD[tidw] = p.dx[tidw]; sS[tidw] = p.stiff[tidw]; }
 #pragma unroll
-	for (int t = 0; t < 4; t++) { rmtab[t * 64 + threadIdx.x] = tlog[t]; ((unsigned long long *)(rmtab + 256))[t * 64 + threadIdx.x] = texp[t]; }
-	wave_sync();      // operator and exp / log tables are this wavefront's own
+	for (int t = 0; t < NTL; t++) { rmtab[t * 64 + tidw] = tlog[t]; ((unsigned long long *)(rmtab + 256))[t * 64 + tidw] = texp[t]; }
+	if (BLK) {
+		lds_barrier();      // the tables are the workgroup's
+		if (idle) return;      // (a wavefront that has ended no longer counts at the workgroup's barriers)
+	} else wave_sync();      // operator and exp / log tables are this wavefront's own
 	// ---- (u x zeta)_xi of the level below the segment (:1011-1037, the xi component alone) and xi_dot of the segment's first interface
 	double ucz_prev = 0.0, xlo = 0.0;
 	if (k0 > 0) {
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		// per-lane 64-bit induction pointer -- two registers per stream, 10 + 10 NT of them -- instead of scalar base + 32-bit lane offset)
 		const int k = WAVE_UNIFORM(kl);
 		// (and the lane offsets redefined per level: hoisted out of the loop, base + lane becomes one 64-bit register pair per source instance)
-		asm volatile("" : "+v"(cb), "+v"(gb), "+v"(cx));
+		asm volatile("" : "+v"(cb), "+v"(gd), "+v"(cx));
 		// ---- loads of the next level's window and of this level's combination terms: in flight during this level's arithmetic
 		double uN = uP, vN = vP, wN = 0.0, tN = 0.0, rN = 0.0;
 		if (k + 1 < k1) {
@@ -169,11 +193,11 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 			tN = ldu(xin + TMX_SLAB_T(L, k + 1) * SX, cx); rN = ldu(xin + TMX_SLAB_R(L, k + 1) * SX, cx);
 		}
 		double xU[NX], xV[NX], xT[NX], xR[NX], xW[NX];
-		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_U(L, k), SS, NS, cb, gb, xU);
-		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_V(L, k), SS, NS, cb, gb, xV);
-		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_T(L, k), SS, NS, cb, gb, xT);
-		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_R(L, k), SS, NS, cb, gb, xR);
-		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, (k > 0) ? k : 1), SS, NS, cb, gb, xW);      // (interface 0 has no base: boundary condition)
+		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_U(L, k), SS, NSD, cb, gd, xU);
+		terms_load<NT, PM, DM>(uvt.src, dmask, TMX_SLAB_V(L, k), SS, NSD, cb, gd, xV);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_T(L, k), SS, NSD, cb, gd, xT);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_R(L, k), SS, NSD, cb, gd, xR);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, (k > 0) ? k : 1), SS, NSD, cb, gd, xW);      // (interface 0 has no base: boundary condition)
 		__builtin_amdgcn_sched_barrier(0);
 		HW_MARK(1);
 
@@ -297,6 +321,12 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		// ---- the stage combination (reference order), then base + increments in the level-parallel kernel's order
 		const double bU = lin_reduce<NT, PM>(xbase, xU), bV = lin_reduce<NT, PM>(xbase, xV);
 		const double bT = lin_reduce<NT, PM>(xbase, xT), bR = lin_reduce<NT, PM>(xbase, xR), bW = lin_reduce<NT, PM>(xbase, xW);
+		if (EM) {
+			// every copy of a node forms the same prefix (the sources are node-unique): each stores it, to the same entry
+			stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, emit_value<NT>(em, xU)); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, emit_value<NT>(em, xV));
+			stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, emit_value<NT>(em, xT)); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, emit_value<NT>(em, xR));
+			if (k > 0) stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, emit_value<NT>(em, xW));
+		}
 		HW_MARK(5);
 		double outU = bU + tU, outV = bV + tV;
 		const double uh = outU, vh = outV;      // H-only values (levels 0, 1: the bottom boundary condition below)
@@ -304,23 +334,46 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		if (k > 0) { outU += tUlo; outV += tVlo; }
 		const double outR = bR - tR, outT = bT - tT;
 		const double outW = bW + tW;
-		{
-			const double v[5] = { outU, outV, outR, outT, outW };
-			const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
-			seam_store<5, RL>(p, &s[0], lane, sdst, sred, v, xup, slab, (k > 0) ? 5 : 4);
-		}
-		if (k == 0) { uh0 = uh; vh0 = vh; }
-		if (k == 1) {
-			// bottom boundary: W of interface 0 from the H-only U, V of levels 0 and 1 extrapolated to the surface (:1615-1638)
-			wave_sync();
-			double ub0 = 0.0, vb0 = 0.0;
-			ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * uh0; ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * uh;
-			vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
-			double e0, e1, e2, ea, eb_;
-			met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
-			const double v1[1] = { -(e0 * ub0 + e1 * vb0) / e2 };
-			const int slab1[1] = { TMX_SLAB_W(L, 0) };
-			seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+		if constexpr (BLK) {
+			// one exchange per level for the whole block; W of the surface (known once level 1's H-only U, V are) and of the lid ride along
+			double extra = 0.0; int xslab = TMX_SLAB_W(L, 0); unsigned vmask = (k > 0) ? 31u : 15u;
+			if (k == 0) { uh0 = uh; vh0 = vh; }
+			if (k == 1) {
+				double ub0 = 0.0, vb0 = 0.0;
+				ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * uh0; ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * uh;
+				vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
+				double e0, e1, e2, ea, eb_;
+				met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
+				extra = -(e0 * ub0 + e1 * vb0) / e2; vmask |= 32u;
+			}
+			if (k == L - 1) {
+				double xWl[NX];
+				terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xWl);
+				extra = lin_reduce<NT, PM>(xbase, xWl); xslab = TMX_SLAB_W(L, L); vmask |= 32u;
+				if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xWl));
+			}
+			const double v[6] = { outU, outV, outR, outT, outW, extra };
+			const int slab[6] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k), xslab };
+			block_seam_store<6>(p, xs[k & 1], pos, sdst, sred, v, xup, slab, vmask);
+		} else {
+			{
+				const double v[5] = { outU, outV, outR, outT, outW };
+				const int slab[5] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k) };
+				seam_store<5, RL>(p, &s[0], lane, sdst, sred, v, xup, slab, (k > 0) ? 5 : 4);
+			}
+			if (k == 0) { uh0 = uh; vh0 = vh; }
+			if (k == 1) {
+				// bottom boundary: W of interface 0 from the H-only U, V of levels 0 and 1 extrapolated to the surface (:1615-1638)
+				wave_sync();
+				double ub0 = 0.0, vb0 = 0.0;
+				ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * uh0; ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * uh;
+				vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
+				double e0, e1, e2, ea, eb_;
+				met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
+				const double v1[1] = { -(e0 * ub0 + e1 * vb0) / e2 };
+				const int slab1[1] = { TMX_SLAB_W(L, 0) };
+				seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
+			}
 		}
 		wave_sync();
 		HW_MARK(6);
@@ -329,11 +382,12 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 		w0 = w1; w1 = wN; t0 = tN; r0 = rN;
 		ucz_prev = uczx; xlo = xhi;
 	}
-	if (k1 == L) {
+	if (!BLK && k1 == L) {
 		// the rigid lid: the H step leaves W there alone; the base's value goes through the seam exchange like every other result
 		double xW[NX];
-		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NS, cb, gb, xW);
+		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
+		if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
 		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
 	}
@@ -345,7 +399,8 @@ __global__ __launch_bounds__(64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, c
 // eight terms; segments of at least two levels so that levels 0 and 1 -- the bottom boundary condition -- belong to one wavefront)
 bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit) {
 	const bool uq = p.t_ucol != nullptr;
-	return uq && fuse_v && !emit && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
+	(void)emit;      // (a stored prefix: the walk's own instantiation)
+	return uq && fuse_v && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
 }
 
 // Segments per column.  One wavefront per segment, two resident per SIMD (256 registers), three for the plain stage and the two-term
@@ -373,7 +428,8 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 }
 
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
-	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask) {
+	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
+	const EmitTerms * emit) {
 	LinTerms xbase;
 	UvTerms uvt;
 	xbase.n = nterms; xbase.premul = premul; xbase.dmask = dmask;
@@ -384,10 +440,21 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms);
 	KParams q = p; q.u_ntiles = ntile;
-	const dim3 blk(64), grd = wg_grid(true, q, ntile, nseg);
-#define LAUNCH_W2(NT_, PM_) do { \
-		if (dmask) hipLaunchKernelGGL((k_h_walk<NT_, PM_, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg); \
-		else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg); } while (0)
+	// block kernels: the launch is over the blocks of the thread order (four wavefronts each), the seams between a block's wavefronts never reach the partial slots
+	const bool blocks = tmxu_blocks_on(e) && p.L >= 3;
+	const int nblk = p.bquads ? e->launch_blocks : e->u.nblocks;
+	if (blocks) q.u_ntiles = nblk;
+	e->u.slots_by_blocks = blocks;
+	const dim3 blk(64, blocks ? 4 : 1), grd = wg_grid(true, q, blocks ? nblk : ntile, nseg);
+	EmitTerms em0; em0.xp = nullptr; em0.first = -1; for (int m = 0; m < 12; m++) em0.coef[m] = 0.0;
+	// (the prefix of a later stage's combination: no own coefficient, three to eight terms, node-unique sources, wavefront-level kernel)
+	const bool emit_ok = emit && emit->xp && !premul && !dmask && !blocks && nterms >= 3 && nterms <= 8;
+	const EmitTerms em = emit_ok ? *emit : em0;
+#define LAUNCH_W3(NT_, PM_, DM_) do { \
+		if (emit_ok && NT_ >= 3 && !PM_ && !DM_) hipLaunchKernelGGL((k_h_walk<(NT_ >= 3 ? NT_ : 3), false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em); \
+		else if (TMX_EXP && blocks) hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, TMX_EXP != 0>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0); \
+		else hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0); } while (0)
+#define LAUNCH_W2(NT_, PM_) do { if (dmask) LAUNCH_W3(NT_, PM_, true); else LAUNCH_W3(NT_, PM_, false); } while (0)
 #define LAUNCH_W(NT_) do { if (NT_ == 0 || premul) LAUNCH_W2(NT_, true); else LAUNCH_W2(NT_, false); } while (0)
 	switch (nterms) {
 		case 0: LAUNCH_W(0); break;
@@ -399,6 +466,7 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 		case 7: LAUNCH_W(7); break;
 		default: LAUNCH_W(8); break;
 	}
+#undef LAUNCH_W3
 #undef LAUNCH_W
 #undef LAUNCH_W2
 }

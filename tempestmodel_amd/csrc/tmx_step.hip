@@ -15,6 +15,7 @@ KParams make_params(const tmx_engine * e) {
 	p.quads = e->stage_quads;      // tile list of a boundary-first stage in progress (hv_stage_split), else all tiles
 	p.NSS = e->NS; p.t_ucol = nullptr; p.t_tinfo = nullptr; p.t_sdst = nullptr; p.t_sred = nullptr; p.part = nullptr; p.NP = 0;      // element-major layout (tmxu_params: node-unique)
 	p.u_ntiles = 0; p.u_xcd = e->u.xcd_order;
+	p.NSD = e->NS; p.t_dcol = nullptr; p.b_sdst = nullptr; p.b_sred = nullptr; p.blk_info = nullptr; p.bquads = nullptr;
 	p.grav = e->cfg.grav; p.Rd = e->cfg.Rd; p.cp = e->cfg.cp; p.p0 = e->cfg.p0;
 	memcpy(p.dx, e->h_dx, sizeof(p.dx)); memcpy(p.stiff, e->h_stiff, sizeof(p.stiff));
 	return p;
@@ -1419,14 +1420,17 @@ extern "C" int tmx_debug_program_unique(int scheme, int first_step, int last_ste
 	return units;
 }
 
+// (the partial slots were filled by block kernels: the shorter list -- what no workgroup averaged)
 static int u_dss_finish(tmx_engine * e, int ix, bool overlapped) {
 	ProfScope ps(e, TMX_K_DSS);
 	const UniqueLayout & u = e->u;
-	if (e->cfg.n_ranks > 1 && u.ngroups_local < u.ngroups) {
-		tmxuk_dss(e, uinst(e, ix), 0, u.ngroups_local);
+	const bool bl = u.slots_by_blocks;
+	const int ng = bl ? u.b_ngroups : u.ngroups, nl = bl ? u.b_ngroups_local : u.ngroups_local;
+	if (e->cfg.n_ranks > 1 && nl < ng) {
+		tmxuk_dss(e, uinst(e, ix), 0, nl, bl);
 		if (overlapped) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_recv, 0));
-		tmxuk_dss(e, uinst(e, ix), u.ngroups_local, u.ngroups);
-	} else tmxuk_dss(e, uinst(e, ix), 0, u.ngroups);
+		tmxuk_dss(e, uinst(e, ix), nl, ng, bl);
+	} else tmxuk_dss(e, uinst(e, ix), 0, ng, bl);
 	return launch_check("DSS of the partial slots");
 }
 
@@ -1440,10 +1444,12 @@ template <class F> static int u_produce_and_average(tmx_engine * e, int ix, int 
 		for (int part = 0; part < 2; part++) {
 			p.quads = part ? u.d_quads_late : u.d_quads_early;
 			e->launch_tiles = part ? u.n_late : u.n_early;
+			p.bquads = part ? u.d_blks_late : u.d_blks_early;      // (block kernels: the same split by blocks)
+			e->launch_blocks = part ? u.nb_late : u.nb_early;
 			{ ProfScope ps(e, prof_slot); kernels(p); }
-			if (part == 0) { p.quads = nullptr; if ((r = exchange(e, p, nullptr, &overlapped))) return r; }
+			if (part == 0) { p.quads = nullptr; p.bquads = nullptr; if ((r = exchange(e, p, nullptr, &overlapped))) return r; }
 		}
-		p.quads = nullptr;
+		p.quads = nullptr; p.bquads = nullptr;
 	} else {
 		{ ProfScope ps(e, prof_slot); kernels(p); }
 		if ((r = exchange(e, p, nullptr, &overlapped))) return r;
@@ -1558,6 +1564,8 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	} else if (dl(ibase)) dmask |= 1u;
 	if (dl(iinit)) dmask |= 1u << 31;
 	REQUIRE(!(held && dmask), TMX_ERR_UNSUPPORTED, "internal: stored prefix with element-major sources");
+	REQUIRE(!dmask || e->u.tile_shape == 0 || tmxk_h_walk_ok(e, tmxu_params(e, make_params(e)), 1, n, false), TMX_ERR_UNSUPPORTED,
+		"internal: copy-by-copy reads of an element-major instance with this thread order need the column-segment walk");
 	const double * xin_uv = dl(iinit) ? inst_uv(e, iinit) : uinst_uv(e, iinit), * base_uv = dl(ibase) ? inst_uv(e, ibase) : uinst_uv(e, ibase);      // (taken before the update instance changes slots)
 	// the update instance is also read (in-place accumulation, or its own coefficient in the combination is not zero): the
 	// element-major kernels read and write a thread's own column, here other elements' threads read the node too -- write the
@@ -1572,7 +1580,12 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	double * out = aliased ? uspare(e) : uinst(e, iupd);
 	const double * base = lc ? nullptr : (dl(ibase) ? inst(e, ibase) : uinst(e, ibase)), * xin = dl(iinit) ? inst(e, iinit) : uinst(e, iinit);
 	EmitTerms em; em.xp = nullptr; em.first = -1;
-	if (emit && lc && !premul && n >= 3 && n <= 8 && !dmask) { em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m]; }
+	// (only a kernel that really stores it: the column-segment walk, or the level-parallel kernel of the experiments flavour; element-major sources: no prefix)
+	const bool walk = tmxk_h_walk_ok(e, tmxu_params(e, make_params(e)), 1, n, true);
+	if (emit && lc && !premul && n >= 3 && n <= 8 && !dmask && (walk ? !tmxu_blocks_on(e) : TMX_EXP != 0)) {      // (the block form of the walk stores none)
+		em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m];
+	}
+	if (emit) e->u.prefix_for = em.xp ? (long long)emit->consumer : -1;      // which operation may start from the stored prefix (run_program_unique)
 	// the stage writes every slab of the update instance: its U,V slabs are its own from here on (what it shared is read through
 	// the pointers taken above), and whoever shared ITS slabs is dead
 	if (e->uvmap[iupd] != iupd) { e->uvmap[iupd] = iupd; e->n_uvshared--; }
@@ -1648,6 +1661,7 @@ static int u_dss(tmx_engine * e, int ix) {
 	int r;
 	if ((r = u_own_uv(e, ix))) return r;
 	{ ProfScope ps(e, TMX_K_DSS); tmxuk_slots_from_u(e, uinst(e, ix)); }
+	e->u.slots_by_blocks = tmxu_blocks_on(e);      // every slot holds its node's value: the shorter list changes the same nodes (a group of identical copies averages to itself)
 	if ((r = exchange(e, tmxu_params(e, make_params(e)), nullptr, &overlapped))) return r;
 	r = u_dss_finish(e, ix, overlapped);
 	u_written(e, ix);
@@ -1698,6 +1712,7 @@ static int u_hvis_core(tmx_engine * e, int iinit, int iupd, int iwork, double dt
 static int run_program_unique(tmx_engine * e, const Program & p) {
 	int r;
 	const std::vector<PrefixPlan> plans = prefix_schedule(e, p);
+	e->u.prefix_for = -1;
 	auto plan_at = [&](size_t i, bool consumer) -> const PrefixPlan * {
 		for (const PrefixPlan & a : plans) if ((consumer ? a.consumer : a.producer) == i) return &a;
 		return nullptr;
@@ -1740,7 +1755,8 @@ static int run_program_unique(tmx_engine * e, const Program & p) {
 			break;
 		case OP_LINCOMB:
 			if (k == 4) {
-				const PrefixPlan * held = plan_at(i, true);      // an earlier stage has stored the leading partial sum of this combination
+				const PrefixPlan * held = plan_at(i, true);      // an earlier stage has stored the leading partial sum of this combination ...
+				if (held && e->u.prefix_for != (long long)i) held = nullptr;      // ... unless it could not (it read an element-major instance copy by copy)
 				if ((r = u_stage(e, p[i + 1].a, o.a, o.a, p[i + 1].coef, o.lc, o.nlc, plan_at(i, false), held ? held->members : 0u))) return r;
 				break;
 			}
@@ -1840,7 +1856,10 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	// Round 5: live-in instances in element-major form are READ that way, copy by copy, by the explicit stages (no check of the copies, no
 	// host synchronisation, no conversion; exact whether the copies agree or not) wherever the program lets only its stages read them
 	u.dlive = 0u;
-	if (dform && u.mixed_option && u.tile_shape == 0 && !(TMX_EXP && u.prefix_option) && dlive_program_ok(p, dform)) {
+	// (a thread reads its own stored copy: the level-parallel kernels take the thread index for the stored column, which only the default thread order
+	// allows; the column-segment walk looks the column up, KParams::t_dcol)
+	const bool own_copy_ok = u.tile_shape == 0 || (u.tile_shape == 4 && e->opt_h_walk != 0 && !e->use_mfma);
+	if (dform && u.mixed_option && own_copy_ok && dlive_program_ok(p, dform)) {
 		for (int k = 0; k < e->cfg.n_instances; k++)
 			if ((dform >> k & 1u) && (e->imap[k] != k || e->uvmap[k] != k) && (r = settle_instance(e, k, false))) return r;
 		u.dlive = dform; need_check = false; u.mixed_steps++;

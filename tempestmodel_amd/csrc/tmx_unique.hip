@@ -53,7 +53,8 @@ template <class T> static int up(T ** d, const std::vector<T> & h, size_t * byte
 void tmxu_free(tmx_engine * e) {
 	UniqueLayout & u = e->u;
 	void * ptrs[] = { u.d_ustate, u.d_part, u.d_g2d_t, u.d_g2d_u, u.d_t_ucol, u.d_t_sdst, u.d_t_sred, u.d_t_tinfo, u.d_t_dcol, u.d_ucol_of_dcol, u.d_u_rep, u.d_slot_ucol,
-		u.d_gsrc, u.d_gdst, u.d_gn, u.d_gx, u.d_gtype, u.d_send_slots, u.d_quads_early, u.d_quads_late, u.d_check, u.d_surf_u };
+		u.d_gsrc, u.d_gdst, u.d_gn, u.d_gx, u.d_gtype, u.d_send_slots, u.d_quads_early, u.d_quads_late, u.d_check, u.d_surf_u,
+		u.d_b_sdst, u.d_b_sred, u.d_blk_info, u.d_b_gsrc, u.d_b_gdst, u.d_b_gn, u.d_b_gx, u.d_b_gtype, u.d_blks_early, u.d_blks_late };
 	for (void * q : ptrs) if (q) hipFree(q);
 	u = UniqueLayout();
 }
@@ -116,6 +117,19 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 			}
 		}
 		telem.insert(telem.end(), left.begin(), left.end());
+	} else if (u.tile_shape == 4) {
+		// 4 x 4 element blocks of every patch, row by row inside a block: a wavefront is a 1 x 4 strip along beta as in the default order, a
+		// workgroup of four wavefronts is a block, whose strip seams it averages itself (block tables below).  Blocks at the patch's ragged
+		// edges (widths that are no multiple of four) are padded to whole wavefronts with padding elements (-1): 15 x 15 patches: 3 of 228.
+		for (int p : e->local_patches) {
+			const PatchInfo & P = e->patches[p];
+			for (int a0 = 0; a0 < P.nea; a0 += 4) for (int b0 = 0; b0 < P.neb; b0 += 4) {
+				const size_t first = telem.size();
+				for (int a = a0; a < std::min(a0 + 4, P.nea); a++) for (int b = b0; b < std::min(b0 + 4, P.neb); b++) telem.push_back(P.elem_base + a * P.neb + b);
+				while ((telem.size() - first) % 4) telem.push_back(-1);
+				T.blk_first.push_back((int)first / 4); T.blk_nt.push_back((int)(telem.size() - first) / 4);
+			}
+		}
 	} else if (u.tile_shape == 3) {
 		// a space-filling curve through every patch (x = beta element, y = alpha element)
 		for (int p : e->local_patches) {
@@ -125,11 +139,19 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 	} else {
 		for (int q = 0; q < e->ne_local; q++) telem.push_back(q);
 	}
-	REQUIRE((int)telem.size() == e->ne_local, TMX_ERR_INVALID, "internal: thread order covers %d of %d elements", (int)telem.size(), e->ne_local);
+	{
+		int real = 0;
+		for (int el : telem) real += (el >= 0);
+		REQUIRE(real == e->ne_local, TMX_ERR_INVALID, "internal: thread order covers %d of %d elements", real, e->ne_local);
+	}
 	u.NTS = ((int)telem.size() * 16 + 63) / 64 * 64;
-	REQUIRE(u.NTS == NS, TMX_ERR_INVALID, "internal: thread space %d != column space %d", u.NTS, NS);
+	// (the block order pads: its thread space may be larger than the column space; every other order is a permutation of the elements)
+	REQUIRE(u.NTS == NS || u.tile_shape == 4, TMX_ERR_INVALID, "internal: thread space %d != column space %d", u.NTS, NS);
+	if (u.tile_shape != 4) {      // every four consecutive wavefronts form a block (the last one may be short)
+		for (int t = 0; t < u.NTS / 64; t += 4) { T.blk_first.push_back(t); T.blk_nt.push_back(std::min(4, u.NTS / 64 - t)); }
+	}
 	std::vector<int> t_dcol(u.NTS, -1), tcol_of_dcol(NS, -1), t_ucol(u.NTS, -1), t_sdst(u.NTS, -1), t_sred(u.NTS, 0);
-	for (size_t t = 0; t < telem.size(); t++) for (int q = 0; q < 16; q++) {
+	for (size_t t = 0; t < telem.size(); t++) if (telem[t] >= 0) for (int q = 0; q < 16; q++) {
 		t_dcol[t * 16 + q] = telem[t] * 16 + q; tcol_of_dcol[telem[t] * 16 + q] = (int)t * 16 + q;
 	}
 	for (int t = 0; t < u.NTS; t++) if (t_dcol[t] >= 0) { t_ucol[t] = ucol_of_dcol[t_dcol[t]]; t_sdst[t] = t_ucol[t]; }
@@ -169,12 +191,52 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 		for (int m = 0; m < n; m++) t_sdst[tb + lanes[m]] = (m == owner) ? t_ucol[tb + lanes[m]] : -1;
 		t_sred[tb + lanes[owner]] = n | (l1 << 4) | (l2 << 10) | (l3 << 16);
 	}
+	// ---- the same one level up: groups whose copies all belong to ONE BLOCK (a workgroup of up to four wavefronts) are averaged by that
+	// workgroup through LDS (block kernels: k_h_walk<.., BLK>, k_hypervis_blk); position of a thread in its block = 64 * wavefront + lane
+	std::vector<int> blk_of_tile(u.NTS / 64, -1);
+	for (size_t b = 0; b < T.blk_first.size(); b++) for (int w = 0; w < T.blk_nt[b]; w++) blk_of_tile[T.blk_first[b] + w] = (int)b;
+	std::vector<char> inblock(ng, 0);
+	std::vector<int> b_sdst = t_sdst, b_sred(u.NTS, 0);      // (threads of in-tile groups and lone nodes start from the wavefront-level entries; overwritten below)
+	for (int t = 0; t < u.NTS; t++) if (t_dcol[t] >= 0) b_sdst[t] = t_ucol[t];
+	for (int g = 0; g < ng; g++) {
+		const int n = gn[g];
+		bool ok = (n == 2 || n == 4);
+		int blk = -1, patch = -1;
+		for (int m = 0; m < n && ok; m++) {
+			const int c = gc[(size_t)g * 4 + m];
+			if (c < 0 || c >= NS) { ok = false; break; }
+			const int tc = tcol_of_dcol[c], pp = patch_of_elem[c / 16];
+			if (m == 0) { blk = blk_of_tile[tc / 64]; patch = pp; }
+			else if (blk_of_tile[tc / 64] != blk || pp != patch) ok = false;
+		}
+		for (int m = 1; m < n && ok; m++) if (((gt[g] >> (2 * m)) & 3) != (gt[g] & 3)) ok = false;
+		if (ok && gx[g] >= 0) ok = false;
+		if (!ok) continue;
+		inblock[g] = 1;
+		const int tb = T.blk_first[blk] * 64;
+		int pos[4], owner = 0;
+		for (int m = 0; m < n; m++) { pos[m] = tcol_of_dcol[gc[(size_t)g * 4 + m]] - tb; if (pos[m] < pos[owner]) owner = m; }
+		int l1, l2 = 0, l3 = 0;
+		if (n == 2) l1 = pos[1 - owner];
+		else {
+			const int ty = (gt[g] >> (2 * owner)) & 3;
+			const int ap = (ty == 0) ? (owner ^ 1) : ((ty == 1) ? (owner ^ 2) : (3 - owner));
+			int rest[2], nr = 0;
+			for (int m = 0; m < 4; m++) if (m != owner && m != ap) rest[nr++] = m;
+			l1 = pos[ap]; l2 = pos[rest[0]]; l3 = pos[rest[1]];
+		}
+		for (int m = 0; m < n; m++) b_sdst[tb + pos[m]] = (m == owner) ? t_ucol[tb + pos[m]] : -1;
+		b_sred[tb + pos[owner]] = n | (l1 << 4) | (l2 << 12) | (l3 << 20);
+	}
 	// partial slots in thread order
 	std::vector<char> needs_slot(u.NTS, 0);
 	for (int g = 0; g < ng; g++) if (!intile[g])
 		for (int m = 0; m < gn[g]; m++) { const int c = gc[(size_t)g * 4 + m]; if (c >= 0 && c < NS) needs_slot[tcol_of_dcol[c]] = 1; }
 	std::vector<int> slot_of_tcol(u.NTS, -1), slot_ucol;
 	for (int t = 0; t < u.NTS; t++) if (needs_slot[t]) { slot_of_tcol[t] = (int)slot_ucol.size(); slot_ucol.push_back(t_ucol[t]); t_sdst[t] = -2 - slot_of_tcol[t]; }
+	// (block tables: the slots keep their numbers; copies of groups no block averages go there as before)
+	for (int g = 0; g < ng; g++) if (!inblock[g])
+		for (int m = 0; m < gn[g]; m++) { const int c = gc[(size_t)g * 4 + m]; if (c >= 0 && c < NS) b_sdst[tcol_of_dcol[c]] = -2 - slot_of_tcol[tcol_of_dcol[c]]; }
 	u.nslots = (int)slot_ucol.size();
 	u.NP = std::max(64, (u.nslots + 63) / 64 * 64);
 	slot_ucol.resize(u.NP, 0);
@@ -195,7 +257,14 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 		ugn.push_back(gn[g]); ugx.push_back(gx[g]); ugt.push_back(gt[g]);
 		if (g < e->ngroups_local) u.ngroups_local++;
 		u.ngroups++;
+		if (!inblock[g]) {      // the DSS kernel's list behind a block kernel: the same entries, fewer of them
+			for (int m = 0; m < 4; m++) { T.b_gsrc.push_back(gsrc[gsrc.size() - 4 + m]); T.b_gdst.push_back(dst[m]); }
+			T.b_gn.push_back(gn[g]); T.b_gx.push_back(gx[g]); T.b_gt.push_back(gt[g]);
+			if (g < e->ngroups_local) u.b_ngroups_local++;
+			u.b_ngroups++;
+		}
 	}
+	REQUIRE(gsrc.size() == 4 * (size_t)u.ngroups, TMX_ERR_INVALID, "internal: DSS group table");
 	// what other ranks need: the slots of the sent columns; tiles that hold one run before the exchange starts
 	std::vector<int> send_slots;
 	std::vector<char> early(u.NTS / 64, 0);
@@ -208,11 +277,22 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 	for (int t = 0; t < (int)early.size(); t++) (early[t] ? qe : ql).push_back(t);
 	u.split = e->cfg.n_ranks > 1 && !qe.empty() && !ql.empty() && e->split_stage;
 	u.n_early = (int)qe.size(); u.n_late = (int)ql.size();
+	// the same split for block kernels: a block runs early if one of its wavefronts does
+	for (size_t b = 0; b < T.blk_first.size(); b++) {
+		bool ea = false;
+		for (int w = 0; w < T.blk_nt[b]; w++) ea = ea || early[T.blk_first[b] + w];
+		(ea ? T.blks_early : T.blks_late).push_back((int)b);
+	}
+	u.nblocks = (int)T.blk_first.size(); u.nb_early = (int)T.blks_early.size(); u.nb_late = (int)T.blks_late.size();
+	T.b_sdst = b_sdst; T.b_sred = b_sred;
+	T.blk_info.resize(T.blk_first.size());
+	for (size_t b = 0; b < T.blk_first.size(); b++) T.blk_info[b] = T.blk_first[b] * 8 + T.blk_nt[b];
 	T.t_dcol = t_dcol; T.t_ucol = t_ucol; T.t_sdst = t_sdst; T.t_sred = t_sred; T.ucol_of_dcol = ucol_of_dcol; T.u_rep = u_rep; T.slot_ucol = slot_ucol;
 	T.gsrc = gsrc; T.gdst = gdst; T.gn = ugn; T.gx = ugx; T.gt = ugt; T.send_slots = send_slots; T.quads_early = qe; T.quads_late = ql;
 	// per tile: where node (0,0) of each of its four elements lives and its patch's row pitch (ucol = base + i * pitch + j)
 	T.tinfo.assign((size_t)(u.NTS / 64) * 8, -1);
 	for (size_t t = 0; t < telem.size(); t++) {
+		if (telem[t] < 0) continue;
 		const int p = patch_of_elem[telem[t]];
 		T.tinfo[(t / 4) * 8 + (t % 4)] = t_ucol[t * 16];
 		T.tinfo[(t / 4) * 8 + 4 + (t % 4)] = 3 * e->patches[p].neb + 1;
@@ -241,6 +321,9 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 	if ((r = up(&u.d_ucol_of_dcol, T.ucol_of_dcol, bytes)) || (r = up(&u.d_u_rep, T.u_rep, bytes)) || (r = up(&u.d_slot_ucol, T.slot_ucol, bytes))) return r;
 	if ((r = up(&u.d_gsrc, T.gsrc, bytes)) || (r = up(&u.d_gdst, T.gdst, bytes)) || (r = up(&u.d_gn, T.gn, bytes)) || (r = up(&u.d_gx, T.gx, bytes)) || (r = up(&u.d_gtype, T.gt, bytes))) return r;
 	if ((r = up(&u.d_send_slots, T.send_slots, bytes)) || (r = up(&u.d_quads_early, T.quads_early, bytes)) || (r = up(&u.d_quads_late, T.quads_late, bytes))) return r;
+	if ((r = up(&u.d_b_sdst, T.b_sdst, bytes)) || (r = up(&u.d_b_sred, T.b_sred, bytes)) || (r = up(&u.d_blk_info, T.blk_info, bytes))) return r;
+	if ((r = up(&u.d_b_gsrc, T.b_gsrc, bytes)) || (r = up(&u.d_b_gdst, T.b_gdst, bytes)) || (r = up(&u.d_b_gn, T.b_gn, bytes)) || (r = up(&u.d_b_gx, T.b_gx, bytes)) || (r = up(&u.d_b_gtype, T.b_gt, bytes))) return r;
+	if ((r = up(&u.d_blks_early, T.blks_early, bytes)) || (r = up(&u.d_blks_late, T.blks_late, bytes))) return r;
 	u.ustride = (size_t)e->nslab * u.NUS;
 	const size_t ub = (size_t)(e->cfg.n_instances + 2) * u.ustride * sizeof(double), pb = (size_t)e->nslab * u.NP * sizeof(double);
 	HIPCHK(hipMalloc((void **)&u.d_ustate, ub)); HIPCHK(hipMemset(u.d_ustate, 0, ub)); *bytes += ub;
@@ -262,6 +345,7 @@ KParams tmxu_params(const tmx_engine * e, const KParams & base) {
 	const UniqueLayout & u = e->u;
 	p.NS = u.NTS; p.ncol = u.NTS; p.g2d = u.d_g2d_t;
 	p.NSS = u.NUS; p.t_ucol = u.d_t_ucol; p.t_tinfo = u.d_t_tinfo; p.t_sdst = u.d_t_sdst; p.t_sred = u.d_t_sred; p.part = u.d_part; p.NP = u.NP;
+	p.NSD = e->NS; p.t_dcol = u.d_t_dcol; p.b_sdst = u.d_b_sdst; p.b_sred = u.d_b_sred; p.blk_info = u.d_blk_info;
 	return p;
 }
 
@@ -390,6 +474,8 @@ void tmxuk_slots_from_u(tmx_engine * e, const double * xu) {
 // unique slabs: one thread per group and slab level, every member's own combination in the reference's order (dss_combine), (U,V)
 // of copies on other panels rotated into the member's frame.  Copies of a node inside one patch receive identical bits, so only the
 // first of them stores (gdst == -1 for the others).
+// (round 6: two / four levels per thread, the group's tables read once and all copies in flight together, cost +6 % / +40 %: the kernel
+// lives on the number of threads in flight, not on the bytes its tables take)
 __global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, size_t NP, double * __restrict__ xu, const double * __restrict__ part,
 	const double * __restrict__ ghost, const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gsrc,
 	const int * __restrict__ gdst, const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int g0)
@@ -452,13 +538,14 @@ __global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, siz
 	(void)nt;
 }
 
-void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1) {
+// blocks: the groups a block kernel left (UniqueLayout::b_*) instead of the groups a wavefront-level kernel leaves
+void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1, bool blocks) {
 	if (g1 <= g0) return;
 	const UniqueLayout & u = e->u;
 	const int nx = (g1 - g0 + 63) / 64, ny = (e->L + 1 + 3) / 4;
 	hipLaunchKernelGGL(k_dss_u, dim3(8 * ((nx + 7) / 8) * ny), dim3(64, 4), 0, e->stream, e->L, e->nt, (size_t)u.NUS, (size_t)u.NP, xu, (const double *)u.d_part,
-		(const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride, g1, (const int *)u.d_gsrc, (const int *)u.d_gdst,
-		(const int *)u.d_gn, (const int *)u.d_gx, (const int *)u.d_gtype, (const double *)e->d_xmat, g0);
+		(const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride, g1, (const int *)(blocks ? u.d_b_gsrc : u.d_gsrc), (const int *)(blocks ? u.d_b_gdst : u.d_gdst),
+		(const int *)(blocks ? u.d_b_gn : u.d_gn), (const int *)(blocks ? u.d_b_gx : u.d_gx), (const int *)(blocks ? u.d_b_gtype : u.d_gtype), (const double *)e->d_xmat, g0);
 }
 
 // ---------------------------------------------------------------------------------------------

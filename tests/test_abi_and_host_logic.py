@@ -256,7 +256,7 @@ def test_options_are_explicit_and_reported():
         # archived experiments and cross-check kernels: the production library holds neither the kernels nor the switch
         lib.tmx_info.restype = ctypes.c_longlong
         assert lib.tmx_info(h, 18) == 0      # TMX_INFO_EXPERIMENTS_BUILD
-        for name, value in ((b"hvis_pull", 1.0), (b"hvis_block", 1.0), (b"vi_pair", 0.0), (b"vi_split_kernels", 1.0), (b"unique_prefix", 1.0),
+        for name, value in ((b"hvis_pull", 1.0), (b"hvis_block", 1.0), (b"vi_pair", 0.0), (b"vi_split_kernels", 1.0), (b"unique_blocks", 1.0), (b"unique_tile_shape", 4.0),
                             (b"debug_skip_exchange", 1.0), (b"vx_fused", 1.0), (b"vt_explicit_v1", 1.0), (b"vi_split_back", 1.0),
                             # round 5: A/B switches no test of the production library uses went the same way
                             (b"vi_stagger", 500.0), (b"xcd_vertical", 0.0), (b"unique_xcd_order", 0.0), (b"tracer_lincomb_pass", 1.0),
@@ -283,7 +283,8 @@ def _unique_tables(e, shape):
     lib = e.lib
     lib.tmx_debug_unique_tables.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     out = {}
-    for what, name in enumerate(("sizes", "t_dcol", "t_ucol", "t_sdst", "t_sred", "gsrc", "gdst", "gn", "slot_ucol", "send_slots", "u_rep", "ucol_of_dcol", "tinfo")):
+    for what, name in enumerate(("sizes", "t_dcol", "t_ucol", "t_sdst", "t_sred", "gsrc", "gdst", "gn", "slot_ucol", "send_slots", "u_rep", "ucol_of_dcol", "tinfo",
+                                 "b_sdst", "b_sred", "blk_info", "b_gsrc", "b_gdst", "b_gn", "blks_early", "blks_late")):
         n = lib.tmx_debug_unique_tables(e.h, shape, what, None, 0)
         assert n >= 0, name
         a = np.zeros(max(n, 1), dtype=np.int32)
@@ -293,7 +294,7 @@ def _unique_tables(e, shape):
 
 
 @pytest.mark.parametrize("ne,npatch,n_ranks", [(5, 6, 1), (6, 24, 1), (12, 24, 3), (7, 6, 1)])
-@pytest.mark.parametrize("shape", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4])
 def test_unique_layout_tables(ne, npatch, n_ranks, shape):
     """Host logic of the node-unique layout (tmxu_tables), on plan-only engines: every unique node is stored by exactly one place
     -- one lane of one tile (alone, or averaging the copies its wavefront holds), or the DSS kernel through the partial slots of all
@@ -304,11 +305,12 @@ def test_unique_layout_tables(ne, npatch, n_ranks, shape):
     for rank in range(n_ranks):
         e = Engine(g, device=-2, rank=rank, n_ranks=n_ranks)
         T = _unique_tables(e, shape)
-        NU, NUS, NTS, nslots, ngroups, nlocal, nearly, nlate = (int(v) for v in T["sizes"])
+        NU, NUS, NTS, nslots, ngroups, nlocal, nearly, nlate, b_ngroups, b_nlocal, nblocks, nb_early, nb_late = (int(v) for v in T["sizes"])
         el = len([p for p in range(npatch) if e.owner[p] == rank]) * (ne * ne * 6 // npatch)
         per_patch = ne * ne * 6 // npatch
         side = int(round(per_patch ** 0.5))
-        assert NU == len(e.local_patches) * (3 * side + 1) ** 2 and NTS == (el * 16 + 63) // 64 * 64
+        assert NU == len(e.local_patches) * (3 * side + 1) ** 2
+        assert (NTS == (el * 16 + 63) // 64 * 64) if shape != 4 else (NTS >= el * 16 and NTS % 64 == 0)      # (the block order pads ragged blocks to whole wavefronts)
         tu, sd, sr, td = T["t_ucol"], T["t_sdst"], T["t_sred"], T["t_dcol"]
         valid = td >= 0
         assert valid.sum() == el * 16 and sorted(td[valid]) == list(range(el * 16))          # thread order = a permutation of the elements' nodes
@@ -351,6 +353,42 @@ def test_unique_layout_tables(ne, npatch, n_ranks, shape):
         for t in range(NTS):
             b, nj = ti[t // 64][(t % 64) // 16], ti[t // 64][4 + (t % 64) // 16]
             assert (tu[t] == -1 and b < 0) or tu[t] == b + ((t >> 2) & 3) * nj + (t & 3)
+        # ---- the same one level up: blocks of (up to) four wavefronts (block kernels)
+        bs, br, bi = T["b_sdst"], T["b_sred"], T["blk_info"]
+        assert len(bi) == nblocks and b_ngroups <= ngroups and b_nlocal <= b_ngroups
+        first, nt = bi >> 3, bi & 7
+        assert ((nt >= 1) & (nt <= 4)).all() and first[0] == 0 and (first[1:] == first[:-1] + nt[:-1]).all() and first[-1] + nt[-1] == NTS // 64      # the blocks tile the thread space
+        blk_of = np.repeat(np.arange(nblocks), nt * 64)
+        bstores = np.zeros(NU, dtype=np.int64)
+        np.add.at(bstores, bs[bs >= 0], 1)
+        bvia = np.zeros(NU, dtype=np.int64)
+        bgd = T["b_gdst"].reshape(-1, 4); bgs = T["b_gsrc"].reshape(-1, 4)
+        assert len(T["b_gn"]) == b_ngroups
+        for k in range(b_ngroups):
+            d = bgd[k][bgd[k] >= 0]
+            bvia[d] += 1
+        assert ((bstores + bvia) == 1).all(), "block tables: a unique node is stored twice or never"
+        # a copy that goes to a slot in the block tables goes to the SAME slot in the wavefront-level tables (one slot array serves both)
+        assert (bs[bs <= -2] == sd[bs <= -2]).all() and set(-2 - bs[bs <= -2]) <= set(slots)
+        # the DSS list behind a block kernel is a sub-list of the full one, in its order
+        full = [tuple(r) for r in np.concatenate([gs, gd], axis=1)]
+        sub = [tuple(r) for r in np.concatenate([bgs, bgd], axis=1)]
+        it = iter(full)
+        assert all(any(x == y for y in it) for x in sub)
+        for t in np.nonzero(br)[0]:
+            n = br[t] & 15
+            assert n in (2, 4) and bs[t] == tu[t]
+            base = first[blk_of[t]] * 64
+            poss = [(br[t] >> sh) & 255 for sh in (4, 12, 20)][:n - 1]
+            for q in poss:
+                assert q < nt[blk_of[t]] * 64 and tu[base + q] == tu[t] and bs[base + q] == -1 and base + q != t
+            assert len(set(poss)) == n - 1
+        bpartners = set()
+        for t in np.nonzero(br)[0]:
+            bpartners |= {first[blk_of[t]] * 64 + ((br[t] >> sh) & 255) for sh in (4, 12, 20)[:(br[t] & 15) - 1]}
+        assert bpartners == set(np.nonzero(valid & (bs == -1))[0])
+        assert sorted(list(T["blks_early"]) + list(T["blks_late"])) == list(range(nblocks)) and (nb_early, nb_late) == (len(T["blks_early"]), len(T["blks_late"]))
+        early_tiles = set(np.nonzero(np.isin(np.arange(NTS // 64), [first[b] + w for b in T["blks_early"] for w in range(nt[b])]))[0])
         # what other ranks need
         send = e.plan(0).reshape(-1, 4) if n_ranks > 1 else np.zeros((0, 4), dtype=np.int32)
         assert len(T["send_slots"]) == len(send) and (nearly > 0) == (len(send) > 0)

@@ -146,3 +146,30 @@ def test_hyperviscosity_fused_with_the_in_patch_dss_is_bit_identical(ne, npatch,
         for (an, ae), (bn, be) in zip(a_inst, b_inst):
             assert np.array_equal(an[[0, 1, 2, 4], 1:-1, 1:-1], bn[[0, 1, 2, 4], 1:-1, 1:-1])
             assert np.array_equal(ae[3, 1:-1, 1:-1], be[3, 1:-1, 1:-1])
+
+
+@pytest.mark.parametrize("ne,npatch,shape,blocks", [(5, 6, 4, -1), (7, 6, 4, -1), (6, 24, 4, -1), (5, 6, 3, 1), (6, 24, 0, 1), (5, 6, 4, 0)])
+@pytest.mark.parametrize("scheme", ["ars343", "strang", "ark232"])
+def test_block_kernels_and_block_thread_orders_are_bit_identical(scheme, ne, npatch, shape, blocks):
+    """Round 6's archived experiment: thread orders 3 (generalised Hilbert curve) and 4 (4 x 4 element blocks, padded at ragged patch
+    edges: 5 x 5 and 7 x 7 element patches here) and the block kernels -- a workgroup of four wavefronts averages the seams between its
+    wavefronts through LDS (k_h_walk<.., BLK>, k_hypervis<.., BLK>), the DSS kernel runs the shorter list.  Three steps after the
+    element-major first one, against the element-major engine, bit for bit."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(ne, 6, npatch)
+    ni = max(7, Engine.scheme_instances(scheme))
+    d = Engine(g, n_instances=ni, options={"unique_layout": 0})
+    u = Engine(g, n_instances=ni, options={"unique_layout": 1, "unique_tile_shape": shape, "unique_blocks": blocks}, flavour="experiments")
+    try:
+        assert u.info(12) == 1 and u.get_option("unique_tile_shape") == shape
+        d.upload_state(0, start); u.upload_state(0, start)
+        for k in range(4):
+            d.step(scheme, 150.0, first=(k == 0)); u.step(scheme, 150.0, first=(k == 0))
+            if k >= 1:
+                assert u.info(13) > 0, "step %d did not run on the node-unique layout" % k
+        d.sync(); u.sync()
+        a, b = d.download_state(0), u.download_state(0)
+        for p_ in range(npatch):
+            assert np.array_equal(a[p_][0], b[p_][0]) and np.array_equal(a[p_][1], b[p_][1]), (scheme, p_)
+    finally:
+        d.close(); u.close()

@@ -59,26 +59,53 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
         d.close(); u.close()
 
 
-def test_stored_prefix_of_a_stage_combination_changes_no_bit():
+@pytest.mark.parametrize("walk", [-1000, 0])
+def test_stored_prefix_of_a_stage_combination_changes_no_bit(walk):
     """ARS343's third stage reads instances 0..4, the leading terms of the fourth stage's combination (1, 0, 2, 3, 4, 5, 6 in the
-    reference's accumulation order): with "unique_prefix" it also stores that partial sum, and the fourth stage reads it and instances 5, 6.  With the
-    option off (the default, and all the production library has: the extra store costs what the four reads save, DESIGN.md
-    section 3a; the storing kernels are in the experiments flavour of the library) every stage reads all its sources; same bits, with shared U,V slabs (the default) and with every copy made."""
+    reference's accumulation order): with "unique_prefix" (the default since round 6) it also stores that partial sum, and the fourth
+    stage reads it and instances 5, 6.  With the option off every stage reads all its sources; same bits, with shared U,V slabs (the
+    default) and with every copy made.  walk = 0: the level-parallel kernel stores a prefix in the experiments flavour of the library
+    only; the production library must then NOT plan one (a prefix nobody stored would be read)."""
     from tempestmodel_amd.engine import Engine
     g, start = gu.make_grid(6, 8, 6)
     for share in (1, 0):
-        a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1, "share_copies": share}, flavour="experiments")
-        b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0, "share_copies": share})      # (the production library)
+        a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1, "share_copies": share, "h_walk": walk})
+        b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0, "share_copies": share, "h_walk": walk})
         try:
             a.upload_state(0, start); b.upload_state(0, start)
             for k in range(5):
                 a.step("ars343", 120.0, first=(k == 0)); b.step("ars343", 120.0, first=(k == 0))
             a.sync(); b.sync()
-            assert a.info(INFO_PREFIX_STAGES) >= 4 and b.info(INFO_PREFIX_STAGES) == 0      # (one per step that ran node-unique)
+            assert (a.info(INFO_PREFIX_STAGES) >= 4 if walk else a.info(INFO_PREFIX_STAGES) == 0) and b.info(INFO_PREFIX_STAGES) == 0      # (one per step that ran node-unique)
             for ix in range(7):
                 assert _same(a.download_state(ix), b.download_state(ix), range(6)), ("instance", ix, "share_copies", share)
         finally:
             a.close(); b.close()
+
+
+def test_stored_prefix_and_copy_by_copy_reads_in_one_run():
+    """A step whose model state is element-major (freshly uploaded: read copy by copy, "unique_mixed") cannot store a prefix -- its third
+    stage reads instance 0 per copy -- and the fourth stage must then read all seven instances; the steps after it store and use one.
+    Alternating uploads and steps, prefix on against prefix off: same bits."""
+    from tempestmodel_amd.engine import Engine
+    g, start = gu.make_grid(5, 6, 6)
+    a = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 1})
+    b = Engine(g, n_instances=7, options={"unique_layout": 1, "unique_prefix": 0})
+    try:
+        a.upload_state(0, start); b.upload_state(0, start)
+        a.step("ars343", 120.0, first=True); b.step("ars343", 120.0, first=True)
+        for k in range(4):
+            if k % 2 == 0:      # a consistent element-major model state again: the next step reads it copy by copy
+                a.sync(); st = a.download_state(0)
+                a.upload_state(0, st); b.upload_state(0, st)
+            mixed0 = a.info(19)
+            a.step("ars343", 120.0); b.step("ars343", 120.0)
+            assert (a.info(19) > mixed0) == (k % 2 == 0)      # TMX_INFO_MIXED_STEPS
+        a.sync(); b.sync()
+        assert a.info(INFO_PREFIX_STAGES) >= 2 and b.info(INFO_PREFIX_STAGES) == 0
+        assert _same(a.download_state(0), b.download_state(0), range(6))
+    finally:
+        a.close(); b.close()
 
 
 def test_unique_layout_against_the_oracle_and_the_golden_vector():
