@@ -322,6 +322,25 @@ def cpu_baseline(ne, L, dt, nsteps_ref, nsteps_port):
             "sypd": dt / tmin / 365.0}
 
 
+def projected_from_rank_share(world, ne, L, measured_ms):
+    """What this N-rank step was expected to take, from the compute share of rank 0 measured on ONE GPU with the wire left out
+    (tools/rank_share_timing.py -> profiles/rNN_rank_shares.json): the share, the share + 6 exchanges at 10 / 30 us of exposed latency,
+    and the measured step beside them.  None when no table of this shape is committed."""
+    path = latest_profile("rank_shares.json")
+    if not path or (ne, L) != (30, 30):
+        return None
+    try:
+        tab = json.load(open(path))
+        share = tab["ms_per_step"].get(str(world))
+        if share is None:
+            return None
+        return {"source": os.path.relpath(path, ROOT), "compute_share_ms": share, "kernel_ms_per_step": tab.get("kernel_ms_per_step", {}).get(str(world)),
+                "projected_ms_per_step": {"exposed_exchange_10us": share + 0.06, "exposed_exchange_30us": share + 0.18},
+                "single_gpu_ms_per_step": tab["ms_per_step"].get("1"), "measured_ms_per_step": measured_ms}
+    except Exception:
+        return None
+
+
 def self_launch(n):
     """Run this script as n ranks under torch.distributed.run (127.0.0.1 rendezvous on a free port) and return the launcher's exit code.
     stdout of the ranks passes through (rank 0 prints the one JSON line), stderr too.  Nothing in this process has initialised the GPU."""
@@ -601,6 +620,13 @@ def main():
     if not state_finite and not ablation_build:
         sys.exit("bench.py: state became non-finite")
 
+    # N > 1: every rank's kernel split travels to rank 0 (the first multi-GPU record should explain itself)
+    rank_kernels = None
+    if world > 1:
+        mine = {k: v[0] / args.steps for k, v in prof.items()}
+        rank_kernels = [None] * world
+        dist.all_gather_object(rank_kernels, mine)
+
     if rank == 0:
         n_el = 6 * ne * ne
         dof_per_step = n_el * 16 * L * 5
@@ -745,7 +771,12 @@ def main():
             out["multi_rank"] = {"rccl_comm_ranks": eng.info(9), "halo_transport": {0: "none", 1: "rccl", 2: "p2p", 3: "loopback"}.get(eng.info(11), "?"),
                                  "rank0_message_bytes_per_peer": {str(k): v * nslab * 8 for k, v in sorted(per_peer.items())},
                                  "rank0_early_tiles": eng.info(7), "rank0_late_tiles": eng.info(8),
-                                 "parity": parity}
+                                 "parity": parity,
+                                 "per_rank_kernel_ms_per_step": rank_kernels,
+                                 "projected_from_rank_share": projected_from_rank_share(world, ne, L, ms_per_step),
+                                 "scaling_note": "strong scaling of a ~1.2 ms step is Amdahl-limited: the per-rank compute share measured on one GPU (wire left out) "
+                                                 "bounds the speed-up before any message is sent; weak scaling (--scaling weak: the grid grows with the rank count) is "
+                                                 "the regime the design is for (9.7-10.2 G element-DOF-updates/s per GPU from ne30 to ne84, profiles/r05_rate_over_sizes.txt)"}
         if ablation_build:      # a library named by TMX_LIBRARY: never a result, say so in the line itself
             out["ablation_build"] = True
             out["library"] = os.environ["TMX_LIBRARY"]

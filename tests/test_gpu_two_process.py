@@ -103,6 +103,31 @@ def test_bench_runs_as_two_rank_processes_on_one_device():
     assert d["multi_rank"]["halo_transport"] == "p2p" and d["sustained"]["steps"] > 0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how a driver may spell the multi-GPU run): the script starts torch.distributed.run
+    itself -- as a child process, before anything in the parent has touched the GPU -- and relays rank 0's JSON line and the exit code.
+    Both ranks on device 0 here (peer-to-peer halo); the line carries every rank's kernel split."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TMX_HALO"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--develop", "1", "--ne", "8", "--levels", "6",
+                        "--dt", "500", "--share-device", "--halo", "p2p", "--no-cpu-baseline", "--sustained-steps", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=400, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    assert "without a launcher" in r.stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["multi_rank"]["parity"]["identical_to_single_rank_engine"] is True
+    split = d["multi_rank"]["per_rank_kernel_ms_per_step"]
+    assert len(split) == 2 and all(s_["vi_solve"] > 0 and s_["h_explicit"] > 0 for s_ in split)
+    # a world that contradicts --gpus is refused, not re-launched
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, RANK="0", WORLD_SIZE="1"),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=120, cwd=root)
+    assert r2.returncode != 0 and "must equal WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
 def test_absent_neighbour_is_reported_not_hung():
     """A rank whose neighbour never sends: the wait kernel gives up after TMX_P2P_TIMEOUT_S and tmx_sync returns TMX_ERR_COMM."""
     with tempfile.TemporaryDirectory() as out:

@@ -29,6 +29,11 @@ else:
 echo "== 0. device count (expect >= 2)"
 python3 -c "import torch; print(torch.cuda.device_count())"
 
+echo "== 0b. the driver's spelling: python bench.py --gpus 2 WITHOUT a launcher (bench.py starts torch.distributed.run itself, as a child process)"
+echo "   expect: stderr says \"without a launcher\", ONE JSON line with n_gpus 2 and multi_rank.per_rank_kernel_ms_per_step of length 2"
+python bench.py --gpus 2 --steps 3 --warmup 1 --develop 1 --sustained-steps 0 --no-cpu-baseline 2>gpurun_out/first_contact_0b.err | tee gpurun_out/first_contact_0b.json | \
+	field "(d['n_gpus'], len(d['multi_rank']['per_rank_kernel_ms_per_step']), d['multi_rank']['parity'])"
+
 echo "== 1. two ranks, RCCL send/recv, 3 steps, NCCL_DEBUG=INFO"
 echo "   expect: 'NCCL INFO ... comm ... nranks 2' from both ranks, then ONE JSON line with"
 echo "           multi_rank.rccl_comm_ranks == 2, multi_rank.halo_transport == 'rccl', multi_rank.parity.identical_to_single_rank_engine == true,"
