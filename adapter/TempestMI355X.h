@@ -35,6 +35,14 @@
 #include "WorkflowProcess.h"
 
 #include "tempest_mi355x.h"
+#include "LinearAlgebra.h"
+
+// the reference's own declaration of dgbsv_ (LinearAlgebra.h: non-const pointers, int result) behind the ABI's probe signature
+static void TempestMI355X_dgbsv(const int * n, const int * kl, const int * ku, const int * nrhs, double * ab, const int * ldab, int * ipiv,
+	double * b, const int * ldb, int * info) {
+	int in = *n, ikl = *kl, iku = *ku, inrhs = *nrhs, ildab = *ldab, ildb = *ldb;
+	dgbsv_(&in, &ikl, &iku, &inrhs, ab, &ildab, ipiv, b, &ildb, info);
+}
 #include "WorkflowProcess.h"
 
 #include <cmath>
@@ -488,6 +496,18 @@ private:
 				Check(tmx_set_patch_metric_factors(m_pEngine, pPatch->GetPatchIndex(), &dXNode[0], &dYNode[0],
 					&(pPatch->GetTopographyDeriv()[0][0][0]), phys.GetEarthRadius(),
 					&(pGrid->GetREtaLevels()[0]), &(pGrid->GetREtaInterfaces()[0])));
+			}
+		}
+		// Which band LU does THIS build's LAPACK compute -- update a - l u as one rounding or two?  The engine holds both; asked here with the
+		// very dgbsv_ that LAPACK::DGBSV calls (LinearAlgebra.h), so that the drop-in equals the CPU path of the build it is dropped into.
+		// An explicit option "lu_fma" (SetOption / --tmx_option) wins.
+		{
+			bool fExplicit = false;
+			for (size_t o = 0; o < m_vecOptions.size(); o++) if (m_vecOptions[o].first == "lu_fma") fExplicit = true;
+			if (!fExplicit) {
+				const int iFlavour = tmx_lu_flavour_from_dgbsv(m_pEngine, &TempestMI355X_dgbsv);
+				if (iFlavour < 0) Announce("WARNING: %s", tmx_last_error());
+				else Announce("MI355X engine: band LU updates %s (this build's dgbsv_)", iFlavour ? "fused" : "as multiply + subtract");
 			}
 		}
 		for (size_t o = 0; o < m_vecOptions.size(); o++) {

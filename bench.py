@@ -658,7 +658,7 @@ def main():
         walk = eng.get_option("h_walk") != 0 and eng.info(12) == 1 and unique_after_timed > 0
         kernel_name = {"h_explicit": "k_h_walk<NT> (column-segment walk)" if walk else "k_h_explicit<true,NT>+k_h_w_update<NT>", "v_implicit": "k_vi_pair (two wavefronts per column group)",
                        "dss": "k_dss", "hypervis": "k_hypervis", "lincomb": "k_lincomb"}[dom]
-        if dom == "v_implicit" and eng.info(1) <= 6400:
+        if dom == "v_implicit" and eng.info(20) == 2:      # TMX_INFO_COLUMN_KERNEL: the kernel that really ran
             kernel_name = "k_vi_group (one column per 16-lane group)"
         mfma = mfma_report(eng.get_option("contraction_mfma") != 0)
         # second accounting, for the layout that ran (layout_model above) and the measured HBM rate = counter traffic / this run's time

@@ -405,7 +405,8 @@ enum {
 	TMX_INFO_UNIQUE_DSS_GROUPS,   /* node groups the DSS kernel of that layout finishes                               */
 	TMX_INFO_PREFIX_STAGES,       /* explicit stages so far whose combination started from a partial sum an earlier stage stored */
 	TMX_INFO_EXPERIMENTS_BUILD,   /* 1: the experiments flavour of the library (archived experiments and cross-check kernels compiled in) */
-	TMX_INFO_MIXED_STEPS          /* steps so far whose explicit stages read an element-major instance copy by copy beside node-unique ones ("unique_mixed") */
+	TMX_INFO_MIXED_STEPS,         /* steps so far whose explicit stages read an element-major instance copy by copy beside node-unique ones ("unique_mixed") */
+	TMX_INFO_COLUMN_KERNEL        /* the column-solve kernel of the last launch: 0 one wavefront per column group, 1 two-wavefront pair, 2 lane group, -1 none yet */
 };
 long long tmx_info(tmx_engine * e, int what);
 
@@ -436,12 +437,27 @@ long long tmx_info(tmx_engine * e, int what);
  *   "vi_*" (column solve kernel selection), "vt_*", "kessler_column", "hvis_pull", "hvis_block", "tracer_lincomb_pass", "udv_separate",
  *   "vx_fused": kernel selection / A-B switches, each with a bit-identity test; "debug_skip_exchange": timing aid with WRONG results
  *   at rank boundaries (tools/rank_share_timing.py only).
- * Archived experiments and cross-check kernels -- "unique_prefix", "hvis_pull", "hvis_block", "vi_split_kernels", "vi_pair" = 0,
+ *   "h_walk"            explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register
+ *                        window (tmx_k_hwalk.hip), segments per column from the grid size; -n = n segments; 0 = the level-parallel kernels.
+ *   "unique_prefix"     1 (default): an explicit stage also stores the leading partial sum of a later stage's combination (ARS343: the
+ *                        fourth stage reads 3 instances instead of 7); 0: every stage reads all its terms.  Same bits.
+ *   "lu_fma"            band LU of the column solves (LAPACK::DGBSV, src/base/LinearAlgebra.cpp:156-202): 1 (default) = updates a - l u fused
+ *                        (a reference linked to OpenBLAS, or to MKL on its FMA code paths), 0 = multiply and subtract rounded separately
+ *                        (a BLAS without fused multiply-adds).  tmx_lu_flavour_from_dgbsv (below) asks the caller's own LAPACK.
+ * Archived experiments and cross-check kernels -- "unique_blocks", "unique_tile_shape" = 3, 4, "hvis_pull", "hvis_block", "vi_split_kernels", "vi_pair" = 0,
  * "vi_carry", "vi_sparse", "vi_split_back", "vi_back_sub", "vx_fused", "vt_explicit_v1", "debug_skip_exchange" -- are compiled into the
  * experiments flavour of the library only (libtempest_mi355x_exp.so, `make -C tempestmodel_amd/csrc exp`; tmx_info(TMX_INFO_EXPERIMENTS_BUILD)):
  * the production library holds neither the kernels nor the switch, and answers TMX_ERR_UNSUPPORTED to any value but the default. */
 int tmx_set_option(tmx_engine * e, const char * name, double value);
 int tmx_get_option(tmx_engine * e, const char * name, double * value);
+/* Which band LU does the CALLER'S LAPACK compute (replaces nothing in the reference: it makes the drop-in safe by default)?  `dgbsv` is the
+ * Fortran-ABI routine the caller's Tempest is linked to (dgbsv_: what LAPACK::DGBSV calls, src/base/LinearAlgebra.h).  A 33 x 33 system of
+ * the column solve's band width is solved by it and, on the host, by LAPACK's algorithm with the update a - l u fused and unfused; returns 1
+ * (fused), 0 (multiply + subtract) and sets the engine's "lu_fma" option accordingly (e may be NULL: probe only), -1 if the routine's bits
+ * are neither (option untouched, tmx_last_error says so).  adapter/TempestMI355X.h calls it when the engine is created. */
+typedef void (*tmx_dgbsv_fn)(const int * n, const int * kl, const int * ku, const int * nrhs, double * ab, const int * ldab, int * ipiv,
+	double * b, const int * ldb, int * info);
+int tmx_lu_flavour_from_dgbsv(tmx_engine * e, tmx_dgbsv_fn dgbsv);
 /* "name=value" lines of every option as in use (defaults included) and, if tmx_options_from_environment applied any, the variables it
  * took; returns the buffer length needed (buf may be NULL). */
 int tmx_options_report(tmx_engine * e, char * buf, int cap);

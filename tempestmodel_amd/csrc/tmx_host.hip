@@ -67,8 +67,10 @@ void prof_collect(tmx_engine * e) {
 // life cycle
 
 static void tmx_record_option_defaults(tmx_engine * e);
+static bool options_table_consistent();
 extern "C" int tmx_create(const tmx_config * cfg, tmx_engine ** out) {
 	REQUIRE(cfg && out, TMX_ERR_INVALID, "tmx_create: null argument");
+	{ static const bool ok = options_table_consistent(); if (!ok) return TMX_ERR_INVALID; }
 	REQUIRE(cfg->abi_version == TMX_ABI_VERSION, TMX_ERR_INVALID, "tmx_create: ABI version %d, library is %d", cfg->abi_version, TMX_ABI_VERSION);
 	REQUIRE(cfg->horizontal_order == TMX_NP, TMX_ERR_UNSUPPORTED, "horizontal order %d unsupported (np = 4 only)", cfg->horizontal_order);
 	REQUIRE(cfg->vertical_order == 1, TMX_ERR_UNSUPPORTED, "vertical order %d unsupported (1 only)", cfg->vertical_order);
@@ -897,7 +899,7 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	// strength is stored per copy of a node) since round 5: the relaxation at the end of StepAfterSubCycle reads node-unique and writes
 	// element-major, and the next step reads that copy by copy ("unique_mixed").  Every other configuration, and every entry point other
 	// than tmx_step, works on the element-major layout as before.
-	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && (!e->rayleigh || e->u.mixed_option) && e->metric_closed &&
+	if (e->u.option != 0 && !e->sw && !e->fully_explicit && !e->udiff && e->nt == 0 && (!e->rayleigh || (e->u.mixed_option && e->u.tile_shape == 0)) && e->metric_closed &&
 	    !e->hvis_pull && !e->hvis_block && !e->use_graph && !e->use_mfma && e->vi_mode == 0) {
 		UniquePlanInput in = { &plan.grp_cols, &plan.grp_n, &plan.grp_x, &plan.grp_type, &plan.send_cols };
 		if ((r = tmxu_build(e, in, &bytes))) return r;
@@ -1427,7 +1429,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
 	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
 	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vite_walk", e->opt_vite_walk); OPT("vx_walk", e->opt_vx_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
-	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows); OPT("h_walk", e->opt_h_walk);
+	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows); OPT("h_walk", e->opt_h_walk); OPT("lu_fma", e->lu_fma);
 #undef OPT
 	return nullptr;
 }
@@ -1436,14 +1438,14 @@ static const OptionDef g_options[] = {
 	{ "unique_tile_shape", "TMX_UNIQUE_TILE", 1, "elements of a wavefront on that layout: 0 (default, measured fastest) the element-major order = 1 x 4 strips that wrap around patch rows, 1 = 2 x 2 blocks, 2 = strips that stay inside a patch row; experiments flavour only: 3 = a generalised Hilbert curve through every patch, 4 = 4 x 4 element blocks of 1 x 4 strips" },
 	{ "unique_blocks", "TMX_UNIQUE_BLOCKS", 2, "archived experiment (round 6: the DSS loses 0.05 ms per step, the producers pay 0.10): block kernels on that layout -- a workgroup of four wavefronts averages the seams between them through LDS, the DSS kernel finishes fewer nodes: -1 (default) on with unique_tile_shape 4, 0 off, 1 on with any thread order" },
 	{ "unique_xcd_order", "TMX_UNIQUE_XCD", 3, "A/B switch, experiments flavour only: 1 (default): every XCD sweeps a contiguous range of tiles" },
-	{ "unique_mixed", "TMX_UNIQUE_MIXED", 0, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
+	{ "unique_mixed", "TMX_UNIQUE_MIXED", 1, "1 (default): the explicit stages read a live-in element-major instance copy by copy (no check, no conversion); 0: check the copies, convert or run the step element-major" },
 	{ "unique_prefix", "TMX_UNIQUE_PREFIX", 0, "1 (default): an explicit stage also stores the leading partial sum of a later stage's combination over the instances both read (ARS343: the fourth stage reads 3 instances instead of 7); 0: every stage reads all its terms" },
 	{ "share_copies", "TMX_SHARE_COPIES", 0, "1 (default): stage copies that stay identical to their source share its slot instead of being made" },
 	{ "xcd_vertical", "TMX_XCD_VERTICAL", 2, "A/B switch, experiments flavour only: 1 (default): level blocks of a column tile on one XCD in the vertical stencil kernels" },
 	{ "vi_carry", "TMX_VI_CARRY", 2, "column solve: carry shared sub-expressions between block rows (1)" },
 	{ "vi_pair", "TMX_VI_PAIR", 2, "column solve: two-wavefront kernel (-1 auto, 0 one-wavefront kernel, 1 on)" },
-	{ "vi_group", "TMX_VI_GROUP", 0, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
-	{ "vi_group_max", "TMX_VI_GROUP_MAX", 0, "largest rank share (unique columns) served by the lane-group kernel (6400)" },
+	{ "vi_group", "TMX_VI_GROUP", 1, "column solve: one column per 16-lane group (-1 auto: up to vi_group_max unique columns, 0, 1)" },
+	{ "vi_group_max", "TMX_VI_GROUP_MAX", 1, "largest rank share (unique columns) served by the lane-group kernel (6400)" },
 	{ "vi_pair_workgroup", "TMX_VI_PAIR_WG", 0, "pairs per workgroup of the two-wavefront kernel (0 auto)" },
 	{ "vi_ring_depth", "TMX_VI_RING_DEPTH", 0, "block rows in the LDS ring between assembly and elimination: 0 auto (3, or 2 where only that fits two workgroups per CU: more than ~38 levels), 2, 3" },
 	{ "vi_producers", "TMX_VI_PRODUCERS", 0, "assembly wavefronts per column group of that kernel: 0 auto (2 on grids that leave every wavefront a SIMD of its own), 1, 2" },
@@ -1475,11 +1477,18 @@ static const OptionDef g_options[] = {
 	{ "vt_lw8", "TMX_VT_LW8", 2, "A/B switch, experiments flavour only: row-parallel tracer kernel: 8 columns per workgroup (-1 auto)" },
 	{ "vt_row_lanes", "TMX_VT_NR", 2, "A/B switch, experiments flavour only: row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
+	{ "lu_fma", "TMX_LU_FMA", 0, "band LU of the column solves: 1 (default) updates a - l u as ONE rounding (fused multiply-add: a reference linked to OpenBLAS, or to MKL on its FMA code paths), 0 = multiply and subtract rounded separately (a BLAS without fused multiply-adds); tmx_lu_flavour_from_dgbsv asks the caller's own LAPACK" },
 	{ "h_walk", "TMX_H_WALK", 0, "explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register window, segments per column from the grid size; -n = n segments; 0 = the level-parallel kernel + k_h_w_update" },
 };
 static void tmx_record_option_defaults(tmx_engine * e) {
 	e->opt_default.clear();
-	for (const OptionDef & d : g_options) e->opt_default.push_back(*option_slot(e, d.name));
+	for (const OptionDef & d : g_options) { int * slot = option_slot(e, d.name); e->opt_default.push_back(slot ? *slot : 0); }
+}
+// every row of g_options has its OPT() line (a row without one used to crash tmx_create): checked once per process
+static bool options_table_consistent() {
+	tmx_engine probe;
+	for (const OptionDef & d : g_options) if (!option_slot(&probe, d.name)) { tmx_set_error("internal: option '%s' has no slot", d.name); return false; }
+	return true;
 }
 extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	REQUIRE(e && name, TMX_ERR_INVALID, "tmx_set_option: null argument");
@@ -1514,7 +1523,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;
@@ -1587,6 +1596,7 @@ extern "C" long long tmx_info(tmx_engine * e, int what) {
 		case TMX_INFO_PREFIX_STAGES: return e->u.prefix_stages;
 		case TMX_INFO_EXPERIMENTS_BUILD: return TMX_EXP;
 		case TMX_INFO_MIXED_STEPS: return e->u.mixed_steps;
+		case TMX_INFO_COLUMN_KERNEL: return e->vi_kernel_launched;
 		case TMX_INFO_COMM_RANKS: {      // what RCCL itself reports for the communicator (0: no communicator)
 			int n = 0;
 			if (e->comm && g_nccl.CommCount && g_nccl.CommCount(e->comm, &n) == 0) return n;
@@ -1619,7 +1629,7 @@ extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 	} else if (what == 5) {
 		v = plan.grp_type;
 	} else return -1;
-	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
+	if (out) { if ((int)v.size() > cap) return -1; if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int)); }      // (an empty table has no data pointer to hand to memcpy: found by the sanitized build)
 	return (int)v.size();
 }
 
@@ -1628,7 +1638,7 @@ extern "C" int tmx_plan_get(tmx_engine * e, int what, int * out, int cap) {
 extern "C" int tmx_plan_get_matrices(tmx_engine * e, double * out, int cap) {
 	if (!e || !e->finalized) return -1;
 	PlanHost & plan = plan_of(e);
-	if (out) { if ((int)plan.xmat.size() > cap) return -1; memcpy(out, plan.xmat.data(), plan.xmat.size() * sizeof(double)); }
+	if (out) { if ((int)plan.xmat.size() > cap) return -1; if (!plan.xmat.empty()) memcpy(out, plan.xmat.data(), plan.xmat.size() * sizeof(double)); }
 	return (int)plan.xmat.size();
 }
 
@@ -1657,7 +1667,7 @@ extern "C" int tmx_debug_unique_tables(tmx_engine * e, int tile_shape, int what,
 		case 9: v = T.send_slots; break; case 10: v = T.u_rep; break; case 11: v = T.ucol_of_dcol; break; case 12: v = T.tinfo; break;
 		default: return -1;
 	}
-	if (out) { if ((int)v.size() > cap) return -1; memcpy(out, v.data(), v.size() * sizeof(int)); }
+	if (out) { if ((int)v.size() > cap) return -1; if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int)); }
 	return (int)v.size();
 }
 

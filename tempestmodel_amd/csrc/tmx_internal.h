@@ -262,6 +262,7 @@ struct tmx_engine {
 	unsigned long long * d_pivot_stats = nullptr;      // tmx_debug_pivot_stats: {uniform pivot steps, all pivot steps} of k_vi_pair, per wavefront
 	int use_mfma = 0;                        // option "contraction_mfma" (TMX_MFMA=1): 4x4 contractions of the fused explicit kernel on the matrix unit (not bit-exact)
 	int vi_group = -1, vi_group_max = 6400;     // lane-group column kernel: -1 auto (nunique <= vi_group_max; column solve per step, group / pair kernel: 0.171 / 0.281 ms at 2 116 columns, 0.237 / 0.279 at 6 075, 0.349 / 0.279 at 8 100), 0 off, 1 on (TMX_VI_GROUP, TMX_VI_GROUP_MAX)
+	int vi_kernel_launched = -1;             // the column-solve kernel of the last launch: 0 one wavefront per column group, 1 pair (assembly || elimination), 2 lane group; -1 none yet
 	int vi_cpw = 64, vi_stream_cols = 0;     // columns per wavefront of k_vi_pair (TMX_VI_CPW; auto: fill every SIMD evenly), stream columns allocated
 	int p2p_timeout_s = 600;                 // peer-to-peer halo: how long a neighbour's message may take (TMX_P2P_TIMEOUT_S; 0 = for ever)
 	const int * stage_quads = nullptr;       // tile list of the boundary-first stage in progress (make_params -> KParams.quads)
@@ -298,6 +299,7 @@ struct tmx_engine {
 	int opt_no_split = 0, opt_metric_stored = 0, opt_tracer_lincomb_pass = 0, opt_udv_separate = 0, opt_vx_fused = 0, opt_skip_exchange = 0,
 	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_walk = -1000, opt_vite_walk = -1000, opt_vx_walk = -1000, opt_vt_lanes = 16,
 	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
+	int lu_fma = 1;                          // option "lu_fma": 1 = band-LU updates as fused multiply-adds (OpenBLAS, MKL's FMA paths), 0 = multiply + subtract (tmx_lu_select.hip)
 	int opt_h_walk = -1000;                  // explicit stage on the node-unique layout: -1000 auto (column-segment walk, segments from the grid size), -n = n segments, 0 = the level-parallel kernel
 	std::vector<int> opt_default;            // default of every option, in g_options order (tmx_record_option_defaults)
 	std::vector<std::string> env_applied;    // "NAME=value" of every environment variable tmx_options_from_environment turned into an option

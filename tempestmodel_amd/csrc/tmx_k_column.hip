@@ -15,6 +15,15 @@
 // Reference behaviour restated (file:line under the reference tree) is cited per kernel.
 #include "tmx_device.h"
 
+// Both flavours of the band LU live in ONE library: this translation unit is compiled twice -- as it stands (LU updates fused, what OpenBLAS
+// and MKL's FMA code paths compute) and with -DTMX_LU_NOFMA (multiply and subtract rounded separately, a BLAS without fused multiply-adds:
+// tmx_device.h, LU_UPD) -- into a namespace each; tmx_lu_select.hip dispatches by the engine's option "lu_fma" (tmx_set_option, any time).
+#ifdef TMX_LU_NOFMA
+namespace lu_nofma {
+#else
+namespace lu_fma {
+#endif
+
 #if TMX_EXP      // the two-kernel cross-check path (option "vi_split_kernels"): in the experiments flavour of the library only
 // ---------------------------------------------------------------------------------------------
 // V implicit, part 1: residual F and analytic band Jacobian of one block row (level) of one column
@@ -1784,11 +1793,13 @@ void tmxk_vi_fused(tmx_engine * e, const KParams & p, const double * xin, double
 	const bool group_fits = (size_t)((e->nunique + 3) / 4) * 64 <= (size_t)TMX_UW * e->vi_stream_cols;
 	if (group_fits && (e->vi_group == 1 || (e->vi_group < 0 && e->nunique <= e->vi_group_max))) {
 		const int nwg = (e->nunique + 3) / 4;
+		e->vi_kernel_launched = 2;
 		if (p.closed) hipLaunchKernelGGL((k_vi_group<true>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
 		else hipLaunchKernelGGL((k_vi_group<false>), dim3(nwg), dim3(64), 0, e->stream, p, xin, xup, dt, e->nunique, ucolp, udepp, e->d_ab, e->d_flag);
 		return;
 	}
 	const bool use_pair = !TMX_EXP || (e->vi_pair == 1) || (e->vi_pair < 0 && e->vi_carry);
+	e->vi_kernel_launched = use_pair ? 1 : 0;      // (tmx_info(TMX_INFO_COLUMN_KERNEL): which kernel really ran, whatever the options asked for)
 	const int cpw = use_pair ? e->vi_cpw : 64;
 	const int ngrp = (e->nunique + cpw - 1) / cpw;
 	if (use_pair) {
@@ -2103,4 +2114,4 @@ void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xi
 		hipLaunchKernelGGL((k_vi_terms_explicit<false, false>), grd, blk, 0, e->stream, p, xin, xup, dt, (const double *)nullptr, 0.0, 0.0, nt_, xm);
 }
 
-
+}      // namespace lu_fma / lu_nofma

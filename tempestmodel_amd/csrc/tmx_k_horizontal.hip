@@ -523,6 +523,8 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	const bool uq = p.t_ucol != nullptr;      // node-unique layout (tmxu_params): 1-D launches, XCD-aware tile order
 	if (uq) e->u.slots_by_blocks = false;      // (wavefront-level seam exchange: the DSS kernel runs its full list)
+	// copy-by-copy reads of element-major sources exist in the node-unique kernels with the vertical part fused in only
+	if (dmask && !(uq && fuse_v)) { tmx_set_error("internal: explicit stage with element-major sources outside the fused node-unique kernels"); hipMemsetAsync(e->d_flag, 0xff, sizeof(int), e->stream); return; }
 	KParams q = p; q.u_ntiles = ntile;
 	const int wstride = TMX_H_FUSE_W ? KT_H : 1;
 	const int nyb = (p.L + KT_H - 1) / KT_H, nyb2 = ((p.L + wstride - 1) / wstride + 1 + 3) / 4;

@@ -15,6 +15,15 @@
 // Reference behaviour restated (file:line under the reference tree) is cited per kernel.
 #include "tmx_device.h"
 
+// Both flavours of the band LU live in ONE library: this translation unit is compiled twice -- as it stands (LU updates fused, what OpenBLAS
+// and MKL's FMA code paths compute) and with -DTMX_LU_NOFMA (multiply and subtract rounded separately, a BLAS without fused multiply-adds:
+// tmx_device.h, LU_UPD) -- into a namespace each; tmx_lu_select.hip dispatches by the engine's option "lu_fma" (tmx_set_option, any time).
+#ifdef TMX_LU_NOFMA
+namespace lu_nofma {
+#else
+namespace lu_fma {
+#endif
+
 template <bool UDV>
 __global__ __launch_bounds__(64 * KT_VE) void k_v_explicit(KParams p, const double * __restrict__ xin,
 	double * __restrict__ xup, double dt, const double * __restrict__ xref, double cf, int ntile, int xmode)
@@ -1344,3 +1353,5 @@ void tmxk_v_filter_tracers(tmx_engine * e, const KParams & p, double * x) {
 // "Ullrich update" (:186-247).  The surface pressure is PressureFromRhoTheta(rho_e0 * rhotheta_e0) of the tracked surface
 // slots (`surf` = [2][NS]: what the reference finds in the interface entries of rho and rho*theta, :113-116), or, when the
 // caller pinned it, the input of tmx_set_patch_physics_inputs.
+
+}      // namespace lu_fma / lu_nofma

@@ -1636,6 +1636,7 @@ static int u_vimp(tmx_engine * e, int a, int b, double dt, bool share) {
 		tmxk_vi_fused(e, tmxu_params_columns(e, make_params(e)), uinst(e, a), uinst(e, b), dt);
 		e->vi_unique = false;
 	}
+	e->u.dlive &= ~(1u << b);      // b is node-unique in every slab from here on (its U,V copied or shared from a, the rest solved): a later stage must not read a stale element-major slot
 	u_written(e, b);
 	if (a != b && share) { e->uvmap[b] = a; e->n_uvshared++; }
 	return launch_check("column solve (node-unique layout)");

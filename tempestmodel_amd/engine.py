@@ -71,11 +71,9 @@ def load_library(flavour=None):
     if flavour not in (None, "production", "experiments"):
         raise ValueError("unknown library flavour %r" % (flavour,))
     path = os.environ.get("TMX_LIBRARY") or LIB_PATH      # TMX_LIBRARY: an experimental build of the same library (tools/ablate.sh)
-    if os.environ.get("TMX_LU_FMA") == "0" and not os.environ.get("TMX_LIBRARY"):
-        # the flavour whose band-LU updates are multiply + subtract (`make -C tempestmodel_amd/csrc nofma`): for a reference
-        # linked to a BLAS without fused multiply-adds
-        path = LIB_PATH.replace(".so", "_nofma.so")
-    elif flavour == "experiments" and not os.environ.get("TMX_LIBRARY"):
+    # (TMX_LU_FMA=0 -- band-LU updates as multiply + subtract, for a reference linked to a BLAS without fused multiply-adds -- used to
+    # select a second library; it is the option "lu_fma" of the one library now, applied with the other TMX_* variables)
+    if flavour == "experiments" and not os.environ.get("TMX_LIBRARY"):
         path = LIB_PATH.replace(".so", "_exp.so")
     if path in _libs:
         return _libs[path]

@@ -91,20 +91,26 @@ def test_layout_groups_and_unique_columns(ne, L, npatch):
     e.close()
 
 
-def test_two_rank_plans_are_mutually_consistent():
+@pytest.mark.parametrize("ne,npatch,nr", [(4, 24, 3), (6, 54, 5), (8, 96, 7), (6, 54, 3), (4, 24, 7)])
+def test_rank_plans_are_mutually_consistent(ne, npatch, nr):
+    """What rank s sends to rank r, in wire order, is what r expects from s, in ghost order -- also on odd layouts (54 / 96 patches over
+    3 / 5 / 7 ranks: uneven patch counts per rank, ranks that are not neighbours)."""
     from tempestmodel_amd.engine import Engine
-    g, _ = gu.make_grid(4, 6, 24)
-    es = [Engine(g, device=-2, rank=r, n_ranks=3) for r in range(3)]
+    g, _ = gu.make_grid(ne, 6, npatch)
+    es = [Engine(g, device=-2, rank=r, n_ranks=nr) for r in range(nr)]
     sends = [e.plan(0).reshape(-1, 4) for e in es]
     recvs = [e.plan(1).reshape(-1, 4) for e in es]
-    for r in range(3):
-        for s in range(3):
+    pairs = 0
+    for r in range(nr):
+        for s in range(nr):
             if r == s:
                 continue
             a = sends[s][sends[s][:, 3] == r][:, :3]       # what s sends to r, in wire order
             b = recvs[r][recvs[r][:, 3] == s][:, :3]       # what r expects from s, in ghost order
             assert np.array_equal(a, b)
-            assert len(a) > 0
+            pairs += len(a) > 0
+    assert pairs >= 2 * (nr - 1)      # every rank has a neighbour, both directions
+    assert sum(len(e.local_patches) for e in es) == npatch
     for e in es:
         e.close()
 
@@ -293,7 +299,7 @@ def _unique_tables(e, shape):
     return out
 
 
-@pytest.mark.parametrize("ne,npatch,n_ranks", [(5, 6, 1), (6, 24, 1), (12, 24, 3), (7, 6, 1)])
+@pytest.mark.parametrize("ne,npatch,n_ranks", [(5, 6, 1), (6, 24, 1), (12, 24, 3), (7, 6, 1), (6, 54, 5), (8, 96, 7), (9, 54, 3)])
 @pytest.mark.parametrize("shape", [0, 1, 2, 3, 4])
 def test_unique_layout_tables(ne, npatch, n_ranks, shape):
     """Host logic of the node-unique layout (tmxu_tables), on plan-only engines: every unique node is stored by exactly one place
@@ -455,3 +461,48 @@ def test_stage_combinations_that_start_from_a_stored_partial_sum():
         assert n >= 0 and all(pairs[2 * k] < pairs[2 * k + 1] and terms[k] >= 1 for k in range(n)), name
         assert all(pairs[2 * k + 1] < pairs[2 * k + 2] for k in range(n - 1)), name      # one slot: the spans do not touch
     assert lib.tmx_debug_program_prefix(99, 0, 0, pairs, terms, 8) == -1
+
+
+def test_lu_flavour_probe_recognises_the_callers_dgbsv():
+    """tmx_lu_flavour_from_dgbsv: which band LU does the caller's LAPACK compute?  Handed the C oracle's dgbsv in either mode (a
+    restatement that is pinned to the real libraries: test_oracle_vs_reference.py) it must name the mode and set the engine's option; handed
+    scipy's LAPACK (an OpenBLAS with FMA kernels on this host, or whatever is installed) it must name one of the two; handed a routine
+    that solves something else it must say so (-1) and leave the option alone."""
+    from tempestmodel_amd import engine as eng
+    from tempestmodel_amd.engine import Engine
+    from oracle_lib import lib as olib
+    lib = eng.load_library()
+    FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int))
+    lib.tmx_lu_flavour_from_dgbsv.argtypes = [ctypes.c_void_p, FN]
+    o = olib()
+    o.orc_dgbsv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+
+    def via_oracle(n, kl, ku, nrhs, ab, ldab, ipiv, b, ldb, info):
+        info[0] = o.orc_dgbsv(n[0], kl[0], ku[0], ab, ldab[0], ipiv, b)
+
+    def via_scipy(n, kl, ku, nrhs, ab, ldab, ipiv, b, ldb, info):
+        from scipy.linalg import lapack
+        A = np.ctypeslib.as_array(ab, shape=(n[0], ldab[0])).T.copy()      # column-major [ldab][n]
+        rhs = np.ctypeslib.as_array(b, shape=(n[0],)).copy()
+        lub, piv, x, inf = lapack.dgbsv(kl[0], ku[0], A, rhs)
+        np.ctypeslib.as_array(b, shape=(n[0],))[:] = x
+        info[0] = inf
+
+    def wrong(n, kl, ku, nrhs, ab, ldab, ipiv, b, ldb, info):
+        np.ctypeslib.as_array(b, shape=(n[0],))[:] = 1.0
+        info[0] = 0
+
+    g, _ = gu.make_grid(3, 4, 6)
+    e = Engine(g, device=-2)
+    try:
+        for mode in (0, 1):
+            o.orc_set_lu_fma(mode)
+            assert lib.tmx_lu_flavour_from_dgbsv(e.h, FN(via_oracle)) == mode and e.get_option("lu_fma") == mode
+        o.orc_set_lu_fma(1)
+        assert lib.tmx_lu_flavour_from_dgbsv(None, FN(via_scipy)) in (0, 1)
+        assert lib.tmx_lu_flavour_from_dgbsv(e.h, FN(wrong)) == -1 and b"neither" in lib.tmx_last_error() and e.get_option("lu_fma") == 1
+    finally:
+        o.orc_set_lu_fma(1)
+        e.close()

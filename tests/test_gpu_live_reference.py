@@ -287,14 +287,13 @@ def test_held_suarez_L60_24_patches_vs_live_reference():
 
 def test_band_lu_without_fused_multiply_add_flavour():
     """A reference linked to a BLAS without fused multiply-adds (plain netlib, MKL on some AMD hosts) evaluates the band LU's
-    updates as multiply + subtract; the oracle restates that with orc_set_lu_fma(0) and the product with its second library
-    flavour (libtempest_mi355x_nofma.so, TMX_LU_FMA=0).  The column solve of that flavour equals the oracle's in that mode
-    bit for bit -- and differs from the default flavour, so the switch is not a no-op.  Runs in a child process (the
-    library is chosen when it is first loaded)."""
+    updates as multiply + subtract; the oracle restates that with orc_set_lu_fma(0) and the product with its option "lu_fma" = 0
+    (both flavours of the band LU are compiled into the one library since round 6; TMX_LU_FMA=0 is the variable the test plumbing turns
+    into the option).  The column solve of that flavour equals the oracle's in that mode bit for bit -- and differs from the default
+    flavour, so the switch is not a no-op.  The child process takes the variable; the same two flavours in ONE process:
+    test_both_band_lu_flavours_in_one_process."""
     import subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "tempestmodel_amd", "libtempest_mi355x_nofma.so")):
-        pytest.fail("libtempest_mi355x_nofma.so is missing: build() makes it (make -C tempestmodel_amd/csrc nofma)")
     code = textwrap.dedent("""
         import os, sys
         sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
@@ -328,22 +327,52 @@ def test_band_lu_without_fused_multiply_add_flavour():
     assert err_nofma <= EXACT and err_fma > EXACT
 
 
+def test_both_band_lu_flavours_in_one_process():
+    """Option "lu_fma" of ONE library, two engines side by side: each equals the oracle in its mode, bit for bit, for the column solve and
+    for three whole ARS343 steps, and the two differ from one another."""
+    from oracle_lib import Oracle, lib
+    from tempestmodel_amd.engine import Engine
+    d = gu.load("steps_ne4_L6_p24.npz")
+    g, _ = gu.make_grid(4, 6, 24)
+    start = gu.expand_compact(d, "step2", g)
+    got = {}
+    try:
+        for fma in (1, 0):
+            lib().orc_set_lu_fma(fma)
+            o = Oracle(g); o.set_state(0, start); o.set_state(1, start); o.set_state(2, start)
+            assert o.v_step_implicit(1, 2, 87.0) == 0
+            e = Engine(g, options={"lu_fma": fma})
+            try:
+                assert e.get_option("lu_fma") == fma
+                e.upload_state(0, start); e.upload_state(1, start); e.copy_data(1, 2); e.v_step_implicit(1, 2, 87.0); e.sync()
+                assert max(gu.prognostic_errors(e.download_state(2), o.get_state(2))) <= EXACT, fma
+                for _ in range(3):
+                    assert o.step_ars343(200.0) == 0
+                    e.step_ars343(200.0)
+                e.sync()
+                got[fma] = e.download_state(0)
+                assert max(gu.prognostic_errors(got[fma], o.get_state(0))) <= EXACT, fma
+            finally:
+                e.close()
+    finally:
+        lib().orc_set_lu_fma(1)
+    assert max(gu.prognostic_errors(got[0], got[1])) > EXACT
+
+
 def test_nofma_flavour_vs_live_mkl_reference():
-    """Pins the second library flavour (libtempest_mi355x_nofma.so: band-LU updates as multiply + subtract) to a REAL reference:
+    """Pins the multiply + subtract flavour of the band LU (option "lu_fma" = 0) to a REAL reference:
     the MKL-linked oracle/_ref/tmx_ref_dump run live on this host.  MKL 2021.4 dispatches a non-FMA level-2 path on the AMD
     hosts of the GPU boxes (tools/host_lapack_probe.sh), which is the host class the flavour exists for.  Whether THIS host is
     one is measured, not assumed: the MKL build and the OpenBLAS-netlib build (FMA kernels on every host) of the reference
     run the same 100 steps at ne4 L10; identical checksums mean MKL uses FMAs here, the default flavour is the matching one
     (test_hundred_steps_ne15_L30 covers it) and this test skips, saying so.  Otherwise BASELINE config 2 (ne15 np4 L30,
     dt 300 s) runs 100 ARS343 steps in the MKL reference, which hands over its own geometry and its state after 2 steps, and
-    the nofma flavour must reproduce the reference's final state bit for bit (child process: the library is chosen at load)."""
+    the multiply + subtract flavour must reproduce the reference's final state bit for bit."""
     import subprocess, sys, tempfile, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mkl_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump")
     ob_bin = os.path.join(root, "oracle", "_ref", "tmx_ref_dump_lapack2")
     gu.need_live_reference(mkl_bin, ob_bin)
-    if not os.path.exists(os.path.join(root, "tempestmodel_amd", "libtempest_mi355x_nofma.so")):
-        pytest.fail("libtempest_mi355x_nofma.so is missing: build() makes it (make -C tempestmodel_amd/csrc nofma)")
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     sums = []
     for b in (mkl_bin, ob_bin):
