@@ -1509,7 +1509,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 		REQUIRE(iv >= 0 && iv <= 4, TMX_ERR_INVALID, "unique_tile_shape: 0, 1 or 2 (3, 4: experiments flavour of the library)");
 		REQUIRE(TMX_EXP || iv <= 2, TMX_ERR_UNSUPPORTED, "tmx_set_option(unique_tile_shape = %d): an archived experiment, compiled into the experiments flavour of the library only (libtempest_mi355x_exp.so)", iv);
 	}
-	if (n == "unique_blocks") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "unique_blocks: -1 (auto), 0 or 1");
+	if (n == "unique_blocks") REQUIRE(iv >= -1 && iv <= 3, TMX_ERR_INVALID, "unique_blocks: -1 (auto), 0, 1, 2 (the walk only) or 3 (the hyperviscosity pass only)");
 	if (n == "p2p_timeout_s") REQUIRE(iv >= 0, TMX_ERR_INVALID, "p2p_timeout_s must not be negative");
 	// integer options that select a kernel shape: only the values a launch knows (everything else used to fall through to a default silently)
 	if (n == "vi_group") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vi_group: -1 (auto), 0 or 1");

@@ -116,6 +116,7 @@ struct UniqueLayout {
 	int b_ngroups = 0, b_ngroups_local = 0, nblocks = 0, nb_early = 0, nb_late = 0;
 	int * d_b_sdst = nullptr, * d_b_sred = nullptr, * d_blk_info = nullptr, * d_b_gsrc = nullptr, * d_b_gdst = nullptr, * d_b_gn = nullptr, * d_b_gx = nullptr, * d_b_gtype = nullptr;
 	int * d_blks_early = nullptr, * d_blks_late = nullptr;
+	bool vite_ok = true;                     // every copy of every node carries the same bits in the per-column geometry k_vi_terms_explicit reads (else programs with StepImplicitTermsExplicitly run element-major)
 	bool slots_by_blocks = false;            // the partial slots in memory were written by block kernels: the DSS runs the shorter list
 	int block_option = -1;                   // tmx_set_option("unique_blocks"): -1 auto (on with the block thread order), 0 off, 1 on
 	size_t ustride = 0;                      // doubles per U-form instance (nslab * NUS)
@@ -346,7 +347,14 @@ void tmxuk_gather_rows(tmx_engine * e, int nrows, const double * xd, double * xu
 #else
 #define TMX_EXP 0
 #endif
-static inline bool tmxu_blocks_on(const tmx_engine * e) { return TMX_EXP && e->u.built && (e->u.block_option == 1 || (e->u.block_option < 0 && e->u.tile_shape == 4)); }
+// which: 0 any, 1 the explicit stage's walk, 2 the hyperviscosity pass (option values 2 / 3 switch only that kernel to its block form: A/B and debugging)
+static inline bool tmxu_blocks_on(const tmx_engine * e, int which = 0) {
+	if (!TMX_EXP || !e->u.built) return false;
+	const int o = e->u.block_option;
+	if (o == 2) return which != 2;
+	if (o == 3) return which != 1;
+	return o == 1 || (o < 0 && e->u.tile_shape == 4);
+}
 
 // kernel launchers (tmx_k_*.hip)
 // the prefix of a later stage's combination that an explicit stage also forms and stores (emit_value in tmx_device.h)

@@ -1087,7 +1087,7 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
 	if (p.t_ucol) {      // node-unique layout (tmxu_params)
 		KParams q = p; q.u_ntiles = ntiles;
-		const bool blocks = tmxu_blocks_on(e);      // a workgroup = a block of the thread order at one level: its seams are averaged in the kernel
+		const bool blocks = tmxu_blocks_on(e, 2);      // a workgroup = a block of the thread order at one level: its seams are averaged in the kernel
 		e->u.slots_by_blocks = blocks;
 		if (blocks) {
 			const int nblk = p.bquads ? e->launch_blocks : e->u.nblocks;

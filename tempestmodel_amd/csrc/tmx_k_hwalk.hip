@@ -441,7 +441,7 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms);
 	KParams q = p; q.u_ntiles = ntile;
 	// block kernels: the launch is over the blocks of the thread order (four wavefronts each), the seams between a block's wavefronts never reach the partial slots
-	const bool blocks = tmxu_blocks_on(e) && p.L >= 3;
+	const bool blocks = tmxu_blocks_on(e, 1) && p.L >= 3;
 	const int nblk = p.bquads ? e->launch_blocks : e->u.nblocks;
 	if (blocks) q.u_ntiles = nblk;
 	e->u.slots_by_blocks = blocks;

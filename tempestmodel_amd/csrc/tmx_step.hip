@@ -1582,7 +1582,7 @@ static int u_stage(tmx_engine * e, int iinit, int ibase, int iupd, double dt, co
 	EmitTerms em; em.xp = nullptr; em.first = -1;
 	// (only a kernel that really stores it: the column-segment walk, or the level-parallel kernel of the experiments flavour; element-major sources: no prefix)
 	const bool walk = tmxk_h_walk_ok(e, tmxu_params(e, make_params(e)), 1, n, true);
-	if (emit && lc && !premul && n >= 3 && n <= 8 && !dmask && (walk ? !tmxu_blocks_on(e) : TMX_EXP != 0)) {      // (the block form of the walk stores none)
+	if (emit && lc && !premul && n >= 3 && n <= 8 && !dmask && (walk ? !tmxu_blocks_on(e, 1) : TMX_EXP != 0)) {      // (the block form of the walk stores none)
 		em.xp = prefix; em.first = emit->first; for (int m = 0; m < 12; m++) em.coef[m] = emit->coef[m];
 	}
 	if (emit) e->u.prefix_for = em.xp ? (long long)emit->consumer : -1;      // which operation may start from the stored prefix (run_program_unique)
@@ -1662,7 +1662,7 @@ static int u_dss(tmx_engine * e, int ix) {
 	int r;
 	if ((r = u_own_uv(e, ix))) return r;
 	{ ProfScope ps(e, TMX_K_DSS); tmxuk_slots_from_u(e, uinst(e, ix)); }
-	e->u.slots_by_blocks = tmxu_blocks_on(e);      // every slot holds its node's value: the shorter list changes the same nodes (a group of identical copies averages to itself)
+	e->u.slots_by_blocks = tmxu_blocks_on(e) && !getenv("TMX_DEBUG_DSS_FULL");      // every slot holds its node's value: the shorter list changes the same nodes (a group of identical copies averages to itself)
 	if ((r = exchange(e, tmxu_params(e, make_params(e)), nullptr, &overlapped))) return r;
 	r = u_dss_finish(e, ix, overlapped);
 	u_written(e, ix);
@@ -1841,6 +1841,10 @@ static int try_step_unique(tmx_engine * e, const Program & p, bool * done) {
 	UniqueLayout & u = e->u;
 	if (!u.built || false || !program_fits_unique(p)) return TMX_OK;
 	if (e->rayleigh && !rayleigh_program_ok(p)) return TMX_OK;
+	// StepImplicitTermsExplicitly evaluates EVERY stored copy of a node with the copy's own column metric (VerticalDynamicsFEM.cpp:543-566:
+	// all interior (i, j), none skipped); the node-unique form evaluates the representative copy once, which is the same only where the
+	// copies' metric entries carry the same bits (UniqueLayout::vite_ok, checked on the host's arrays when the layout is built)
+	if (!u.vite_ok) for (const Op & o : p) if (o.kind == OP_VITE) return TMX_OK;
 	int r;
 	unsigned written = 0u, livein = 0u;
 	const bool noop = false;

@@ -241,7 +241,7 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 	u.NP = std::max(64, (u.nslots + 63) / 64 * 64);
 	slot_ucol.resize(u.NP, 0);
 	std::vector<int> gsrc, gdst, ugn, ugx, ugt;
-	u.ngroups = 0; u.ngroups_local = 0;
+	u.ngroups = 0; u.ngroups_local = 0; u.b_ngroups = 0; u.b_ngroups_local = 0;
 	for (int g = 0; g < ng; g++) {
 		if (intile[g]) continue;
 		int dst[4] = { -1, -1, -1, -1 };
@@ -314,6 +314,17 @@ int tmxu_build(tmx_engine * e, const UniquePlanInput & in, size_t * bytes) {
 		for (int t = 0; t < u.NTS; t++)
 			g2t[(size_t)f * u.NTS + t] = (T.t_dcol[t] >= 0) ? e->h_g2d[(size_t)f * NS + T.t_dcol[t]] : ((f == G2_J2D || f == G2_JN || f == G2_JE) ? 1.0 : 0.0);
 		for (int uu = 0; uu < u.NUS; uu++) g2u[(size_t)f * u.NUS + uu] = e->h_g2d[(size_t)f * NS + T.u_rep[uu]];
+	}
+	// do the copies of every node agree, bit for bit, in the per-column geometry the explicitly evaluated implicit terms read (k_vi_terms_explicit:
+	// horizontal metric, Jacobians, d_xi R, the factors of the closed-form 3-D metric)?  The reference evaluates that operator per stored copy.
+	{
+		static const int rows[] = { G2_C2A0, G2_C2A1, G2_C2B1, G2_DRX, G2_JE, G2_JN, G2_MP, G2_MA, G2_MB, G2_MC, G2_DAZ, G2_DBZ, G2_IDX, G2_IDX2 };
+		u.vite_ok = true;
+		for (int c = 0; c < e->ncol && u.vite_ok; c++) {
+			const int rep = T.u_rep[T.ucol_of_dcol[c]];
+			if (rep == c) continue;
+			for (int f : rows) if (memcmp(&e->h_g2d[(size_t)f * NS + c], &e->h_g2d[(size_t)f * NS + rep], sizeof(double)) != 0) { u.vite_ok = false; break; }
+		}
 	}
 	if ((r = up(&u.d_t_tinfo, T.tinfo, bytes))) return r;
 	if ((r = up(&u.d_g2d_t, g2t, bytes)) || (r = up(&u.d_g2d_u, g2u, bytes))) return r;

