@@ -165,7 +165,7 @@ def test_block_kernels_and_block_thread_orders_are_bit_identical(scheme, ne, npa
         d.upload_state(0, start); u.upload_state(0, start)
         for k in range(4):
             d.step(scheme, 150.0, first=(k == 0)); u.step(scheme, 150.0, first=(k == 0))
-            if k >= 1:
+            if k >= 1 and not (scheme == "ark232" and npatch == 24):      # (ARK232 on grids whose metric copies differ runs element-major: test_steps_on_the_unique_layout_are_bit_identical)
                 assert u.info(13) > 0, "step %d did not run on the node-unique layout" % k
         d.sync(); u.sync()
         a, b = d.download_state(0), u.download_state(0)

@@ -49,9 +49,10 @@ def test_steps_on_the_unique_layout_are_bit_identical(scheme, ne, npatch, shape)
                 assert u.info(INFO_UNIQUE_INSTANCES) > 0, "step %d did not run on the node-unique layout" % k
         d.sync(); u.sync()
         conv = u.info(INFO_UNIQUE_CONVERSIONS)
+        ran_unique = u.info(INFO_UNIQUE_INSTANCES) > 0
         for ix in range(ni):
             assert _same(u.download_state(ix), d.download_state(ix), range(npatch)), (scheme, "instance", ix)
-        assert u.info(INFO_UNIQUE_CONVERSIONS) > conv      # the downloads converted what they read (a reader leaves the node-unique copy valid beside it)
+        assert u.info(INFO_UNIQUE_CONVERSIONS) > conv or not ran_unique      # the downloads converted what they read (a reader leaves the node-unique copy valid beside it)
         # and on from the converted state: two more steps
         for k in range(2):
             d.step(scheme, 150.0); u.step(scheme, 150.0)
