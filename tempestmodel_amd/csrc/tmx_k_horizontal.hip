@@ -1085,6 +1085,7 @@ void tmxk_hypervis(tmx_engine * e, const KParams & p, const double * xsrc, const
 	const int ntiles = p.quads ? e->launch_tiles : p.NS / 64, nyb = (p.L + 1 + 3) / 4;
 	dim3 blk(64, 4);
 	DssPull d = { (const int4 *)e->d_colref, (const double *)e->d_xmat, (const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride };
+	if (tmxk_hv_walk_ok(e, p)) { tmxk_hv_walk(e, p, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale); return; }      // node-unique layout: the pass as a walk (tmx_k_hwalk.hip)
 	if (p.t_ucol) {      // node-unique layout (tmxu_params)
 		KParams q = p; q.u_ntiles = ntiles;
 		const bool blocks = tmxu_blocks_on(e, 2);      // a workgroup = a block of the thread order at one level: its seams are averaged in the kernel

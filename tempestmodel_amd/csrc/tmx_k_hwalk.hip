@@ -127,6 +127,9 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
 	const int sdst = BLK ? p.b_sdst[col] : p.t_sdst[col], sred = BLK ? p.b_sred[col] : p.t_sred[col];
 	const int pos = wv * 64 + lane;      // BLK: position in the block
+	// EM: one copy per node stores the prefix -- the thread whose stored column is the node's representative copy (bit 30 of the seam word,
+	// set by tmxu_tables: 50 784 stores per slab instead of 86 400 identical ones to the same entries)
+	const bool emit_here = (sred >> 30) & 1;
 	// ---- window of the first level
 	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
 	{
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		// ---- the stage combination (reference order), then base + increments in the level-parallel kernel's order
 		const double bU = lin_reduce<NT, PM>(xbase, xU), bV = lin_reduce<NT, PM>(xbase, xV);
 		const double bT = lin_reduce<NT, PM>(xbase, xT), bR = lin_reduce<NT, PM>(xbase, xR), bW = lin_reduce<NT, PM>(xbase, xW);
-		if (EM) {
-			// every copy of a node forms the same prefix (the sources are node-unique): each stores it, to the same entry
+		if (EM && emit_here) {
+			// every copy of a node forms the same prefix (the sources are node-unique): the copy that stores or hands on the stage's own result stores it
 			stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, emit_value<NT>(em, xU)); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, emit_value<NT>(em, xV));
 			stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, emit_value<NT>(em, xT)); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, emit_value<NT>(em, xR));
 			if (k > 0) stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, emit_value<NT>(em, xW));
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 				double xWl[NX];
 				terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xWl);
 				extra = lin_reduce<NT, PM>(xbase, xWl); xslab = TMX_SLAB_W(L, L); vmask |= 32u;
-				if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xWl));
+				if (EM && emit_here) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xWl));
 			}
 			const double v[6] = { outU, outV, outR, outT, outW, extra };
 			const int slab[6] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k), xslab };
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		double xW[NX];
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
-		if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
+		if (EM && emit_here) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
 		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
 	}
@@ -404,10 +407,11 @@ bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nte
 }
 
 // Segments per column.  One wavefront per segment, two resident per SIMD (256 registers), three for the plain stage and the two-term
-// combination (168): the count whose wavefronts fill the chip's slots most evenly -- whole rounds, or many of them -- with at least five
-// levels each; every segment costs a halo level and its own loads (geometry, tables, first window), priced at 2 % of the launch per segment
-// (measured: ne30 3 / 4 / 6 segments 0.404 / 0.430 / 0.415 ms per step; the 8-rank share of ne30, 169 tiles, 6 / 10 / 15 segments 0.178 /
-// 0.148 / 0.129 against 0.151 of the level-parallel kernel: a small grid wants short segments, i.e. wavefronts on every SIMD).
+// combination (168).  A segment costs its wavefront a prologue (geometry, tables, first window, halo level) worth about 1.3 levels
+// (profiles/r06_walk_phase_timing.txt: 9 600 cycles against 7 500 per level), and the launch takes as many rounds as its wavefronts need of
+// the chip's slots: the count that minimises  rounds x (1.3 + levels per segment).  ne30: 3 segments (4 050 wavefronts in 4 096 slots, two
+// rounds) for the combinations, 2 for the plain stage; the 8-rank share of ne30 (169 tiles): 12; measured beside it: ne30 3 / 4 / 6 segments
+// 0.404 / 0.430 / 0.415 ms per step, the 8-rank share 6 / 10 / 15 segments 0.178 / 0.148 / 0.129 against 0.151 of the level-parallel kernel.
 int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms) {
 	int nseg = 1;
 	if (e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
@@ -415,11 +419,11 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 		static int cus = 0;      // (one device kind per process)
 		if (!cus) { int dev = 0, n = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
 		const double slots = (double)cus * 4 * (nterms <= 2 ? 3 : 2);
-		double best = -1.0;
+		double best = 1e300;
 		for (int n = 1; n <= p.L / 2 || n == 1; n++) {
 			const double rounds = (double)ntiles * n / slots;
-			const double eff = rounds / (double)(long long)(rounds + 0.999999) - 0.02 * n - (rounds < 1.0 ? 0.25 * (1.0 - rounds) : 0.0);      // fill of the last round; a per-segment cost; idle SIMDs
-			if (eff > best) { best = eff; nseg = n; }
+			const double t = ((rounds <= 1.02) ? 1.0 : (double)(long long)(rounds + 0.98)) * (1.3 + (double)p.L / n);
+			if (t < best) { best = t; nseg = n; }
 		}
 	}
 	if (nseg > p.L / 2) nseg = p.L / 2;
@@ -469,4 +473,141 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 #undef LAUNCH_W3
 #undef LAUNCH_W
 #undef LAUNCH_W2
+}
+
+// ---------------------------------------------------------------------------------------------
+// The hyperviscosity pass of the node-unique layout as a walk: k_hypervis<false, UQ, HB> (tmx_k_horizontal.hip; ApplyScalarHyperdiffusion /
+// ApplyVectorHyperdiffusion, HorizontalDynamicsFEM.cpp:1867-2414), statement for statement, with a wavefront walking a segment of the L + 1
+// levels (the last one holds W of the lid alone): the nine per-column geometry values, the seam tables and the viscosity coefficients once
+// per segment instead of once per level (11 of the level-parallel kernel's 21 loads per thread and level), the next level's five fields and
+// five base values in flight during this level's two rounds of contractions.  No coupling between levels: any split into segments will do.
+template <bool HB>
+__global__ __launch_bounds__(64, 3) void k_hv_walk(KParams p, const double * __restrict__ xsrc, const double * __restrict__ xbase, double * __restrict__ xout,
+	double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, int nseg)
+{
+	constexpr int RL = TMX_UQ_ROWLEN(true);
+	__shared__ double s[8][RL];
+	__shared__ double sD[16], sS[16];
+	const int lane = tile_lane<true>(), lp = lds_pos<true>(lane);
+	if (threadIdx.x < 16) { sD[threadIdx.x] = p.dx[threadIdx.x]; sS[threadIdx.x] = p.stiff[threadIdx.x]; }
+	const int L = p.L;
+	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS;
+	int tix, seg;
+	if (!wg_tile<true>(p, nseg, tix, seg)) return;
+	const int tile = p.quads ? p.quads[tix] : tix;
+	const int k0 = WAVE_UNIFORM((seg * (L + 1)) / nseg), k1 = WAVE_UNIFORM(((seg + 1) * (L + 1)) / nseg);
+	const int col = tile * 64 + lane;
+	const int uc0 = tile_ucol(p, tile, lane);
+	const bool here = uc0 >= 0;
+	unsigned cb = (unsigned)max(uc0, 0) * 8u;
+	const unsigned gb = (unsigned)col * 8u;
+	// per-column constants (padding lanes: the level-parallel kernel's neutral values)
+	double c2a0 = 0, c2a1 = 0, c2b1 = 0, j2d = 1, jn = 1, je = 1;
+	if (here) {
+		c2a0 = ldu(p.g2d + G2_C2A0 * NS, gb); c2a1 = ldu(p.g2d + G2_C2A1 * NS, gb); c2b1 = ldu(p.g2d + G2_C2B1 * NS, gb);
+		j2d = ldu(p.g2d + G2_J2D * NS, gb); jn = ldu(p.g2d + G2_JN * NS, gb); je = ldu(p.g2d + G2_JE * NS, gb);
+	}
+	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
+	const double nsc = scale ? ldu(p.g2d + G2_NUS * NS, gb) : 1.0;
+	const double nu_s = nu_s_in * nsc, nu_d = nu_d_in * nsc, nu_v = nu_v_in * nsc;
+	const int sdst = p.t_sdst[col], sred = p.t_sred[col];
+	const double invJ2 = 1.0 / j2d, invJ = 1.0 / jn, rje = 1.0 / je;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<true>(lane & 48);
+	const bool hb = HB && xbase != nullptr;
+	// the first level's fields (a level >= L has W alone; a padding lane reads nothing)
+	auto ld = [&](const double * x, int slab) -> double { return here ? ldu(x + (size_t)slab * SS, cb) : 0.0; };
+	double psiW = ld(xsrc, TMX_SLAB_W(L, k0)), psiT = 0, psiR = 0, ua = 0, ub = 0, bW = 0, bT = 0, bR = 0, bU = 0, bV = 0;
+	if (k0 < L) { psiT = ld(xsrc, TMX_SLAB_T(L, k0)); psiR = ld(xsrc, TMX_SLAB_R(L, k0)); ua = ld(xsrc, TMX_SLAB_U(L, k0)); ub = ld(xsrc, TMX_SLAB_V(L, k0)); }
+	if (hb) {
+		bW = ld(xbase, TMX_SLAB_W(L, k0));
+		if (k0 < L) { bT = ld(xbase, TMX_SLAB_T(L, k0)); bR = ld(xbase, TMX_SLAB_R(L, k0)); bU = ld(xbase, TMX_SLAB_U(L, k0)); bV = ld(xbase, TMX_SLAB_V(L, k0)); }
+	}
+	wave_sync();
+	for (int kl = k0; kl < k1; kl++) {
+		const int kk = WAVE_UNIFORM(kl);
+		asm volatile("" : "+v"(cb));      // (lane offset redefined per level: base + lane stays scalar base + 32-bit offset, cf. k_h_walk)
+		const bool actn = kk < L;
+		// ---- the next level's loads, in flight during this level's contractions
+		double nW = 0, nT = 0, nR = 0, nU = 0, nV = 0, nbW = 0, nbT = 0, nbR = 0, nbU = 0, nbV = 0;
+		if (kk + 1 < k1) {
+			const bool an = kk + 1 < L;
+			nW = ld(xsrc, TMX_SLAB_W(L, kk + 1));
+			if (an) { nT = ld(xsrc, TMX_SLAB_T(L, kk + 1)); nR = ld(xsrc, TMX_SLAB_R(L, kk + 1)); nU = ld(xsrc, TMX_SLAB_U(L, kk + 1)); nV = ld(xsrc, TMX_SLAB_V(L, kk + 1)); }
+			if (hb) {
+				nbW = ld(xbase, TMX_SLAB_W(L, kk + 1));
+				if (an) { nbT = ld(xbase, TMX_SLAB_T(L, kk + 1)); nbR = ld(xbase, TMX_SLAB_R(L, kk + 1)); nbU = ld(xbase, TMX_SLAB_U(L, kk + 1)); nbV = ld(xbase, TMX_SLAB_V(L, kk + 1)); }
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		const double cua = c2a0 * ua + c2a1 * ub;
+		const double cub = c2a1 * ua + c2b1 * ub;
+		s[0][lp] = psiT; s[1][lp] = psiR; s[2][lp] = psiW;
+		s[3][lp] = ua;   s[4][lp] = ub;
+		s[5][lp] = j2d * cua; s[6][lp] = j2d * cub;
+		wave_sync();
+		double daT = 0, dbT = 0, daR = 0, dbR = 0, daW = 0, dbW = 0, daub = 0, dbua = 0, dajua = 0, dbjub = 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+			const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+			daT += s[0][la] * Da; dbT += s[0][lb] * Db;
+			daR += s[1][la] * Da; dbR += s[1][lb] * Db;
+			daW += s[2][la] * Da; dbW += s[2][lb] * Db;
+			daub += s[4][la] * Da; dbua += s[3][lb] * Db;
+			dajua += s[5][la] * Da; dbjub += s[6][lb] * Db;
+		}
+		daT *= ida; dbT *= idb; daR *= ida; dbR *= idb; daW *= ida; dbW *= idb;
+		daub *= ida; dbua *= idb; dajua *= ida; dbjub *= idb;
+		const double dv = (dajua + dbjub) * invJ2, cl = (daub - dbua) * invJ2;
+		wave_sync();
+		s[0][lp] = jn * (c2a0 * daT + c2a1 * dbT); s[1][lp] = jn * (c2a1 * daT + c2b1 * dbT);
+		s[2][lp] = jn * (c2a0 * daR + c2a1 * dbR); s[3][lp] = jn * (c2a1 * daR + c2b1 * dbR);
+		s[4][lp] = je * (c2a0 * daW + c2a1 * dbW); s[5][lp] = je * (c2a1 * daW + c2b1 * dbW);
+		s[6][lp] = dv; s[7][lp] = cl;
+		wave_sync();
+		double uaT = 0, ubT = 0, uaR = 0, ubR = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+			const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+			uaT += s[0][la] * Sa; ubT += s[1][lb] * Sb;
+			uaR += s[2][la] * Sa; ubR += s[3][lb] * Sb;
+			uaW += s[4][la] * Sa; ubW += s[5][lb] * Sb;
+			dad -= Sa * s[6][la]; dbd -= Sb * s[6][lb];
+			dac -= Sa * s[7][la]; dbc -= Sb * s[7][lb];
+		}
+		uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
+		dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
+		const double oW = bW - dt * rje * nu_s * (uaW + ubW);
+		double oT = 0, oR = 0, oU = 0, oV = 0;
+		if (actn) {
+			oT = bT - dt * invJ * nu_s * (uaT + ubT);
+			oR = bR - dt * invJ * nu_s * (uaR + ubR);
+			const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
+			const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
+			oU = bU - dt * upa;
+			oV = bV - dt * upb;
+		}
+		wave_sync();
+		{
+			const double v[5] = { oW, oT, oR, oU, oV };
+			const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
+			seam_store<5, RL>(p, &s[0], lane, here ? sdst : -1, sred, v, xout, slab, actn ? 5 : 1);
+		}
+		wave_sync();
+		psiW = nW; psiT = nT; psiR = nR; ua = nU; ub = nV; bW = nbW; bT = nbT; bR = nbR; bU = nbU; bV = nbV;
+	}
+}
+
+bool tmxk_hv_walk_ok(const tmx_engine * e, const KParams & p) { return p.t_ucol != nullptr && e->opt_hv_walk != 0 && !tmxu_blocks_on(e, 2); }
+
+void tmxk_hv_walk(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu_s, double nu_d, double nu_v, int scale) {
+	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
+	KParams q = p; q.u_ntiles = ntile;
+	KParams pl = p; pl.L = p.L + 1;      // (segments over the L + 1 levels)
+	const int nseg = tmxk_h_walk_segments(e, pl, ntile, 0);
+	e->u.slots_by_blocks = false;
+	const dim3 grd = wg_grid(true, q, ntile, nseg);
+	if (xbase) hipLaunchKernelGGL(k_hv_walk<true>, grd, dim3(64), 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, nseg);
+	else hipLaunchKernelGGL(k_hv_walk<false>, grd, dim3(64), 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, nseg);
 }
