@@ -507,9 +507,9 @@ __global__ __launch_bounds__(256) void k_h_w_update(KParams p, LinTerms xbase, d
 void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv,
 	const EmitTerms * emit, unsigned dmask) {
-	// node-unique layout, vertical part fused in: the column-segment walk (tmx_k_hwalk.hip) does the whole stage, W of every interface included
+	// the column-segment walk (tmx_k_hwalk.hip) does the whole stage, W of every interface included (node-unique layout: with the vertical part fused in)
 	if (tmxk_h_walk_ok(e, p, fuse_v, nterms, emit && emit->xp)) {
-		tmxk_h_walk(e, p, xin, xbase_ptr, xup, dt, nterms, src, coef, premul, xin_uv, xbase_uv, src_uv, dmask, emit);
+		tmxk_h_walk(e, p, xin, xbase_ptr, xup, dt, fuse_v, nterms, src, coef, premul, xin_uv, xbase_uv, src_uv, dmask, emit);
 		return;
 	}
 	// base of the update: a plain instance (nterms == 0) or a linear combination evaluated in the kernels

@@ -75,7 +75,10 @@ typedef const double __attribute__((address_space(4))) * tmx_cdp;
 // are averaged through LDS (block_seam_store, tables KParams::b_sdst / b_sred), W of the surface and of the lid travel with levels 1 and L-1
 // EM: the stage also forms and stores the leading partial sum of a LATER stage's combination from the terms it has loaded anyway (EmitTerms,
 // emit_value in tmx_device.h; prefix_plan in tmx_step.hip): the later stage then reads that one instance instead of the members
-template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false>
+// UQ = false: the ELEMENT-MAJOR layout (every configuration the node-unique one does not cover: tracers, uniform diffusion, fully explicit
+// vertical dynamics, a step the engine keeps element-major): a thread reads and writes its own stored column, no seam exchange, the DSS
+// kernel averages afterwards as the reference does.  FV = false: H.StepExplicit alone (the caller runs V.StepExplicit as a kernel of its own).
+template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false, bool UQ = true, bool FV = true>
 __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg, EmitTerms em)
 {
 	constexpr int RL = TMX_UQ_ROWLEN(true);
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 #pragma unroll
 	for (int t = 0; t < NTL; t++) { tlog[t] = tmx_rm_log_tab[t * 64 + tidw]; texp[t] = tmx_rm_exp_tab[t * 64 + tidw]; }
 	const int L = p.L;
-	const size_t NS = (size_t)p.NS, SS = (size_t)p.NSS, NSD = (size_t)p.NSD;
+	const size_t NS = (size_t)p.NS, SS = UQ ? (size_t)p.NSS : NS, NSD = (size_t)p.NSD;
 	int tix, seg;
-	if (!wg_tile<true>(p, nseg, tix, seg)) return;
+	if (!wg_tile<UQ>(p, nseg, tix, seg)) return;
 	int tile;
 	bool idle = false;      // BLK: a wavefront beyond the block's last one only keeps the barriers company
 	if (BLK) {
@@ -108,7 +111,9 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	} else tile = p.quads ? p.quads[tix] : tix;
 	const int k0 = WAVE_UNIFORM((seg * L) / nseg), k1 = WAVE_UNIFORM(((seg + 1) * L) / nseg);
 	const int col = tile * 64 + lane;
-	const int uc = max(tile_ucol(p, tile, lane), 0);      // padding lanes (a whole element of the last tile): node 0, nothing stored (t_sdst = -1)
+	// padding lanes (a whole element of the last tile): node 0, nothing stored (UQ: t_sdst = -1; element-major: col >= ncol)
+	const int uc = UQ ? max(tile_ucol(p, tile, lane), 0) : min(col, p.ncol - 1);
+	const bool here = UQ || col < p.ncol;
 	unsigned cb = (unsigned)uc * 8u, gb = (unsigned)col * 8u;
 	// where the thread's own stored copy sits in an element-major instance (mixed reads, DM): its stored column, that layout's stride
 	unsigned gd = DM ? (unsigned)max(p.t_dcol[col], 0) * 8u : gb;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	const double jn = ldu(p.g2d + G2_JN * NS, gb), j2d = ldu(p.g2d + G2_J2D * NS, gb), fcor = ldu(p.g2d + G2_F * NS, gb);
 	const MetCol mc = met_col(p, col);
 	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
-	const int sdst = BLK ? p.b_sdst[col] : p.t_sdst[col], sred = BLK ? p.b_sred[col] : p.t_sred[col];
+	const int sdst = UQ ? (BLK ? p.b_sdst[col] : p.t_sdst[col]) : 0, sred = UQ ? (BLK ? p.b_sred[col] : p.t_sred[col]) : 0;
 	const int pos = wv * 64 + lane;      // BLK: position in the block
 	// EM: one copy per node stores the prefix -- the thread whose stored column is the node's representative copy (bit 30 of the seam word,
 	// set by tmxu_tables: 50 784 stores per slab instead of 86 400 identical ones to the same entries)
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		double dxub = 0.0; dxub += dm * vM; dxub += d0 * v0; dxub += dp * vP;
 		// xi_dot on interface k+1 (VerticalDynamicsFEM.cpp:816-828), zero at the lid; interface k's is carried from the level below
 		double xhi = 0.0;
-		if (k + 1 <= L - 1) {
+		if (FV && k + 1 <= L - 1) {
 			double ue = 0.0, ve = 0.0;
 			ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * u0; ue += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * uP;
 			ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, -1) * v0; ve += OPK(TMX_OP_INTERP_NODE_TO_REDGE, k + 1, 0) * vP;
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		const double tU = dt * upa, tV = dt * upb;
 		// first-order upwind penalty on U,V (VerticalDynamicsFEM.cpp:984-1023): left then right operator
 		double tUhi = 0, tVhi = 0, tUlo = 0, tVlo = 0;
-		if (k < L - 1) {
+		if (FV && k < L - 1) {
 			double b = 0.0;
 			b += OPK(TMX_OP_PENALTY_LEFT, k, 0) * u0; b += OPK(TMX_OP_PENALTY_LEFT, k, 1) * uP;
 			tUhi = b * w_hi;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 			b += OPK(TMX_OP_PENALTY_LEFT, k, 0) * v0; b += OPK(TMX_OP_PENALTY_LEFT, k, 1) * vP;
 			tVhi = b * w_hi;
 		}
-		if (k > 0) {
+		if (FV && k > 0) {
 			double b = 0.0;
 			b += OPK(TMX_OP_PENALTY_RIGHT, k, -1) * uM; b += OPK(TMX_OP_PENALTY_RIGHT, k, 0) * u0;
 			tUlo = b * w_lo;
@@ -333,11 +338,28 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		HW_MARK(5);
 		double outU = bU + tU, outV = bV + tV;
 		const double uh = outU, vh = outV;      // H-only values (levels 0, 1: the bottom boundary condition below)
-		if (k < L - 1) { outU += tUhi; outV += tVhi; }
-		if (k > 0) { outU += tUlo; outV += tVlo; }
+		if (FV && k < L - 1) { outU += tUhi; outV += tVhi; }
+		if (FV && k > 0) { outU += tUlo; outV += tVlo; }
 		const double outR = bR - tR, outT = bT - tT;
 		const double outW = bW + tW;
-		if constexpr (BLK) {
+		if constexpr (!UQ) {
+			// element-major: the thread's own column
+			if (here) {
+				stu(xup + TMX_SLAB_U(L, k) * NS, cb, outU); stu(xup + TMX_SLAB_V(L, k) * NS, cb, outV);
+				stu(xup + TMX_SLAB_R(L, k) * NS, cb, outR); stu(xup + TMX_SLAB_T(L, k) * NS, cb, outT);
+				if (k > 0) stu(xup + TMX_SLAB_W(L, k) * NS, cb, outW);
+			}
+			if (k == 0) { uh0 = uh; vh0 = vh; }
+			if (k == 1) {
+				// bottom boundary: W of interface 0 from the H-only U, V of levels 0 and 1 extrapolated to the surface (:1615-1638)
+				double ub0 = 0.0, vb0 = 0.0;
+				ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * uh0; ub0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * uh;
+				vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
+				double e0, e1, e2, ea, eb_;
+				met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
+				if (here) stu(xup + TMX_SLAB_W(L, 0) * NS, cb, -(e0 * ub0 + e1 * vb0) / e2);
+			}
+		} else if constexpr (BLK) {
 			// one exchange per level for the whole block; W of the surface (known once level 1's H-only U, V are) and of the lid ride along
 			double extra = 0.0; int xslab = TMX_SLAB_W(L, 0); unsigned vmask = (k > 0) ? 31u : 15u;
 			if (k == 0) { uh0 = uh; vh0 = vh; }
@@ -390,6 +412,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		double xW[NX];
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
+		if constexpr (!UQ) { if (here) stu(xup + TMX_SLAB_W(L, L) * NS, cb, v1[0]); HW_MARK(6); HW_END(NT); return; }
 		if (EM && emit_here) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
 		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
@@ -403,7 +426,8 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit) {
 	const bool uq = p.t_ucol != nullptr;
 	(void)emit;      // (a stored prefix: the walk's own instantiation)
-	return uq && fuse_v && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
+	// node-unique layout: with the vertical part fused in (what the steppers run); element-major layout: with or without it
+	return (uq ? fuse_v != 0 : true) && p.closed && nterms != 1 && nterms <= 8 && e->opt_h_walk != 0 && p.L >= 2 && !e->use_mfma;
 }
 
 // Segments per column.  One wavefront per segment, two resident per SIMD (256 registers), three for the plain stage and the two-term
@@ -431,7 +455,7 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 	return nseg;
 }
 
-void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt,
+void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
 	const EmitTerms * emit) {
 	LinTerms xbase;
@@ -444,6 +468,28 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms);
 	KParams q = p; q.u_ntiles = ntile;
+	if (!p.t_ucol) {
+		// element-major layout: 2-D launch (tile list or all tiles) x segments
+		EmitTerms em1; em1.xp = nullptr; em1.first = -1; for (int m = 0; m < 12; m++) em1.coef[m] = 0.0;
+		const dim3 grd(ntile, nseg), blk(64);
+#define LAUNCH_D2(NT_, PM_) do { \
+			if (fuse_v) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1); \
+			else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1); } while (0)
+#define LAUNCH_D(NT_) do { if (NT_ == 0 || premul) LAUNCH_D2(NT_, true); else LAUNCH_D2(NT_, false); } while (0)
+		switch (nterms) {
+			case 0: LAUNCH_D(0); break;
+			case 2: LAUNCH_D(2); break;
+			case 3: LAUNCH_D(3); break;
+			case 4: LAUNCH_D(4); break;
+			case 5: LAUNCH_D(5); break;
+			case 6: LAUNCH_D(6); break;
+			case 7: LAUNCH_D(7); break;
+			default: LAUNCH_D(8); break;
+		}
+#undef LAUNCH_D
+#undef LAUNCH_D2
+		return;
+	}
 	// block kernels: the launch is over the blocks of the thread order (four wavefronts each), the seams between a block's wavefronts never reach the partial slots
 	const bool blocks = tmxu_blocks_on(e, 1) && p.L >= 3;
 	const int nblk = p.bquads ? e->launch_blocks : e->u.nblocks;
