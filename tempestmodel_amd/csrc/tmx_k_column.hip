@@ -714,10 +714,6 @@ template <bool SPARSE, bool PRED, int TYPE, bool NTS = TMX_NTS_DEFAULT>
 __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], double pb, double * __restrict__ AB, double * __restrict__ RHS,
 	int jcol, int NUS, int u, int * umask)
 {
-#ifdef TMX_ABL_NO_USTORE     // ablation builds: elimination without the U-row stream (one value kept alive)
-	if (piv[0] == 12345.678 && pb == 1.0) AB[0] = piv[1];
-	return;
-#endif
 #if TMX_USTREAM16
 	auto val = [&](int e) -> double { return e == 9 ? pb : piv[e]; };
 	double * row = AB + (size_t)jcol * TMX_RS(NUS);
@@ -773,18 +769,12 @@ __device__ __forceinline__ void lu_store_urow(const double (&piv)[TMX_BW], doubl
 // 27 entries, plus the three residuals: 20 doubles per column instead of 30.  A third fewer LDS writes and reads per block row,
 // and room for a THREE-deep ring in the LDS that held two dense block rows (TMX_RING_DEPTH).  TMX_RSLOT[kind][d] = slot of band
 // entry d of the row of that kind, -1 = structural zero (the consumer takes the literal 0.0 the dense ring carried).
-#ifndef TMX_RING_DENSE
 #define TMX_RING_NQ 20
 __device__ constexpr int TMX_RSLOT[3][TMX_BW] = {
 	{ -1, 0, -1, -1, 1, 2, -1, 3, 4 },          // rho*theta row
 	{ 5, 6, 7, 8, 9, 10, -1, 11, -1 },          // W row
 	{ -1, 12, -1, 13, 14, -1, 15, 16, -1 } };   // rho row
 #define TMX_RSLOT_RHS 17                        // + kind
-#else      // A/B builds: every entry travels
-#define TMX_RING_NQ 30
-__device__ constexpr int TMX_RSLOT[3][TMX_BW] = { { 0, 1, 2, 3, 4, 5, 6, 7, 8 }, { 9, 10, 11, 12, 13, 14, 15, 16, 17 }, { 18, 19, 20, 21, 22, 23, 24, 25, 26 } };
-#define TMX_RSLOT_RHS 27
-#endif
 // entry c of the incoming matrix row: INK < 0: a dense row of stride IS (registers, zeros); INK = kind: the ring's block row at `in`
 template <int INK, int IS>
 __device__ __forceinline__ double lu_in_entry(const double * in, int c) {
@@ -812,25 +802,6 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 	for (int c = 0; c < TMX_BW; c++) { piv[c] = (c == Z && PV != 4) ? 0.0 : R[PV][c]; t0[c] = (c == Z) ? 0.0 : R[0][c]; }
 	const double pb = b[PV], tb0 = b[0];
 	if (piv[0] == 0.0) singular = true;
-#if TMX_TAIL == 1
-	lu_store_urow<SPARSE, false, TYPE, NTS>(piv, pb, AB, RHS, jcol, NUS, u, umask);
-	const double rcp = 1.0 / piv[0];
-#pragma unroll
-	for (int r = 1; r < 5; r++) {
-		// after the interchange position r holds old row r, except position PV, which holds old row 0
-		const double l = ((r == PV) ? t0[0] : R[r][0]) * rcp;
-#pragma unroll
-		for (int c = 1; c < TMX_BW; c++) {
-			const double src = (r == PV) ? t0[c] : ((c == Z && r != 4) ? 0.0 : R[r][c]);
-			R[r - 1][c - 1] = LU_UPD(src, l, piv[c]);
-		}
-		R[r - 1][TMX_BW - 1] = 0.0;
-		b[r - 1] = LU_UPD((r == PV) ? tb0 : b[r], pb, l);
-	}
-#pragma unroll
-	for (int c = 0; c < TMX_BW; c++) R[4][c] = lu_in_entry<INK, IS>(inrow, c);      // IS: stride of the incoming row (1 registers, 64 LDS ring)
-	b[4] = inb;
-#else
 	// The reciprocal of the pivot and the four multipliers are started BEFORE the U-row stores: the IEEE division is a chain
 	// of a dozen dependent instructions, and the (conditional) stores -- which nothing waits for -- cover its latency.  The
 	// first entry of the incoming row is what the NEXT pivot search waits for: its LDS read is issued up front as well.
@@ -855,7 +826,6 @@ __device__ __forceinline__ void lu_pivot_tail_uniform(double (&R)[5][TMX_BW], do
 #pragma unroll
 	for (int c = 1; c < TMX_BW; c++) R[4][c] = lu_in_entry<INK, IS>(inrow, c);      // IS: stride of the incoming row (1 registers, 64 LDS ring)
 	b[4] = inb;
-#endif
 }
 
 // One elimination step.  UNI: try the wave-uniform specialisations first (a ballot checks that all lanes agree on
@@ -992,13 +962,8 @@ __device__ __forceinline__ void vi_load_urow(URow & d, int row, int L, size_t NS
 	for (int c = 0; c < 4; c++) d.u[c] = rb[c * 64];
 #pragma unroll
 	for (int c = 4; c < TMX_BW; c++) {
-#ifdef TMX_EXP_BRANCHY_BACK
-		d.u[c] = 0.0;
-		if (mk & (1 << c)) d.u[c] = rb[c * 64];
-#else
 		const double * bp = (mk & (1 << c)) ? rb + c * 64 : zp;
 		d.u[c] = bp[0];
-#endif
 	}
 	d.y = rb[TMX_BW * 64];
 #endif
@@ -1260,11 +1225,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	// (Measured and not kept, round 4: the roles in the other order -- consumer first -- for the workgroups of the second dispatch round, or
 	// for every other workgroup, so that two workgroups sharing a CU would put a producer and a consumer on every SIMD: column solve
 	// 0.500 / 0.486 against 0.480 ms per step.)
-#ifndef TMX_PAIR3_INTERLEAVED
 	const int role = (NPROD == 2) ? (wv == 2 ? 1 : 0) : ((PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1)), pair = (NPROD == 2) ? 0 : ((PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1));
-#else
-	const int role = wv & 1, pair = wv >> 1;
-#endif
 	double * ring = etal + 2 * L + 1 + (size_t)pair * RD * NQ * 64;          // [PAIRS][RD][NQ][64]
 	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * RD * NQ * 64;       // [512] exp / log tables (exner_from_rhotheta_lds)
 	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
@@ -1355,11 +1316,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 		struct LevRaw { double un, vn, pn, rn, we; };
 		auto load_raw = [&](int l) {
 			LevRaw r;
-#ifdef TMX_ABL_P_LEVEL0      // ablation builds: every level's loads hit the same five cache-resident rows
-			const int lc = (l & 1), le = (l & 1);
-#else
 			const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l), le = l < 0 ? 0 : (l > L ? L : l);
-#endif
 			r.un = xin[TMX_SLAB_U(L, lc) * NS + col]; r.vn = xin[TMX_SLAB_V(L, lc) * NS + col];
 			r.pn = xin[TMX_SLAB_T(L, lc) * NS + col]; r.rn = xin[TMX_SLAB_R(L, lc) * NS + col];
 			r.we = xin[TMX_SLAB_W(L, le) * NS + col];
@@ -1389,9 +1346,6 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 		auto block_row = [&](int t, LevRaw & rYl, const LevRaw & rYm) {
 			if (DEEP) rYl = load_raw(t + 4);
 			else { /* issued below, after the shift */ }
-#ifdef TMX_ABL_FAST_PRODUCER      // ablation builds: the block row is evaluated once, the ring is refilled with it every time
-			if (t == 0)
-#endif
 #ifdef TMX_PAIR_TIMING
 			{
 			PMARK(tp_seg[4]);      // prefetch issue
@@ -1402,11 +1356,6 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 			// Interior block rows whose Exner arguments are ordinary numbers in every lane can take the branch-free instantiation
 			// (one basic block of 350 vector instructions per block row).  Measured: SLOWER -- the assembly alone 118 instead of
 			// 98 us per launch, the kernel +3 % -- so it stays an experiment (-DTMX_INTERIOR_ROWS).
-#ifdef TMX_INTERIOR_ROWS
-			if (t >= 1 && t <= L - 2 && __builtin_amdgcn_ballot_w64(!exner_arg_in_main_range(p, nB.pn)) == 0)
-				compute_block<true, false, true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
-			else
-#endif
 			compute_block<true>(p, opsl, cc, t, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, 0.0, 0.0, rmtab);
 #endif
 			PMARK(tp_work);
@@ -1451,9 +1400,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	// Two wavefronts per SIMD: the elimination is the critical role, the assembly has slack (101 k against 146 k cycles
 	// per column), so the consumer takes issue priority wherever it shares a SIMD (same-box A/B at ne30, three alternations
 	// each: 202 -> 185 us per launch on one box, 213 -> 206 us on another; -DTMX_NO_SETPRIO builds without it).
-#ifndef TMX_NO_SETPRIO
 	__builtin_amdgcn_s_setprio(3);
-#endif
 	// The incoming block row stays in the LDS ring until the pivot step that takes it in (stride-64 reads inside
 	// lu_pivot_step) instead of being copied to 30 registers first: the consumer then fits the register budget of
 	// two wavefronts per SIMD, which is what lets the pair kernel run on grids with more pairs than CUs x 2.
@@ -1497,9 +1444,6 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 			b[3] = QF(0); b[4] = QF(1);
 			lu_pivot_step<0, SPARSE, true, 64, -1, 2, NTSK>(R, b, singular, AB, RHS, 0, NUS, u, q, QF(2), umask, &nuni);      // pivot 0 takes in row 5
 		} else
-#ifdef TMX_ABL_NO_ELIM            // ablation builds: the consumer only keeps the hand-over rhythm
-		if (m < 0)
-#endif
 		{
 			// matrix rows 3m-5 (W of level m-2), 3m-4 (rho), 3m-3 (rho*theta of level m-1)
 			lu_pivot_step<1, SPARSE, true, 64, TMX_EXPECT_W, 0, NTSK>(R, b, singular, AB, RHS, 3 * m - 5, NUS, u, q, QF(0), umask, &nuni);
@@ -1528,10 +1472,8 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	if (singular) atomicOr(flag, TMX_FLAG_SINGULAR);
 	// statistics for bench.py (stats = {pivot steps on the wave-uniform path, all pivot steps}, per wavefront)
 	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
-#ifndef TMX_ABL_NO_BACK      // ablation builds (tools/ablate.sh): time of the forward phase alone
 	if (BACK) vi_back_substitute<NTSK>(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
 	else for (int j = lane; j < n; j += 64) gmask[(size_t)grp * n + j] = umask[j];      // this wavefront's own LDS writes: no barrier needed
-#endif
 #ifdef TMX_PAIR_TIMING
 	if (stats && lane == 0) {
 		unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);
