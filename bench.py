@@ -62,7 +62,7 @@ HBM_PEAK_GBS = 8000.0
 PROFILE_TAG = next((t for t in ("r06", "r05", "r04", "r03", "r02") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_pmc_traffic_ne30_L30_n1.json"))), "r02")
 # rocprof kernel-name prefixes per operation, for the PMC traffic table (profiles/r01_pmc_traffic.json)
 OP_ROCPROF = {"h_explicit": ["k_h_explicit", "k_h_w_update", "k_h_walk"], "v_implicit": ["k_vi_fused", "k_vi_pair", "k_vi_group"], "dss": ["k_dss", "k_dss_u"],
-              "hypervis": ["k_hypervis"], "lincomb": ["k_lincomb"]}
+              "hypervis": ["k_hypervis", "k_hv_walk"], "lincomb": ["k_lincomb"]}
 
 
 def csrc_sha16():
@@ -90,13 +90,18 @@ def library_kernels():
         names = set()
         try:
             blob = open(path, "rb").read()
-            for m in re.finditer(rb"_Z(\d+)(k_[a-z0-9_]+)", blob):
+            for m in re.finditer(rb"_Z(?:N\d+[a-z_]+?)?(\d+)(k_[a-z0-9_]+)", blob):      # (plain and namespaced: _ZN6lu_fma9k_vi_pair...)
                 n = int(m.group(1))
                 names.add(m.group(2)[:n].decode())
         except Exception:
             pass
         _LIB_KERNELS = names
     return _LIB_KERNELS
+
+
+def kernel_base(name):
+    """rocprof kernel name -> base name: return type, template arguments, parameters and namespaces (lu_fma:: / lu_nofma::) stripped."""
+    return name.replace("void ", "").split("<")[0].split("(")[0].split("::")[-1]
 
 
 def profile_kernels_known(names):
@@ -110,14 +115,14 @@ def profile_kernels_known(names):
 
 def traffic_table(ne, L, world):
     """The newest committed PMC table of the shape (path, parsed json) or (None, None); refused (None) when it names kernels the loaded library does not hold."""
-    for t in ("r05", "r04", "r03", "r02"):      # (the newest table of the shape; r04 on: the node-unique layout, the default)
+    for t in ("r06", "r05", "r04", "r03", "r02"):      # (the newest table of the shape; r04 on: the node-unique layout, the default)
         c = os.path.join(ROOT, "profiles", "%s_pmc_traffic_ne%d_L%d_n%d.json" % (t, ne, L, world))
         if os.path.exists(c):
             try:
                 tab = json.load(open(c))
             except Exception:
                 return None, None
-            ok, unknown = profile_kernels_known([k.replace("void ", "").split("<")[0].split("(")[0] for k in tab["kernels"]])
+            ok, unknown = profile_kernels_known([kernel_base(k) for k in tab["kernels"]])
             if not ok:
                 sys.stderr.write("bench: %s names kernels the loaded library does not hold (%s): its traffic figures are not used\n" % (os.path.relpath(c, ROOT), ", ".join(unknown)))
                 return None, None
@@ -163,7 +168,7 @@ def measured_traffic(op, ne, L, world, launches_per_step):
     try:
         per_step = 0.0
         for name, row in tab["kernels"].items():
-            base = name.replace("void ", "").split("<")[0].split("(")[0]
+            base = kernel_base(name)
             if base in OP_ROCPROF[op]:
                 per_step += row["hbm_bytes_per_launch"] * row["launches"] / tab["steps"]
         return per_step / launches_per_step if per_step > 0 and launches_per_step > 0 else None
@@ -208,7 +213,7 @@ def dominant_kernel_from_stats(ne, L, world):
         return None
     try:
         def base_of(r):
-            return r["Name"].replace("void ", "").split("<")[0].split("(")[0]
+            return kernel_base(r["Name"])
         known = {n for names in OP_ROCPROF.values() for n in names}
         rows = [r for r in csv.DictReader(open(path)) if base_of(r) in known]      # the step's kernels (not the memsets / copies of the set-up)
         ok, unknown = profile_kernels_known([base_of(r) for r in rows])
@@ -671,7 +676,7 @@ def main():
         if ttab is not None:
             known = {n for names in OP_ROCPROF.values() for n in names}
             step_traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] / ttab["steps"] for k, r in ttab["kernels"].items()
-                               if k.replace("void ", "").split("<")[0].split("(")[0] in known)
+                               if kernel_base(k) in known)
         sha_now = csrc_sha16()
         sha_prof = (ttab or {}).get("csrc_sha16")
 

@@ -132,9 +132,6 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
 	const int sdst = UQ ? (BLK ? p.b_sdst[col] : p.t_sdst[col]) : 0, sred = UQ ? (BLK ? p.b_sred[col] : p.t_sred[col]) : 0;
 	const int pos = wv * 64 + lane;      // BLK: position in the block
-	// EM: one copy per node stores the prefix -- the thread whose stored column is the node's representative copy (bit 30 of the seam word,
-	// set by tmxu_tables: 50 784 stores per slab instead of 86 400 identical ones to the same entries)
-	const bool emit_here = (sred >> 30) & 1;
 	// ---- window of the first level
 	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
 	{
@@ -329,8 +326,10 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		// ---- the stage combination (reference order), then base + increments in the level-parallel kernel's order
 		const double bU = lin_reduce<NT, PM>(xbase, xU), bV = lin_reduce<NT, PM>(xbase, xV);
 		const double bT = lin_reduce<NT, PM>(xbase, xT), bR = lin_reduce<NT, PM>(xbase, xR), bW = lin_reduce<NT, PM>(xbase, xW);
-		if (EM && emit_here) {
-			// every copy of a node forms the same prefix (the sources are node-unique): the copy that stores or hands on the stage's own result stores it
+		if (EM) {
+			// every copy of a node forms the same prefix (the sources are node-unique): each stores it, to the same entry (one store per node
+			// -- the representative copy alone -- and the later destination's position resolved by a uniform switch instead of selects both
+			// measured the same: what the prefix costs is its 61 MB of stores, 0.02 ms per step of the 0.05 the fourth stage saves)
 			stu(em.xp + TMX_SLAB_U(L, k) * SS, cb, emit_value<NT>(em, xU)); stu(em.xp + TMX_SLAB_V(L, k) * SS, cb, emit_value<NT>(em, xV));
 			stu(em.xp + TMX_SLAB_T(L, k) * SS, cb, emit_value<NT>(em, xT)); stu(em.xp + TMX_SLAB_R(L, k) * SS, cb, emit_value<NT>(em, xR));
 			if (k > 0) stu(em.xp + TMX_SLAB_W(L, k) * SS, cb, emit_value<NT>(em, xW));
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 				double xWl[NX];
 				terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xWl);
 				extra = lin_reduce<NT, PM>(xbase, xWl); xslab = TMX_SLAB_W(L, L); vmask |= 32u;
-				if (EM && emit_here) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xWl));
+				if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xWl));
 			}
 			const double v[6] = { outU, outV, outR, outT, outW, extra };
 			const int slab[6] = { TMX_SLAB_U(L, k), TMX_SLAB_V(L, k), TMX_SLAB_R(L, k), TMX_SLAB_T(L, k), TMX_SLAB_W(L, k), xslab };
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
 		if constexpr (!UQ) { if (here) stu(xup + TMX_SLAB_W(L, L) * NS, cb, v1[0]); HW_MARK(6); HW_END(NT); return; }
-		if (EM && emit_here) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
+		if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
 		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
 	}

@@ -191,9 +191,6 @@ int tmxu_tables(tmx_engine * e, const UniquePlanInput & in, UniqueTables & T) {
 		for (int m = 0; m < n; m++) t_sdst[tb + lanes[m]] = (m == owner) ? t_ucol[tb + lanes[m]] : -1;
 		t_sred[tb + lanes[owner]] = n | (l1 << 4) | (l2 << 10) | (l3 << 16);
 	}
-	// bit 30 of a thread's seam word: its stored column is the node's representative copy (one thread per unique node: who stores a value that
-	// every copy of the node computes alike, e.g. the prefix of a later stage's combination)
-	for (int t = 0; t < u.NTS; t++) if (t_dcol[t] >= 0 && u_rep[t_ucol[t]] == t_dcol[t]) t_sred[t] |= 1 << 30;
 	// ---- the same one level up: groups whose copies all belong to ONE BLOCK (a workgroup of up to four wavefronts) are averaged by that
 	// workgroup through LDS (block kernels: k_h_walk<.., BLK>, k_hypervis_blk); position of a thread in its block = 64 * wavefront + lane
 	std::vector<int> blk_of_tile(u.NTS / 64, -1);

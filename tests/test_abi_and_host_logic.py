@@ -317,12 +317,8 @@ def test_unique_layout_tables(ne, npatch, n_ranks, shape):
         side = int(round(per_patch ** 0.5))
         assert NU == len(e.local_patches) * (3 * side + 1) ** 2
         assert (NTS == (el * 16 + 63) // 64 * 64) if shape != 4 else (NTS >= el * 16 and NTS % 64 == 0)      # (the block order pads ragged blocks to whole wavefronts)
-        tu, sd, sr, td = T["t_ucol"], T["t_sdst"], T["t_sred"].copy(), T["t_dcol"]
+        tu, sd, sr, td = T["t_ucol"], T["t_sdst"], T["t_sred"], T["t_dcol"]
         valid = td >= 0
-        # bit 30 of the seam word: the thread holds the node's representative copy -- exactly one thread per unique node
-        rep = (sr >> 30) & 1
-        sr &= 0x3fffffff
-        assert sorted(tu[rep == 1]) == list(range(NU)) and (td[rep == 1] == T["u_rep"][tu[rep == 1]]).all()
         assert valid.sum() == el * 16 and sorted(td[valid]) == list(range(el * 16))          # thread order = a permutation of the elements' nodes
         assert (tu[valid] == T["ucol_of_dcol"][td[valid]]).all() and (tu[~valid] == -1).all() and (sd[~valid] == -1).all()
         # who stores each unique node
