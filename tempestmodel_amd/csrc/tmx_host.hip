@@ -1429,7 +1429,7 @@ static int * option_slot(tmx_engine * e, const std::string & n) {
 	OPT("udv_separate", e->opt_udv_separate); OPT("vx_fused", e->opt_vx_fused); OPT("debug_skip_exchange", e->opt_skip_exchange);
 	OPT("exchange_overlap_off", e->opt_no_exchange_overlap); OPT("kessler_column", e->opt_kessler_column);
 	OPT("vt_column", e->opt_vt_column); OPT("vt_explicit_v1", e->opt_vt_explicit_v1); OPT("vt_explicit_walk", e->opt_vt_walk); OPT("vite_walk", e->opt_vite_walk); OPT("vx_walk", e->opt_vx_walk); OPT("vt_lanes", e->opt_vt_lanes); OPT("vt_lw8", e->opt_vt_lw8);
-	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows); OPT("h_walk", e->opt_h_walk); OPT("hv_walk", e->opt_hv_walk); OPT("lu_fma", e->lu_fma);
+	OPT("vt_row_lanes", e->opt_vt_nr); OPT("vt_rows", e->opt_vt_rows); OPT("h_walk", e->opt_h_walk); OPT("hv_walk", e->opt_hv_walk); OPT("h_walk_udiff", e->opt_h_walk_udiff); OPT("lu_fma", e->lu_fma);
 #undef OPT
 	return nullptr;
 }
@@ -1478,6 +1478,7 @@ static const OptionDef g_options[] = {
 	{ "vt_row_lanes", "TMX_VT_NR", 2, "A/B switch, experiments flavour only: row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
 	{ "lu_fma", "TMX_LU_FMA", 0, "band LU of the column solves: 1 (default) updates a - l u as ONE rounding (fused multiply-add: a reference linked to OpenBLAS, or to MKL on its FMA code paths), 0 = multiply and subtract rounded separately (a BLAS without fused multiply-adds); tmx_lu_flavour_from_dgbsv asks the caller's own LAPACK" },
+	{ "h_walk_udiff", "TMX_H_WALK_UDIFF", 0, "uniform-diffusion configurations: 1 (default) the explicit stage's walk applies the horizontal uniform diffusion to its results in registers, 0 = k_uniform_diffusion as a pass of its own (bit-identical)" },
 	{ "hv_walk", "TMX_HV_WALK", 0, "hyperviscosity pass on the node-unique layout: 1 (default) a wavefront walks a segment of levels (k_hv_walk), 0 = the level-parallel k_hypervis (bit-identical)" },
 	{ "h_walk", "TMX_H_WALK", 0, "explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register window, segments per column from the grid size; -n = n segments; 0 = the level-parallel kernel + k_h_w_update" },
 };
@@ -1524,7 +1525,7 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "hv_walk" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "hv_walk" || n == "h_walk_udiff" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;

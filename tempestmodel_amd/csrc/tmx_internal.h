@@ -301,6 +301,7 @@ struct tmx_engine {
 	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_walk = -1000, opt_vite_walk = -1000, opt_vx_walk = -1000, opt_vt_lanes = 16,
 	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
 	int lu_fma = 1;                          // option "lu_fma": 1 = band-LU updates as fused multiply-adds (OpenBLAS, MKL's FMA paths), 0 = multiply + subtract (tmx_lu_select.hip)
+	int opt_h_walk_udiff = 1;                // the walk applies the horizontal uniform diffusion itself (element-major uniform-diffusion configurations): 1 (default), 0 = k_uniform_diffusion as a pass of its own
 	int opt_hv_walk = 1;                     // hyperviscosity pass on the node-unique layout as a walk (k_hv_walk): 1 (default), 0 = the level-parallel k_hypervis
 	int opt_h_walk = -1000;                  // explicit stage on the node-unique layout: -1000 auto (column-segment walk, segments from the grid size), -n = n segments, 0 = the level-parallel kernel
 	std::vector<int> opt_default;            // default of every option, in g_options order (tmx_record_option_defaults)
@@ -370,6 +371,7 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
 	const EmitTerms * emit = nullptr);
+bool tmxk_h_walk_fuses_udiff(const tmx_engine * e, const KParams & p, int fuse_v, int nterms);      // the walk applies the horizontal uniform diffusion itself
 bool tmxk_hv_walk_ok(const tmx_engine * e, const KParams & p);      // the hyperviscosity pass as a walk (same file)
 void tmxk_hv_walk(tmx_engine * e, const KParams & p, const double * xsrc, const double * xbase, double * xout, double dt, double nu_s, double nu_d, double nu_v, int scale);
 void tmxk_h_walk_timing_read(unsigned long long * out);      // diagnostic builds (-DTMX_H_TIMING): [8 instantiations][7 phases + count], cleared by the read

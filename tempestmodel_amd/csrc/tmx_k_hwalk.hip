@@ -78,12 +78,17 @@ typedef const double __attribute__((address_space(4))) * tmx_cdp;
 // UQ = false: the ELEMENT-MAJOR layout (every configuration the node-unique one does not cover: tracers, uniform diffusion, fully explicit
 // vertical dynamics, a step the engine keeps element-major): a thread reads and writes its own stored column, no seam exchange, the DSS
 // kernel averages afterwards as the reference does.  FV = false: H.StepExplicit alone (the caller runs V.StepExplicit as a kernel of its own).
-template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false, bool UQ = true, bool FV = true>
-__global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg, EmitTerms em)
+// UD (element-major, FV = false): the horizontal uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (:1817-1859; k_uniform_diffusion,
+// tmx_k_horizontal.hip, statement for statement) applied to the level's results in registers before they are stored -- that kernel's pass over the
+// initial, the reference and the update instance (20 slab reads / writes per point) shrinks to the four reference slabs.
+struct UdiffArgs { const double * xref; double ks, kv; };
+template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false, bool UQ = true, bool FV = true, bool UD = false>
+__global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg, EmitTerms em,
+	UdiffArgs ud)
 {
 	constexpr int RL = TMX_UQ_ROWLEN(true);
 	constexpr int NW = BLK ? 4 : 1;
-	__shared__ double sw[NW][9][RL];
+	__shared__ double sw[NW][UD ? 10 : 9][RL];
 	__shared__ double xs[BLK ? 2 : 1][BLK ? 6 : 1][BLK ? 256 : 1];
 	__shared__ double sD[16], sS[16];
 	__shared__ double rmtab[TMX_RMTAB_DOUBLES];
@@ -132,6 +137,8 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	const double ida = ldu(p.g2d + G2_IDA * NS, gb), idb = ldu(p.g2d + G2_IDB * NS, gb);
 	const int sdst = UQ ? (BLK ? p.b_sdst[col] : p.t_sdst[col]) : 0, sred = UQ ? (BLK ? p.b_sred[col] : p.t_sred[col]) : 0;
 	const int pos = wv * 64 + lane;      // BLK: position in the block
+	const double je = UD ? ldu(p.g2d + G2_JE * NS, gb) : 1.0;      // UD: Jacobian on interfaces
+	double xW0 = 0.0;      // UD: the diffusion increment of W on the surface, formed at level 0, applied when level 1 knows W there
 	// ---- window of the first level
 	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
 	{
@@ -203,6 +210,11 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_T(L, k), SS, NSD, cb, gd, xT);
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_R(L, k), SS, NSD, cb, gd, xR);
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, (k > 0) ? k : 1), SS, NSD, cb, gd, xW);      // (interface 0 has no base: boundary condition)
+		double rfT = 0.0, rfU = 0.0, rfV = 0.0, rfW = 0.0;      // UD: the reference state of this level / interface
+		if (UD) {
+			rfT = ldu(ud.xref + TMX_SLAB_T(L, k) * NS, cb); rfU = ldu(ud.xref + TMX_SLAB_U(L, k) * NS, cb);
+			rfV = ldu(ud.xref + TMX_SLAB_V(L, k) * NS, cb); rfW = ldu(ud.xref + TMX_SLAB_W(L, k) * NS, cb);
+		}
 		__builtin_amdgcn_sched_barrier(0);
 		HW_MARK(1);
 
@@ -339,8 +351,79 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		const double uh = outU, vh = outV;      // H-only values (levels 0, 1: the bottom boundary condition below)
 		if (FV && k < L - 1) { outU += tUhi; outV += tVhi; }
 		if (FV && k > 0) { outU += tUlo; outV += tVlo; }
-		const double outR = bR - tR, outT = bT - tT;
-		const double outW = bW + tW;
+		const double outR = bR - tR;
+		double outT = bT - tT, outW = bW + tW;
+		if constexpr (UD) {
+			// horizontal uniform diffusion of rho*theta, W (relative to the reference state) and of U, V (divergence / curl form, state and reference
+			// apart), k_uniform_diffusion's statements on this level's values; the stage combination's terms are reduced by now (their registers are free)
+			wave_sync();
+			const double psiT = t0 - rfT, psiW = w0 - rfW;
+			s[0][lp] = psiT; s[1][lp] = psiW;
+			s[2][lp] = u0; s[3][lp] = v0; s[4][lp] = j2d * (c2a0 * u0 + c2a1 * v0); s[5][lp] = j2d * (c2a1 * u0 + c2b1 * v0);
+			s[6][lp] = rfU; s[7][lp] = rfV; s[8][lp] = j2d * (c2a0 * rfU + c2a1 * rfV); s[9][lp] = j2d * (c2a1 * rfU + c2b1 * rfV);
+			wave_sync();
+			double daT = 0, dbT = 0, daW = 0, dbW = 0;
+			double dUb = 0, dbUa = 0, dajua = 0, dbjub = 0, dUbr = 0, dbUar = 0, dajuar = 0, dbjubr = 0;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+				const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+				daT += s[0][la] * Da; dbT += s[0][lb] * Db;
+				daW += s[1][la] * Da; dbW += s[1][lb] * Db;
+				dUb += s[3][la] * Da; dbUa += s[2][lb] * Db;
+				dajua += s[4][la] * Da; dbjub += s[5][lb] * Db;
+			}
+			asm volatile("" : "+v"(daT), "+v"(dbT), "+v"(daW), "+v"(dbW) : : "memory");
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+				const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+				dUbr += s[7][la] * Da; dbUar += s[6][lb] * Db;
+				dajuar += s[8][la] * Da; dbjubr += s[9][lb] * Db;
+			}
+			daT *= ida; dbT *= idb; daW *= ida; dbW *= idb;
+			dUb *= ida; dbUa *= idb; dajua *= ida; dbjub *= idb;
+			dUbr *= ida; dbUar *= idb; dajuar *= ida; dbjubr *= idb;
+			const double invJ2 = 1.0 / j2d;
+			const double dv = (dajua + dbjub) * invJ2, cl = (dUb - dbUa) * invJ2;
+			const double dvr = (dajuar + dbjubr) * invJ2, clr = (dUbr - dbUar) * invJ2;
+			wave_sync();
+			s[0][lp] = jn * (c2a0 * daT + c2a1 * dbT); s[1][lp] = jn * (c2a1 * daT + c2b1 * dbT);
+			s[2][lp] = je * (c2a0 * daW + c2a1 * dbW); s[3][lp] = je * (c2a1 * daW + c2b1 * dbW);
+			s[4][lp] = dv; s[5][lp] = cl; s[6][lp] = dvr; s[7][lp] = clr;
+			wave_sync();
+			double uaT = 0, ubT = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0, dadr = 0, dbdr = 0, dacr = 0, dbcr = 0;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+				const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+				uaT += s[0][la] * Sa; ubT += s[1][lb] * Sb;
+				uaW += s[2][la] * Sa; ubW += s[3][lb] * Sb;
+				dad -= Sa * s[4][la]; dbd -= Sb * s[4][lb];
+			}
+			asm volatile("" : "+v"(uaT), "+v"(ubT), "+v"(uaW), "+v"(ubW) : : "memory");
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+				const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+				dac -= Sa * s[5][la]; dbc -= Sb * s[5][lb];
+				dadr -= Sa * s[6][la]; dbdr -= Sb * s[6][lb];
+				dacr -= Sa * s[7][la]; dbcr -= Sb * s[7][lb];
+			}
+			uaT *= ida; ubT *= idb; uaW *= ida; ubW *= idb;
+			dad *= ida; dbd *= idb; dac *= ida; dbc *= idb; dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
+			const double xW = dt * (1.0 / je) * ud.kv * (uaW + ubW);
+			if (k == 0) xW0 = xW; else outW = outW - xW;
+			outT = outT - dt * (1.0 / jn) * ud.ks * (uaT + ubT);
+			const double nkv = -ud.kv;
+			const double upa = nkv * dad - nkv * j2d * (c2a1 * dac + c2b1 * dbc);
+			const double upb = nkv * dbd + nkv * j2d * (c2a0 * dac + c2a1 * dbc);
+			const double upar = ud.kv * dadr - ud.kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
+			const double upbr = ud.kv * dbdr + ud.kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
+			outU -= dt * upa; outU -= dt * upar;
+			outV -= dt * upb; outV -= dt * upbr;
+			wave_sync();
+		}
 		if constexpr (!UQ) {
 			// element-major: the thread's own column
 			if (here) {
@@ -356,7 +439,9 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 				vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 0) * vh0; vb0 += OPK(TMX_OP_INTERP_NODE_TO_REDGE, 0, 1) * vh;
 				double e0, e1, e2, ea, eb_;
 				met_eval(mc, etac[L], e0, e1, e2, ea, eb_);
-				if (here) stu(xup + TMX_SLAB_W(L, 0) * NS, cb, -(e0 * ub0 + e1 * vb0) / e2);
+				double wb = -(e0 * ub0 + e1 * vb0) / e2;
+				if (UD) wb = wb - xW0;      // (the surface's diffusion increment, formed at level 0 from the initial W there)
+				if (here) stu(xup + TMX_SLAB_W(L, 0) * NS, cb, wb);
 			}
 		} else if constexpr (BLK) {
 			// one exchange per level for the whole block; W of the surface (known once level 1's H-only U, V are) and of the lid ride along
@@ -411,7 +496,30 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		double xW[NX];
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, L), SS, NSD, cb, gd, xW);
 		const double v1[1] = { lin_reduce<NT, PM>(xbase, xW) };
-		if constexpr (!UQ) { if (here) stu(xup + TMX_SLAB_W(L, L) * NS, cb, v1[0]); HW_MARK(6); HW_END(NT); return; }
+		if constexpr (!UQ) {
+			double wl = v1[0];
+			if constexpr (UD) {
+				// the lid's W diffuses too (k_uniform_diffusion's interface L: W alone); w0 holds the initial W of the lid after the last slide
+				const double psiW = w0 - ldu(ud.xref + TMX_SLAB_W(L, L) * NS, cb);
+				wave_sync();
+				s[1][lp] = psiW;
+				wave_sync();
+				double daW = 0, dbW = 0;
+#pragma unroll
+				for (int t = 0; t < 4; t++) { daW += s[1][eb + 4 * t + j] * sD[t * 4 + i]; dbW += s[1][eb + 4 * i + t] * sD[t * 4 + j]; }
+				daW *= ida; dbW *= idb;
+				wave_sync();
+				s[2][lp] = je * (c2a0 * daW + c2a1 * dbW); s[3][lp] = je * (c2a1 * daW + c2b1 * dbW);
+				wave_sync();
+				double uaW = 0, ubW = 0;
+#pragma unroll
+				for (int t = 0; t < 4; t++) { uaW += s[2][eb + 4 * t + j] * sS[i * 4 + t]; ubW += s[3][eb + 4 * i + t] * sS[j * 4 + t]; }
+				uaW *= ida; ubW *= idb;
+				wl = wl - dt * (1.0 / je) * ud.kv * (uaW + ubW);
+			}
+			if (here) stu(xup + TMX_SLAB_W(L, L) * NS, cb, wl);
+			HW_MARK(6); HW_END(NT); return;
+		}
 		if (EM) stu(em.xp + TMX_SLAB_W(L, L) * SS, cb, emit_value<NT>(em, xW));
 		const int slab1[1] = { TMX_SLAB_W(L, L) };
 		seam_store<1, RL>(p, &s[0], lane, sdst, sred, v1, xup, slab1, 1);
@@ -454,6 +562,11 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 	return nseg;
 }
 
+// Does the walk apply the horizontal uniform diffusion itself?  (element-major layout, V.StepExplicit not fused in: the uniform-diffusion configurations)
+bool tmxk_h_walk_fuses_udiff(const tmx_engine * e, const KParams & p, int fuse_v, int nterms) {
+	return e->udiff && !p.t_ucol && !fuse_v && e->opt_h_walk_udiff != 0 && tmxk_h_walk_ok(e, p, fuse_v, nterms, false);
+}
+
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
 	const EmitTerms * emit) {
@@ -471,9 +584,12 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 		// element-major layout: 2-D launch (tile list or all tiles) x segments
 		EmitTerms em1; em1.xp = nullptr; em1.first = -1; for (int m = 0; m < 12; m++) em1.coef[m] = 0.0;
 		const dim3 grd(ntile, nseg), blk(64);
+		const bool udf = tmxk_h_walk_fuses_udiff(e, p, fuse_v, nterms);
+		const UdiffArgs ud0 = { nullptr, 0.0, 0.0 }, ud1 = { (const double *)e->d_ref, e->cfg.uniform_diffusion_scalar, e->cfg.uniform_diffusion_vector };
 #define LAUNCH_D2(NT_, PM_) do { \
-			if (fuse_v) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1); \
-			else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1); } while (0)
+			if (fuse_v) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud0); \
+			else if (udf) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud1); \
+			else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud0); } while (0)
 #define LAUNCH_D(NT_) do { if (NT_ == 0 || premul) LAUNCH_D2(NT_, true); else LAUNCH_D2(NT_, false); } while (0)
 		switch (nterms) {
 			case 0: LAUNCH_D(0); break;
@@ -496,13 +612,14 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	e->u.slots_by_blocks = blocks;
 	const dim3 blk(64, blocks ? 4 : 1), grd = wg_grid(true, q, blocks ? nblk : ntile, nseg);
 	EmitTerms em0; em0.xp = nullptr; em0.first = -1; for (int m = 0; m < 12; m++) em0.coef[m] = 0.0;
+	const UdiffArgs udn = { nullptr, 0.0, 0.0 };
 	// (the prefix of a later stage's combination: no own coefficient, three to eight terms, node-unique sources, wavefront-level kernel)
 	const bool emit_ok = emit && emit->xp && !premul && !dmask && !blocks && nterms >= 3 && nterms <= 8;
 	const EmitTerms em = emit_ok ? *emit : em0;
 #define LAUNCH_W3(NT_, PM_, DM_) do { \
-		if (emit_ok && NT_ >= 3 && !PM_ && !DM_) hipLaunchKernelGGL((k_h_walk<(NT_ >= 3 ? NT_ : 3), false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em); \
-		else if (TMX_EXP && blocks) hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, TMX_EXP != 0>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0); \
-		else hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0); } while (0)
+		if (emit_ok && NT_ >= 3 && !PM_ && !DM_) hipLaunchKernelGGL((k_h_walk<(NT_ >= 3 ? NT_ : 3), false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em, udn); \
+		else if (TMX_EXP && blocks) hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, TMX_EXP != 0>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0, udn); \
+		else hipLaunchKernelGGL((k_h_walk<NT_, PM_, DM_, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em0, udn); } while (0)
 #define LAUNCH_W2(NT_, PM_) do { if (dmask) LAUNCH_W3(NT_, PM_, true); else LAUNCH_W3(NT_, PM_, false); } while (0)
 #define LAUNCH_W(NT_) do { if (NT_ == 0 || premul) LAUNCH_W2(NT_, true); else LAUNCH_W2(NT_, false); } while (0)
 	switch (nterms) {

@@ -138,8 +138,9 @@ extern "C" int tmx_linear_combine_data(tmx_engine * e, const double * coeff, int
 // dynamics
 
 // uniform-diffusion extras at the end of HorizontalDynamicsFEM::StepExplicit (:1817-1859)
-static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt) {
-	if (!e->udiff) return TMX_OK;
+// fused: the explicit stage's kernel has applied it already (tmxk_h_walk_fuses_udiff)
+static int h_uniform_diffusion(tmx_engine * e, int iinit, int iupd, double dt, bool fused = false) {
+	if (!e->udiff || fused) return TMX_OK;
 	int r; if ((r = check_reference_state(e))) return r;
 	tmxk_uniform_diffusion(e, make_params(e), inst(e, iinit), e->d_ref, inst(e, iupd), dt, e->cfg.uniform_diffusion_scalar, e->cfg.uniform_diffusion_vector);
 	return TMX_OK;
@@ -172,10 +173,12 @@ extern "C" int tmx_h_step_explicit(tmx_engine * e, int iinit, int iupd, double d
 	// same precondition as the reference (HorizontalDynamicsFEM.cpp:1793-1796)
 	REQUIRE(iinit != iupd, TMX_ERR_INVALID, "StepExplicit: initial and update data instance must be distinct");
 	ProfScope ps(e, TMX_K_H_EXPLICIT);
+	const bool udf = !e->sw && tmxk_h_walk_fuses_udiff(e, make_params(e), 0, 0);
+	if (udf && (r = check_reference_state(e))) return r;
 	if (e->sw) tmxk_sw_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
 	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, 0);
 	if (e->nt > 0) tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt);
-	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
+	if ((r = h_uniform_diffusion(e, iinit, iupd, dt, udf))) return r;
 	return launch_check("h_step_explicit");
 }
 
@@ -206,6 +209,8 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 	// read them through the instance pointer, and the stepper never shares U,V there
 	REQUIRE(!e->n_uvshared || (!e->udiff && !e->fully_explicit && !e->sw), TMX_ERR_UNSUPPORTED, "internal: shared U,V slabs in a configuration whose kernels do not take them");
 	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
+	const bool udf = tmxk_h_walk_fuses_udiff(e, make_params(e), e->udiff ? 0 : 1, n);
+	if (udf && (r = check_reference_state(e))) return r;
 	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul, inst_uv(e, iinit), inst_uv(e, iupd), srcuv);
 	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1, 0, nullptr, nullptr, 0, inst_uv(e, iinit), inst_uv(e, ibase), nullptr);
 	if (e->nt > 0) {
@@ -223,7 +228,7 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 		} else
 			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 0, nullptr, nullptr, 0, inst_uv(e, iinit));
 	}
-	if ((r = h_uniform_diffusion(e, iinit, iupd, dt))) return r;
+	if ((r = h_uniform_diffusion(e, iinit, iupd, dt, udf))) return r;
 	const bool uvx = uvx_fused(e);
 	if (e->udiff && !uvx) {
 		if (udv_fused(e) && (r = check_reference_state(e))) return r;
