@@ -143,7 +143,7 @@ extern "C" void tmx_destroy(tmx_engine * e) {
 		if (e->xstream) { hipStreamSynchronize(e->xstream); hipStreamDestroy(e->xstream); hipEventDestroy(e->ev_pack); hipEventDestroy(e->ev_recv); }
 		prof_collect(e);
 		if (e->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(e->comm);
-		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
+		free_dev(e->d_state); free_dev(e->d_ref); free_dev(e->d_refd); free_dev(e->d_area); free_dev(e->d_w0); free_dev(e->d_eta); free_dev(e->d_ray_nu); free_dev(e->d_ray_ref); free_dev(e->d_g2d); free_dev(e->d_g3n); free_dev(e->d_g3e); free_dev(e->d_ops);
 		free_dev(e->d_scratch); free_dev(e->d_grp_cols); free_dev(e->d_colref); free_dev(e->d_hvblocks); free_dev(e->d_grp_n); free_dev(e->d_grp_x); free_dev(e->d_grp_type); free_dev(e->d_xmat); free_dev(e->d_zlev); free_dev(e->d_prect); free_dev(e->d_kes); free_dev(e->d_quads_early); free_dev(e->d_quads_late); free_dev(e->d_pivot_stats); free_dev(e->d_image);
 		if (e->d_ghost_own) e->d_ghost = e->d_ghost_own;          // p2p mode pointed d_ghost into the shared block
 		for (void * q : e->p2p_peer) if (q) hipIpcCloseMemHandle(q);
@@ -1007,6 +1007,7 @@ extern "C" int tmx_set_patch_reference_state(tmx_engine * e, int patch, const do
 	HIPCHK(hipMemcpy2D(e->d_ref + c0, (size_t)e->NS * sizeof(double), buf.data(), (size_t)ncp * sizeof(double),
 		(size_t)ncp * sizeof(double), e->nslab, hipMemcpyHostToDevice));
 	P.ref_set = true;
+	e->refd_valid = false;
 	return TMX_OK;
 }
 
@@ -1478,7 +1479,7 @@ static const OptionDef g_options[] = {
 	{ "vt_row_lanes", "TMX_VT_NR", 2, "A/B switch, experiments flavour only: row lanes of that kernel (0 auto)" },
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
 	{ "lu_fma", "TMX_LU_FMA", 0, "band LU of the column solves: 1 (default) updates a - l u as ONE rounding (fused multiply-add: a reference linked to OpenBLAS, or to MKL on its FMA code paths), 0 = multiply and subtract rounded separately (a BLAS without fused multiply-adds); tmx_lu_flavour_from_dgbsv asks the caller's own LAPACK" },
-	{ "h_walk_udiff", "TMX_H_WALK_UDIFF", 0, "uniform-diffusion configurations: 1 (default) the explicit stage's walk applies the horizontal uniform diffusion to its results in registers, 0 = k_uniform_diffusion as a pass of its own (bit-identical)" },
+	{ "h_walk_udiff", "TMX_H_WALK_UDIFF", 0, "uniform-diffusion configurations: the explicit stage's walk applies the horizontal uniform diffusion to its results in registers (1) and V.StepExplicit's U,V part behind it (2, default); 0 = k_uniform_diffusion and k_v_explicit as passes of their own (bit-identical)" },
 	{ "hv_walk", "TMX_HV_WALK", 0, "hyperviscosity pass on the node-unique layout: 1 (default) a wavefront walks a segment of levels (k_hv_walk), 0 = the level-parallel k_hypervis (bit-identical)" },
 	{ "h_walk", "TMX_H_WALK", 0, "explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register window, segments per column from the grid size; -n = n segments; 0 = the level-parallel kernel + k_h_w_update" },
 };
@@ -1524,8 +1525,9 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vi_back_sub") REQUIRE(iv == 1 || iv == 2 || iv == 4, TMX_ERR_INVALID, "vi_back_sub: 1, 2 or 4");
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
+	if (n == "h_walk_udiff") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "h_walk_udiff: 0, 1 or 2");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "hv_walk" || n == "h_walk_udiff" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "hv_walk" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;

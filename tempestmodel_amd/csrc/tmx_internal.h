@@ -292,6 +292,8 @@ struct tmx_engine {
 	bool fully_explicit = false, udiff = false;   // cfg.fully_explicit / cfg.uniform_diffusion
 	std::vector<double> h_ref;               // reference state in slab layout until tmx_finalize
 	double * d_ref = nullptr;                // [nslab][NS] reference state + reference tracers (uniform diffusion)
+	double * d_refd = nullptr;               // [4 L][NS] the reference's own diffusion increments of U, V (tmx_k_hwalk.hip, k_ref_diffusion_terms), formed on first use
+	bool refd_valid = false;                 // ... and again after tmx_set_patch_reference_state
 	double * h_stage = nullptr; size_t h_stage_n = 0;   // pinned host staging buffer of tmx_upload_state / tmx_download_state
 	bool prof = false;
 	int use_graph = 0;                       // option "step_graph" (TMX_GRAPH=1): replay single-rank steps from a captured hipGraph (measured: no gain, see tmx_step)
@@ -301,7 +303,7 @@ struct tmx_engine {
 	    opt_no_exchange_overlap = 0, opt_kessler_column = 0, opt_vi_sparse = 1, opt_vt_column = 0, opt_vt_explicit_v1 = 0, opt_vt_walk = -1000, opt_vite_walk = -1000, opt_vx_walk = -1000, opt_vt_lanes = 16,
 	    opt_vt_lw8 = -1, opt_vt_nr = 0, opt_vt_rows = 1, opt_vi_cpw = 0;
 	int lu_fma = 1;                          // option "lu_fma": 1 = band-LU updates as fused multiply-adds (OpenBLAS, MKL's FMA paths), 0 = multiply + subtract (tmx_lu_select.hip)
-	int opt_h_walk_udiff = 1;                // the walk applies the horizontal uniform diffusion itself (element-major uniform-diffusion configurations): 1 (default), 0 = k_uniform_diffusion as a pass of its own
+	int opt_h_walk_udiff = 2;                // the walk applies the horizontal uniform diffusion itself (element-major uniform-diffusion configurations): 1; 2 (default) V.StepExplicit's U,V part too; 0 = k_uniform_diffusion / k_v_explicit as passes of their own
 	int opt_hv_walk = 1;                     // hyperviscosity pass on the node-unique layout as a walk (k_hv_walk): 1 (default), 0 = the level-parallel k_hypervis
 	int opt_h_walk = -1000;                  // explicit stage on the node-unique layout: -1000 auto (column-segment walk, segments from the grid size), -n = n segments, 0 = the level-parallel kernel
 	std::vector<int> opt_default;            // default of every option, in g_options order (tmx_record_option_defaults)

@@ -78,17 +78,85 @@ typedef const double __attribute__((address_space(4))) * tmx_cdp;
 // UQ = false: the ELEMENT-MAJOR layout (every configuration the node-unique one does not cover: tracers, uniform diffusion, fully explicit
 // vertical dynamics, a step the engine keeps element-major): a thread reads and writes its own stored column, no seam exchange, the DSS
 // kernel averages afterwards as the reference does.  FV = false: H.StepExplicit alone (the caller runs V.StepExplicit as a kernel of its own).
-// UD (element-major, FV = false): the horizontal uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (:1817-1859; k_uniform_diffusion,
+// UD (element-major): the horizontal uniform diffusion at the end of HorizontalDynamicsFEM::StepExplicit (:1817-1859; k_uniform_diffusion,
 // tmx_k_horizontal.hip, statement for statement) applied to the level's results in registers before they are stored -- that kernel's pass over the
-// initial, the reference and the update instance (20 slab reads / writes per point) shrinks to the four reference slabs.
-struct UdiffArgs { const double * xref; double ks, kv; };
+// initial, the reference and the update instance (20 slab reads / writes per point) shrinks to four slabs: the reference's rho*theta and W, and the
+// diffusion increments of the REFERENCE's U, V, which do not change from step to step and are formed once (k_ref_diffusion_terms below: the
+// same statements on the same operands, stored instead of used at once).
+// UD with FV: V.StepExplicit's part on U, V follows in the same registers (VerticalDynamicsFEM.cpp:984-1023 upwind penalty, :1059-1105 vertical
+// uniform diffusion -- k_v_explicit_slide, tmx_k_vertical.hip, statement for statement): the window holds U, V of the levels k - 2 .. k + 2, the
+// reference's DiffDiff sums come from the stored terms too.  k_v_explicit_slide's pass over U, V, W, the reference and the update is not run.
+struct UdiffArgs { const double * xref; double ks, kv; const double * xrefd; double cfv; int udv; };
+// slabs of the stored reference terms [4 L][NS]: horizontal increments of U, V (upar, upbr of k_uniform_diffusion), DiffDiffNodeToNode of U_ref, V_ref
+#define TMX_REFD_HU(L, k) (k)
+#define TMX_REFD_HV(L, k) ((L) + (k))
+#define TMX_REFD_DU(L, k) (2 * (L) + (k))
+#define TMX_REFD_DV(L, k) (3 * (L) + (k))
+
+// The reference state's share of the uniform diffusion of U, V, once per reference state: one wavefront = four elements at one level.
+__global__ __launch_bounds__(64) void k_ref_diffusion_terms(KParams p, const double * __restrict__ xref, double * __restrict__ xrefd, double kv)
+{
+	__shared__ double s[4][64];
+	__shared__ double sD[16], sS[16];
+	const int lane = threadIdx.x;
+	if (lane < 16) { sD[lane] = p.dx[lane]; sS[lane] = p.stiff[lane]; }
+	const int L = p.L, k = blockIdx.y;
+	const size_t NS = (size_t)p.NS;
+	const int colr = blockIdx.x * 64 + lane;
+	const bool here = colr < p.ncol;
+	const int col = here ? colr : p.ncol - 1;
+	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lane & 48;
+	const double c2a0 = p.g2d[G2_C2A0 * NS + col], c2a1 = p.g2d[G2_C2A1 * NS + col], c2b1 = p.g2d[G2_C2B1 * NS + col];
+	const double j2d = p.g2d[G2_J2D * NS + col], ida = p.g2d[G2_IDA * NS + col], idb = p.g2d[G2_IDB * NS + col];
+	const double ra = xref[TMX_SLAB_U(L, k) * NS + col], rb = xref[TMX_SLAB_V(L, k) * NS + col];
+	s[0][lane] = ra; s[1][lane] = rb; s[2][lane] = j2d * (c2a0 * ra + c2a1 * rb); s[3][lane] = j2d * (c2a1 * ra + c2b1 * rb);
+	__syncthreads();
+	double daubr = 0, dbuar = 0, dajuar = 0, dbjubr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
+		daubr += s[1][la] * Da; dbuar += s[0][lb] * Db;
+		dajuar += s[2][la] * Da; dbjubr += s[3][lb] * Db;
+	}
+	daubr *= ida; dbuar *= idb; dajuar *= ida; dbjubr *= idb;
+	const double invJ2 = 1.0 / j2d;
+	const double dvr = (dajuar + dbjubr) * invJ2, clr = (daubr - dbuar) * invJ2;
+	__syncthreads();
+	s[0][lane] = dvr; s[1][lane] = clr;
+	__syncthreads();
+	double dadr = 0, dbdr = 0, dacr = 0, dbcr = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
+		const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
+		dadr -= Sa * s[0][la]; dbdr -= Sb * s[0][lb];
+		dacr -= Sa * s[1][la]; dbcr -= Sb * s[1][lb];
+	}
+	dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
+	const double upar = kv * dadr - kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
+	const double upbr = kv * dbdr + kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
+	// DiffDiffNodeToNode of the reference's U, V (the accumulation of k_v_explicit_slide / v_explicit_point: in-range levels, offsets ascending)
+	double ddr[2] = { 0.0, 0.0 };
+#pragma unroll
+	for (int off = -2; off <= 2; off++) {
+		const int l = k + off;
+		if (l < 0 || l >= L) continue;
+		const double c = p.ops[((TMX_OP_DIFFDIFF_NODE_TO_NODE * (L + 1)) + k) * TMX_OPW + (off + 2)];
+		ddr[0] += c * xref[TMX_SLAB_U(L, l) * NS + col];
+		ddr[1] += c * xref[TMX_SLAB_V(L, l) * NS + col];
+	}
+	if (!here) return;
+	xrefd[TMX_REFD_HU(L, k) * NS + col] = upar; xrefd[TMX_REFD_HV(L, k) * NS + col] = upbr;
+	xrefd[TMX_REFD_DU(L, k) * NS + col] = ddr[0]; xrefd[TMX_REFD_DV(L, k) * NS + col] = ddr[1];
+}
 template <int NT, bool PM, bool DM, bool BLK = false, bool EM = false, bool UQ = true, bool FV = true, bool UD = false>
 __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(KParams p, const double * __restrict__ xin, LinTerms xbase, double * xup, double dt, UvTerms uvt, int nseg, EmitTerms em,
 	UdiffArgs ud)
 {
 	constexpr int RL = TMX_UQ_ROWLEN(true);
 	constexpr int NW = BLK ? 4 : 1;
-	__shared__ double sw[NW][UD ? 10 : 9][RL];
+	__shared__ double sw[NW][9][RL];
 	__shared__ double xs[BLK ? 2 : 1][BLK ? 6 : 1][BLK ? 256 : 1];
 	__shared__ double sD[16], sS[16];
 	__shared__ double rmtab[TMX_RMTAB_DOUBLES];
@@ -141,6 +209,11 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 	double xW0 = 0.0;      // UD: the diffusion increment of W on the surface, formed at level 0, applied when level 1 knows W there
 	// ---- window of the first level
 	double uM, u0, uP, vM, v0, vP, w0, w1, t0, r0;
+	double uMM = 0.0, vMM = 0.0;      // FV with UD: level k - 2 (the DiffDiff stencil)
+	if (FV && UD) {
+		const int kmm = (k0 > 1) ? k0 - 2 : 0;
+		uMM = ldu(xuv + TMX_SLAB_U(L, kmm) * SX, cx); vMM = ldu(xuv + TMX_SLAB_V(L, kmm) * SX, cx);
+	}
 	{
 		const int km = (k0 > 0) ? k0 - 1 : 0, kp = (k0 < L - 1) ? k0 + 1 : L - 1;
 		uM = ldu(xuv + TMX_SLAB_U(L, km) * SX, cx); u0 = ldu(xuv + TMX_SLAB_U(L, k0) * SX, cx); uP = ldu(xuv + TMX_SLAB_U(L, kp) * SX, cx);
@@ -198,9 +271,11 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		asm volatile("" : "+v"(cb), "+v"(gd), "+v"(cx));
 		// ---- loads of the next level's window and of this level's combination terms: in flight during this level's arithmetic
 		double uN = uP, vN = vP, wN = 0.0, tN = 0.0, rN = 0.0;
-		if (k + 1 < k1) {
+		if (k + 1 < k1 || (FV && UD && k + 2 < L)) {      // (FV with UD: level k + 2 enters the DiffDiff stencil of a segment's last level too)
 			const int kpp = (k + 2 < L) ? k + 2 : L - 1;
 			uN = ldu(xuv + TMX_SLAB_U(L, kpp) * SX, cx); vN = ldu(xuv + TMX_SLAB_V(L, kpp) * SX, cx);
+		}
+		if (k + 1 < k1) {
 			wN = ldu(xin + TMX_SLAB_W(L, k + 2) * SX, cx);
 			tN = ldu(xin + TMX_SLAB_T(L, k + 1) * SX, cx); rN = ldu(xin + TMX_SLAB_R(L, k + 1) * SX, cx);
 		}
@@ -210,10 +285,11 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_T(L, k), SS, NSD, cb, gd, xT);
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_R(L, k), SS, NSD, cb, gd, xR);
 		terms_load<NT, PM, DM>(xbase.src, dmask, TMX_SLAB_W(L, (k > 0) ? k : 1), SS, NSD, cb, gd, xW);      // (interface 0 has no base: boundary condition)
-		double rfT = 0.0, rfU = 0.0, rfV = 0.0, rfW = 0.0;      // UD: the reference state of this level / interface
+		double rfT = 0.0, rfW = 0.0, hdU = 0.0, hdV = 0.0, ddU = 0.0, ddV = 0.0;      // UD: the reference's rho*theta, W of this level / interface, its stored U, V terms
 		if (UD) {
-			rfT = ldu(ud.xref + TMX_SLAB_T(L, k) * NS, cb); rfU = ldu(ud.xref + TMX_SLAB_U(L, k) * NS, cb);
-			rfV = ldu(ud.xref + TMX_SLAB_V(L, k) * NS, cb); rfW = ldu(ud.xref + TMX_SLAB_W(L, k) * NS, cb);
+			rfT = ldu(ud.xref + TMX_SLAB_T(L, k) * NS, cb); rfW = ldu(ud.xref + TMX_SLAB_W(L, k) * NS, cb);
+			hdU = ldu(ud.xrefd + TMX_REFD_HU(L, k) * NS, cb); hdV = ldu(ud.xrefd + TMX_REFD_HV(L, k) * NS, cb);
+			if (FV && ud.udv) { ddU = ldu(ud.xrefd + TMX_REFD_DU(L, k) * NS, cb); ddV = ldu(ud.xrefd + TMX_REFD_DV(L, k) * NS, cb); }
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		HW_MARK(1);
@@ -349,8 +425,8 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		HW_MARK(5);
 		double outU = bU + tU, outV = bV + tV;
 		const double uh = outU, vh = outV;      // H-only values (levels 0, 1: the bottom boundary condition below)
-		if (FV && k < L - 1) { outU += tUhi; outV += tVhi; }
-		if (FV && k > 0) { outU += tUlo; outV += tVlo; }
+		if (FV && !UD && k < L - 1) { outU += tUhi; outV += tVhi; }
+		if (FV && !UD && k > 0) { outU += tUlo; outV += tVlo; }
 		const double outR = bR - tR;
 		double outT = bT - tT, outW = bW + tW;
 		if constexpr (UD) {
@@ -360,10 +436,9 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 			const double psiT = t0 - rfT, psiW = w0 - rfW;
 			s[0][lp] = psiT; s[1][lp] = psiW;
 			s[2][lp] = u0; s[3][lp] = v0; s[4][lp] = j2d * (c2a0 * u0 + c2a1 * v0); s[5][lp] = j2d * (c2a1 * u0 + c2b1 * v0);
-			s[6][lp] = rfU; s[7][lp] = rfV; s[8][lp] = j2d * (c2a0 * rfU + c2a1 * rfV); s[9][lp] = j2d * (c2a1 * rfU + c2b1 * rfV);
 			wave_sync();
 			double daT = 0, dbT = 0, daW = 0, dbW = 0;
-			double dUb = 0, dbUa = 0, dajua = 0, dbjub = 0, dUbr = 0, dbUar = 0, dajuar = 0, dbjubr = 0;
+			double dUb = 0, dbUa = 0, dajua = 0, dbjub = 0;
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
@@ -373,26 +448,16 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 				dUb += s[3][la] * Da; dbUa += s[2][lb] * Db;
 				dajua += s[4][la] * Da; dbjub += s[5][lb] * Db;
 			}
-			asm volatile("" : "+v"(daT), "+v"(dbT), "+v"(daW), "+v"(dbW) : : "memory");
-#pragma unroll
-			for (int t = 0; t < 4; t++) {
-				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
-				const double Da = sD[t * 4 + i], Db = sD[t * 4 + j];
-				dUbr += s[7][la] * Da; dbUar += s[6][lb] * Db;
-				dajuar += s[8][la] * Da; dbjubr += s[9][lb] * Db;
-			}
 			daT *= ida; dbT *= idb; daW *= ida; dbW *= idb;
 			dUb *= ida; dbUa *= idb; dajua *= ida; dbjub *= idb;
-			dUbr *= ida; dbUar *= idb; dajuar *= ida; dbjubr *= idb;
 			const double invJ2 = 1.0 / j2d;
 			const double dv = (dajua + dbjub) * invJ2, cl = (dUb - dbUa) * invJ2;
-			const double dvr = (dajuar + dbjubr) * invJ2, clr = (dUbr - dbUar) * invJ2;
 			wave_sync();
 			s[0][lp] = jn * (c2a0 * daT + c2a1 * dbT); s[1][lp] = jn * (c2a1 * daT + c2b1 * dbT);
 			s[2][lp] = je * (c2a0 * daW + c2a1 * dbW); s[3][lp] = je * (c2a1 * daW + c2b1 * dbW);
-			s[4][lp] = dv; s[5][lp] = cl; s[6][lp] = dvr; s[7][lp] = clr;
+			s[4][lp] = dv; s[5][lp] = cl;
 			wave_sync();
-			double uaT = 0, ubT = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0, dadr = 0, dbdr = 0, dacr = 0, dbcr = 0;
+			double uaT = 0, ubT = 0, uaW = 0, ubW = 0, dad = 0, dbd = 0, dac = 0, dbc = 0;
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
@@ -407,22 +472,33 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 				const int la = eb + 4 * t + j, lb = eb + 4 * i + t;
 				const double Sa = sS[i * 4 + t], Sb = sS[j * 4 + t];
 				dac -= Sa * s[5][la]; dbc -= Sb * s[5][lb];
-				dadr -= Sa * s[6][la]; dbdr -= Sb * s[6][lb];
-				dacr -= Sa * s[7][la]; dbcr -= Sb * s[7][lb];
 			}
 			uaT *= ida; ubT *= idb; uaW *= ida; ubW *= idb;
-			dad *= ida; dbd *= idb; dac *= ida; dbc *= idb; dadr *= ida; dbdr *= idb; dacr *= ida; dbcr *= idb;
+			dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
 			const double xW = dt * (1.0 / je) * ud.kv * (uaW + ubW);
 			if (k == 0) xW0 = xW; else outW = outW - xW;
 			outT = outT - dt * (1.0 / jn) * ud.ks * (uaT + ubT);
 			const double nkv = -ud.kv;
 			const double upa = nkv * dad - nkv * j2d * (c2a1 * dac + c2b1 * dbc);
 			const double upb = nkv * dbd + nkv * j2d * (c2a0 * dac + c2a1 * dbc);
-			const double upar = ud.kv * dadr - ud.kv * j2d * (c2a1 * dacr + c2b1 * dbcr);
-			const double upbr = ud.kv * dbdr + ud.kv * j2d * (c2a0 * dacr + c2a1 * dbcr);
-			outU -= dt * upa; outU -= dt * upar;
-			outV -= dt * upb; outV -= dt * upbr;
+			outU -= dt * upa; outU -= dt * hdU;      // (hdU, hdV: the reference's increments upar, upbr, k_ref_diffusion_terms)
+			outV -= dt * upb; outV -= dt * hdV;
 			wave_sync();
+			if constexpr (FV) {
+				// V.StepExplicit on U, V after the horizontal diffusion, as the reference orders them: upwind penalty, then the vertical uniform diffusion
+				if (k < L - 1) { outU += tUhi; outV += tVhi; }
+				if (k > 0) { outU += tUlo; outV += tVlo; }
+				if (ud.udv) {
+					double ddu = 0.0, ddv = 0.0;
+					if (k >= 2) { const double c = OPK(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, -2); ddu += c * uMM; ddv += c * vMM; }
+					if (k >= 1) { const double c = OPK(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, -1); ddu += c * uM; ddv += c * vM; }
+					{ const double c = OPK(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, 0); ddu += c * u0; ddv += c * v0; }
+					if (k + 1 < L) { const double c = OPK(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, 1); ddu += c * uP; ddv += c * vP; }
+					if (k + 2 < L) { const double c = OPK(TMX_OP_DIFFDIFF_NODE_TO_NODE, k, 2); ddu += c * uN; ddv += c * vN; }
+					outU += dt * ud.cfv * (ddu - ddU);
+					outV += dt * ud.cfv * (ddv - ddV);
+				}
+			}
 		}
 		if constexpr (!UQ) {
 			// element-major: the thread's own column
@@ -487,6 +563,7 @@ __global__ __launch_bounds__(BLK ? 256 : 64, TMX_HW_WAVES_PER_EU) void k_h_walk(
 		wave_sync();
 		HW_MARK(6);
 		// ---- slide the window
+		if (FV && UD) { uMM = uM; vMM = vM; }
 		uM = u0; u0 = uP; uP = uN; vM = v0; v0 = vP; vP = vN;
 		w0 = w1; w1 = wN; t0 = tN; r0 = rN;
 		ucz_prev = uczx; xlo = xhi;
@@ -562,9 +639,26 @@ int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, in
 	return nseg;
 }
 
-// Does the walk apply the horizontal uniform diffusion itself?  (element-major layout, V.StepExplicit not fused in: the uniform-diffusion configurations)
+// Does the walk apply the horizontal uniform diffusion itself?  (element-major layout: the uniform-diffusion configurations; with V.StepExplicit's
+// U, V part behind it -- fuse_v -- from option h_walk_udiff = 2 on)
 bool tmxk_h_walk_fuses_udiff(const tmx_engine * e, const KParams & p, int fuse_v, int nterms) {
-	return e->udiff && !p.t_ucol && !fuse_v && e->opt_h_walk_udiff != 0 && tmxk_h_walk_ok(e, p, fuse_v, nterms, false);
+	return e->udiff && !p.t_ucol && (fuse_v ? e->opt_h_walk_udiff >= 2 : e->opt_h_walk_udiff != 0) && tmxk_h_walk_ok(e, p, fuse_v, nterms, false);
+}
+
+// the stored reference terms (UdiffArgs::xrefd), formed when the reference state has changed since they were
+static const double * ref_diffusion_terms(tmx_engine * e, const KParams & p) {
+	if (!e->d_refd) {
+		const size_t rb = (size_t)4 * p.L * p.NS * sizeof(double);
+		if (hipMalloc((void **)&e->d_refd, rb) != hipSuccess) { e->d_refd = nullptr; return nullptr; }
+		hipMemsetAsync(e->d_refd, 0, rb, e->stream);
+		e->hbm_bytes += rb; e->refd_valid = false;
+	}
+	if (!e->refd_valid) {
+		KParams q = p; q.quads = nullptr;      // every tile, whatever list the stage runs on
+		hipLaunchKernelGGL(k_ref_diffusion_terms, dim3(p.NS / 64, p.L), dim3(64), 0, e->stream, q, (const double *)e->d_ref, e->d_refd, e->cfg.uniform_diffusion_vector);
+		e->refd_valid = true;
+	}
+	return e->d_refd;
 }
 
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
@@ -585,9 +679,12 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 		EmitTerms em1; em1.xp = nullptr; em1.first = -1; for (int m = 0; m < 12; m++) em1.coef[m] = 0.0;
 		const dim3 grd(ntile, nseg), blk(64);
 		const bool udf = tmxk_h_walk_fuses_udiff(e, p, fuse_v, nterms);
-		const UdiffArgs ud0 = { nullptr, 0.0, 0.0 }, ud1 = { (const double *)e->d_ref, e->cfg.uniform_diffusion_scalar, e->cfg.uniform_diffusion_vector };
+		// (fuse_v with uniform diffusion: the vertical diffusion of U, V rides along where k_v_explicit_slide would apply it -- the fully explicit mode)
+		const UdiffArgs ud0 = { nullptr, 0.0, 0.0, nullptr, 0.0, 0 }, ud1 = { (const double *)e->d_ref, e->cfg.uniform_diffusion_scalar, e->cfg.uniform_diffusion_vector,
+			udf ? ref_diffusion_terms(e, p) : nullptr, e->cfg.uniform_diffusion_vector / (e->cfg.ztop * e->cfg.ztop), (e->fully_explicit && !e->opt_udv_separate) ? 1 : 0 };
 #define LAUNCH_D2(NT_, PM_) do { \
-			if (fuse_v) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud0); \
+			if (fuse_v && udf) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud1); \
+			else if (fuse_v) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud0); \
 			else if (udf) hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false, true>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud1); \
 			else hipLaunchKernelGGL((k_h_walk<NT_, PM_, false, false, false, false, false>), grd, blk, 0, e->stream, q, xin, xbase, xup, dt, uvt, nseg, em1, ud0); } while (0)
 #define LAUNCH_D(NT_) do { if (NT_ == 0 || premul) LAUNCH_D2(NT_, true); else LAUNCH_D2(NT_, false); } while (0)
@@ -612,7 +709,7 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	e->u.slots_by_blocks = blocks;
 	const dim3 blk(64, blocks ? 4 : 1), grd = wg_grid(true, q, blocks ? nblk : ntile, nseg);
 	EmitTerms em0; em0.xp = nullptr; em0.first = -1; for (int m = 0; m < 12; m++) em0.coef[m] = 0.0;
-	const UdiffArgs udn = { nullptr, 0.0, 0.0 };
+	const UdiffArgs udn = { nullptr, 0.0, 0.0, nullptr, 0.0, 0 };
 	// (the prefix of a later stage's combination: no own coefficient, three to eight terms, node-unique sources, wavefront-level kernel)
 	const bool emit_ok = emit && emit->xp && !premul && !dmask && !blocks && nterms >= 3 && nterms <= 8;
 	const EmitTerms em = emit_ok ? *emit : em0;

@@ -208,11 +208,15 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 	// U,V slabs that live in another instance's slot are understood by k_h_explicit and k_h_tracers only; the kernels of the other configurations
 	// read them through the instance pointer, and the stepper never shares U,V there
 	REQUIRE(!e->n_uvshared || (!e->udiff && !e->fully_explicit && !e->sw), TMX_ERR_UNSUPPORTED, "internal: shared U,V slabs in a configuration whose kernels do not take them");
-	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference
-	const bool udf = tmxk_h_walk_fuses_udiff(e, make_params(e), e->udiff ? 0 : 1, n);
+	// with uniform diffusion the horizontal diffusion of U,V precedes the vertical penalty, as in the reference: V.StepExplicit's U,V part is
+	// fused in only where the same kernel applies that diffusion first (the walk, option h_walk_udiff = 2)
+	const bool uvx = uvx_fused(e);
+	const bool vfu = e->udiff && !uvx && tmxk_h_walk_fuses_udiff(e, make_params(e), 1, n);
+	const int fv = e->udiff ? (vfu ? 1 : 0) : 1;
+	const bool udf = vfu || tmxk_h_walk_fuses_udiff(e, make_params(e), fv, n);
 	if (udf && (r = check_reference_state(e))) return r;
-	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, e->udiff ? 0 : 1, n, src, cf, premul, inst_uv(e, iinit), inst_uv(e, iupd), srcuv);
-	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, e->udiff ? 0 : 1, 0, nullptr, nullptr, 0, inst_uv(e, iinit), inst_uv(e, ibase), nullptr);
+	if (n > 0) tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), inst(e, iupd), dt, fv, n, src, cf, premul, inst_uv(e, iinit), inst_uv(e, iupd), srcuv);
+	else tmxk_h_explicit(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, fv, 0, nullptr, nullptr, 0, inst_uv(e, iinit), inst_uv(e, ibase), nullptr);
 	if (e->nt > 0) {
 		if (n > 0) {
 			// tracers: the combination of the tracer slabs is evaluated inside the tracer kernel, which updates in place
@@ -229,8 +233,7 @@ static int hv_stage_kernels(tmx_engine * e, int iinit, int ibase, int iupd, doub
 			tmxk_h_tracers(e, make_params(e), inst(e, iinit), inst(e, ibase), inst(e, iupd), dt, 0, nullptr, nullptr, 0, inst_uv(e, iinit));
 	}
 	if ((r = h_uniform_diffusion(e, iinit, iupd, dt, udf))) return r;
-	const bool uvx = uvx_fused(e);
-	if (e->udiff && !uvx) {
+	if (e->udiff && !uvx && !vfu) {
 		if (udv_fused(e) && (r = check_reference_state(e))) return r;
 		tmxk_v_explicit(e, make_params(e), inst(e, iinit), inst(e, iupd), dt, udv_fused(e));
 	}

@@ -349,7 +349,8 @@ def test_shallow_water_test2_strang():
 def test_stage_copies_left_out_and_fused_uv_update_are_bit_identical(monkeypatch, scheme):
     """Fully explicit vertical mode (BASELINE config 4's): the CopyData in front of the V.StepImplicit that does nothing is not
     performed -- the copy reads its source's slot (TMX_SHARE_COPIES=0: every copy made); TMX_VX_FUSED=1 runs V.StepExplicit's
-    U,V update inside the kernel of the explicitly treated terms instead of its own launch.  Same doubles, in instance 0
+    U,V update inside the kernel of the explicitly treated terms instead of its own launch; TMX_H_WALK_UDIFF chooses how much of the
+    uniform diffusion and of V.StepExplicit the explicit stage's walk applies itself.  Same doubles, in instance 0
     and in every other instance a caller can ask for between steps (the work instance of StepAfterSubCycle aside)."""
     from tempestmodel_amd.engine import Engine
     d = gu.load("steps_udiff_ars343_ne3_L6_p6.npz")
@@ -357,13 +358,18 @@ def test_stage_copies_left_out_and_fused_uv_update_are_bit_identical(monkeypatch
     st, tr = gu.expand_compact(d, "initial", g), gu.expand_compact_tracers(d, "initial", g)
     ninst = Engine.scheme_instances(scheme)
     runs = []
-    for variant in ({}, {"TMX_SHARE_COPIES": "0"}, {"TMX_VX_FUSED": "1"}, {"probe": True}):
+    # (h_walk_udiff: 2 = default, the explicit stage's walk applies the horizontal uniform diffusion and V.StepExplicit's U,V part to its
+    # results in registers; 1 = the diffusion alone, k_v_explicit_slide a pass of its own; 0 = k_uniform_diffusion a pass of its own too)
+    for variant in ({}, {"TMX_SHARE_COPIES": "0"}, {"TMX_VX_FUSED": "1"}, {"probe": True}, {"TMX_H_WALK_UDIFF": "1"}, {"TMX_H_WALK_UDIFF": "0"},
+                    {"TMX_H_WALK_UDIFF": "2", "TMX_UDV_SEPARATE": "1"}):
         monkeypatch.delenv("TMX_SHARE_COPIES", raising=False)
         monkeypatch.delenv("TMX_VX_FUSED", raising=False)
+        monkeypatch.delenv("TMX_H_WALK_UDIFF", raising=False)
+        monkeypatch.delenv("TMX_UDV_SEPARATE", raising=False)
         for k, v in variant.items():
             if k.startswith("TMX_"):
                 monkeypatch.setenv(k, v)
-        e = Engine(g, n_instances=ninst, fully_explicit=True, uniform_diffusion=UDIFF, flavour="experiments" if "TMX_VX_FUSED" in variant else None)
+        e = Engine(g, n_instances=ninst, fully_explicit=True, uniform_diffusion=UDIFF, flavour="experiments" if ("TMX_VX_FUSED" in variant or "TMX_UDV_SEPARATE" in variant) else None)
         try:
             e.upload_state(0, st); e.upload_tracers(0, tr)
             for step in (1, 2, 3):
