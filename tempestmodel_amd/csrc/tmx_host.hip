@@ -1480,7 +1480,7 @@ static const OptionDef g_options[] = {
 	{ "vt_rows", "TMX_VT_ROWS", 0, "1 (default): row-parallel implicit tracer update" },
 	{ "lu_fma", "TMX_LU_FMA", 0, "band LU of the column solves: 1 (default) updates a - l u as ONE rounding (fused multiply-add: a reference linked to OpenBLAS, or to MKL on its FMA code paths), 0 = multiply and subtract rounded separately (a BLAS without fused multiply-adds); tmx_lu_flavour_from_dgbsv asks the caller's own LAPACK" },
 	{ "h_walk_udiff", "TMX_H_WALK_UDIFF", 0, "uniform-diffusion configurations: the explicit stage's walk applies the horizontal uniform diffusion to its results in registers (1) and V.StepExplicit's U,V part behind it (2, default); 0 = k_uniform_diffusion and k_v_explicit as passes of their own (bit-identical)" },
-	{ "hv_walk", "TMX_HV_WALK", 0, "hyperviscosity pass on the node-unique layout: 1 (default) a wavefront walks a segment of levels (k_hv_walk), 0 = the level-parallel k_hypervis (bit-identical)" },
+	{ "hv_walk", "TMX_HV_WALK", 0, "hyperviscosity pass on the node-unique layout: 1 (default) a wavefront walks a segment of levels (k_hv_walk; -n: n segments per column), 0 = the level-parallel k_hypervis (bit-identical)" },
 	{ "h_walk", "TMX_H_WALK", 0, "explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register window, segments per column from the grid size; -n = n segments; 0 = the level-parallel kernel + k_h_w_update" },
 };
 static void tmx_record_option_defaults(tmx_engine * e) {
@@ -1525,9 +1525,10 @@ extern "C" int tmx_set_option(tmx_engine * e, const char * name, double value) {
 	if (n == "vi_back_sub") REQUIRE(iv == 1 || iv == 2 || iv == 4, TMX_ERR_INVALID, "vi_back_sub: 1, 2 or 4");
 	if (n == "vt_lanes") REQUIRE(iv == 8 || iv == 16 || iv == 32 || iv == 64, TMX_ERR_INVALID, "vt_lanes: 8, 16, 32 or 64");
 	if (n == "vt_row_lanes") REQUIRE(iv == 0 || iv == 4 || iv == 8 || iv == 16 || iv == 32, TMX_ERR_INVALID, "vt_row_lanes: 0 (auto), 4, 8, 16 or 32");
+	if (n == "hv_walk") REQUIRE(iv <= 1 && iv >= -64, TMX_ERR_INVALID, "hv_walk: 0, 1 or -n (n segments)");
 	if (n == "h_walk_udiff") REQUIRE(iv >= 0 && iv <= 2, TMX_ERR_INVALID, "h_walk_udiff: 0, 1 or 2");
 	if (n == "vt_lw8") REQUIRE(iv >= -1 && iv <= 1, TMX_ERR_INVALID, "vt_lw8: -1 (auto), 0 or 1");
-	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "hv_walk" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
+	if (n == "unique_xcd_order" || n == "unique_mixed" || n == "unique_prefix" || n == "lu_fma" || n == "share_copies" || n == "xcd_vertical" || n == "vt_rows" || n == "vi_sparse" || n == "vi_carry" || n == "step_graph" || n == "contraction_mfma")
 		REQUIRE(iv == 0 || iv == 1 || ((n == "vi_carry") && iv == -1), TMX_ERR_INVALID, "%s: 0 or 1", name);
 	*slot = iv;
 	return TMX_OK;

@@ -620,13 +620,14 @@ bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nte
 // the chip's slots: the count that minimises  rounds x (1.3 + levels per segment).  ne30: 3 segments (4 050 wavefronts in 4 096 slots, two
 // rounds) for the combinations, 2 for the plain stage; the 8-rank share of ne30 (169 tiles): 12; measured beside it: ne30 3 / 4 / 6 segments
 // 0.404 / 0.430 / 0.415 ms per step, the 8-rank share 6 / 10 / 15 segments 0.178 / 0.148 / 0.129 against 0.151 of the level-parallel kernel.
-int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms) {
+int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms, int waves_per_simd) {
 	int nseg = 1;
-	if (e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
+	if (waves_per_simd == 0 && e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
+	else if (waves_per_simd != 0 && e->opt_hv_walk < 0) nseg = -e->opt_hv_walk;
 	else {
 		static int cus = 0;      // (one device kind per process)
 		if (!cus) { int dev = 0, n = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
-		const double slots = (double)cus * 4 * (nterms <= 2 ? 3 : 2);
+		const double slots = (double)cus * 4 * (waves_per_simd ? waves_per_simd : (nterms <= 2 ? 3 : 2));
 		double best = 1e300;
 		for (int n = 1; n <= p.L / 2 || n == 1; n++) {
 			const double rounds = (double)ntiles * n / slots;
@@ -741,7 +742,7 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 // per segment instead of once per level (11 of the level-parallel kernel's 21 loads per thread and level), the next level's five fields and
 // five base values in flight during this level's two rounds of contractions.  No coupling between levels: any split into segments will do.
 template <bool HB>
-__global__ __launch_bounds__(64, 3) void k_hv_walk(KParams p, const double * __restrict__ xsrc, const double * __restrict__ xbase, double * __restrict__ xout,
+__global__ __launch_bounds__(64, 4) void k_hv_walk(KParams p, const double * __restrict__ xsrc, const double * __restrict__ xbase, double * __restrict__ xout,
 	double dt, double nu_s_in, double nu_d_in, double nu_v_in, int scale, int nseg)
 {
 	constexpr int RL = TMX_UQ_ROWLEN(true);
@@ -772,32 +773,29 @@ __global__ __launch_bounds__(64, 3) void k_hv_walk(KParams p, const double * __r
 	const int sdst = p.t_sdst[col], sred = p.t_sred[col];
 	const double invJ2 = 1.0 / j2d, invJ = 1.0 / jn, rje = 1.0 / je;
 	const int q = lane & 15, i = q >> 2, j = q & 3, eb = lds_pos<true>(lane & 48);
-	const bool hb = HB && xbase != nullptr;
-	// the first level's fields (a level >= L has W alone; a padding lane reads nothing)
-	auto ld = [&](const double * x, int slab) -> double { return here ? ldu(x + (size_t)slab * SS, cb) : 0.0; };
-	double psiW = ld(xsrc, TMX_SLAB_W(L, k0)), psiT = 0, psiR = 0, ua = 0, ub = 0, bW = 0, bT = 0, bR = 0, bU = 0, bV = 0;
-	if (k0 < L) { psiT = ld(xsrc, TMX_SLAB_T(L, k0)); psiR = ld(xsrc, TMX_SLAB_R(L, k0)); ua = ld(xsrc, TMX_SLAB_U(L, k0)); ub = ld(xsrc, TMX_SLAB_V(L, k0)); }
-	if (hb) {
-		bW = ld(xbase, TMX_SLAB_W(L, k0));
-		if (k0 < L) { bT = ld(xbase, TMX_SLAB_T(L, k0)); bR = ld(xbase, TMX_SLAB_R(L, k0)); bU = ld(xbase, TMX_SLAB_U(L, k0)); bV = ld(xbase, TMX_SLAB_V(L, k0)); }
-	}
-	wave_sync();
-	for (int kl = k0; kl < k1; kl++) {
-		const int kk = WAVE_UNIFORM(kl);
+	// a level's fields: W of interface k and, below the lid, rho*theta, rho, U, V of level k (a level >= L has W alone: the others re-read level L - 1,
+	// unused); padding lanes read node 0 and store nothing.  Every load unconditional, so that the loads in flight can be counted (s_waitcnt vmcnt(n)).
+	struct Lev { double W, T, R, U, V, bW, bT, bR, bU, bV; };
+	auto load_level = [&](Lev & v, int k) {
+		const int kw = min(k, L), kn = min(k, L - 1);
+		v.W = ldu(xsrc + (size_t)TMX_SLAB_W(L, kw) * SS, cb);
+		v.T = ldu(xsrc + (size_t)TMX_SLAB_T(L, kn) * SS, cb); v.R = ldu(xsrc + (size_t)TMX_SLAB_R(L, kn) * SS, cb);
+		v.U = ldu(xsrc + (size_t)TMX_SLAB_U(L, kn) * SS, cb); v.V = ldu(xsrc + (size_t)TMX_SLAB_V(L, kn) * SS, cb);
+		if (HB) {
+			v.bW = ldu(xbase + (size_t)TMX_SLAB_W(L, kw) * SS, cb);
+			v.bT = ldu(xbase + (size_t)TMX_SLAB_T(L, kn) * SS, cb); v.bR = ldu(xbase + (size_t)TMX_SLAB_R(L, kn) * SS, cb);
+			v.bU = ldu(xbase + (size_t)TMX_SLAB_U(L, kn) * SS, cb); v.bV = ldu(xbase + (size_t)TMX_SLAB_V(L, kn) * SS, cb);
+		} else { v.bW = v.bT = v.bR = v.bU = v.bV = 0.0; }
+	};
+	// Level k with its fields in `c`; `nx` holds the level after it and becomes `c`; the loads of level kload go into `ld` (= nx) at the top.  The fields of the next level are made to ARRIVE before this level's stores are issued: the stores sit in
+	// divergent branches (seam_store), the compiler cannot count them and waits for everything in flight wherever a load issued before them is
+	// first used behind them -- that is for the stores' own completion, once per level (measured: the wait at the loop's end).
+	auto level = [&](int kk, Lev & c, Lev & nx, Lev & ld, int kload) {
 		asm volatile("" : "+v"(cb));      // (lane offset redefined per level: base + lane stays scalar base + 32-bit offset, cf. k_h_walk)
 		const bool actn = kk < L;
-		// ---- the next level's loads, in flight during this level's contractions
-		double nW = 0, nT = 0, nR = 0, nU = 0, nV = 0, nbW = 0, nbT = 0, nbR = 0, nbU = 0, nbV = 0;
-		if (kk + 1 < k1) {
-			const bool an = kk + 1 < L;
-			nW = ld(xsrc, TMX_SLAB_W(L, kk + 1));
-			if (an) { nT = ld(xsrc, TMX_SLAB_T(L, kk + 1)); nR = ld(xsrc, TMX_SLAB_R(L, kk + 1)); nU = ld(xsrc, TMX_SLAB_U(L, kk + 1)); nV = ld(xsrc, TMX_SLAB_V(L, kk + 1)); }
-			if (hb) {
-				nbW = ld(xbase, TMX_SLAB_W(L, kk + 1));
-				if (an) { nbT = ld(xbase, TMX_SLAB_T(L, kk + 1)); nbR = ld(xbase, TMX_SLAB_R(L, kk + 1)); nbU = ld(xbase, TMX_SLAB_U(L, kk + 1)); nbV = ld(xbase, TMX_SLAB_V(L, kk + 1)); }
-			}
-		}
+		load_level(ld, kload);
 		__builtin_amdgcn_sched_barrier(0);
+		const double psiT = actn ? c.T : 0.0, psiR = actn ? c.R : 0.0, ua = actn ? c.U : 0.0, ub = actn ? c.V : 0.0, psiW = c.W;
 		const double cua = c2a0 * ua + c2a1 * ub;
 		const double cub = c2a1 * ua + c2b1 * ub;
 		s[0][lp] = psiT; s[1][lp] = psiR; s[2][lp] = psiW;
@@ -837,24 +835,36 @@ __global__ __launch_bounds__(64, 3) void k_hv_walk(KParams p, const double * __r
 		}
 		uaT *= ida; ubT *= idb; uaR *= ida; ubR *= idb; uaW *= ida; ubW *= idb;
 		dad *= ida; dbd *= idb; dac *= ida; dbc *= idb;
-		const double oW = bW - dt * rje * nu_s * (uaW + ubW);
+		const double oW = c.bW - dt * rje * nu_s * (uaW + ubW);
 		double oT = 0, oR = 0, oU = 0, oV = 0;
 		if (actn) {
-			oT = bT - dt * invJ * nu_s * (uaT + ubT);
-			oR = bR - dt * invJ * nu_s * (uaR + ubR);
+			oT = c.bT - dt * invJ * nu_s * (uaT + ubT);
+			oR = c.bR - dt * invJ * nu_s * (uaR + ubR);
 			const double upa = nu_d * dad - nu_v * j2d * (c2a1 * dac + c2b1 * dbc);
 			const double upb = nu_d * dbd + nu_v * j2d * (c2a0 * dac + c2a1 * dbc);
-			oU = bU - dt * upa;
-			oV = bV - dt * upb;
+			oU = c.bU - dt * upa;
+			oV = c.bV - dt * upb;
 		}
 		wave_sync();
+		// the next level's fields are here before this level's stores leave
+		c = nx;
+		asm volatile("" : "+v"(c.W), "+v"(c.T), "+v"(c.R), "+v"(c.U), "+v"(c.V));
+		if (HB) asm volatile("" : "+v"(c.bW), "+v"(c.bT), "+v"(c.bR), "+v"(c.bU), "+v"(c.bV));
 		{
 			const double v[5] = { oW, oT, oR, oU, oV };
 			const int slab[5] = { TMX_SLAB_W(L, kk), TMX_SLAB_T(L, kk), TMX_SLAB_R(L, kk), TMX_SLAB_U(L, kk), TMX_SLAB_V(L, kk) };
 			seam_store<5, RL>(p, &s[0], lane, here ? sdst : -1, sred, v, xout, slab, actn ? 5 : 1);
 		}
 		wave_sync();
-		psiW = nW; psiT = nT; psiR = nR; ua = nU; ub = nV; bW = nbW; bT = nbT; bR = nbR; bU = nbU; bV = nbV;
+	};
+	// (measured beside it, ne30: the level after next loaded too -- two staging sets -- 0.110 against 0.108 ms per step for the two passes, and 0.144 where
+	// the third set spills; profiles/r06_hv_walk_segments_ab.txt)
+	Lev C, N;
+	load_level(C, k0);
+	wave_sync();
+	for (int kl = k0; kl < k1; kl++) {
+		const int kk = WAVE_UNIFORM(kl);
+		level(kk, C, N, N, min(kk + 1, k1 - 1));
 	}
 }
 
@@ -864,7 +874,7 @@ void tmxk_hv_walk(tmx_engine * e, const KParams & p, const double * xsrc, const 
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
 	KParams q = p; q.u_ntiles = ntile;
 	KParams pl = p; pl.L = p.L + 1;      // (segments over the L + 1 levels)
-	const int nseg = tmxk_h_walk_segments(e, pl, ntile, 0);
+	const int nseg = tmxk_h_walk_segments(e, pl, ntile, 0, 4);      // (128 registers: four wavefronts per SIMD; ne30: 3 segments = 4 050 wavefronts in 4 096 slots)
 	e->u.slots_by_blocks = false;
 	const dim3 grd = wg_grid(true, q, ntile, nseg);
 	if (xbase) hipLaunchKernelGGL(k_hv_walk<true>, grd, dim3(64), 0, e->stream, q, xsrc, xbase, xout, dt, nu_s, nu_d, nu_v, scale, nseg);
