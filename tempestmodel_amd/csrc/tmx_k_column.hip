@@ -1899,10 +1899,14 @@ __global__ __launch_bounds__(128) void k_vi_terms_explicit_slide(KParams p, cons
 	const int L = p.L;
 	constexpr int MM = CLOSED ? 1 : 2;
 	double * etal = opsl_mem + TMX_OP_COUNT * (L + 1) * TMX_OPW;
+	// the exp / log tables of the Exner function in LDS too: read from global memory each lookup is a vector-memory load behind an
+	// s_waitcnt vmcnt(0), i.e. two waits per block row for every level prefetch in flight (the column solve's assembly: the same)
+	double * rmtab = etal + 2 * L + 1;
 	{
 		const int tid = threadIdx.y * 64 + threadIdx.x;
 		for (int t = tid; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += 128) opsl[t] = p.ops[t];
 		if (CLOSED) for (int t = tid; t < 2 * L + 1; t += 128) etal[t] = p.eta[t];
+		tmx_rm_tables_to_lds(rmtab, tid, 128);
 		__syncthreads();
 	}
 	const size_t NS = (size_t)p.NS;
@@ -2004,15 +2008,9 @@ __global__ __launch_bounds__(128) void k_vi_terms_explicit_slide(KParams p, cons
 		{
 			NodeLev nA; nA.un = rA.un; nA.vn = rA.vn; nA.pn = rA.pn; nA.rn = rA.rn; nA.ca2 = 0.0; nA.cb2 = 0.0; nA.cx2 = 0.0;      // (with the carry a block row reads no metric term of level k - 1)
 			EdgeLev eA; eA.we = rA.we; eA.ce0 = 0.0; eA.ce1 = 0.0; eA.ce2 = 0.0;
-			compute_block<true, UD>(p, opsl, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, udP, udW);
+			compute_block<true, UD>(p, opsl, cc, k, nA, nB, nC, eA, eB, eC, rP, rW, rR, fP, fW, fR, cy, udP, udW, rmtab);
 		}
-		if (k >= k0) {
-			if (k < L) {
-				xup[TMX_SLAB_T(L, k) * NS + col] = upT - dt * fP;
-				xup[TMX_SLAB_R(L, k) * NS + col] = upR - dt * fR;
-			}
-			xup[TMX_SLAB_W(L, k) * NS + col] = upW - dt * fW;
-		}
+		const double resT = upT - dt * fP, resR = upR - dt * fR, resW = upW - dt * fW;
 		pm2 = rA.pn; wm2 = rA.we;
 		rA.un = nB.un; rA.vn = nB.vn; rA.pn = nB.pn; rA.rn = nB.rn; rA.we = eB.we;
 		nB = nC; eB = eC;
@@ -2021,13 +2019,25 @@ __global__ __launch_bounds__(128) void k_vi_terms_explicit_slide(KParams p, cons
 		tr[0] = tr[1]; tr[1] = tr[2]; tr[2] = tr[3]; tr[3] = tr[4]; tr[4] = trn;
 		wr[0] = wr[1]; wr[1] = wr[2]; wr[2] = wr[3]; wr[3] = wr[4]; wr[4] = wrn;
 		upT = upTn; upR = upRn; upW = upWn;
+		// The block row's stores LAST, behind the window's move (which evaluates the metric terms of the level that enters, i.e. reads values
+		// loaded an iteration ago): the stores sit in a branch, the compiler cannot count them, and a loaded value first used behind them waits
+		// for everything in flight -- the stores' own completion and the prefetch of two levels ahead -- once per block row.  The values the
+		// next block row updates are made to land before the stores too (they were loaded with this block row's operands).
+		asm volatile("" : "+v"(upT), "+v"(upR), "+v"(upW));
+		if (k >= k0) {
+			if (k < L) {
+				xup[TMX_SLAB_T(L, k) * NS + col] = resT;
+				xup[TMX_SLAB_R(L, k) * NS + col] = resR;
+			}
+			xup[TMX_SLAB_W(L, k) * NS + col] = resW;
+		}
 	}
 }
 #undef OPCL
 
 void tmxk_vi_terms_explicit(tmx_engine * e, const KParams & p, const double * xin, double * xup, double dt, bool with_uv) {
 	const int nt_ = NTILES(e, p), xm = e->xcd_vertical;
-	const size_t lds_slide = ((size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW + 2 * p.L + 1) * sizeof(double);
+	const size_t lds_slide = ((size_t)TMX_OP_COUNT * (p.L + 1) * TMX_OPW + 2 * p.L + 1 + TMX_RMTAB_DOUBLES) * sizeof(double);
 	if (e->opt_vite_walk < 0 && !with_uv && lds_slide <= 64 * 1024) {      // a thread walks (a segment of) its column; -n = n segments, -1000 = chosen from the grid size
 		int nseg = -e->opt_vite_walk;
 		if (e->opt_vite_walk == -1000) for (nseg = 2; nt_ * nseg < 2048 && (p.L + 1) / (nseg + 2) >= 5; nseg += 2) { }

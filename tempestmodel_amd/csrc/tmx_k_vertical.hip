@@ -104,6 +104,7 @@ __global__ __launch_bounds__(128) void k_v_explicit_slide(KParams p, const doubl
 			metric_edge<MM>(p, mc, m, col, e0, e1, e2, etal);
 			xd_hi = e0 * ue + e1 * ve + e2 * wm;
 		}
+		double res[2] = { 0.0, 0.0 };
 		if (k >= k0) {      // level k: window entry 2
 			const double w_hi = dt * fabs(xd_hi), w_lo = dt * fabs(xd_lo);
 #pragma unroll
@@ -135,13 +136,17 @@ __global__ __launch_bounds__(128) void k_v_explicit_slide(KParams p, const doubl
 					}
 					out += dt * cf * (dd - ddr);
 				}
-				xup[(size_t)(v * L + k) * NS + col] = out;
+				res[v] = out;
 			}
 		}
 		xd_lo = xd_hi; wm = wn; upU = upUn; upV = upVn;
 #pragma unroll
 		for (int j = 0; j < 4; j++) { uw[j] = uw[j + 1]; vw[j] = vw[j + 1]; ur[j] = ur[j + 1]; vr[j] = vr[j + 1]; }
 		uw[4] = eU; vw[4] = eV; ur[4] = eUR; vr[4] = eVR;
+		// the stores last, the entering level landed before them (see k_v_tracers_explicit_slide)
+		asm volatile("" : "+v"(uw[4]), "+v"(vw[4]), "+v"(wm), "+v"(upU), "+v"(upV));
+		if (UDV) asm volatile("" : "+v"(ur[4]), "+v"(vr[4]));
+		if (k >= k0) { xup[(size_t)k * NS + col] = res[0]; xup[(size_t)(L + k) * NS + col] = res[1]; }
 	}
 }
 #undef OPCL
@@ -1183,6 +1188,7 @@ __global__ __launch_bounds__(128) void k_v_tracers_explicit_slide(KParams p, int
 				re_hi += OPCL(TMX_OP_INTERP_NODE_TO_REDGE, m, off) * rh[off + 2];
 			}
 		}
+		double res[NTR];
 #pragma unroll
 		for (int t = 0; t < NTR; t++) {
 			double qe = 0.0;
@@ -1223,8 +1229,8 @@ __global__ __launch_bounds__(128) void k_v_tracers_explicit_slide(KParams p, int
 				}
 				F -= aux;
 				if (F != 0.0) F /= idt;
-				xup[(size_t)TMX_SLAB_Q(L, c0 + t, k) * NS + col] = up[t] - F;
-			}
+				res[t] = up[t] - F;
+			} else res[t] = 0.0;
 			mf_lo[t] = mf_hi;
 			// the window moves up one level
 			q[t][0] = q[t][1]; q[t][1] = q[t][2]; q[t][2] = q[t][3]; q[t][3] = eQ[t];
@@ -1235,6 +1241,16 @@ __global__ __launch_bounds__(128) void k_v_tracers_explicit_slide(KParams p, int
 		uw[0] = uw[1]; uw[1] = uw[2]; uw[2] = uw[3]; uw[3] = eU;
 		vw[0] = vw[1]; vw[1] = vw[2]; vw[2] = vw[3]; vw[3] = eV;
 		rh[0] = rh[1]; rh[1] = rh[2]; rh[2] = rh[3]; rh[3] = eR;
+		// The level's stores LAST, behind everything that reads a value loaded in this iteration: the stores sit in a branch, the compiler
+		// cannot count them, and a loaded value first used behind them waits for everything in flight (s_waitcnt vmcnt(0)) -- i.e. for the
+		// stores' own completion, once per tracer and level (the entering level's values are made to land first: the empty asm statements).
+		asm volatile("" : "+v"(uw[3]), "+v"(vw[3]), "+v"(wm));
+#pragma unroll
+		for (int t = 0; t < NTR; t++) asm volatile("" : "+v"(q[t][3]), "+v"(mr[t][3]), "+v"(up[t]));
+		if (k >= k0) {
+#pragma unroll
+			for (int t = 0; t < NTR; t++) xup[(size_t)TMX_SLAB_Q(L, c0 + t, k) * NS + col] = res[t];
+		}
 	}
 }
 
