@@ -622,8 +622,8 @@ bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nte
 // 0.404 / 0.430 / 0.415 ms per step, the 8-rank share 6 / 10 / 15 segments 0.178 / 0.148 / 0.129 against 0.151 of the level-parallel kernel.
 int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms, int waves_per_simd) {
 	int nseg = 1;
-	if (waves_per_simd == 0 && e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
-	else if (waves_per_simd != 0 && e->opt_hv_walk < 0) nseg = -e->opt_hv_walk;
+	if (waves_per_simd != 4 && e->opt_h_walk < 0 && e->opt_h_walk > -1000) nseg = -e->opt_h_walk;
+	else if (waves_per_simd == 4 && e->opt_hv_walk < 0) nseg = -e->opt_hv_walk;      // (the hyperviscosity walk's call)
 	else {
 		static int cus = 0;      // (one device kind per process)
 		if (!cus) { int dev = 0, n = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
@@ -673,7 +673,9 @@ void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const do
 	for (int m = 0; m < nterms; m++) { xbase.src[m] = src[m]; xbase.coef[m] = coef[m]; uvt.src[m] = src_uv ? src_uv[m] : src[m]; }
 	for (int m = (nterms > 0 ? nterms : 1); m < 12; m++) { xbase.src[m] = xbase.src[0]; xbase.coef[m] = 0.0; uvt.src[m] = uvt.src[0]; }
 	const int ntile = p.quads ? e->launch_tiles : p.NS / 64;
-	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms);
+	// (the kernels that apply the uniform diffusion hold 190 - 256 registers whatever the number of terms: two wavefronts per SIMD)
+	// (three wavefronts per SIMD -- at most 168 registers -- for the plain stage and the two-term combination without a coefficient of its own)
+	const int nseg = tmxk_h_walk_segments(e, p, ntile, nterms, ((!p.t_ucol && tmxk_h_walk_fuses_udiff(e, p, fuse_v, nterms)) || (nterms == 2 && premul)) ? 2 : 0);
 	KParams q = p; q.u_ntiles = ntile;
 	if (!p.t_ucol) {
 		// element-major layout: 2-D launch (tile list or all tiles) x segments
