@@ -439,8 +439,9 @@ long long tmx_info(tmx_engine * e, int what);
  *   at rank boundaries (tools/rank_share_timing.py only).
  *   "h_walk"            explicit stage on the node-unique layout: -1000 (default) a wavefront walks a column segment with a sliding register
  *                        window (tmx_k_hwalk.hip), segments per column from the grid size; -n = n segments; 0 = the level-parallel kernels.
- *   "hv_walk", "h_walk_udiff"   1 (defaults): the hyperviscosity pass of the node-unique layout as a walk / the horizontal uniform diffusion
- *                        (HorizontalDynamicsFEM.cpp:1817-1859) applied by the element-major walk to its results in registers; 0 = the kernels of their own.
+ *   "hv_walk"           1 (default): the hyperviscosity pass of the node-unique layout as a walk (-n: n segments per column); 0 = the level-parallel kernel.
+ *   "h_walk_udiff"      uniform-diffusion configurations: the element-major walk applies the horizontal uniform diffusion (HorizontalDynamicsFEM.cpp:1817-1859)
+ *                        to its results in registers (1) and V.StepExplicit's U,V part (VerticalDynamicsFEM.cpp:984-1105) behind it (2, default); 0 = kernels of their own.
  *   "unique_prefix"     1 (default): an explicit stage also stores the leading partial sum of a later stage's combination (ARS343: the
  *                        fourth stage reads 3 instances instead of 7); 0: every stage reads all its terms.  Same bits.
  *   "lu_fma"            band LU of the column solves (LAPACK::DGBSV, src/base/LinearAlgebra.cpp:156-202): 1 (default) = updates a - l u fused

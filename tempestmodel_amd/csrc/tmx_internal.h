@@ -369,6 +369,7 @@ void tmxk_h_explicit(tmx_engine * e, const KParams & p, const double * xin, cons
 	unsigned dmask = 0u);      // dmask: LinTerms::dmask (node-unique kernels: which sources are element-major instances read per copy)
 // the same stage as a column-segment walk (tmx_k_hwalk.hip): node-unique layout, vertical part fused in
 bool tmxk_h_walk_ok(const tmx_engine * e, const KParams & p, int fuse_v, int nterms, bool emit);
+void tmxk_h_walk_prepare(tmx_engine * e, const KParams & p);
 int tmxk_h_walk_segments(const tmx_engine * e, const KParams & p, int ntiles, int nterms, int waves_per_simd = 0);
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,

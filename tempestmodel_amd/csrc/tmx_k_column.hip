@@ -1304,14 +1304,17 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 		cc.jn = p.g2d[G2_JN * NS + col]; cc.je = p.g2d[G2_JE * NS + col]; cc.drx = p.g2d[G2_DRX * NS + col];
 		cc.invdt = 1.0 / dt; cc.upc = 0.5 * (1.0 / (double)L); cc.cv = p.cp - p.Rd;
 		const MetCol mcol = met_col(p, col);
-		// Level window of block row t: nodes / interfaces t-1, t, t+1 in (A, B, C).  The loads of level t+4 are issued at the top
-		// of iteration t into one of two staging sets (Y0 / Y1, alternating: the loop body is instantiated twice) and are first
-		// touched -- by a register move into N1 -- at the end of iteration t+1, two block rows later: under load the memory latency
-		// of this kernel is longer than one block row (measured: with the loads of level t+2 moved into place at the top of the
-		// next iteration the producer stalled 1 000 - 2 700 cycles per block row on its prefetch), and vmcnt retires in order,
-		// so a wait for the newest load cannot be hidden behind older ones.  The staging sets hold the five loaded values of a
-		// level only; the closed-form metric of the level is evaluated when it enters the window (stored-metric engines, whose
-		// levels carry six more loaded values, keep the one-row scheme: DEEP = false).
+		// Level window of block row t: nodes / interfaces t-1, t, t+1 in (A, B, C).  Under load the memory latency of this kernel is
+		// longer than one block row (measured: with the loads of level t+2 moved into place at the top of the next iteration the
+		// producer stalled 1 000 - 2 700 cycles per block row on its prefetch), and vmcnt retires in order, so a wait for the newest
+		// load cannot be hidden behind older ones.  DEEP: block rows go in PAIRS; the raw values of the levels t+3 and t+4 are loaded
+		// at the top of the pair's first row (staging sets Y0, Y1) and first touched at the end of its second row, two block rows
+		// later -- so NOTHING in flight at any point where the compiler touches a loaded value is younger than two rows.  (Round 5
+		// loaded one level at the top of every row: the set loaded by a pair's second row was live across the loop's back-edge, the
+		// register allocator moved it there -- a move of registers whose loads are in flight is a wait for them -- and every second
+		// row waited for loads one row old; a conditional second row made that an s_waitcnt vmcnt(0).)  The staging sets hold the
+		// five loaded values of a level only; the closed-form metric of the level is evaluated when it enters the window
+		// (stored-metric engines, whose levels carry six more loaded values, keep the one-row scheme: DEEP = false).
 		constexpr bool DEEP = CLOSED;
 		struct LevRaw { double un, vn, pn, rn, we; };
 		auto load_raw = [&](int l) {
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 		};
 		NodeLev nA = load_node<MM>(p, mcol, xin, -1, col, etal), nB = load_node<MM>(p, mcol, xin, 0, col, etal), nC = load_node<MM>(p, mcol, xin, 1, col, etal);
 		EdgeLev eA = load_edge<MM>(p, mcol, xin, -1, col, etal), eB = load_edge<MM>(p, mcol, xin, 0, col, etal), eC = load_edge<MM>(p, mcol, xin, 1, col, etal);
-		LevRaw rN1 = load_raw(2), rY0 = load_raw(3), rY1 = rY0;
+		LevRaw rN1 = load_raw(2), rY0 = rN1, rY1 = rN1;
 		NodeLev nN = load_node<MM>(p, mcol, xin, 2, col, etal);      // DEEP = false: level t+2, loaded one block row ahead
 		EdgeLev eN = load_edge<MM>(p, mcol, xin, 2, col, etal);
 		BlkCarry cy = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1343,9 +1346,10 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 #else
 #define PMARK(acc)
 #endif
-		auto block_row = [&](int t, LevRaw & rYl, const LevRaw & rYm) {
-			if (DEEP) rYl = load_raw(t + 4);
-			else { /* issued below, after the shift */ }
+		// phase: 0 = first row of a pair (loads the levels that this pair's second row and the next pair's first row take in), 1 = second row,
+		// 2 = a lone last row
+		auto block_row = [&](int t, int phase) {
+			if (DEEP && phase == 0) { rY0 = load_raw(t + 3); rY1 = load_raw(t + 4); }
 #ifdef TMX_PAIR_TIMING
 			{
 			PMARK(tp_seg[4]);      // prefetch issue
@@ -1372,16 +1376,22 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 			q[(TMX_RSLOT_RHS + 0) * 64] = fP; q[(TMX_RSLOT_RHS + 1) * 64] = fW; q[(TMX_RSLOT_RHS + 2) * 64] = fR;
 			ring_post(rcount, t + 1, lane);
 			nA = nB; nB = nC; eA = eB; eB = eC;
-			if (DEEP) { enter(rN1, t + 2, nC, eC); rN1 = rYm; }
+			if (DEEP) {
+				// first row: level t+2 from N1 (here since the last pair); second row: level t+2 = the pair's first load, and N1 <- its second
+				if (phase != 1) enter(rN1, t + 2, nC, eC);
+				else { enter(rY0, t + 2, nC, eC); rN1 = rY1; }
+			}
 			else { nC = nN; eC = eN; nN = load_node<MM>(p, mcol, xin, t + 3, col, etal); eN = load_edge<MM>(p, mcol, xin, t + 3, col, etal); }
 #ifdef TMX_PAIR_TIMING
 			PMARK(tp_seg[5]);      // ring writes + window shift (DEEP: touches loads issued two block rows earlier)
 #endif
 		};
-		for (int t = 0; t <= L; t += 2) {
-			block_row(t, rY0, rY1);
-			if (t + 1 <= L) block_row(t + 1, rY1, rY0);
+		int t = 0;
+		for (; t + 1 <= L; t += 2) {
+			block_row(t, 0);
+			block_row(t + 1, 1);
 		}
+		if (t <= L) block_row(t, 2);
 #ifdef TMX_PAIR_TIMING
 		if (stats && lane == 0) {
 			unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);

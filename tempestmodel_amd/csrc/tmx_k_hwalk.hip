@@ -662,6 +662,11 @@ static const double * ref_diffusion_terms(tmx_engine * e, const KParams & p) {
 	return e->d_refd;
 }
 
+// Before a step is captured into a graph: what the walk would allocate or compute on first use (neither is allowed while the stream captures)
+void tmxk_h_walk_prepare(tmx_engine * e, const KParams & p) {
+	if (e->udiff && !e->refd_valid && e->d_ref && tmxk_h_walk_fuses_udiff(e, p, 0, 0)) (void)ref_diffusion_terms(e, p);
+}
+
 void tmxk_h_walk(tmx_engine * e, const KParams & p, const double * xin, const double * xbase_ptr, double * xup, double dt, int fuse_v,
 	int nterms, const double * const * src, const double * coef, int premul, const double * xin_uv, const double * xbase_uv, const double * const * src_uv, unsigned dmask,
 	const EmitTerms * emit) {

@@ -1670,7 +1670,7 @@ static int u_dss(tmx_engine * e, int ix) {
 	int r;
 	if ((r = u_own_uv(e, ix))) return r;
 	{ ProfScope ps(e, TMX_K_DSS); tmxuk_slots_from_u(e, uinst(e, ix)); }
-	e->u.slots_by_blocks = tmxu_blocks_on(e) && !getenv("TMX_DEBUG_DSS_FULL");      // every slot holds its node's value: the shorter list changes the same nodes (a group of identical copies averages to itself)
+	e->u.slots_by_blocks = tmxu_blocks_on(e);      // every slot holds its node's value: the shorter list changes the same nodes (a group of identical copies averages to itself)
 	if ((r = exchange(e, tmxu_params(e, make_params(e)), nullptr, &overlapped))) return r;
 	r = u_dss_finish(e, ix, overlapped);
 	u_written(e, ix);
@@ -1926,6 +1926,11 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 	// Multi-rank steps (RCCL calls on a second stream) and profiled steps always use the plain sequence.
 	if (e->use_graph && (e->cfg.n_ranks == 1 || (TMX_EXP && e->opt_skip_exchange)) && !e->prof && !e->lb) {
 		StepGraphKey key = { scheme, first_step ? 1 : 0, last_step ? 1 : 0, dt };
+		if (e->udiff) {      // (the reference state's stored diffusion terms: allocated and formed outside the capture)
+			bool all = true;
+			for (int lp : e->local_patches) all = all && e->patches[lp].ref_set;
+			if (all) tmxk_h_walk_prepare(e, make_params(e));
+		}
 		for (auto & g : e->graphs)
 			if (g.key.scheme == key.scheme && g.key.first == key.first && g.key.last == key.last && g.key.dt == key.dt) {
 				HIPCHK(hipGraphLaunch(g.exec, e->stream));
@@ -1935,7 +1940,7 @@ extern "C" int tmx_step(tmx_engine * e, int scheme, int first_step, int last_ste
 		HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
 		r = run_program(e, p);
 		const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
-		if (r) { if (graph) hipGraphDestroy(graph); return r; }
+		if (r) { if (graph) hipGraphDestroy(graph); (void)hipGetLastError(); return r; }      // (the error is reported; it must not stay behind as the runtime's last error)
 		if (ce != hipSuccess || !graph) {
 			(void)hipGetLastError();
 			e->use_graph = false;                 // capture not possible here: run the plain sequence from now on

@@ -482,20 +482,19 @@ void tmxuk_slots_from_u(tmx_engine * e, const double * xu) {
 }
 
 // k_dss (tmx_k_exchange.hip) with the copies read from the partial slots (or the ghost buffer) and the results written to the
-// unique slabs: one thread per group and slab level, every member's own combination in the reference's order (dss_combine), (U,V)
+// unique slabs: one thread per group, level and class of variables, every member's own combination in the reference's order (dss_combine), (U,V)
 // of copies on other panels rotated into the member's frame.  Copies of a node inside one patch receive identical bits, so only the
 // first of them stores (gdst == -1 for the others).
 // (round 6: two / four levels per thread, the group's tables read once and all copies in flight together, cost +6 % / +40 %: the kernel
-// lives on the number of threads in flight, not on the bytes its tables take)
-__global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, size_t NP, double * __restrict__ xu, const double * __restrict__ part,
+// lives on the number of threads in flight, not on the bytes its tables take.  The other direction pays a little: a wavefront = ONE class
+// of variables (vc: W | rho*theta | rho | U,V) of one level -- four times the threads, 56 registers instead of 78, eight wavefronts per
+// SIMD instead of six: 0.216 - 0.219 -> 0.205 - 0.212 ms per step for the six launches, profiles/r06_dss_and_column_null_results.txt)
+template <int vc>
+__device__ __forceinline__ void dss_u_body(int L, size_t NUS, size_t NP, double * __restrict__ xu, const double * __restrict__ part,
 	const double * __restrict__ ghost, const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gsrc,
-	const int * __restrict__ gdst, const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int g0)
+	const int * __restrict__ gdst, const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int g, int kk)
 {
-	int bx, by;
-	if (!xcd_tile((ngroups - g0 + 63) / 64, (L + 1 + 3) / 4, bx, by)) return;
-	const int g = g0 + bx * 64 + threadIdx.x;
-	const int kk = by * 4 + WAVE_UNIFORM(threadIdx.y);
-	if (g >= ngroups || kk > L) return;
+	if (vc > 0 && kk >= L) return;
 	const int n = gn[g];
 	const int4 c4 = *(const int4 *)(gsrc + g * 4), d4 = *(const int4 *)(gdst + g * 4);
 	const int c[4] = { c4.x, c4.y, c4.z, c4.w }, d[4] = { d4.x, d4.y, d4.z, d4.w };
@@ -512,11 +511,12 @@ __global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, siz
 	slabs[0] = TMX_SLAB_W(L, kk);
 	slabs[1] = lev ? TMX_SLAB_T(L, kk) : slabs[0]; slabs[2] = lev ? TMX_SLAB_R(L, kk) : slabs[0];
 	slabs[3] = lev ? TMX_SLAB_U(L, kk) : slabs[0]; slabs[4] = lev ? TMX_SLAB_V(L, kk) : slabs[0];
+	auto mine = [&](int t) { return vc == 3 ? t >= 3 : t == vc; };      // the slabs of this wavefront's class
 	double v[5][4];
 #pragma unroll
 	for (int t = 0; t < 5; t++)
 #pragma unroll
-		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
+		for (int m = 0; m < 4; m++) v[t][m] = (m < n && (t == 0 || lev) && mine(t)) ? ptr[m][(size_t)slabs[t] * str[m]] : 0.0;
 	const bool same = (gt == 0) && (n != 3);
 	const int t0 = gt & 3, t1 = (gt >> 2) & 3, t2 = (gt >> 4) & 3, t3 = (gt >> 6) & 3;
 #define DSS_SCALAR(W0, W1, W2, W3, O0, O1, O2, O3) do { \
@@ -525,8 +525,9 @@ __global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, siz
 		       O2 = dss_combine<2>(W0, W1, W2, W3, n, t2); O3 = dss_combine<3>(W0, W1, W2, W3, n, t3); } } while (0)
 	double out[5][4];
 #pragma unroll
-	for (int t = 0; t < 3; t++) DSS_SCALAR(v[t][0], v[t][1], v[t][2], v[t][3], out[t][0], out[t][1], out[t][2], out[t][3]);
-	if (xi < 0) {
+	for (int t = 0; t < 3; t++) if (mine(t)) DSS_SCALAR(v[t][0], v[t][1], v[t][2], v[t][3], out[t][0], out[t][1], out[t][2], out[t][3]);
+	if (!mine(3)) { }
+	else if (xi < 0) {
 		DSS_SCALAR(v[3][0], v[3][1], v[3][2], v[3][3], out[3][0], out[3][1], out[3][2], out[3][3]);
 		DSS_SCALAR(v[4][0], v[4][1], v[4][2], v[4][3], out[4][0], out[4][1], out[4][2], out[4][3]);
 	} else {
@@ -544,16 +545,30 @@ __global__ __launch_bounds__(256, 4) void k_dss_u(int L, int nt, size_t NUS, siz
 	for (int t = 0; t < 5; t++)
 #pragma unroll
 		for (int m = 0; m < 4; m++)
-			if (d[m] >= 0 && (t == 0 || lev)) xu[(size_t)slabs[t] * NUS + d[m]] = out[t][m];
+			if (d[m] >= 0 && (t == 0 || lev) && mine(t)) xu[(size_t)slabs[t] * NUS + d[m]] = out[t][m];
 #undef DSS_SCALAR
+}
+__global__ __launch_bounds__(256, 8) void k_dss_u(int L, int nt, size_t NUS, size_t NP, double * __restrict__ xu, const double * __restrict__ part,
+	const double * __restrict__ ghost, const int * __restrict__ gbase, const int * __restrict__ gstride, int ngroups, const int * __restrict__ gsrc,
+	const int * __restrict__ gdst, const int * __restrict__ gn, const int * __restrict__ gx, const int * __restrict__ gtype, const double * __restrict__ xmat, int g0)
+{
+	int bx, by;
 	(void)nt;
+	// a workgroup = the four classes of variables of one level of 64 groups
+	if (!xcd_tile((ngroups - g0 + 63) / 64, L + 1, bx, by)) return;
+	const int kk = by, vc = WAVE_UNIFORM(threadIdx.y);
+	const int g = g0 + bx * 64 + threadIdx.x;
+	if (g >= ngroups || kk > L) return;
+#define DSS_GO(VC_) dss_u_body<VC_>(L, NUS, NP, xu, part, ghost, gbase, gstride, ngroups, gsrc, gdst, gn, gx, gtype, xmat, g, kk)
+	if (vc == 0) DSS_GO(0); else if (vc == 1) DSS_GO(1); else if (vc == 2) DSS_GO(2); else DSS_GO(3);
+#undef DSS_GO
 }
 
 // blocks: the groups a block kernel left (UniqueLayout::b_*) instead of the groups a wavefront-level kernel leaves
 void tmxuk_dss(tmx_engine * e, double * xu, int g0, int g1, bool blocks) {
 	if (g1 <= g0) return;
 	const UniqueLayout & u = e->u;
-	const int nx = (g1 - g0 + 63) / 64, ny = (e->L + 1 + 3) / 4;
+	const int nx = (g1 - g0 + 63) / 64, ny = e->L + 1;
 	hipLaunchKernelGGL(k_dss_u, dim3(8 * ((nx + 7) / 8) * ny), dim3(64, 4), 0, e->stream, e->L, e->nt, (size_t)u.NUS, (size_t)u.NP, xu, (const double *)u.d_part,
 		(const double *)e->d_ghost, (const int *)e->d_ghost_base, (const int *)e->d_ghost_stride, g1, (const int *)(blocks ? u.d_b_gsrc : u.d_gsrc), (const int *)(blocks ? u.d_b_gdst : u.d_gdst),
 		(const int *)(blocks ? u.d_b_gn : u.d_gn), (const int *)(blocks ? u.d_b_gx : u.d_gx), (const int *)(blocks ? u.d_b_gtype : u.d_gtype), (const double *)e->d_xmat, g0);
