@@ -49,7 +49,7 @@ run 2 --halo auto --steps 10 --warmup 2 --develop 2 --sustained-steps 0 --no-cpu
 	field "(d['config']['parallelism'], d['multi_rank']['parity'])"
 
 echo "== 3. strong scaling of the headline problem (ne30 L30), RCCL: N = 1, 2, 4, $NMAX"
-echo "   expect (DESIGN.md section 6, projected from the per-rank compute share): ms_per_step ~ 1.6 / 1.1-1.2 / 0.76-0.88 / 0.59-0.71;"
+echo "   expect (DESIGN.md section 6, projected from the per-rank compute share + 10-30 us exposed per exchange): ms_per_step ~ 1.14-1.17 / 0.91-1.03 / 0.65-0.77 / 0.56-0.68;"
 echo "           parity true at every N; early/late tiles non-zero at every N > 1 (the boundary-first split is on)"
 for n in 1 2 4 $NMAX; do
 	if [ $n -eq 1 ]; then python bench.py --steps 20 --warmup 3 --sustained-steps 0 --no-cpu-baseline > gpurun_out/first_contact_3_n1.json 2>/dev/null;
