@@ -781,7 +781,7 @@ def main():
                                  "projected_from_rank_share": projected_from_rank_share(world, ne, L, ms_per_step),
                                  "scaling_note": "strong scaling of a ~1.2 ms step is Amdahl-limited: the per-rank compute share measured on one GPU (wire left out) "
                                                  "bounds the speed-up before any message is sent; weak scaling (--scaling weak: the grid grows with the rank count) is "
-                                                 "the regime the design is for (9.7-10.2 G element-DOF-updates/s per GPU from ne30 to ne84, profiles/r05_rate_over_sizes.txt)"}
+                                                 "the regime the design is for (11.2-12.8 G element-DOF-updates/s per GPU from ne30 to ne84, profiles/r06_other_shapes.txt)"}
         if ablation_build:      # a library named by TMX_LIBRARY: never a result, say so in the line itself
             out["ablation_build"] = True
             out["library"] = os.environ["TMX_LIBRARY"]
