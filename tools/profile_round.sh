@@ -30,6 +30,7 @@ one fetch_d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch_d -o ${TAG
 one write_d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write_d -o ${TAG} -- python3 $B
 unset TMX_UNIQUE
 one l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/${TAG}_l2 -o ${TAG} -- python3 $B
+one lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_lds -o ${TAG} -- python3 $B
 export TMX_MFMA=1
 one mfma1 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma1 -o ${TAG} -- python3 $B
 one trace_mfma1 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_mfma1 -o ${TAG} -- python3 $B
