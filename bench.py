@@ -720,9 +720,10 @@ def main():
                        "state_layout": ("node-unique inside tmx_step (%d instances in that form at the end of the timed region, %d partial slots, "
                                         "%d node groups left to the DSS kernel of %d)" % (unique_after_timed, eng.info(15), eng.info(16), eng.info(2)))
                                        if eng.info(12) == 1 else "element-major (16 nodes per element, seam nodes duplicated)"},
-            # `bound`: what limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64
-            # chains of its two co-scheduled wavefronts, see `limited_by`); the roofline its `frac` is priced against is HBM either way
-            "roofline": {"bound": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
+            # `bound`: the roofline `frac` is priced against (HBM: every kernel of the path is fp64 stencil / band work, no GEMM); `limiter`: what
+            # limits the dominant operation as measured ("hbm", or "latency" for the column solve: dependent fp64 chains of its two co-scheduled
+            # wavefronts beside the U-row stream, see `limited_by`)
+            "roofline": {"bound": "hbm", "limiter": "hbm" if OP_BOUND[dom].startswith("hbm") else "latency", "priced_against": "hbm",
                          "kernel": kernel_name, "operation": dom, "dominant_by": dom_note,
                          "dominant_operation": dom_op, "operation_share_of_kernel_time": {op: round(v, 4) for op, v in op_share.items()},
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
