@@ -893,7 +893,8 @@ extern "C" int tmx_finalize(tmx_engine * e) {
 	const size_t abb = (size_t)n * (TMX_BW + 1) * e->vi_stream_cols * sizeof(double) + zpage, rb = (size_t)n * e->NUS * sizeof(double);
 	HIPCHK(hipMalloc((void **)&e->d_ab, abb)); HIPCHK(hipMemset((char *)e->d_ab + abb - zpage, 0, zpage)); bytes += abb;
 	HIPCHK(hipMalloc((void **)&e->d_rhs, rb)); bytes += rb;
-	HIPCHK(hipMalloc((void **)&e->d_flag, sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, sizeof(int)));
+	// (behind the flag word: the order slots of the column solve's workgroups, one int per CU -- 16 XCC ids x 256 CU / SH / SE ids; k_vi_pair)
+	HIPCHK(hipMalloc((void **)&e->d_flag, (64 + 4096) * sizeof(int))); HIPCHK(hipMemset(e->d_flag, 0, (64 + 4096) * sizeof(int)));
 	// Node-unique state layout (tmx_unique.hip): for the configurations all of whose step kernels have the U form -- the
 	// nonhydrostatic set with implicit vertical dynamics, no tracers, no uniform diffusion, closed-form metric; a Rayleigh layer (its
 	// strength is stored per copy of a node) since round 5: the relaxation at the end of StepAfterSubCycle reads node-unique and writes

@@ -1225,16 +1225,36 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	// (Measured and not kept, round 4: the roles in the other order -- consumer first -- for the workgroups of the second dispatch round, or
 	// for every other workgroup, so that two workgroups sharing a CU would put a producer and a consumer on every SIMD: column solve
 	// 0.500 / 0.486 against 0.480 ms per step.)
-	const int role = (NPROD == 2) ? (wv == 2 ? 1 : 0) : ((PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1)), pair = (NPROD == 2) ? 0 : ((PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1));
+	// Round 6: WHICH of a CU's two workgroups takes the other order is no longer guessed from blockIdx (it helped only in the runs where the dispatcher
+	// really put workgroups i and i + 256 on one CU: profiles/r06_column_roles_ab.txt) -- a workgroup claims one of two order slots of the CU it finds
+	// itself on (hardware id registers; the slots live behind the engine's flag word) and releases it at its end.
+#ifndef TMX_VI_CU_ORDER
+#define TMX_VI_CU_ORDER 1
+#endif
+	constexpr bool CUORD = TMX_VI_CU_ORDER && PAIRS == 2 && NPROD == 1;
+	__shared__ int s_order;
+	const int role0 = (NPROD == 2) ? (wv == 2 ? 1 : 0) : ((PAIRS == 3) ? ((0x31 >> wv) & 1) : (wv & 1)), pair = (NPROD == 2) ? 0 : ((PAIRS == 3) ? ((0x990 >> (2 * wv)) & 3) : (wv >> 1));
+	int * cu_slot = nullptr;
+	if (CUORD) {
+		const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_ID (CU, SH, SE in bits 8..15), XCC_ID
+		cu_slot = flag + 64 + (((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
+		if (wv == 0 && lane == 0) {
+			int order = 0;
+			if (atomicOr(cu_slot, 1) & 1) { order = 1; atomicOr(cu_slot, 2); }      // the first order is taken on this CU: the other one
+			s_order = order;
+		}
+	}
 	double * ring = etal + 2 * L + 1 + (size_t)pair * RD * NQ * 64;          // [PAIRS][RD][NQ][64]
 	double * rmtab = etal + 2 * L + 1 + (size_t)PAIRS * RD * NQ * 64;       // [512] exp / log tables (exner_from_rhotheta_lds)
 	int * umask = (int *)(rmtab + TMX_RMTAB_DOUBLES) + pair * TMX_FTOT * (L + 1);   // [PAIRS][3(L+1)]
 	int * rcount = (int *)(rmtab + TMX_RMTAB_DOUBLES) + PAIRS * TMX_FTOT * (L + 1) + 4 * pair;   // [PAIRS]{produced, consumed, produced by the second producer, -}
-	if (role == 1 && lane == 0) { rcount[0] = 0; rcount[1] = 0; rcount[2] = 0; }
+	if (role0 == 1 && lane == 0) { rcount[0] = 0; rcount[1] = 0; rcount[2] = 0; }
 	for (int t = wv * 64 + lane; t < TMX_OP_COUNT * (L + 1) * TMX_OPW; t += NTHR) opsl[t] = p.ops[t];
 	if (CLOSED) for (int t = wv * 64 + lane; t < 2 * L + 1; t += NTHR) etal[t] = p.eta[t];
 	tmx_rm_tables_to_lds(rmtab, wv * 64 + lane, NTHR);
 	__syncthreads();
+	const int order = CUORD ? WAVE_UNIFORM(s_order) : 0;
+	const int role = role0 ^ order;      // (order 1: elimination first, assembly second -- with the CU's other workgroup an assembly and an elimination wavefront on every SIMD)
 	const size_t NS = (size_t)p.NS;
 	// cpw columns per wavefront (64, or fewer so that the column groups fill every SIMD of the chip evenly: tmxk_vi_fused).
 	// Lanes beyond the group's columns do not return -- the block-row loops below are full of workgroup barriers -- they
@@ -1484,6 +1504,7 @@ __global__ __launch_bounds__(PAIRS * 64 * (1 + NPROD)) __attribute__((amdgpu_wav
 	if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)nuni); atomicAdd(&stats[1], (unsigned long long)n); }
 	if (BACK) vi_back_substitute<NTSK>(L, NS, n, u, col, NUS, AB, RHS, xin, xup, udep, umask, lane);
 	else for (int j = lane; j < n; j += 64) gmask[(size_t)grp * n + j] = umask[j];      // this wavefront's own LDS writes: no barrier needed
+	if (CUORD && pair == 0 && lane == 0) atomicAnd(cu_slot, ~(1 << order));      // the order slot is free again (the workgroup's other wavefronts are about to end too)
 #ifdef TMX_PAIR_TIMING
 	if (stats && lane == 0) {
 		unsigned long long * q = stats + 2 + 8 * ((size_t)(blockIdx.x * PAIRS + pair) * 2 + role);
